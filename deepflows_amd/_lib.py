@@ -1,0 +1,124 @@
+"""ctypes loader for libdfhip.so (the C ABI declared in include/dfhip.h).
+
+The library is built in-tree (deepflows_amd/csrc/Makefile -> deepflows_amd/libdfhip.so).
+There is NO fallback: if the shared object is missing or no HIP device is visible, asking
+for the `hip` device raises — the product path never computes on the CPU.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfhip.so")
+
+_lib = None
+
+# status -> exception class, the classes pybind11 raised for the reference's CUDA module
+# (std::invalid_argument -> ValueError, out_of_range -> IndexError, runtime_error ->
+# RuntimeError, bad_alloc -> MemoryError; SURVEY §8b "Errors")
+_EXC = {1: ValueError, 2: IndexError, 3: RuntimeError, 4: MemoryError}
+
+P = c_void_p
+I64P = POINTER(c_int64)
+PP = POINTER(c_void_p)
+
+_SIGS = {
+    "dfhip_init": [c_int],
+    "dfhip_device_count": [POINTER(c_int)],
+    "dfhip_sync": [],
+    "dfhip_device_name": [c_char_p, c_int],
+    "dfhip_malloc": [c_int64, POINTER(c_void_p)],
+    "dfhip_free": [P],
+    "dfhip_pool_stats": [I64P, I64P, I64P],
+    "dfhip_pool_trim": [],
+    "dfhip_h2d": [P, P, c_int64],
+    "dfhip_d2h": [P, P, c_int64],
+    "dfhip_d2d": [P, P, c_int64],
+    "dfhip_fill": [P, c_int64, c_float],
+    "dfhip_compact": [P, P, c_int64, c_int, I64P, I64P, c_int64],
+    "dfhip_ewise_setitem": [P, P, c_int64, c_int, I64P, I64P, c_int64],
+    "dfhip_scalar_setitem": [c_int64, c_float, P, c_int, I64P, I64P, c_int64],
+    "dfhip_matmul": [P, P, P, c_int64, c_int64, c_int64],
+    "dfhip_reduce_sum": [P, P, c_int64, c_int64],
+    "dfhip_reduce_max": [P, P, c_int64, c_int64],
+    "dfhip_gemm": [P, P, P, P, c_int64, c_int64, c_int64, c_int, c_int],
+    "dfhip_conv2d_forward": [P, P, P, P] + [c_int] * 8,
+    "dfhip_conv2d_wgrad": [P, P, P] + [c_int] * 8,
+    "dfhip_conv2d_dgrad": [P, P, P] + [c_int] * 9,
+    "dfhip_bn2d_forward_train": [P] * 8 + [c_int, c_int, c_int, c_float, c_float],
+    "dfhip_bn2d_forward_eval": [P] * 6 + [c_int, c_int, c_int, c_float],
+    "dfhip_bn2d_backward": [P] * 8 + [c_int, c_int, c_int, c_float],
+    "dfhip_maxpool2d_forward": [P, P, c_int, c_int, c_int, c_int],
+    "dfhip_maxpool2d_backward": [P, P, P, P, c_int, c_int, c_int, c_int],
+    "dfhip_relu_forward": [P, P, c_int64],
+    "dfhip_relu_backward": [P, P, P, P, c_int64],
+    "dfhip_softmax_ce_forward": [P, P, P, c_int, c_int],
+    "dfhip_softmax_ce_backward": [P, P, P, P, c_int, c_int],
+    "dfhip_reduce_to_shape": [P, P, c_int, I64P, c_int, I64P],
+    "dfhip_reduce_axis": [P, P, c_int64, c_int64, c_int64, c_int, c_float],
+    "dfhip_broadcast_axis": [P, P, c_int64, c_int64, c_int64, c_float],
+    "dfhip_axpy": [P, P, c_float, c_int64],
+    "dfhip_adam_step": [c_int, PP, PP, PP, PP, I64P, c_double, c_double, c_double, c_double,
+                        c_double, c_int, c_double],
+    "dfhip_sgd_step": [c_int, PP, PP, PP, I64P, c_double, c_double, c_double, c_int, c_double],
+    "dfhip_pack": [c_int, PP, I64P, P],
+    "dfhip_unpack": [c_int, PP, I64P, P],
+    "dfhip_comm_unique_id": [c_char_p],
+    "dfhip_comm_init": [c_int, c_int, c_char_p],
+    "dfhip_allreduce_sum": [P, c_int64],
+    "dfhip_comm_destroy": [],
+    "dfhip_graph_begin": [],
+    "dfhip_graph_end": [POINTER(c_void_p)],
+    "dfhip_graph_launch": [P],
+    "dfhip_graph_destroy": [P],
+    "dfhip_event_create": [POINTER(c_void_p)],
+    "dfhip_event_record": [P],
+    "dfhip_event_elapsed_ms": [P, P, POINTER(c_float)],
+    "dfhip_event_destroy": [P],
+    "dfhip_prof_enable": [c_int],
+    "dfhip_prof_reset": [],
+}
+for _n in ("add", "mul", "div", "maximum", "eq", "ge"):
+    _SIGS["dfhip_ewise_" + _n] = [P, P, P, c_int64]
+for _n in ("add", "mul", "div", "power", "maximum", "eq", "ge"):
+    _SIGS["dfhip_scalar_" + _n] = [P, c_float, P, c_int64]
+for _n in ("log", "exp", "tanh"):
+    _SIGS["dfhip_ewise_" + _n] = [P, P, c_int64]
+
+# every symbol include/dfhip.h declares (tests check the .so exports all of them)
+ALL_SYMBOLS = sorted(list(_SIGS) + ["dfhip_last_error", "dfhip_stream", "dfhip_prof_read"])
+
+
+def library_present():
+    return os.path.exists(LIB_PATH)
+
+
+def load():
+    """dlopen libdfhip.so and attach argument types. Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C deepflows_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()')")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_int
+    lib.dfhip_last_error.argtypes = []
+    lib.dfhip_last_error.restype = c_char_p
+    lib.dfhip_stream.argtypes = []
+    lib.dfhip_stream.restype = c_void_p
+    lib.dfhip_prof_read.argtypes = [c_int, POINTER(c_char_p), POINTER(c_double), I64P,
+                                    POINTER(c_double), POINTER(c_double)]
+    lib.dfhip_prof_read.restype = c_int
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = _lib.dfhip_last_error().decode("utf-8", "replace")
+        raise _EXC.get(status, RuntimeError)(msg)

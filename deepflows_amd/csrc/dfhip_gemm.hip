@@ -1,0 +1,242 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32): the `matmul` primitive
+// (reference: ndarray_backend_cuda.cu:443-466, a 4x4-thread naive kernel with a global-memory
+// K loop) and the transposed-operand forms matmul.grad_fn needs (tensor.py:699-716), which in
+// the reference cost a compact() copy of the transposed operand before every call.
+//
+// Structure (per 256-thread workgroup = 4 waves in a 2x2 grid):
+//   * block tile (2*TM*32) x (2*TN*32), K step 32, two LDS buffers;
+//   * global -> registers -> LDS staging with the lanes running along whichever operand
+//     dimension is contiguous in memory (so both the plain and the transposed forms read
+//     coalesced); the next K step is fetched into registers while the current one is in the
+//     matrix cores, one barrier per step;
+//   * LDS tiles are K-major ([k][row], row contiguous), so a fragment read is 32 consecutive
+//     floats per half-wave: conflict-free ds_read_b32, one read per operand per MFMA;
+//   * the f32 MFMA is exact fp32 (a k-ordered fmaf chain), 64 cycles per instruction per SIMD:
+//     one wave per SIMD with its TM*TN accumulator tiles already saturates the pipe;
+//   * small outputs with a long reduction are split along K into slabs that a second kernel
+//     sums in a fixed order (deterministic, no float atomics).
+#include <algorithm>
+
+#include "dfhip_internal.h"
+
+using namespace dfhip;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+
+template <int TM, int TN, bool A_KCONTIG, bool B_KCONTIG>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A,
+                                              const float* __restrict__ B,
+                                              const float* __restrict__ bias,
+                                              float* __restrict__ C, int M, int K, int P,
+                                              int64_t a_sm, int64_t a_sk, int64_t b_sk,
+                                              int64_t b_sp, int k_per_split, int64_t slab_stride) {
+  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+  constexpr int LDA = BM + 1, LDB = BN + 1;
+  constexpr int EA = BM * BK / 256, EB = BN * BK / 256;  // elements per thread per step
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                   // [2][BK][LDA]
+  float* Bs = smem + 2 * BK * LDA;    // [2][BK][LDB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, p0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * k_per_split;
+  const int kend = min(K, kbeg + k_per_split);
+  C += (int64_t)blockIdx.z * slab_stride;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+  float ra[EA], rb[EB];
+
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < EA; e++) {
+      int r, k;
+      if (A_KCONTIG) { k = tid & 31; r = (tid >> 5) + 8 * e; }
+      else { r = tid % BM; k = tid / BM + (256 / BM) * e; }
+      int gm = m0 + r, gk = k0 + k;
+      ra[e] = (gm < M && gk < kend) ? A[(int64_t)gm * a_sm + (int64_t)gk * a_sk] : 0.0f;
+    }
+#pragma unroll
+    for (int e = 0; e < EB; e++) {
+      int r, k;
+      if (B_KCONTIG) { k = tid & 31; r = (tid >> 5) + 8 * e; }
+      else { r = tid % BN; k = tid / BN + (256 / BN) * e; }
+      int gp = p0 + r, gk = k0 + k;
+      rb[e] = (gp < P && gk < kend) ? B[(int64_t)gk * b_sk + (int64_t)gp * b_sp] : 0.0f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* as = As + buf * BK * LDA;
+    float* bs = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int e = 0; e < EA; e++) {
+      int r, k;
+      if (A_KCONTIG) { k = tid & 31; r = (tid >> 5) + 8 * e; }
+      else { r = tid % BM; k = tid / BM + (256 / BM) * e; }
+      as[k * LDA + r] = ra[e];
+    }
+#pragma unroll
+    for (int e = 0; e < EB; e++) {
+      int r, k;
+      if (B_KCONTIG) { k = tid & 31; r = (tid >> 5) + 8 * e; }
+      else { r = tid % BN; k = tid / BN + (256 / BN) * e; }
+      bs[k * LDB + r] = rb[e];
+    }
+  };
+
+  const int nsteps = (kend - kbeg + BK - 1) / BK;
+  if (nsteps > 0) {
+    load_tile(kbeg);
+    store_tile(0);
+  }
+  __syncthreads();
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int s = 0; s < nsteps; s++) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) load_tile(kbeg + (s + 1) * BK);
+    const float* as = As + buf * BK * LDA + half * LDA + wm * (TM * 32) + l31;
+    const float* bs = Bs + buf * BK * LDB + half * LDB + wn * (TN * 32) + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) a[i] = as[kk * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; j++) b[j] = bs[kk * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < nsteps) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      int col = p0 + (wn * TN + j) * 32 + l31;
+      float bv = (bias != nullptr && col < P) ? bias[col] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < M && col < P) C[(int64_t)row * P + col] = acc[i][j][r] + bv;
+      }
+    }
+}
+
+// out[i] = sum_s slabs[s][i] (+ bias[i % P]) in slab order
+__global__ __launch_bounds__(256) void k_slab_sum(const float* __restrict__ slabs,
+                                                  const float* __restrict__ bias,
+                                                  float* __restrict__ out, int64_t n, int splits,
+                                                  int P) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    float v = slabs[i];
+    for (int s = 1; s < splits; s++) v += slabs[(int64_t)s * n + i];
+    if (bias) v += bias[i % P];
+    out[i] = v;
+  }
+}
+
+template <int TM, int TN>
+int launch_cfg(const float* a, const float* b, const float* bias, float* out, int M, int K, int P,
+               int ta, int tb, int splits) {
+  constexpr int BM = 2 * TM * 32, BN = 2 * TN * 32;
+  size_t lds = (size_t)2 * BK * ((BM + 1) + (BN + 1)) * sizeof(float);
+  int64_t a_sm = ta ? 1 : K, a_sk = ta ? M : 1;
+  int64_t b_sk = tb ? 1 : P, b_sp = tb ? K : 1;
+  int k_per_split = (int)df_ceil_div(df_ceil_div(K, splits), BK) * BK;
+  if (k_per_split < BK) k_per_split = BK;
+  splits = (int)std::max<int64_t>(1, df_ceil_div(K, k_per_split));
+  float* dst = out;
+  int64_t slab = 0;
+  if (splits > 1) {
+    slab = (int64_t)M * P;
+    dst = workspace((size_t)slab * splits * sizeof(float));
+    if (!dst) return DFHIP_OUT_OF_MEMORY;
+  }
+  dim3 grid((unsigned)df_ceil_div(P, BN), (unsigned)df_ceil_div(M, BM), (unsigned)splits);
+  const float* kbias = splits > 1 ? nullptr : bias;
+#define DF_GEMM_LAUNCH(AK, BKC)                                                                   \
+  do {                                                                                            \
+    static bool attr_set = false;                                                                 \
+    if (!attr_set) {                                                                              \
+      DF_HIP(hipFuncSetAttribute((const void*)k_gemm<TM, TN, AK, BKC>,                            \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+      attr_set = true;                                                                            \
+    }                                                                                             \
+    hipLaunchKernelGGL((k_gemm<TM, TN, AK, BKC>), grid, dim3(256), lds, stream(), a, b, kbias,    \
+                       dst, M, K, P, a_sm, a_sk, b_sk, b_sp, k_per_split, slab);                  \
+  } while (0)
+  bool ak = !ta, bk = tb != 0;
+  if (ak && bk) DF_GEMM_LAUNCH(true, true);
+  else if (ak && !bk) DF_GEMM_LAUNCH(true, false);
+  else if (!ak && bk) DF_GEMM_LAUNCH(false, true);
+  else DF_GEMM_LAUNCH(false, false);
+#undef DF_GEMM_LAUNCH
+  DF_LAUNCH_CHECK();
+  if (splits > 1) {
+    int64_t n = slab;
+    int blocks = (int)std::min<int64_t>(df_ceil_div(n, 256), (int64_t)num_cus() * 8);
+    hipLaunchKernelGGL(k_slab_sum, dim3(blocks), dim3(256), 0, stream(), dst, bias, out, n, splits, P);
+    DF_LAUNCH_CHECK();
+  }
+  return DFHIP_OK;
+}
+
+int gemm_dispatch(const float* a, const float* b, const float* bias, float* out, int64_t m,
+                  int64_t k, int64_t p, int ta, int tb) {
+  DF_INIT();
+  DF_CHECK_ARG(m >= 0 && k >= 0 && p >= 0, "matmul: negative dimension");
+  DF_CHECK_ARG(m < ((int64_t)1 << 31) && k < ((int64_t)1 << 31) && p < ((int64_t)1 << 31),
+               "matmul: dimension too large");
+  if (m == 0 || p == 0) return DFHIP_OK;
+  DF_CHECK_ARG(out && (k == 0 || (a && b)), "matmul: null array");
+  ProfScope prof("gemm_mfma_f32", 2.0 * (double)m * (double)k * (double)p,
+                 4.0 * ((double)m * k + (double)k * p + (double)m * p));
+  int M = (int)m, K = (int)k, P = (int)p;
+  int cus = num_cus();
+  int64_t t128 = df_ceil_div(M, 128) * df_ceil_div(P, 128);
+  int64_t t64 = df_ceil_div(M, 64) * df_ceil_div(P, 64);
+  if (t128 >= 2 * (int64_t)cus && P > 64) return launch_cfg<2, 2>(a, b, bias, out, M, K, P, ta, tb, 1);
+  if (P <= 64 && df_ceil_div(M, 128) >= 2 * (int64_t)cus)
+    return launch_cfg<2, 1>(a, b, bias, out, M, K, P, ta, tb, 1);
+  int splits = 1;
+  if (t64 < (int64_t)cus * 2 && K >= 256) {
+    int64_t want = df_ceil_div((int64_t)cus * 4, t64);
+    int64_t maxs = K / 128;
+    splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, maxs));
+  }
+  return launch_cfg<1, 1>(a, b, bias, out, M, K, P, ta, tb, splits);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dfhip_matmul(const float* a, const float* b, float* out, int64_t m, int64_t n, int64_t p) {
+  return gemm_dispatch(a, b, nullptr, out, m, n, p, 0, 0);
+}
+
+int dfhip_gemm(const float* a, const float* b, const float* bias, float* out, int64_t m, int64_t n,
+               int64_t p, int ta, int tb) {
+  return gemm_dispatch(a, b, bias, out, m, n, p, ta, tb);
+}
+
+}  // extern "C"

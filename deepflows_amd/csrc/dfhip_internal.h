@@ -1,0 +1,68 @@
+// Internal helpers shared by the libdfhip translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/dfhip.h"
+
+namespace dfhip {
+
+// thread-local error text behind dfhip_last_error()
+void set_error(const char* fmt, ...);
+hipStream_t stream();          // the single library stream
+bool initialised();
+int ensure_init();             // lazy dfhip_init(LOCAL_RANK or 0)
+int num_cus();
+
+// RAII HIP-event bracket around one kernel family launch (active only if profiling on)
+struct ProfScope {
+  int slot;
+  hipEvent_t e0, e1;
+  bool on;
+  ProfScope(const char* family, double flops, double bytes);
+  ~ProfScope();
+};
+
+// scratch workspace (grown on demand, never shrunk); stream-ordered reuse
+float* workspace(size_t bytes);
+// second, independent scratch area (for kernels that need two live scratch buffers)
+float* workspace2(size_t bytes);
+
+}  // namespace dfhip
+
+#define DF_CHECK_ARG(cond, ...)                      \
+  do {                                               \
+    if (!(cond)) {                                   \
+      dfhip::set_error(__VA_ARGS__);                 \
+      return DFHIP_INVALID_ARGUMENT;                 \
+    }                                                \
+  } while (0)
+
+#define DF_HIP(call)                                                                     \
+  do {                                                                                   \
+    hipError_t e__ = (call);                                                             \
+    if (e__ != hipSuccess) {                                                             \
+      dfhip::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                       __LINE__);                                                        \
+      return e__ == hipErrorOutOfMemory ? DFHIP_OUT_OF_MEMORY : DFHIP_RUNTIME_ERROR;     \
+    }                                                                                    \
+  } while (0)
+
+#define DF_LAUNCH_CHECK()                                                              \
+  do {                                                                                 \
+    hipError_t e__ = hipGetLastError();                                                \
+    if (e__ != hipSuccess) {                                                           \
+      dfhip::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__),     \
+                       __FILE__, __LINE__);                                            \
+      return DFHIP_RUNTIME_ERROR;                                                      \
+    }                                                                                  \
+  } while (0)
+
+#define DF_INIT()                              \
+  do {                                         \
+    int s__ = dfhip::ensure_init();            \
+    if (s__ != DFHIP_OK) return s__;           \
+  } while (0)
+
+static inline int64_t df_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,589 @@
+// libdfhip runtime: device/stream ownership, the caching pool behind Array(size),
+// host<->device copies, hipGraph capture, HIP-event profiling and the RCCL communicator.
+//
+// Replaces the runtime half of the reference's CUDA module
+// (DeepFlows/backend/backend_src/ndarray_backend_cuda.cu:48-83 CudaArray = raw
+// cudaMalloc/cudaFree per Array, :667-716 blocking cudaMemcpy, default stream everywhere).
+// MI355X design: ONE process per GPU, ONE explicit non-blocking stream, a size-bucketed
+// stream-ordered pool (a training step allocates ~3.6k arrays, SURVEY F8 — none of them may
+// reach hipMalloc in steady state), capture of the whole step into a hipGraph.
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "dfhip_internal.h"
+
+namespace dfhip {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static std::mutex g_mu;
+static bool g_init = false;
+static int g_device = 0;
+static hipStream_t g_stream = nullptr;
+static int g_num_cus = 256;
+static char g_devname[256] = "";
+
+hipStream_t stream() { return g_stream; }
+bool initialised() { return g_init; }
+int num_cus() { return g_num_cus; }
+
+static int do_init(int device_id) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_init) {
+    if (device_id >= 0 && device_id != g_device) {
+      set_error("dfhip already initialised on device %d (asked for %d)", g_device, device_id);
+      return DFHIP_INVALID_ARGUMENT;
+    }
+    return DFHIP_OK;
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    set_error("no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    return DFHIP_RUNTIME_ERROR;
+  }
+  if (device_id < 0) {
+    const char* lr = getenv("LOCAL_RANK");
+    device_id = lr ? atoi(lr) % count : 0;
+  }
+  if (device_id >= count) {
+    set_error("device %d out of range (%d visible)", device_id, count);
+    return DFHIP_INVALID_ARGUMENT;
+  }
+  DF_HIP(hipSetDevice(device_id));
+  DF_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  hipDeviceProp_t prop;
+  DF_HIP(hipGetDeviceProperties(&prop, device_id));
+  g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  snprintf(g_devname, sizeof(g_devname), "%s (%s)", prop.name, prop.gcnArchName);
+  g_device = device_id;
+  g_init = true;
+  return DFHIP_OK;
+}
+
+int ensure_init() { return g_init ? DFHIP_OK : do_init(-1); }
+
+// ---------------------------------------------------------------------------------------
+// Caching pool.  Exact-size free lists (rounded to 256 B); a training loop requests the
+// same sizes every step, so after one warm-up step nothing reaches hipMalloc.  Frees are
+// stream-ordered: a buffer handed back is only ever reused by later work on the same
+// stream, so no event is needed.  Buffers served while a capture is open become owned by
+// that capture (they are recycled only inside it and are never handed to eager code
+// afterwards, because the instantiated graph keeps writing to them on every replay).
+// ---------------------------------------------------------------------------------------
+struct Block {
+  size_t bytes;
+  int owner;  // 0 = general pool, >0 = capture id
+};
+static std::unordered_map<void*, Block> g_blocks;                         // every live/free block
+static std::unordered_map<size_t, std::vector<void*>> g_free;             // general pool
+static std::unordered_map<int, std::unordered_map<size_t, std::vector<void*>>> g_cap_free;
+static int g_capture_open = 0;  // id of the capture being recorded (0 = none)
+static int g_capture_seq = 0;
+static int64_t g_reserved = 0, g_in_use = 0, g_n_hipmalloc = 0;
+
+static size_t round_bytes(int64_t n_floats) {
+  size_t b = (size_t)(n_floats > 0 ? n_floats : 1) * sizeof(float);
+  return (b + 255) & ~(size_t)255;
+}
+
+static int pool_alloc(size_t bytes, void** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  void* p = nullptr;
+  if (g_capture_open) {
+    auto& fl = g_cap_free[g_capture_open][bytes];
+    if (!fl.empty()) {
+      p = fl.back();
+      fl.pop_back();
+    }
+  }
+  if (!p) {
+    auto it = g_free.find(bytes);
+    if (it != g_free.end() && !it->second.empty()) {
+      p = it->second.back();
+      it->second.pop_back();
+    }
+  }
+  if (!p) {
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      // give cached blocks back to the driver once, then retry
+      for (auto& kv : g_free) {
+        for (void* q : kv.second) {
+          g_reserved -= (int64_t)g_blocks[q].bytes;
+          g_blocks.erase(q);
+          (void)hipFree(q);
+        }
+        kv.second.clear();
+      }
+      e = hipMalloc(&p, bytes);
+      if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return DFHIP_OUT_OF_MEMORY;
+      }
+    }
+    g_n_hipmalloc++;
+    g_reserved += (int64_t)bytes;
+    g_blocks[p] = Block{bytes, 0};
+  }
+  g_blocks[p].owner = g_capture_open;
+  g_in_use += (int64_t)bytes;
+  *out = p;
+  return DFHIP_OK;
+}
+
+static int pool_free(void* p) {
+  if (!p) return DFHIP_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_blocks.find(p);
+  if (it == g_blocks.end()) {
+    set_error("dfhip_free: pointer %p was not allocated by dfhip_malloc", p);
+    return DFHIP_INVALID_ARGUMENT;
+  }
+  g_in_use -= (int64_t)it->second.bytes;
+  if (it->second.owner)
+    g_cap_free[it->second.owner][it->second.bytes].push_back(p);
+  else
+    g_free[it->second.bytes].push_back(p);
+  return DFHIP_OK;
+}
+
+struct ScratchSlot {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+static ScratchSlot g_ws[2];
+static float* scratch(int i, size_t bytes) {
+  // A scratch area is simply a pool block that is returned to the pool as soon as a
+  // bigger one is needed; stream order makes the hand-over safe.
+  bytes = (bytes + 255) & ~(size_t)255;
+  ScratchSlot& s = g_ws[i];
+  bool wrong_owner = false;
+  if (s.p) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    wrong_owner = g_blocks[s.p].owner != g_capture_open;
+  }
+  if (s.p && s.bytes >= bytes && !wrong_owner) return (float*)s.p;
+  if (s.p) pool_free(s.p);
+  s.p = nullptr;
+  s.bytes = 0;
+  void* p = nullptr;
+  if (pool_alloc(bytes, &p) != DFHIP_OK) return nullptr;
+  s.p = p;
+  s.bytes = bytes;
+  return (float*)p;
+}
+float* workspace(size_t bytes) { return scratch(0, bytes); }
+float* workspace2(size_t bytes) { return scratch(1, bytes); }
+
+// ---------------------------------------------------------------------------------------
+// profiling: HIP events around kernel families on the library stream
+// ---------------------------------------------------------------------------------------
+struct ProfSlot {
+  const char* name;
+  double ms = 0, flops = 0, bytes = 0;
+  int64_t calls = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+static bool g_prof_on = false;
+static std::vector<ProfSlot> g_prof;
+static std::vector<hipEvent_t> g_event_pool;
+
+static hipEvent_t get_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+static void prof_resolve(ProfSlot& s) {
+  for (auto& pr : s.pending) {
+    float ms = 0;
+    if (hipEventSynchronize(pr.second) == hipSuccess &&
+        hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess)
+      s.ms += ms;
+    g_event_pool.push_back(pr.first);
+    g_event_pool.push_back(pr.second);
+  }
+  s.pending.clear();
+}
+ProfScope::ProfScope(const char* family, double flops, double bytes) : slot(-1), e0(nullptr), e1(nullptr), on(false) {
+  if (!g_prof_on || g_capture_open) return;
+  for (size_t i = 0; i < g_prof.size(); i++)
+    if (g_prof[i].name == family || strcmp(g_prof[i].name, family) == 0) slot = (int)i;
+  if (slot < 0) {
+    ProfSlot s;
+    s.name = family;
+    g_prof.push_back(s);
+    slot = (int)g_prof.size() - 1;
+  }
+  g_prof[slot].calls++;
+  g_prof[slot].flops += flops;
+  g_prof[slot].bytes += bytes;
+  e0 = get_event();
+  e1 = get_event();
+  if (!e0 || !e1) return;
+  on = true;
+  (void)hipEventRecord(e0, g_stream);
+}
+ProfScope::~ProfScope() {
+  if (!on) return;
+  (void)hipEventRecord(e1, g_stream);
+  ProfSlot& s = g_prof[slot];
+  s.pending.emplace_back(e0, e1);
+  if (s.pending.size() > 2048) prof_resolve(s);
+}
+
+}  // namespace dfhip
+
+using namespace dfhip;
+
+extern "C" {
+
+int dfhip_init(int device_id) { return do_init(device_id); }
+
+int dfhip_device_count(int* out) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  *out = (e == hipSuccess) ? c : 0;
+  return DFHIP_OK;
+}
+
+const char* dfhip_last_error(void) { return g_err; }
+
+int dfhip_sync(void) {
+  DF_INIT();
+  DF_HIP(hipStreamSynchronize(g_stream));
+  return DFHIP_OK;
+}
+
+void* dfhip_stream(void) { return (void*)g_stream; }
+
+int dfhip_device_name(char* out, int cap) {
+  DF_INIT();
+  snprintf(out, cap, "%s", g_devname);
+  return DFHIP_OK;
+}
+
+int dfhip_malloc(int64_t n_floats, float** out) {
+  DF_INIT();
+  DF_CHECK_ARG(n_floats >= 0, "Array size must be >= 0 (got %lld)", (long long)n_floats);
+  void* p = nullptr;
+  int s = pool_alloc(round_bytes(n_floats), &p);
+  *out = (float*)p;
+  return s;
+}
+
+int dfhip_free(float* p) { return pool_free((void*)p); }
+
+int dfhip_pool_stats(int64_t* bytes_reserved, int64_t* bytes_in_use, int64_t* n_hipmalloc) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (bytes_reserved) *bytes_reserved = g_reserved;
+  if (bytes_in_use) *bytes_in_use = g_in_use;
+  if (n_hipmalloc) *n_hipmalloc = g_n_hipmalloc;
+  return DFHIP_OK;
+}
+
+int dfhip_pool_trim(void) {
+  DF_INIT();
+  DF_HIP(hipStreamSynchronize(g_stream));
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& kv : g_free) {
+    for (void* q : kv.second) {
+      g_reserved -= (int64_t)g_blocks[q].bytes;
+      g_blocks.erase(q);
+      (void)hipFree(q);
+    }
+    kv.second.clear();
+  }
+  return DFHIP_OK;
+}
+
+// Host buffers handed over by NumPy are pageable: stage through pinned memory so the copy
+// is a real async DMA on the library stream, then wait (the protocol's from_numpy /
+// to_numpy are blocking calls, ndarray_backend_cuda.cu:667-716).
+static void* g_pinned = nullptr;
+static size_t g_pinned_bytes = 0;
+static int pinned(size_t bytes, void** out) {
+  if (g_pinned_bytes < bytes) {
+    if (g_pinned) (void)hipHostFree(g_pinned);
+    g_pinned = nullptr;
+    g_pinned_bytes = 0;
+    size_t want = bytes < (size_t)(8 << 20) ? (size_t)(8 << 20) : bytes;
+    DF_HIP(hipHostMalloc(&g_pinned, want, hipHostMallocDefault));
+    g_pinned_bytes = want;
+  }
+  *out = g_pinned;
+  return DFHIP_OK;
+}
+
+int dfhip_h2d(const float* host, float* dst, int64_t n) {
+  DF_INIT();
+  DF_CHECK_ARG(n >= 0 && (n == 0 || (host && dst)), "h2d: null pointer");
+  if (n == 0) return DFHIP_OK;
+  size_t bytes = (size_t)n * sizeof(float);
+  const size_t chunk = (size_t)64 << 20;
+  for (size_t off = 0; off < bytes; off += chunk) {
+    size_t b = bytes - off < chunk ? bytes - off : chunk;
+    void* stage = nullptr;
+    int s = pinned(b, &stage);
+    if (s != DFHIP_OK) return s;
+    memcpy(stage, (const char*)host + off, b);
+    DF_HIP(hipMemcpyAsync((char*)dst + off, stage, b, hipMemcpyHostToDevice, g_stream));
+    DF_HIP(hipStreamSynchronize(g_stream));  // the pinned stage is reused by the next chunk
+  }
+  return DFHIP_OK;
+}
+
+int dfhip_d2h(const float* src, float* host, int64_t n) {
+  DF_INIT();
+  DF_CHECK_ARG(n >= 0 && (n == 0 || (host && src)), "d2h: null pointer");
+  if (n == 0) return DFHIP_OK;
+  size_t bytes = (size_t)n * sizeof(float);
+  const size_t chunk = (size_t)64 << 20;
+  for (size_t off = 0; off < bytes; off += chunk) {
+    size_t b = bytes - off < chunk ? bytes - off : chunk;
+    void* stage = nullptr;
+    int s = pinned(b, &stage);
+    if (s != DFHIP_OK) return s;
+    DF_HIP(hipMemcpyAsync(stage, (const char*)src + off, b, hipMemcpyDeviceToHost, g_stream));
+    DF_HIP(hipStreamSynchronize(g_stream));
+    memcpy((char*)host + off, stage, b);
+  }
+  return DFHIP_OK;
+}
+
+int dfhip_d2d(const float* src, float* dst, int64_t n) {
+  DF_INIT();
+  if (n == 0) return DFHIP_OK;
+  DF_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, g_stream));
+  return DFHIP_OK;
+}
+
+// ---- hipGraph capture ------------------------------------------------------------------
+struct GraphExec {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  int capture_id;
+};
+
+int dfhip_graph_begin(void) {
+  DF_INIT();
+  DF_CHECK_ARG(!g_capture_open, "a capture is already open");
+  DF_HIP(hipStreamSynchronize(g_stream));
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_capture_open = ++g_capture_seq;
+  }
+  hipError_t e = hipStreamBeginCapture(g_stream, hipStreamCaptureModeRelaxed);
+  if (e != hipSuccess) {
+    g_capture_open = 0;
+    set_error("hipStreamBeginCapture failed: %s", hipGetErrorString(e));
+    return DFHIP_RUNTIME_ERROR;
+  }
+  return DFHIP_OK;
+}
+
+int dfhip_graph_end(void** graph_exec) {
+  DF_CHECK_ARG(g_capture_open, "no capture open");
+  int id = g_capture_open;
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(g_stream, &graph);
+  g_capture_open = 0;
+  if (e != hipSuccess || !graph) {
+    set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    return DFHIP_RUNTIME_ERROR;
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return DFHIP_RUNTIME_ERROR;
+  }
+  GraphExec* g = new GraphExec{graph, exec, id};
+  *graph_exec = g;
+  return DFHIP_OK;
+}
+
+int dfhip_graph_launch(void* graph_exec) {
+  DF_CHECK_ARG(graph_exec, "null graph");
+  GraphExec* g = (GraphExec*)graph_exec;
+  DF_HIP(hipGraphLaunch(g->exec, g_stream));
+  return DFHIP_OK;
+}
+
+int dfhip_graph_destroy(void* graph_exec) {
+  if (!graph_exec) return DFHIP_OK;
+  GraphExec* g = (GraphExec*)graph_exec;
+  (void)hipStreamSynchronize(g_stream);
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  {
+    // the capture's private blocks go back to the general pool
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_blocks)
+      if (kv.second.owner == g->capture_id) kv.second.owner = 0;
+    auto it = g_cap_free.find(g->capture_id);
+    if (it != g_cap_free.end()) {
+      for (auto& kv : it->second)
+        for (void* p : kv.second) g_free[kv.first].push_back(p);
+      g_cap_free.erase(it);
+    }
+  }
+  delete g;
+  return DFHIP_OK;
+}
+
+// ---- events / profiling ----------------------------------------------------------------
+int dfhip_event_create(void** ev) {
+  DF_INIT();
+  hipEvent_t e;
+  DF_HIP(hipEventCreate(&e));
+  *ev = (void*)e;
+  return DFHIP_OK;
+}
+int dfhip_event_record(void* ev) {
+  DF_HIP(hipEventRecord((hipEvent_t)ev, g_stream));
+  return DFHIP_OK;
+}
+int dfhip_event_elapsed_ms(void* start, void* stop, float* ms) {
+  DF_HIP(hipEventSynchronize((hipEvent_t)stop));
+  DF_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return DFHIP_OK;
+}
+int dfhip_event_destroy(void* ev) {
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+  return DFHIP_OK;
+}
+
+int dfhip_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return DFHIP_OK;
+}
+int dfhip_prof_reset(void) {
+  for (auto& s : g_prof) {
+    prof_resolve(s);
+    s.ms = s.flops = s.bytes = 0;
+    s.calls = 0;
+  }
+  return DFHIP_OK;
+}
+int dfhip_prof_read(int cap, const char** names, double* total_ms, int64_t* calls,
+                    double* flops, double* bytes) {
+  int n = 0;
+  for (auto& s : g_prof) {
+    prof_resolve(s);
+    if (n >= cap) break;
+    if (s.calls == 0) continue;
+    names[n] = s.name;
+    total_ms[n] = s.ms;
+    calls[n] = s.calls;
+    flops[n] = s.flops;
+    bytes[n] = s.bytes;
+    n++;
+  }
+  return n;
+}
+
+// ---- RCCL (loaded lazily: a single-GPU process never pays for librccl) -----------------
+typedef struct { char internal[128]; } df_nccl_uid;
+typedef void* df_nccl_comm;
+static void* g_rccl = nullptr;
+static int (*p_ncclGetUniqueId)(df_nccl_uid*) = nullptr;
+static int (*p_ncclCommInitRank)(df_nccl_comm*, int, df_nccl_uid, int) = nullptr;
+static int (*p_ncclAllReduce)(const void*, void*, size_t, int, int, df_nccl_comm, hipStream_t) = nullptr;
+static int (*p_ncclCommDestroy)(df_nccl_comm) = nullptr;
+static const char* (*p_ncclGetErrorString)(int) = nullptr;
+static df_nccl_comm g_comm = nullptr;
+static int g_world = 1;
+
+static int load_rccl() {
+  if (g_rccl) return DFHIP_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
+                         "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    g_rccl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl) break;
+  }
+  if (!g_rccl) {
+    set_error("cannot load librccl: %s", dlerror());
+    return DFHIP_RUNTIME_ERROR;
+  }
+  p_ncclGetUniqueId = (decltype(p_ncclGetUniqueId))dlsym(g_rccl, "ncclGetUniqueId");
+  p_ncclCommInitRank = (decltype(p_ncclCommInitRank))dlsym(g_rccl, "ncclCommInitRank");
+  p_ncclAllReduce = (decltype(p_ncclAllReduce))dlsym(g_rccl, "ncclAllReduce");
+  p_ncclCommDestroy = (decltype(p_ncclCommDestroy))dlsym(g_rccl, "ncclCommDestroy");
+  p_ncclGetErrorString = (decltype(p_ncclGetErrorString))dlsym(g_rccl, "ncclGetErrorString");
+  if (!p_ncclGetUniqueId || !p_ncclCommInitRank || !p_ncclAllReduce || !p_ncclCommDestroy) {
+    set_error("librccl is missing a required symbol");
+    return DFHIP_RUNTIME_ERROR;
+  }
+  return DFHIP_OK;
+}
+#define DF_NCCL(call)                                                                   \
+  do {                                                                                  \
+    int r__ = (call);                                                                   \
+    if (r__ != 0) {                                                                     \
+      set_error("%s failed: %s", #call, p_ncclGetErrorString ? p_ncclGetErrorString(r__) : "?"); \
+      return DFHIP_RUNTIME_ERROR;                                                       \
+    }                                                                                   \
+  } while (0)
+
+int dfhip_comm_unique_id(char* out128) {
+  int s = load_rccl();
+  if (s != DFHIP_OK) return s;
+  df_nccl_uid id;
+  DF_NCCL(p_ncclGetUniqueId(&id));
+  memcpy(out128, id.internal, 128);
+  return DFHIP_OK;
+}
+
+int dfhip_comm_init(int rank, int world, const char* id128) {
+  DF_INIT();
+  DF_CHECK_ARG(world >= 1 && rank >= 0 && rank < world, "bad rank/world %d/%d", rank, world);
+  DF_CHECK_ARG(!g_comm, "communicator already initialised");
+  int s = load_rccl();
+  if (s != DFHIP_OK) return s;
+  df_nccl_uid id;
+  memcpy(id.internal, id128, 128);
+  DF_NCCL(p_ncclCommInitRank(&g_comm, world, id, rank));
+  g_world = world;
+  return DFHIP_OK;
+}
+
+int dfhip_allreduce_sum(float* buf, int64_t n) {
+  DF_INIT();
+  DF_CHECK_ARG(g_comm, "dfhip_comm_init has not been called");
+  if (n == 0) return DFHIP_OK;
+  ProfScope prof("rccl_allreduce", 0.0, 2.0 * (double)n * 4.0);
+  // ncclFloat32 = 7, ncclSum = 0
+  DF_NCCL(p_ncclAllReduce(buf, buf, (size_t)n, 7, 0, g_comm, g_stream));
+  return DFHIP_OK;
+}
+
+int dfhip_comm_destroy(void) {
+  if (g_comm) {
+    (void)hipStreamSynchronize(g_stream);
+    p_ncclCommDestroy(g_comm);
+    g_comm = nullptr;
+  }
+  return DFHIP_OK;
+}
+
+}  // extern "C"

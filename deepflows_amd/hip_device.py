@@ -1,0 +1,375 @@
+"""The `hip` device module: the object a BackendDevice wraps (reference protocol:
+DeepFlows/backend/backend_tensor.py:11-28 `BackendDevice.__getattr__` delegates every call
+to `mod`; the NumPy module is :66-170, the CUDA pybind module
+backend_src/ndarray_backend_cuda.cu:515-717).
+
+`HipModule` exposes
+  * the 26 protocol entry points with the reference's names and argument order
+    (`Array, fill, from_numpy, to_numpy, compact, ewise_setitem, scalar_setitem,
+    ewise_{add,mul,div,maximum,eq,ge}, scalar_{add,mul,div,power,maximum,eq,ge},
+    ewise_{log,exp,tanh}, matmul, reduce_{sum,max}`), and
+  * the fused hot-path entry points (conv2d_*, bn2d_*, maxpool2d_*, relu_*, softmax_ce_*,
+    reduce_to_shape, reduce_axis, broadcast_axis, axpy, adam_step, sgd_step, pack, unpack,
+    allreduce_sum, graph capture) that a front-end picks up with `hasattr(device.mod, ...)`.
+
+Every method is a thin ctypes call into libdfhip.so; nothing is computed in Python.
+"""
+import ctypes
+from ctypes import byref, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+
+import numpy as np
+
+from . import _lib
+
+
+class HipArray:
+    """Flat fp32 device buffer (reference: CudaArray, ndarray_backend_cuda.cu:48-83).
+    `.size` (elements) is part of the protocol (backend_tensor.py:304-308)."""
+
+    __slots__ = ("ptr", "size", "_free", "__weakref__")
+
+    def __init__(self, size, lib):
+        size = int(size)
+        if size < 0:
+            raise ValueError("Array size must be >= 0")
+        out = c_void_p()
+        _lib.check(lib.dfhip_malloc(size, byref(out)))
+        self.ptr = out.value
+        self.size = size
+        self._free = lib.dfhip_free
+
+    def __del__(self):
+        p = getattr(self, "ptr", None)
+        if p:
+            try:
+                self._free(p)
+            except Exception:
+                pass
+            self.ptr = None
+
+    def __repr__(self):
+        return f"HipArray(size={self.size}, ptr=0x{(self.ptr or 0):x})"
+
+
+def _dims(seq):
+    n = len(seq)
+    return n, (c_int64 * max(n, 1))(*[int(v) for v in seq])
+
+
+def _ptr_table(handles):
+    return (c_void_p * len(handles))(*[h.ptr if h is not None else None for h in handles])
+
+
+class HipGraph:
+    """An instantiated hipGraph of everything enqueued between capture_begin/capture_end."""
+
+    def __init__(self, mod, handle, keep):
+        self._mod = mod
+        self._h = handle
+        self._keep = keep  # python objects whose device buffers the graph reads/writes
+
+    def replay(self):
+        _lib.check(self._mod._lib.dfhip_graph_launch(self._h))
+
+    def destroy(self):
+        if self._h:
+            self._mod._lib.dfhip_graph_destroy(self._h)
+            self._h = None
+            self._keep = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class HipModule:
+    name = "hip"
+    fused = True        # front-end: use the fused entry points
+    lazy_grad = True    # front-end: do not allocate a zero .grad per autograd node
+
+    def __init__(self, device_id=-1):
+        self._lib = _lib.load()
+        _lib.check(self._lib.dfhip_init(int(device_id)))
+        buf = ctypes.create_string_buffer(256)
+        _lib.check(self._lib.dfhip_device_name(buf, 256))
+        self.device_name = buf.value.decode()
+        self.conv_dgrad_mode = "overwrite"   # reference-exact col2im; "accumulate" = true gradient
+
+    # ---- memory ---------------------------------------------------------------------------
+    def Array(self, size):
+        return HipArray(size, self._lib)
+
+    def fill(self, handle, value):
+        _lib.check(self._lib.dfhip_fill(handle.ptr, handle.size, float(value)))
+
+    def from_numpy(self, np_array, handle):
+        # any dtype / shape, contiguous (nn/init.py:16 passes float64); pybind cast it to float32
+        a = np.ascontiguousarray(np_array, dtype=np.float32).reshape(-1)
+        if a.size != handle.size:
+            raise ValueError(f"from_numpy: array has {a.size} elements, handle has {handle.size}")
+        _lib.check(self._lib.dfhip_h2d(a.ctypes.data, handle.ptr, a.size))
+
+    def to_numpy(self, handle, shape, strides, offset):
+        shape = tuple(int(s) for s in shape)
+        strides = tuple(int(s) for s in strides)
+        offset = int(offset)
+        if any(s == 0 for s in shape):
+            return np.zeros(shape, dtype=np.float32)
+        lo = offset + sum((n - 1) * st for n, st in zip(shape, strides) if st < 0)
+        hi = offset + sum((n - 1) * st for n, st in zip(shape, strides) if st > 0)
+        if lo < 0 or hi >= handle.size:
+            raise IndexError("to_numpy: view exceeds the array")
+        span = np.empty(hi - lo + 1, dtype=np.float32)
+        _lib.check(self._lib.dfhip_d2h(handle.ptr + 4 * lo, span.ctypes.data, span.size))
+        view = np.lib.stride_tricks.as_strided(span[offset - lo:], shape=shape,
+                                               strides=tuple(4 * s for s in strides))
+        return np.array(view, dtype=np.float32, copy=True)
+
+    def compact(self, src, dst, shape, strides, offset):
+        nd, sh = _dims(shape)
+        _, st = _dims(strides)
+        _lib.check(self._lib.dfhip_compact(src.ptr, dst.ptr, dst.size, nd, sh, st, int(offset)))
+
+    def ewise_setitem(self, src, dst, shape, strides, offset):
+        nd, sh = _dims(shape)
+        _, st = _dims(strides)
+        _lib.check(self._lib.dfhip_ewise_setitem(src.ptr, dst.ptr, src.size, nd, sh, st, int(offset)))
+
+    def scalar_setitem(self, size, value, dst, shape, strides, offset):
+        nd, sh = _dims(shape)
+        _, st = _dims(strides)
+        _lib.check(self._lib.dfhip_scalar_setitem(int(size), float(value), dst.ptr, nd, sh, st, int(offset)))
+
+    # ---- elementwise ----------------------------------------------------------------------
+    def _binary(self, fn, a, b, out):
+        if a.size != out.size or b.size != out.size:
+            raise ValueError("elementwise operands must have the same size")
+        _lib.check(fn(a.ptr, b.ptr, out.ptr, out.size))
+
+    def _scalar(self, fn, a, s, out):
+        if a.size != out.size:
+            raise ValueError("elementwise operands must have the same size")
+        _lib.check(fn(a.ptr, float(s), out.ptr, out.size))
+
+    def _unary(self, fn, a, out):
+        if a.size != out.size:
+            raise ValueError("elementwise operands must have the same size")
+        _lib.check(fn(a.ptr, out.ptr, out.size))
+
+    def ewise_add(self, a, b, out): self._binary(self._lib.dfhip_ewise_add, a, b, out)
+    def ewise_mul(self, a, b, out): self._binary(self._lib.dfhip_ewise_mul, a, b, out)
+    def ewise_div(self, a, b, out): self._binary(self._lib.dfhip_ewise_div, a, b, out)
+    def ewise_maximum(self, a, b, out): self._binary(self._lib.dfhip_ewise_maximum, a, b, out)
+    def ewise_eq(self, a, b, out): self._binary(self._lib.dfhip_ewise_eq, a, b, out)
+    def ewise_ge(self, a, b, out): self._binary(self._lib.dfhip_ewise_ge, a, b, out)
+
+    def scalar_add(self, a, s, out): self._scalar(self._lib.dfhip_scalar_add, a, s, out)
+    def scalar_mul(self, a, s, out): self._scalar(self._lib.dfhip_scalar_mul, a, s, out)
+    def scalar_div(self, a, s, out): self._scalar(self._lib.dfhip_scalar_div, a, s, out)
+    def scalar_power(self, a, s, out): self._scalar(self._lib.dfhip_scalar_power, a, s, out)
+    def scalar_maximum(self, a, s, out): self._scalar(self._lib.dfhip_scalar_maximum, a, s, out)
+    def scalar_eq(self, a, s, out): self._scalar(self._lib.dfhip_scalar_eq, a, s, out)
+    def scalar_ge(self, a, s, out): self._scalar(self._lib.dfhip_scalar_ge, a, s, out)
+
+    def ewise_log(self, a, out): self._unary(self._lib.dfhip_ewise_log, a, out)
+    def ewise_exp(self, a, out): self._unary(self._lib.dfhip_ewise_exp, a, out)
+    def ewise_tanh(self, a, out): self._unary(self._lib.dfhip_ewise_tanh, a, out)
+
+    # ---- contraction / reduction ------------------------------------------------------------
+    def matmul(self, a, b, out, m, n, p):
+        m, n, p = int(m), int(n), int(p)
+        if a.size != m * n or b.size != n * p or out.size != m * p:
+            raise ValueError("matmul: array sizes do not match (m, n, p)")
+        _lib.check(self._lib.dfhip_matmul(a.ptr, b.ptr, out.ptr, m, n, p))
+
+    def reduce_sum(self, a, out, reduce_size):
+        _lib.check(self._lib.dfhip_reduce_sum(a.ptr, out.ptr, a.size // int(reduce_size), int(reduce_size)))
+
+    def reduce_max(self, a, out, reduce_size):
+        _lib.check(self._lib.dfhip_reduce_max(a.ptr, out.ptr, a.size // int(reduce_size), int(reduce_size)))
+
+    # ---- fused hot path ---------------------------------------------------------------------
+    def gemm(self, a, b, bias, out, m, n, p, ta=False, tb=False):
+        _lib.check(self._lib.dfhip_gemm(a.ptr, b.ptr, bias.ptr if bias is not None else None,
+                                        out.ptr, int(m), int(n), int(p), int(ta), int(tb)))
+
+    def conv2d_forward(self, x, w, bias, y, N, C, H, W, O, k, stride, pad):
+        _lib.check(self._lib.dfhip_conv2d_forward(x.ptr, w.ptr, bias.ptr if bias is not None else None,
+                                                  y.ptr, N, C, H, W, O, k, stride, pad))
+
+    def conv2d_wgrad(self, x, dy, dw, N, C, H, W, O, k, stride, pad):
+        _lib.check(self._lib.dfhip_conv2d_wgrad(x.ptr, dy.ptr, dw.ptr, N, C, H, W, O, k, stride, pad))
+
+    def conv2d_dgrad(self, dy, w, dx, N, C, H, W, O, k, stride, pad, mode=None):
+        mode = self.conv_dgrad_mode if mode is None else mode
+        m = {"overwrite": 0, "accumulate": 1}[mode]
+        _lib.check(self._lib.dfhip_conv2d_dgrad(dy.ptr, w.ptr, dx.ptr, N, C, H, W, O, k, stride, pad, m))
+
+    def bn2d_forward_train(self, x, gamma, beta, y, save_mean, save_var, running_mean, running_var,
+                           N, C, HW, eps, momentum):
+        g = lambda h: h.ptr if h is not None else None
+        _lib.check(self._lib.dfhip_bn2d_forward_train(x.ptr, g(gamma), g(beta), y.ptr, g(save_mean),
+                                                      g(save_var), g(running_mean), g(running_var),
+                                                      N, C, HW, float(eps), float(momentum)))
+
+    def bn2d_forward_eval(self, x, gamma, beta, y, running_mean, running_var, N, C, HW, eps):
+        g = lambda h: h.ptr if h is not None else None
+        _lib.check(self._lib.dfhip_bn2d_forward_eval(x.ptr, g(gamma), g(beta), y.ptr, running_mean.ptr,
+                                                     running_var.ptr, N, C, HW, float(eps)))
+
+    def bn2d_backward(self, dy, x, gamma, save_mean, save_var, dx, dgamma, dbeta, N, C, HW, eps):
+        g = lambda h: h.ptr if h is not None else None
+        _lib.check(self._lib.dfhip_bn2d_backward(dy.ptr, x.ptr, g(gamma), save_mean.ptr, save_var.ptr,
+                                                 g(dx), g(dgamma), g(dbeta), N, C, HW, float(eps)))
+
+    def maxpool2d_forward(self, x, y, NC, H, W, k):
+        _lib.check(self._lib.dfhip_maxpool2d_forward(x.ptr, y.ptr, NC, H, W, k))
+
+    def maxpool2d_backward(self, x, y, dy, dx, NC, H, W, k):
+        _lib.check(self._lib.dfhip_maxpool2d_backward(x.ptr, y.ptr, dy.ptr, dx.ptr, NC, H, W, k))
+
+    def relu_forward(self, x, y):
+        _lib.check(self._lib.dfhip_relu_forward(x.ptr, y.ptr, y.size))
+
+    def relu_backward(self, x, y, g, dx):
+        _lib.check(self._lib.dfhip_relu_backward(x.ptr, y.ptr, g.ptr, dx.ptr, dx.size))
+
+    def softmax_ce_forward(self, logits, target, loss, rows, cols):
+        _lib.check(self._lib.dfhip_softmax_ce_forward(logits.ptr, target.ptr, loss.ptr, rows, cols))
+
+    def softmax_ce_backward(self, logits, target, gloss, dlogits, rows, cols):
+        _lib.check(self._lib.dfhip_softmax_ce_backward(logits.ptr, target.ptr, gloss.ptr, dlogits.ptr,
+                                                       rows, cols))
+
+    def reduce_to_shape(self, src, dst, src_shape, dst_shape):
+        ns, ss = _dims(src_shape)
+        nd, ds = _dims(dst_shape)
+        _lib.check(self._lib.dfhip_reduce_to_shape(src.ptr, dst.ptr, ns, ss, nd, ds))
+
+    def reduce_axis(self, src, dst, outer, red, inner, op="sum", scale=1.0):
+        _lib.check(self._lib.dfhip_reduce_axis(src.ptr, dst.ptr, int(outer), int(red), int(inner),
+                                               0 if op == "sum" else 1, float(scale)))
+
+    def broadcast_axis(self, src, dst, outer, red, inner, scale=1.0):
+        _lib.check(self._lib.dfhip_broadcast_axis(src.ptr, dst.ptr, int(outer), int(red), int(inner),
+                                                  float(scale)))
+
+    def axpy(self, dst, src, alpha=1.0):
+        _lib.check(self._lib.dfhip_axpy(dst.ptr, src.ptr, float(alpha), dst.size))
+
+    def copy(self, src, dst):
+        _lib.check(self._lib.dfhip_d2d(src.ptr, dst.ptr, dst.size))
+
+    def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step,
+                  grad_scale=1.0):
+        n = len(params)
+        sizes = (c_int64 * n)(*[p.size for p in params])
+        _lib.check(self._lib.dfhip_adam_step(n, _ptr_table(params), _ptr_table(grads), _ptr_table(exp_avg),
+                                             _ptr_table(exp_avg_sq), sizes, lr, beta1, beta2, eps,
+                                             weight_decay, int(step), grad_scale))
+
+    def sgd_step(self, params, grads, momentum_buf, lr, momentum, weight_decay, nesterov, grad_scale=1.0):
+        n = len(params)
+        sizes = (c_int64 * n)(*[p.size for p in params])
+        mb = _ptr_table(momentum_buf) if momentum_buf else None
+        _lib.check(self._lib.dfhip_sgd_step(n, _ptr_table(params), _ptr_table(grads), mb, sizes, lr,
+                                            momentum, weight_decay, int(bool(nesterov)), grad_scale))
+
+    def pack(self, srcs, flat):
+        n = len(srcs)
+        sizes = (c_int64 * n)(*[s.size for s in srcs])
+        _lib.check(self._lib.dfhip_pack(n, _ptr_table(srcs), sizes, flat.ptr))
+
+    def unpack(self, dsts, flat):
+        n = len(dsts)
+        sizes = (c_int64 * n)(*[d.size for d in dsts])
+        _lib.check(self._lib.dfhip_unpack(n, _ptr_table(dsts), sizes, flat.ptr))
+
+    # ---- collectives (RCCL over xGMI) ---------------------------------------------------------
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(self._lib.dfhip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        _lib.check(self._lib.dfhip_comm_init(int(rank), int(world), unique_id))
+
+    def allreduce_sum(self, handle, count=None):
+        _lib.check(self._lib.dfhip_allreduce_sum(handle.ptr, handle.size if count is None else int(count)))
+
+    def comm_destroy(self):
+        self._lib.dfhip_comm_destroy()
+
+    # ---- stream, graphs, timing ---------------------------------------------------------------
+    def synchronize(self):
+        _lib.check(self._lib.dfhip_sync())
+
+    def capture_begin(self):
+        _lib.check(self._lib.dfhip_graph_begin())
+
+    def capture_end(self, keep=None):
+        h = c_void_p()
+        _lib.check(self._lib.dfhip_graph_end(byref(h)))
+        return HipGraph(self, h, keep)
+
+    def event(self):
+        e = c_void_p()
+        _lib.check(self._lib.dfhip_event_create(byref(e)))
+        return e
+
+    def event_record(self, e):
+        _lib.check(self._lib.dfhip_event_record(e))
+
+    def event_elapsed_ms(self, e0, e1):
+        ms = c_float()
+        _lib.check(self._lib.dfhip_event_elapsed_ms(e0, e1, byref(ms)))
+        return ms.value
+
+    def pool_stats(self):
+        a, b, c = c_int64(), c_int64(), c_int64()
+        self._lib.dfhip_pool_stats(byref(a), byref(b), byref(c))
+        return {"reserved_bytes": a.value, "in_use_bytes": b.value, "hipmalloc_calls": c.value}
+
+    def prof_enable(self, on=True):
+        self._lib.dfhip_prof_enable(int(bool(on)))
+
+    def prof_reset(self):
+        self._lib.dfhip_prof_reset()
+
+    def prof_read(self):
+        cap = 64
+        names = (c_char_p * cap)()
+        ms = (c_double * cap)()
+        calls = (c_int64 * cap)()
+        flops = (c_double * cap)()
+        nbytes = (c_double * cap)()
+        n = self._lib.dfhip_prof_read(cap, names, ms, calls, flops, nbytes)
+        return {names[i].decode(): {"ms": ms[i], "calls": calls[i], "flops": flops[i], "bytes": nbytes[i]}
+                for i in range(n)}
+
+
+_module = None
+
+
+def get_module():
+    """Cached singleton (the reference re-instantiates every device on each Device() call,
+    backend_tensor.py:189-196; device factories must therefore be cheap)."""
+    global _module
+    if _module is None:
+        _module = HipModule()
+    return _module
+
+
+def available():
+    """True iff libdfhip.so is built AND a HIP device is visible. Never raises."""
+    if not _lib.library_present():
+        return False
+    try:
+        lib = _lib.load()
+        n = c_int()
+        lib.dfhip_device_count(byref(n))
+        return n.value > 0
+    except Exception:
+        return False

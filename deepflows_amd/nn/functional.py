@@ -1,0 +1,367 @@
+"""nn.functional — host-side mirror of DeepFlows/nn/functional.py.
+
+Every function keeps the reference's name and argument meaning.  Each has two bodies:
+  * the PRIMITIVE path restates the reference's composition over the 25 device primitives
+    (pad -> im2col by k*k strided setitems -> GEMM, softmax-CE as max/exp/sum/log chains, ...);
+    it runs on any device module and is what the NumPy oracle and the CPU baseline execute;
+  * the FUSED path (taken when `device.mod.fused`) is one autograd node backed by the
+    hand-written HIP kernels of libdfhip.so (implicit-GEMM conv, one-pass BN, ...), with
+    gradients defined to equal what the reference's autograd produces for the same graph —
+    including its quirks: ReLU passes the gradient at x == 0, every tied maximum of a pooling
+    window receives the gradient, and the conv input gradient is "last writer wins"
+    (functional.py:285-294) unless the device is switched to conv_dgrad_mode="accumulate".
+"""
+import numpy as np
+
+from .. import backend_api, tensor
+from ..autograd import is_grad_enable
+from ..backend_selection import BackendTensor
+from ..tensor import Tensor
+
+
+def _fused(t):
+    return bool(getattr(t.device.mod, "fused", False))
+
+
+def _new(shape, device):
+    return BackendTensor.make(tuple(int(s) for s in shape), device=device)
+
+
+class _FusedNode(Tensor):
+    """Autograd node produced by one fused kernel; parents are the differentiable inputs."""
+
+    def __init__(self, data, inputs):
+        req = is_grad_enable() and any(p is not None and p.requires_grad for p in inputs)
+        super().__init__(array=data, device=data.device, requires_grad=req)
+        if self.requires_grad:
+            for p in inputs:
+                if p is not None:
+                    p.build_edge(self)
+
+    def __repr__(self):
+        return f"Tensor({self.data}, op={self.__class__.__name__})"
+
+
+# ---- linear / activations ---------------------------------------------------------------------
+class _LinearFused(_FusedNode):
+    def __init__(self, x, w, b):
+        self.x, self.w, self.b = x, w, b
+        m, k = x.shape
+        p = w.shape[1]
+        xd, wd = x.data.compact(), w.data.compact()
+        out = _new((m, p), x.device)
+        x.device.gemm(xd._handle, wd._handle, b.data.compact()._handle if b is not None else None,
+                      out._handle, m, k, p, False, False)
+        self._saved = (xd, wd)
+        super().__init__(out, [x, w, b])
+
+    def grad_fn(self, node, grad):
+        xd, wd = self._saved
+        g = grad.compact()
+        m, k = xd.shape
+        p = wd.shape[1]
+        dev = g.device
+        if node is self.x:
+            out = _new((m, k), dev)
+            dev.gemm(g._handle, wd._handle, None, out._handle, m, p, k, False, True)   # dY . W^T
+            return out
+        if node is self.w:
+            out = _new((k, p), dev)
+            dev.gemm(xd._handle, g._handle, None, out._handle, k, m, p, True, False)   # X^T . dY
+            return out
+        out = _new(self.b.shape, dev)
+        dev.reduce_to_shape(g._handle, out._handle, g.shape, self.b.shape)
+        return out
+
+
+def linear(input: Tensor, weight: Tensor, bias=None):
+    if _fused(input) and input.ndim == 2 and weight.ndim == 2:
+        return _LinearFused(input, weight, bias)
+    affine = input @ weight
+    if bias is not None:
+        affine = affine + bias
+    return affine
+
+
+class _ReLUFused(_FusedNode):
+    def __init__(self, x):
+        self.xd = x.data.compact()
+        out = _new(x.shape, x.device)
+        x.device.relu_forward(self.xd._handle, out._handle)
+        super().__init__(out, [x])
+
+    def grad_fn(self, node, grad):
+        out = _new(self.xd.shape, grad.device)
+        grad.device.relu_backward(self.xd._handle, self.data._handle, grad.compact()._handle, out._handle)
+        return out
+
+
+def relu(input: Tensor) -> Tensor:
+    if _fused(input):
+        return _ReLUFused(input)
+    return tensor.maximum(input, 0)
+
+
+class tanh(tensor.UnaryOperator):
+    def forward(self, input):
+        return backend_api.tanh(input.data)
+
+    def grad_fn(self, input, grad):
+        return (1 - self.data ** 2) * grad
+
+
+def leaky_relu(input: Tensor, negative_slope: float):
+    return tensor.maximum(input, input * negative_slope)
+
+
+def softmax(input: Tensor, dim=None, keepdims=False):
+    dim = 1 if dim is None else dim
+    shifted = input - tensor.max(input, dim, True)
+    e = tensor.exp(shifted)
+    return e / tensor.sum(e, dim, True)
+
+
+def log_softmax(input: Tensor, dim=None, keepdims=False):
+    dim = 1 if dim is None else dim
+    shifted = input - tensor.max(input, dim, True)
+    return shifted - tensor.log(tensor.sum(tensor.exp(shifted), dim, True))
+
+
+# ---- losses --------------------------------------------------------------------------------------
+def nll_loss(input: Tensor, target: Tensor, reduction: str = 'mean'):
+    nll = -input * target
+    if reduction == 'mean':
+        return tensor.mean(nll)
+    if reduction == 'sum':
+        return tensor.sum(nll)
+    assert 0, "reduction must be mean or sum."
+
+
+def mse_loss(input: Tensor, target: Tensor, reduction: str = 'mean'):
+    sq = tensor.square(input - target)
+    if reduction == 'mean':
+        return tensor.mean(sq)
+    if reduction == 'sum':
+        return tensor.sum(sq)
+    assert 0, "reduction must be mean or sum."
+
+
+class _CrossEntropyFused(_FusedNode):
+    def __init__(self, logits, target):
+        self.ld = logits.data.compact()
+        self.td = target.data.compact()
+        rows, cols = self.ld.shape
+        out = _new((1,), logits.device)
+        logits.device.softmax_ce_forward(self.ld._handle, self.td._handle, out._handle, rows, cols)
+        super().__init__(out, [logits])
+
+    def grad_fn(self, node, grad):
+        rows, cols = self.ld.shape
+        out = _new((rows, cols), grad.device)
+        grad.device.softmax_ce_backward(self.ld._handle, self.td._handle, grad.compact()._handle,
+                                        out._handle, rows, cols)
+        return out
+
+
+def cross_entropy(input: Tensor, target: Tensor, reduction: str = 'mean', dim: int = 1):
+    if (_fused(input) and reduction == 'mean' and dim == 1 and input.ndim == 2
+            and not target.requires_grad):
+        return _CrossEntropyFused(input, target)
+    m = tensor.max(input, dim, True)
+    shifted = input - m
+    lse = tensor.log(tensor.sum(tensor.exp(shifted), dim, True))
+    nll = -(shifted - lse) * target
+    if reduction == 'mean':
+        per_sample = tensor.sum(nll, dim, True)
+        return tensor.sum(per_sample) * (1.0 / input.shape[0])
+    if reduction == 'sum':
+        return tensor.sum(nll)
+    assert 0, "reduction must be mean or sum."
+
+
+# ---- im2col building blocks (primitive path; functional.py:249-313) ---------------------------------
+class _im2col2d(tensor.UnaryOperator):
+    def __init__(self, x, kernel_size, stride):
+        self.N, self.C, self.H, self.W = x.shape
+        self.k, self.s = kernel_size, stride
+        self.oh = (self.H - self.k) // self.s + 1
+        self.ow = (self.W - self.k) // self.s + 1
+        super().__init__(x)
+
+    def forward(self, x):
+        xp = x.data
+        col = backend_api.zeros((self.N, self.C, self.k, self.k, self.oh, self.ow), device=x.device)
+        for i in range(self.k):
+            i_hi = i + self.oh * self.s
+            for j in range(self.k):
+                j_hi = j + self.ow * self.s
+                col[:, :, i, j, :, :] = xp[:, :, i:i_hi:self.s, j:j_hi:self.s]
+        return col
+
+    def grad_fn(self, x, grad):
+        gx = backend_api.zeros((self.N, self.C, self.H, self.W), device=x.device)
+        for i in range(self.k):
+            i_hi = i + self.oh * self.s
+            for j in range(self.k):
+                j_hi = j + self.ow * self.s
+                # assignment, not accumulation: overlapping windows overwrite (functional.py:292-293)
+                gx[:, :, i:i_hi:self.s, j:j_hi:self.s] = grad[:, :, i, j, :, :]
+        return gx
+
+
+class _pad2d(tensor.UnaryOperator):
+    def __init__(self, x, pad_width=0):
+        self.p = pad_width
+        super().__init__(x)
+
+    def forward(self, x):
+        return backend_api.pad(x.data, ((0, 0), (0, 0), (self.p, self.p), (self.p, self.p)))
+
+    def grad_fn(self, x, grad):
+        if self.p == 0:
+            return grad
+        return grad[:, :, self.p:-self.p, self.p:-self.p]
+
+
+# ---- conv2d ---------------------------------------------------------------------------------------
+class _Conv2dFused(_FusedNode):
+    def __init__(self, x, w, bias, padding, stride):
+        self.x, self.w, self.bias = x, w, bias
+        N, C, H, W = (int(v) for v in x.shape)
+        O, _, k, _ = (int(v) for v in w.shape)
+        oh = (H + 2 * padding - k) // stride + 1
+        ow = (W + 2 * padding - k) // stride + 1
+        self.geo = (N, C, H, W, O, k, int(stride), int(padding))
+        self.xd, self.wd = x.data.compact(), w.data.compact()
+        out = _new((N, O, oh, ow), x.device)
+        x.device.conv2d_forward(self.xd._handle, self.wd._handle,
+                                bias.data.compact()._handle if bias is not None else None,
+                                out._handle, *self.geo)
+        super().__init__(out, [x, w, bias])
+
+    def grad_fn(self, node, grad):
+        g = grad.compact()
+        dev = g.device
+        if node is self.x:
+            out = _new(self.xd.shape, dev)
+            dev.conv2d_dgrad(g._handle, self.wd._handle, out._handle, *self.geo)
+            return out
+        if node is self.w:
+            out = _new(self.wd.shape, dev)
+            dev.conv2d_wgrad(self.xd._handle, g._handle, out._handle, *self.geo)
+            return out
+        out = _new(self.bias.shape, dev)
+        dev.reduce_to_shape(g._handle, out._handle, g.shape, self.bias.shape)
+        return out
+
+
+def conv2d(x: Tensor, kernel: Tensor, padding: int = 0, stride: int = 1, bias=None):
+    """x (N,C,H,W), kernel (O,C,k,k) -> (N,O,oh,ow).  `bias` (1,O,1,1) is an extension used by
+    nn.Conv2d so the fused kernel adds it in its epilogue; the reference adds it in
+    Conv2d.forward (conv.py:104-108)."""
+    if _fused(x):
+        return _Conv2dFused(x, kernel, bias, padding, stride)
+    N = x.shape[0]
+    O, _, k, _ = kernel.shape
+    col = _im2col2d(_pad2d(x, padding), k, stride)
+    oh, ow = col.shape[-2:]
+    col = col.transpose(0, 4, 5, 1, 2, 3).reshape(N * oh * ow, -1)
+    out = col @ kernel.reshape(O, -1).T
+    out = out.reshape(N, oh, ow, -1).transpose(0, 3, 1, 2)
+    return out if bias is None else out + bias
+
+
+# ---- pooling ------------------------------------------------------------------------------------------
+class _MaxPool2dFused(_FusedNode):
+    def __init__(self, x, k):
+        N, C, H, W = (int(v) for v in x.shape)
+        self.geo = (N * C, H, W, int(k))
+        self.xd = x.data.compact()
+        out = _new((N, C, (H - k) // k + 1, (W - k) // k + 1), x.device)
+        x.device.maxpool2d_forward(self.xd._handle, out._handle, *self.geo)
+        super().__init__(out, [x])
+
+    def grad_fn(self, node, grad):
+        out = _new(self.xd.shape, grad.device)
+        grad.device.maxpool2d_backward(self.xd._handle, self.data._handle, grad.compact()._handle,
+                                       out._handle, *self.geo)
+        return out
+
+
+def max_pool2d(x: Tensor, kernel_size: int, stride: int, padding=0):
+    if _fused(x) and padding == 0 and stride == kernel_size:
+        return _MaxPool2dFused(x, kernel_size)
+    N, C = x.shape[0], x.shape[1]
+    col = _im2col2d(_pad2d(x, padding), kernel_size, stride)
+    oh, ow = col.shape[-2:]
+    col = col.transpose(0, 4, 5, 1, 2, 3).reshape(-1, kernel_size * kernel_size)
+    out = col.max(1)
+    return out.reshape(N, oh, ow, C).transpose(0, 3, 1, 2)
+
+
+def avg_pool2d(x: Tensor, kernel_size: int, stride: int, padding=0):
+    N, C = x.shape[0], x.shape[1]
+    col = _im2col2d(_pad2d(x, padding), kernel_size, stride)
+    oh, ow = col.shape[-2:]
+    col = col.transpose(0, 4, 5, 1, 2, 3).reshape(-1, kernel_size * kernel_size)
+    # mean over the window = sum / k^2 (padding zeros included, functional.py:395-396)
+    out = tensor.sum(col, 1, True) * (1.0 / (kernel_size * kernel_size))
+    return out.reshape(N, oh, ow, C).transpose(0, 3, 1, 2)
+
+
+# ---- batch norm (used by nn.BatchNorm2d; the reference inlines it in batchnorm.py:30-55) ----------------
+class _BatchNorm2dFused(_FusedNode):
+    def __init__(self, x, weight, bias, running_mean, running_var, eps, momentum):
+        self.x, self.weight, self.bias = x, weight, bias
+        N, C, H, W = (int(v) for v in x.shape)
+        self.geo = (N, C, H * W)
+        self.eps = float(eps)
+        dev = x.device
+        self.xd = x.data.compact()
+        self.wd = weight.data.compact() if weight is not None else None
+        out = _new(x.shape, dev)
+        self.mean, self.var = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+        h = lambda t: t._handle if t is not None else None
+        dev.bn2d_forward_train(self.xd._handle, h(self.wd),
+                               h(bias.data.compact()) if bias is not None else None, out._handle,
+                               self.mean._handle, self.var._handle,
+                               h(running_mean.data) if running_mean is not None else None,
+                               h(running_var.data) if running_var is not None else None,
+                               N, C, H * W, self.eps, float(momentum))
+        self._grads = None
+        super().__init__(out, [x, weight, bias])
+
+    def grad_fn(self, node, grad):
+        if self._grads is None or self._grads[0] is not grad:
+            dev = grad.device
+            N, C, HW = self.geo
+            need_dx = self.x.requires_grad
+            dx = _new(self.xd.shape, dev) if need_dx else None
+            dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+            h = lambda t: t._handle if t is not None else None
+            dev.bn2d_backward(grad.compact()._handle, self.xd._handle, h(self.wd), self.mean._handle,
+                              self.var._handle, h(dx), dg._handle, db._handle, N, C, HW, self.eps)
+            self._grads = (grad, dx, dg, db)
+        _, dx, dg, db = self._grads
+        if node is self.x:
+            return dx
+        return dg if node is self.weight else db
+
+
+def batch_norm2d_train(x, weight, bias, running_mean, running_var, eps, momentum):
+    return _BatchNorm2dFused(x, weight, bias, running_mean, running_var, eps, momentum)
+
+
+class _BatchNorm2dEvalFused(_FusedNode):
+    def __init__(self, x, weight, bias, running_mean, running_var, eps):
+        N, C, H, W = (int(v) for v in x.shape)
+        out = _new(x.shape, x.device)
+        h = lambda t: t.data.compact()._handle if t is not None else None
+        x.device.bn2d_forward_eval(x.data.compact()._handle, h(weight), h(bias), out._handle,
+                                   running_mean.data._handle, running_var.data._handle, N, C, H * W,
+                                   float(eps))
+        super().__init__(out, [])
+
+
+def batch_norm2d_eval(x, weight, bias, running_mean, running_var, eps):
+    return _BatchNorm2dEvalFused(x, weight, bias, running_mean, running_var, eps)

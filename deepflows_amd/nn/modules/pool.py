@@ -1,0 +1,28 @@
+"""Pooling modules — mirror of DeepFlows/nn/modules/pool.py (MaxPool2d default stride=0,
+pool.py:44)."""
+from .. import functional as F
+from .module import Module
+
+
+class MaxPool2d(Module):
+    def __init__(self, kernel_size: int, stride: int = 0, padding: int = 0) -> None:
+        super().__init__()
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+
+    def forward(self, x):
+        return F.max_pool2d(x, self.kernel_size, self.stride, self.padding)
+
+    def extra_repr(self):
+        return f"kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}"
+
+
+class AvgPool2d(Module):
+    def __init__(self, kernel_size: int, stride: int, padding: int = 0) -> None:
+        super().__init__()
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+
+    def forward(self, x):
+        return F.avg_pool2d(x, self.kernel_size, self.stride, self.padding)
+
+    def extra_repr(self):
+        return f"kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}"

@@ -1,0 +1,52 @@
+"""Adam — mirror of DeepFlows/optim/adam.py:7-64: bias-corrected, weight decay added to the
+gradient, `t` starts at 1 and advances once per step(), parameters without a gradient are
+skipped.  On a fused device: one multi-tensor in-place kernel (17 launches per parameter in
+the reference) with the same operation order; scalars are rounded to fp32 where the
+reference's NumPy device rounds them."""
+from .. import backend_api
+from .optimizer import Optimizer
+
+
+class Adam(Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay=0) -> None:
+        super().__init__(params)
+        self.lr = lr
+        self.beta1, self.beta2 = betas
+        self.eps = eps
+        self.weight_decay = weight_decay
+        self.v = [backend_api.zeros_like(p.data) for p in self.params]
+        self.s = [backend_api.zeros_like(p.data) for p in self.params]
+        self.t = 1
+
+    def step(self):
+        mod = self._fused_mod()
+        if mod is not None:
+            live = [i for i, p in enumerate(self.params) if p.grad is not None]
+            if live:
+                for i in live:
+                    self.params[i].data = self.params[i].data.compact()
+                mod.adam_step([self.params[i].data._handle for i in live],
+                              [self.params[i].grad.compact()._handle for i in live],
+                              [self.v[i]._handle for i in live], [self.s[i]._handle for i in live],
+                              self.lr, self.beta1, self.beta2, self.eps, self.weight_decay, self.t,
+                              self.grad_scale)
+            self.t += 1
+            return
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                continue
+            g = p.grad.data if hasattr(p.grad, 'data') else p.grad
+            if self.grad_scale != 1.0:
+                g = g * self.grad_scale
+            w = p.data
+            if self.weight_decay > 0:
+                g = g + w * self.weight_decay
+            self.v[i] = self.v[i] * self.beta1 + g * (1 - self.beta1)
+            self.s[i] = self.s[i] * self.beta2 + g ** 2 * (1 - self.beta2)
+            v_hat = self.v[i] / (1 - self.beta1 ** self.t)
+            s_hat = self.s[i] / (1 - self.beta2 ** self.t)
+            p.data = w - v_hat / (s_hat ** 0.5 + self.eps) * self.lr
+            p.children.clear()
+            p.parents.clear()
+        self.t += 1

@@ -1,0 +1,187 @@
+"""The reference's hot-path workloads, restated on this package's nn API: the model classes
+its training scripts define and the per-batch step they run.
+
+  LinearRegressionModel  test/LinearRegression.py:27-33
+  MLP                    BASELINE config 784->256->10 (script variant 784->100->20->10:
+                         test/MLP_MNIST_cuda.py:44-56)
+  CIFAR10_CNN            test/CNN_CIFAR10_cuda.py:61-108
+  ResidualBlock / ResNet18   test/ResNet_CIFAR10_cuda.py:20-100 (channels 32/64/128/256,
+                         max-pool after the stem, NO ReLU inside the blocks, global average
+                         pool written as two `mean(axis=2)` calls)
+  train_step             the loop body of test/ResNet_CIFAR10_cuda.py:185-190
+
+`register_blocks`: the reference keeps its residual blocks in plain Python lists, which
+nn.Module does not register, so `model.parameters()` yields 5 of the 62 tensors and the
+optimizer never touches the blocks.  register_blocks=False reproduces that
+exactly; register_blocks=True (default) registers every block so all 2 797 610 parameters are
+trained and all-reduced.
+"""
+import numpy as np
+
+from . import nn, tensor
+from .tensor import Graph, Tensor
+
+
+class LinearRegressionModel(nn.Module):
+    def __init__(self, device="hip"):
+        super().__init__()
+        self.linear = nn.Linear(1, 1, device=device)
+
+    def forward(self, x):
+        return self.linear(x)
+
+
+class MLP(nn.Module):
+    def __init__(self, sizes=(784, 256, 10), device="hip"):
+        super().__init__()
+        self.n_layers = len(sizes) - 1
+        for i in range(self.n_layers):
+            setattr(self, f"fc{i + 1}", nn.Linear(sizes[i], sizes[i + 1], device=device))
+
+    def forward(self, x):
+        for i in range(self.n_layers):
+            x = getattr(self, f"fc{i + 1}")(x)
+            if i + 1 < self.n_layers:
+                x = nn.functional.relu(x)
+        return x
+
+
+class CIFAR10_CNN(nn.Module):
+    def __init__(self, num_classes=10, device="hip"):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 32, kernel_size=5, padding=2, device=device)
+        self.bn1 = nn.BatchNorm2d(32, device=device)
+        self.relu1 = nn.ReLU()
+        self.pool1 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.conv2 = nn.Conv2d(32, 64, kernel_size=5, padding=2, device=device)
+        self.bn2 = nn.BatchNorm2d(64, device=device)
+        self.relu2 = nn.ReLU()
+        self.pool2 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.conv3 = nn.Conv2d(64, 128, kernel_size=3, padding=1, device=device)
+        self.bn3 = nn.BatchNorm2d(128, device=device)
+        self.relu3 = nn.ReLU()
+        self.pool3 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.drop = nn.Dropout(0.5)
+        self.fc = nn.Linear(128 * 4 * 4, num_classes, device=device)
+
+    def forward(self, x):
+        x = self.pool1(self.relu1(self.bn1(self.conv1(x))))
+        x = self.pool2(self.relu2(self.bn2(self.conv2(x))))
+        x = self.pool3(self.relu3(self.bn3(self.conv3(x))))
+        x = x.reshape(x.shape[0], -1)
+        x = self.drop(x)
+        return self.fc(x)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, stride=1, downsample=None, device="hip"):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1,
+                               bias=False, device=device)
+        self.bn1 = nn.BatchNorm2d(out_channels, device=device)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1,
+                               bias=False, device=device)
+        self.bn2 = nn.BatchNorm2d(out_channels, device=device)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.bn1(self.conv1(x))
+        out = self.bn2(self.conv2(out))
+        if self.downsample is not None:
+            for layer in self.downsample:
+                identity = layer(identity)
+        return out + identity
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=10, device="hip", register_blocks=True,
+                 widths=(32, 64, 128, 256)):
+        super().__init__()
+        self._dev = device
+        self._register = register_blocks
+        self.in_channels = widths[0]
+        self.conv1 = nn.Conv2d(3, widths[0], kernel_size=3, stride=1, padding=1, bias=False, device=device)
+        self.bn1 = nn.BatchNorm2d(widths[0], device=device)
+        self.relu = nn.ReLU()
+        self.pool1 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.layer1 = self._make_layer(block, widths[0], layers[0], stride=1)
+        self.layer2 = self._make_layer(block, widths[1], layers[1], stride=2)
+        self.layer3 = self._make_layer(block, widths[2], layers[2], stride=2)
+        self.layer4 = self._make_layer(block, widths[3], layers[3], stride=2)
+        self.fc = nn.Linear(widths[3], num_classes, device=device)
+
+    def _make_layer(self, block, out_channels, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.in_channels != out_channels:
+            conv = nn.Conv2d(self.in_channels, out_channels, kernel_size=1, stride=stride, bias=False,
+                             device=self._dev)
+            bn = nn.BatchNorm2d(out_channels, device=self._dev)
+            downsample = nn.ModuleList([conv, bn]) if self._register else [conv, bn]
+        layers = [block(self.in_channels, out_channels, stride, downsample, device=self._dev)]
+        self.in_channels = out_channels
+        for _ in range(1, blocks):
+            layers.append(block(self.in_channels, out_channels, device=self._dev))
+        return nn.ModuleList(layers) if self._register else layers
+
+    def forward(self, x):
+        if not isinstance(x, Tensor):
+            x = Tensor(x)
+        x = self.pool1(self.relu(self.bn1(self.conv1(x))))
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in stage:
+                x = blk(x)
+        x = tensor.mean(x, axis=2)     # divides by the TOTAL element count
+        x = tensor.mean(x, axis=2)
+        return self.fc(x)
+
+
+def ResNet18(num_classes=10, device="hip", register_blocks=True):
+    return ResNet(ResidualBlock, [2, 2, 2, 2], num_classes, device, register_blocks)
+
+
+def all_block_parameters(model):
+    """Every parameter of a ResNet including unregistered list-held blocks, in construction
+    order (for checks on the register_blocks=False variant)."""
+    seen, out = set(), []
+
+    def visit(m):
+        for p in m._parameters.values():
+            if p is not None and id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        for c in m._modules.values():
+            if c is not None:
+                visit(c)
+        for v in m.__dict__.values():
+            if isinstance(v, (list, tuple)):
+                for item in v:
+                    if isinstance(item, nn.Module):
+                        visit(item)
+    visit(model)
+    return sorted(out, key=lambda p: p.unique_id)
+
+
+def smooth_one_hot(labels, num_classes=10, eps=0.0):
+    """one-hot fp32 targets, optionally label-smoothed (test/ResNet_CIFAR10_cuda.py:181-183)."""
+    y = np.eye(num_classes, dtype=np.float32)[np.asarray(labels)]
+    if eps:
+        y = y * (1 - eps) + eps / num_classes
+    return y.astype(np.float32)
+
+
+def train_step(model, criterion, optimizer, inputs, targets, sync=None):
+    """One batch: forward, loss, zero_grad, backward, (gradient all-reduce), optimizer step."""
+    outputs = model(inputs)
+    loss = criterion(outputs, targets)
+    optimizer.zero_grad()
+    loss.backward()
+    if sync is not None:
+        sync()
+    optimizer.step()
+    return loss, outputs
+
+
+def end_of_step():
+    Graph.free_graph()

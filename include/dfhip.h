@@ -1,0 +1,231 @@
+/*
+ * dfhip.h — C ABI of libdfhip.so, the MI355X (gfx950) `hip` device for DeepFlows'
+ * BackendTensor protocol.
+ *
+ * Every entry point below is what the reference's device-module binding for this
+ * path would bind (the reference binds its CUDA device through pybind11 in
+ * DeepFlows/backend/backend_src/ndarray_backend_cuda.cu:515-717; the Python call
+ * sites are in DeepFlows/backend/backend_tensor.py).  The citation after each
+ * declaration names the reference interface it replaces.
+ *
+ * Conventions
+ *   - all buffers are device pointers to fp32 (the reference is fp32-only,
+ *     ndarray_backend_cuda.cu:19 `scalar_t`); sizes are in ELEMENTS;
+ *   - shapes / strides / offsets are int64 in elements, strides may be 0
+ *     (broadcast) or negative (flip), at most DFHIP_MAX_DIMS dims
+ *     (ndarray_backend_cuda.cu:107-124 `CudaVec`, MAX_VEC_SIZE 8);
+ *   - every function returns a dfhip_status; on failure a thread-local message
+ *     is available from dfhip_last_error().  The Python shim maps the status to
+ *     the exception class pybind11 raised for the CUDA module
+ *     (invalid_argument→ValueError, out_of_range→IndexError,
+ *     runtime_error→RuntimeError, bad_alloc→MemoryError);
+ *   - all work is enqueued on ONE non-blocking HIP stream owned by the library
+ *     (the reference uses the default stream, ndarray_backend_cuda.cu:138);
+ *     only dfhip_d2h and dfhip_sync block the host;
+ *   - no PyTorch types, no C++ types: plain pointers and sizes.
+ */
+#ifndef DFHIP_H
+#define DFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFHIP_MAX_DIMS 8
+
+typedef enum {
+  DFHIP_OK = 0,
+  DFHIP_INVALID_ARGUMENT = 1, /* -> ValueError  (std::invalid_argument / domain_error) */
+  DFHIP_OUT_OF_RANGE = 2,     /* -> IndexError  (std::out_of_range)                     */
+  DFHIP_RUNTIME_ERROR = 3,    /* -> RuntimeError (hip launch / memcpy / alloc failure)  */
+  DFHIP_OUT_OF_MEMORY = 4     /* -> MemoryError (std::bad_alloc)                        */
+} dfhip_status;
+
+/* ---- runtime ----------------------------------------------------------------------- */
+int dfhip_init(int device_id);                 /* hipSetDevice + stream + pool; idempotent  */
+int dfhip_device_count(int* out);
+const char* dfhip_last_error(void);
+int dfhip_sync(void);                          /* hipStreamSynchronize on the library stream */
+void* dfhip_stream(void);                      /* the hipStream_t all kernels are launched on */
+int dfhip_device_name(char* out, int cap);
+
+/* Array(size): ndarray_backend_cuda.cu:48-83 (CudaArray: cudaMalloc / cudaFree deleter).
+ * Here: a size-bucketed, stream-ordered caching pool (no hipMalloc in steady state).   */
+int dfhip_malloc(int64_t n_floats, float** out);
+int dfhip_free(float* p);
+int dfhip_pool_stats(int64_t* bytes_reserved, int64_t* bytes_in_use, int64_t* n_hipmalloc);
+int dfhip_pool_trim(void);
+
+/* from_numpy / to_numpy: ndarray_backend_cuda.cu:667-716 (blocking cudaMemcpy).       */
+int dfhip_h2d(const float* host, float* dst, int64_t n);
+int dfhip_d2h(const float* src, float* host, int64_t n);
+int dfhip_d2d(const float* src, float* dst, int64_t n);
+
+/* ---- the 25 device primitives (backend_tensor.py:66-170 NumpyBackend;                */
+/*      ndarray_backend_cuda.cu:127-509 kernels) ---------------------------------------- */
+/* fill: .cu:127-144 */
+int dfhip_fill(float* out, int64_t n, float val);
+/* compact: .cu:147-176; out[g] = a[offset + sum_i idx_i(g)*strides_i], g row-major      */
+int dfhip_compact(const float* a, float* out, int64_t n_out, int ndim,
+                  const int64_t* shape, const int64_t* strides, int64_t offset);
+/* ewise_setitem: .cu:178-198; out[offset + sum idx_i(g)*strides_i] = a[g] (scatter)     */
+int dfhip_ewise_setitem(const float* a, float* out, int64_t n, int ndim,
+                        const int64_t* shape, const int64_t* strides, int64_t offset);
+/* scalar_setitem: .cu:200-221 */
+int dfhip_scalar_setitem(int64_t n, float val, float* out, int ndim,
+                         const int64_t* shape, const int64_t* strides, int64_t offset);
+/* ewise binary: .cu:224-229 add, 259-262 mul, 285-288 div, 325-328 maximum,
+ * 351-354 eq, 377-380 ge (eq/ge produce 1.0f / 0.0f)                                   */
+int dfhip_ewise_add(const float* a, const float* b, float* out, int64_t n);
+int dfhip_ewise_mul(const float* a, const float* b, float* out, int64_t n);
+int dfhip_ewise_div(const float* a, const float* b, float* out, int64_t n);
+int dfhip_ewise_maximum(const float* a, const float* b, float* out, int64_t n);
+int dfhip_ewise_eq(const float* a, const float* b, float* out, int64_t n);
+int dfhip_ewise_ge(const float* a, const float* b, float* out, int64_t n);
+/* scalar binary: .cu:246-249 add, 272-275 mul, 298-307 div, 312-315 power,
+ * 338-341 maximum, 364-367 eq, 390-393 ge.  Values follow the NumPy device
+ * (backend_tensor.py:109-143): scalar_div by 0 gives inf/nan, it does not throw.       */
+int dfhip_scalar_add(const float* a, float s, float* out, int64_t n);
+int dfhip_scalar_mul(const float* a, float s, float* out, int64_t n);
+int dfhip_scalar_div(const float* a, float s, float* out, int64_t n);
+int dfhip_scalar_power(const float* a, float s, float* out, int64_t n);
+int dfhip_scalar_maximum(const float* a, float s, float* out, int64_t n);
+int dfhip_scalar_eq(const float* a, float s, float* out, int64_t n);
+int dfhip_scalar_ge(const float* a, float s, float* out, int64_t n);
+/* unary: .cu:403-406 log, 416-419 exp, 429-432 tanh.  log follows NumPy
+ * (backend_tensor.py:145-146): log(0) = -inf, log(<0) = nan.                           */
+int dfhip_ewise_log(const float* a, float* out, int64_t n);
+int dfhip_ewise_exp(const float* a, float* out, int64_t n);
+int dfhip_ewise_tanh(const float* a, float* out, int64_t n);
+/* matmul: .cu:443-466; out[M x P] = a[M x N] . b[N x P], row-major, fp32 MFMA          */
+int dfhip_matmul(const float* a, const float* b, float* out, int64_t m, int64_t n, int64_t p);
+/* reduce_sum / reduce_max: .cu:469-509; out[g] = reduce of reduce_size contiguous inputs */
+int dfhip_reduce_sum(const float* a, float* out, int64_t n_out, int64_t reduce_size);
+int dfhip_reduce_max(const float* a, float* out, int64_t n_out, int64_t reduce_size);
+
+/* ---- fused hot-path entry points ------------------------------------------------------
+ * The reference composes these from the primitives above in Python; a
+ * front-end uses them when `hasattr(device.mod, ...)`.                                   */
+
+/* GEMM with transposed operands, replaces compact()+matmul in tensor.py:699-716
+ * (matmul.grad_fn).  out[M x P] = op(a) . op(b); ta: a is stored [N x M]; tb: b is
+ * stored [P x N].  If `bias` is not NULL (length P) it is added to every row
+ * (F.linear, nn/functional.py:8-12).                                                   */
+int dfhip_gemm(const float* a, const float* b, const float* bias, float* out,
+               int64_t m, int64_t n, int64_t p, int ta, int tb);
+
+/* Conv2d forward: nn/functional.py:316-344 (pad -> im2col -> GEMM) + conv.py:104-108
+ * (bias (1,O,1,1), may be NULL).  x (N,C,H,W), w (O,C,k,k), y (N,O,oh,ow), all NCHW.  */
+int dfhip_conv2d_forward(const float* x, const float* w, const float* bias, float* y,
+                         int N, int C, int H, int W, int O, int k, int stride, int pad);
+/* weight gradient: tensor.py:716 (A^T . dC) for the conv GEMM; dw (O,C,k,k)            */
+int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw,
+                       int N, int C, int H, int W, int O, int k, int stride, int pad);
+/* input gradient: tensor.py:708 (dC . B^T) followed by __im2col2d.grad_fn
+ * (nn/functional.py:285-294) and __pad2d.grad_fn (:307-313).
+ * mode 0 = "overwrite": reference-exact last-writer-wins col2im (functional.py:292-293);
+ * mode 1 = "accumulate": the mathematically correct sum over overlapping windows.      */
+int dfhip_conv2d_dgrad(const float* dy, const float* w, float* dx,
+                       int N, int C, int H, int W, int O, int k, int stride, int pad, int mode);
+
+/* BatchNorm2d training forward: nn/modules/batchnorm.py:30-55.  Biased variance; running
+ * stats r = r*(1-momentum) + batch*momentum (both may be NULL).  save_mean / save_var
+ * (C floats each) feed the backward.                                                    */
+int dfhip_bn2d_forward_train(const float* x, const float* gamma, const float* beta, float* y,
+                             float* save_mean, float* save_var, float* running_mean,
+                             float* running_var, int N, int C, int HW, float eps, float momentum);
+int dfhip_bn2d_forward_eval(const float* x, const float* gamma, const float* beta, float* y,
+                            const float* running_mean, const float* running_var,
+                            int N, int C, int HW, float eps);
+/* backward of that expression graph (autograd through batchnorm.py:32-55): dx, dgamma,
+ * dbeta (any of dx/dgamma/dbeta may be NULL).                                           */
+int dfhip_bn2d_backward(const float* dy, const float* x, const float* gamma,
+                        const float* save_mean, const float* save_var, float* dx,
+                        float* dgamma, float* dbeta, int N, int C, int HW, float eps);
+
+/* MaxPool2d with kernel == stride, no padding: nn/functional.py:347-374; backward is
+ * tensor.max.grad_fn (tensor.py:779-791): every tied maximum receives the gradient.     */
+int dfhip_maxpool2d_forward(const float* x, float* y, int NC, int H, int W, int k);
+int dfhip_maxpool2d_backward(const float* x, const float* y, const float* dy, float* dx,
+                             int NC, int H, int W, int k);
+
+/* ReLU = tensor.maximum(x, 0) (nn/functional.py:15-16); backward (y == x) * g
+ * (tensor.py:872-877): x == 0 passes the gradient.                                      */
+int dfhip_relu_forward(const float* x, float* y, int64_t n);
+int dfhip_relu_backward(const float* x, const float* y, const float* g, float* dx, int64_t n);
+
+/* cross_entropy(reduction='mean') on dense targets: nn/functional.py:104-115.
+ * loss is one float; logits/target are (rows, cols) row-major.                          */
+int dfhip_softmax_ce_forward(const float* logits, const float* target, float* loss,
+                             int rows, int cols);
+/* dlogits = gscale * (softmax * sum(target) - target) / rows, gscale read from the
+ * device scalar `gloss` (the upstream gradient of the (1,)-shaped loss).                */
+int dfhip_softmax_ce_backward(const float* logits, const float* target, const float* gloss,
+                              float* dlogits, int rows, int cols);
+
+/* Sum `src` over the axes in which dst_shape is 1 (or missing leading axes): replaces
+ * the host un-broadcast of tensor.py:462-483.  Shapes are right-aligned.                */
+int dfhip_reduce_to_shape(const float* src, float* dst, int src_ndim, const int64_t* src_shape,
+                          int dst_ndim, const int64_t* dst_shape);
+/* Single-axis reduce of a compact (outer, red, inner) array without the permute copy of
+ * backend_tensor.py:624-657; op 0 = sum, 1 = max; result multiplied by `scale`
+ * (BackendTensor.mean divides by the TOTAL element count, backend_tensor.py:659-662).   */
+int dfhip_reduce_axis(const float* src, float* dst, int64_t outer, int64_t red, int64_t inner,
+                      int op, float scale);
+/* dst[(o, r, i)] = src[(o, i)] * scale : backward of the above (tensor.py:763-766).     */
+int dfhip_broadcast_axis(const float* src, float* dst, int64_t outer, int64_t red,
+                         int64_t inner, float scale);
+/* dst += alpha * src (gradient accumulation, tensor.py:486-493).                        */
+int dfhip_axpy(float* dst, const float* src, float alpha, int64_t n);
+
+/* Multi-tensor optimizer steps.  ptr tables are HOST arrays of device pointers, sizes in
+ * elements.  grad_scale multiplies every gradient first (1/world for data parallel).
+ * Adam: optim/adam.py:28-64 (t = step count starting at 1).  SGD: optim/sgd.py:16-24.
+ * Hyper-parameters arrive as doubles (Python floats) and are rounded to fp32 at exactly the
+ * points where the reference's NumPy device rounds them (np.float32(s), backend_tensor.py:
+ * 109-125), e.g. 1-beta1 and 1-beta1**t are formed in double first.                      */
+int dfhip_adam_step(int n_tensors, float* const* params, const float* const* grads,
+                    float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
+                    double lr, double beta1, double beta2, double eps, double weight_decay,
+                    int step, double grad_scale);
+int dfhip_sgd_step(int n_tensors, float* const* params, const float* const* grads,
+                   float* const* momentum_buf, const int64_t* sizes, double lr, double momentum,
+                   double weight_decay, int nesterov, double grad_scale);
+
+/* Pack / unpack a list of tensors into one flat bucket (gradient all-reduce payload).   */
+int dfhip_pack(int n_tensors, const float* const* srcs, const int64_t* sizes, float* flat);
+int dfhip_unpack(int n_tensors, float* const* dsts, const int64_t* sizes, const float* flat);
+
+/* ---- data-parallel exchange over RCCL / xGMI (new functionality; the reference has no
+ *      collective) ---------------------------------------------------- */
+int dfhip_comm_unique_id(char* out128);                       /* ncclGetUniqueId          */
+int dfhip_comm_init(int rank, int world, const char* id128);  /* ncclCommInitRank         */
+int dfhip_allreduce_sum(float* buf, int64_t n);               /* in place, library stream */
+int dfhip_comm_destroy(void);
+
+/* ---- whole-step capture (hipGraph) -------------------------------------------------- */
+int dfhip_graph_begin(void);                   /* hipStreamBeginCapture on the library stream */
+int dfhip_graph_end(void** graph_exec);        /* end capture + instantiate                  */
+int dfhip_graph_launch(void* graph_exec);
+int dfhip_graph_destroy(void* graph_exec);
+
+/* ---- measurement helpers ------------------------------------------------------------ */
+int dfhip_event_create(void** ev);
+int dfhip_event_record(void* ev);              /* on the library stream */
+int dfhip_event_elapsed_ms(void* start, void* stop, float* ms);  /* synchronises on stop */
+int dfhip_event_destroy(void* ev);
+/* per-kernel-family HIP-event timing: when enabled every launch of the family is
+ * bracketed by events on the library stream (used by bench.py for roofline.achieved).   */
+int dfhip_prof_enable(int on);
+int dfhip_prof_reset(void);
+/* returns number of families written; names are static strings */
+int dfhip_prof_read(int cap, const char** names, double* total_ms, int64_t* calls,
+                    double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFHIP_H */
