@@ -603,20 +603,34 @@ int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C,
   g.x = x; g.dy = dy;
   g.N = N; g.C = C; g.H = H; g.W = W; g.O = O; g.oh = oh; g.ow = ow;
   g.k = k; g.stride = stride; g.pad = pad;
-  int gi;
-  plan_groups(N, oh, ow, 256, g.BI, g.BR, g.BC, gi, g.gr, g.gc);
-  g.ngroups = gi * g.gr * g.gc;
-  g.PR = (g.BR - 1) * stride + k;
-  g.PC = (g.BC - 1) * stride + k;
-  g.PE = g.BI * g.PR * g.PC;
   const int KW = C * k * k;
+  const int k2 = k * k;
   const int ktiles32 = (int)df_ceil_div(KW, 32);
+  int OT, KT;
   if (O <= 32) {
-    if (ktiles32 >= 7) return launch_wgrad<1, 9>(g, dw);
-    if (ktiles32 >= 3) return launch_wgrad<1, 4>(g, dw);
-    return launch_wgrad<1, 1>(g, dw);
+    OT = 1;
+    KT = ktiles32 >= 7 ? 9 : (ktiles32 >= 3 ? 4 : 1);
+  } else {
+    OT = 2;
+    KT = ktiles32 >= 3 ? 4 : 1;
   }
-  if (ktiles32 >= 3) return launch_wgrad<2, 4>(g, dw);
+  // shrink the pixel group until patch + dY tile fit the LDS
+  const int CH = std::min(C, (KT * 32 + k2 - 2) / k2 + 1);
+  for (int tp = 256; tp >= 32; tp >>= 1) {
+    int gi;
+    plan_groups(N, oh, ow, tp, g.BI, g.BR, g.BC, gi, g.gr, g.gc);
+    g.ngroups = gi * g.gr * g.gc;
+    g.PR = (g.BR - 1) * stride + k;
+    g.PC = (g.BC - 1) * stride + k;
+    g.PE = g.BI * g.PR * g.PC;
+    int BMPP = (g.BI * g.BR * g.BC + 7) & ~7;
+    size_t stage = ((size_t)CH * g.PE + (size_t)OT * 32 * (BMPP + 1)) * 4 + ((size_t)g.PE + BMPP) * 4;
+    if (stage <= 144 * 1024) break;
+  }
+  if (OT == 1 && KT == 9) return launch_wgrad<1, 9>(g, dw);
+  if (OT == 1 && KT == 4) return launch_wgrad<1, 4>(g, dw);
+  if (OT == 1) return launch_wgrad<1, 1>(g, dw);
+  if (KT == 4) return launch_wgrad<2, 4>(g, dw);
   return launch_wgrad<2, 1>(g, dw);
 }
 
