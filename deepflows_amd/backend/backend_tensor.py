@@ -148,7 +148,9 @@ class BackendTensor:
         elif isinstance(other, np.ndarray):
             device = device if device is not None else default_device()
             arr = BackendTensor.make(other.shape, device=device)
-            arr.device.from_numpy(np.ascontiguousarray(other.astype(np.float32)), arr._handle)
+            with np.errstate(over="ignore", invalid="ignore"):     # tensor.empty() hands over garbage
+                host = np.ascontiguousarray(other.astype(np.float32))
+            arr.device.from_numpy(host, arr._handle)
             self._adopt(arr)
         else:
             self._adopt(BackendTensor(np.array(other), device))

@@ -22,6 +22,8 @@
 // GEMM with the pixel operand masked to the lanes whose selected tap equals the tap of the
 // current k index: same kernel, one compare+select per operand read, results identical to
 // the reference because every masked product is an exact +0.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "dfhip_internal.h"
@@ -54,6 +56,7 @@ struct Geo {
   int wC;                  // C of the (O,C,k,k) weight tensor
   int pad, stride, oh, ow; // conv geometry (for the overwrite tap selection)
   int64_t slab_stride;
+  int dbg;                 // debug: 1 skip staging, 2 skip compute, 4 skip epilogue, 8 skip goff
 };
 
 __device__ __forceinline__ void decode_pixel(const Geo& g, int q, int& img, int& r, int& col) {
@@ -207,6 +210,215 @@ __global__ __launch_bounds__(256) void k_conv_igemm(Geo g) {
   // epilogue: accumulator register rr of lane (half, l31) is D[channel][pixel] with
   // channel = (rr&3) + 8*(rr>>2) + 4*half, pixel = l31
   if (pvalid) {
+    const int64_t dplane = (int64_t)g.HD * g.WD;
+    float* out = g.dst + (int64_t)blockIdx.z * g.slab_stride +
+                 (int64_t)(n0 + img) * g.CD * dplane + (int64_t)(r0 + r) * g.WD + (c0 + col);
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) {
+      int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+      if (d < g.CD) {
+        float v = acc[rr];
+        if (g.bias) v += g.bias[d];
+        out[(int64_t)d * dplane] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward / input-gradient, producer-consumer form (source channels % 8 == 0):
+//   * 512-thread workgroup: waves 0-3 run the matrix cores (one 32-pixel x 32-channel tile
+//     each), waves 4-7 stage the NEXT channel chunk (patch + weights) into the other LDS buffer
+//     while they do, one barrier per chunk.  The MFMA pipe of a SIMD is fed by its compute
+//     wave, its loader wave only issues VMEM / LDS / address arithmetic;
+//   * K is ordered (tap, channel): inside a tap the operand addresses advance by constants
+//     (2*PE and 2*WLD floats per k pair), so the inner loop is ds_read + MFMA only, unrolled
+//     by four k pairs with the next group's reads issued ahead of the current MFMAs;
+//   * overwrite mode: a tap that no lane of the wave selects contributes exact zeros and is
+//     skipped (wave-uniform branch) - for a 3x3 stride-1 layer that leaves one tap in nine
+//     for interior tiles.
+// ---------------------------------------------------------------------------------------
+template <int KS, int MODE>
+__global__ __launch_bounds__(512, 4) void k_conv_igemm_ws(Geo g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int k = KS, k2 = KS * KS;
+  constexpr int WLD = 33;
+  const int CCP = g.CC;                 // channels per chunk, multiple of 8
+  const int CCQ = CCP + 1;              // weight rows per tap (+1: spreads the staging writes over banks)
+  const int xs_floats = CCP * g.PE + 64;          // +64: the last prefetch group reads past the chunk
+  const int ws_floats = k2 * CCQ * WLD + 8 * WLD;
+  float* Xs0 = smem;
+  float* Ws0 = Xs0 + 2 * xs_floats;
+  int* goff = (int*)(Ws0 + 2 * ws_floats);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const bool loader = wave >= 4;
+
+  int gx = blockIdx.x;
+  const int gcx = gx % g.gc; gx /= g.gc;
+  const int grx = gx % g.gr; gx /= g.gr;
+  const int n0 = gx * g.BI, r0 = grx * g.BR, c0 = gcx * g.BC;
+  const int d0 = blockIdx.y * 32;
+  const int cs_beg = blockIdx.z * g.cs_per_split;
+  const int cs_end = min(g.CS, cs_beg + g.cs_per_split);
+  const int nchunks = (cs_end - cs_beg) / CCP;
+  const int64_t src_plane = (int64_t)g.HS * g.WS;
+
+  for (int j = tid; j < ((g.dbg & 8) ? 0 : g.PE); j += 512) {
+    int per_img = g.PR * g.PC;
+    int img = j / per_img;
+    int rem = j - img * per_img;
+    int pr = rem / g.PC, pc = rem - pr * g.PC;
+    int u = r0 * g.so + g.u0 + pr, v = c0 * g.so + g.u0 + pc;
+    bool ok = (n0 + img < g.N) && u >= 0 && v >= 0 && (u % g.sd) == 0 && (v % g.sd) == 0;
+    int su = u / g.sd, sv = v / g.sd;
+    ok = ok && su < g.HS && sv < g.WS;
+    goff[j] = ok ? (int)((int64_t)img * g.CS * src_plane + (int64_t)su * g.WS + sv) : -1;
+  }
+
+  // compute waves: this wave's 32-pixel tile
+  int q = (wave & 3) * 32 + l31, img, r, col;
+  decode_pixel(g, q, img, r, col);
+  const bool pvalid = q < g.BI * g.BR * g.BC && n0 + img < g.N && r0 + r < g.HD && c0 + col < g.WD;
+  const int abase = (pvalid ? img * g.PR * g.PC + r * g.so * g.PC + col * g.so : 0) + half * g.PE;
+  int tapsel = -2;
+  if (MODE == 2 && pvalid) {
+    int ti = last_tap(r0 + r + g.pad, k, g.stride, g.oh);
+    int tj = last_tap(c0 + col + g.pad, k, g.stride, g.ow);
+    tapsel = (ti < 0 || tj < 0) ? -1 : ti * k + tj;
+  }
+
+  auto stage = [&](int chunk, int buf, int nthreads, int t0) {
+    // called by `nthreads` threads whose local index is t0 (all 512 in the prologue, the 256
+    // loader threads in the main loop)
+    const int cb = cs_beg + chunk * CCP;
+    float* Xs = Xs0 + buf * xs_floats;
+    float* Ws = Ws0 + buf * ws_floats;
+    const int nw = nthreads >> 6, w0 = t0 >> 6, ln = t0 & 63;
+    // Patch: the gather offsets of 4 consecutive 64-element slices are read once and used for
+    // a group of 4 channels: 16 independent global loads in flight per thread, no branches
+    // (out-of-image elements load offset 0 and are zeroed by a select).
+    for (int cg = w0 * 4; cg < CCP; cg += nw * 4) {
+      const float* base = g.src + ((int64_t)n0 * g.CS + cb + cg) * src_plane;
+      float* xs = Xs + (size_t)cg * g.PE;
+      for (int j0 = ln; j0 < g.PE; j0 += 256) {
+        int go[4];
+        float v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          int j = j0 + 64 * u;
+          go[u] = j < g.PE ? goff[j] : -1;
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+          for (int u = 0; u < 4; u++) v[cc][u] = base[(int64_t)cc * src_plane + (go[u] >= 0 ? go[u] : 0)];
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            int j = j0 + 64 * u;
+            if (j < g.PE) xs[cc * g.PE + j] = go[u] >= 0 ? v[cc][u] : 0.0f;
+          }
+      }
+    }
+    // Weights: 32*CCP*k2 elements per chunk, flat index f -> (row, e) with the lanes running
+    // along the contiguous global dimension; all of a thread's loads are issued before the
+    // first LDS store.
+    {
+      const int run = MODE == 0 ? CCP * k2 : 32 * k2;      // contiguous floats per row
+      const int nrows = MODE == 0 ? 32 : CCP;               // rows: d (forward) or c (dgrad)
+      const int total = run * nrows;
+      const int dmax = g.CD - d0;
+      constexpr int U = 6;
+      for (int f0 = t0; f0 < total; f0 += nthreads * U) {
+        float v[U];
+        int row[U], e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          int f = f0 + nthreads * u;
+          f = f < total ? f : 0;
+          row[u] = f / run;
+          e[u] = f - row[u] * run;
+          int64_t src;
+          bool ok;
+          if (MODE == 0) {
+            ok = row[u] < dmax;
+            src = ((int64_t)(d0 + (ok ? row[u] : 0)) * g.wC + cb) * k2 + e[u];
+          } else {
+            ok = e[u] / k2 < dmax;
+            src = ((int64_t)(cb + row[u]) * g.wC + d0) * k2 + (ok ? e[u] : 0);
+          }
+          v[u] = g.wgt[src];
+          if (!ok) v[u] = 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (f0 + nthreads * u < total) {
+            int c, t, d;
+            if (MODE == 0) { d = row[u]; c = e[u] / k2; t = e[u] - c * k2; }
+            else { c = row[u]; d = e[u] / k2; t = e[u] - d * k2; }
+            Ws[(t * CCQ + c) * WLD + d] = v[u];
+          }
+        }
+      }
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int rr = 0; rr < 16; rr++) acc[rr] = 0.0f;
+
+  __syncthreads();                      // goff ready
+  if (nchunks > 0 && !(g.dbg & 1)) stage(0, 0, 512, tid);
+  __syncthreads();
+
+  for (int ch = 0; ch < nchunks; ch++) {
+    const int buf = ch & 1;
+    if (loader) {
+      if (ch + 1 < nchunks && !(g.dbg & 1)) stage(ch + 1, buf ^ 1, 256, tid - 256);
+    } else if (!(g.dbg & 2)) {
+      const float* Xs = Xs0 + buf * xs_floats + abase;
+      const float* Ws = Ws0 + buf * ws_floats + half * WLD + l31;
+      const int np = CCP >> 1;          // k pairs per tap, multiple of 4
+#pragma unroll
+      for (int t = 0; t < k2; t++) {
+        if (MODE == 2) {
+          if (__ballot(tapsel == t) == 0ull) continue;
+        }
+        const int i = t / k, j = t - i * k;
+        const int toff = MODE == 0 ? i * g.PC + j : (k - 1 - i) * g.PC + (k - 1 - j);
+        const float* bp = Xs + toff;
+        const float* ap = Ws + t * CCQ * WLD;
+        const int bstep = 2 * g.PE, astep = 2 * WLD;
+        float a0 = ap[0], a1 = ap[astep], a2 = ap[2 * astep], a3 = ap[3 * astep];
+        float b0 = bp[0], b1 = bp[bstep], b2 = bp[2 * bstep], b3 = bp[3 * bstep];
+        for (int p = 0; p < np; p += 4) {
+          ap += 4 * astep;
+          bp += 4 * bstep;
+          float na0 = 0.f, na1 = 0.f, na2 = 0.f, na3 = 0.f, nb0 = 0.f, nb1 = 0.f, nb2 = 0.f, nb3 = 0.f;
+          if (p + 4 < np) {
+            na0 = ap[0]; na1 = ap[astep]; na2 = ap[2 * astep]; na3 = ap[3 * astep];
+            nb0 = bp[0]; nb1 = bp[bstep]; nb2 = bp[2 * bstep]; nb3 = bp[3 * bstep];
+          }
+          if (MODE == 2) {
+            const bool sel = tapsel == t;
+            b0 = sel ? b0 : 0.0f; b1 = sel ? b1 : 0.0f; b2 = sel ? b2 : 0.0f; b3 = sel ? b3 : 0.0f;
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);
+          a0 = na0; a1 = na1; a2 = na2; a3 = na3;
+          b0 = nb0; b1 = nb1; b2 = nb2; b3 = nb3;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (!loader && pvalid && !(g.dbg & 4)) {
     const int64_t dplane = (int64_t)g.HD * g.WD;
     float* out = g.dst + (int64_t)blockIdx.z * g.slab_stride +
                  (int64_t)(n0 + img) * g.CD * dplane + (int64_t)(r0 + r) * g.WD + (c0 + col);
@@ -404,15 +616,46 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WGeo g) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_flat_slab_sum(const float* __restrict__ slabs,
-                                                       float* __restrict__ out, int64_t n,
-                                                       int splits) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t step = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += step) {
-    float v = slabs[i];
-    for (int s = 1; s < splits; s++) v += slabs[(int64_t)s * n + i];
-    out[i] = v;
+// out[i] = sum_s slabs[s][i], summed in a fixed order.  A block owns 256 consecutive elements
+// (64 lanes x float4); its 16 waves take the slabs s = w, w+16, ... with 8 loads in flight,
+// and the 16 partials are combined through LDS.
+__global__ __launch_bounds__(1024) void k_flat_slab_sum(const float* __restrict__ slabs,
+                                                        float* __restrict__ out, int64_t n,
+                                                        int splits) {
+  __shared__ float4 part[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t i = ((int64_t)blockIdx.x * 64 + lane) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((n & 3) == 0 && i + 3 < n) {
+    for (int s0 = w; s0 < splits; s0 += 16 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int s = s0 + 16 * u;
+        v[u] = *reinterpret_cast<const float4*>(slabs + (int64_t)(s < splits ? s : 0) * n + i);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (s0 + 16 * u < splits) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+  } else {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 4; e++)
+      if (i + e < n)
+        for (int s = w; s < splits; s += 16) t[e] += slabs[(int64_t)s * n + i + e];
+    acc = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  part[w][lane] = acc;
+  __syncthreads();
+  if (w == 0) {
+    float4 r = part[0][lane];
+    for (int k = 1; k < 16; k++) {
+      float4 q = part[k][lane];
+      r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+    }
+    float t[4] = {r.x, r.y, r.z, r.w};
+    for (int e = 0; e < 4; e++)
+      if (i + e < n) out[i + e] = t[e];
   }
 }
 
@@ -451,7 +694,97 @@ int check_conv_args(const char* name, int N, int C, int H, int W, int O, int k, 
 
 constexpr size_t kLdsBudget = 64 * 1024;  // keeps two workgroups resident per CU
 
+template <int KS, int MODE>
+int launch_igemm_ws(const Geo& g, dim3 grid, size_t lds) {
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv_igemm_ws<KS, MODE>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)std::max(lds, (size_t)65536)));
+    attr_lds = std::max(lds, (size_t)65536);
+  }
+  hipLaunchKernelGGL((k_conv_igemm_ws<KS, MODE>), grid, dim3(512), lds, stream(), g);
+  return DFHIP_OK;
+}
+
+int finish_slabs(const Geo& g, int splits, float* final_dst, const float* bias, int64_t out_elems) {
+  if (splits > 1) {
+    int nb = (int)std::min<int64_t>(df_ceil_div(out_elems, 256), (int64_t)num_cus() * 8);
+    hipLaunchKernelGGL(k_conv_slab_sum, dim3(nb), dim3(256), 0, stream(), g.dst, bias, final_dst,
+                       out_elems, splits, (int64_t)g.HD * g.WD, g.CD);
+    DF_LAUNCH_CHECK();
+  }
+  return DFHIP_OK;
+}
+
+// producer-consumer kernel; returns -1 when the shape is not eligible
+int run_igemm_ws(Geo g, int dest_channels, float* final_dst, const float* bias) {
+  if (g.CS % 8 != 0 || !(g.k == 1 || g.k == 3 || g.k == 5)) return -1;
+  {
+    const char* e = getenv("DFHIP_CONV_DBG");
+    g.dbg = e ? atoi(e) : 0;
+  }
+  const int k2 = g.k * g.k;
+  int gi;
+  plan_groups(g.N, g.HD, g.WD, kTP, g.BI, g.BR, g.BC, gi, g.gr, g.gc);
+  g.PR = (g.BR - 1) * g.so + g.k;
+  g.PC = (g.BC - 1) * g.so + g.k;
+  g.PE = g.BI * g.PR * g.PC;
+  auto lds_for = [&](int ccp) {
+    size_t xs = (size_t)ccp * g.PE + 64, ws = (size_t)k2 * (ccp + 1) * 33 + 8 * 33;
+    return (2 * (xs + ws) + (size_t)g.PE) * 4;
+  };
+  int ccp = 0;
+  for (int c : {32, 16, 8})
+    if (g.CS % c == 0 && lds_for(c) <= 76 * 1024) { ccp = c; break; }
+  if (!ccp) {
+    if (lds_for(8) > 150 * 1024) return -1;
+    ccp = 8;
+  }
+  // prefer at least two chunks per block so staging overlaps the matrix cores
+  if (ccp > 8 && g.CS / ccp < 2) ccp /= 2;
+  g.CC = ccp;
+  const int pixel_blocks = gi * g.gr * g.gc;
+  const int dtiles = (int)df_ceil_div(dest_channels, 32);
+  const int chunks = g.CS / ccp;
+  int64_t blocks = (int64_t)pixel_blocks * dtiles;
+  int splits = 1;
+  int64_t target = (int64_t)num_cus() * 2;
+  if (blocks < target) splits = (int)std::min<int64_t>(chunks, df_ceil_div(target, blocks));
+  while (chunks % splits) splits--;      // equal, whole chunks per split
+  g.cs_per_split = (chunks / splits) * ccp;
+  const int64_t out_elems = (int64_t)g.N * g.CD * g.HD * g.WD;
+  g.slab_stride = 0;
+  g.dst = final_dst;
+  g.bias = bias;
+  if (splits > 1) {
+    float* ws = workspace((size_t)out_elems * splits * sizeof(float));
+    if (!ws) return DFHIP_OUT_OF_MEMORY;
+    g.dst = ws;
+    g.slab_stride = out_elems;
+    g.bias = nullptr;
+  }
+  size_t lds = lds_for(ccp);
+  dim3 grid((unsigned)pixel_blocks, (unsigned)dtiles, (unsigned)splits);
+  int st = DFHIP_OK;
+#define DF_WS(KSV)                                                        \
+  (g.mode == 0 ? launch_igemm_ws<KSV, 0>(g, grid, lds)                    \
+               : (g.mode == 1 ? launch_igemm_ws<KSV, 1>(g, grid, lds)     \
+                              : launch_igemm_ws<KSV, 2>(g, grid, lds)))
+  if (g.k == 1) st = DF_WS(1);
+  else if (g.k == 3) st = DF_WS(3);
+  else st = DF_WS(5);
+#undef DF_WS
+  if (st != DFHIP_OK) return st;
+  DF_LAUNCH_CHECK();
+  return finish_slabs(g, splits, final_dst, bias, out_elems);
+}
+
 int run_igemm(Geo g, int dest_channels, float* final_dst, const float* bias) {
+  {
+    int st = run_igemm_ws(g, dest_channels, final_dst, bias);
+    if (st >= 0) return st;
+  }
   const int k2 = g.k * g.k;
   int gi;
   plan_groups(g.N, g.HD, g.WD, kTP, g.BI, g.BR, g.BC, gi, g.gr, g.gc);
@@ -498,13 +831,7 @@ int run_igemm(Geo g, int dest_channels, float* final_dst, const float* bias) {
   dim3 grid((unsigned)pixel_blocks, (unsigned)dtiles, (unsigned)splits);
   hipLaunchKernelGGL(k_conv_igemm, grid, dim3(256), lds, stream(), g);
   DF_LAUNCH_CHECK();
-  if (splits > 1) {
-    int nb = (int)std::min<int64_t>(df_ceil_div(out_elems, 256), (int64_t)num_cus() * 8);
-    hipLaunchKernelGGL(k_conv_slab_sum, dim3(nb), dim3(256), 0, stream(), g.dst, bias, final_dst,
-                       out_elems, splits, (int64_t)g.HD * g.WD, g.CD);
-    DF_LAUNCH_CHECK();
-  }
-  return DFHIP_OK;
+  return finish_slabs(g, splits, final_dst, bias, out_elems);
 }
 
 template <int OT, int KT>
@@ -539,8 +866,8 @@ int launch_wgrad(WGeo g, float* dw) {
   hipLaunchKernelGGL((k_conv_wgrad<OT, KT>), grid, dim3(256), lds, stream(), g);
   DF_LAUNCH_CHECK();
   if (gx > 1) {
-    int nb = (int)std::min<int64_t>(df_ceil_div(n, 256), (int64_t)num_cus() * 8);
-    hipLaunchKernelGGL(k_flat_slab_sum, dim3(nb), dim3(256), 0, stream(), slabs, dw, n, gx);
+    hipLaunchKernelGGL(k_flat_slab_sum, dim3((unsigned)df_ceil_div(n, 256)), dim3(1024), 0, stream(), slabs,
+                       dw, n, gx);
     DF_LAUNCH_CHECK();
   }
   return DFHIP_OK;

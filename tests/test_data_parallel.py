@@ -1,0 +1,102 @@
+"""CPU, world_size 2 over gloo: the gradient bucket (pack -> all-reduce(sum) -> views) and the
+1/world averaging inside the optimizer reproduce single-process training on the concatenated
+batch gradient average."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import ROOT
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["DF_ROOT"])
+import torch.distributed as dist
+from deepflows_amd import backend_api, nn, optim, parallel, workloads
+from deepflows_amd.tensor import Graph, Tensor
+from oracle.numpy_device import NumpyDevice
+
+dev = backend_api.register_device("cpu", NumpyDevice())
+backend_api.set_default_device("cpu")
+comm = parallel.init_communicator(dev)
+rank, world = comm.rank, comm.world
+np.random.seed(0)
+model = workloads.MLP((12, 16, 4), device=dev)
+opt = optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4)
+bucket = parallel.GradientBucket(opt.params, comm)
+opt.grad_scale = 1.0 / world
+rng = np.random.default_rng(100 + rank)
+losses = []
+for step in range(3):
+    x = rng.standard_normal((8, 12)).astype(np.float32)
+    y = np.eye(4, dtype=np.float32)[rng.integers(0, 4, 8)]
+    loss, _ = workloads.train_step(model, nn.CrossEntropyLoss(), opt, Tensor(x, device=dev), Tensor(y, device=dev),
+                                   sync=bucket.sync if world > 1 else None)
+    losses.append(float(loss.numpy()[0]))
+    Graph.free_graph()
+out = {"rank": rank, "losses": losses, "params": [p.data.numpy().tolist() for p in model.parameters()]}
+json.dump(out, open(os.path.join(os.environ["DF_OUT"], f"rank{rank}.json"), "w"))
+comm.barrier()
+'''
+
+
+def _reference_single_process():
+    """world=1 math: average of the two ranks' gradients applied by one Adam."""
+    sys.path.insert(0, ROOT)
+    from deepflows_amd import backend_api, nn, optim, workloads
+    from deepflows_amd.tensor import Graph, Tensor
+    from oracle.numpy_device import NumpyDevice
+    dev = backend_api.register_device("cpu", NumpyDevice())
+    try:
+        np.random.seed(0)
+        model = workloads.MLP((12, 16, 4), device=dev)
+        opt = optim.Adam(model.parameters(), lr=1e-2, weight_decay=5e-4)
+        rngs = [np.random.default_rng(100 + r) for r in range(2)]
+        for step in range(3):
+            grads = None
+            for rng in rngs:
+                x = rng.standard_normal((8, 12)).astype(np.float32)
+                y = np.eye(4, dtype=np.float32)[rng.integers(0, 4, 8)]
+                loss = nn.CrossEntropyLoss()(model(Tensor(x, device=dev)), Tensor(y, device=dev))
+                opt.zero_grad()
+                loss.backward()
+                g = [p.grad.numpy().copy() for p in model.parameters()]
+                grads = g if grads is None else [a + b for a, b in zip(grads, g)]
+                Graph.free_graph()
+            for p, g in zip(model.parameters(), grads):
+                p.grad = backend_api.Btensor((g * np.float32(0.5)).astype(np.float32), device=dev)
+            opt.step()
+        return [p.data.numpy() for p in model.parameters()]
+    finally:
+        backend_api.unregister_device("cpu")
+
+
+def test_world2_gloo_matches_averaged_gradients(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, DF_ROOT=ROOT, DF_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1")
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    outs = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(2)]
+    # replicas stay identical
+    for a, b in zip(outs[0]["params"], outs[1]["params"]):
+        assert np.array_equal(np.array(a), np.array(b))
+    want = _reference_single_process()
+    for a, w in zip(outs[0]["params"], want):
+        a = np.array(a, dtype=np.float32)
+        assert np.abs(a - w).max() <= 1e-5 * max(1.0, np.abs(w).max())
+
+
+def test_world1_bucket_is_a_noop():
+    sys.path.insert(0, ROOT)
+    from deepflows_amd import parallel
+    comm = parallel.LocalCommunicator()
+    b = parallel.GradientBucket([], comm)
+    assert b.flat is None
+    b.sync()

@@ -1,0 +1,114 @@
+"""CPU: host logic of the front-end mirror (views, broadcasting, registration quirks, schedulers)
+on the oracle device."""
+import math
+
+import numpy as np
+import pytest
+
+from deepflows_amd import backend_api, nn, optim, tensor, workloads
+from deepflows_amd.backend import BackendTensor
+from deepflows_amd.tensor import Graph, Tensor
+
+
+def test_views_never_copy_and_compact_materialises(cpu_oracle):
+    a = BackendTensor(np.arange(24, dtype=np.float32).reshape(2, 3, 4), device=cpu_oracle)
+    p = a.permute((2, 0, 1))
+    assert p._handle is a._handle and not p.is_compact()
+    assert np.array_equal(p.numpy(), np.arange(24).reshape(2, 3, 4).transpose(2, 0, 1))
+    c = p.compact()
+    assert c.is_compact() and c._handle is not a._handle
+    s = a[0:2, 1:3, 0:4:2]
+    assert s.shape == (2, 2, 2) and np.array_equal(s.numpy(), np.arange(24).reshape(2, 3, 4)[:, 1:3, ::2])
+    # a contiguous slice of a larger buffer is NOT compact (handle.size differs)
+    assert not a[0:1, 0:3, 0:4].is_compact()
+    with pytest.raises(ValueError):
+        p.reshape((24,))
+    assert a.reshape((-1, 4)).shape == (6, 4) and a.reshape((6, -1)).shape == (6, 4)
+
+
+def test_only_other_is_broadcast(cpu_oracle):
+    x = BackendTensor(np.ones((2, 3), np.float32), device=cpu_oracle)
+    b = BackendTensor(np.arange(3, dtype=np.float32).reshape(1, 3), device=cpu_oracle)
+    assert np.array_equal((x + b).numpy(), np.ones((2, 3)) + np.arange(3))
+    with pytest.raises(AssertionError):
+        b + x                                    # self is never broadcast (backend_tensor.py:533-542)
+
+
+def test_mean_divides_by_total_count(cpu_oracle):
+    a = BackendTensor(np.arange(24, dtype=np.float32).reshape(2, 3, 2, 2), device=cpu_oracle)
+    m = a.mean(axis=2)
+    assert np.allclose(m.numpy(), np.arange(24).reshape(2, 3, 2, 2).sum(2) / 24.0)
+
+
+def test_setitem_scatters_into_the_view(cpu_oracle):
+    a = backend_api.zeros((3, 4), device=cpu_oracle)
+    a[1:3, 1:3] = BackendTensor(np.array([[1, 2], [3, 4]], np.float32), device=cpu_oracle)
+    want = np.zeros((3, 4), np.float32)
+    want[1:3, 1:3] = [[1, 2], [3, 4]]
+    assert np.array_equal(a.numpy(), want)
+
+
+def test_plain_lists_are_not_registered(cpu_oracle):
+    np.random.seed(0)
+    ref_style = workloads.ResNet18(10, device=cpu_oracle, register_blocks=False)
+    full = workloads.ResNet18(10, device=cpu_oracle, register_blocks=True)
+    p5 = list(ref_style.parameters())
+    assert len(p5) == 5 and sum(p.size for p in p5) == 3498
+    p62 = list(full.parameters())
+    assert len(p62) == 62 and sum(p.size for p in p62) == 2797610
+    assert len(workloads.all_block_parameters(ref_style)) == 62
+
+
+def test_train_eval_toggle_global_grad_flag(cpu_oracle):
+    from deepflows_amd.autograd import is_grad_enable
+    m = nn.Linear(3, 2, device=cpu_oracle)
+    m.eval()
+    assert not is_grad_enable()
+    y = m(Tensor(np.ones((1, 3), np.float32), device=cpu_oracle))
+    assert not y.requires_grad and y not in Graph.node_list
+    m.train()
+    assert is_grad_enable()
+
+
+def test_backward_only_from_1d_and_free_graph_keeps_leaves(cpu_oracle):
+    w = Tensor(np.ones((2, 2), np.float32), device=cpu_oracle, requires_grad=True)
+    y = w * 2.0
+    with pytest.raises(ValueError):
+        y.backward()
+    loss = tensor.sum(y)
+    loss.backward()
+    assert np.array_equal(w.grad.numpy(), np.full((2, 2), 2.0, np.float32))
+    assert Graph.node_list == [w]
+
+
+def test_schedulers_match_closed_forms(cpu_oracle):
+    class Opt:
+        lr = 0.1
+    o = Opt()
+    s = optim.WarmupCosineLR(o, warmup_epochs=5, T_max=20, eta_min=1e-5)
+    lrs = []
+    for _ in range(8):
+        s.step()
+        lrs.append(o.lr)
+    assert lrs[0] == 0.0 and abs(lrs[5] - 0.1) < 1e-12
+    t = 1
+    assert abs(lrs[6] - (1e-5 + (0.1 - 1e-5) * (1 + math.cos(math.pi * t / 20)) / 2)) < 1e-12
+    o2 = Opt()
+    s2 = optim.StepLR(o2, step_size=2, gamma=0.5)
+    out = []
+    for _ in range(5):
+        s2.step()
+        out.append(o2.lr)
+    assert out == [0.1, 0.1, 0.05, 0.05, 0.025]
+
+
+def test_state_dict_roundtrip_excludes_bn_running_stats(cpu_oracle):
+    np.random.seed(1)
+    m = workloads.CIFAR10_CNN(10, device=cpu_oracle)
+    sd = m.state_dict()
+    assert "bn1.weight" in sd and "bn1.running_mean" not in sd     # plain attributes in the reference
+    np.random.seed(2)
+    m2 = workloads.CIFAR10_CNN(10, device=cpu_oracle)
+    m2.load_state_dict({k: v.numpy() for k, v in sd.items()})
+    for k, v in m2.state_dict().items():
+        assert np.array_equal(v.numpy(), sd[k].numpy()), k
