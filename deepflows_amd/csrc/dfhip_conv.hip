@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "dfhip_internal.h"
 
@@ -56,7 +57,9 @@ struct Geo {
   int wC;                  // C of the (O,C,k,k) weight tensor
   int pad, stride, oh, ow; // conv geometry (for the overwrite tap selection)
   int64_t slab_stride;
-  int dbg;                 // debug: 1 skip staging, 2 skip compute, 4 skip epilogue, 8 skip goff
+  int PT;                  // v3: 32-pixel tiles per workgroup (8 / PT k-split slices)
+  unsigned long long* stamps;  // diagnostic builds only (DFHIP_CONV_STAMP): per-block time stamps
+  int dbg;                     // diagnostics: 1 = loaders idle in the main loop, 2 = no MFMAs
 };
 
 __device__ __forceinline__ void decode_pixel(const Geo& g, int q, int& img, int& r, int& col) {
@@ -225,28 +228,169 @@ __global__ __launch_bounds__(256) void k_conv_igemm(Geo g) {
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// forward / input-gradient, producer-consumer form (source channels % 8 == 0):
-//   * 512-thread workgroup: waves 0-3 run the matrix cores (one 32-pixel x 32-channel tile
-//     each), waves 4-7 stage the NEXT channel chunk (patch + weights) into the other LDS buffer
-//     while they do, one barrier per chunk.  The MFMA pipe of a SIMD is fed by its compute
-//     wave, its loader wave only issues VMEM / LDS / address arithmetic;
-//   * K is ordered (tap, channel): inside a tap the operand addresses advance by constants
-//     (2*PE and 2*WLD floats per k pair), so the inner loop is ds_read + MFMA only, unrolled
-//     by four k pairs with the next group's reads issued ahead of the current MFMAs;
-//   * overwrite mode: a tap that no lane of the wave selects contributes exact zeros and is
-//     skipped (wave-uniform branch) - for a 3x3 stride-1 layer that leaves one tap in nine
-//     for interior tiles.
-// ---------------------------------------------------------------------------------------
+// ---- staging helpers of the producer-consumer kernel ------------------------------------
+// Staging is split into ISSUE (global loads into registers) and COMMIT (LDS stores) so that the
+// loads of chunk c+2 are in flight while chunk c is in the matrix cores: a loader thread keeps up
+// to 2 x 16 patch elements and 10 float4 weight vectors outstanding across a barrier.
+constexpr int kMaxItems = 2;   // patch items (4 channels x 4 slices of 64 elements) per loader wave
+constexpr int kWU = 10;        // float4 weight vectors per loader thread
+
+struct PatchRegs {
+  int go[kMaxItems][4];
+  float v[kMaxItems][4][4];
+};
+struct WeightRegs {
+  float4 v[kWU];
+};
+
+__device__ __forceinline__ void patch_issue(const Geo& g, const float* __restrict__ src_base,
+                                            const int* __restrict__ goff, int CCP, int64_t plane,
+                                            int nthreads, int t0, PatchRegs& R) {
+  const int nw = nthreads >> 6, w0 = t0 >> 6, ln = t0 & 63;
+  const int nsg = (g.PE + 255) >> 8;
+  const int nitems = nsg * (CCP >> 2);
+#pragma unroll
+  for (int it = 0; it < kMaxItems; it++) {
+    const int item = w0 + it * nw;
+    const bool live = item < nitems;
+    const int cg = live ? item / nsg : 0, sg = live ? item - cg * nsg : 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int j = (sg * 4 + u) * 64 + ln;
+      R.go[it][u] = (live && j < g.PE) ? goff[j] : -1;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) {
+      const float* base = src_base + (int64_t)(cg * 4 + cc) * plane;
+#pragma unroll
+      for (int u = 0; u < 4; u++) R.v[it][cc][u] = base[R.go[it][u] >= 0 ? R.go[it][u] : 0];
+    }
+  }
+}
+
+__device__ __forceinline__ void patch_commit(const Geo& g, float* __restrict__ Xs, int CCP,
+                                             int nthreads, int t0, const PatchRegs& R) {
+  const int nw = nthreads >> 6, w0 = t0 >> 6, ln = t0 & 63;
+  const int nsg = (g.PE + 255) >> 8;
+  const int nitems = nsg * (CCP >> 2);
+#pragma unroll
+  for (int it = 0; it < kMaxItems; it++) {
+    const int item = w0 + it * nw;
+    if (item < nitems) {
+      const int cg = item / nsg, sg = item - cg * nsg;
+#pragma unroll
+      for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          int j = (sg * 4 + u) * 64 + ln;
+          if (j < g.PE) Xs[(cg * 4 + cc) * g.PE + j] = R.go[it][u] >= 0 ? R.v[it][cc][u] : 0.0f;
+        }
+    }
+  }
+}
+
+// Weights of one channel chunk keep their GLOBAL order in LDS, so a commit is a plain float4
+// store with no per-element decode:
+//   forward (MODE 0): W[d0+d][cb+c][t]  -> Wl[d * RS + c*k2 + t],  RS = CCP*k2 + 4
+//            (lanes of the A-operand read run along d: row stride = 4 mod 32 -> 4-way bank
+//            conflict on one ds_read_b32 per two MFMAs, far below the LDS budget)
+//   dgrad   (MODE 1): W[cb+c][d0+d][t]  -> Wl[c * 32*k2 + d*k2 + t]
+//            (lanes run along d with stride k2, odd -> conflict-free)
+// Rows start 16-byte aligned in global memory (channel counts are multiples of 8).
 template <int KS, int MODE>
-__global__ __launch_bounds__(512, 4) void k_conv_igemm_ws(Geo g) {
+__device__ __forceinline__ int wl_row_stride(int CCP) {
+  return MODE == 0 ? CCP * KS * KS + 4 : 32 * KS * KS;
+}
+
+template <int KS, int MODE>
+__device__ __forceinline__ void weights_issue(const Geo& g, int CCP, int cb, int d0, int nthreads,
+                                              int t0, WeightRegs& R) {
+  constexpr int k2 = KS * KS;
+  const int run4 = (MODE == 0 ? CCP * k2 : 32 * k2) >> 2;
+  const int nrows = MODE == 0 ? 32 : CCP;
+  const int total4 = run4 * nrows;
+  const int dmax = min(32, g.CD - d0);
+  const int dr = nthreads / run4, de = nthreads - dr * run4;
+  int f = t0 < total4 ? t0 : t0 % total4;
+  int row = f / run4, e4 = f - row * run4;
+#pragma unroll
+  for (int u = 0; u < kWU; u++) {
+    int64_t src;
+    if (MODE == 0) {
+      int d = row < dmax ? row : 0;
+      src = ((int64_t)(d0 + d) * g.wC + cb) * k2 + 4 * e4;
+    } else {
+      int e = 4 * e4;
+      e = e + 3 < dmax * k2 ? e : 0;
+      src = ((int64_t)(cb + row) * g.wC + d0) * k2 + e;
+    }
+    R.v[u] = *reinterpret_cast<const float4*>(g.wgt + src);
+    // next vector of this thread (f += nthreads), wrapping dead slots onto live vectors
+    row += dr;
+    e4 += de;
+    if (e4 >= run4) { e4 -= run4; row++; }
+    if (row >= nrows) row -= nrows * (row / nrows);
+  }
+}
+
+template <int KS, int MODE>
+__device__ __forceinline__ void weights_commit(const Geo& g, float* __restrict__ Wl, int CCP, int d0,
+                                               int nthreads, int t0, const WeightRegs& R) {
+  constexpr int k2 = KS * KS;
+  const int run4 = (MODE == 0 ? CCP * k2 : 32 * k2) >> 2;
+  const int nrows = MODE == 0 ? 32 : CCP;
+  const int total4 = run4 * nrows;
+  const int RS = wl_row_stride<KS, MODE>(CCP);
+  const int dmax = min(32, g.CD - d0);
+  const int dr = nthreads / run4, de = nthreads - dr * run4;
+  int row = t0 / run4, e4 = t0 - row * run4;
+#pragma unroll
+  for (int u = 0; u < kWU; u++) {
+    if (t0 + nthreads * u < total4) {
+      float4 v = R.v[u];
+      if (MODE == 0) {
+        if (row >= dmax) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (dmax < 32) {          // partial destination tile: zero the channels that do not exist
+        float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++)
+          if ((4 * e4 + qd) / k2 >= dmax || 4 * e4 + 3 >= dmax * k2) vv[qd] = 0.0f;
+        v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      }
+      *reinterpret_cast<float4*>(Wl + row * RS + 4 * e4) = v;
+    }
+    row += dr;
+    e4 += de;
+    if (e4 >= run4) { e4 -= run4; row++; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward / input-gradient, producer-consumer form (source channels % 8 == 0, k in {1,3,5}).
+//
+// One workgroup = one job = (pixel group of PT 32-pixel tiles) x (32 destination channels) over
+// the WHOLE reduction; 12 waves:
+//   waves 0-7  matrix-core waves, two per SIMD so one wave's LDS wait hides behind the other's
+//              MFMAs.  Wave w owns pixel tile  w % PT  and the k-split slice  w / PT  (KSPLIT =
+//              8 / PT slices of every channel chunk); the KSPLIT partial accumulators of a tile
+//              are summed through LDS at the end - no partial slabs in HBM, no second kernel;
+//   waves 8-11 loaders: stage the NEXT channel chunk (patch through the gather table, weights
+//              transposed to [tap][channel][dest]) into the other LDS buffer, all global loads
+//              of a thread issued before its first LDS store; one barrier per chunk.
+// The host picks PT in {8,4,2,1} so that every ResNet-18 layer at batch 256 becomes ~256 jobs
+// (one per CU) of equal matrix-core work: 144 MFMAs per wave.
+// K is ordered (tap, channel): inside a tap the operand addresses advance by constants.
+// Overwrite mode: a tap that no lane of the wave selects contributes exact zeros and is skipped.
+// ---------------------------------------------------------------------------------------
+template <int KS, int MODE, int NPK, int NTW>
+__global__ __launch_bounds__(512) void k_conv_igemm_v3(Geo g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int k = KS, k2 = KS * KS;
-  constexpr int WLD = 33;
-  const int CCP = g.CC;                 // channels per chunk, multiple of 8
-  const int CCQ = CCP + 1;              // weight rows per tap (+1: spreads the staging writes over banks)
-  const int xs_floats = CCP * g.PE + 64;          // +64: the last prefetch group reads past the chunk
-  const int ws_floats = k2 * CCQ * WLD + 8 * WLD;
+  constexpr int WM = MODE == 0 ? 0 : 1;
+  const int CCP = g.CC;                 // channels per chunk: 8, 16 or 32
+  const int RS = wl_row_stride<KS, WM>(CCP);
+  const int xs_floats = CCP * g.PE;
+  const int ws_floats = (MODE == 0 ? 32 : CCP) * RS;
   float* Xs0 = smem;
   float* Ws0 = Xs0 + 2 * xs_floats;
   int* goff = (int*)(Ws0 + 2 * ws_floats);
@@ -254,18 +398,30 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm_ws(Geo g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const bool loader = wave >= 4;
+  int stamp_i = 0;
+#define DF_STAMP()                                                                              \
+  do {                                                                                          \
+    if (g.stamps && lane == 0 && (wave == 0 || wave == 4) && stamp_i < 30)                      \
+      g.stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave == 4)) * 32 + stamp_i++] = \
+          __builtin_readcyclecounter();                                                         \
+  } while (0)
+  DF_STAMP();
+  // PT 32-pixel tiles per workgroup; a matrix-core wave owns NTW of them (two when PT >= 2, so
+  // the weight operand is read once for two MFMAs) and one of the KSPLIT slices of every chunk
+  const int PT = g.PT;
+  const int tgroups = PT / NTW;         // wave groups along the pixel tiles
+  const int KSPLIT = 4 / tgroups;
+  const int tw = (wave & 3) % tgroups, ks = (wave & 3) / tgroups;
 
   int gx = blockIdx.x;
   const int gcx = gx % g.gc; gx /= g.gc;
   const int grx = gx % g.gr; gx /= g.gr;
   const int n0 = gx * g.BI, r0 = grx * g.BR, c0 = gcx * g.BC;
   const int d0 = blockIdx.y * 32;
-  const int cs_beg = blockIdx.z * g.cs_per_split;
-  const int cs_end = min(g.CS, cs_beg + g.cs_per_split);
-  const int nchunks = (cs_end - cs_beg) / CCP;
+  const int nchunks = g.CS / CCP;
   const int64_t src_plane = (int64_t)g.HS * g.WS;
 
-  for (int j = tid; j < ((g.dbg & 8) ? 0 : g.PE); j += 512) {
+  for (int j = tid; j < g.PE; j += 512) {
     int per_img = g.PR * g.PC;
     int img = j / per_img;
     int rem = j - img * per_img;
@@ -277,161 +433,186 @@ __global__ __launch_bounds__(512, 4) void k_conv_igemm_ws(Geo g) {
     goff[j] = ok ? (int)((int64_t)img * g.CS * src_plane + (int64_t)su * g.WS + sv) : -1;
   }
 
-  // compute waves: this wave's 32-pixel tile
-  int q = (wave & 3) * 32 + l31, img, r, col;
-  decode_pixel(g, q, img, r, col);
-  const bool pvalid = q < g.BI * g.BR * g.BC && n0 + img < g.N && r0 + r < g.HD && c0 + col < g.WD;
-  const int abase = (pvalid ? img * g.PR * g.PC + r * g.so * g.PC + col * g.so : 0) + half * g.PE;
-  int tapsel = -2;
-  if (MODE == 2 && pvalid) {
-    int ti = last_tap(r0 + r + g.pad, k, g.stride, g.oh);
-    int tj = last_tap(c0 + col + g.pad, k, g.stride, g.ow);
-    tapsel = (ti < 0 || tj < 0) ? -1 : ti * k + tj;
+  // the wave's pixel tiles
+  int abase[2], tapsel[2];
+  bool pvalid[2];
+  int64_t out_off[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    int q = (tw * NTW + e) * 32 + l31, img, r, col;
+    decode_pixel(g, q, img, r, col);
+    pvalid[e] = e < NTW && q < g.BI * g.BR * g.BC && n0 + img < g.N && r0 + r < g.HD && c0 + col < g.WD;
+    abase[e] = (pvalid[e] ? img * g.PR * g.PC + r * g.so * g.PC + col * g.so : 0) + half * g.PE;
+    tapsel[e] = -2;
+    if (MODE == 2 && pvalid[e]) {
+      int ti = last_tap(r0 + r + g.pad, k, g.stride, g.oh);
+      int tj = last_tap(c0 + col + g.pad, k, g.stride, g.ow);
+      tapsel[e] = (ti < 0 || tj < 0) ? -1 : ti * k + tj;
+    }
+    out_off[e] = (int64_t)(n0 + img) * g.CD * g.HD * g.WD + (int64_t)(r0 + r) * g.WD + (c0 + col);
   }
 
-  auto stage = [&](int chunk, int buf, int nthreads, int t0) {
-    // called by `nthreads` threads whose local index is t0 (all 512 in the prologue, the 256
-    // loader threads in the main loop)
-    const int cb = cs_beg + chunk * CCP;
-    float* Xs = Xs0 + buf * xs_floats;
-    float* Ws = Ws0 + buf * ws_floats;
-    const int nw = nthreads >> 6, w0 = t0 >> 6, ln = t0 & 63;
-    // Patch: the gather offsets of 4 consecutive 64-element slices are read once and used for
-    // a group of 4 channels: 16 independent global loads in flight per thread, no branches
-    // (out-of-image elements load offset 0 and are zeroed by a select).
-    for (int cg = w0 * 4; cg < CCP; cg += nw * 4) {
-      const float* base = g.src + ((int64_t)n0 * g.CS + cb + cg) * src_plane;
-      float* xs = Xs + (size_t)cg * g.PE;
-      for (int j0 = ln; j0 < g.PE; j0 += 256) {
-        int go[4];
-        float v[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          int j = j0 + 64 * u;
-          go[u] = j < g.PE ? goff[j] : -1;
-        }
-#pragma unroll
-        for (int cc = 0; cc < 4; cc++)
-#pragma unroll
-          for (int u = 0; u < 4; u++) v[cc][u] = base[(int64_t)cc * src_plane + (go[u] >= 0 ? go[u] : 0)];
-#pragma unroll
-        for (int cc = 0; cc < 4; cc++)
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            int j = j0 + 64 * u;
-            if (j < g.PE) xs[cc * g.PE + j] = go[u] >= 0 ? v[cc][u] : 0.0f;
-          }
-      }
-    }
-    // Weights: 32*CCP*k2 elements per chunk, flat index f -> (row, e) with the lanes running
-    // along the contiguous global dimension; all of a thread's loads are issued before the
-    // first LDS store.
-    {
-      const int run = MODE == 0 ? CCP * k2 : 32 * k2;      // contiguous floats per row
-      const int nrows = MODE == 0 ? 32 : CCP;               // rows: d (forward) or c (dgrad)
-      const int total = run * nrows;
-      const int dmax = g.CD - d0;
-      constexpr int U = 6;
-      for (int f0 = t0; f0 < total; f0 += nthreads * U) {
-        float v[U];
-        int row[U], e[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          int f = f0 + nthreads * u;
-          f = f < total ? f : 0;
-          row[u] = f / run;
-          e[u] = f - row[u] * run;
-          int64_t src;
-          bool ok;
-          if (MODE == 0) {
-            ok = row[u] < dmax;
-            src = ((int64_t)(d0 + (ok ? row[u] : 0)) * g.wC + cb) * k2 + e[u];
-          } else {
-            ok = e[u] / k2 < dmax;
-            src = ((int64_t)(cb + row[u]) * g.wC + d0) * k2 + (ok ? e[u] : 0);
-          }
-          v[u] = g.wgt[src];
-          if (!ok) v[u] = 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          if (f0 + nthreads * u < total) {
-            int c, t, d;
-            if (MODE == 0) { d = row[u]; c = e[u] / k2; t = e[u] - c * k2; }
-            else { c = row[u]; d = e[u] / k2; t = e[u] - d * k2; }
-            Ws[(t * CCQ + c) * WLD + d] = v[u];
-          }
-        }
-      }
-    }
+  PatchRegs pregs;
+  WeightRegs wregs;
+  auto issue = [&](int chunk, int nthreads, int t0) {
+    const int cb = chunk * CCP;
+    weights_issue<KS, WM>(g, CCP, cb, d0, nthreads, t0, wregs);
+    patch_issue(g, g.src + ((int64_t)n0 * g.CS + cb) * src_plane, goff, CCP, src_plane, nthreads, t0, pregs);
+  };
+  auto commit = [&](int buf, int nthreads, int t0) {
+    patch_commit(g, Xs0 + buf * xs_floats, CCP, nthreads, t0, pregs);
+    weights_commit<KS, WM>(g, Ws0 + buf * ws_floats, CCP, d0, nthreads, t0, wregs);
   };
 
-  f32x16 acc;
+  f32x16 acc0, acc1;
 #pragma unroll
-  for (int rr = 0; rr < 16; rr++) acc[rr] = 0.0f;
+  for (int rr = 0; rr < 16; rr++) { acc0[rr] = 0.0f; acc1[rr] = 0.0f; }
 
+  DF_STAMP();
   __syncthreads();                      // goff ready
-  if (nchunks > 0 && !(g.dbg & 1)) stage(0, 0, 512, tid);
+  DF_STAMP();
+  // prologue: every wave helps with chunk 0, then the loaders put chunk 1 in flight
+  issue(0, 512, tid);
+  commit(0, 512, tid);
+  DF_STAMP();
+  if (loader) {
+    __builtin_amdgcn_s_setprio(1);      // few instructions, but each gates a chunk
+    if (nchunks > 1) issue(1, 256, tid - 256);
+  }
   __syncthreads();
+  DF_STAMP();
 
+  // k pairs of a tap that this wave owns (>= 1); a compile-time count lets the tap x pair nest
+  // unroll into straight-line code whose LDS reads are hoisted ahead of the MFMAs
+  const int npk = NPK ? NPK : (CCP >> 1) / KSPLIT;
+  const int c_first = 2 * ks * npk;     // first channel of the wave's slice inside a chunk
   for (int ch = 0; ch < nchunks; ch++) {
     const int buf = ch & 1;
     if (loader) {
-      if (ch + 1 < nchunks && !(g.dbg & 1)) stage(ch + 1, buf ^ 1, 256, tid - 256);
+      // chunk ch+1 (loaded during the previous iteration) goes to the buffer the matrix cores
+      // finished with at the last barrier; chunk ch+2 is put in flight for the next iteration
+      if (!(g.dbg & 1)) {
+        if (ch + 1 < nchunks) commit(buf ^ 1, 256, tid - 256);
+        DF_STAMP();
+        if (ch + 2 < nchunks) issue(ch + 2, 256, tid - 256);
+      }
     } else if (!(g.dbg & 2)) {
-      const float* Xs = Xs0 + buf * xs_floats + abase;
-      const float* Ws = Ws0 + buf * ws_floats + half * WLD + l31;
-      const int np = CCP >> 1;          // k pairs per tap, multiple of 4
+      const float* Xb = Xs0 + buf * xs_floats + c_first * g.PE;
+      const float* bq0 = Xb + abase[0];
+      const float* bq1 = Xb + abase[1];
+      // A operand: weights in global order (see wl_row_stride)
+      const float* aq = Ws0 + buf * ws_floats +
+                        (MODE == 0 ? l31 * RS + (c_first + half) * k2 : (c_first + half) * RS + l31 * k2);
+      const int astep = MODE == 0 ? 2 * k2 : 2 * RS;   // per k pair
+      const int bstep = 2 * g.PE;
+      if (NPK > 0 && MODE != 2) {
+        // one flat, fully unrolled sequence over (tap, pair) with the operands of step s+1 read
+        // from LDS before the MFMAs of step s are issued
+        constexpr int NS = k2 * (NPK > 0 ? NPK : 1);
+        auto offB = [&](int sidx) {
+          int t = sidx / (NPK > 0 ? NPK : 1), pp = sidx - t * (NPK > 0 ? NPK : 1);
+          int i = t / k, j = t - i * k;
+          return (MODE == 0 ? i * g.PC + j : (k - 1 - i) * g.PC + (k - 1 - j)) + pp * bstep;
+        };
+        auto offA = [&](int sidx) {
+          int t = sidx / (NPK > 0 ? NPK : 1), pp = sidx - t * (NPK > 0 ? NPK : 1);
+          return t + pp * astep;
+        };
+        float a_c = aq[offA(0)], b0_c = bq0[offB(0)], b1_c = NTW == 2 ? bq1[offB(0)] : 0.0f;
 #pragma unroll
-      for (int t = 0; t < k2; t++) {
-        if (MODE == 2) {
-          if (__ballot(tapsel == t) == 0ull) continue;
+        for (int sidx = 0; sidx < NS; sidx++) {
+          float a_n = a_c, b0_n = b0_c, b1_n = b1_c;
+          if (sidx + 1 < NS) {
+            a_n = aq[offA(sidx + 1)];
+            b0_n = bq0[offB(sidx + 1)];
+            if (NTW == 2) b1_n = bq1[offB(sidx + 1)];
+          }
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b0_c, acc0, 0, 0, 0);
+          if (NTW == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b1_c, acc1, 0, 0, 0);
+          a_c = a_n; b0_c = b0_n; b1_c = b1_n;
         }
-        const int i = t / k, j = t - i * k;
-        const int toff = MODE == 0 ? i * g.PC + j : (k - 1 - i) * g.PC + (k - 1 - j);
-        const float* bp = Xs + toff;
-        const float* ap = Ws + t * CCQ * WLD;
-        const int bstep = 2 * g.PE, astep = 2 * WLD;
-        float a0 = ap[0], a1 = ap[astep], a2 = ap[2 * astep], a3 = ap[3 * astep];
-        float b0 = bp[0], b1 = bp[bstep], b2 = bp[2 * bstep], b3 = bp[3 * bstep];
-        for (int p = 0; p < np; p += 4) {
-          ap += 4 * astep;
-          bp += 4 * bstep;
-          float na0 = 0.f, na1 = 0.f, na2 = 0.f, na3 = 0.f, nb0 = 0.f, nb1 = 0.f, nb2 = 0.f, nb3 = 0.f;
-          if (p + 4 < np) {
-            na0 = ap[0]; na1 = ap[astep]; na2 = ap[2 * astep]; na3 = ap[3 * astep];
-            nb0 = bp[0]; nb1 = bp[bstep]; nb2 = bp[2 * bstep]; nb3 = bp[3 * bstep];
-          }
+      } else {
+#pragma unroll
+        for (int t = 0; t < k2; t++) {
+          bool sel0 = true, sel1 = true;
           if (MODE == 2) {
-            const bool sel = tapsel == t;
-            b0 = sel ? b0 : 0.0f; b1 = sel ? b1 : 0.0f; b2 = sel ? b2 : 0.0f; b3 = sel ? b3 : 0.0f;
+            sel0 = tapsel[0] == t;
+            sel1 = tapsel[1] == t;
+            if (__ballot(sel0 || sel1) == 0ull) continue;
           }
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);
-          a0 = na0; a1 = na1; a2 = na2; a3 = na3;
-          b0 = nb0; b1 = nb1; b2 = nb2; b3 = nb3;
+          const int i = t / k, j = t - i * k;
+          const int toff = MODE == 0 ? i * g.PC + j : (k - 1 - i) * g.PC + (k - 1 - j);
+          const float* bp0 = bq0 + toff;
+          const float* bp1 = bq1 + toff;
+          const float* ap = aq + t;
+#pragma unroll 2
+          for (int p = 0; p < npk; p++) {
+            float a = ap[p * astep];
+            float b0 = bp0[p * bstep];
+            float b1 = NTW == 2 ? bp1[p * bstep] : 0.0f;
+            if (MODE == 2) { b0 = sel0 ? b0 : 0.0f; b1 = sel1 ? b1 : 0.0f; }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            if (NTW == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+          }
+        }
+      }
+    }
+    DF_STAMP();
+    __syncthreads();
+    DF_STAMP();
+  }
+
+  // sum the KSPLIT partial accumulators of every pixel tile through LDS (staging buffers are free)
+  float* red = smem;                    // [PT][KSPLIT-1][16][64]
+  if (KSPLIT > 1) {
+    if (!loader && ks > 0) {
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        if (e < NTW) {
+          float* dstp = red + ((size_t)((tw * NTW + e) * (KSPLIT - 1) + ks - 1) * 16) * 64 + lane;
+#pragma unroll
+          for (int rr = 0; rr < 16; rr++) dstp[rr * 64] = e == 0 ? acc0[rr] : acc1[rr];
         }
       }
     }
     __syncthreads();
-  }
-
-  if (!loader && pvalid && !(g.dbg & 4)) {
-    const int64_t dplane = (int64_t)g.HD * g.WD;
-    float* out = g.dst + (int64_t)blockIdx.z * g.slab_stride +
-                 (int64_t)(n0 + img) * g.CD * dplane + (int64_t)(r0 + r) * g.WD + (c0 + col);
+    if (!loader && ks == 0) {
+      for (int s2 = 0; s2 < KSPLIT - 1; s2++) {
 #pragma unroll
-    for (int rr = 0; rr < 16; rr++) {
-      int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-      if (d < g.CD) {
-        float v = acc[rr];
-        if (g.bias) v += g.bias[d];
-        out[(int64_t)d * dplane] = v;
+        for (int e = 0; e < 2; e++) {
+          if (e < NTW) {
+            const float* srcp = red + ((size_t)((tw * NTW + e) * (KSPLIT - 1) + s2) * 16) * 64 + lane;
+#pragma unroll
+            for (int rr = 0; rr < 16; rr++) {
+              if (e == 0) acc0[rr] += srcp[rr * 64];
+              else acc1[rr] += srcp[rr * 64];
+            }
+          }
+        }
       }
     }
   }
+
+  if (!loader && ks == 0) {
+    const int64_t dplane = (int64_t)g.HD * g.WD;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      if (pvalid[e]) {
+        float* out = g.dst + out_off[e];
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) {
+          int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+          if (d < g.CD) {
+            float v = e == 0 ? acc0[rr] : acc1[rr];
+            if (g.bias) v += g.bias[d];
+            out[(int64_t)d * dplane] = v;
+          }
+        }
+      }
+    }
+  }
+  DF_STAMP();
+#undef DF_STAMP
 }
 
 // out[i] = sum_s slabs[s][i] (+ bias[(i / plane) % CD])
@@ -694,17 +875,31 @@ int check_conv_args(const char* name, int N, int C, int H, int W, int O, int k, 
 
 constexpr size_t kLdsBudget = 64 * 1024;  // keeps two workgroups resident per CU
 
-template <int KS, int MODE>
-int launch_igemm_ws(const Geo& g, dim3 grid, size_t lds) {
+template <int KS, int MODE, int NPK, int NTW>
+int launch_igemm_v3n(const Geo& g, dim3 grid, size_t lds) {
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv_igemm_ws<KS, MODE>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv_igemm_v3<KS, MODE, NPK, NTW>,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)std::max(lds, (size_t)65536)));
     attr_lds = std::max(lds, (size_t)65536);
   }
-  hipLaunchKernelGGL((k_conv_igemm_ws<KS, MODE>), grid, dim3(512), lds, stream(), g);
+  hipLaunchKernelGGL((k_conv_igemm_v3<KS, MODE, NPK, NTW>), grid, dim3(512), lds, stream(), g);
   return DFHIP_OK;
+}
+
+template <int KS, int MODE>
+int launch_igemm_v3(const Geo& g, dim3 grid, size_t lds) {
+  const int ksplit = g.PT >= 2 ? 8 / g.PT : 4;
+  const int npk = (g.CC >> 1) / ksplit;
+  const int ntw = g.PT >= 2 ? 2 : 1;
+  if constexpr (KS == 3 && MODE != 2) {
+    if (npk == 4 && ntw == 2) return launch_igemm_v3n<KS, MODE, 4, 2>(g, grid, lds);
+    if (npk == 2 && ntw == 2) return launch_igemm_v3n<KS, MODE, 2, 2>(g, grid, lds);
+    if (npk == 4 && ntw == 1) return launch_igemm_v3n<KS, MODE, 4, 1>(g, grid, lds);
+  }
+  if (ntw == 2) return launch_igemm_v3n<KS, MODE, 0, 2>(g, grid, lds);
+  return launch_igemm_v3n<KS, MODE, 0, 1>(g, grid, lds);
 }
 
 int finish_slabs(const Geo& g, int splits, float* final_dst, const float* bias, int64_t out_elems) {
@@ -718,71 +913,96 @@ int finish_slabs(const Geo& g, int splits, float* final_dst, const float* bias, 
 }
 
 // producer-consumer kernel; returns -1 when the shape is not eligible
-int run_igemm_ws(Geo g, int dest_channels, float* final_dst, const float* bias) {
-  if (g.CS % 8 != 0 || !(g.k == 1 || g.k == 3 || g.k == 5)) return -1;
-  {
-    const char* e = getenv("DFHIP_CONV_DBG");
-    g.dbg = e ? atoi(e) : 0;
-  }
+int run_igemm_v3(Geo g, int dest_channels, float* final_dst, const float* bias) {
+  if (g.CS % 8 != 0 || !(g.k == 1 || g.k == 3)) return -1;
   const int k2 = g.k * g.k;
-  int gi;
-  plan_groups(g.N, g.HD, g.WD, kTP, g.BI, g.BR, g.BC, gi, g.gr, g.gc);
-  g.PR = (g.BR - 1) * g.so + g.k;
-  g.PC = (g.BC - 1) * g.so + g.k;
-  g.PE = g.BI * g.PR * g.PC;
-  auto lds_for = [&](int ccp) {
-    size_t xs = (size_t)ccp * g.PE + 64, ws = (size_t)k2 * (ccp + 1) * 33 + 8 * 33;
-    return (2 * (xs + ws) + (size_t)g.PE) * 4;
-  };
-  int ccp = 0;
-  for (int c : {32, 16, 8})
-    if (g.CS % c == 0 && lds_for(c) <= 76 * 1024) { ccp = c; break; }
-  if (!ccp) {
-    if (lds_for(8) > 150 * 1024) return -1;
-    ccp = 8;
-  }
-  // prefer at least two chunks per block so staging overlaps the matrix cores
-  if (ccp > 8 && g.CS / ccp < 2) ccp /= 2;
-  g.CC = ccp;
-  const int pixel_blocks = gi * g.gr * g.gc;
   const int dtiles = (int)df_ceil_div(dest_channels, 32);
-  const int chunks = g.CS / ccp;
-  int64_t blocks = (int64_t)pixel_blocks * dtiles;
-  int splits = 1;
-  int64_t target = (int64_t)num_cus() * 2;
-  if (blocks < target) splits = (int)std::min<int64_t>(chunks, df_ceil_div(target, blocks));
-  while (chunks % splits) splits--;      // equal, whole chunks per split
-  g.cs_per_split = (chunks / splits) * ccp;
-  const int64_t out_elems = (int64_t)g.N * g.CD * g.HD * g.WD;
+  auto lds_for = [&](int ccp, int pt) {
+    size_t wl = g.mode == 0 ? (size_t)32 * (ccp * k2 + 4) : (size_t)ccp * 32 * k2;
+    size_t stage_b = (2 * ((size_t)ccp * g.PE + wl) + (size_t)g.PE) * 4;
+    size_t red_b = (size_t)pt * ((pt >= 2 ? 8 / pt : 4) - 1) * 16 * 64 * 4;
+    return std::max(stage_b, red_b);
+  };
+  // pixel tiles per workgroup: the largest group that still yields about one job per CU
+  int gi = 1, chosen = 0, ccp = 0;
+  for (int pt : {8, 4, 2, 1}) {
+    const int ksplit = pt >= 2 ? 8 / pt : 4;
+    plan_groups(g.N, g.HD, g.WD, 32 * pt, g.BI, g.BR, g.BC, gi, g.gr, g.gc);
+    g.PR = (g.BR - 1) * g.so + g.k;
+    g.PC = (g.BC - 1) * g.so + g.k;
+    g.PE = g.BI * g.PR * g.PC;
+    int64_t jobs = (int64_t)gi * g.gr * g.gc * dtiles;
+    if (jobs < (int64_t)num_cus() && pt > 1) continue;
+    // channels per chunk: >= 2 per k-split slice, at most ~8 chunks, must divide CS and fit LDS
+    int c = std::max(8, 2 * ksplit);
+    while (c < 32 && g.CS / c > 8 && g.CS % (2 * c) == 0) c *= 2;
+    if (g.CS % c != 0) continue;
+    auto fits = [&](int cc) {
+      int items = (int)df_ceil_div(g.PE, 256) * (cc / 4);
+      int w4 = 8 * cc * k2;   // float4 weight vectors per chunk
+      return lds_for(cc, pt) <= 150 * 1024 && items <= 4 * kMaxItems && w4 <= 256 * kWU;
+    };
+    while (c > std::max(8, 2 * ksplit) && !fits(c)) c /= 2;
+    if (!fits(c) || g.CS % c != 0) continue;
+    chosen = pt;
+    ccp = c;
+    break;
+  }
+  if (!chosen) return -1;
+  g.PT = chosen;
+  g.CC = ccp;
+  g.cs_per_split = g.CS;
   g.slab_stride = 0;
   g.dst = final_dst;
   g.bias = bias;
-  if (splits > 1) {
-    float* ws = workspace((size_t)out_elems * splits * sizeof(float));
-    if (!ws) return DFHIP_OUT_OF_MEMORY;
-    g.dst = ws;
-    g.slab_stride = out_elems;
-    g.bias = nullptr;
-  }
-  size_t lds = lds_for(ccp);
-  dim3 grid((unsigned)pixel_blocks, (unsigned)dtiles, (unsigned)splits);
+  const int pixel_blocks = gi * g.gr * g.gc;
+  size_t lds = lds_for(ccp, chosen);
+  dim3 grid((unsigned)pixel_blocks, (unsigned)dtiles, 1);
   int st = DFHIP_OK;
-#define DF_WS(KSV)                                                        \
-  (g.mode == 0 ? launch_igemm_ws<KSV, 0>(g, grid, lds)                    \
-               : (g.mode == 1 ? launch_igemm_ws<KSV, 1>(g, grid, lds)     \
-                              : launch_igemm_ws<KSV, 2>(g, grid, lds)))
-  if (g.k == 1) st = DF_WS(1);
-  else if (g.k == 3) st = DF_WS(3);
-  else st = DF_WS(5);
-#undef DF_WS
+  g.stamps = nullptr;
+  g.dbg = getenv("DFHIP_CONV_DBG") ? atoi(getenv("DFHIP_CONV_DBG")) : 0;
+  static int stamp_mode = -1;
+  if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
+  const size_t nstamp = (size_t)pixel_blocks * dtiles * 2 * 32;
+  if (stamp_mode) {
+    g.stamps = (unsigned long long*)workspace2(nstamp * 8);
+    (void)hipMemsetAsync(g.stamps, 0, nstamp * 8, stream());
+  }
+#define DF_V3(KSV)                                                        \
+  (g.mode == 0 ? launch_igemm_v3<KSV, 0>(g, grid, lds)                    \
+               : (g.mode == 1 ? launch_igemm_v3<KSV, 1>(g, grid, lds)     \
+                              : launch_igemm_v3<KSV, 2>(g, grid, lds)))
+  if (g.k == 1) st = DF_V3(1);
+  else st = DF_V3(3);
+#undef DF_V3
   if (st != DFHIP_OK) return st;
   DF_LAUNCH_CHECK();
-  return finish_slabs(g, splits, final_dst, bias, out_elems);
+  if (stamp_mode) {
+    std::vector<unsigned long long> h(nstamp);
+    (void)hipStreamSynchronize(stream());
+    (void)hipMemcpy(h.data(), g.stamps, nstamp * 8, hipMemcpyDeviceToHost);
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (size_t b = 0; b < nstamp / 64; b++) {
+      if (h[b * 64]) tmin = std::min(tmin, h[b * 64]);
+      for (int i = 0; i < 64; i++) tmax = std::max(tmax, h[b * 64 + i]);
+    }
+    fprintf(stderr, "[stamp] mode %d k %d PT %d CC %d PE %d grid %d x %d lds %zu span %llu cycles\n", g.mode, g.k,
+            g.PT, g.CC, g.PE, pixel_blocks, dtiles, lds, tmax - tmin);
+    for (size_t b : {(size_t)0, nstamp / 64 / 2, nstamp / 64 - 1}) {
+      for (int w = 0; w < 2; w++) {
+        fprintf(stderr, "[stamp]  block %zu %s:", b, w ? "loader " : "compute");
+        for (int i = 0; i < 32 && h[(b * 2 + w) * 32 + i]; i++)
+          fprintf(stderr, " %llu", h[(b * 2 + w) * 32 + i] - tmin);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+  return DFHIP_OK;
 }
 
 int run_igemm(Geo g, int dest_channels, float* final_dst, const float* bias) {
   {
-    int st = run_igemm_ws(g, dest_channels, final_dst, bias);
+    int st = run_igemm_v3(g, dest_channels, final_dst, bias);
     if (st >= 0) return st;
   }
   const int k2 = g.k * g.k;
