@@ -645,6 +645,8 @@ struct WGeo {
   int PR, PC, PE;
   int CH;      // max channels a block's kk range can touch
   int lds_floats;  // size of the staging region (also used for the cross-wave reduction)
+  // v2 (producer-consumer) only: exact division by multiplication, magic = ceil(2^32 / d)
+  unsigned m_prpc, m_pc, m_brbc, m_bc, m_br;
 };
 
 template <int OT, int KT>
@@ -790,6 +792,259 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WGeo g) {
         v += red[((wave * 4 + 1) * 16 + rr) * 64 + lane];
         v += red[((wave * 4 + 2) * 16 + rr) * 64 + lane];
         v += red[((wave * 4 + 3) * 16 + rr) * 64 + lane];
+        int o = o0 + ti * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        if (o < g.O && kk < KW) out[(int64_t)o * KW + kk] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient, producer-consumer form.  Same decomposition as above (every matrix-core wave
+// keeps all OT x KT accumulator tiles and reduces its share of the pixels; partials are summed
+// through LDS at the end), plus:
+//   * 4 loader waves stage pixel group g+1 into the second LDS buffer while group g is in the
+//     matrix cores, with the global loads of group g+2 already in flight in registers;
+//   * no gather tables: a loader lane derives the source offset of its patch / dY elements
+//     arithmetically (exact division by multiplication with host-supplied magics);
+//   * pixels are walked row by row, so inside a row both operand addresses advance by constants
+//     (no dependent LDS read in front of an MFMA).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic) {
+  return magic ? __umulhi(n, magic) : n;          // magic == 0 encodes "divide by 1"
+}
+
+template <int NIT>
+struct GatherRegs {
+  int off[NIT][4];
+  float v[NIT][4][4];
+};
+
+// element j of the per-channel patch of a group -> offset inside one channel plane of x, or -1
+__device__ __forceinline__ int wg_patch_off(const WGeo& g, int j, int n0, int r0) {
+  if (j >= g.PE) return -1;
+  unsigned img = fast_div(j, g.m_prpc);
+  unsigned rem = j - img * (g.PR * g.PC);
+  unsigned pr = fast_div(rem, g.m_pc);
+  unsigned pc = rem - pr * g.PC;
+  int u = r0 * g.stride - g.pad + (int)pr, v = -g.pad + (int)pc;
+  int n = n0 + (int)img;
+  bool ok = n < g.N && u >= 0 && v >= 0 && u < g.H && v < g.W;
+  return ok ? (int)(((int64_t)img * g.C) * g.H * g.W + (int64_t)u * g.W + v) : -1;
+}
+
+// pixel q of a group -> offset inside one channel plane of dy, or -1
+__device__ __forceinline__ int wg_dy_off(const WGeo& g, int q, int n0, int r0, int BMP) {
+  if (q >= BMP) return -1;
+  unsigned img = fast_div(q, g.m_brbc);
+  unsigned rem = q - img * (g.BR * g.BC);
+  unsigned r = fast_div(rem, g.m_bc);
+  unsigned col = rem - r * g.BC;
+  int n = n0 + (int)img;
+  bool ok = n < g.N && r0 + (int)r < g.oh;
+  return ok ? (int)(((int64_t)img * g.O) * g.oh * g.ow + (int64_t)(r0 + r) * g.ow + col) : -1;
+}
+
+// rows x cols gather of a [rows][ncols] tile through per-column offsets (shared by all rows):
+// item = 4 rows x 4 slices of 64 columns, items dealt round-robin to the loader waves
+template <int NIT, class OffFn>
+__device__ __forceinline__ void gather_issue(const float* __restrict__ base, int64_t row_stride, int nrows,
+                                             int ncols, int lw, int ln, OffFn off_of, GatherRegs<NIT>& R) {
+  const int nsg = (ncols + 255) >> 8;
+  const int nitems = nsg * ((nrows + 3) >> 2);
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int item = lw + 4 * it;
+    const bool live = item < nitems;
+    const int rg = live ? item / nsg : 0, sg = live ? item - rg * nsg : 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) R.off[it][u] = live ? off_of((sg * 4 + u) * 64 + ln) : -1;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      int row = rg * 4 + rr;
+      const float* rb = base + (int64_t)(row < nrows ? row : 0) * row_stride;
+#pragma unroll
+      for (int u = 0; u < 4; u++) R.v[it][rr][u] = rb[R.off[it][u] >= 0 ? R.off[it][u] : 0];
+    }
+  }
+}
+
+template <int NIT>
+__device__ __forceinline__ void gather_commit(float* __restrict__ dst, int dst_row_stride, int nrows, int ncols,
+                                              int ncols_padded, int lw, int ln, const GatherRegs<NIT>& R) {
+  const int nsg = (ncols + 255) >> 8;
+  const int nitems = nsg * ((nrows + 3) >> 2);
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int item = lw + 4 * it;
+    if (item < nitems) {
+      const int rg = item / nsg, sg = item - rg * nsg;
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        int row = rg * 4 + rr;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          int j = (sg * 4 + u) * 64 + ln;
+          if (row < nrows && j < ncols_padded) dst[row * dst_row_stride + j] = R.off[it][u] >= 0 ? R.v[it][rr][u] : 0.0f;
+        }
+      }
+    }
+  }
+}
+
+template <int OT, int KT, int PIT, int DIT>
+__global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k2 = g.k * g.k;
+  const int KW = g.C * k2;
+  const int BMP = g.BI * g.BR * g.BC;
+  const int BMPP = (BMP + 7) & ~7;
+  const int DLD = BMPP + 1;          // odd row stride: lanes run along o
+  const int xs_floats = g.CH * g.PE;
+  const int dy_floats = OT * 32 * DLD;
+  float* Xs0 = smem;                 // [2][CH][PE]
+  float* Ds0 = Xs0 + 2 * xs_floats;  // [2][OT*32][DLD]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const bool loader = wave >= 4;
+  const int lw = wave & 3;
+  const int kk0 = blockIdx.y * (KT * 32);
+  const int o0 = blockIdx.z * (OT * 32);
+  const int cA = kk0 / k2;
+  const int cB = min(g.C, (min(KW, kk0 + KT * 32) - 1) / k2 + 1);
+  const int chn = cB - cA;
+  const int orows = min(OT * 32, g.O - o0);
+  const int64_t xplane = (int64_t)g.H * g.W, yplane = (int64_t)g.oh * g.ow;
+
+  int koffL[KT];
+#pragma unroll
+  for (int t = 0; t < KT; t++) {
+    int kk = kk0 + t * 32 + l31;
+    int off = 0;
+    if (kk < KW) {
+      int c = kk / k2, tt = kk - c * k2;
+      int i = tt / g.k, j = tt - i * g.k;
+      off = (c - cA) * g.PE + i * g.PC + j;
+    }
+    koffL[t] = off;
+  }
+
+  f32x16 acc[OT][KT];
+#pragma unroll
+  for (int a = 0; a < OT; a++)
+#pragma unroll
+    for (int b = 0; b < KT; b++)
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) acc[a][b][rr] = 0.0f;
+
+  GatherRegs<PIT> pregs;
+  GatherRegs<DIT> dregs;
+  // groups of this block: blockIdx.x, blockIdx.x + gridDim.x, ...
+  const int my_groups = (g.ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  auto group_origin = [&](int gi_, int& n0, int& r0) {
+    int grp = blockIdx.x + gi_ * gridDim.x;
+    int gimg = grp / g.gr;
+    n0 = gimg * g.BI;
+    r0 = (grp - gimg * g.gr) * g.BR;
+  };
+  auto issue = [&](int gi_) {
+    int n0, r0;
+    group_origin(gi_, n0, r0);
+    gather_issue<PIT>(g.x + ((int64_t)n0 * g.C + cA) * xplane, xplane, chn, g.PE, lw, lane,
+                      [&](int j) { return wg_patch_off(g, j, n0, r0); }, pregs);
+    gather_issue<DIT>(g.dy + ((int64_t)n0 * g.O + o0) * yplane, yplane, orows, BMP, lw, lane,
+                      [&](int q) { return wg_dy_off(g, q, n0, r0, BMP); }, dregs);
+  };
+  auto commit = [&](int buf) {
+    gather_commit<PIT>(Xs0 + buf * xs_floats, g.PE, chn, g.PE, g.PE, lw, lane, pregs);
+    // every one of the OT*32 rows is written (missing output channels as zeros); pixels are
+    // padded to BMPP with zeros so a wave always reduces whole pairs
+    gather_commit<DIT>(Ds0 + buf * dy_floats, DLD, orows, BMP, BMPP, lw, lane, dregs);
+  };
+  // rows of dYs beyond `orows` are never staged: zero them once in both buffers
+  for (int e = tid; e < 2 * dy_floats; e += 512) {
+    int r = (e % dy_floats) / DLD;
+    if (r >= orows) Ds0[e] = 0.0f;
+  }
+
+  if (loader && my_groups > 0) {
+    issue(0);
+    commit(0);
+    if (my_groups > 1) issue(1);
+  }
+  __syncthreads();
+
+  const int R = g.BI * g.BR;          // pixel rows of a group
+  const int ppr = g.BC >> 1;          // pixel pairs per row
+  for (int gi_ = 0; gi_ < my_groups; gi_++) {
+    const int buf = gi_ & 1;
+    if (loader) {
+      if (gi_ + 1 < my_groups) commit(buf ^ 1);
+      if (gi_ + 2 < my_groups) issue(gi_ + 2);
+    } else {
+      const float* Xs = Xs0 + buf * xs_floats;
+      const float* Ds = Ds0 + buf * dy_floats + l31 * DLD + half;
+      for (int ri = lw; ri < R; ri += 4) {
+        unsigned img = fast_div(ri, g.m_br);
+        int r = ri - (int)img * g.BR;
+        const float* xr = Xs + (int)img * g.PR * g.PC + r * g.stride * g.PC + half * g.stride;
+        const float* dr = Ds + ri * g.BC;
+#pragma unroll 2
+        for (int p = 0; p < ppr; p++) {
+          float a[OT], b[KT];
+#pragma unroll
+          for (int t = 0; t < OT; t++) a[t] = dr[t * 32 * DLD + 2 * p];
+#pragma unroll
+          for (int t = 0; t < KT; t++) b[t] = xr[koffL[t] + 2 * p * g.stride];
+#pragma unroll
+          for (int i = 0; i < OT; i++)
+#pragma unroll
+            for (int j = 0; j < KT; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // cross-wave reduction through LDS, four tiles per round; matrix-core wave w finishes tile 4*round + w
+  float* red = smem;  // [4 tiles][4 waves][16][64]
+  float* out = g.dst + (int64_t)blockIdx.x * g.O * KW;
+  constexpr int NTILES = OT * KT;
+#pragma unroll
+  for (int round = 0; round < (NTILES + 3) / 4; round++) {
+    __syncthreads();
+    if (!loader) {
+#pragma unroll
+      for (int tt = 0; tt < 4; tt++) {
+        int tile = round * 4 + tt;
+        if (tile < NTILES) {
+          int ti = tile / KT, tj = tile % KT;
+#pragma unroll
+          for (int rr = 0; rr < 16; rr++) {
+            float v = 0.0f;
+#pragma unroll
+            for (int a = 0; a < OT; a++)
+#pragma unroll
+              for (int b = 0; b < KT; b++)
+                if (a == ti && b == tj) v = acc[a][b][rr];
+            red[((tt * 4 + lw) * 16 + rr) * 64 + lane] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    int tile = round * 4 + lw;
+    if (!loader && tile < NTILES) {
+      int ti = tile / KT, tj = tile % KT;
+      int kk = kk0 + tj * 32 + l31;
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) {
+        float v = red[((lw * 4 + 0) * 16 + rr) * 64 + lane];
+        v += red[((lw * 4 + 1) * 16 + rr) * 64 + lane];
+        v += red[((lw * 4 + 2) * 16 + rr) * 64 + lane];
+        v += red[((lw * 4 + 3) * 16 + rr) * 64 + lane];
         int o = o0 + ti * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
         if (o < g.O && kk < KW) out[(int64_t)o * KW + kk] = v;
       }
@@ -1093,6 +1348,75 @@ int launch_wgrad(WGeo g, float* dw) {
   return DFHIP_OK;
 }
 
+unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)((((uint64_t)1 << 32) + d - 1) / d); }
+
+template <int OT, int KT, int PIT, int DIT>
+int launch_wgrad_v2(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
+  const int64_t n = (int64_t)g.O * g.C * g.k * g.k;
+  float* slabs = dw;
+  if (gx > 1) {
+    slabs = workspace((size_t)n * gx * sizeof(float));
+    if (!slabs) return DFHIP_OUT_OF_MEMORY;
+  }
+  g.dst = slabs;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_v2<OT, KT, PIT, DIT>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)std::max(lds, (size_t)65536)));
+    attr_lds = std::max(lds, (size_t)65536);
+  }
+  dim3 grid((unsigned)gx, (unsigned)ktg, (unsigned)otg);
+  hipLaunchKernelGGL((k_conv_wgrad_v2<OT, KT, PIT, DIT>), grid, dim3(512), lds, stream(), g);
+  DF_LAUNCH_CHECK();
+  if (gx > 1) {
+    hipLaunchKernelGGL(k_flat_slab_sum, dim3((unsigned)df_ceil_div(n, 256)), dim3(1024), 0, stream(), slabs,
+                       dw, n, gx);
+    DF_LAUNCH_CHECK();
+  }
+  return DFHIP_OK;
+}
+
+// returns -1 when the shape is not eligible for the producer-consumer weight-gradient kernel
+int run_wgrad_v2(WGeo g, float* dw) {
+  const int k2 = g.k * g.k;
+  const int KW = g.C * k2;
+  if ((g.ow & 1) || KW < 64) return -1;
+  const int OT = g.O <= 32 ? 1 : 2;
+  const int KT = g.O <= 32 ? 5 : 2;
+  const int CH = std::min(g.C, (KT * 32 + k2 - 2) / k2 + 1);
+  int gi = 1;
+  size_t lds = 0;
+  bool ok = false;
+  for (int tp : {128, 64, 32}) {
+    plan_groups(g.N, g.oh, g.ow, tp, g.BI, g.BR, g.BC, gi, g.gr, g.gc);
+    if (g.BC != g.ow) continue;                    // whole rows only
+    g.PR = (g.BR - 1) * g.stride + g.k;
+    g.PC = (g.BC - 1) * g.stride + g.k;
+    g.PE = g.BI * g.PR * g.PC;
+    int BMP = g.BI * g.BR * g.BC, BMPP = (BMP + 7) & ~7;
+    if ((g.BI * g.BR) % 4) continue;               // rows deal evenly to the four matrix-core waves
+    size_t stage = 2 * ((size_t)CH * g.PE + (size_t)OT * 32 * (BMPP + 1)) * 4;
+    size_t red = (size_t)4 * 4 * 16 * 64 * 4;
+    lds = std::max(stage, red);
+    int pitems = (int)df_ceil_div(CH, 4) * (int)df_ceil_div(g.PE, 256);
+    int ditems = OT * 8 * (int)df_ceil_div(BMPP, 256);
+    if (lds <= 150 * 1024 && pitems <= 8 && ditems <= 4 * (OT == 1 ? 2 : 4) && g.PE < 65536) { ok = true; break; }
+  }
+  if (!ok) return -1;
+  g.CH = CH;
+  g.ngroups = gi * g.gr;
+  g.m_prpc = magic_u32(g.PR * g.PC);
+  g.m_pc = magic_u32(g.PC);
+  g.m_brbc = magic_u32(g.BR * g.BC);
+  g.m_bc = magic_u32(g.BC);
+  g.m_br = magic_u32(g.BR);
+  const int ktg = (int)df_ceil_div(KW, KT * 32), otg = (int)df_ceil_div(g.O, OT * 32);
+  int gx = (int)std::max<int64_t>(1, std::min<int64_t>(g.ngroups, (int64_t)num_cus() / ((int64_t)ktg * otg)));
+  if (OT == 1) return launch_wgrad_v2<1, 5, 2, 2>(g, dw, lds, gx, ktg, otg);
+  return launch_wgrad_v2<2, 2, 2, 4>(g, dw, lds, gx, ktg, otg);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1150,6 +1474,10 @@ int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C,
   g.x = x; g.dy = dy;
   g.N = N; g.C = C; g.H = H; g.W = W; g.O = O; g.oh = oh; g.ow = ow;
   g.k = k; g.stride = stride; g.pad = pad;
+  {
+    int st = run_wgrad_v2(g, dw);
+    if (st >= 0) return st;
+  }
   const int KW = C * k * k;
   const int k2 = k * k;
   const int ktiles32 = (int)df_ceil_div(KW, 32);
