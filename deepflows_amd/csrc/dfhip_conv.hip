@@ -35,6 +35,11 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// n / d for n*d < 2^32 with magic = ceil(2^32 / d); magic == 0 encodes d == 1
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic) {
+  return magic ? __umulhi(n, magic) : n;
+}
+
 constexpr int kTP = 128;  // destination pixels per workgroup (4 waves x one 32-pixel tile)
 
 struct Geo {
@@ -60,6 +65,7 @@ struct Geo {
   int PT;                  // v3: 32-pixel tiles per workgroup (8 / PT k-split slices)
   unsigned long long* stamps;  // diagnostic builds only (DFHIP_CONV_STAMP): per-block time stamps
   int dbg;                     // diagnostics: 1 = loaders idle in the main loop, 2 = no MFMAs
+  unsigned m_perimg, m_pc, m_sd;   // exact division by multiplication (magic = ceil(2^32/d), 0 = divide by 1)
 };
 
 __device__ __forceinline__ void decode_pixel(const Geo& g, int q, int& img, int& r, int& col) {
@@ -393,7 +399,6 @@ __global__ __launch_bounds__(512) void k_conv_igemm_v3(Geo g) {
   const int ws_floats = (MODE == 0 ? 32 : CCP) * RS;
   float* Xs0 = smem;
   float* Ws0 = Xs0 + 2 * xs_floats;
-  int* goff = (int*)(Ws0 + 2 * ws_floats);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -421,18 +426,6 @@ __global__ __launch_bounds__(512) void k_conv_igemm_v3(Geo g) {
   const int nchunks = g.CS / CCP;
   const int64_t src_plane = (int64_t)g.HS * g.WS;
 
-  for (int j = tid; j < g.PE; j += 512) {
-    int per_img = g.PR * g.PC;
-    int img = j / per_img;
-    int rem = j - img * per_img;
-    int pr = rem / g.PC, pc = rem - pr * g.PC;
-    int u = r0 * g.so + g.u0 + pr, v = c0 * g.so + g.u0 + pc;
-    bool ok = (n0 + img < g.N) && u >= 0 && v >= 0 && (u % g.sd) == 0 && (v % g.sd) == 0;
-    int su = u / g.sd, sv = v / g.sd;
-    ok = ok && su < g.HS && sv < g.WS;
-    goff[j] = ok ? (int)((int64_t)img * g.CS * src_plane + (int64_t)su * g.WS + sv) : -1;
-  }
-
   // the wave's pixel tiles
   int abase[2], tapsel[2];
   bool pvalid[2];
@@ -452,16 +445,114 @@ __global__ __launch_bounds__(512) void k_conv_igemm_v3(Geo g) {
     out_off[e] = (int64_t)(n0 + img) * g.CD * g.HD * g.WD + (int64_t)(r0 + r) * g.WD + (c0 + col);
   }
 
-  PatchRegs pregs;
-  WeightRegs wregs;
-  auto issue = [&](int chunk, int nthreads, int t0) {
-    const int cb = chunk * CCP;
-    weights_issue<KS, WM>(g, CCP, cb, d0, nthreads, t0, wregs);
-    patch_issue(g, g.src + ((int64_t)n0 * g.CS + cb) * src_plane, goff, CCP, src_plane, nthreads, t0, pregs);
+  // ---- loader descriptors: everything that does not depend on the chunk is computed ONCE ----
+  // per thread (source offsets inside a channel plane, LDS destinations, weight vector offsets);
+  // per chunk a loader then only adds a wave-uniform base pointer (scalar) to 32-bit lane
+  // offsets, so staging a chunk is ~40 loads + ~70 LDS stores and almost no VALU.
+  const int lw = __builtin_amdgcn_readfirstlane(wave) & 3;
+  const int lt = tid & 255;
+  int p_go[kMaxItems][4];     // >= 0 source offset, -1 = padding (store zero), -2 = no such element
+  int p_lx[kMaxItems];        // LDS float index of (first channel of the item, first slice, lane)
+  int p_cg[kMaxItems];        // first channel of the item (wave-uniform), -1 = no item
+  unsigned w_off[kWU];        // float offset of the vector relative to the chunk's weight base
+  int w_lx[kWU];              // LDS float index, -1 = dead slot
+  if (loader) {
+    const int nsg = (g.PE + 255) >> 8;
+    const int nitems = nsg * (CCP >> 2);
+    const int per_img = g.PR * g.PC;
+#pragma unroll
+    for (int it = 0; it < kMaxItems; it++) {
+      const int item = lw + 4 * it;
+      const bool live = item < nitems;
+      const int cg = live ? item / nsg : 0, sg = live ? item - cg * nsg : 0;
+      p_cg[it] = live ? cg * 4 : -1;
+      p_lx[it] = (cg * 4) * g.PE + sg * 256 + lane;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int j = sg * 256 + u * 64 + lane;
+        int go = -2;
+        if (live && j < g.PE) {
+          int img = (int)fast_div((unsigned)j, g.m_perimg);
+          int rem = j - img * per_img;
+          int pr = (int)fast_div((unsigned)rem, g.m_pc), pc = rem - pr * g.PC;
+          int uu = r0 * g.so + g.u0 + pr, vv = c0 * g.so + g.u0 + pc;
+          bool ok = (n0 + img < g.N) && uu >= 0 && vv >= 0;
+          int su = ok ? (int)fast_div((unsigned)uu, g.m_sd) : 0, sv = ok ? (int)fast_div((unsigned)vv, g.m_sd) : 0;
+          ok = ok && su * g.sd == uu && sv * g.sd == vv && su < g.HS && sv < g.WS;
+          go = ok ? (int)((int64_t)img * g.CS * src_plane + (int64_t)su * g.WS + sv) : -1;
+        }
+        p_go[it][u] = go;
+      }
+    }
+    const int run4 = (MODE == 0 ? CCP * k2 : 32 * k2) >> 2;
+    const int total4 = run4 * (MODE == 0 ? 32 : CCP);
+    const int dmax = min(32, g.CD - d0);
+    const unsigned m_run4 = (unsigned)((((uint64_t)1 << 32) + run4 - 1) / (unsigned)run4);
+#pragma unroll
+    for (int u = 0; u < kWU; u++) {
+      const int f = lt + 256 * u;
+      const bool live = f < total4;
+      const int ff = live ? f : 0;
+      const int row = run4 > 1 ? (int)__umulhi((unsigned)ff, m_run4) : ff, e4 = ff - row * run4;
+      if (MODE == 0) {
+        const bool ok = row < dmax;
+        w_off[u] = (unsigned)(((d0 + (ok ? row : 0)) * g.wC) * k2 + 4 * e4);
+      } else {
+        w_off[u] = (unsigned)((row * g.wC + d0) * k2 + 4 * e4);   // host guarantees CD % 32 == 0
+      }
+      w_lx[u] = live ? row * RS + 4 * e4 : -1;
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < kMaxItems; it++) {
+      p_cg[it] = -1; p_lx[it] = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) p_go[it][u] = -2;
+    }
+#pragma unroll
+    for (int u = 0; u < kWU; u++) { w_off[u] = 0; w_lx[u] = -1; }
+  }
+  const int dmax_ = min(32, g.CD - d0);
+  float p_v[kMaxItems][4][4];
+  float4 w_v[kWU];
+  auto issue = [&](int chunk) {
+    const float* wb = g.wgt + (int64_t)chunk * CCP * (MODE == 0 ? k2 : g.wC * k2);
+#pragma unroll
+    for (int u = 0; u < kWU; u++) w_v[u] = *reinterpret_cast<const float4*>(wb + w_off[u]);
+    const float* xb = g.src + ((int64_t)n0 * g.CS + (int64_t)chunk * CCP) * src_plane;
+#pragma unroll
+    for (int it = 0; it < kMaxItems; it++) {
+      if (p_cg[it] >= 0) {
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+          const float* cbp = xb + (int64_t)(p_cg[it] + cc) * src_plane;
+#pragma unroll
+          for (int u = 0; u < 4; u++) p_v[it][cc][u] = cbp[p_go[it][u] > 0 ? p_go[it][u] : 0];
+        }
+      }
+    }
   };
-  auto commit = [&](int buf, int nthreads, int t0) {
-    patch_commit(g, Xs0 + buf * xs_floats, CCP, nthreads, t0, pregs);
-    weights_commit<KS, WM>(g, Ws0 + buf * ws_floats, CCP, d0, nthreads, t0, wregs);
+  auto commit = [&](int buf) {
+    float* Xs = Xs0 + buf * xs_floats;
+    float* Wl = Ws0 + buf * ws_floats;
+#pragma unroll
+    for (int it = 0; it < kMaxItems; it++) {
+      if (p_cg[it] >= 0) {
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (p_go[it][u] > -2) Xs[p_lx[it] + cc * g.PE + u * 64] = p_go[it][u] >= 0 ? p_v[it][cc][u] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kWU; u++) {
+      if (w_lx[u] >= 0) {
+        float4 v = w_v[u];
+        if (MODE == 0 && dmax_ < 32 && w_lx[u] / RS >= dmax_) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(Wl + w_lx[u]) = v;
+      }
+    }
   };
 
   f32x16 acc0, acc1;
@@ -469,15 +560,12 @@ __global__ __launch_bounds__(512) void k_conv_igemm_v3(Geo g) {
   for (int rr = 0; rr < 16; rr++) { acc0[rr] = 0.0f; acc1[rr] = 0.0f; }
 
   DF_STAMP();
-  __syncthreads();                      // goff ready
-  DF_STAMP();
-  // prologue: every wave helps with chunk 0, then the loaders put chunk 1 in flight
-  issue(0, 512, tid);
-  commit(0, 512, tid);
-  DF_STAMP();
   if (loader) {
-    __builtin_amdgcn_s_setprio(1);      // few instructions, but each gates a chunk
-    if (nchunks > 1) issue(1, 256, tid - 256);
+    __builtin_amdgcn_s_setprio(1);
+    issue(0);
+    commit(0);
+    DF_STAMP();
+    if (nchunks > 1) issue(1);
   }
   __syncthreads();
   DF_STAMP();
@@ -492,9 +580,9 @@ __global__ __launch_bounds__(512) void k_conv_igemm_v3(Geo g) {
       // chunk ch+1 (loaded during the previous iteration) goes to the buffer the matrix cores
       // finished with at the last barrier; chunk ch+2 is put in flight for the next iteration
       if (!(g.dbg & 1)) {
-        if (ch + 1 < nchunks) commit(buf ^ 1, 256, tid - 256);
+        if (ch + 1 < nchunks) commit(buf ^ 1);
         DF_STAMP();
-        if (ch + 2 < nchunks) issue(ch + 2, 256, tid - 256);
+        if (ch + 2 < nchunks) issue(ch + 2);
       }
     } else if (!(g.dbg & 2)) {
       const float* Xb = Xs0 + buf * xs_floats + c_first * g.PE;
@@ -810,10 +898,6 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WGeo g) {
 //   * pixels are walked row by row, so inside a row both operand addresses advance by constants
 //     (no dependent LDS read in front of an MFMA).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned magic) {
-  return magic ? __umulhi(n, magic) : n;          // magic == 0 encodes "divide by 1"
-}
-
 template <int NIT>
 struct GatherRegs {
   int off[NIT][4];
@@ -1130,6 +1214,8 @@ int check_conv_args(const char* name, int N, int C, int H, int W, int O, int k, 
 
 constexpr size_t kLdsBudget = 64 * 1024;  // keeps two workgroups resident per CU
 
+unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)((((uint64_t)1 << 32) + d - 1) / d); }
+
 template <int KS, int MODE, int NPK, int NTW>
 int launch_igemm_v3n(const Geo& g, dim3 grid, size_t lds) {
   static size_t attr_lds = 0;
@@ -1170,6 +1256,7 @@ int finish_slabs(const Geo& g, int splits, float* final_dst, const float* bias, 
 // producer-consumer kernel; returns -1 when the shape is not eligible
 int run_igemm_v3(Geo g, int dest_channels, float* final_dst, const float* bias) {
   if (g.CS % 8 != 0 || !(g.k == 1 || g.k == 3)) return -1;
+  if (g.mode != 0 && g.CD % 32 != 0) return -1;   // dgrad weight rows are staged as whole 32-channel runs
   const int k2 = g.k * g.k;
   const int dtiles = (int)df_ceil_div(dest_channels, 32);
   auto lds_for = [&](int ccp, int pt) {
@@ -1206,6 +1293,9 @@ int run_igemm_v3(Geo g, int dest_channels, float* final_dst, const float* bias) 
   if (!chosen) return -1;
   g.PT = chosen;
   g.CC = ccp;
+  g.m_perimg = magic_u32((unsigned)(g.PR * g.PC));
+  g.m_pc = magic_u32((unsigned)g.PC);
+  g.m_sd = magic_u32((unsigned)g.sd);
   g.cs_per_split = g.CS;
   g.slab_stride = 0;
   g.dst = final_dst;
@@ -1347,8 +1437,6 @@ int launch_wgrad(WGeo g, float* dw) {
   }
   return DFHIP_OK;
 }
-
-unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)((((uint64_t)1 << 32) + d - 1) / d); }
 
 template <int OT, int KT, int PIT, int DIT>
 int launch_wgrad_v2(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
