@@ -888,95 +888,74 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WGeo g) {
 }
 
 // ---------------------------------------------------------------------------------------
-// weight gradient, producer-consumer form.  Same decomposition as above (every matrix-core wave
-// keeps all OT x KT accumulator tiles and reduces its share of the pixels; partials are summed
-// through LDS at the end), plus:
-//   * 4 loader waves stage pixel group g+1 into the second LDS buffer while group g is in the
-//     matrix cores, with the global loads of group g+2 already in flight in registers;
-//   * no gather tables: a loader lane derives the source offset of its patch / dY elements
-//     arithmetically (exact division by multiplication with host-supplied magics);
-//   * pixels are walked row by row, so inside a row both operand addresses advance by constants
-//     (no dependent LDS read in front of an MFMA).
+// weight gradient, producer-consumer form with LDS-DMA staging.
+// Same decomposition as above (every matrix-core wave keeps all OT x KT accumulator tiles and
+// reduces its share of the pixel rows of a group; partials are summed through LDS at the end):
+//   * waves 4-7 are loaders.  They stage pixel group g+2 into a 3-slot LDS ring with
+//     `global_load_lds` (the load writes LDS directly: no staging registers, ~1 instruction per
+//     256 B), while group g is in the matrix cores; a counted s_waitcnt keeps the newest group in
+//     flight across the workgroup barrier (raw s_barrier: __syncthreads() would drain it);
+//   * a loader lane's source offsets inside a channel plane are computed once per block (exact
+//     division by multiplication), per group only for row bands whose halo depends on the band;
+//     per load the address is a scalar base + 32-bit lane offset; halo / padding lanes read a
+//     zero word instead;
+//   * pixels are walked row by row, so inside a row both operand addresses advance by constants.
 // ---------------------------------------------------------------------------------------
-template <int NIT>
-struct GatherRegs {
-  int off[NIT][4];
-  float v[NIT][4][4];
-};
+__device__ float g_zero_words[64];   // zero-initialised: the source of halo / padding elements
 
-// element j of the per-channel patch of a group -> offset inside one channel plane of x, or -1
-__device__ __forceinline__ int wg_patch_off(const WGeo& g, int j, int n0, int r0) {
-  if (j >= g.PE) return -1;
+typedef __attribute__((address_space(3))) void* df_lds_ptr;
+typedef const __attribute__((address_space(1))) void* df_glb_ptr;
+
+// wait until at most `n` of this wave's vector-memory operations are outstanding (n wave-uniform)
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+#define DF_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    DF_W(0) DF_W(1) DF_W(2) DF_W(3) DF_W(4) DF_W(5) DF_W(6) DF_W(7) DF_W(8) DF_W(9)
+    DF_W(10) DF_W(11) DF_W(12) DF_W(13) DF_W(14) DF_W(15) DF_W(16) DF_W(17) DF_W(18) DF_W(19)
+    DF_W(20) DF_W(21) DF_W(22) DF_W(23) DF_W(24) DF_W(25) DF_W(26) DF_W(27) DF_W(28) DF_W(29)
+    DF_W(30) DF_W(31) DF_W(32) DF_W(33) DF_W(34) DF_W(35) DF_W(36) DF_W(37) DF_W(38) DF_W(39)
+    DF_W(40) DF_W(41) DF_W(42) DF_W(43) DF_W(44) DF_W(45) DF_W(46) DF_W(47) DF_W(48) DF_W(49)
+    DF_W(50) DF_W(51) DF_W(52) DF_W(53) DF_W(54) DF_W(55) DF_W(56) DF_W(57) DF_W(58) DF_W(59)
+    DF_W(60) DF_W(61) DF_W(62)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef DF_W
+}
+
+__device__ __forceinline__ void df_barrier() {
+  // LDS reads/writes of this wave retired, then the workgroup barrier; LDS-DMA stays in flight
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// element j of the per-channel patch of a group -> offset inside one channel plane of x,
+// -1 = zero (halo / padding), -2 = no such element
+__device__ __forceinline__ int wg_patch_off(const WGeo& g, int j, int r0) {
+  if (j >= g.PE) return -2;
   unsigned img = fast_div(j, g.m_prpc);
   unsigned rem = j - img * (g.PR * g.PC);
   unsigned pr = fast_div(rem, g.m_pc);
   unsigned pc = rem - pr * g.PC;
   int u = r0 * g.stride - g.pad + (int)pr, v = -g.pad + (int)pc;
-  int n = n0 + (int)img;
-  bool ok = n < g.N && u >= 0 && v >= 0 && u < g.H && v < g.W;
+  bool ok = u >= 0 && v >= 0 && u < g.H && v < g.W;
   return ok ? (int)(((int64_t)img * g.C) * g.H * g.W + (int64_t)u * g.W + v) : -1;
 }
 
-// pixel q of a group -> offset inside one channel plane of dy, or -1
-__device__ __forceinline__ int wg_dy_off(const WGeo& g, int q, int n0, int r0, int BMP) {
-  if (q >= BMP) return -1;
+// pixel q of a group -> offset inside one channel plane of dy; -1 zero, -2 none
+__device__ __forceinline__ int wg_dy_off(const WGeo& g, int q, int r0, int BMP) {
+  if (q >= BMP) return -2;
   unsigned img = fast_div(q, g.m_brbc);
   unsigned rem = q - img * (g.BR * g.BC);
   unsigned r = fast_div(rem, g.m_bc);
   unsigned col = rem - r * g.BC;
-  int n = n0 + (int)img;
-  bool ok = n < g.N && r0 + (int)r < g.oh;
+  bool ok = r0 + (int)r < g.oh;
   return ok ? (int)(((int64_t)img * g.O) * g.oh * g.ow + (int64_t)(r0 + r) * g.ow + col) : -1;
 }
 
-// rows x cols gather of a [rows][ncols] tile through per-column offsets (shared by all rows):
-// item = 4 rows x 4 slices of 64 columns, items dealt round-robin to the loader waves
-template <int NIT, class OffFn>
-__device__ __forceinline__ void gather_issue(const float* __restrict__ base, int64_t row_stride, int nrows,
-                                             int ncols, int lw, int ln, OffFn off_of, GatherRegs<NIT>& R) {
-  const int nsg = (ncols + 255) >> 8;
-  const int nitems = nsg * ((nrows + 3) >> 2);
-#pragma unroll
-  for (int it = 0; it < NIT; it++) {
-    const int item = lw + 4 * it;
-    const bool live = item < nitems;
-    const int rg = live ? item / nsg : 0, sg = live ? item - rg * nsg : 0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) R.off[it][u] = live ? off_of((sg * 4 + u) * 64 + ln) : -1;
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      int row = rg * 4 + rr;
-      const float* rb = base + (int64_t)(row < nrows ? row : 0) * row_stride;
-#pragma unroll
-      for (int u = 0; u < 4; u++) R.v[it][rr][u] = rb[R.off[it][u] >= 0 ? R.off[it][u] : 0];
-    }
-  }
-}
+constexpr int kWgSlots = 3;     // LDS ring depth
+constexpr int kWgPSl = 8;       // patch slices of 64 elements per channel (PE <= 512)
+constexpr int kWgDSl = 2;       // pixel slices of 64 per output channel (group <= 128 pixels)
 
-template <int NIT>
-__device__ __forceinline__ void gather_commit(float* __restrict__ dst, int dst_row_stride, int nrows, int ncols,
-                                              int ncols_padded, int lw, int ln, const GatherRegs<NIT>& R) {
-  const int nsg = (ncols + 255) >> 8;
-  const int nitems = nsg * ((nrows + 3) >> 2);
-#pragma unroll
-  for (int it = 0; it < NIT; it++) {
-    const int item = lw + 4 * it;
-    if (item < nitems) {
-      const int rg = item / nsg, sg = item - rg * nsg;
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        int row = rg * 4 + rr;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          int j = (sg * 4 + u) * 64 + ln;
-          if (row < nrows && j < ncols_padded) dst[row * dst_row_stride + j] = R.off[it][u] >= 0 ? R.v[it][rr][u] : 0.0f;
-        }
-      }
-    }
-  }
-}
-
-template <int OT, int KT, int PIT, int DIT>
+template <int OT, int KT>
 __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int k2 = g.k * g.k;
@@ -986,13 +965,12 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
   const int DLD = BMPP + 1;          // odd row stride: lanes run along o
   const int xs_floats = g.CH * g.PE;
   const int dy_floats = OT * 32 * DLD;
-  float* Xs0 = smem;                 // [2][CH][PE]
-  float* Ds0 = Xs0 + 2 * xs_floats;  // [2][OT*32][DLD]
+  const int slot_floats = xs_floats + dy_floats;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const bool loader = wave >= 4;
-  const int lw = wave & 3;
+  const int lw = __builtin_amdgcn_readfirstlane(wave) & 3;
   const int kk0 = blockIdx.y * (KT * 32);
   const int o0 = blockIdx.z * (OT * 32);
   const int cA = kk0 / k2;
@@ -1000,6 +978,10 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
   const int chn = cB - cA;
   const int orows = min(OT * 32, g.O - o0);
   const int64_t xplane = (int64_t)g.H * g.W, yplane = (int64_t)g.oh * g.ow;
+
+  // every slot starts as zeros: dY rows of missing output channels and the pixel padding are
+  // never written by the loaders
+  for (int e = tid; e < kWgSlots * slot_floats; e += 512) smem[e] = 0.0f;
 
   int koffL[KT];
 #pragma unroll
@@ -1022,8 +1004,6 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
 #pragma unroll
       for (int rr = 0; rr < 16; rr++) acc[a][b][rr] = 0.0f;
 
-  GatherRegs<PIT> pregs;
-  GatherRegs<DIT> dregs;
   // groups of this block: blockIdx.x, blockIdx.x + gridDim.x, ...
   const int my_groups = (g.ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   auto group_origin = [&](int gi_, int& n0, int& r0) {
@@ -1032,43 +1012,73 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
     n0 = gimg * g.BI;
     r0 = (grp - gimg * g.gr) * g.BR;
   };
+
+  int p_off[kWgPSl], d_off[kWgDSl];
+  auto describe = [&](int r0) {
+#pragma unroll
+    for (int sl = 0; sl < kWgPSl; sl++) p_off[sl] = wg_patch_off(g, sl * 64 + lane, r0);
+#pragma unroll
+    for (int sl = 0; sl < kWgDSl; sl++) d_off[sl] = wg_dy_off(g, sl * 64 + lane, r0, BMP);
+  };
+  int dma_per_group = 0;      // DMA instructions this wave issues per group (wave-uniform)
   auto issue = [&](int gi_) {
     int n0, r0;
     group_origin(gi_, n0, r0);
-    gather_issue<PIT>(g.x + ((int64_t)n0 * g.C + cA) * xplane, xplane, chn, g.PE, lw, lane,
-                      [&](int j) { return wg_patch_off(g, j, n0, r0); }, pregs);
-    gather_issue<DIT>(g.dy + ((int64_t)n0 * g.O + o0) * yplane, yplane, orows, BMP, lw, lane,
-                      [&](int q) { return wg_dy_off(g, q, n0, r0, BMP); }, dregs);
+    if (g.gr > 1) describe(r0);
+    float* slot = smem + (gi_ % kWgSlots) * slot_floats;
+    const float* xb = g.x + ((int64_t)n0 * g.C + cA) * xplane;
+    const float* yb = g.dy + ((int64_t)n0 * g.O + o0) * yplane;
+    int cnt = 0;
+#pragma unroll
+    for (int sl = 0; sl < kWgDSl; sl++) {
+      const int off = d_off[sl];
+      if (__ballot(off > -2) != 0ull) {
+        for (int o = lw; o < orows; o += 4) {
+          const float* src = off >= 0 ? yb + (int64_t)o * yplane + off : g_zero_words + lane;
+          if (off > -2)
+            __builtin_amdgcn_global_load_lds((df_glb_ptr)src, (df_lds_ptr)(slot + xs_floats + o * DLD + sl * 64), 4, 0, 0);
+          cnt++;
+        }
+      }
+    }
+#pragma unroll
+    for (int sl = 0; sl < kWgPSl; sl++) {
+      const int off = p_off[sl];
+      if (__ballot(off > -2) != 0ull) {
+        for (int c = lw; c < chn; c += 4) {
+          const float* src = off >= 0 ? xb + (int64_t)c * xplane + off : g_zero_words + lane;
+          if (off > -2)
+            __builtin_amdgcn_global_load_lds((df_glb_ptr)src, (df_lds_ptr)(slot + c * g.PE + sl * 64), 4, 0, 0);
+          cnt++;
+        }
+      }
+    }
+    dma_per_group = cnt;
   };
-  auto commit = [&](int buf) {
-    gather_commit<PIT>(Xs0 + buf * xs_floats, g.PE, chn, g.PE, g.PE, lw, lane, pregs);
-    // every one of the OT*32 rows is written (missing output channels as zeros); pixels are
-    // padded to BMPP with zeros so a wave always reduces whole pairs
-    gather_commit<DIT>(Ds0 + buf * dy_floats, DLD, orows, BMP, BMPP, lw, lane, dregs);
-  };
-  // rows of dYs beyond `orows` are never staged: zero them once in both buffers
-  for (int e = tid; e < 2 * dy_floats; e += 512) {
-    int r = (e % dy_floats) / DLD;
-    if (r >= orows) Ds0[e] = 0.0f;
-  }
 
-  if (loader && my_groups > 0) {
-    issue(0);
-    commit(0);
+  df_barrier();                      // zero fill done
+  if (loader) {
+    describe(0);
+    if (my_groups > 0) issue(0);
     if (my_groups > 1) issue(1);
+    wait_vmcnt_le(my_groups > 1 ? dma_per_group : 0);   // group 0 landed, group 1 may still fly
   }
-  __syncthreads();
+  df_barrier();
 
   const int R = g.BI * g.BR;          // pixel rows of a group
   const int ppr = g.BC >> 1;          // pixel pairs per row
   for (int gi_ = 0; gi_ < my_groups; gi_++) {
-    const int buf = gi_ & 1;
     if (loader) {
-      if (gi_ + 1 < my_groups) commit(buf ^ 1);
-      if (gi_ + 2 < my_groups) issue(gi_ + 2);
+      // slot (gi_+2) % 3 was read during iteration gi_-1, which ended with a barrier
+      if (gi_ + 2 < my_groups) {
+        issue(gi_ + 2);
+        wait_vmcnt_le(dma_per_group);       // everything but the newest group: group gi_+1 landed
+      } else {
+        wait_vmcnt_le(0);
+      }
     } else {
-      const float* Xs = Xs0 + buf * xs_floats;
-      const float* Ds = Ds0 + buf * dy_floats + l31 * DLD + half;
+      const float* Xs = smem + (gi_ % kWgSlots) * slot_floats;
+      const float* Ds = Xs + xs_floats + l31 * DLD + half;
       for (int ri = lw; ri < R; ri += 4) {
         unsigned img = fast_div(ri, g.m_br);
         int r = ri - (int)img * g.BR;
@@ -1089,7 +1099,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
         }
       }
     }
-    __syncthreads();
+    df_barrier();
   }
 
   // cross-wave reduction through LDS, four tiles per round; matrix-core wave w finishes tile 4*round + w
@@ -1098,7 +1108,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
   constexpr int NTILES = OT * KT;
 #pragma unroll
   for (int round = 0; round < (NTILES + 3) / 4; round++) {
-    __syncthreads();
+    df_barrier();
     if (!loader) {
 #pragma unroll
       for (int tt = 0; tt < 4; tt++) {
@@ -1118,7 +1128,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
         }
       }
     }
-    __syncthreads();
+    df_barrier();
     int tile = round * 4 + lw;
     if (!loader && tile < NTILES) {
       int ti = tile / KT, tj = tile % KT;
@@ -1438,7 +1448,7 @@ int launch_wgrad(WGeo g, float* dw) {
   return DFHIP_OK;
 }
 
-template <int OT, int KT, int PIT, int DIT>
+template <int OT, int KT>
 int launch_wgrad_v2(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
   const int64_t n = (int64_t)g.O * g.C * g.k * g.k;
   float* slabs = dw;
@@ -1449,13 +1459,13 @@ int launch_wgrad_v2(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
   g.dst = slabs;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_v2<OT, KT, PIT, DIT>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_v2<OT, KT>,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)std::max(lds, (size_t)65536)));
     attr_lds = std::max(lds, (size_t)65536);
   }
   dim3 grid((unsigned)gx, (unsigned)ktg, (unsigned)otg);
-  hipLaunchKernelGGL((k_conv_wgrad_v2<OT, KT, PIT, DIT>), grid, dim3(512), lds, stream(), g);
+  hipLaunchKernelGGL((k_conv_wgrad_v2<OT, KT>), grid, dim3(512), lds, stream(), g);
   DF_LAUNCH_CHECK();
   if (gx > 1) {
     hipLaunchKernelGGL(k_flat_slab_sum, dim3((unsigned)df_ceil_div(n, 256)), dim3(1024), 0, stream(), slabs,
@@ -1478,18 +1488,18 @@ int run_wgrad_v2(WGeo g, float* dw) {
   bool ok = false;
   for (int tp : {128, 64, 32}) {
     plan_groups(g.N, g.oh, g.ow, tp, g.BI, g.BR, g.BC, gi, g.gr, g.gc);
-    if (g.BC != g.ow) continue;                    // whole rows only
+    if (g.BC != g.ow || g.N % g.BI != 0) continue;  // whole rows, whole groups only
+    if (g.oh % g.BR != 0) continue;                // equal row bands
     g.PR = (g.BR - 1) * g.stride + g.k;
     g.PC = (g.BC - 1) * g.stride + g.k;
     g.PE = g.BI * g.PR * g.PC;
     int BMP = g.BI * g.BR * g.BC, BMPP = (BMP + 7) & ~7;
     if ((g.BI * g.BR) % 4) continue;               // rows deal evenly to the four matrix-core waves
-    size_t stage = 2 * ((size_t)CH * g.PE + (size_t)OT * 32 * (BMPP + 1)) * 4;
+    size_t stage = (size_t)kWgSlots * ((size_t)CH * g.PE + (size_t)OT * 32 * (BMPP + 1)) * 4;
     size_t red = (size_t)4 * 4 * 16 * 64 * 4;
     lds = std::max(stage, red);
-    int pitems = (int)df_ceil_div(CH, 4) * (int)df_ceil_div(g.PE, 256);
-    int ditems = OT * 8 * (int)df_ceil_div(BMPP, 256);
-    if (lds <= 150 * 1024 && pitems <= 8 && ditems <= 4 * (OT == 1 ? 2 : 4) && g.PE < 65536) { ok = true; break; }
+    int dma = (int)df_ceil_div(g.PE, 64) * (int)df_ceil_div(CH, 4) + (int)df_ceil_div(BMP, 64) * OT * 8;
+    if (lds <= 156 * 1024 && g.PE <= 64 * kWgPSl && BMP <= 64 * kWgDSl && 2 * dma <= 62) { ok = true; break; }
   }
   if (!ok) return -1;
   g.CH = CH;
@@ -1501,8 +1511,8 @@ int run_wgrad_v2(WGeo g, float* dw) {
   g.m_br = magic_u32(g.BR);
   const int ktg = (int)df_ceil_div(KW, KT * 32), otg = (int)df_ceil_div(g.O, OT * 32);
   int gx = (int)std::max<int64_t>(1, std::min<int64_t>(g.ngroups, (int64_t)num_cus() / ((int64_t)ktg * otg)));
-  if (OT == 1) return launch_wgrad_v2<1, 5, 2, 2>(g, dw, lds, gx, ktg, otg);
-  return launch_wgrad_v2<2, 2, 2, 4>(g, dw, lds, gx, ktg, otg);
+  if (OT == 1) return launch_wgrad_v2<1, 5>(g, dw, lds, gx, ktg, otg);
+  return launch_wgrad_v2<2, 2>(g, dw, lds, gx, ktg, otg);
 }
 
 }  // namespace
