@@ -735,6 +735,7 @@ struct WGeo {
   int lds_floats;  // size of the staging region (also used for the cross-wave reduction)
   // v2 (producer-consumer) only: exact division by multiplication, magic = ceil(2^32 / d)
   unsigned m_prpc, m_pc, m_brbc, m_bc, m_br;
+  unsigned long long* stamps;   // diagnostics (DFHIP_CONV_STAMP)
 };
 
 template <int OT, int KT>
@@ -979,6 +980,14 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
   const int orows = min(OT * 32, g.O - o0);
   const int64_t xplane = (int64_t)g.H * g.W, yplane = (int64_t)g.oh * g.ow;
 
+  int stamp_i = 0;
+#define WG_STAMP()                                                                               \
+  do {                                                                                           \
+    if (g.stamps && lane == 0 && (wave == 0 || wave == 4) && stamp_i < 30)                       \
+      g.stamps[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2 + (wave == 4)) * 32 + stamp_i++] = \
+          __builtin_readcyclecounter();                                                          \
+  } while (0)
+  WG_STAMP();
   // every slot starts as zeros: dY rows of missing output channels and the pixel padding are
   // never written by the loaders
   for (int e = tid; e < kWgSlots * slot_floats; e += 512) smem[e] = 0.0f;
@@ -1057,13 +1066,17 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
   };
 
   df_barrier();                      // zero fill done
+  WG_STAMP();
   if (loader) {
     describe(0);
     if (my_groups > 0) issue(0);
     if (my_groups > 1) issue(1);
+    WG_STAMP();
     wait_vmcnt_le(my_groups > 1 ? dma_per_group : 0);   // group 0 landed, group 1 may still fly
   }
+  WG_STAMP();
   df_barrier();
+  WG_STAMP();
 
   const int R = g.BI * g.BR;          // pixel rows of a group
   const int ppr = g.BC >> 1;          // pixel pairs per row
@@ -1072,6 +1085,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
       // slot (gi_+2) % 3 was read during iteration gi_-1, which ended with a barrier
       if (gi_ + 2 < my_groups) {
         issue(gi_ + 2);
+        WG_STAMP();
         wait_vmcnt_le(dma_per_group);       // everything but the newest group: group gi_+1 landed
       } else {
         wait_vmcnt_le(0);
@@ -1099,7 +1113,9 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
         }
       }
     }
+    WG_STAMP();
     df_barrier();
+    WG_STAMP();
   }
 
   // cross-wave reduction through LDS, four tiles per round; matrix-core wave w finishes tile 4*round + w
@@ -1144,6 +1160,8 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
       }
     }
   }
+  WG_STAMP();
+#undef WG_STAMP
 }
 
 // out[i] = sum_s slabs[s][i], summed in a fixed order.  A block owns 256 consecutive elements
@@ -1465,8 +1483,31 @@ int launch_wgrad_v2(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
     attr_lds = std::max(lds, (size_t)65536);
   }
   dim3 grid((unsigned)gx, (unsigned)ktg, (unsigned)otg);
+  static int stamp_mode = -1;
+  if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
+  const size_t nstamp = (size_t)gx * ktg * otg * 2 * 32;
+  g.stamps = nullptr;
+  if (stamp_mode) {
+    g.stamps = (unsigned long long*)workspace2(nstamp * 8);
+    (void)hipMemsetAsync(g.stamps, 0, nstamp * 8, stream());
+  }
   hipLaunchKernelGGL((k_conv_wgrad_v2<OT, KT>), grid, dim3(512), lds, stream(), g);
   DF_LAUNCH_CHECK();
+  if (stamp_mode) {
+    std::vector<unsigned long long> h(nstamp);
+    (void)hipStreamSynchronize(stream());
+    (void)hipMemcpy(h.data(), g.stamps, nstamp * 8, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[wstamp] OT %d KT %d C %d O %d PE %d BI %d BR %d groups %d grid %d x %d x %d lds %zu\n", OT, KT, g.C,
+            g.O, g.PE, g.BI, g.BR, g.ngroups, gx, ktg, otg, lds);
+    for (size_t b : {(size_t)0, nstamp / 64 / 2}) {
+      for (int w = 0; w < 2; w++) {
+        fprintf(stderr, "[wstamp]  block %zu %s:", b, w ? "loader " : "compute");
+        unsigned long long t0 = h[(b * 2) * 32];
+        for (int i = 0; i < 32 && h[(b * 2 + w) * 32 + i]; i++) fprintf(stderr, " %lld", (long long)(h[(b * 2 + w) * 32 + i] - t0));
+        fprintf(stderr, "\n");
+      }
+    }
+  }
   if (gx > 1) {
     hipLaunchKernelGGL(k_flat_slab_sum, dim3((unsigned)df_ceil_div(n, 256)), dim3(1024), 0, stream(), slabs,
                        dw, n, gx);

@@ -1,0 +1,149 @@
+"""GPU parity at the BASELINE's full sizes (ResNet-18 CIFAR variant, batch 256): every conv
+layer shape forward / weight gradient / input gradient (both modes), BatchNorm2d, MaxPool2d and
+Adam, against the NumPy oracle (oracle/ref_ops.py), plus size-independent properties."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+N = 256
+LAYERS = {"stem": (3, 32, 32, 32, 3, 1, 1), "l1": (32, 16, 16, 32, 3, 1, 1), "l2a": (32, 16, 16, 64, 3, 2, 1),
+          "l2": (64, 8, 8, 64, 3, 1, 1), "l2d": (32, 16, 16, 64, 1, 2, 0), "l3a": (64, 8, 8, 128, 3, 2, 1),
+          "l3": (128, 4, 4, 128, 3, 1, 1), "l3d": (64, 8, 8, 128, 1, 2, 0), "l4a": (128, 4, 4, 256, 3, 2, 1),
+          "l4": (256, 2, 2, 256, 3, 1, 1), "l4d": (128, 4, 4, 256, 1, 2, 0),
+          "cnn2": (32, 16, 16, 64, 5, 1, 2)}
+
+
+def _arr(mod, a):
+    h = mod.Array(a.size)
+    mod.from_numpy(a, h)
+    return h
+
+
+def _back(mod, h, shape):
+    return mod.to_numpy(h, (h.size,), (1,), 0).reshape(shape)
+
+
+@pytest.mark.parametrize("name", list(LAYERS))
+def test_conv_layer_full_size(hip_device, name):
+    mod = hip_device.mod
+    C, H, W, O, k, s, p = LAYERS[name]
+    n = 64 if name == "cnn2" else N
+    oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    rng = np.random.default_rng(hash(name) % 1000)
+    x = rng.standard_normal((n, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((O, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+    dy = rng.standard_normal((n, O, oh, ow)).astype(np.float32)
+    geo = (n, C, H, W, O, k, s, p)
+    xh, wh, dyh = _arr(mod, x), _arr(mod, w), _arr(mod, dy)
+    yh = mod.Array(n * O * oh * ow)
+    mod.conv2d_forward(xh, wh, None, yh, *geo)
+    assert_close(_back(mod, yh, (n, O, oh, ow)), R.conv2d_forward(x, w, None, s, p), 1e-4, name + " forward")
+    dwh = mod.Array(w.size)
+    mod.conv2d_wgrad(xh, dyh, dwh, *geo)
+    assert_close(_back(mod, dwh, w.shape), R.conv2d_wgrad(x, dy, k, s, p), 1e-4, name + " wgrad")
+    dxh = mod.Array(x.size)
+    for mode in ("overwrite", "accumulate"):
+        mod.conv2d_dgrad(dyh, wh, dxh, *geo, mode=mode)
+        assert_close(_back(mod, dxh, x.shape), R.conv2d_dgrad(dy, w, x.shape, s, p, mode), 1e-4,
+                     f"{name} dgrad {mode}")
+
+
+def test_conv_linearity_and_bias(hip_device):
+    """conv(a*x1 + x2) == a*conv(x1) + conv(x2) (no bias); bias adds per output channel."""
+    mod = hip_device.mod
+    C, H, W, O, k, s, p = LAYERS["l2"]
+    geo = (N, C, H, W, O, k, s, p)
+    rng = np.random.default_rng(5)
+    x1 = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    x2 = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((O, C, k, k)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(O).astype(np.float32)
+    out = []
+    for xx, bias in ((x1, None), (x2, None), (np.float32(2.0) * x1 + x2, None), (x1, b)):
+        yh = mod.Array(N * O * H * W)
+        mod.conv2d_forward(_arr(mod, xx), _arr(mod, w), _arr(mod, bias) if bias is not None else None, yh, *geo)
+        out.append(_back(mod, yh, (N, O, H, W)))
+    assert_close(out[2], np.float32(2.0) * out[0] + out[1], 1e-4, "linearity")
+    assert_close(out[3], out[0] + b.reshape(1, O, 1, 1), 1e-6, "bias epilogue")
+
+
+@pytest.mark.parametrize("shape", [(256, 32, 32, 32), (256, 64, 8, 8), (256, 256, 2, 2)])
+def test_batchnorm_full_size(hip_device, shape):
+    mod = hip_device.mod
+    n, c, h, w = shape
+    rng = np.random.default_rng(c)
+    x = (rng.standard_normal(shape) * 1.7 + 0.3).astype(np.float32)
+    gam = rng.standard_normal((1, c, 1, 1)).astype(np.float32)
+    bet = rng.standard_normal((1, c, 1, 1)).astype(np.float32)
+    dy = rng.standard_normal(shape).astype(np.float32)
+    xh, yh = _arr(mod, x), mod.Array(x.size)
+    mean, var = mod.Array(c), mod.Array(c)
+    rm, rv = _arr(mod, np.zeros(c, np.float32)), _arr(mod, np.ones(c, np.float32))
+    mod.bn2d_forward_train(xh, _arr(mod, gam), _arr(mod, bet), yh, mean, var, rm, rv, n, c, h * w, 1e-5, 0.1)
+    y_ref, m_ref, v_ref = R.batchnorm2d_train(x, gam, bet)
+    assert_close(_back(mod, yh, shape), y_ref, 1e-4, "bn y")
+    assert_close(_back(mod, mean, (1, c, 1, 1)), m_ref, 1e-4, "bn mean")
+    assert_close(_back(mod, var, (1, c, 1, 1)), v_ref, 1e-4, "bn var")
+    assert_close(_back(mod, rv, (1, c, 1, 1)), 0.9 + 0.1 * v_ref, 1e-4, "running var")
+    dx, dg, db = mod.Array(x.size), mod.Array(c), mod.Array(c)
+    mod.bn2d_backward(_arr(mod, dy), xh, _arr(mod, gam), mean, var, dx, dg, db, n, c, h * w, 1e-5)
+    dx_ref, dg_ref, db_ref = R.batchnorm2d_backward(dy, x, gam, m_ref, v_ref)
+    assert_close(_back(mod, dx, shape), dx_ref, 2e-4, "bn dx")
+    assert_close(_back(mod, dg, (1, c, 1, 1)), dg_ref, 1e-4, "bn dgamma")
+    assert_close(_back(mod, db, (1, c, 1, 1)), db_ref, 1e-4, "bn dbeta")
+
+
+def test_maxpool_full_size(hip_device):
+    mod = hip_device.mod
+    rng = np.random.default_rng(3)
+    x = rng.integers(-4, 5, size=(256, 32, 32, 32)).astype(np.float32)   # many ties
+    dy = rng.standard_normal((256, 32, 16, 16)).astype(np.float32)
+    xh, yh, dxh = _arr(mod, x), mod.Array(256 * 32 * 256), mod.Array(x.size)
+    mod.maxpool2d_forward(xh, yh, 256 * 32, 32, 32, 2)
+    y = _back(mod, yh, (256, 32, 16, 16))
+    assert np.array_equal(y, R.maxpool2d_forward(x, 2))
+    mod.maxpool2d_backward(xh, yh, _arr(mod, dy), dxh, 256 * 32, 32, 32, 2)
+    assert np.array_equal(_back(mod, dxh, x.shape), R.maxpool2d_backward(x, y, dy, 2))
+
+
+def test_adam_full_parameter_set(hip_device):
+    """All 62 ResNet-18 tensors (2 797 610 elements) in one multi-tensor launch, 2 steps."""
+    mod = hip_device.mod
+    rng = np.random.default_rng(11)
+    sizes = [864, 32, 32] + [9216, 32, 32] * 4 + [18432, 64, 64, 2048, 64, 64, 36864, 64, 64] + [36864, 64, 64] * 2 + \
+            [73728, 128, 128, 8192, 128, 128] + [147456, 128, 128] * 3 + [294912, 256, 256, 32768, 256, 256] + \
+            [589824, 256, 256] * 3 + [2560, 10]
+    ps = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+    vs = [np.zeros(n, np.float32) for n in sizes]
+    ss = [np.zeros(n, np.float32) for n in sizes]
+    ph, vh, sh = [_arr(mod, a) for a in ps], [_arr(mod, a) for a in vs], [_arr(mod, a) for a in ss]
+    for t in (1, 2):
+        gs = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+        mod.adam_step(ph, [_arr(mod, g) for g in gs], vh, sh, 1e-3, 0.9, 0.999, 1e-8, 5e-4, t)
+        for i in range(len(sizes)):
+            ps[i], vs[i], ss[i] = R.adam_step(ps[i], gs[i], vs[i], ss[i], t, 1e-3, wd=5e-4)
+    for i in (0, 3, 20, 40, 58, 60, 61):
+        assert_close(_back(mod, ph[i], (sizes[i],)), ps[i], 1e-5, f"adam param {i}")
+
+
+def test_elementwise_checksum_at_scale(hip_device):
+    """a + b, a * b and relu on 8.4 M elements (the stem activation): exact against NumPy."""
+    mod = hip_device.mod
+    rng = np.random.default_rng(1)
+    n = 256 * 32 * 32 * 32 + 3              # not a multiple of 4: exercises the scalar tail
+    a = rng.standard_normal(n).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    ah, bh, oh_ = _arr(mod, a), _arr(mod, b), mod.Array(n)
+    mod.ewise_add(ah, bh, oh_)
+    assert np.array_equal(_back(mod, oh_, (n,)), a + b)
+    mod.ewise_mul(ah, bh, oh_)
+    assert np.array_equal(_back(mod, oh_, (n,)), a * b)
+    mod.relu_forward(ah, oh_)
+    assert np.array_equal(_back(mod, oh_, (n,)), np.maximum(a, 0))
+    s = mod.Array(1)
+    mod.reduce_sum(ah, s, n)
+    assert abs(float(_back(mod, s, (1,))[0]) - float(a.astype(np.float64).sum())) < 1e-4 * np.abs(a).sum()
