@@ -234,473 +234,223 @@ __global__ __launch_bounds__(256) void k_conv_igemm(Geo g) {
   }
 }
 
-// ---- staging helpers of the producer-consumer kernel ------------------------------------
-// Staging is split into ISSUE (global loads into registers) and COMMIT (LDS stores) so that the
-// loads of chunk c+2 are in flight while chunk c is in the matrix cores: a loader thread keeps up
-// to 2 x 16 patch elements and 10 float4 weight vectors outstanding across a barrier.
-constexpr int kMaxItems = 2;   // patch items (4 channels x 4 slices of 64 elements) per loader wave
-constexpr int kWU = 10;        // float4 weight vectors per loader thread
-
-struct PatchRegs {
-  int go[kMaxItems][4];
-  float v[kMaxItems][4][4];
-};
-struct WeightRegs {
-  float4 v[kWU];
-};
-
-__device__ __forceinline__ void patch_issue(const Geo& g, const float* __restrict__ src_base,
-                                            const int* __restrict__ goff, int CCP, int64_t plane,
-                                            int nthreads, int t0, PatchRegs& R) {
-  const int nw = nthreads >> 6, w0 = t0 >> 6, ln = t0 & 63;
-  const int nsg = (g.PE + 255) >> 8;
-  const int nitems = nsg * (CCP >> 2);
-#pragma unroll
-  for (int it = 0; it < kMaxItems; it++) {
-    const int item = w0 + it * nw;
-    const bool live = item < nitems;
-    const int cg = live ? item / nsg : 0, sg = live ? item - cg * nsg : 0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      int j = (sg * 4 + u) * 64 + ln;
-      R.go[it][u] = (live && j < g.PE) ? goff[j] : -1;
-    }
-#pragma unroll
-    for (int cc = 0; cc < 4; cc++) {
-      const float* base = src_base + (int64_t)(cg * 4 + cc) * plane;
-#pragma unroll
-      for (int u = 0; u < 4; u++) R.v[it][cc][u] = base[R.go[it][u] >= 0 ? R.go[it][u] : 0];
-    }
-  }
-}
-
-__device__ __forceinline__ void patch_commit(const Geo& g, float* __restrict__ Xs, int CCP,
-                                             int nthreads, int t0, const PatchRegs& R) {
-  const int nw = nthreads >> 6, w0 = t0 >> 6, ln = t0 & 63;
-  const int nsg = (g.PE + 255) >> 8;
-  const int nitems = nsg * (CCP >> 2);
-#pragma unroll
-  for (int it = 0; it < kMaxItems; it++) {
-    const int item = w0 + it * nw;
-    if (item < nitems) {
-      const int cg = item / nsg, sg = item - cg * nsg;
-#pragma unroll
-      for (int cc = 0; cc < 4; cc++)
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          int j = (sg * 4 + u) * 64 + ln;
-          if (j < g.PE) Xs[(cg * 4 + cc) * g.PE + j] = R.go[it][u] >= 0 ? R.v[it][cc][u] : 0.0f;
-        }
-    }
-  }
-}
-
-// Weights of one channel chunk keep their GLOBAL order in LDS, so a commit is a plain float4
-// store with no per-element decode:
-//   forward (MODE 0): W[d0+d][cb+c][t]  -> Wl[d * RS + c*k2 + t],  RS = CCP*k2 + 4
-//            (lanes of the A-operand read run along d: row stride = 4 mod 32 -> 4-way bank
-//            conflict on one ds_read_b32 per two MFMAs, far below the LDS budget)
-//   dgrad   (MODE 1): W[cb+c][d0+d][t]  -> Wl[c * 32*k2 + d*k2 + t]
-//            (lanes run along d with stride k2, odd -> conflict-free)
-// Rows start 16-byte aligned in global memory (channel counts are multiples of 8).
-template <int KS, int MODE>
-__device__ __forceinline__ int wl_row_stride(int CCP) {
-  return MODE == 0 ? CCP * KS * KS + 4 : 32 * KS * KS;
-}
-
-template <int KS, int MODE>
-__device__ __forceinline__ void weights_issue(const Geo& g, int CCP, int cb, int d0, int nthreads,
-                                              int t0, WeightRegs& R) {
-  constexpr int k2 = KS * KS;
-  const int run4 = (MODE == 0 ? CCP * k2 : 32 * k2) >> 2;
-  const int nrows = MODE == 0 ? 32 : CCP;
-  const int total4 = run4 * nrows;
-  const int dmax = min(32, g.CD - d0);
-  const int dr = nthreads / run4, de = nthreads - dr * run4;
-  int f = t0 < total4 ? t0 : t0 % total4;
-  int row = f / run4, e4 = f - row * run4;
-#pragma unroll
-  for (int u = 0; u < kWU; u++) {
-    int64_t src;
-    if (MODE == 0) {
-      int d = row < dmax ? row : 0;
-      src = ((int64_t)(d0 + d) * g.wC + cb) * k2 + 4 * e4;
-    } else {
-      int e = 4 * e4;
-      e = e + 3 < dmax * k2 ? e : 0;
-      src = ((int64_t)(cb + row) * g.wC + d0) * k2 + e;
-    }
-    R.v[u] = *reinterpret_cast<const float4*>(g.wgt + src);
-    // next vector of this thread (f += nthreads), wrapping dead slots onto live vectors
-    row += dr;
-    e4 += de;
-    if (e4 >= run4) { e4 -= run4; row++; }
-    if (row >= nrows) row -= nrows * (row / nrows);
-  }
-}
-
-template <int KS, int MODE>
-__device__ __forceinline__ void weights_commit(const Geo& g, float* __restrict__ Wl, int CCP, int d0,
-                                               int nthreads, int t0, const WeightRegs& R) {
-  constexpr int k2 = KS * KS;
-  const int run4 = (MODE == 0 ? CCP * k2 : 32 * k2) >> 2;
-  const int nrows = MODE == 0 ? 32 : CCP;
-  const int total4 = run4 * nrows;
-  const int RS = wl_row_stride<KS, MODE>(CCP);
-  const int dmax = min(32, g.CD - d0);
-  const int dr = nthreads / run4, de = nthreads - dr * run4;
-  int row = t0 / run4, e4 = t0 - row * run4;
-#pragma unroll
-  for (int u = 0; u < kWU; u++) {
-    if (t0 + nthreads * u < total4) {
-      float4 v = R.v[u];
-      if (MODE == 0) {
-        if (row >= dmax) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else if (dmax < 32) {          // partial destination tile: zero the channels that do not exist
-        float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int qd = 0; qd < 4; qd++)
-          if ((4 * e4 + qd) / k2 >= dmax || 4 * e4 + 3 >= dmax * k2) vv[qd] = 0.0f;
-        v = make_float4(vv[0], vv[1], vv[2], vv[3]);
-      }
-      *reinterpret_cast<float4*>(Wl + row * RS + 4 * e4) = v;
-    }
-    row += dr;
-    e4 += de;
-    if (e4 >= run4) { e4 -= run4; row++; }
-  }
-}
-
 // ---------------------------------------------------------------------------------------
-// forward / input-gradient, producer-consumer form (source channels % 8 == 0, k in {1,3,5}).
+// forward / input-gradient, main kernel (source channels % 8 == 0, k in {1,3}).
 //
 // One workgroup = one job = (pixel group of PT 32-pixel tiles) x (32 destination channels) over
-// the WHOLE reduction; 12 waves:
-//   waves 0-7  matrix-core waves, two per SIMD so one wave's LDS wait hides behind the other's
-//              MFMAs.  Wave w owns pixel tile  w % PT  and the k-split slice  w / PT  (KSPLIT =
-//              8 / PT slices of every channel chunk); the KSPLIT partial accumulators of a tile
-//              are summed through LDS at the end - no partial slabs in HBM, no second kernel;
-//   waves 8-11 loaders: stage the NEXT channel chunk (patch through the gather table, weights
-//              transposed to [tap][channel][dest]) into the other LDS buffer, all global loads
-//              of a thread issued before its first LDS store; one barrier per chunk.
-// The host picks PT in {8,4,2,1} so that every ResNet-18 layer at batch 256 becomes ~256 jobs
-// (one per CU) of equal matrix-core work: 144 MFMAs per wave.
-// K is ordered (tap, channel): inside a tap the operand addresses advance by constants.
-// Overwrite mode: a tap that no lane of the wave selects contributes exact zeros and is skipped.
+// the whole reduction.  All 8 waves run the matrix cores (two per SIMD, so one wave's LDS wait
+// hides behind the other's MFMAs): wave w owns pixel tile  w % PT  and slice  w / PT  of the
+// KSPLIT = 8 / PT slices of every channel chunk; the KSPLIT partial accumulators of a tile are
+// summed through LDS at the end (no partial slabs in HBM, no second kernel).  The host picks PT
+// so that every ResNet-18 layer at batch 256 is ~256-512 jobs of 144 MFMAs per wave.
+//
+// Staging moves the source planes AS THEY ARE (no halo, no gather): for one channel chunk the
+// LDS image is [channel][image][rows x W], filled with 16-byte loads whose addresses are a
+// scalar chunk base + a 32-bit lane offset computed once per job.  Padding, dilation (strided
+// input gradient) and the "last writer" tap selection of the overwrite mode are handled on the
+// READ side instead: every lane keeps, per tap, the LDS offset of its pixel's source element
+// and one validity bit; an invalid (pixel, tap) reads offset 0 and is zeroed by a select, and a
+// tap that is invalid for every lane of the wave is skipped.  A chunk is loaded into registers
+// while the previous one is in the matrix cores and stored to the other LDS buffer before the
+// barrier: a thread moves ~1 patch vector and ~1-5 weight vectors per chunk.
+//
+// Weights keep their GLOBAL order in LDS (a commit is a plain float4 store):
+//   forward:  W[d0+d][cb+c][t] -> Wl[d * RS + c*k2 + t], RS = CCP*k2 + 4  (A-operand lanes run
+//             along d: 4-way bank conflict on one ds_read_b32 per MFMA, well inside LDS budget)
+//   dgrad:    W[cb+c][d0+d][t] -> Wl[c * 32*k2 + d*k2 + t]                (stride k2: conflict-free)
 // ---------------------------------------------------------------------------------------
-template <int KS, int MODE, int NPK, int NTW>
-__global__ __launch_bounds__(512) void k_conv_igemm_v3(Geo g) {
+constexpr int kPV = 2;   // patch float4 vectors per thread per chunk
+constexpr int kWV = 5;   // weight float4 vectors per thread per chunk
+
+template <int KS, int MODE>
+__global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int k = KS, k2 = KS * KS;
-  constexpr int WM = MODE == 0 ? 0 : 1;
-  const int CCP = g.CC;                 // channels per chunk: 8, 16 or 32
-  const int RS = wl_row_stride<KS, WM>(CCP);
-  const int xs_floats = CCP * g.PE;
+  const int CCP = g.CC;                       // channels per chunk: 8, 16 or 32
+  const int RS = MODE == 0 ? CCP * k2 + 4 : 32 * k2;
+  const int PEp = g.PE;                       // floats per channel in the LDS image: BI * RL
+  const int xs_floats = CCP * PEp;
   const int ws_floats = (MODE == 0 ? 32 : CCP) * RS;
   float* Xs0 = smem;
   float* Ws0 = Xs0 + 2 * xs_floats;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const bool loader = wave >= 4;
-  int stamp_i = 0;
-#define DF_STAMP()                                                                              \
-  do {                                                                                          \
-    if (g.stamps && lane == 0 && (wave == 0 || wave == 4) && stamp_i < 30)                      \
-      g.stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave == 4)) * 32 + stamp_i++] = \
-          __builtin_readcyclecounter();                                                         \
-  } while (0)
-  DF_STAMP();
-  // PT 32-pixel tiles per workgroup; a matrix-core wave owns NTW of them (two when PT >= 2, so
-  // the weight operand is read once for two MFMAs) and one of the KSPLIT slices of every chunk
-  const int PT = g.PT;
-  const int tgroups = PT / NTW;         // wave groups along the pixel tiles
-  const int KSPLIT = 4 / tgroups;
-  const int tw = (wave & 3) % tgroups, ks = (wave & 3) / tgroups;
+  const int PT = g.PT, KSPLIT = 8 / g.PT;
+  const int pt = wave % PT, ks = wave / PT;
 
   int gx = blockIdx.x;
-  const int gcx = gx % g.gc; gx /= g.gc;
   const int grx = gx % g.gr; gx /= g.gr;
-  const int n0 = gx * g.BI, r0 = grx * g.BR, c0 = gcx * g.BC;
+  const int n0 = gx * g.BI, r0 = grx * g.BR;
   const int d0 = blockIdx.y * 32;
   const int nchunks = g.CS / CCP;
   const int64_t src_plane = (int64_t)g.HS * g.WS;
+  // source rows this group needs (clipped to the image): [su_lo, su_lo + RLr)
+  const int RL = PEp / g.BI;                  // floats per (image, channel) in LDS = RLr * WS
+  // first staged source row: the first row the band can touch, pulled back so that the RLr staged
+  // rows never run past the image
+  const int su_lo = min(max(0, (r0 * g.so + g.u0 >= 0 ? (r0 * g.so + g.u0) / g.sd : 0)), g.HS - RL / g.WS);
 
-  // the wave's pixel tiles
-  int abase[2], tapsel[2];
-  bool pvalid[2];
-  int64_t out_off[2];
-#pragma unroll
-  for (int e = 0; e < 2; e++) {
-    int q = (tw * NTW + e) * 32 + l31, img, r, col;
-    decode_pixel(g, q, img, r, col);
-    pvalid[e] = e < NTW && q < g.BI * g.BR * g.BC && n0 + img < g.N && r0 + r < g.HD && c0 + col < g.WD;
-    abase[e] = (pvalid[e] ? img * g.PR * g.PC + r * g.so * g.PC + col * g.so : 0) + half * g.PE;
-    tapsel[e] = -2;
-    if (MODE == 2 && pvalid[e]) {
+  // ---- per-lane, per-tap read descriptors of this wave's pixel tile ----
+  int q = pt * 32 + l31, img, r, col;
+  decode_pixel(g, q, img, r, col);
+  const bool pvalid = q < g.BI * g.BR * g.BC && n0 + img < g.N && r0 + r < g.HD;
+  int poff[k2];
+  unsigned vmask = 0;
+  {
+    int tapsel = -2;
+    if (MODE == 2 && pvalid) {
       int ti = last_tap(r0 + r + g.pad, k, g.stride, g.oh);
-      int tj = last_tap(c0 + col + g.pad, k, g.stride, g.ow);
-      tapsel[e] = (ti < 0 || tj < 0) ? -1 : ti * k + tj;
+      int tj = last_tap(col + g.pad, k, g.stride, g.ow);
+      tapsel = (ti < 0 || tj < 0) ? -1 : ti * k + tj;
     }
-    out_off[e] = (int64_t)(n0 + img) * g.CD * g.HD * g.WD + (int64_t)(r0 + r) * g.WD + (c0 + col);
+#pragma unroll
+    for (int t = 0; t < k2; t++) {
+      const int i = t / k, j = t - i * k;
+      const int ti = MODE == 0 ? i : k - 1 - i, tj = MODE == 0 ? j : k - 1 - j;
+      int un = (r0 + r) * g.so + g.u0 + ti, vn = col * g.so + g.u0 + tj;
+      bool ok = pvalid && un >= 0 && vn >= 0;
+      int su = ok ? un / g.sd : 0, sv = ok ? vn / g.sd : 0;
+      ok = ok && su * g.sd == un && sv * g.sd == vn && su < g.HS && sv < g.WS;
+      if (MODE == 2) ok = ok && tapsel == t;
+      poff[t] = ok ? img * RL + (su - su_lo) * g.WS + sv : 0;
+      vmask |= ok ? (1u << t) : 0u;
+    }
   }
 
-  // ---- loader descriptors: everything that does not depend on the chunk is computed ONCE ----
-  // per thread (source offsets inside a channel plane, LDS destinations, weight vector offsets);
-  // per chunk a loader then only adds a wave-uniform base pointer (scalar) to 32-bit lane
-  // offsets, so staging a chunk is ~40 loads + ~70 LDS stores and almost no VALU.
-  const int lw = __builtin_amdgcn_readfirstlane(wave) & 3;
-  const int lt = tid & 255;
-  int p_go[kMaxItems][4];     // >= 0 source offset, -1 = padding (store zero), -2 = no such element
-  int p_lx[kMaxItems];        // LDS float index of (first channel of the item, first slice, lane)
-  int p_cg[kMaxItems];        // first channel of the item (wave-uniform), -1 = no item
-  unsigned w_off[kWU];        // float offset of the vector relative to the chunk's weight base
-  int w_lx[kWU];              // LDS float index, -1 = dead slot
-  if (loader) {
-    const int nsg = (g.PE + 255) >> 8;
-    const int nitems = nsg * (CCP >> 2);
-    const int per_img = g.PR * g.PC;
+  // ---- staging descriptors (chunk-invariant) ----
+  // patch: vector v of the chunk image -> (channel c, image, q4); LDS float index = 4 * v
+  const int RL4 = RL >> 2;
+  const int pvecs = CCP * g.BI * RL4;
+  unsigned p_src[kPV];
 #pragma unroll
-    for (int it = 0; it < kMaxItems; it++) {
-      const int item = lw + 4 * it;
-      const bool live = item < nitems;
-      const int cg = live ? item / nsg : 0, sg = live ? item - cg * nsg : 0;
-      p_cg[it] = live ? cg * 4 : -1;
-      p_lx[it] = (cg * 4) * g.PE + sg * 256 + lane;
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int j = sg * 256 + u * 64 + lane;
-        int go = -2;
-        if (live && j < g.PE) {
-          int img = (int)fast_div((unsigned)j, g.m_perimg);
-          int rem = j - img * per_img;
-          int pr = (int)fast_div((unsigned)rem, g.m_pc), pc = rem - pr * g.PC;
-          int uu = r0 * g.so + g.u0 + pr, vv = c0 * g.so + g.u0 + pc;
-          bool ok = (n0 + img < g.N) && uu >= 0 && vv >= 0;
-          int su = ok ? (int)fast_div((unsigned)uu, g.m_sd) : 0, sv = ok ? (int)fast_div((unsigned)vv, g.m_sd) : 0;
-          ok = ok && su * g.sd == uu && sv * g.sd == vv && su < g.HS && sv < g.WS;
-          go = ok ? (int)((int64_t)img * g.CS * src_plane + (int64_t)su * g.WS + sv) : -1;
-        }
-        p_go[it][u] = go;
-      }
-    }
-    const int run4 = (MODE == 0 ? CCP * k2 : 32 * k2) >> 2;
-    const int total4 = run4 * (MODE == 0 ? 32 : CCP);
-    const int dmax = min(32, g.CD - d0);
-    const unsigned m_run4 = (unsigned)((((uint64_t)1 << 32) + run4 - 1) / (unsigned)run4);
-#pragma unroll
-    for (int u = 0; u < kWU; u++) {
-      const int f = lt + 256 * u;
-      const bool live = f < total4;
-      const int ff = live ? f : 0;
-      const int row = run4 > 1 ? (int)__umulhi((unsigned)ff, m_run4) : ff, e4 = ff - row * run4;
-      if (MODE == 0) {
-        const bool ok = row < dmax;
-        w_off[u] = (unsigned)(((d0 + (ok ? row : 0)) * g.wC) * k2 + 4 * e4);
-      } else {
-        w_off[u] = (unsigned)((row * g.wC + d0) * k2 + 4 * e4);   // host guarantees CD % 32 == 0
-      }
-      w_lx[u] = live ? row * RS + 4 * e4 : -1;
-    }
-  } else {
-#pragma unroll
-    for (int it = 0; it < kMaxItems; it++) {
-      p_cg[it] = -1; p_lx[it] = 0;
-#pragma unroll
-      for (int u = 0; u < 4; u++) p_go[it][u] = -2;
-    }
-#pragma unroll
-    for (int u = 0; u < kWU; u++) { w_off[u] = 0; w_lx[u] = -1; }
+  for (int u = 0; u < kPV; u++) {
+    int v = tid + 512 * u;
+    v = v < pvecs ? v : 0;
+    int c = v / (g.BI * RL4);
+    int rem = v - c * (g.BI * RL4);
+    int im = rem / RL4, q4 = rem - im * RL4;
+    int imc = min(im, g.N - 1 - n0);            // images past the batch end are never read
+    p_src[u] = (unsigned)(((int64_t)imc * g.CS + c) * src_plane + (int64_t)su_lo * g.WS + 4 * q4);
   }
-  const int dmax_ = min(32, g.CD - d0);
-  float p_v[kMaxItems][4][4];
-  float4 w_v[kWU];
-  auto issue = [&](int chunk) {
-    const float* wb = g.wgt + (int64_t)chunk * CCP * (MODE == 0 ? k2 : g.wC * k2);
+  const int run4 = (MODE == 0 ? CCP * k2 : 32 * k2) >> 2;
+  const int wvecs = run4 * (MODE == 0 ? 32 : CCP);
+  const int dmax = min(32, g.CD - d0);
+  unsigned w_src[kWV];
+  int w_lx[kWV];
 #pragma unroll
-    for (int u = 0; u < kWU; u++) w_v[u] = *reinterpret_cast<const float4*>(wb + w_off[u]);
-    const float* xb = g.src + ((int64_t)n0 * g.CS + (int64_t)chunk * CCP) * src_plane;
-#pragma unroll
-    for (int it = 0; it < kMaxItems; it++) {
-      if (p_cg[it] >= 0) {
-#pragma unroll
-        for (int cc = 0; cc < 4; cc++) {
-          const float* cbp = xb + (int64_t)(p_cg[it] + cc) * src_plane;
-#pragma unroll
-          for (int u = 0; u < 4; u++) p_v[it][cc][u] = cbp[p_go[it][u] > 0 ? p_go[it][u] : 0];
-        }
-      }
-    }
-  };
-  auto commit = [&](int buf) {
-    float* Xs = Xs0 + buf * xs_floats;
-    float* Wl = Ws0 + buf * ws_floats;
-#pragma unroll
-    for (int it = 0; it < kMaxItems; it++) {
-      if (p_cg[it] >= 0) {
-#pragma unroll
-        for (int cc = 0; cc < 4; cc++)
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            if (p_go[it][u] > -2) Xs[p_lx[it] + cc * g.PE + u * 64] = p_go[it][u] >= 0 ? p_v[it][cc][u] : 0.0f;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kWU; u++) {
-      if (w_lx[u] >= 0) {
-        float4 v = w_v[u];
-        if (MODE == 0 && dmax_ < 32 && w_lx[u] / RS >= dmax_) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(Wl + w_lx[u]) = v;
-      }
-    }
-  };
-
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int rr = 0; rr < 16; rr++) { acc0[rr] = 0.0f; acc1[rr] = 0.0f; }
-
-  DF_STAMP();
-  if (loader) {
-    __builtin_amdgcn_s_setprio(1);
-    issue(0);
-    commit(0);
-    DF_STAMP();
-    if (nchunks > 1) issue(1);
+  for (int u = 0; u < kWV; u++) {
+    int f = tid + 512 * u;
+    const bool live = f < wvecs;
+    f = live ? f : 0;
+    int row = f / run4, e4 = f - row * run4;
+    if (MODE == 0) w_src[u] = (unsigned)(((d0 + min(row, dmax - 1)) * g.wC) * k2 + 4 * e4);
+    else w_src[u] = (unsigned)((row * g.wC + d0) * k2 + 4 * e4);     // host guarantees CD % 32 == 0
+    w_lx[u] = live ? ((MODE == 0 && row >= dmax) ? -2 : row * RS + 4 * e4) : -1;
   }
+
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 pv0, pv1, wv0, wv1, wv2, wv3, wv4;
+#define DF_ISSUE(chunk)                                                                          \
+  do {                                                                                           \
+    const float* wb = g.wgt + (int64_t)(chunk) * CCP * (MODE == 0 ? k2 : g.wC * k2);            \
+    wv0 = *reinterpret_cast<const f32x4*>(wb + w_src[0]);                                        \
+    wv1 = *reinterpret_cast<const f32x4*>(wb + w_src[1]);                                        \
+    wv2 = *reinterpret_cast<const f32x4*>(wb + w_src[2]);                                        \
+    wv3 = *reinterpret_cast<const f32x4*>(wb + w_src[3]);                                        \
+    wv4 = *reinterpret_cast<const f32x4*>(wb + w_src[4]);                                        \
+    const float* xb = g.src + ((int64_t)n0 * g.CS + (int64_t)(chunk) * CCP) * src_plane;         \
+    pv0 = *reinterpret_cast<const f32x4*>(xb + p_src[0]);                                        \
+    pv1 = *reinterpret_cast<const f32x4*>(xb + p_src[1]);                                        \
+  } while (0)
+#define DF_WSTORE(u, val)                                                                        \
+  do {                                                                                           \
+    if (w_lx[u] >= 0) *reinterpret_cast<f32x4*>(Wl_ + w_lx[u]) = (val);                          \
+    else if (w_lx[u] == -2) {                                                                    \
+      int f_ = tid + 512 * (u);                                                                  \
+      int row_ = f_ / run4, e4_ = f_ - row_ * run4;                                              \
+      *reinterpret_cast<f32x4*>(Wl_ + row_ * RS + 4 * e4_) = (f32x4){0.f, 0.f, 0.f, 0.f};        \
+    }                                                                                            \
+  } while (0)
+#define DF_COMMIT(buf)                                                                           \
+  do {                                                                                           \
+    float* Xs_ = Xs0 + (buf) * xs_floats;                                                        \
+    float* Wl_ = Ws0 + (buf) * ws_floats;                                                        \
+    if (tid < pvecs) *reinterpret_cast<f32x4*>(Xs_ + 4 * tid) = pv0;                             \
+    if (tid + 512 < pvecs) *reinterpret_cast<f32x4*>(Xs_ + 4 * (tid + 512)) = pv1;               \
+    DF_WSTORE(0, wv0); DF_WSTORE(1, wv1); DF_WSTORE(2, wv2); DF_WSTORE(3, wv3); DF_WSTORE(4, wv4); \
+  } while (0)
+
+  f32x16 acc;
+#pragma unroll
+  for (int rr = 0; rr < 16; rr++) acc[rr] = 0.0f;
+
+  DF_ISSUE(0);
+  DF_COMMIT(0);
   __syncthreads();
-  DF_STAMP();
 
-  // k pairs of a tap that this wave owns (>= 1); a compile-time count lets the tap x pair nest
-  // unroll into straight-line code whose LDS reads are hoisted ahead of the MFMAs
-  const int npk = NPK ? NPK : (CCP >> 1) / KSPLIT;
-  const int c_first = 2 * ks * npk;     // first channel of the wave's slice inside a chunk
+  const int npk = (CCP >> 1) / KSPLIT;        // k pairs of a tap that this wave owns (>= 1)
+  const int c_first = 2 * ks * npk + half;    // this lane's first channel inside a chunk
+  const int astep = MODE == 0 ? 2 * k2 : 2 * RS;
+  const int bstep = 2 * PEp;
   for (int ch = 0; ch < nchunks; ch++) {
     const int buf = ch & 1;
-    if (loader) {
-      // chunk ch+1 (loaded during the previous iteration) goes to the buffer the matrix cores
-      // finished with at the last barrier; chunk ch+2 is put in flight for the next iteration
-      if (!(g.dbg & 1)) {
-        if (ch + 1 < nchunks) commit(buf ^ 1);
-        DF_STAMP();
-        if (ch + 2 < nchunks) issue(ch + 2);
-      }
-    } else if (!(g.dbg & 2)) {
-      const float* Xb = Xs0 + buf * xs_floats + c_first * g.PE;
-      const float* bq0 = Xb + abase[0];
-      const float* bq1 = Xb + abase[1];
-      // A operand: weights in global order (see wl_row_stride)
-      const float* aq = Ws0 + buf * ws_floats +
-                        (MODE == 0 ? l31 * RS + (c_first + half) * k2 : (c_first + half) * RS + l31 * k2);
-      const int astep = MODE == 0 ? 2 * k2 : 2 * RS;   // per k pair
-      const int bstep = 2 * g.PE;
-      if (NPK > 0 && MODE != 2) {
-        // one flat, fully unrolled sequence over (tap, pair) with the operands of step s+1 read
-        // from LDS before the MFMAs of step s are issued
-        constexpr int NS = k2 * (NPK > 0 ? NPK : 1);
-        auto offB = [&](int sidx) {
-          int t = sidx / (NPK > 0 ? NPK : 1), pp = sidx - t * (NPK > 0 ? NPK : 1);
-          int i = t / k, j = t - i * k;
-          return (MODE == 0 ? i * g.PC + j : (k - 1 - i) * g.PC + (k - 1 - j)) + pp * bstep;
-        };
-        auto offA = [&](int sidx) {
-          int t = sidx / (NPK > 0 ? NPK : 1), pp = sidx - t * (NPK > 0 ? NPK : 1);
-          return t + pp * astep;
-        };
-        float a_c = aq[offA(0)], b0_c = bq0[offB(0)], b1_c = NTW == 2 ? bq1[offB(0)] : 0.0f;
+    if (ch + 1 < nchunks) DF_ISSUE(ch + 1);    // lands while this chunk is in the matrix cores
+    const float* Xb = Xs0 + buf * xs_floats + c_first * PEp;
+    const float* aq = Ws0 + buf * ws_floats + (MODE == 0 ? l31 * RS + c_first * k2 : c_first * RS + l31 * k2);
 #pragma unroll
-        for (int sidx = 0; sidx < NS; sidx++) {
-          float a_n = a_c, b0_n = b0_c, b1_n = b1_c;
-          if (sidx + 1 < NS) {
-            a_n = aq[offA(sidx + 1)];
-            b0_n = bq0[offB(sidx + 1)];
-            if (NTW == 2) b1_n = bq1[offB(sidx + 1)];
-          }
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b0_c, acc0, 0, 0, 0);
-          if (NTW == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b1_c, acc1, 0, 0, 0);
-          a_c = a_n; b0_c = b0_n; b1_c = b1_n;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < k2; t++) {
-          bool sel0 = true, sel1 = true;
-          if (MODE == 2) {
-            sel0 = tapsel[0] == t;
-            sel1 = tapsel[1] == t;
-            if (__ballot(sel0 || sel1) == 0ull) continue;
-          }
-          const int i = t / k, j = t - i * k;
-          const int toff = MODE == 0 ? i * g.PC + j : (k - 1 - i) * g.PC + (k - 1 - j);
-          const float* bp0 = bq0 + toff;
-          const float* bp1 = bq1 + toff;
-          const float* ap = aq + t;
-#pragma unroll 2
-          for (int p = 0; p < npk; p++) {
-            float a = ap[p * astep];
-            float b0 = bp0[p * bstep];
-            float b1 = NTW == 2 ? bp1[p * bstep] : 0.0f;
-            if (MODE == 2) { b0 = sel0 ? b0 : 0.0f; b1 = sel1 ? b1 : 0.0f; }
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-            if (NTW == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-          }
+    for (int t = 0; t < k2; t++) {
+      const bool ok = (vmask >> t) & 1u;
+      if (__ballot(ok) != 0ull) {              // else: nobody in the wave reads through this tap
+        const float* bp = Xb + poff[t];
+        const float* ap = aq + t;
+#pragma unroll 4
+        for (int p = 0; p < npk; p++) {
+          float a = ap[p * astep];
+          float b = bp[p * bstep];
+          b = ok ? b : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
       }
     }
-    DF_STAMP();
+    if (ch + 1 < nchunks) DF_COMMIT(buf ^ 1);  // the other buffer was released at the last barrier
     __syncthreads();
-    DF_STAMP();
   }
+#undef DF_ISSUE
+#undef DF_COMMIT
+#undef DF_WSTORE
 
   // sum the KSPLIT partial accumulators of every pixel tile through LDS (staging buffers are free)
   float* red = smem;                    // [PT][KSPLIT-1][16][64]
   if (KSPLIT > 1) {
-    if (!loader && ks > 0) {
+    if (ks > 0) {
+      float* dstp = red + ((size_t)(pt * (KSPLIT - 1) + ks - 1) * 16) * 64 + lane;
 #pragma unroll
-      for (int e = 0; e < 2; e++) {
-        if (e < NTW) {
-          float* dstp = red + ((size_t)((tw * NTW + e) * (KSPLIT - 1) + ks - 1) * 16) * 64 + lane;
-#pragma unroll
-          for (int rr = 0; rr < 16; rr++) dstp[rr * 64] = e == 0 ? acc0[rr] : acc1[rr];
-        }
-      }
+      for (int rr = 0; rr < 16; rr++) dstp[rr * 64] = acc[rr];
     }
     __syncthreads();
-    if (!loader && ks == 0) {
+    if (ks == 0) {
       for (int s2 = 0; s2 < KSPLIT - 1; s2++) {
+        const float* srcp = red + ((size_t)(pt * (KSPLIT - 1) + s2) * 16) * 64 + lane;
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-          if (e < NTW) {
-            const float* srcp = red + ((size_t)((tw * NTW + e) * (KSPLIT - 1) + s2) * 16) * 64 + lane;
-#pragma unroll
-            for (int rr = 0; rr < 16; rr++) {
-              if (e == 0) acc0[rr] += srcp[rr * 64];
-              else acc1[rr] += srcp[rr * 64];
-            }
-          }
-        }
+        for (int rr = 0; rr < 16; rr++) acc[rr] += srcp[rr * 64];
       }
     }
   }
 
-  if (!loader && ks == 0) {
+  if (ks == 0 && pvalid) {
     const int64_t dplane = (int64_t)g.HD * g.WD;
+    float* out = g.dst + (int64_t)(n0 + img) * g.CD * dplane + (int64_t)(r0 + r) * g.WD + col;
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-      if (pvalid[e]) {
-        float* out = g.dst + out_off[e];
-#pragma unroll
-        for (int rr = 0; rr < 16; rr++) {
-          int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-          if (d < g.CD) {
-            float v = e == 0 ? acc0[rr] : acc1[rr];
-            if (g.bias) v += g.bias[d];
-            out[(int64_t)d * dplane] = v;
-          }
-        }
+    for (int rr = 0; rr < 16; rr++) {
+      int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+      if (d < g.CD) {
+        float v = acc[rr];
+        if (g.bias) v += g.bias[d];
+        out[(int64_t)d * dplane] = v;
       }
     }
   }
-  DF_STAMP();
-#undef DF_STAMP
 }
 
 // out[i] = sum_s slabs[s][i] (+ bias[(i / plane) % CD])
@@ -1244,31 +994,17 @@ constexpr size_t kLdsBudget = 64 * 1024;  // keeps two workgroups resident per C
 
 unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)((((uint64_t)1 << 32) + d - 1) / d); }
 
-template <int KS, int MODE, int NPK, int NTW>
-int launch_igemm_v3n(const Geo& g, dim3 grid, size_t lds) {
+template <int KS, int MODE>
+int launch_igemm_v4(const Geo& g, dim3 grid, size_t lds) {
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv_igemm_v3<KS, MODE, NPK, NTW>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv_igemm_v4<KS, MODE>,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)std::max(lds, (size_t)65536)));
     attr_lds = std::max(lds, (size_t)65536);
   }
-  hipLaunchKernelGGL((k_conv_igemm_v3<KS, MODE, NPK, NTW>), grid, dim3(512), lds, stream(), g);
+  hipLaunchKernelGGL((k_conv_igemm_v4<KS, MODE>), grid, dim3(512), lds, stream(), g);
   return DFHIP_OK;
-}
-
-template <int KS, int MODE>
-int launch_igemm_v3(const Geo& g, dim3 grid, size_t lds) {
-  const int ksplit = g.PT >= 2 ? 8 / g.PT : 4;
-  const int npk = (g.CC >> 1) / ksplit;
-  const int ntw = g.PT >= 2 ? 2 : 1;
-  if constexpr (KS == 3 && MODE != 2) {
-    if (npk == 4 && ntw == 2) return launch_igemm_v3n<KS, MODE, 4, 2>(g, grid, lds);
-    if (npk == 2 && ntw == 2) return launch_igemm_v3n<KS, MODE, 2, 2>(g, grid, lds);
-    if (npk == 4 && ntw == 1) return launch_igemm_v3n<KS, MODE, 4, 1>(g, grid, lds);
-  }
-  if (ntw == 2) return launch_igemm_v3n<KS, MODE, 0, 2>(g, grid, lds);
-  return launch_igemm_v3n<KS, MODE, 0, 1>(g, grid, lds);
 }
 
 int finish_slabs(const Geo& g, int splits, float* final_dst, const float* bias, int64_t out_elems) {
@@ -1281,39 +1017,43 @@ int finish_slabs(const Geo& g, int splits, float* final_dst, const float* bias, 
   return DFHIP_OK;
 }
 
-// producer-consumer kernel; returns -1 when the shape is not eligible
-int run_igemm_v3(Geo g, int dest_channels, float* final_dst, const float* bias) {
+static int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// main kernel; returns -1 when the shape is not eligible (the generic kernel takes it then)
+int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias) {
   if (g.CS % 8 != 0 || !(g.k == 1 || g.k == 3)) return -1;
-  if (g.mode != 0 && g.CD % 32 != 0) return -1;   // dgrad weight rows are staged as whole 32-channel runs
+  if (g.mode != 0 && g.CD % 32 != 0) return -1;    // dgrad weight rows are staged as whole 32-channel runs
+  if ((g.HS * g.WS) % 4 != 0) return -1;            // channel planes must stay 16-byte aligned
   const int k2 = g.k * g.k;
   const int dtiles = (int)df_ceil_div(dest_channels, 32);
-  auto lds_for = [&](int ccp, int pt) {
-    size_t wl = g.mode == 0 ? (size_t)32 * (ccp * k2 + 4) : (size_t)ccp * 32 * k2;
-    size_t stage_b = (2 * ((size_t)ccp * g.PE + wl) + (size_t)g.PE) * 4;
-    size_t red_b = (size_t)pt * ((pt >= 2 ? 8 / pt : 4) - 1) * 16 * 64 * 4;
-    return std::max(stage_b, red_b);
-  };
-  // pixel tiles per workgroup: the largest group that still yields about one job per CU
   int gi = 1, chosen = 0, ccp = 0;
+  size_t lds = 0;
   for (int pt : {8, 4, 2, 1}) {
-    const int ksplit = pt >= 2 ? 8 / pt : 4;
+    const int ksplit = 8 / pt;
     plan_groups(g.N, g.HD, g.WD, 32 * pt, g.BI, g.BR, g.BC, gi, g.gr, g.gc);
-    g.PR = (g.BR - 1) * g.so + g.k;
-    g.PC = (g.BC - 1) * g.so + g.k;
-    g.PE = g.BI * g.PR * g.PC;
-    int64_t jobs = (int64_t)gi * g.gr * g.gc * dtiles;
+    if (g.BC != g.WD || g.gc != 1) continue;        // whole destination rows only
+    if (g.HD % g.BR != 0) continue;                 // equal row bands (same source row count)
+    // source rows a group touches, clipped to the image; identical for every band when computed
+    // for the widest (interior) case, so use the un-clipped span and clip per group in the kernel
+    int span_lo = floor_div(g.u0, g.sd), span_hi = floor_div((g.BR - 1) * g.so + g.u0 + g.k - 1, g.sd);
+    int RLr = std::min(g.HS, span_hi - span_lo + 1);
+    if (g.gr == 1) RLr = g.HS;                      // whole-image groups stage the whole plane
+    int RL = RLr * g.WS;
+    if (RL % 4 != 0 || (g.gr > 1 && (g.WS % 4 != 0))) continue;
+    g.PE = g.BI * RL;
+    int64_t jobs = (int64_t)gi * g.gr * dtiles;
     if (jobs < (int64_t)num_cus() && pt > 1) continue;
-    // channels per chunk: >= 2 per k-split slice, at most ~8 chunks, must divide CS and fit LDS
-    int c = std::max(8, 2 * ksplit);
-    while (c < 32 && g.CS / c > 8 && g.CS % (2 * c) == 0) c *= 2;
-    if (g.CS % c != 0) continue;
     auto fits = [&](int cc) {
-      int items = (int)df_ceil_div(g.PE, 256) * (cc / 4);
-      int w4 = 8 * cc * k2;   // float4 weight vectors per chunk
-      return lds_for(cc, pt) <= 150 * 1024 && items <= 4 * kMaxItems && w4 <= 256 * kWU;
+      size_t wl = g.mode == 0 ? (size_t)32 * (cc * k2 + 4) : (size_t)cc * 32 * k2;
+      size_t stage_b = 2 * ((size_t)cc * g.PE + wl) * 4;
+      size_t red_b = (size_t)pt * (ksplit - 1) * 16 * 64 * 4;
+      lds = std::max(stage_b, red_b);
+      int pvecs = cc * g.PE / 4, wvecs = 8 * cc * k2;
+      return lds <= 76 * 1024 && pvecs <= 512 * kPV && wvecs <= 512 * kWV;
     };
-    while (c > std::max(8, 2 * ksplit) && !fits(c)) c /= 2;
-    if (!fits(c) || g.CS % c != 0) continue;
+    int c = std::max(8, 2 * ksplit);
+    while (c < 32 && g.CS / c > 8 && g.CS % (2 * c) == 0 && fits(2 * c)) c *= 2;
+    if (g.CS % c != 0 || !fits(c)) continue;
     chosen = pt;
     ccp = c;
     break;
@@ -1321,61 +1061,27 @@ int run_igemm_v3(Geo g, int dest_channels, float* final_dst, const float* bias) 
   if (!chosen) return -1;
   g.PT = chosen;
   g.CC = ccp;
-  g.m_perimg = magic_u32((unsigned)(g.PR * g.PC));
-  g.m_pc = magic_u32((unsigned)g.PC);
-  g.m_sd = magic_u32((unsigned)g.sd);
   g.cs_per_split = g.CS;
   g.slab_stride = 0;
   g.dst = final_dst;
   g.bias = bias;
-  const int pixel_blocks = gi * g.gr * g.gc;
-  size_t lds = lds_for(ccp, chosen);
-  dim3 grid((unsigned)pixel_blocks, (unsigned)dtiles, 1);
+  dim3 grid((unsigned)(gi * g.gr), (unsigned)dtiles, 1);
   int st = DFHIP_OK;
-  g.stamps = nullptr;
-  g.dbg = getenv("DFHIP_CONV_DBG") ? atoi(getenv("DFHIP_CONV_DBG")) : 0;
-  static int stamp_mode = -1;
-  if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
-  const size_t nstamp = (size_t)pixel_blocks * dtiles * 2 * 32;
-  if (stamp_mode) {
-    g.stamps = (unsigned long long*)workspace2(nstamp * 8);
-    (void)hipMemsetAsync(g.stamps, 0, nstamp * 8, stream());
-  }
-#define DF_V3(KSV)                                                        \
-  (g.mode == 0 ? launch_igemm_v3<KSV, 0>(g, grid, lds)                    \
-               : (g.mode == 1 ? launch_igemm_v3<KSV, 1>(g, grid, lds)     \
-                              : launch_igemm_v3<KSV, 2>(g, grid, lds)))
-  if (g.k == 1) st = DF_V3(1);
-  else st = DF_V3(3);
-#undef DF_V3
+#define DF_V4(KSV)                                                        \
+  (g.mode == 0 ? launch_igemm_v4<KSV, 0>(g, grid, lds)                    \
+               : (g.mode == 1 ? launch_igemm_v4<KSV, 1>(g, grid, lds)     \
+                              : launch_igemm_v4<KSV, 2>(g, grid, lds)))
+  if (g.k == 1) st = DF_V4(1);
+  else st = DF_V4(3);
+#undef DF_V4
   if (st != DFHIP_OK) return st;
   DF_LAUNCH_CHECK();
-  if (stamp_mode) {
-    std::vector<unsigned long long> h(nstamp);
-    (void)hipStreamSynchronize(stream());
-    (void)hipMemcpy(h.data(), g.stamps, nstamp * 8, hipMemcpyDeviceToHost);
-    unsigned long long tmin = ~0ull, tmax = 0;
-    for (size_t b = 0; b < nstamp / 64; b++) {
-      if (h[b * 64]) tmin = std::min(tmin, h[b * 64]);
-      for (int i = 0; i < 64; i++) tmax = std::max(tmax, h[b * 64 + i]);
-    }
-    fprintf(stderr, "[stamp] mode %d k %d PT %d CC %d PE %d grid %d x %d lds %zu span %llu cycles\n", g.mode, g.k,
-            g.PT, g.CC, g.PE, pixel_blocks, dtiles, lds, tmax - tmin);
-    for (size_t b : {(size_t)0, nstamp / 64 / 2, nstamp / 64 - 1}) {
-      for (int w = 0; w < 2; w++) {
-        fprintf(stderr, "[stamp]  block %zu %s:", b, w ? "loader " : "compute");
-        for (int i = 0; i < 32 && h[(b * 2 + w) * 32 + i]; i++)
-          fprintf(stderr, " %llu", h[(b * 2 + w) * 32 + i] - tmin);
-        fprintf(stderr, "\n");
-      }
-    }
-  }
   return DFHIP_OK;
 }
 
 int run_igemm(Geo g, int dest_channels, float* final_dst, const float* bias) {
   {
-    int st = run_igemm_v3(g, dest_channels, final_dst, bias);
+    int st = run_igemm_v4(g, dest_channels, final_dst, bias);
     if (st >= 0) return st;
   }
   const int k2 = g.k * g.k;
