@@ -1042,7 +1042,8 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias) 
     if (RL % 4 != 0 || (g.gr > 1 && (g.WS % 4 != 0))) continue;
     g.PE = g.BI * RL;
     int64_t jobs = (int64_t)gi * g.gr * dtiles;
-    if (jobs < (int64_t)num_cus() && pt > 1) continue;
+    static int jobmul = getenv("DFHIP_JOBMUL") ? atoi(getenv("DFHIP_JOBMUL")) : 1;
+    if (jobs < (int64_t)num_cus() * jobmul && pt > 1) continue;
     auto fits = [&](int cc) {
       size_t wl = g.mode == 0 ? (size_t)32 * (cc * k2 + 4) : (size_t)cc * 32 * k2;
       size_t stage_b = 2 * ((size_t)cc * g.PE + wl) * 4;
@@ -1051,8 +1052,9 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias) 
       int pvecs = cc * g.PE / 4, wvecs = 8 * cc * k2;
       return lds <= 76 * 1024 && pvecs <= 512 * kPV && wvecs <= 512 * kWV;
     };
+    static int maxchunks = getenv("DFHIP_MAXCHUNKS") ? atoi(getenv("DFHIP_MAXCHUNKS")) : 8;
     int c = std::max(8, 2 * ksplit);
-    while (c < 32 && g.CS / c > 8 && g.CS % (2 * c) == 0 && fits(2 * c)) c *= 2;
+    while (c < 32 && g.CS / c > maxchunks && g.CS % (2 * c) == 0 && fits(2 * c)) c *= 2;
     if (g.CS % c != 0 || !fits(c)) continue;
     chosen = pt;
     ccp = c;
