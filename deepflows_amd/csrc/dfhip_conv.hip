@@ -639,89 +639,36 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WGeo g) {
 }
 
 // ---------------------------------------------------------------------------------------
-// weight gradient, producer-consumer form with LDS-DMA staging.
-// Same decomposition as above (every matrix-core wave keeps all OT x KT accumulator tiles and
-// reduces its share of the pixel rows of a group; partials are summed through LDS at the end):
-//   * waves 4-7 are loaders.  They stage pixel group g+2 into a 3-slot LDS ring with
-//     `global_load_lds` (the load writes LDS directly: no staging registers, ~1 instruction per
-//     256 B), while group g is in the matrix cores; a counted s_waitcnt keeps the newest group in
-//     flight across the workgroup barrier (raw s_barrier: __syncthreads() would drain it);
-//   * a loader lane's source offsets inside a channel plane are computed once per block (exact
-//     division by multiplication), per group only for row bands whose halo depends on the band;
-//     per load the address is a scalar base + 32-bit lane offset; halo / padding lanes read a
-//     zero word instead;
-//   * pixels are walked row by row, so inside a row both operand addresses advance by constants.
+// weight gradient, main kernel.  Same decomposition as the generic kernel above (every wave
+// keeps all OT x KT accumulator tiles and reduces its share of the pixel rows of a group;
+// partials are summed through LDS at the end), with the staging scheme of k_conv_igemm_v4:
+//   * all 8 waves run the matrix cores (two per SIMD); a wave takes every 8th pixel row;
+//   * the x planes and the dY tile are staged AS THEY ARE with 16-byte loads (scalar group base
+//     + a lane offset computed once per block): x as [channel][image][rows x W] without halo,
+//     dY as [o][pixels]; group g+1 is loaded into registers while group g is in the matrix
+//     cores and stored to the other LDS buffer before the barrier;
+//   * padding is resolved on the READ side: a lane of the B operand owns one (channel, tap), so
+//     per pixel row / pixel pair two compares decide whether its element exists; a missing one
+//     reads a neighbouring in-range address and is zeroed by a select.
 // ---------------------------------------------------------------------------------------
-__device__ float g_zero_words[64];   // zero-initialised: the source of halo / padding elements
-
-typedef __attribute__((address_space(3))) void* df_lds_ptr;
-typedef const __attribute__((address_space(1))) void* df_glb_ptr;
-
-// wait until at most `n` of this wave's vector-memory operations are outstanding (n wave-uniform)
-__device__ __forceinline__ void wait_vmcnt_le(int n) {
-#define DF_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-  switch (n) {
-    DF_W(0) DF_W(1) DF_W(2) DF_W(3) DF_W(4) DF_W(5) DF_W(6) DF_W(7) DF_W(8) DF_W(9)
-    DF_W(10) DF_W(11) DF_W(12) DF_W(13) DF_W(14) DF_W(15) DF_W(16) DF_W(17) DF_W(18) DF_W(19)
-    DF_W(20) DF_W(21) DF_W(22) DF_W(23) DF_W(24) DF_W(25) DF_W(26) DF_W(27) DF_W(28) DF_W(29)
-    DF_W(30) DF_W(31) DF_W(32) DF_W(33) DF_W(34) DF_W(35) DF_W(36) DF_W(37) DF_W(38) DF_W(39)
-    DF_W(40) DF_W(41) DF_W(42) DF_W(43) DF_W(44) DF_W(45) DF_W(46) DF_W(47) DF_W(48) DF_W(49)
-    DF_W(50) DF_W(51) DF_W(52) DF_W(53) DF_W(54) DF_W(55) DF_W(56) DF_W(57) DF_W(58) DF_W(59)
-    DF_W(60) DF_W(61) DF_W(62)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef DF_W
-}
-
-__device__ __forceinline__ void df_barrier() {
-  // LDS reads/writes of this wave retired, then the workgroup barrier; LDS-DMA stays in flight
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// element j of the per-channel patch of a group -> offset inside one channel plane of x,
-// -1 = zero (halo / padding), -2 = no such element
-__device__ __forceinline__ int wg_patch_off(const WGeo& g, int j, int r0) {
-  if (j >= g.PE) return -2;
-  unsigned img = fast_div(j, g.m_prpc);
-  unsigned rem = j - img * (g.PR * g.PC);
-  unsigned pr = fast_div(rem, g.m_pc);
-  unsigned pc = rem - pr * g.PC;
-  int u = r0 * g.stride - g.pad + (int)pr, v = -g.pad + (int)pc;
-  bool ok = u >= 0 && v >= 0 && u < g.H && v < g.W;
-  return ok ? (int)(((int64_t)img * g.C) * g.H * g.W + (int64_t)u * g.W + v) : -1;
-}
-
-// pixel q of a group -> offset inside one channel plane of dy; -1 zero, -2 none
-__device__ __forceinline__ int wg_dy_off(const WGeo& g, int q, int r0, int BMP) {
-  if (q >= BMP) return -2;
-  unsigned img = fast_div(q, g.m_brbc);
-  unsigned rem = q - img * (g.BR * g.BC);
-  unsigned r = fast_div(rem, g.m_bc);
-  unsigned col = rem - r * g.BC;
-  bool ok = r0 + (int)r < g.oh;
-  return ok ? (int)(((int64_t)img * g.O) * g.oh * g.ow + (int64_t)(r0 + r) * g.ow + col) : -1;
-}
-
-constexpr int kWgSlots = 3;     // LDS ring depth
-constexpr int kWgPSl = 8;       // patch slices of 64 elements per channel (PE <= 512)
-constexpr int kWgDSl = 2;       // pixel slices of 64 per output channel (group <= 128 pixels)
-
-template <int OT, int KT>
-__global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
+template <int OT, int KT, int DV>
+__global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int k2 = g.k * g.k;
   const int KW = g.C * k2;
-  const int BMP = g.BI * g.BR * g.BC;
-  const int BMPP = (BMP + 7) & ~7;
-  const int DLD = BMPP + 1;          // odd row stride: lanes run along o
-  const int xs_floats = g.CH * g.PE;
+  const int BRBC = g.BR * g.BC;
+  const int BMP = g.BI * BRBC;
+  const int DLD = BMP + 4;                    // dY row stride: 16-byte aligned rows, 4-way read conflict
+  const int PEp = g.PE;                       // floats per channel in LDS: BI * RL
+  const int RL = PEp / g.BI;
+  const int RLr = RL / g.W;
+  const int guard = (g.k * g.W + g.k + 3) & ~3;
   const int dy_floats = OT * 32 * DLD;
-  const int slot_floats = xs_floats + dy_floats;
+  const int buf_floats = dy_floats + guard + g.CH * PEp + guard;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const bool loader = wave >= 4;
-  const int lw = __builtin_amdgcn_readfirstlane(wave) & 3;
   const int kk0 = blockIdx.y * (KT * 32);
   const int o0 = blockIdx.z * (OT * 32);
   const int cA = kk0 / k2;
@@ -730,29 +677,19 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
   const int orows = min(OT * 32, g.O - o0);
   const int64_t xplane = (int64_t)g.H * g.W, yplane = (int64_t)g.oh * g.ow;
 
-  int stamp_i = 0;
-#define WG_STAMP()                                                                               \
-  do {                                                                                           \
-    if (g.stamps && lane == 0 && (wave == 0 || wave == 4) && stamp_i < 30)                       \
-      g.stamps[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2 + (wave == 4)) * 32 + stamp_i++] = \
-          __builtin_readcyclecounter();                                                          \
-  } while (0)
-  WG_STAMP();
-  // every slot starts as zeros: dY rows of missing output channels and the pixel padding are
-  // never written by the loaders
-  for (int e = tid; e < kWgSlots * slot_floats; e += 512) smem[e] = 0.0f;
-
-  int koffL[KT];
+  // B-operand lane descriptors: this lane's (channel, tap) of every kk tile
+  int koffL[KT], il[KT], jl[KT];
 #pragma unroll
   for (int t = 0; t < KT; t++) {
     int kk = kk0 + t * 32 + l31;
-    int off = 0;
+    koffL[t] = 0; il[t] = -(1 << 20); jl[t] = -(1 << 20);      // no such kk: never valid
     if (kk < KW) {
       int c = kk / k2, tt = kk - c * k2;
       int i = tt / g.k, j = tt - i * g.k;
-      off = (c - cA) * g.PE + i * g.PC + j;
+      il[t] = i - g.pad;
+      jl[t] = j - g.pad;
+      koffL[t] = (c - cA) * PEp + il[t] * g.W + jl[t];
     }
-    koffL[t] = off;
   }
 
   f32x16 acc[OT][KT];
@@ -763,98 +700,97 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
 #pragma unroll
       for (int rr = 0; rr < 16; rr++) acc[a][b][rr] = 0.0f;
 
-  // groups of this block: blockIdx.x, blockIdx.x + gridDim.x, ...
-  const int my_groups = (g.ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  auto group_origin = [&](int gi_, int& n0, int& r0) {
-    int grp = blockIdx.x + gi_ * gridDim.x;
-    int gimg = grp / g.gr;
-    n0 = gimg * g.BI;
-    r0 = (grp - gimg * g.gr) * g.BR;
-  };
+  // zero both buffers once: dY rows of missing output channels, guards
+  for (int e = tid; e < 2 * buf_floats; e += 512) smem[e] = 0.0f;
 
-  int p_off[kWgPSl], d_off[kWgDSl];
-  auto describe = [&](int r0) {
+  // staging descriptors (group-invariant up to a scalar base)
+  const int RL4 = RL >> 2, BRBC4 = BRBC >> 2;
+  const int pvecs = chn * g.BI * RL4, dvecs = orows * g.BI * BRBC4;
+  unsigned p_src[2], d_src[DV];
+  int d_lx[DV];
 #pragma unroll
-    for (int sl = 0; sl < kWgPSl; sl++) p_off[sl] = wg_patch_off(g, sl * 64 + lane, r0);
-#pragma unroll
-    for (int sl = 0; sl < kWgDSl; sl++) d_off[sl] = wg_dy_off(g, sl * 64 + lane, r0, BMP);
-  };
-  int dma_per_group = 0;      // DMA instructions this wave issues per group (wave-uniform)
-  auto issue = [&](int gi_) {
-    int n0, r0;
-    group_origin(gi_, n0, r0);
-    if (g.gr > 1) describe(r0);
-    float* slot = smem + (gi_ % kWgSlots) * slot_floats;
-    const float* xb = g.x + ((int64_t)n0 * g.C + cA) * xplane;
-    const float* yb = g.dy + ((int64_t)n0 * g.O + o0) * yplane;
-    int cnt = 0;
-#pragma unroll
-    for (int sl = 0; sl < kWgDSl; sl++) {
-      const int off = d_off[sl];
-      if (__ballot(off > -2) != 0ull) {
-        for (int o = lw; o < orows; o += 4) {
-          const float* src = off >= 0 ? yb + (int64_t)o * yplane + off : g_zero_words + lane;
-          if (off > -2)
-            __builtin_amdgcn_global_load_lds((df_glb_ptr)src, (df_lds_ptr)(slot + xs_floats + o * DLD + sl * 64), 4, 0, 0);
-          cnt++;
-        }
-      }
-    }
-#pragma unroll
-    for (int sl = 0; sl < kWgPSl; sl++) {
-      const int off = p_off[sl];
-      if (__ballot(off > -2) != 0ull) {
-        for (int c = lw; c < chn; c += 4) {
-          const float* src = off >= 0 ? xb + (int64_t)c * xplane + off : g_zero_words + lane;
-          if (off > -2)
-            __builtin_amdgcn_global_load_lds((df_glb_ptr)src, (df_lds_ptr)(slot + c * g.PE + sl * 64), 4, 0, 0);
-          cnt++;
-        }
-      }
-    }
-    dma_per_group = cnt;
-  };
-
-  df_barrier();                      // zero fill done
-  WG_STAMP();
-  if (loader) {
-    describe(0);
-    if (my_groups > 0) issue(0);
-    if (my_groups > 1) issue(1);
-    WG_STAMP();
-    wait_vmcnt_le(my_groups > 1 ? dma_per_group : 0);   // group 0 landed, group 1 may still fly
+  for (int u = 0; u < 2; u++) {
+    int v = tid + 512 * u;
+    v = v < pvecs ? v : 0;
+    int c = v / (g.BI * RL4);
+    int rem = v - c * (g.BI * RL4);
+    int im = rem / RL4, q4 = rem - im * RL4;
+    p_src[u] = (unsigned)(((int64_t)im * g.C + c) * xplane + 4 * q4);
   }
-  WG_STAMP();
-  df_barrier();
-  WG_STAMP();
+#pragma unroll
+  for (int u = 0; u < DV; u++) {
+    int v = tid + 512 * u;
+    const bool live = v < dvecs;
+    v = live ? v : 0;
+    int o = v / (g.BI * BRBC4);
+    int rem = v - o * (g.BI * BRBC4);
+    int im = rem / BRBC4, q4 = rem - im * BRBC4;
+    d_src[u] = (unsigned)(((int64_t)im * g.O + o) * yplane + 4 * q4);
+    d_lx[u] = live ? o * DLD + im * BRBC + 4 * q4 : -1;
+  }
+
+  const int my_groups = (g.ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  f32x4 pv0, pv1, dv[DV];
+  int su_lo_cur = 0, r0_cur = 0, su_lo_nxt = 0, r0_nxt = 0;
+#define WG_ISSUE(gi_)                                                                            \
+  do {                                                                                           \
+    int grp_ = blockIdx.x + (gi_) * gridDim.x;                                                   \
+    int gimg_ = grp_ / g.gr;                                                                     \
+    int n0_ = gimg_ * g.BI;                                                                      \
+    r0_nxt = (grp_ - gimg_ * g.gr) * g.BR;                                                       \
+    su_lo_nxt = min(max(0, r0_nxt * g.stride - g.pad), g.H - RLr);                               \
+    const float* xb_ = g.x + ((int64_t)n0_ * g.C + cA) * xplane + (int64_t)su_lo_nxt * g.W;      \
+    const float* yb_ = g.dy + ((int64_t)n0_ * g.O + o0) * yplane + (int64_t)r0_nxt * g.ow;       \
+    _Pragma("unroll") for (int u_ = 0; u_ < DV; u_++) dv[u_] = *reinterpret_cast<const f32x4*>(yb_ + d_src[u_]); \
+    pv0 = *reinterpret_cast<const f32x4*>(xb_ + p_src[0]);                                       \
+    pv1 = *reinterpret_cast<const f32x4*>(xb_ + p_src[1]);                                       \
+  } while (0)
+#define WG_COMMIT(buf)                                                                           \
+  do {                                                                                           \
+    float* Ds_ = smem + (buf) * buf_floats;                                                      \
+    float* Xs_ = Ds_ + dy_floats + guard;                                                        \
+    _Pragma("unroll") for (int u_ = 0; u_ < DV; u_++)                                            \
+      if (d_lx[u_] >= 0) *reinterpret_cast<f32x4*>(Ds_ + d_lx[u_]) = dv[u_];                     \
+    if (tid < pvecs) *reinterpret_cast<f32x4*>(Xs_ + 4 * tid) = pv0;                             \
+    if (tid + 512 < pvecs) *reinterpret_cast<f32x4*>(Xs_ + 4 * (tid + 512)) = pv1;               \
+  } while (0)
+
+  __syncthreads();                             // zero fill done
+  if (my_groups > 0) {
+    WG_ISSUE(0);
+    WG_COMMIT(0);
+  }
+  su_lo_cur = su_lo_nxt; r0_cur = r0_nxt;
+  __syncthreads();
 
   const int R = g.BI * g.BR;          // pixel rows of a group
   const int ppr = g.BC >> 1;          // pixel pairs per row
   for (int gi_ = 0; gi_ < my_groups; gi_++) {
-    if (loader) {
-      // slot (gi_+2) % 3 was read during iteration gi_-1, which ended with a barrier
-      if (gi_ + 2 < my_groups) {
-        issue(gi_ + 2);
-        WG_STAMP();
-        wait_vmcnt_le(dma_per_group);       // everything but the newest group: group gi_+1 landed
-      } else {
-        wait_vmcnt_le(0);
-      }
-    } else {
-      const float* Xs = smem + (gi_ % kWgSlots) * slot_floats;
-      const float* Ds = Xs + xs_floats + l31 * DLD + half;
-      for (int ri = lw; ri < R; ri += 4) {
+    const int buf = gi_ & 1;
+    if (gi_ + 1 < my_groups) WG_ISSUE(gi_ + 1);
+    {
+      const float* Ds = smem + buf * buf_floats + l31 * DLD + half;
+      const float* Xs = smem + buf * buf_floats + dy_floats + guard;
+      for (int ri = wave; ri < R; ri += 8) {
         unsigned img = fast_div(ri, g.m_br);
         int r = ri - (int)img * g.BR;
-        const float* xr = Xs + (int)img * g.PR * g.PC + r * g.stride * g.PC + half * g.stride;
+        const int srow = (r0_cur + r) * g.stride;                  // source row of tap i = pad
+        const float* xr = Xs + (int)img * RL + (srow - su_lo_cur) * g.W + half * g.stride;
         const float* dr = Ds + ri * g.BC;
+        bool rok[KT];
+#pragma unroll
+        for (int t = 0; t < KT; t++) rok[t] = (unsigned)(srow + il[t]) < (unsigned)g.H;
 #pragma unroll 2
         for (int p = 0; p < ppr; p++) {
+          const int scol = (2 * p + half) * g.stride;              // source column of tap j = pad
           float a[OT], b[KT];
 #pragma unroll
           for (int t = 0; t < OT; t++) a[t] = dr[t * 32 * DLD + 2 * p];
 #pragma unroll
-          for (int t = 0; t < KT; t++) b[t] = xr[koffL[t] + 2 * p * g.stride];
+          for (int t = 0; t < KT; t++) {
+            float v = xr[koffL[t] + 2 * p * g.stride];
+            b[t] = (rok[t] && (unsigned)(scol + jl[t]) < (unsigned)g.W) ? v : 0.0f;
+          }
 #pragma unroll
           for (int i = 0; i < OT; i++)
 #pragma unroll
@@ -863,55 +799,55 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v2(WGeo g) {
         }
       }
     }
-    WG_STAMP();
-    df_barrier();
-    WG_STAMP();
+    if (gi_ + 1 < my_groups) WG_COMMIT(buf ^ 1);
+    su_lo_cur = su_lo_nxt; r0_cur = r0_nxt;
+    __syncthreads();
   }
+#undef WG_ISSUE
+#undef WG_COMMIT
 
-  // cross-wave reduction through LDS, four tiles per round; matrix-core wave w finishes tile 4*round + w
-  float* red = smem;  // [4 tiles][4 waves][16][64]
+  // cross-wave reduction through LDS, two tiles per round: every wave stores its partial of both
+  // tiles, then wave w sums registers 4*(w&3).. of tile w>>2 over the eight partials
+  float* red = smem;  // [2 tiles][8 waves][16][64]
   float* out = g.dst + (int64_t)blockIdx.x * g.O * KW;
   constexpr int NTILES = OT * KT;
 #pragma unroll
-  for (int round = 0; round < (NTILES + 3) / 4; round++) {
-    df_barrier();
-    if (!loader) {
+  for (int round = 0; round < (NTILES + 1) / 2; round++) {
+    __syncthreads();
 #pragma unroll
-      for (int tt = 0; tt < 4; tt++) {
-        int tile = round * 4 + tt;
-        if (tile < NTILES) {
-          int ti = tile / KT, tj = tile % KT;
+    for (int tt = 0; tt < 2; tt++) {
+      int tile = round * 2 + tt;
+      if (tile < NTILES) {
+        int ti = tile / KT, tj = tile % KT;
 #pragma unroll
-          for (int rr = 0; rr < 16; rr++) {
-            float v = 0.0f;
+        for (int rr = 0; rr < 16; rr++) {
+          float v = 0.0f;
 #pragma unroll
-            for (int a = 0; a < OT; a++)
+          for (int a = 0; a < OT; a++)
 #pragma unroll
-              for (int b = 0; b < KT; b++)
-                if (a == ti && b == tj) v = acc[a][b][rr];
-            red[((tt * 4 + lw) * 16 + rr) * 64 + lane] = v;
-          }
+            for (int b = 0; b < KT; b++)
+              if (a == ti && b == tj) v = acc[a][b][rr];
+          red[((tt * 8 + wave) * 16 + rr) * 64 + lane] = v;
         }
       }
     }
-    df_barrier();
-    int tile = round * 4 + lw;
-    if (!loader && tile < NTILES) {
+    __syncthreads();
+    const int tt = wave >> 2;
+    const int tile = round * 2 + tt;
+    if (tile < NTILES) {
       int ti = tile / KT, tj = tile % KT;
       int kk = kk0 + tj * 32 + l31;
 #pragma unroll
-      for (int rr = 0; rr < 16; rr++) {
-        float v = red[((lw * 4 + 0) * 16 + rr) * 64 + lane];
-        v += red[((lw * 4 + 1) * 16 + rr) * 64 + lane];
-        v += red[((lw * 4 + 2) * 16 + rr) * 64 + lane];
-        v += red[((lw * 4 + 3) * 16 + rr) * 64 + lane];
+      for (int q = 0; q < 4; q++) {
+        const int rr = (wave & 3) * 4 + q;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) v += red[((tt * 8 + w) * 16 + rr) * 64 + lane];
         int o = o0 + ti * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
         if (o < g.O && kk < KW) out[(int64_t)o * KW + kk] = v;
       }
     }
   }
-  WG_STAMP();
-#undef WG_STAMP
 }
 
 // out[i] = sum_s slabs[s][i], summed in a fixed order.  A block owns 256 consecutive elements
@@ -1174,8 +1110,8 @@ int launch_wgrad(WGeo g, float* dw) {
   return DFHIP_OK;
 }
 
-template <int OT, int KT>
-int launch_wgrad_v2(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
+template <int OT, int KT, int DV>
+int launch_wgrad_v3(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
   const int64_t n = (int64_t)g.O * g.C * g.k * g.k;
   float* slabs = dw;
   if (gx > 1) {
@@ -1185,37 +1121,14 @@ int launch_wgrad_v2(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
   g.dst = slabs;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_v2<OT, KT>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_v3<OT, KT, DV>,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)std::max(lds, (size_t)65536)));
     attr_lds = std::max(lds, (size_t)65536);
   }
   dim3 grid((unsigned)gx, (unsigned)ktg, (unsigned)otg);
-  static int stamp_mode = -1;
-  if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
-  const size_t nstamp = (size_t)gx * ktg * otg * 2 * 32;
-  g.stamps = nullptr;
-  if (stamp_mode) {
-    g.stamps = (unsigned long long*)workspace2(nstamp * 8);
-    (void)hipMemsetAsync(g.stamps, 0, nstamp * 8, stream());
-  }
-  hipLaunchKernelGGL((k_conv_wgrad_v2<OT, KT>), grid, dim3(512), lds, stream(), g);
+  hipLaunchKernelGGL((k_conv_wgrad_v3<OT, KT, DV>), grid, dim3(512), lds, stream(), g);
   DF_LAUNCH_CHECK();
-  if (stamp_mode) {
-    std::vector<unsigned long long> h(nstamp);
-    (void)hipStreamSynchronize(stream());
-    (void)hipMemcpy(h.data(), g.stamps, nstamp * 8, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[wstamp] OT %d KT %d C %d O %d PE %d BI %d BR %d groups %d grid %d x %d x %d lds %zu\n", OT, KT, g.C,
-            g.O, g.PE, g.BI, g.BR, g.ngroups, gx, ktg, otg, lds);
-    for (size_t b : {(size_t)0, nstamp / 64 / 2}) {
-      for (int w = 0; w < 2; w++) {
-        fprintf(stderr, "[wstamp]  block %zu %s:", b, w ? "loader " : "compute");
-        unsigned long long t0 = h[(b * 2) * 32];
-        for (int i = 0; i < 32 && h[(b * 2 + w) * 32 + i]; i++) fprintf(stderr, " %lld", (long long)(h[(b * 2 + w) * 32 + i] - t0));
-        fprintf(stderr, "\n");
-      }
-    }
-  }
   if (gx > 1) {
     hipLaunchKernelGGL(k_flat_slab_sum, dim3((unsigned)df_ceil_div(n, 256)), dim3(1024), 0, stream(), slabs,
                        dw, n, gx);
@@ -1224,44 +1137,45 @@ int launch_wgrad_v2(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
   return DFHIP_OK;
 }
 
-// returns -1 when the shape is not eligible for the producer-consumer weight-gradient kernel
-int run_wgrad_v2(WGeo g, float* dw) {
+// returns -1 when the shape is not eligible for the main weight-gradient kernel
+int run_wgrad_v3(WGeo g, float* dw) {
   const int k2 = g.k * g.k;
   const int KW = g.C * k2;
-  if ((g.ow & 1) || KW < 64) return -1;
+  if (g.ow & 1) return -1;
+  if ((g.H * g.W) % 4 != 0 || (g.oh * g.ow) % 4 != 0) return -1;   // 16-byte aligned channel planes
   const int OT = g.O <= 32 ? 1 : 2;
-  const int KT = g.O <= 32 ? 5 : 2;
+  const int KT = (g.k == 1 || KW <= 32) ? 1 : (g.O <= 32 ? 5 : 2);
   const int CH = std::min(g.C, (KT * 32 + k2 - 2) / k2 + 1);
   int gi = 1;
   size_t lds = 0;
   bool ok = false;
-  for (int tp : {128, 64, 32}) {
+  for (int tp : {256, 128, 64, 32}) {
     plan_groups(g.N, g.oh, g.ow, tp, g.BI, g.BR, g.BC, gi, g.gr, g.gc);
-    if (g.BC != g.ow || g.N % g.BI != 0) continue;  // whole rows, whole groups only
-    if (g.oh % g.BR != 0) continue;                // equal row bands
-    g.PR = (g.BR - 1) * g.stride + g.k;
-    g.PC = (g.BC - 1) * g.stride + g.k;
-    g.PE = g.BI * g.PR * g.PC;
-    int BMP = g.BI * g.BR * g.BC, BMPP = (BMP + 7) & ~7;
-    if ((g.BI * g.BR) % 4) continue;               // rows deal evenly to the four matrix-core waves
-    size_t stage = (size_t)kWgSlots * ((size_t)CH * g.PE + (size_t)OT * 32 * (BMPP + 1)) * 4;
-    size_t red = (size_t)4 * 4 * 16 * 64 * 4;
-    lds = std::max(stage, red);
-    int dma = (int)df_ceil_div(g.PE, 64) * (int)df_ceil_div(CH, 4) + (int)df_ceil_div(BMP, 64) * OT * 8;
-    if (lds <= 156 * 1024 && g.PE <= 64 * kWgPSl && BMP <= 64 * kWgDSl && 2 * dma <= 62) { ok = true; break; }
+    if (g.BC != g.ow || g.gc != 1 || g.N % g.BI != 0 || g.oh % g.BR != 0) continue;
+    if ((g.BI * g.BR) % 8) continue;               // rows deal evenly to the eight waves
+    int RLr = g.gr == 1 ? g.H : std::min(g.H, (g.BR - 1) * g.stride + g.k);
+    int RL = RLr * g.W, BRBC = g.BR * g.BC;
+    if (RL % 4 || BRBC % 4) continue;
+    if (g.gr > 1 && (g.W % 4 || g.ow % 4)) continue;
+    g.PE = g.BI * RL;
+    int BMP = g.BI * BRBC;
+    int guard = (g.k * g.W + g.k + 3) & ~3;
+    size_t buf = (size_t)OT * 32 * (BMP + 4) + 2 * guard + (size_t)CH * g.PE;
+    size_t red = (size_t)2 * 8 * 16 * 64;
+    lds = std::max(2 * buf, red) * 4;
+    int pvecs = CH * g.PE / 4, dvecs = OT * 32 * BMP / 4;
+    if (lds <= 150 * 1024 && pvecs <= 1024 && dvecs <= 512 * 4) { ok = true; break; }
   }
   if (!ok) return -1;
   g.CH = CH;
   g.ngroups = gi * g.gr;
-  g.m_prpc = magic_u32(g.PR * g.PC);
-  g.m_pc = magic_u32(g.PC);
-  g.m_brbc = magic_u32(g.BR * g.BC);
-  g.m_bc = magic_u32(g.BC);
   g.m_br = magic_u32(g.BR);
   const int ktg = (int)df_ceil_div(KW, KT * 32), otg = (int)df_ceil_div(g.O, OT * 32);
   int gx = (int)std::max<int64_t>(1, std::min<int64_t>(g.ngroups, (int64_t)num_cus() / ((int64_t)ktg * otg)));
-  if (OT == 1) return launch_wgrad_v2<1, 5>(g, dw, lds, gx, ktg, otg);
-  return launch_wgrad_v2<2, 2>(g, dw, lds, gx, ktg, otg);
+  if (OT == 1 && KT == 5) return launch_wgrad_v3<1, 5, 4>(g, dw, lds, gx, ktg, otg);
+  if (OT == 1) return launch_wgrad_v3<1, 1, 4>(g, dw, lds, gx, ktg, otg);
+  if (KT == 2) return launch_wgrad_v3<2, 2, 4>(g, dw, lds, gx, ktg, otg);
+  return launch_wgrad_v3<2, 1, 4>(g, dw, lds, gx, ktg, otg);
 }
 
 }  // namespace
@@ -1322,7 +1236,7 @@ int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C,
   g.N = N; g.C = C; g.H = H; g.W = W; g.O = O; g.oh = oh; g.ow = ow;
   g.k = k; g.stride = stride; g.pad = pad;
   {
-    int st = run_wgrad_v2(g, dw);
+    int st = run_wgrad_v3(g, dw);
     if (st >= 0) return st;
   }
   const int KW = C * k * k;
