@@ -269,6 +269,144 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(
   });
 }
 
+// ---- single-launch BatchNorm for channels of at most 16 384 elements (N*HW) ------------------
+// One 512-thread workgroup owns a channel and keeps its elements in registers (<= 8 float4 per
+// thread): x is read from HBM once (8 B per element instead of 12), mean and the centred second
+// moment are two block reductions over registers, no partials buffer, no second launch.
+constexpr int kBnVec = 8;
+
+__global__ __launch_bounds__(512) void k_bn_fused_fwd(const float* __restrict__ x,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      float* __restrict__ y,
+                                                      float* __restrict__ save_mean,
+                                                      float* __restrict__ save_var,
+                                                      float* __restrict__ running_mean,
+                                                      float* __restrict__ running_var, int N, int C,
+                                                      int HW, float eps, float momentum) {
+  __shared__ float sh[8];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int hw4 = HW >> 2, nvec = N * hw4;
+  const int64_t img_stride = (int64_t)C * HW;
+  const float* base = x + (int64_t)c * HW;
+  float4 v[kBnVec];
+  int64_t off[kBnVec];
+  float s = 0.0f;
+#pragma unroll
+  for (int u = 0; u < kBnVec; u++) {
+    int e = tid + 512 * u;
+    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    off[u] = -1;
+    if (e < nvec) {
+      int n = e / hw4, h4 = e - n * hw4;
+      off[u] = (int64_t)n * img_stride + 4 * h4;
+      v[u] = *reinterpret_cast<const float4*>(base + off[u]);
+      s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+    }
+  }
+  auto block_sum512 = [&](float t) {
+    t = wave_sum(t);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = t;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]));
+  };
+  const float m = (float)N * (float)HW;
+  const float mean = block_sum512(s) / m;
+  float q = 0.0f;
+#pragma unroll
+  for (int u = 0; u < kBnVec; u++)
+    if (off[u] >= 0) {
+      float a = v[u].x - mean, b = v[u].y - mean, cc = v[u].z - mean, d = v[u].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  const float var = block_sum512(q) / m;
+  if (tid == 0) {
+    if (save_mean) save_mean[c] = mean;
+    if (save_var) save_var[c] = var;
+    if (running_mean) running_mean[c] = running_mean[c] * (1.0f - momentum) + mean * momentum;
+    if (running_var) running_var[c] = running_var[c] * (1.0f - momentum) + var * momentum;
+  }
+  const float sd = sqrtf(var + eps);
+  const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+  float* ybase = y + (int64_t)c * HW;
+#pragma unroll
+  for (int u = 0; u < kBnVec; u++)
+    if (off[u] >= 0) {
+      float4 r;
+      r.x = (v[u].x - mean) / sd * w + b;
+      r.y = (v[u].y - mean) / sd * w + b;
+      r.z = (v[u].z - mean) / sd * w + b;
+      r.w = (v[u].w - mean) / sd * w + b;
+      *reinterpret_cast<float4*>(ybase + off[u]) = r;
+    }
+}
+
+__global__ __launch_bounds__(512) void k_bn_fused_bwd(const float* __restrict__ dy,
+                                                      const float* __restrict__ x,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ save_mean,
+                                                      const float* __restrict__ save_var,
+                                                      float* __restrict__ dx, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, int N, int C, int HW,
+                                                      float eps) {
+  __shared__ float sh[16];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int hw4 = HW >> 2, nvec = N * hw4;
+  const int64_t img_stride = (int64_t)C * HW;
+  const float mean = save_mean[c], sd = sqrtf(save_var[c] + eps);
+  const float* xb = x + (int64_t)c * HW;
+  const float* gb = dy + (int64_t)c * HW;
+  float4 xh[kBnVec], gv[kBnVec];
+  int64_t off[kBnVec];
+  float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int u = 0; u < kBnVec; u++) {
+    int e = tid + 512 * u;
+    off[u] = -1;
+    if (e < nvec) {
+      int n = e / hw4, h4 = e - n * hw4;
+      off[u] = (int64_t)n * img_stride + 4 * h4;
+      float4 xv = *reinterpret_cast<const float4*>(xb + off[u]);
+      gv[u] = *reinterpret_cast<const float4*>(gb + off[u]);
+      xh[u].x = (xv.x - mean) / sd; xh[u].y = (xv.y - mean) / sd;
+      xh[u].z = (xv.z - mean) / sd; xh[u].w = (xv.w - mean) / sd;
+      s1 += (gv[u].x + gv[u].y) + (gv[u].z + gv[u].w);
+      s2 += (gv[u].x * xh[u].x + gv[u].y * xh[u].y) + (gv[u].z * xh[u].z + gv[u].w * xh[u].w);
+    }
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((tid & 63) == 0) { sh[tid >> 6] = s1; sh[8 + (tid >> 6)] = s2; }
+  __syncthreads();
+  float sdy = 0.0f, sdyx = 0.0f;
+#pragma unroll
+  for (int w8 = 0; w8 < 8; w8++) { sdy += sh[w8]; sdyx += sh[8 + w8]; }
+  if (tid == 0) {
+    if (dgamma) dgamma[c] = sdyx;
+    if (dbeta) dbeta[c] = sdy;
+  }
+  if (!dx) return;
+  const float w = gamma ? gamma[c] : 1.0f;
+  const float m = (float)N * (float)HW;
+  const float k1 = sdy / m, k2 = sdyx / m;
+  float* db = dx + (int64_t)c * HW;
+#pragma unroll
+  for (int u = 0; u < kBnVec; u++)
+    if (off[u] >= 0) {
+      float4 r;
+      r.x = (gv[u].x - k1 - xh[u].x * k2) * w / sd;
+      r.y = (gv[u].y - k1 - xh[u].y * k2) * w / sd;
+      r.z = (gv[u].z - k1 - xh[u].z * k2) * w / sd;
+      r.w = (gv[u].w - k1 - xh[u].w * k2) * w / sd;
+      *reinterpret_cast<float4*>(db + off[u]) = r;
+    }
+}
+
+inline bool bn_fused_ok(int N, int C, int HW) {
+  return (HW & 3) == 0 && (int64_t)N * HW <= (int64_t)512 * 4 * kBnVec && C >= 32;
+}
+
 void bn_split(int N, int C, int& S, int& ipb) {
   int want = (int)df_ceil_div((int64_t)num_cus() * 4, C);
   S = std::max(1, std::min(want, N));
@@ -651,12 +789,18 @@ int dfhip_bn2d_forward_train(const float* x, const float* gamma, const float* be
   DF_INIT();
   DF_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bn2d_forward: non-positive dimension");
   DF_CHECK_ARG(x && y, "bn2d_forward: null array");
+  double n = (double)N * C * HW;
+  ProfScope prof("bn2d_fwd", 0.0, 12.0 * n);
+  if (bn_fused_ok(N, C, HW)) {
+    hipLaunchKernelGGL(k_bn_fused_fwd, dim3((unsigned)C), dim3(512), 0, stream(), x, gamma, beta, y, save_mean,
+                       save_var, running_mean, running_var, N, C, HW, eps, momentum);
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
   int S, ipb;
   bn_split(N, C, S, ipb);
   float* partial = workspace((size_t)C * S * 3 * sizeof(float));
   if (!partial) return DFHIP_OUT_OF_MEMORY;
-  double n = (double)N * C * HW;
-  ProfScope prof("bn2d_fwd", 0.0, 12.0 * n);
   dim3 grid((unsigned)C, (unsigned)S);
   hipLaunchKernelGGL(k_bn_stats, grid, dim3(kThreads), 0, stream(), x, partial, N, C, HW, S, ipb);
   DF_LAUNCH_CHECK();
@@ -687,11 +831,17 @@ int dfhip_bn2d_backward(const float* dy, const float* x, const float* gamma, con
   DF_INIT();
   DF_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bn2d_backward: non-positive dimension");
   DF_CHECK_ARG(dy && x && save_mean && save_var, "bn2d_backward: null array");
+  ProfScope prof("bn2d_bwd", 0.0, 20.0 * (double)N * C * HW);
+  if (bn_fused_ok(N, C, HW)) {
+    hipLaunchKernelGGL(k_bn_fused_bwd, dim3((unsigned)C), dim3(512), 0, stream(), dy, x, gamma, save_mean,
+                       save_var, dx, dgamma, dbeta, N, C, HW, eps);
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
   int S, ipb;
   bn_split(N, C, S, ipb);
   float* partial = workspace((size_t)C * S * 2 * sizeof(float));
   if (!partial) return DFHIP_OUT_OF_MEMORY;
-  ProfScope prof("bn2d_bwd", 0.0, 20.0 * (double)N * C * HW);
   dim3 grid((unsigned)C, (unsigned)S);
   hipLaunchKernelGGL(k_bn_bwd_stats, grid, dim3(kThreads), 0, stream(), dy, x, save_mean, save_var,
                      partial, N, C, HW, S, ipb, eps);
