@@ -66,6 +66,7 @@ struct Geo {
   unsigned long long* stamps;  // diagnostic builds only (DFHIP_CONV_STAMP): per-block time stamps
   int dbg;                     // diagnostics: 1 = loaders idle in the main loop, 2 = no MFMAs
   unsigned m_perimg, m_pc, m_sd;   // exact division by multiplication (magic = ceil(2^32/d), 0 = divide by 1)
+  unsigned m_brbc, m_bc, m_birl4, m_rl4, m_run4;
 };
 
 __device__ __forceinline__ void decode_pixel(const Geo& g, int q, int& img, int& r, int& col) {
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(Geo g) {
 constexpr int kPV = 2;   // patch float4 vectors per thread per chunk
 constexpr int kWV = 5;   // weight float4 vectors per thread per chunk
 
-template <int KS, int MODE>
+template <int KS, int MODE, int NPK>
 __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int k = KS, k2 = KS * KS;
@@ -278,6 +279,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   const int half = lane >> 5, l31 = lane & 31;
   const int PT = g.PT, KSPLIT = 8 / g.PT;
   const int pt = wave % PT, ks = wave / PT;
+  int stamp_i = 0;
+#define DF_STAMP()                                                                              \
+  do {                                                                                          \
+    if (g.stamps && lane == 0 && (wave == 0 || wave == 7) && stamp_i < 30)                      \
+      g.stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave == 7)) * 32 + stamp_i++] = \
+          __builtin_readcyclecounter();                                                         \
+  } while (0)
+  DF_STAMP();
 
   int gx = blockIdx.x;
   const int grx = gx % g.gr; gx /= g.gr;
@@ -292,8 +301,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   const int su_lo = min(max(0, (r0 * g.so + g.u0 >= 0 ? (r0 * g.so + g.u0) / g.sd : 0)), g.HS - RL / g.WS);
 
   // ---- per-lane, per-tap read descriptors of this wave's pixel tile ----
-  int q = pt * 32 + l31, img, r, col;
-  decode_pixel(g, q, img, r, col);
+  const int q = pt * 32 + l31;
+  const int img = (int)fast_div((unsigned)q, g.m_brbc);
+  const int qrem = q - img * (g.BR * g.BC);
+  const int r = (int)fast_div((unsigned)qrem, g.m_bc), col = qrem - r * g.BC;
   const bool pvalid = q < g.BI * g.BR * g.BC && n0 + img < g.N && r0 + r < g.HD;
   int poff[k2];
   unsigned vmask = 0;
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
       const int ti = MODE == 0 ? i : k - 1 - i, tj = MODE == 0 ? j : k - 1 - j;
       int un = (r0 + r) * g.so + g.u0 + ti, vn = col * g.so + g.u0 + tj;
       bool ok = pvalid && un >= 0 && vn >= 0;
-      int su = ok ? un / g.sd : 0, sv = ok ? vn / g.sd : 0;
+      int su = ok ? (int)fast_div((unsigned)un, g.m_sd) : 0, sv = ok ? (int)fast_div((unsigned)vn, g.m_sd) : 0;
       ok = ok && su * g.sd == un && sv * g.sd == vn && su < g.HS && sv < g.WS;
       if (MODE == 2) ok = ok && tapsel == t;
       poff[t] = ok ? img * RL + (su - su_lo) * g.WS + sv : 0;
@@ -327,9 +338,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   for (int u = 0; u < kPV; u++) {
     int v = tid + 512 * u;
     v = v < pvecs ? v : 0;
-    int c = v / (g.BI * RL4);
+    int c = (int)fast_div((unsigned)v, g.m_birl4);
     int rem = v - c * (g.BI * RL4);
-    int im = rem / RL4, q4 = rem - im * RL4;
+    int im = (int)fast_div((unsigned)rem, g.m_rl4), q4 = rem - im * RL4;
     int imc = min(im, g.N - 1 - n0);            // images past the batch end are never read
     p_src[u] = (unsigned)(((int64_t)imc * g.CS + c) * src_plane + (int64_t)su_lo * g.WS + 4 * q4);
   }
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
     int f = tid + 512 * u;
     const bool live = f < wvecs;
     f = live ? f : 0;
-    int row = f / run4, e4 = f - row * run4;
+    int row = (int)fast_div((unsigned)f, g.m_run4), e4 = f - row * run4;
     if (MODE == 0) w_src[u] = (unsigned)(((d0 + min(row, dmax - 1)) * g.wC) * k2 + 4 * e4);
     else w_src[u] = (unsigned)((row * g.wC + d0) * k2 + 4 * e4);     // host guarantees CD % 32 == 0
     w_lx[u] = live ? ((MODE == 0 && row >= dmax) ? -2 : row * RS + 4 * e4) : -1;
@@ -385,11 +396,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
 #pragma unroll
   for (int rr = 0; rr < 16; rr++) acc[rr] = 0.0f;
 
+  DF_STAMP();
   DF_ISSUE(0);
+  DF_STAMP();
   DF_COMMIT(0);
+  DF_STAMP();
   __syncthreads();
+  DF_STAMP();
 
-  const int npk = (CCP >> 1) / KSPLIT;        // k pairs of a tap that this wave owns (>= 1)
+  // k pairs of a tap that this wave owns (>= 1); a compile-time count lets the tap x pair nest
+  // unroll into straight-line code whose LDS reads are hoisted ahead of the MFMAs
+  const int npk = NPK ? NPK : (CCP >> 1) / KSPLIT;
   const int c_first = 2 * ks * npk + half;    // this lane's first channel inside a chunk
   const int astep = MODE == 0 ? 2 * k2 : 2 * RS;
   const int bstep = 2 * PEp;
@@ -404,17 +421,30 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
       if (__ballot(ok) != 0ull) {              // else: nobody in the wave reads through this tap
         const float* bp = Xb + poff[t];
         const float* ap = aq + t;
-#pragma unroll 4
-        for (int p = 0; p < npk; p++) {
-          float a = ap[p * astep];
-          float b = bp[p * bstep];
-          b = ok ? b : 0.0f;
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        if (NPK) {
+#pragma unroll
+          for (int p = 0; p < (NPK ? NPK : 1); p++) {
+            float a = ap[p * astep];
+            float b = bp[p * bstep];
+            b = ok ? b : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+          }
+        } else {
+#pragma unroll 2
+          for (int p = 0; p < npk; p++) {
+            float a = ap[p * astep];
+            float b = bp[p * bstep];
+            b = ok ? b : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+          }
         }
       }
     }
+    DF_STAMP();
     if (ch + 1 < nchunks) DF_COMMIT(buf ^ 1);  // the other buffer was released at the last barrier
+    DF_STAMP();
     __syncthreads();
+    DF_STAMP();
   }
 #undef DF_ISSUE
 #undef DF_COMMIT
@@ -451,6 +481,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
       }
     }
   }
+  DF_STAMP();
+#undef DF_STAMP
 }
 
 // out[i] = sum_s slabs[s][i] (+ bias[(i / plane) % CD])
@@ -930,17 +962,27 @@ constexpr size_t kLdsBudget = 64 * 1024;  // keeps two workgroups resident per C
 
 unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)((((uint64_t)1 << 32) + d - 1) / d); }
 
-template <int KS, int MODE>
-int launch_igemm_v4(const Geo& g, dim3 grid, size_t lds) {
+template <int KS, int MODE, int NPK>
+int launch_igemm_v4n(const Geo& g, dim3 grid, size_t lds) {
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv_igemm_v4<KS, MODE>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv_igemm_v4<KS, MODE, NPK>,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)std::max(lds, (size_t)65536)));
     attr_lds = std::max(lds, (size_t)65536);
   }
-  hipLaunchKernelGGL((k_conv_igemm_v4<KS, MODE>), grid, dim3(512), lds, stream(), g);
+  hipLaunchKernelGGL((k_conv_igemm_v4<KS, MODE, NPK>), grid, dim3(512), lds, stream(), g);
   return DFHIP_OK;
+}
+
+template <int KS, int MODE>
+int launch_igemm_v4(const Geo& g, dim3 grid, size_t lds) {
+  const int npk = (g.CC >> 1) / (8 / g.PT);
+  if (npk == 1) return launch_igemm_v4n<KS, MODE, 1>(g, grid, lds);
+  if (npk == 2) return launch_igemm_v4n<KS, MODE, 2>(g, grid, lds);
+  if (npk == 4) return launch_igemm_v4n<KS, MODE, 4>(g, grid, lds);
+  if (npk == 8) return launch_igemm_v4n<KS, MODE, 8>(g, grid, lds);
+  return launch_igemm_v4n<KS, MODE, 0>(g, grid, lds);
 }
 
 int finish_slabs(const Geo& g, int splits, float* final_dst, const float* bias, int64_t out_elems) {
@@ -988,7 +1030,7 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias) 
       int pvecs = cc * g.PE / 4, wvecs = 8 * cc * k2;
       return lds <= 76 * 1024 && pvecs <= 512 * kPV && wvecs <= 512 * kWV;
     };
-    static int maxchunks = getenv("DFHIP_MAXCHUNKS") ? atoi(getenv("DFHIP_MAXCHUNKS")) : 8;
+    static int maxchunks = getenv("DFHIP_MAXCHUNKS") ? atoi(getenv("DFHIP_MAXCHUNKS")) : 2;
     int c = std::max(8, 2 * ksplit);
     while (c < 32 && g.CS / c > maxchunks && g.CS % (2 * c) == 0 && fits(2 * c)) c *= 2;
     if (g.CS % c != 0 || !fits(c)) continue;
@@ -999,12 +1041,29 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias) 
   if (!chosen) return -1;
   g.PT = chosen;
   g.CC = ccp;
+  g.m_sd = magic_u32((unsigned)g.sd);
+  g.m_brbc = magic_u32((unsigned)(g.BR * g.BC));
+  g.m_bc = magic_u32((unsigned)g.BC);
+  {
+    const int RL4 = g.PE / g.BI / 4;
+    g.m_birl4 = magic_u32((unsigned)(g.BI * RL4));
+    g.m_rl4 = magic_u32((unsigned)RL4);
+    g.m_run4 = magic_u32((unsigned)((g.mode == 0 ? ccp * k2 : 32 * k2) / 4));
+  }
   g.cs_per_split = g.CS;
   g.slab_stride = 0;
   g.dst = final_dst;
   g.bias = bias;
   dim3 grid((unsigned)(gi * g.gr), (unsigned)dtiles, 1);
   int st = DFHIP_OK;
+  g.stamps = nullptr;
+  static int stamp_mode = -1;
+  if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
+  const size_t nstamp = (size_t)grid.x * grid.y * 2 * 32;
+  if (stamp_mode) {
+    g.stamps = (unsigned long long*)workspace2(nstamp * 8);
+    (void)hipMemsetAsync(g.stamps, 0, nstamp * 8, stream());
+  }
 #define DF_V4(KSV)                                                        \
   (g.mode == 0 ? launch_igemm_v4<KSV, 0>(g, grid, lds)                    \
                : (g.mode == 1 ? launch_igemm_v4<KSV, 1>(g, grid, lds)     \
@@ -1014,6 +1073,21 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias) 
 #undef DF_V4
   if (st != DFHIP_OK) return st;
   DF_LAUNCH_CHECK();
+  if (stamp_mode) {
+    std::vector<unsigned long long> h(nstamp);
+    (void)hipStreamSynchronize(stream());
+    (void)hipMemcpy(h.data(), g.stamps, nstamp * 8, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[stamp4] mode %d k %d PT %d CC %d PE %d grid %u x %u lds %zu\n", g.mode, g.k, g.PT, g.CC, g.PE,
+            grid.x, grid.y, lds);
+    for (size_t b : {(size_t)0, nstamp / 64 / 2}) {
+      for (int w = 0; w < 2; w++) {
+        fprintf(stderr, "[stamp4]  block %zu wave %d:", b, w ? 7 : 0);
+        unsigned long long t0 = h[(b * 2) * 32];
+        for (int i = 0; i < 32 && h[(b * 2 + w) * 32 + i]; i++) fprintf(stderr, " %lld", (long long)(h[(b * 2 + w) * 32 + i] - t0));
+        fprintf(stderr, "\n");
+      }
+    }
+  }
   return DFHIP_OK;
 }
 
