@@ -113,7 +113,8 @@ def init_communicator(device):
     """Build the communicator for the launch environment (RANK / WORLD_SIZE / MASTER_* as set
     by torch.distributed.run).  world == 1 needs no process group."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    force = os.environ.get("DF_FORCE_COMM", "") == "1"       # tests: exercise the collective with one rank
+    if world <= 1 and not force:
         return LocalCommunicator()
     import torch.distributed as dist
     if not dist.is_initialized():
@@ -133,7 +134,7 @@ class GradientBucket:
         self.sizes = [int(p.size) for p in self.params]
         self.total = sum(self.sizes)
         self.flat = None
-        if comm.world > 1 and self.params:
+        if (comm.world > 1 or isinstance(comm, TorchHostCommunicator)) and self.params:
             dev = self.params[0].device
             self.flat = BackendTensor.make((self.total,), device=dev)
             self.flat.fill(0.0)

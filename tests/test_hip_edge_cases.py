@@ -1,0 +1,136 @@
+"""GPU: protocol edge cases of the hip device — empty arrays, ragged tails, error classes,
+8-dimension limit, views with offsets / negative strides / stride 0, pool reuse."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _arr(mod, a):
+    h = mod.Array(a.size)
+    mod.from_numpy(a, h)
+    return h
+
+
+def _back(mod, h):
+    return mod.to_numpy(h, (h.size,), (1,), 0)
+
+
+def test_empty_and_ragged_sizes(hip_device):
+    mod = hip_device.mod
+    e = mod.Array(0)
+    mod.fill(e, 1.0)
+    mod.ewise_add(e, e, e)
+    assert mod.to_numpy(e, (0,), (1,), 0).shape == (0,)
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 5, 63, 64, 65, 255, 257, 1023, 4097):
+        a, b = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+        out = mod.Array(n)
+        mod.ewise_mul(_arr(mod, a), _arr(mod, b), out)
+        assert np.array_equal(_back(mod, out), a * b), n
+        mod.scalar_maximum(_arr(mod, a), 0.25, out)
+        assert np.array_equal(_back(mod, out), np.maximum(a, np.float32(0.25))), n
+        s = mod.Array(1)
+        mod.reduce_max(_arr(mod, a), s, n)
+        assert _back(mod, s)[0] == a.max()
+
+
+def test_error_classes_match_the_cuda_module(hip_device):
+    mod = hip_device.mod
+    a, out = mod.Array(4), mod.Array(5)
+    with pytest.raises(ValueError):
+        mod.ewise_add(a, a, out)                       # size mismatch (.cu:232-236)
+    with pytest.raises(ValueError):
+        mod.compact(a, mod.Array(1), (1,) * 9, (1,) * 9, 0)     # > 8 dims (.cu:113-118)
+    with pytest.raises(ValueError):
+        mod.compact(a, mod.Array(3), (2, 2), (2, 1), 0)          # view size != out size
+    with pytest.raises(IndexError):
+        mod.to_numpy(a, (5,), (1,), 0)                           # view exceeds the array
+    with pytest.raises(ValueError):
+        mod.from_numpy(np.zeros(3, np.float32), a)
+    with pytest.raises(ValueError):
+        mod.matmul(a, a, out, 2, 2, 2)
+    with pytest.raises(ValueError):
+        mod.conv2d_forward(a, a, None, a, 1, 1, 2, 2, 1, 5, 1, 0)   # kernel larger than input
+
+
+def test_numpy_value_semantics(hip_device):
+    mod = hip_device.mod
+    a = _arr(mod, np.array([1.0, -2.0, 0.0, np.inf], np.float32))
+    out = mod.Array(4)
+    mod.scalar_div(a, 0.0, out)                                  # NumPy device: inf/nan, no exception
+    got = _back(mod, out)
+    assert np.isposinf(got[0]) and np.isneginf(got[1]) and np.isnan(got[2])
+    mod.ewise_maximum(a, _arr(mod, np.array([np.nan, 1.0, 0.0, 0.0], np.float32)), out)
+    got = _back(mod, out)
+    assert np.isnan(got[0]) and got[1] == 1.0                    # np.maximum propagates NaN
+    mod.scalar_power(a, 2.0, out)
+    assert np.array_equal(_back(mod, out)[:3], np.array([1.0, 4.0, 0.0], np.float32))
+
+
+def test_views_offsets_negative_and_zero_strides(hip_device):
+    mod = hip_device.mod
+    base = np.arange(120, dtype=np.float32)
+    h = _arr(mod, base)
+    cases = [((2, 3, 4), (60, 20, 5), 3), ((5, 4), (-24, 1), 100), ((3, 2, 2, 5), (0, 60, 0, 1), 7),
+             ((1, 1, 6), (0, 0, -2), 20), ((2, 2, 2, 2, 2, 2, 2), (64, 32, 16, 8, 4, 2, 1), 0)]
+    for shp, st, off in cases:
+        want = np.lib.stride_tricks.as_strided(base[off:] if all(s >= 0 for s in st) else base,
+                                               shape=shp, strides=tuple(4 * s for s in st)) \
+            if all(s >= 0 for s in st) else None
+        if want is None:
+            idx = np.indices(shp)
+            want = base[off + sum(idx[d] * st[d] for d in range(len(shp)))]
+        out = mod.Array(int(np.prod(shp)))
+        mod.compact(h, out, shp, st, off)
+        assert np.array_equal(_back(mod, out).reshape(shp), want), (shp, st, off)
+        assert np.array_equal(mod.to_numpy(h, shp, st, off), want)
+    # np.int64 extents (they appear after permute(), backend_tensor.py:405-406)
+    out = mod.Array(12)
+    mod.compact(h, out, (np.int64(3), np.int64(4)), (np.int64(1), np.int64(3)), np.int64(0))
+    assert np.array_equal(_back(mod, out).reshape(3, 4), base[:12].reshape(4, 3).T)
+
+
+def test_pool_reuses_blocks_without_new_hipmalloc(hip_device):
+    mod = hip_device.mod
+    for _ in range(3):
+        hs = [mod.Array(1000 + i) for i in range(50)]
+        del hs
+    before = mod.pool_stats()["hipmalloc_calls"]
+    for _ in range(5):
+        hs = [mod.Array(1000 + i) for i in range(50)]
+        del hs
+    assert mod.pool_stats()["hipmalloc_calls"] == before
+
+
+def test_transposed_gemm_operands_and_bias(hip_device):
+    mod = hip_device.mod
+    rng = np.random.default_rng(2)
+    for (m, k, p) in ((128, 784, 256), (256, 256, 10), (37, 19, 5), (1, 300, 1), (300, 1, 7)):
+        A = rng.standard_normal((m, k)).astype(np.float32)
+        B = rng.standard_normal((k, p)).astype(np.float32)
+        bias = rng.standard_normal(p).astype(np.float32)
+        want = A @ B
+        for ta in (False, True):
+            for tb in (False, True):
+                a = _arr(mod, np.ascontiguousarray(A.T if ta else A))
+                b = _arr(mod, np.ascontiguousarray(B.T if tb else B))
+                out = mod.Array(m * p)
+                mod.gemm(a, b, None, out, m, k, p, ta, tb)
+                got = _back(mod, out).reshape(m, p)
+                assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), (m, k, p, ta, tb)
+        out = mod.Array(m * p)
+        mod.gemm(_arr(mod, A), _arr(mod, B), _arr(mod, bias), out, m, k, p, False, False)
+        assert np.abs(_back(mod, out).reshape(m, p) - (want + bias)).max() <= 1e-4 * max(1.0, np.abs(want).max())
+
+
+def test_split_k_gemm_long_reduction(hip_device):
+    """im2col-style A^T.dC: small output, 65 536-long reduction (primitive-path wgrad)."""
+    mod = hip_device.mod
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((65536, 27)).astype(np.float32)
+    D = rng.standard_normal((65536, 32)).astype(np.float32)
+    out = mod.Array(27 * 32)
+    mod.gemm(_arr(mod, A), _arr(mod, D), None, out, 27, 65536, 32, True, False)
+    want = A.astype(np.float64).T @ D.astype(np.float64)
+    assert np.abs(_back(mod, out).reshape(27, 32) - want).max() <= 1e-4 * np.abs(want).max()
