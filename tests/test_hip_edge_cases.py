@@ -70,7 +70,7 @@ def test_numpy_value_semantics(hip_device):
 
 def test_views_offsets_negative_and_zero_strides(hip_device):
     mod = hip_device.mod
-    base = np.arange(120, dtype=np.float32)
+    base = np.arange(128, dtype=np.float32)
     h = _arr(mod, base)
     cases = [((2, 3, 4), (60, 20, 5), 3), ((5, 4), (-24, 1), 100), ((3, 2, 2, 5), (0, 60, 0, 1), 7),
              ((1, 1, 6), (0, 0, -2), 20), ((2, 2, 2, 2, 2, 2, 2), (64, 32, 16, 8, 4, 2, 1), 0)]
