@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "dfhip_internal.h"
@@ -701,6 +702,14 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
+  int stamp_i = 0;
+#define WG_STAMP()                                                                              \
+  do {                                                                                          \
+    if (g.stamps && tid == 0 && stamp_i < 32)                                                   \
+      g.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + stamp_i++] = \
+          __builtin_readcyclecounter();                                                         \
+  } while (0)
+  WG_STAMP();
   const int kk0 = blockIdx.y * (KT * 32);
   const int o0 = blockIdx.z * (OT * 32);
   const int cA = kk0 / k2;
@@ -787,13 +796,16 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
     if (tid + 512 < pvecs) *reinterpret_cast<f32x4*>(Xs_ + 4 * (tid + 512)) = pv1;               \
   } while (0)
 
+  WG_STAMP();
   __syncthreads();                             // zero fill done
+  WG_STAMP();
   if (my_groups > 0) {
     WG_ISSUE(0);
     WG_COMMIT(0);
   }
   su_lo_cur = su_lo_nxt; r0_cur = r0_nxt;
   __syncthreads();
+  WG_STAMP();
 
   const int R = g.BI * g.BR;          // pixel rows of a group
   const int ppr = g.BC >> 1;          // pixel pairs per row
@@ -831,9 +843,11 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
         }
       }
     }
+    WG_STAMP();
     if (gi_ + 1 < my_groups) WG_COMMIT(buf ^ 1);
     su_lo_cur = su_lo_nxt; r0_cur = r0_nxt;
     __syncthreads();
+    WG_STAMP();
   }
 #undef WG_ISSUE
 #undef WG_COMMIT
@@ -878,6 +892,353 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
         int o = o0 + ti * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
         if (o < g.O && kk < KW) out[(int64_t)o * KW + kk] = v;
       }
+    }
+  }
+  WG_STAMP();
+#undef WG_STAMP
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient, tap-major kernel (3x3 and 1x1 layers with >= 16 input channels).
+//
+// dW[o][c][i][j] = sum over (n, r, s) of dY[n][o][r][s] * X[n][c][r*stride+i-pad][s*stride+j-pad].
+// An accumulator tile is 32 output channels x 32 input channels of ONE tap, so a wave keeps
+// k*k tiles (9 x 16 registers) and the reduction index of an MFMA step is a pixel: whether a tap
+// falls into the padding is then the same for all 64 lanes and such steps are SKIPPED by a scalar
+// branch instead of being multiplied by zero (2x2 images: 56 % of the dense steps, 4x4: 31 %).
+// The two k slots of the 32x32x2 MFMA are the two images of an image pair at the same pixel, so
+// both halves of the wave agree on validity as well.  The dY operand of a step is read once and
+// used by all k*k taps.
+//
+//   grid = (pixel slabs, C/32, O/32); a block walks its groups (BI images x BR output rows),
+//   staging X[32 channels] and dY[32 channels] of group g+1 into the other LDS buffer while group
+//   g is in the matrix cores; the eight waves split the steps of a group; at the end they are
+//   summed through LDS (float4 reduce-scatter, four taps per round) and written as one slab in
+//   accumulator order, which k_wgrad_tap_sum adds over the pixel slabs and scatters to OIHW.
+//
+// LDS image: [channel][image pair][pixel][2 images], channel stride == 2 (mod 64) floats: the 64
+// lanes of an operand read (32 channels x 2 images) hit 64 different banks.
+// ---------------------------------------------------------------------------------------
+struct TGeo {
+  const float* x;
+  const float* dy;
+  float* slabs;
+  int N, C, H, W, O, oh, ow;
+  int k, stride, pad;
+  int BI, BR, gr, ngroups;   // group = BI images x BR output rows (whole rows)
+  int RLr;                   // source rows staged per group
+  int XST, DST;              // channel strides in LDS (floats)
+  int ksg;                   // MFMA steps per group = BI/2 * BR * ow
+  unsigned m_brow, m_ow;     // magic dividers: BR*ow, ow
+  unsigned m_xc, m_xp;       // staging: P*RL4, RL4
+  unsigned m_dc, m_dp;       // staging: P*BRBC4, BRBC4
+  unsigned long long* stamps;
+};
+
+template <int KS, int XV, int DV, bool DENSE>
+__global__ __launch_bounds__(512) void k_conv_wgrad_tap(TGeo g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int T = KS * KS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  int stamp_i = 0;
+#define TG_STAMP()                                                                              \
+  do {                                                                                          \
+    if (g.stamps && tid == 0 && stamp_i < 16)                                                   \
+      g.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + stamp_i++] = \
+          __builtin_readcyclecounter();                                                         \
+  } while (0)
+  TG_STAMP();
+  const int c0 = blockIdx.y * 32, o0 = blockIdx.z * 32;
+  const int cn = min(32, g.C - c0), on = min(32, g.O - o0);
+  const int P = g.BI >> 1;
+  const int RL = g.RLr * g.W;                 // staged floats per (image, channel)
+  const int BRBC = g.BR * g.ow;
+  const int RL4 = RL >> 2, BRBC4 = BRBC >> 2;
+  const int buf_floats = 32 * (g.DST + g.XST);
+  const int64_t xplane = (int64_t)g.H * g.W, yplane = (int64_t)g.oh * g.ow;
+
+  // ---- staging descriptors: item = (channel, image pair, 4 pixels); group-invariant ----
+  const int xitems = cn * P * RL4, ditems = on * P * BRBC4;
+  unsigned x_src[XV], d_src[DV];
+  int x_lx[XV], d_lx[DV];
+#pragma unroll
+  for (int u = 0; u < XV; u++) {
+    int v = tid + 512 * u;
+    const bool live = v < xitems;
+    v = live ? v : 0;
+    int c = (int)fast_div((unsigned)v, g.m_xc);
+    int rem = v - c * (P * RL4);
+    int pp = (int)fast_div((unsigned)rem, g.m_xp), q4 = rem - pp * RL4;
+    x_src[u] = (unsigned)(((int64_t)(2 * pp) * g.C + c) * xplane + 4 * q4);
+    x_lx[u] = live ? 32 * g.DST + c * g.XST + (pp * RL + 4 * q4) * 2 : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < DV; u++) {
+    int v = tid + 512 * u;
+    const bool live = v < ditems;
+    v = live ? v : 0;
+    int o = (int)fast_div((unsigned)v, g.m_dc);
+    int rem = v - o * (P * BRBC4);
+    int pp = (int)fast_div((unsigned)rem, g.m_dp), q4 = rem - pp * BRBC4;
+    d_src[u] = (unsigned)(((int64_t)(2 * pp) * g.O + o) * yplane + 4 * q4);
+    d_lx[u] = live ? o * g.DST + (pp * BRBC + 4 * q4) * 2 : -1;
+  }
+  const int64_t x_img = (int64_t)g.C * xplane, d_img = (int64_t)g.O * yplane;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; t++)
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) acc[t][rr] = 0.0f;
+
+  const int my_groups = (g.ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  f32x4 xa[XV], xb[XV], da[DV], db[DV];
+  int su_lo_cur = 0, r0_cur = 0, su_lo_nxt = 0, r0_nxt = 0;
+#define TG_ISSUE(gi_)                                                                            \
+  do {                                                                                           \
+    int grp_ = blockIdx.x + (gi_) * gridDim.x;                                                   \
+    int gimg_ = grp_ / g.gr;                                                                     \
+    int n0_ = gimg_ * g.BI;                                                                      \
+    r0_nxt = (grp_ - gimg_ * g.gr) * g.BR;                                                       \
+    su_lo_nxt = min(max(0, r0_nxt * g.stride - g.pad), g.H - g.RLr);                             \
+    const float* xb_ = g.x + ((int64_t)n0_ * g.C + c0) * xplane + (int64_t)su_lo_nxt * g.W;      \
+    const float* yb_ = g.dy + ((int64_t)n0_ * g.O + o0) * yplane + (int64_t)r0_nxt * g.ow;       \
+    _Pragma("unroll") for (int u_ = 0; u_ < DV; u_++) {                                          \
+      da[u_] = *reinterpret_cast<const f32x4*>(yb_ + d_src[u_]);                                 \
+      db[u_] = *reinterpret_cast<const f32x4*>(yb_ + d_src[u_] + d_img);                         \
+    }                                                                                            \
+    _Pragma("unroll") for (int u_ = 0; u_ < XV; u_++) {                                          \
+      xa[u_] = *reinterpret_cast<const f32x4*>(xb_ + x_src[u_]);                                 \
+      xb[u_] = *reinterpret_cast<const f32x4*>(xb_ + x_src[u_] + x_img);                         \
+    }                                                                                            \
+  } while (0)
+#define TG_PUT(base_, lx_, va_, vb_)                                                             \
+  do {                                                                                           \
+    if ((lx_) >= 0) {                                                                            \
+      f32x2* q_ = reinterpret_cast<f32x2*>((base_) + (lx_));                                     \
+      q_[0] = (f32x2){(va_).x, (vb_).x};                                                         \
+      q_[1] = (f32x2){(va_).y, (vb_).y};                                                         \
+      q_[2] = (f32x2){(va_).z, (vb_).z};                                                         \
+      q_[3] = (f32x2){(va_).w, (vb_).w};                                                         \
+    }                                                                                            \
+  } while (0)
+#define TG_COMMIT(buf)                                                                           \
+  do {                                                                                           \
+    float* B_ = smem + (buf) * buf_floats;                                                       \
+    _Pragma("unroll") for (int u_ = 0; u_ < DV; u_++) TG_PUT(B_, d_lx[u_], da[u_], db[u_]);      \
+    _Pragma("unroll") for (int u_ = 0; u_ < XV; u_++) TG_PUT(B_, x_lx[u_], xa[u_], xb[u_]);      \
+  } while (0)
+
+  TG_STAMP();
+  if (my_groups > 0) {
+    TG_ISSUE(0);
+    TG_COMMIT(0);
+  }
+  su_lo_cur = su_lo_nxt; r0_cur = r0_nxt;
+  __syncthreads();
+  TG_STAMP();
+
+  // this wave's share of the steps of a group
+  const int e_lo = (wave * g.ksg) >> 3, e_hi = ((wave + 1) * g.ksg) >> 3;
+  const int lane_d = l31 * g.DST + half;
+  const int lane_x = 32 * g.DST + l31 * g.XST + half;
+  const int W2 = 2 * g.W;
+
+  for (int gi_ = 0; gi_ < my_groups; gi_++) {
+    const int buf = gi_ & 1;
+    if (gi_ + 1 < my_groups) TG_ISSUE(gi_ + 1);
+    {
+      const float* Dl = smem + buf * buf_floats + lane_d;
+      const float* Xl = smem + buf * buf_floats + lane_x;
+      // Two operand sets (this step / next step) used in turn: while the MFMAs of a step issue,
+      // the scalar decode and the LDS reads of the next step are placed BETWEEN them in program
+      // order (scheduling barriers keep them there) — the two waves of a SIMD run in lockstep
+      // through the matrix pipe, so whatever sits before the first or after the last MFMA of
+      // a step is time in which the pipe idles for both.
+      float a_0, b_0[T], a_1, b_1[T];
+      unsigned m_0, m_1;
+      int e_n = e_lo;
+      int pr_n = (int)fast_div((unsigned)e_lo, g.m_brow);
+      int r_n, s_n;
+      {
+        const int rem_ = e_lo - pr_n * BRBC;
+        r_n = (int)fast_div((unsigned)rem_, g.m_ow);
+        s_n = rem_ - r_n * g.ow;
+      }
+      int xoff_n;
+#define TG_DECODE(MOUT)                                                                          \
+  do {                                                                                           \
+    const int rs_ = (r0_cur + r_n) * g.stride - g.pad, cs_ = s_n * g.stride - g.pad;             \
+    unsigned rowb_ = 0, colb_ = 0;                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < KS; i_++) {                                          \
+      rowb_ |= ((unsigned)(rs_ + i_) < (unsigned)g.H ? 1u : 0u) << i_;                           \
+      colb_ |= ((unsigned)(cs_ + i_) < (unsigned)g.W ? 1u : 0u) << i_;                           \
+    }                                                                                            \
+    unsigned mm_ = 0;                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < KS; i_++)                                            \
+      mm_ |= ((rowb_ >> i_) & 1u) ? (colb_ << (i_ * KS)) : 0u;                                   \
+    MOUT = mm_;                                                                                  \
+    xoff_n = 2 * (pr_n * RL + (rs_ - su_lo_cur) * g.W + cs_);                                    \
+  } while (0)
+#define TG_ADVANCE()                                                                             \
+  do {                                                                                           \
+    if (e_n + 1 < e_hi) {                                                                        \
+      e_n++; s_n++;                                                                              \
+      if (s_n == g.ow) { s_n = 0; r_n++; if (r_n == g.BR) { r_n = 0; pr_n++; } }                 \
+    }                                                                                            \
+  } while (0)
+#define TG_READ_ROW(i_, BN)                                                                      \
+  do {                                                                                           \
+    const float* xq_ = Xl + xoff_n + (i_) * W2;                                                  \
+    _Pragma("unroll") for (int j_ = 0; j_ < KS; j_++) BN[(i_) * KS + j_] = xq_[2 * j_];          \
+  } while (0)
+#define TG_MFMA(t_, AC, BC, MC)                                                                  \
+  do {                                                                                           \
+    if (DENSE) {                                                                                 \
+      const float bz_ = ((MC >> (t_)) & 1u) ? BC[t_] : 0.0f;                                     \
+      acc[t_] = __builtin_amdgcn_mfma_f32_32x32x2f32(AC, bz_, acc[t_], 0, 0, 0);                 \
+    } else if ((MC >> (t_)) & 1u) {                                                              \
+      acc[t_] = __builtin_amdgcn_mfma_f32_32x32x2f32(AC, BC[t_], acc[t_], 0, 0, 0);              \
+    }                                                                                            \
+  } while (0)
+#define TG_SB() __builtin_amdgcn_sched_barrier(0)
+#define TG_STEP(AC, BC, MC, AN, BN, MN)                                                          \
+  do {                                                                                           \
+    TG_MFMA(0, AC, BC, MC); TG_SB();                                                             \
+    TG_ADVANCE(); TG_DECODE(MN); TG_SB();                                                        \
+    if (T > 1) { TG_MFMA(1 % T, AC, BC, MC); TG_SB(); }                                          \
+    AN = Dl[2 * e_n]; TG_READ_ROW(0, BN); TG_SB();                                               \
+    if (T > 1) {                                                                                 \
+      TG_MFMA(2 % T, AC, BC, MC); TG_SB();                                                       \
+      TG_READ_ROW(1 % KS, BN); TG_SB();                                                          \
+      TG_MFMA(3 % T, AC, BC, MC); TG_SB();                                                       \
+      TG_READ_ROW(2 % KS, BN); TG_SB();                                                          \
+      TG_MFMA(4 % T, AC, BC, MC); TG_MFMA(5 % T, AC, BC, MC); TG_MFMA(6 % T, AC, BC, MC);        \
+      TG_MFMA(7 % T, AC, BC, MC); TG_MFMA(8 % T, AC, BC, MC);                                    \
+    }                                                                                            \
+  } while (0)
+      if (g.stamps && lane == 0 && gi_ == 0)
+        g.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + 24 + wave] =
+            __builtin_readcyclecounter();
+      if (e_lo < e_hi) {
+        TG_DECODE(m_0);
+        a_0 = Dl[2 * e_n];
+#pragma unroll
+        for (int i = 0; i < KS; i++) TG_READ_ROW(i, b_0);
+        for (int e = e_lo; e < e_hi; e += 2) {      // host: an even number of steps per wave
+          TG_STEP(a_0, b_0, m_0, a_1, b_1, m_1);
+          TG_SB();
+          TG_STEP(a_1, b_1, m_1, a_0, b_0, m_0);
+          TG_SB();
+        }
+      }
+      if (g.stamps && lane == 0 && gi_ == 0)
+        g.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + 16 + wave] =
+            __builtin_readcyclecounter();
+#undef TG_DECODE
+#undef TG_ADVANCE
+#undef TG_READ_ROW
+#undef TG_MFMA
+#undef TG_SB
+#undef TG_STEP
+    }
+    TG_STAMP();
+    if (gi_ + 1 < my_groups) TG_COMMIT(buf ^ 1);
+    su_lo_cur = su_lo_nxt; r0_cur = r0_nxt;
+    __syncthreads();
+    TG_STAMP();
+  }
+#undef TG_ISSUE
+#undef TG_PUT
+#undef TG_COMMIT
+
+  // reduce-scatter of the eight wave partials through LDS, four taps per round:
+  // red[tt][wave][q][lane] (float4 = accumulator registers 4q..4q+3); wave w sums (tt, q) = 2w, 2w+1
+  f32x4* red = reinterpret_cast<f32x4*>(smem);
+  float* slab = g.slabs + (((int64_t)blockIdx.x * gridDim.z + blockIdx.z) * gridDim.y + blockIdx.y) * (T * 1024);
+#pragma unroll
+  for (int round = 0; round < (T + 3) / 4; round++) {
+    if (round > 0) __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 4; tt++) {
+      if (round * 4 + tt < T) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const f32x16& A_ = acc[(round * 4 + tt) < T ? (round * 4 + tt) : 0];
+          red[((tt * 8 + wave) * 4 + q) * 64 + lane] = (f32x4){A_[4 * q], A_[4 * q + 1], A_[4 * q + 2], A_[4 * q + 3]};
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++) {
+      const int combo = 2 * wave + cc;
+      const int tt = combo >> 2, q = combo & 3;
+      const int t = round * 4 + tt;
+      if (t < T) {
+        f32x4 v = red[((tt * 8 + 0) * 4 + q) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 8; w++) {
+          f32x4 u = red[((tt * 8 + w) * 4 + q) * 64 + lane];
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        *reinterpret_cast<f32x4*>(slab + (int64_t)t * 1024 + (q * 64 + lane) * 4) = v;
+      }
+    }
+  }
+  TG_STAMP();
+#undef TG_STAMP
+}
+
+// dW[o][c][t] = sum over pixel slabs of slab[ps][ot][ct][t][q][lane][comp]; accumulator register
+// rr = 4q + comp of lane (half, col) is row comp + 8q + 4*half, column col of the 32 x 32 tile.
+// A block takes 256 / SL float4 items and SL slices of the slabs; slices are combined through LDS.
+__global__ __launch_bounds__(256) void k_wgrad_tap_sum(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                       int ps, int SL, int OT, int CT, int T, int O, int C) {
+  __shared__ float4 part[256];
+  const int ipb = 256 / SL;                       // items per block
+  const int it = threadIdx.x % ipb, sl = threadIdx.x / ipb;
+  const int64_t item = (int64_t)blockIdx.x * ipb + it;
+  const int64_t nitems = (int64_t)OT * CT * T * 256;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (item < nitems) {
+    const float4* src = reinterpret_cast<const float4*>(slabs) + item;
+    for (int s0 = sl; s0 < ps; s0 += SL * 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        int s = s0 + SL * u;
+        v[u] = src[(int64_t)(s < ps ? s : 0) * nitems];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (s0 + SL * u < ps) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl == 0 && item < nitems) {
+    float4 r = part[it];
+    for (int k = 1; k < SL; k++) {
+      float4 q = part[k * ipb + it];
+      r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+    }
+    const int lane = (int)(item & 63), q = (int)((item >> 6) & 3);
+    int64_t tile = item >> 8;
+    const int t = (int)(tile % T);
+    tile /= T;
+    const int ct = (int)(tile % CT), ot = (int)(tile / CT);
+    const int c = ct * 32 + (lane & 31);
+    const int o = ot * 32 + 8 * q + 4 * (lane >> 5);
+    if (c < C) {
+      float vals[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (o + e < O) dw[((int64_t)(o + e) * C + c) * T + t] = vals[e];
     }
   }
 }
@@ -1079,13 +1440,28 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias) 
     (void)hipMemcpy(h.data(), g.stamps, nstamp * 8, hipMemcpyDeviceToHost);
     fprintf(stderr, "[stamp4] mode %d k %d PT %d CC %d PE %d grid %u x %u lds %zu\n", g.mode, g.k, g.PT, g.CC, g.PE,
             grid.x, grid.y, lds);
-    for (size_t b : {(size_t)0, nstamp / 64 / 2}) {
-      for (int w = 0; w < 2; w++) {
-        fprintf(stderr, "[stamp4]  block %zu wave %d:", b, w ? 7 : 0);
-        unsigned long long t0 = h[(b * 2) * 32];
-        for (int i = 0; i < 32 && h[(b * 2 + w) * 32 + i]; i++) fprintf(stderr, " %lld", (long long)(h[(b * 2 + w) * 32 + i] - t0));
-        fprintf(stderr, "\n");
+    {
+      // whole-grid view: span from the first block's first stamp to the last block's last stamp,
+      // and the mean duration of every segment of wave 0 over all blocks
+      const size_t nb = nstamp / 64;
+      unsigned long long tmin = ~0ull, tmax = 0, smax = 0;
+      double seg[32] = {0};
+      int nseg = 0;
+      for (size_t b = 0; b < nb; b++) {
+        const unsigned long long* r = &h[(b * 2) * 32];
+        int n = 0;
+        while (n < 32 && r[n]) n++;
+        if (!n) continue;
+        tmin = std::min(tmin, r[0]);
+        smax = std::max(smax, r[0]);
+        tmax = std::max(tmax, r[n - 1]);
+        for (int i = 1; i < n; i++) seg[i] += (double)(r[i] - r[i - 1]);
+        nseg = std::max(nseg, n);
       }
+      fprintf(stderr, "[stamp4]  grid span %lld, last block start +%lld; mean segments:", (long long)(tmax - tmin),
+              (long long)(smax - tmin));
+      for (int i = 1; i < nseg; i++) fprintf(stderr, " %.0f", seg[i] / nb);
+      fprintf(stderr, "\n");
     }
   }
   return DFHIP_OK;
@@ -1201,8 +1577,34 @@ int launch_wgrad_v3(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
     attr_lds = std::max(lds, (size_t)65536);
   }
   dim3 grid((unsigned)gx, (unsigned)ktg, (unsigned)otg);
+  static int stamp_mode = -1;
+  if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
+  const size_t nb = (size_t)gx * ktg * otg;
+  g.stamps = nullptr;
+  if (stamp_mode) {
+    g.stamps = (unsigned long long*)workspace2(nb * 32 * 8);
+    (void)hipMemsetAsync(g.stamps, 0, nb * 32 * 8, stream());
+  }
   hipLaunchKernelGGL((k_conv_wgrad_v3<OT, KT, DV>), grid, dim3(512), lds, stream(), g);
   DF_LAUNCH_CHECK();
+  if (stamp_mode) {
+    std::vector<unsigned long long> h(nb * 32);
+    (void)hipStreamSynchronize(stream());
+    (void)hipMemcpy(h.data(), g.stamps, nb * 32 * 8, hipMemcpyDeviceToHost);
+    double seg[32] = {0};
+    int nseg = 0;
+    for (size_t b = 0; b < nb; b++) {
+      const unsigned long long* r = &h[b * 32];
+      int n = 0;
+      while (n < 32 && r[n]) n++;
+      for (int i = 1; i < n; i++) seg[i] += (double)(r[i] - r[i - 1]);
+      nseg = std::max(nseg, n);
+    }
+    fprintf(stderr, "[stampw] OT %d KT %d grid %d x %d x %d groups %d (BI %d BR %d) lds %zu; mean segments:", OT, KT, gx,
+            ktg, otg, g.ngroups, g.BI, g.BR, lds);
+    for (int i = 1; i < nseg; i++) fprintf(stderr, " %.0f", seg[i] / nb);
+    fprintf(stderr, "\n");
+  }
   if (gx > 1) {
     hipLaunchKernelGGL(k_flat_slab_sum, dim3((unsigned)df_ceil_div(n, 256)), dim3(1024), 0, stream(), slabs,
                        dw, n, gx);
@@ -1250,6 +1652,138 @@ int run_wgrad_v3(WGeo g, float* dw) {
   if (OT == 1) return launch_wgrad_v3<1, 1, 4>(g, dw, lds, gx, ktg, otg);
   if (KT == 2) return launch_wgrad_v3<2, 2, 4>(g, dw, lds, gx, ktg, otg);
   return launch_wgrad_v3<2, 1, 4>(g, dw, lds, gx, ktg, otg);
+}
+
+// ---- tap-major weight gradient: plan + launch ----
+template <int KS, int XV, int DV, bool DENSE>
+int launch_wgrad_tap(TGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
+  const int T = KS * KS;
+  g.slabs = workspace((size_t)ps * OT * CT * T * 1024 * sizeof(float));
+  if (!g.slabs) return DFHIP_OUT_OF_MEMORY;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_tap<KS, XV, DV, DENSE>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536)));
+    attr_lds = std::max(lds, (size_t)65536);
+  }
+  dim3 grid((unsigned)ps, (unsigned)CT, (unsigned)OT);
+  static int stamp_mode = -1;
+  if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
+  const size_t nb = (size_t)ps * CT * OT;
+  g.stamps = nullptr;
+  if (stamp_mode) {
+    g.stamps = (unsigned long long*)workspace2(nb * 32 * 8);
+    (void)hipMemsetAsync(g.stamps, 0, nb * 32 * 8, stream());
+  }
+  hipLaunchKernelGGL((k_conv_wgrad_tap<KS, XV, DV, DENSE>), grid, dim3(512), lds, stream(), g);
+  DF_LAUNCH_CHECK();
+  int SL = 1;
+  while (SL * 2 <= std::min(ps, 16)) SL *= 2;
+  const int64_t nitems = (int64_t)OT * CT * T * 256;
+  hipLaunchKernelGGL(k_wgrad_tap_sum, dim3((unsigned)df_ceil_div(nitems, 256 / SL)), dim3(256), 0, stream(),
+                     g.slabs, dw, ps, SL, OT, CT, T, g.O, g.C);
+  DF_LAUNCH_CHECK();
+  if (stamp_mode) {
+    std::vector<unsigned long long> h(nb * 32);
+    (void)hipStreamSynchronize(stream());
+    (void)hipMemcpy(h.data(), g.stamps, nb * 32 * 8, hipMemcpyDeviceToHost);
+    double seg[32] = {0};
+    int nseg = 0;
+    for (size_t b = 0; b < nb; b++) {
+      const unsigned long long* r = &h[b * 32];
+      int n = 0;
+      while (n < 16 && r[n]) n++;
+      for (int i = 1; i < n; i++) seg[i] += (double)(r[i] - r[i - 1]);
+      nseg = std::max(nseg, n);
+    }
+    fprintf(stderr, "[stampt] k %d XV %d DV %d grid %d x %d x %d groups %d (BI %d BR %d) steps/group %d lds %zu; mean segments:",
+            KS, XV, DV, ps, CT, OT, g.ngroups, g.BI, g.BR, g.ksg, lds);
+    for (int i = 1; i < nseg; i++) fprintf(stderr, " %.0f", seg[i] / nb);
+    fprintf(stderr, "\n[stampt]   group 0 per wave (start, end) since block start:");
+    for (int w = 0; w < 8; w++) {
+      double a = 0, e = 0;
+      for (size_t b = 0; b < nb; b++) {
+        a += (double)(h[b * 32 + 24 + w] - h[b * 32]);
+        e += (double)(h[b * 32 + 16 + w] - h[b * 32]);
+      }
+      fprintf(stderr, " (%.0f, %.0f)", a / nb, e / nb);
+    }
+    fprintf(stderr, "\n");
+  }
+  return DFHIP_OK;
+}
+
+// LDS channel stride: the smallest value >= n that is 2 (mod 64)
+static int bank_stride(int n) { return ((n - 2 + 63) / 64) * 64 + 2; }
+
+// returns -1 when the shape is not eligible for the tap-major kernel
+int run_wgrad_tap(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
+                  int k, int stride, int pad) {
+  static int enabled = getenv("DFHIP_WGRAD_TAP") ? atoi(getenv("DFHIP_WGRAD_TAP")) : 1;
+  if (!enabled) return -1;
+  if (!(k == 1 || k == 3) || C < 16 || (N & 1)) return -1;
+  if ((H * W) % 4 != 0 || (oh * ow) % 4 != 0) return -1;
+  if (pad >= k) return -1;
+  const int CT = (int)df_ceil_div(C, 32), OT = (int)df_ceil_div(O, 32);
+  const int64_t steps_total = (int64_t)(N / 2) * oh * ow;
+  const int ps0 = std::max(1, num_cus() / (CT * OT));
+  static int gpb = getenv("DFHIP_WGRAD_GPB") ? atoi(getenv("DFHIP_WGRAD_GPB")) : 2;   // groups per block aimed at
+  const double target = (double)std::max<int64_t>(16, steps_total / ps0 / std::max(1, gpb));
+  TGeo g = {};
+  double best = 1e30;
+  size_t best_lds = 0;
+  for (int BR = oh; BR >= 1; BR--) {
+    if (oh % BR) continue;
+    const int gr = oh / BR;
+    const int RLr = gr == 1 ? H : std::min(H, (BR - 1) * stride + k);
+    const int RL = RLr * W, BRBC = BR * ow;
+    if (RL % 4 || BRBC % 4) continue;
+    if (gr > 1 && (W % 4)) continue;
+    for (int BI = 2; BI <= N && BI <= 128; BI *= 2) {
+      if (N % BI) break;
+      const int ksg = BI / 2 * BRBC;
+      if (ksg % 16) continue;                      // an even number of steps for each of the 8 waves
+      const int xitems = 32 * (BI / 2) * (RL / 4), ditems = 32 * (BI / 2) * (BRBC / 4);
+      if (xitems > 512 * 3 || ditems > 512 * 2) break;
+      const int XST = bank_stride(BI * RL), DST = bank_stride(BI * BRBC);
+      const size_t red = (k == 3 ? 4 : 1) * (size_t)8 * 4 * 64 * 16;
+      const size_t lds = std::max((size_t)2 * 32 * (XST + DST) * 4, red);
+      if (lds > 160 * 1024) break;
+      double score = std::fabs(std::log((double)ksg / target)) - 1e-3 * BR;
+      if (score < best) {
+        best = score; best_lds = lds;
+        g.BI = BI; g.BR = BR; g.gr = gr; g.RLr = RLr; g.XST = XST; g.DST = DST; g.ksg = ksg;
+      }
+    }
+  }
+  if (best > 1e29) return -1;
+  g.x = x; g.dy = dy;
+  g.N = N; g.C = C; g.H = H; g.W = W; g.O = O; g.oh = oh; g.ow = ow; g.k = k; g.stride = stride; g.pad = pad;
+  g.ngroups = (N / g.BI) * g.gr;
+  const int P = g.BI / 2, RL4 = g.RLr * W / 4, BRBC4 = g.BR * ow / 4;
+  g.m_brow = magic_u32((unsigned)(g.BR * ow));
+  g.m_ow = magic_u32((unsigned)ow);
+  g.m_xc = magic_u32((unsigned)(P * RL4));
+  g.m_xp = magic_u32((unsigned)RL4);
+  g.m_dc = magic_u32((unsigned)(P * BRBC4));
+  g.m_dp = magic_u32((unsigned)BRBC4);
+  const int ps = std::max(1, std::min(g.ngroups, ps0));
+  const int xv = (int)df_ceil_div(32 * P * RL4, 512), dv = (int)df_ceil_div(32 * P * BRBC4, 512);
+  // images of 8 x 8 and more lose little to the padding taps; smaller ones skip them
+  static int dense_min = getenv("DFHIP_WGRAD_DENSE_MIN") ? atoi(getenv("DFHIP_WGRAD_DENSE_MIN")) : 8;
+  const bool dense = k == 3 && std::min(oh, ow) >= dense_min;
+  if (k == 3 && dense) {
+    if (xv <= 1 && dv <= 1) return launch_wgrad_tap<3, 1, 1, true>(g, dw, best_lds, ps, CT, OT);
+    if (xv <= 2 && dv <= 1) return launch_wgrad_tap<3, 2, 1, true>(g, dw, best_lds, ps, CT, OT);
+    return launch_wgrad_tap<3, 3, 2, true>(g, dw, best_lds, ps, CT, OT);
+  }
+  if (k == 3) {
+    if (xv <= 1 && dv <= 1) return launch_wgrad_tap<3, 1, 1, false>(g, dw, best_lds, ps, CT, OT);
+    if (xv <= 2 && dv <= 1) return launch_wgrad_tap<3, 2, 1, false>(g, dw, best_lds, ps, CT, OT);
+    return launch_wgrad_tap<3, 3, 2, false>(g, dw, best_lds, ps, CT, OT);
+  }
+  if (xv <= 2 && dv <= 1) return launch_wgrad_tap<1, 2, 1, true>(g, dw, best_lds, ps, CT, OT);
+  return launch_wgrad_tap<1, 3, 2, true>(g, dw, best_lds, ps, CT, OT);
 }
 
 }  // namespace
@@ -1310,7 +1844,9 @@ int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C,
   g.N = N; g.C = C; g.H = H; g.W = W; g.O = O; g.oh = oh; g.ow = ow;
   g.k = k; g.stride = stride; g.pad = pad;
   {
-    int st = run_wgrad_v3(g, dw);
+    int st = run_wgrad_tap(x, dy, dw, N, C, H, W, O, oh, ow, k, stride, pad);
+    if (st >= 0) return st;
+    st = run_wgrad_v3(g, dw);
     if (st >= 0) return st;
   }
   const int KW = C * k * k;
