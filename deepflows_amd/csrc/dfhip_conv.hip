@@ -281,12 +281,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   const int PT = g.PT, KSPLIT = 8 / g.PT;
   const int pt = wave % PT, ks = wave / PT;
   int stamp_i = 0;
+#ifdef DFHIP_STAMPS
 #define DF_STAMP()                                                                              \
   do {                                                                                          \
     if (g.stamps && lane == 0 && (wave == 0 || wave == 7) && stamp_i < 30)                      \
       g.stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wave == 7)) * 32 + stamp_i++] = \
           __builtin_readcyclecounter();                                                         \
   } while (0)
+#else
+#define DF_STAMP() do { } while (0)
+#endif
   DF_STAMP();
 
   int gx = blockIdx.x;
@@ -703,12 +707,16 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   int stamp_i = 0;
+#ifdef DFHIP_STAMPS
 #define WG_STAMP()                                                                              \
   do {                                                                                          \
     if (g.stamps && tid == 0 && stamp_i < 32)                                                   \
       g.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + stamp_i++] = \
           __builtin_readcyclecounter();                                                         \
   } while (0)
+#else
+#define WG_STAMP() do { } while (0)
+#endif
   WG_STAMP();
   const int kk0 = blockIdx.y * (KT * 32);
   const int o0 = blockIdx.z * (OT * 32);
@@ -945,12 +953,16 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_tap(TGeo g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   int stamp_i = 0;
+#ifdef DFHIP_STAMPS
 #define TG_STAMP()                                                                              \
   do {                                                                                          \
     if (g.stamps && tid == 0 && stamp_i < 16)                                                   \
       g.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + stamp_i++] = \
           __builtin_readcyclecounter();                                                         \
   } while (0)
+#else
+#define TG_STAMP() do { } while (0)
+#endif
   TG_STAMP();
   const int c0 = blockIdx.y * 32, o0 = blockIdx.z * 32;
   const int cn = min(32, g.C - c0), on = min(32, g.O - o0);
@@ -1121,9 +1133,11 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_tap(TGeo g) {
       TG_MFMA(7 % T, AC, BC, MC); TG_MFMA(8 % T, AC, BC, MC);                                    \
     }                                                                                            \
   } while (0)
+#ifdef DFHIP_STAMPS
       if (g.stamps && lane == 0 && gi_ == 0)
         g.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + 24 + wave] =
             __builtin_readcyclecounter();
+#endif
       if (e_lo < e_hi) {
         TG_DECODE(m_0);
         a_0 = Dl[2 * e_n];
@@ -1136,9 +1150,11 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_tap(TGeo g) {
           TG_SB();
         }
       }
+#ifdef DFHIP_STAMPS
       if (g.stamps && lane == 0 && gi_ == 0)
         g.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + 16 + wave] =
             __builtin_readcyclecounter();
+#endif
 #undef TG_DECODE
 #undef TG_ADVANCE
 #undef TG_READ_ROW
@@ -1194,6 +1210,310 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_tap(TGeo g) {
 #undef TG_STAMP
 }
 
+// ---------------------------------------------------------------------------------------
+// weight gradient, row-unit kernel: the tap-major decomposition above with the image width fixed
+// at compile time.  The unit of work of a wave is one output row of one image pair: it reads the
+// dY row (OW values per lane) and the k source rows (W values per lane each) with 16-byte LDS
+// reads and then issues, straight-line and from registers only,
+//     acc[i][j] += dY[s] (x) X[i][s*STRIDE + j - PAD]     for every (s, j) inside the image,
+// so padding columns cost nothing (the combinations do not exist in the code), padding rows are
+// one scalar branch per source row, and there is no per-step address or mask arithmetic left.
+// LDS image: [channel][image][row][W] as in global memory (staging is a plain 16-byte copy);
+// the two k slots of the MFMA are images 2p and 2p+1.  Channel stride == 4 (mod 64) floats
+// (16-byte reads of 16 lanes cover the 64 banks), == 2 (mod 64) when rows are two floats wide.
+// ---------------------------------------------------------------------------------------
+struct RGeo {
+  const float* x;
+  const float* dy;
+  float* slabs;
+  int N, C, H, O, oh;
+  int BI, BR, gr, ngroups;   // group = BI images x BR output rows
+  int RLr;                   // source rows staged per group
+  int XST, DST;              // channel strides in LDS (floats)
+  int units;                 // BI/2 * BR
+  unsigned m_br;             // magic divider: BR
+  unsigned m_xc, m_xi;       // staging x: BI*RL4, RL4
+  unsigned m_dc, m_di;       // staging dY: BI*B4, B4
+  int dbg;
+  unsigned long long* stamps;
+};
+
+template <int NV>
+__device__ __forceinline__ void lds_read_row(const float* p, float (&v)[NV]) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  if constexpr (NV % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < NV / 4; q++) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < NV / 2; q++) {
+      f32x2 t = *reinterpret_cast<const f32x2*>(p + 2 * q);
+      v[2 * q] = t.x; v[2 * q + 1] = t.y;
+    }
+  }
+}
+
+// One wave per SIMD (256 threads): a single wave issues independent MFMAs back to back at the
+// pipe rate, the operands of the next unit are read while the current one is in the matrix cores,
+// and the final cross-wave sum moves half the bytes of an 8-wave block (one LDS round).
+constexpr int kRowsWaves = 4;
+
+template <int KS, int PAD, int STRIDE, int W, int OW, int UR>
+__global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int T = KS * KS;
+  constexpr int NW = kRowsWaves, NT = 64 * NW;
+  constexpr int SVX = 6, SVD = 4;              // X / dY vectors per thread in flight across a group
+  constexpr int NXR = (UR - 1) * STRIDE + KS;  // source rows under the UR output rows of a unit
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  int stamp_i = 0;
+#ifdef DFHIP_STAMPS
+#define RG_STAMP()                                                                              \
+  do {                                                                                          \
+    if (g.stamps && tid == 0 && stamp_i < 16)                                                   \
+      g.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + stamp_i++] = \
+          __builtin_readcyclecounter();                                                         \
+  } while (0)
+#else
+#define RG_STAMP() do { } while (0)
+#endif
+  RG_STAMP();
+  const int c0 = blockIdx.y * 32, o0 = blockIdx.z * 32;
+  const int cn = min(32, g.C - c0), on = min(32, g.O - o0);
+  const int RL = g.RLr * W;                   // staged floats per (image, channel)
+  const int BRBC = g.BR * OW;
+  const int RL4 = RL >> 2, B4 = BRBC >> 2;
+  const int xbase = 32 * g.DST;               // X image follows the dY image
+  const int buf_floats = 32 * (g.DST + g.XST);
+  const int64_t xplane = (int64_t)g.H * W, yplane = (int64_t)g.oh * OW;
+  const int xitems = cn * g.BI * RL4, ditems = on * g.BI * B4;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; t++)
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) acc[t][rr] = 0.0f;
+
+  // ---- staging: 16-byte copies, item v -> (channel, image, float4 of the contiguous run) ----
+  auto x_item = [&](int v, unsigned& src, int& lx) {
+    int c = (int)fast_div((unsigned)v, g.m_xc);
+    int rem = v - c * (g.BI * RL4);
+    int im = (int)fast_div((unsigned)rem, g.m_xi), q4 = rem - im * RL4;
+    src = (unsigned)(((int64_t)im * g.C + c) * xplane + 4 * q4);
+    lx = xbase + c * g.XST + im * RL + 4 * q4;
+  };
+  auto d_item = [&](int v, unsigned& src, int& lx) {
+    int o = (int)fast_div((unsigned)v, g.m_dc);
+    int rem = v - o * (g.BI * B4);
+    int im = (int)fast_div((unsigned)rem, g.m_di), q4 = rem - im * B4;
+    src = (unsigned)(((int64_t)im * g.O + o) * yplane + 4 * q4);
+    lx = o * g.DST + im * BRBC + 4 * q4;
+  };
+  auto lds_put = [&](float* base, int lx, f32x4 v) {
+    if (((g.XST | g.DST) & 3) == 0) {
+      *reinterpret_cast<f32x4*>(base + lx) = v;
+    } else {
+      f32x2* q = reinterpret_cast<f32x2*>(base + lx);
+      q[0] = (f32x2){v.x, v.y};
+      q[1] = (f32x2){v.z, v.w};
+    }
+  };
+  int su_lo_cur = 0, r0_cur = 0, su_lo_nxt = 0, r0_nxt = 0;
+  const float* xg_nxt = nullptr;
+  const float* yg_nxt = nullptr;
+  auto group_base = [&](int gi) {
+    int grp = blockIdx.x + gi * gridDim.x;
+    int gimg = grp / g.gr;
+    int n0 = gimg * g.BI;
+    r0_nxt = (grp - gimg * g.gr) * g.BR;
+    su_lo_nxt = min(max(0, r0_nxt * STRIDE - PAD), g.H - g.RLr);
+    xg_nxt = g.x + ((int64_t)n0 * g.C + c0) * xplane + (int64_t)su_lo_nxt * W;
+    yg_nxt = g.dy + ((int64_t)n0 * g.O + o0) * yplane + (int64_t)r0_nxt * OW;
+  };
+  // descriptors of the vectors this thread keeps in flight across a group
+  unsigned xs_src[SVX], ds_src[SVD];
+  int xs_lx[SVX], ds_lx[SVD];
+#pragma unroll
+  for (int u = 0; u < SVX; u++) {
+    int v = tid + NT * u;
+    x_item(v < xitems ? v : 0, xs_src[u], xs_lx[u]);
+    if (v >= xitems) xs_lx[u] = -1;
+  }
+#pragma unroll
+  for (int u = 0; u < SVD; u++) {
+    int v = tid + NT * u;
+    d_item(v < ditems ? v : 0, ds_src[u], ds_lx[u]);
+    if (v >= ditems) ds_lx[u] = -1;
+  }
+  // everything beyond SV vectors per thread is copied synchronously, six X and four dY vectors
+  // per thread in flight per pass (host: groups after the first fit the SV vectors)
+  auto stage_rest = [&](float* base, int firstx, int firstd) {
+    int vx = tid + NT * firstx, vd = tid + NT * firstd;
+    while (vx < xitems || vd < ditems) {
+      f32x4 tx[6], td[4];
+      int lx[6], ld[4];
+#pragma unroll
+      for (int u = 0; u < 6; u++) {
+        int v = vx + NT * u;
+        unsigned src;
+        x_item(v < xitems ? v : 0, src, lx[u]);
+        if (v >= xitems) lx[u] = -1;
+        tx[u] = *reinterpret_cast<const f32x4*>(xg_nxt + src);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        int v = vd + NT * u;
+        unsigned src;
+        d_item(v < ditems ? v : 0, src, ld[u]);
+        if (v >= ditems) ld[u] = -1;
+        td[u] = *reinterpret_cast<const f32x4*>(yg_nxt + src);
+      }
+#pragma unroll
+      for (int u = 0; u < 6; u++)
+        if (lx[u] >= 0) lds_put(base, lx[u], tx[u]);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (ld[u] >= 0) lds_put(base, ld[u], td[u]);
+      vx += NT * 6;
+      vd += NT * 4;
+    }
+  };
+
+  const int my_groups = (g.ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  RG_STAMP();
+  if (my_groups > 0) {
+    group_base(0);
+    stage_rest(smem, 0, 0);
+  }
+  su_lo_cur = su_lo_nxt; r0_cur = r0_nxt;
+  __syncthreads();
+  RG_STAMP();
+
+  const int lane_d = l31 * g.DST + half * BRBC;
+  const int lane_x = xbase + l31 * g.XST + half * RL;
+
+  f32x4 xsv[SVX], dsv[SVD];
+  for (int gi_ = 0; gi_ < my_groups; gi_++) {
+    const int buf = gi_ & 1;
+    const bool more = gi_ + 1 < my_groups;
+    if (more && !g.dbg) {
+      group_base(gi_ + 1);
+#pragma unroll
+      for (int u = 0; u < SVD; u++) dsv[u] = *reinterpret_cast<const f32x4*>(yg_nxt + ds_src[u]);
+#pragma unroll
+      for (int u = 0; u < SVX; u++) xsv[u] = *reinterpret_cast<const f32x4*>(xg_nxt + xs_src[u]);
+    }
+    {
+      const float* Dl = smem + buf * buf_floats + lane_d;
+      const float* Xl = smem + buf * buf_floats + lane_x;
+      // a source row (of the NXR under a unit) is read only if some (output row, tap row) uses it
+      float a_n[UR][OW], b_n[NXR][W];
+      int rs_n = 0;
+#define RG_LOAD(u_)                                                                              \
+  do {                                                                                           \
+    const int uu_ = (u_);                                                                        \
+    const int pr_ = (int)fast_div((unsigned)uu_, g.m_br);                                        \
+    const int r_ = (uu_ - pr_ * (g.BR / UR)) * UR;                                               \
+    rs_n = (r0_cur + r_) * STRIDE - PAD;         /* source row of (output row 0, tap row 0) */   \
+    _Pragma("unroll") for (int ur_ = 0; ur_ < UR; ur_++)                                         \
+      lds_read_row<OW>(Dl + 2 * pr_ * BRBC + (r_ + ur_) * OW, a_n[ur_]);                         \
+    _Pragma("unroll") for (int xr_ = 0; xr_ < NXR; xr_++)                                        \
+      if (row_used(xr_)) lds_read_row<W>(Xl + 2 * pr_ * RL + (rs_n + xr_ - su_lo_cur) * W, b_n[xr_]); \
+  } while (0)
+      auto row_used = [](int xr) {
+        for (int ur = 0; ur < UR; ur++)
+          for (int i = 0; i < KS; i++)
+            if (ur * STRIDE + i == xr) return true;
+        return false;
+      };
+      if (wave < g.units) {
+        RG_LOAD(wave);
+        for (int u = wave; u < g.units; u += NW) {
+          float a[UR][OW], b[NXR][W];
+#pragma unroll
+          for (int ur = 0; ur < UR; ur++)
+#pragma unroll
+            for (int s = 0; s < OW; s++) a[ur][s] = a_n[ur][s];
+#pragma unroll
+          for (int xr = 0; xr < NXR; xr++)
+#pragma unroll
+            for (int c = 0; c < W; c++) b[xr][c] = b_n[xr][c];
+          const int rs = rs_n;
+          RG_LOAD(min(u + NW, g.units - 1));       // next unit's operands land during the MFMAs below
+#pragma unroll
+          for (int ur = 0; ur < UR; ur++) {
+#pragma unroll
+            for (int i = 0; i < KS; i++) {
+              if ((unsigned)(rs + ur * STRIDE + i) < (unsigned)g.H) {
+#pragma unroll
+                for (int s = 0; s < OW; s++)
+#pragma unroll
+                  for (int j = 0; j < KS; j++) {
+                    const int col = s * STRIDE + j - PAD;
+                    if (col >= 0 && col < W)
+                      acc[i * KS + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                          a[ur][s], b[ur * STRIDE + i][col >= 0 && col < W ? col : 0], acc[i * KS + j], 0, 0, 0);
+                  }
+              }
+            }
+          }
+        }
+      }
+#undef RG_LOAD
+    }
+    RG_STAMP();
+    if (more && g.dbg) {
+      group_base(gi_ + 1);
+      stage_rest(smem + (buf ^ 1) * buf_floats, 0, 0);
+    } else if (more) {
+      float* B_ = smem + (buf ^ 1) * buf_floats;
+#pragma unroll
+      for (int u = 0; u < SVD; u++)
+        if (ds_lx[u] >= 0) lds_put(B_, ds_lx[u], dsv[u]);
+#pragma unroll
+      for (int u = 0; u < SVX; u++)
+        if (xs_lx[u] >= 0) lds_put(B_, xs_lx[u], xsv[u]);
+      stage_rest(B_, SVX, SVD);
+    }
+    su_lo_cur = su_lo_nxt; r0_cur = r0_nxt;
+    __syncthreads();
+    RG_STAMP();
+  }
+
+  // cross-wave sum through LDS in one round: red[t][wave][q][lane] (float4 = accumulator registers
+  // 4q..4q+3); wave w then sums the T (tap, q) combinations w, w + NW, ...
+  f32x4* red = reinterpret_cast<f32x4*>(smem);
+  float* slab = g.slabs + (((int64_t)blockIdx.x * gridDim.z + blockIdx.z) * gridDim.y + blockIdx.y) * (T * 1024);
+#pragma unroll
+  for (int t = 0; t < T; t++)
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      red[((t * NW + wave) * 4 + q) * 64 + lane] = (f32x4){acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+  __syncthreads();
+#pragma unroll
+  for (int cc = 0; cc < T; cc++) {
+    const int combo = cc * NW + wave;
+    const int t = combo >> 2, q = combo & 3;
+    f32x4 v = red[((t * NW + 0) * 4 + q) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < NW; w++) {
+      f32x4 u = red[((t * NW + w) * 4 + q) * 64 + lane];
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    *reinterpret_cast<f32x4*>(slab + (int64_t)t * 1024 + (q * 64 + lane) * 4) = v;
+  }
+  RG_STAMP();
+#undef RG_STAMP
+}
+
 // dW[o][c][t] = sum over pixel slabs of slab[ps][ot][ct][t][q][lane][comp]; accumulator register
 // rr = 4q + comp of lane (half, col) is row comp + 8q + 4*half, column col of the 32 x 32 tile.
 // A block takes 256 / SL float4 items and SL slices of the slabs; slices are combined through LDS.
@@ -1207,15 +1527,15 @@ __global__ __launch_bounds__(256) void k_wgrad_tap_sum(const float* __restrict__
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (item < nitems) {
     const float4* src = reinterpret_cast<const float4*>(slabs) + item;
-    for (int s0 = sl; s0 < ps; s0 += SL * 4) {
-      float4 v[4];
+    for (int s0 = sl; s0 < ps; s0 += SL * 8) {
+      float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < 8; u++) {
         int s = s0 + SL * u;
-        v[u] = src[(int64_t)(s < ps ? s : 0) * nitems];
+        v[u] = s < ps ? src[(int64_t)s * nitems] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+      for (int u = 0; u < 8; u++)
         if (s0 + SL * u < ps) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
   }
@@ -1654,6 +1974,127 @@ int run_wgrad_v3(WGeo g, float* dw) {
   return launch_wgrad_v3<2, 1, 4>(g, dw, lds, gx, ktg, otg);
 }
 
+// ---- row-unit weight gradient: plan + launch ----
+template <int KS, int PAD, int STRIDE, int W, int OW, int UR>
+int launch_wgrad_rows(RGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
+  const int T = KS * KS;
+  g.slabs = workspace((size_t)ps * OT * CT * T * 1024 * sizeof(float));
+  if (!g.slabs) return DFHIP_OUT_OF_MEMORY;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_rows<KS, PAD, STRIDE, W, OW, UR>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536)));
+    attr_lds = std::max(lds, (size_t)65536);
+  }
+  dim3 grid((unsigned)ps, (unsigned)CT, (unsigned)OT);
+  static int stamp_mode = -1;
+  if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
+  const size_t nb = (size_t)ps * CT * OT;
+  g.stamps = nullptr;
+  if (stamp_mode) {
+    g.stamps = (unsigned long long*)workspace2(nb * 32 * 8);
+    (void)hipMemsetAsync(g.stamps, 0, nb * 32 * 8, stream());
+  }
+  hipLaunchKernelGGL((k_conv_wgrad_rows<KS, PAD, STRIDE, W, OW, UR>), grid, dim3(64 * kRowsWaves), lds, stream(), g);
+  DF_LAUNCH_CHECK();
+  int SL = 1;                                     // slices: eight slabs per thread, at most 32 slices
+  while (SL < 32 && SL * 8 < ps) SL *= 2;
+  const int64_t nitems = (int64_t)OT * CT * T * 256;
+  hipLaunchKernelGGL(k_wgrad_tap_sum, dim3((unsigned)df_ceil_div(nitems, 256 / SL)), dim3(256), 0, stream(),
+                     g.slabs, dw, ps, SL, OT, CT, T, g.O, g.C);
+  DF_LAUNCH_CHECK();
+  if (stamp_mode) {
+    std::vector<unsigned long long> h(nb * 32);
+    (void)hipStreamSynchronize(stream());
+    (void)hipMemcpy(h.data(), g.stamps, nb * 32 * 8, hipMemcpyDeviceToHost);
+    double seg[32] = {0};
+    int nseg = 0;
+    for (size_t b = 0; b < nb; b++) {
+      const unsigned long long* r = &h[b * 32];
+      int n = 0;
+      while (n < 16 && r[n]) n++;
+      for (int i = 1; i < n; i++) seg[i] += (double)(r[i] - r[i - 1]);
+      nseg = std::max(nseg, n);
+    }
+    fprintf(stderr, "[stampr] k %d s %d W %d grid %d x %d x %d groups %d (BI %d BR %d) units/group %d lds %zu; mean segments:",
+            KS, STRIDE, W, ps, CT, OT, g.ngroups, g.BI, g.BR, g.units, lds);
+    for (int i = 1; i < nseg; i++) fprintf(stderr, " %.0f", seg[i] / nb);
+    fprintf(stderr, "\n");
+  }
+  return DFHIP_OK;
+}
+
+// LDS channel stride: the smallest value >= n that is r (mod 64)
+static int bank_stride_r(int n, int r) { return ((n - r + 63) / 64) * 64 + r; }
+
+// returns -1 when the shape is not one the row-unit kernel is built for
+int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
+                   int k, int stride, int pad) {
+  static int enabled = getenv("DFHIP_WGRAD_ROWS") ? atoi(getenv("DFHIP_WGRAD_ROWS")) : 1;
+  if (!enabled) return -1;
+  if (C < 16 || (N & 1)) return -1;
+  const bool k3 = k == 3 && pad == 1, k1 = k == 1 && pad == 0 && stride == 2;
+  if (!k3 && !k1) return -1;
+  if (!(W == 16 || W == 8 || W == 4 || (W == 2 && stride == 1))) return -1;
+  if (ow != (W + 2 * pad - k) / stride + 1 || (stride == 2 && ow * 2 != W) || stride > 2) return -1;
+  if ((H * W) % 4 != 0 || (oh * ow) % 4 != 0) return -1;
+  const int CT = (int)df_ceil_div(C, 32), OT = (int)df_ceil_div(O, 32);
+  const int ps0 = std::max(1, num_cus() / (CT * OT));
+  static int gpb = getenv("DFHIP_WGRAD_GPB") ? atoi(getenv("DFHIP_WGRAD_GPB")) : 2;   // groups per block aimed at
+  const int UR0 = k == 1 ? 1 : (stride == 1 ? (W == 16 ? 1 : (W == 8 ? 2 : (W == 4 ? 4 : 2))) : (W == 16 ? 1 : 2));
+  const double per_block = (double)(N / 2) * (oh / UR0) / ps0;
+  const double target = std::max((double)kRowsWaves, per_block / std::max(1, gpb));
+  // output rows per unit (must match the instantiations below)
+  const int UR = k == 1 ? 1 : (stride == 1 ? (W == 16 ? 1 : (W == 8 ? 2 : (W == 4 ? 4 : 2))) : (W == 16 ? 1 : 2));
+  RGeo g = {};
+  double best = 1e30;
+  size_t best_lds = 0;
+  for (int BR = oh; BR >= 1; BR--) {
+    if (oh % BR || BR % UR) continue;
+    const int gr = oh / BR;
+    const int RLr = gr == 1 ? H : std::min(H, (BR - 1) * stride + k);
+    const int RL = RLr * W, BRBC = BR * ow;
+    if (RL % 4 || BRBC % 4) continue;
+    if (gr > 1 && (W % 4)) continue;
+    for (int BI = 2; BI <= N && BI <= 128; BI *= 2) {
+      if (N % BI) break;
+      const int units = BI / 2 * (BR / UR);
+      if (units % kRowsWaves) continue;
+      const int xv = (int)df_ceil_div(32 * BI * (RL / 4), 64 * kRowsWaves), dv = (int)df_ceil_div(32 * BI * (BRBC / 4), 64 * kRowsWaves);
+      if ((xv > 6 || dv > 4) && (N / BI) * gr > ps0) continue;   // later groups must fit the in-flight vectors
+      const int XST = bank_stride_r(BI * RL, W >= 4 ? 4 : 2), DST = bank_stride_r(BI * BRBC, ow >= 4 ? 4 : 2);
+      const size_t red = (size_t)k * k * kRowsWaves * 4 * 64 * 16;
+      const size_t lds = std::max((size_t)2 * 32 * (XST + DST) * 4, red);
+      if (lds > 160 * 1024) break;
+      double score = std::fabs(std::log((double)units / target)) - 1e-3 * BR;
+      if (score < best) {
+        best = score; best_lds = lds;
+        g.BI = BI; g.BR = BR; g.gr = gr; g.RLr = RLr; g.XST = XST; g.DST = DST; g.units = units;
+      }
+    }
+  }
+  if (best > 1e29) return -1;
+  g.x = x; g.dy = dy;
+  g.N = N; g.C = C; g.H = H; g.O = O; g.oh = oh;
+  g.ngroups = (N / g.BI) * g.gr;
+  const int RL4 = g.RLr * W / 4, B4 = g.BR * ow / 4;
+  g.m_br = magic_u32((unsigned)(g.BR / UR));
+  g.m_xc = magic_u32((unsigned)(g.BI * RL4));
+  g.m_xi = magic_u32((unsigned)RL4);
+  g.m_dc = magic_u32((unsigned)(g.BI * B4));
+  g.m_di = magic_u32((unsigned)B4);
+  const int ps = std::max(1, std::min(g.ngroups, ps0));
+  g.dbg = getenv("DFHIP_WGRAD_DBG") ? atoi(getenv("DFHIP_WGRAD_DBG")) : 0;
+#define DF_ROWS(KSV, PADV, SV, WV, OWV, URV) \
+  if (k == KSV && stride == SV && W == WV && UR == URV)  \
+    return launch_wgrad_rows<KSV, PADV, SV, WV, OWV, URV>(g, dw, best_lds, ps, CT, OT);
+  DF_ROWS(3, 1, 1, 16, 16, 1) DF_ROWS(3, 1, 1, 8, 8, 2) DF_ROWS(3, 1, 1, 4, 4, 4) DF_ROWS(3, 1, 1, 2, 2, 2)
+  DF_ROWS(3, 1, 2, 16, 8, 1) DF_ROWS(3, 1, 2, 8, 4, 2) DF_ROWS(3, 1, 2, 4, 2, 2)
+  DF_ROWS(1, 0, 2, 16, 8, 1) DF_ROWS(1, 0, 2, 8, 4, 1) DF_ROWS(1, 0, 2, 4, 2, 1)
+#undef DF_ROWS
+  return -1;
+}
+
 // ---- tap-major weight gradient: plan + launch ----
 template <int KS, int XV, int DV, bool DENSE>
 int launch_wgrad_tap(TGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
@@ -1677,8 +2118,8 @@ int launch_wgrad_tap(TGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
   }
   hipLaunchKernelGGL((k_conv_wgrad_tap<KS, XV, DV, DENSE>), grid, dim3(512), lds, stream(), g);
   DF_LAUNCH_CHECK();
-  int SL = 1;
-  while (SL * 2 <= std::min(ps, 16)) SL *= 2;
+  int SL = 1;                                     // slices: eight slabs per thread, at most 32 slices
+  while (SL < 32 && SL * 8 < ps) SL *= 2;
   const int64_t nitems = (int64_t)OT * CT * T * 256;
   hipLaunchKernelGGL(k_wgrad_tap_sum, dim3((unsigned)df_ceil_div(nitems, 256 / SL)), dim3(256), 0, stream(),
                      g.slabs, dw, ps, SL, OT, CT, T, g.O, g.C);
@@ -1844,7 +2285,9 @@ int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C,
   g.N = N; g.C = C; g.H = H; g.W = W; g.O = O; g.oh = oh; g.ow = ow;
   g.k = k; g.stride = stride; g.pad = pad;
   {
-    int st = run_wgrad_tap(x, dy, dw, N, C, H, W, O, oh, ow, k, stride, pad);
+    int st = run_wgrad_rows(x, dy, dw, N, C, H, W, O, oh, ow, k, stride, pad);
+    if (st >= 0) return st;
+    st = run_wgrad_tap(x, dy, dw, N, C, H, W, O, oh, ow, k, stride, pad);
     if (st >= 0) return st;
     st = run_wgrad_v3(g, dw);
     if (st >= 0) return st;
