@@ -1210,6 +1210,76 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_tap(TGeo g) {
 #undef TG_STAMP
 }
 
+// dW[o][c][t] = sum over pixel slabs of slab[ps][ot][ct][t][q][lane][comp]; accumulator register
+// rr = 4q + comp of lane (half, col) is row comp + 8q + 4*half, column col of the 32 x 32 tile.
+// A (virtual) block of 256 threads takes 256 / SL float4 items and SL slices of the slabs; slices
+// are combined through LDS (part: 256 float4).
+struct SlabSum {
+  const float* slabs;
+  float* dw;
+  int ps, SL, OT, CT, T, O, C;
+  int nvb;                      // virtual blocks: ceil(OT*CT*T*256 / (256 / SL)); 0 = nothing to do
+};
+
+// load phase: the (at most eight) slabs this thread adds for virtual block vb (host: ps <= 8 * SL)
+__device__ __forceinline__ void slab_sum_load(const SlabSum& a, int vb, float4 (&v)[8]) {
+  const int ipb = 256 / a.SL;                     // items per block
+  const int it = threadIdx.x % ipb, sl = threadIdx.x / ipb;
+  const int64_t item = (int64_t)vb * ipb + it;
+  const int64_t nitems = (int64_t)a.OT * a.CT * a.T * 256;
+  const float4* src = reinterpret_cast<const float4*>(a.slabs) + item;
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    int s = sl + a.SL * u;
+    v[u] = (item < nitems && s < a.ps) ? src[(int64_t)s * nitems] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// finish phase: add, combine the slices through LDS, scatter to OIHW
+__device__ __forceinline__ void slab_sum_finish(const SlabSum& a, int vb, const float4 (&v)[8], float4* part) {
+  const int ipb = 256 / a.SL;
+  const int it = threadIdx.x % ipb, sl = threadIdx.x / ipb;
+  const int64_t item = (int64_t)vb * ipb + it;
+  const int64_t nitems = (int64_t)a.OT * a.CT * a.T * 256;
+  float4 acc = v[0];
+#pragma unroll
+  for (int u = 1; u < 8; u++) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl == 0 && item < nitems) {
+    float4 r = part[it];
+    for (int k = 1; k < a.SL; k++) {
+      float4 q = part[k * ipb + it];
+      r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+    }
+    const int lane = (int)(item & 63), q = (int)((item >> 6) & 3);
+    int64_t tile = item >> 8;
+    const int t = (int)(tile % a.T);
+    tile /= a.T;
+    const int ct = (int)(tile % a.CT), ot = (int)(tile / a.CT);
+    const int c = ct * 32 + (lane & 31);
+    const int o = ot * 32 + 8 * q + 4 * (lane >> 5);
+    if (c < a.C) {
+      float vals[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (o + e < a.O) a.dw[((int64_t)(o + e) * a.C + c) * a.T + t] = vals[e];
+    }
+  }
+  __syncthreads();                                // part is reused by the caller's next virtual block
+}
+
+__device__ __forceinline__ void slab_sum_vblock(const SlabSum& a, int vb, float4* part) {
+  float4 v[8];
+  slab_sum_load(a, vb, v);
+  slab_sum_finish(a, vb, v, part);
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_tap_sum(SlabSum a) {
+  __shared__ float4 part[256];
+  slab_sum_vblock(a, blockIdx.x, part);
+}
+
 // ---------------------------------------------------------------------------------------
 // weight gradient, row-unit kernel: the tap-major decomposition above with the image width fixed
 // at compile time.  The unit of work of a wave is one output row of one image pair: it reads the
@@ -1235,6 +1305,7 @@ struct RGeo {
   unsigned m_xc, m_xi;       // staging x: BI*RL4, RL4
   unsigned m_dc, m_di;       // staging dY: BI*B4, B4
   int dbg;
+  SlabSum pend;              // slab sum of the previous weight gradient, done by this launch's blocks
   unsigned long long* stamps;
 };
 
@@ -1269,7 +1340,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   constexpr int T = KS * KS;
   constexpr int NW = kRowsWaves, NT = 64 * NW;
-  constexpr int SVX = 6, SVD = 4;              // X / dY vectors per thread in flight across a group
+  constexpr int SVX = 10, SVD = 4;             // X / dY vectors per thread in flight across a group
   constexpr int NXR = (UR - 1) * STRIDE + KS;  // source rows under the UR output rows of a unit
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1389,9 +1460,36 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
 
   const int my_groups = (g.ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   RG_STAMP();
+  f32x4 xsv[SVX], dsv[SVD];
   if (my_groups > 0) {
     group_base(0);
-    stage_rest(smem, 0, 0);
+#pragma unroll
+    for (int u = 0; u < SVD; u++) dsv[u] = *reinterpret_cast<const f32x4*>(yg_nxt + ds_src[u]);
+#pragma unroll
+    for (int u = 0; u < SVX; u++) xsv[u] = *reinterpret_cast<const f32x4*>(xg_nxt + xs_src[u]);
+  }
+  // This block's share of the previous layer's slab sum: the slabs of its first two virtual blocks
+  // are loaded now and added after the main loop (their latency hides behind it); any further
+  // ones are done on the spot.
+  constexpr int PVB = 2;
+  float4 pv[PVB][8];
+  const int nblk = gridDim.x * gridDim.y * gridDim.z;
+  const int me = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  if (g.pend.nvb > 0) {
+#pragma unroll
+    for (int j = 0; j < PVB; j++)
+      if (me + j * nblk < g.pend.nvb) slab_sum_load(g.pend, me + j * nblk, pv[j]);
+    for (int vb = me + PVB * nblk; vb < g.pend.nvb; vb += nblk)
+      slab_sum_vblock(g.pend, vb, reinterpret_cast<float4*>(smem));
+  }
+  if (my_groups > 0) {
+#pragma unroll
+    for (int u = 0; u < SVD; u++)
+      if (ds_lx[u] >= 0) lds_put(smem, ds_lx[u], dsv[u]);
+#pragma unroll
+    for (int u = 0; u < SVX; u++)
+      if (xs_lx[u] >= 0) lds_put(smem, xs_lx[u], xsv[u]);
+    stage_rest(smem, SVX, SVD);
   }
   su_lo_cur = su_lo_nxt; r0_cur = r0_nxt;
   __syncthreads();
@@ -1400,7 +1498,6 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
   const int lane_d = l31 * g.DST + half * BRBC;
   const int lane_x = xbase + l31 * g.XST + half * RL;
 
-  f32x4 xsv[SVX], dsv[SVD];
   for (int gi_ = 0; gi_ < my_groups; gi_++) {
     const int buf = gi_ & 1;
     const bool more = gi_ + 1 < my_groups;
@@ -1488,6 +1585,12 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
     RG_STAMP();
   }
 
+  if (g.pend.nvb > 0) {
+#pragma unroll
+    for (int j = 0; j < PVB; j++)
+      if (me + j * nblk < g.pend.nvb) slab_sum_finish(g.pend, me + j * nblk, pv[j], reinterpret_cast<float4*>(smem));
+  }
+
   // cross-wave sum through LDS in one round: red[t][wave][q][lane] (float4 = accumulator registers
   // 4q..4q+3); wave w then sums the T (tap, q) combinations w, w + NW, ...
   f32x4* red = reinterpret_cast<f32x4*>(smem);
@@ -1514,54 +1617,6 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
 #undef RG_STAMP
 }
 
-// dW[o][c][t] = sum over pixel slabs of slab[ps][ot][ct][t][q][lane][comp]; accumulator register
-// rr = 4q + comp of lane (half, col) is row comp + 8q + 4*half, column col of the 32 x 32 tile.
-// A block takes 256 / SL float4 items and SL slices of the slabs; slices are combined through LDS.
-__global__ __launch_bounds__(256) void k_wgrad_tap_sum(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                       int ps, int SL, int OT, int CT, int T, int O, int C) {
-  __shared__ float4 part[256];
-  const int ipb = 256 / SL;                       // items per block
-  const int it = threadIdx.x % ipb, sl = threadIdx.x / ipb;
-  const int64_t item = (int64_t)blockIdx.x * ipb + it;
-  const int64_t nitems = (int64_t)OT * CT * T * 256;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (item < nitems) {
-    const float4* src = reinterpret_cast<const float4*>(slabs) + item;
-    for (int s0 = sl; s0 < ps; s0 += SL * 8) {
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        int s = s0 + SL * u;
-        v[u] = s < ps ? src[(int64_t)s * nitems] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (s0 + SL * u < ps) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-    }
-  }
-  part[threadIdx.x] = acc;
-  __syncthreads();
-  if (sl == 0 && item < nitems) {
-    float4 r = part[it];
-    for (int k = 1; k < SL; k++) {
-      float4 q = part[k * ipb + it];
-      r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
-    }
-    const int lane = (int)(item & 63), q = (int)((item >> 6) & 3);
-    int64_t tile = item >> 8;
-    const int t = (int)(tile % T);
-    tile /= T;
-    const int ct = (int)(tile % CT), ot = (int)(tile / CT);
-    const int c = ct * 32 + (lane & 31);
-    const int o = ot * 32 + 8 * q + 4 * (lane >> 5);
-    if (c < C) {
-      float vals[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-      for (int e = 0; e < 4; e++)
-        if (o + e < O) dw[((int64_t)(o + e) * C + c) * T + t] = vals[e];
-    }
-  }
-}
 
 // out[i] = sum_s slabs[s][i], summed in a fixed order.  A block owns 256 consecutive elements
 // (64 lanes x float4); its 16 waves take the slabs s = w, w+16, ... with 8 loads in flight,
@@ -1974,11 +2029,37 @@ int run_wgrad_v3(WGeo g, float* dw) {
   return launch_wgrad_v3<2, 1, 4>(g, dw, lds, gx, ktg, otg);
 }
 
+// ---- deferred slab sum (see dfhip_internal.h) ----
+struct DeferredSum {
+  SlabSum a;
+  bool active = false;
+  int slot = -1;
+};
+DeferredSum g_def;
+
+SlabSum make_slab_sum(const float* slabs, float* dw, int ps, int OT, int CT, int T, int O, int C) {
+  SlabSum a;
+  a.slabs = slabs; a.dw = dw; a.ps = ps; a.OT = OT; a.CT = CT; a.T = T; a.O = O; a.C = C;
+  a.SL = 1;                                       // slices: at most eight slabs per thread
+  while (a.SL < 256 && a.SL * 8 < ps) a.SL *= 2;
+  a.nvb = (int)df_ceil_div((int64_t)OT * CT * T * 256, 256 / a.SL);
+  return a;
+}
+
+int launch_slab_sum(const SlabSum& a) {
+  hipLaunchKernelGGL(k_wgrad_tap_sum, dim3((unsigned)a.nvb), dim3(256), 0, stream(), a);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
 // ---- row-unit weight gradient: plan + launch ----
 template <int KS, int PAD, int STRIDE, int W, int OW, int UR>
 int launch_wgrad_rows(RGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
   const int T = KS * KS;
-  g.slabs = workspace((size_t)ps * OT * CT * T * 1024 * sizeof(float));
+  static int defer = getenv("DFHIP_WGRAD_DEFER") ? atoi(getenv("DFHIP_WGRAD_DEFER")) : 1;
+  // the slabs go to the scratch slot the pending sum does not read
+  const int slot = g_def.active ? 1 - g_def.slot : 0;
+  g.slabs = workspace_slot(slot, (size_t)ps * OT * CT * T * 1024 * sizeof(float));
   if (!g.slabs) return DFHIP_OUT_OF_MEMORY;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
@@ -1987,40 +2068,20 @@ int launch_wgrad_rows(RGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
     attr_lds = std::max(lds, (size_t)65536);
   }
   dim3 grid((unsigned)ps, (unsigned)CT, (unsigned)OT);
-  static int stamp_mode = -1;
-  if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
-  const size_t nb = (size_t)ps * CT * OT;
   g.stamps = nullptr;
-  if (stamp_mode) {
-    g.stamps = (unsigned long long*)workspace2(nb * 32 * 8);
-    (void)hipMemsetAsync(g.stamps, 0, nb * 32 * 8, stream());
+  g.pend = SlabSum{};
+  if (g_def.active) {                             // this launch's blocks do the previous layer's sum
+    g.pend = g_def.a;
+    g_def.active = false;
+    g_def.slot = -1;
   }
   hipLaunchKernelGGL((k_conv_wgrad_rows<KS, PAD, STRIDE, W, OW, UR>), grid, dim3(64 * kRowsWaves), lds, stream(), g);
   DF_LAUNCH_CHECK();
-  int SL = 1;                                     // slices: eight slabs per thread, at most 32 slices
-  while (SL < 32 && SL * 8 < ps) SL *= 2;
-  const int64_t nitems = (int64_t)OT * CT * T * 256;
-  hipLaunchKernelGGL(k_wgrad_tap_sum, dim3((unsigned)df_ceil_div(nitems, 256 / SL)), dim3(256), 0, stream(),
-                     g.slabs, dw, ps, SL, OT, CT, T, g.O, g.C);
-  DF_LAUNCH_CHECK();
-  if (stamp_mode) {
-    std::vector<unsigned long long> h(nb * 32);
-    (void)hipStreamSynchronize(stream());
-    (void)hipMemcpy(h.data(), g.stamps, nb * 32 * 8, hipMemcpyDeviceToHost);
-    double seg[32] = {0};
-    int nseg = 0;
-    for (size_t b = 0; b < nb; b++) {
-      const unsigned long long* r = &h[b * 32];
-      int n = 0;
-      while (n < 16 && r[n]) n++;
-      for (int i = 1; i < n; i++) seg[i] += (double)(r[i] - r[i - 1]);
-      nseg = std::max(nseg, n);
-    }
-    fprintf(stderr, "[stampr] k %d s %d W %d grid %d x %d x %d groups %d (BI %d BR %d) units/group %d lds %zu; mean segments:",
-            KS, STRIDE, W, ps, CT, OT, g.ngroups, g.BI, g.BR, g.units, lds);
-    for (int i = 1; i < nseg; i++) fprintf(stderr, " %.0f", seg[i] / nb);
-    fprintf(stderr, "\n");
-  }
+  SlabSum mine = make_slab_sum(g.slabs, dw, ps, OT, CT, T, g.O, g.C);
+  if (!defer) return launch_slab_sum(mine);
+  g_def.a = mine;
+  g_def.active = true;
+  g_def.slot = slot;
   return DFHIP_OK;
 }
 
@@ -2061,7 +2122,7 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
       const int units = BI / 2 * (BR / UR);
       if (units % kRowsWaves) continue;
       const int xv = (int)df_ceil_div(32 * BI * (RL / 4), 64 * kRowsWaves), dv = (int)df_ceil_div(32 * BI * (BRBC / 4), 64 * kRowsWaves);
-      if ((xv > 6 || dv > 4) && (N / BI) * gr > ps0) continue;   // later groups must fit the in-flight vectors
+      if ((xv > 10 || dv > 4) && (N / BI) * gr > ps0) continue;  // later groups must fit the in-flight vectors
       const int XST = bank_stride_r(BI * RL, W >= 4 ? 4 : 2), DST = bank_stride_r(BI * BRBC, ow >= 4 ? 4 : 2);
       const size_t red = (size_t)k * k * kRowsWaves * 4 * 64 * 16;
       const size_t lds = std::max((size_t)2 * 32 * (XST + DST) * 4, red);
@@ -2118,12 +2179,10 @@ int launch_wgrad_tap(TGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
   }
   hipLaunchKernelGGL((k_conv_wgrad_tap<KS, XV, DV, DENSE>), grid, dim3(512), lds, stream(), g);
   DF_LAUNCH_CHECK();
-  int SL = 1;                                     // slices: eight slabs per thread, at most 32 slices
-  while (SL < 32 && SL * 8 < ps) SL *= 2;
-  const int64_t nitems = (int64_t)OT * CT * T * 256;
-  hipLaunchKernelGGL(k_wgrad_tap_sum, dim3((unsigned)df_ceil_div(nitems, 256 / SL)), dim3(256), 0, stream(),
-                     g.slabs, dw, ps, SL, OT, CT, T, g.O, g.C);
-  DF_LAUNCH_CHECK();
+  {
+    int st_ = launch_slab_sum(make_slab_sum(g.slabs, dw, ps, OT, CT, T, g.O, g.C));
+    if (st_ != DFHIP_OK) return st_;
+  }
   if (stamp_mode) {
     std::vector<unsigned long long> h(nb * 32);
     (void)hipStreamSynchronize(stream());
@@ -2229,6 +2288,22 @@ int run_wgrad_tap(const float* x, const float* dy, float* dw, int N, int C, int 
 
 }  // namespace
 
+namespace dfhip {
+int flush_deferred() {
+  if (!g_def.active) return DFHIP_OK;
+  g_def.active = false;
+  g_def.slot = -1;
+  return launch_slab_sum(g_def.a);
+}
+bool deferred_touches(const void* p) {
+  if (!g_def.active || !p) return false;
+  const float* q = (const float*)p;
+  const float* lo = g_def.a.dw;
+  return q >= lo && q < lo + (int64_t)g_def.a.O * g_def.a.C * g_def.a.T;
+}
+int deferred_scratch_slot() { return g_def.active ? g_def.slot : -1; }
+}  // namespace dfhip
+
 extern "C" {
 
 int dfhip_conv2d_forward(const float* x, const float* w, const float* bias, float* y, int N, int C,
@@ -2252,7 +2327,10 @@ int dfhip_conv2d_forward(const float* x, const float* w, const float* bias, floa
 
 int dfhip_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int H, int W,
                        int O, int k, int stride, int pad, int mode) {
-  DF_INIT();
+  DF_INIT_KEEP();          // sits between two weight gradients of a backward pass
+  DF_TOUCH(dy);
+  DF_TOUCH(w);
+  DF_TOUCH(dx);
   int oh, ow;
   int s = check_conv_args("conv2d_dgrad", N, C, H, W, O, k, stride, pad, oh, ow);
   if (s != DFHIP_OK) return s;
@@ -2272,7 +2350,10 @@ int dfhip_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C,
 
 int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W,
                        int O, int k, int stride, int pad) {
-  DF_INIT();
+  DF_INIT_KEEP();          // the row-unit kernel takes the pending slab sum along; other paths flush
+  DF_TOUCH(x);
+  DF_TOUCH(dy);
+  DF_TOUCH(dw);
   int oh, ow;
   int s = check_conv_args("conv2d_wgrad", N, C, H, W, O, k, stride, pad, oh, ow);
   if (s != DFHIP_OK) return s;
@@ -2287,6 +2368,8 @@ int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C,
   {
     int st = run_wgrad_rows(x, dy, dw, N, C, H, W, O, oh, ow, k, stride, pad);
     if (st >= 0) return st;
+    st = flush_deferred();
+    if (st != DFHIP_OK) return st;
     st = run_wgrad_tap(x, dy, dw, N, C, H, W, O, oh, ow, k, stride, pad);
     if (st >= 0) return st;
     st = run_wgrad_v3(g, dw);

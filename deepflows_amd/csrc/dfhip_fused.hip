@@ -828,7 +828,15 @@ int dfhip_bn2d_forward_eval(const float* x, const float* gamma, const float* bet
 int dfhip_bn2d_backward(const float* dy, const float* x, const float* gamma, const float* save_mean,
                         const float* save_var, float* dx, float* dgamma, float* dbeta, int N, int C,
                         int HW, float eps) {
-  DF_INIT();
+  DF_INIT_KEEP();
+  DF_TOUCH(dy);
+  DF_TOUCH(x);
+  DF_TOUCH(gamma);
+  DF_TOUCH(save_mean);
+  DF_TOUCH(save_var);
+  DF_TOUCH(dx);
+  DF_TOUCH(dgamma);
+  DF_TOUCH(dbeta);
   DF_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bn2d_backward: non-positive dimension");
   DF_CHECK_ARG(dy && x && save_mean && save_var, "bn2d_backward: null array");
   ProfScope prof("bn2d_bwd", 0.0, 20.0 * (double)N * C * HW);
@@ -867,7 +875,11 @@ int dfhip_maxpool2d_forward(const float* x, float* y, int NC, int H, int W, int 
 
 int dfhip_maxpool2d_backward(const float* x, const float* y, const float* dy, float* dx, int NC,
                              int H, int W, int k) {
-  DF_INIT();
+  DF_INIT_KEEP();
+  DF_TOUCH(x);
+  DF_TOUCH(y);
+  DF_TOUCH(dy);
+  DF_TOUCH(dx);
   DF_CHECK_ARG(NC > 0 && H > 0 && W > 0 && k >= 1 && k <= H && k <= W, "maxpool2d: bad geometry");
   DF_CHECK_ARG(x && y && dy && dx, "maxpool2d_backward: null array");
   int oh = (H - k) / k + 1, ow = (W - k) / k + 1;
@@ -891,7 +903,11 @@ int dfhip_relu_forward(const float* x, float* y, int64_t n) {
 }
 
 int dfhip_relu_backward(const float* x, const float* y, const float* g, float* dx, int64_t n) {
-  DF_INIT();
+  DF_INIT_KEEP();
+  DF_TOUCH(x);
+  DF_TOUCH(y);
+  DF_TOUCH(g);
+  DF_TOUCH(dx);
   DF_CHECK_ARG(n >= 0, "relu_backward: negative size");
   if (n == 0) return DFHIP_OK;
   DF_CHECK_ARG(x && y && g && dx, "relu_backward: null array");

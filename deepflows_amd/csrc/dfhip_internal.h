@@ -28,6 +28,16 @@ struct ProfScope {
 float* workspace(size_t bytes);
 // second, independent scratch area (for kernels that need two live scratch buffers)
 float* workspace2(size_t bytes);
+float* workspace_slot(int slot, size_t bytes);
+
+// Deferred work: the slab sum of a weight gradient rides on the NEXT weight-gradient launch (its
+// blocks add the slabs while their own first loads are in flight).  Every C entry point flushes it
+// (DF_INIT) except the few that are called between two weight gradients of a backward pass, which
+// keep it (DF_INIT_KEEP) and flush only if one of their arrays is the pending destination
+// (DF_TOUCH).
+int flush_deferred();
+bool deferred_touches(const void* p);
+int deferred_scratch_slot();          // scratch slot holding the pending slabs, -1 if none
 
 }  // namespace dfhip
 
@@ -59,10 +69,26 @@ float* workspace2(size_t bytes);
     }                                                                                  \
   } while (0)
 
+#define DF_INIT_KEEP()                         \
+  do {                                         \
+    int s__ = dfhip::ensure_init();            \
+    if (s__ != DFHIP_OK) return s__;           \
+  } while (0)
+
 #define DF_INIT()                              \
   do {                                         \
     int s__ = dfhip::ensure_init();            \
     if (s__ != DFHIP_OK) return s__;           \
+    s__ = dfhip::flush_deferred();             \
+    if (s__ != DFHIP_OK) return s__;           \
+  } while (0)
+
+#define DF_TOUCH(p)                                  \
+  do {                                               \
+    if (dfhip::deferred_touches((const void*)(p))) { \
+      int s__ = dfhip::flush_deferred();             \
+      if (s__ != DFHIP_OK) return s__;               \
+    }                                                \
   } while (0)
 
 static inline int64_t df_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

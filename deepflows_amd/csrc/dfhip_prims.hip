@@ -105,7 +105,10 @@ __global__ __launch_bounds__(kThreads) void k_fill(float* __restrict__ out, int6
 
 template <class Op, class Fn>
 int launch_binary(const char* name, const float* a, const float* b, float* out, int64_t n, Fn) {
-  DF_INIT();
+  DF_INIT_KEEP();          // gradient accumulation sits between two weight gradients of a backward pass
+  DF_TOUCH(a);
+  DF_TOUCH(b);
+  DF_TOUCH(out);
   DF_CHECK_ARG(n >= 0, "%s: negative size", name);
   if (n == 0) return DFHIP_OK;
   DF_CHECK_ARG(a && b && out, "%s: null array", name);

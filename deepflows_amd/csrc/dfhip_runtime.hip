@@ -168,6 +168,7 @@ static ScratchSlot g_ws[2];
 static float* scratch(int i, size_t bytes) {
   // A scratch area is simply a pool block that is returned to the pool as soon as a
   // bigger one is needed; stream order makes the hand-over safe.
+  if (deferred_scratch_slot() == i) (void)flush_deferred();   // its slabs live in this slot
   bytes = (bytes + 255) & ~(size_t)255;
   ScratchSlot& s = g_ws[i];
   bool wrong_owner = false;
@@ -187,6 +188,7 @@ static float* scratch(int i, size_t bytes) {
 }
 float* workspace(size_t bytes) { return scratch(0, bytes); }
 float* workspace2(size_t bytes) { return scratch(1, bytes); }
+float* workspace_slot(int slot, size_t bytes) { return scratch(slot & 1, bytes); }
 
 // ---------------------------------------------------------------------------------------
 // profiling: HIP events around kernel families on the library stream
@@ -272,7 +274,10 @@ int dfhip_sync(void) {
   return DFHIP_OK;
 }
 
-void* dfhip_stream(void) { return (void*)g_stream; }
+void* dfhip_stream(void) {
+  (void)flush_deferred();
+  return (void*)g_stream;
+}
 
 int dfhip_device_name(char* out, int cap) {
   DF_INIT();
@@ -281,7 +286,7 @@ int dfhip_device_name(char* out, int cap) {
 }
 
 int dfhip_malloc(int64_t n_floats, float** out) {
-  DF_INIT();
+  DF_INIT_KEEP();
   DF_CHECK_ARG(n_floats >= 0, "Array size must be >= 0 (got %lld)", (long long)n_floats);
   void* p = nullptr;
   int s = pool_alloc(round_bytes(n_floats), &p);
@@ -289,7 +294,10 @@ int dfhip_malloc(int64_t n_floats, float** out) {
   return s;
 }
 
-int dfhip_free(float* p) { return pool_free((void*)p); }
+int dfhip_free(float* p) {
+  DF_TOUCH(p);
+  return pool_free((void*)p);
+}
 
 int dfhip_pool_stats(int64_t* bytes_reserved, int64_t* bytes_in_use, int64_t* n_hipmalloc) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -401,6 +409,7 @@ int dfhip_graph_begin(void) {
 
 int dfhip_graph_end(void** graph_exec) {
   DF_CHECK_ARG(g_capture_open, "no capture open");
+  { int f__ = flush_deferred(); if (f__ != DFHIP_OK) return f__; }
   int id = g_capture_open;
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamEndCapture(g_stream, &graph);
@@ -423,6 +432,7 @@ int dfhip_graph_end(void** graph_exec) {
 
 int dfhip_graph_launch(void* graph_exec) {
   DF_CHECK_ARG(graph_exec, "null graph");
+  { int f__ = flush_deferred(); if (f__ != DFHIP_OK) return f__; }
   GraphExec* g = (GraphExec*)graph_exec;
   DF_HIP(hipGraphLaunch(g->exec, g_stream));
   return DFHIP_OK;
@@ -459,6 +469,7 @@ int dfhip_event_create(void** ev) {
   return DFHIP_OK;
 }
 int dfhip_event_record(void* ev) {
+  { int f__ = flush_deferred(); if (f__ != DFHIP_OK) return f__; }
   DF_HIP(hipEventRecord((hipEvent_t)ev, g_stream));
   return DFHIP_OK;
 }
@@ -486,6 +497,7 @@ int dfhip_prof_reset(void) {
 }
 int dfhip_prof_read(int cap, const char** names, double* total_ms, int64_t* calls,
                     double* flops, double* bytes) {
+  (void)flush_deferred();
   int n = 0;
   for (auto& s : g_prof) {
     prof_resolve(s);
@@ -578,6 +590,7 @@ int dfhip_allreduce_sum(float* buf, int64_t n) {
 }
 
 int dfhip_comm_destroy(void) {
+  (void)flush_deferred();
   if (g_comm) {
     (void)hipStreamSynchronize(g_stream);
     p_ncclCommDestroy(g_comm);
