@@ -126,6 +126,23 @@ def main():
         loss = step()
     mod.synchronize()
 
+    # the timed steps replay one captured step (hipGraph) unless --no-graph; same kernels, same
+    # order, one host call per step instead of ~170
+    captured = None
+    if not args.no_graph:
+        try:
+            from deepflows_amd.graph_step import CapturedTrainStep
+            captured = CapturedTrainStep(model, crit, opt, xt, yt, sync=sync)
+            for _ in range(2):
+                loss = captured.replay()
+            mod.synchronize()
+        except Exception as e:                      # stay on the eager path, say so
+            print(f"[bench] step capture failed ({type(e).__name__}: {e}); timing the eager path", file=sys.stderr)
+            captured = None
+    eager_step = step
+    if captured is not None:
+        step = captured.replay
+
     comm.barrier()
     mod.synchronize()
     e0, e1 = mod.event(), mod.event()
@@ -134,6 +151,7 @@ def main():
     for _ in range(args.steps):
         loss = step()
     mod.event_record(e1)
+    host_issue = time.perf_counter() - t0        # the host has queued everything; the GPU may still run
     mod.synchronize()
     comm.barrier()
     wall = time.perf_counter() - t0
@@ -141,11 +159,14 @@ def main():
     gpu_ms = mod.event_elapsed_ms(e0, e1)
     final_loss = float(loss.numpy()[0])
 
-    # second pass over the same K steps with per-family HIP events (roofline)
+    # second pass over the same K steps with per-family HIP events (roofline); events cannot be
+    # recorded inside a graph replay, so this pass issues the same step eagerly
+    if captured is not None:
+        opt.device_hyper = False
     mod.prof_reset()
     mod.prof_enable(True)
     for _ in range(args.steps):
-        step()
+        eager_step()
     mod.synchronize()
     mod.prof_enable(False)
     prof = mod.prof_read()
@@ -185,9 +206,10 @@ def main():
             "config": {"workload": "ResNet-18 (CIFAR variant 32/64/128/256, test/ResNet_CIFAR10_cuda.py) "
                                    "train step: fwd + CE + bwd + Adam, bs 256 per GPU, fp32",
                        "global_batch": BATCH * comm.world, "parallelism": f"dp{comm.world}",
-                       "conv_dgrad": args.dgrad, "registered_params": args.registration,
+                       "conv_dgrad": args.dgrad, "dispatch": "hipgraph" if captured is not None else "eager", "registered_params": args.registration,
                        "allreduce_elems": bucket.total if comm.world > 1 else 0},
-            "gpu_ms_per_step": gpu_ms / args.steps, "final_loss": final_loss,
+            "gpu_ms_per_step": gpu_ms / args.steps, "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
+            "final_loss": final_loss,
             "roofline": roofline,
             "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in
                         sorted(fams.items(), key=lambda kv: -kv[1]["ms_per_step"])},

@@ -43,6 +43,8 @@ _SIGS = {
     "dfhip_reduce_max": [P, P, c_int64, c_int64],
     "dfhip_gemm": [P, P, P, P, c_int64, c_int64, c_int64, c_int, c_int],
     "dfhip_conv2d_forward": [P, P, P, P] + [c_int] * 8,
+    "dfhip_conv2d_forward_stats": [P, P, P, P] + [c_int] * 8 + [P, c_int, POINTER(c_int)],
+    "dfhip_bn2d_forward_partials": [P, P, c_int] + [P] * 8 + [c_int, c_int, c_int, c_float, c_float],
     "dfhip_conv2d_wgrad": [P, P, P] + [c_int] * 8,
     "dfhip_conv2d_dgrad": [P, P, P] + [c_int] * 9,
     "dfhip_bn2d_forward_train": [P] * 8 + [c_int, c_int, c_int, c_float, c_float],
@@ -60,6 +62,8 @@ _SIGS = {
     "dfhip_axpy": [P, P, c_float, c_int64],
     "dfhip_adam_step": [c_int, PP, PP, PP, PP, I64P, c_double, c_double, c_double, c_double,
                         c_double, c_int, c_double],
+    "dfhip_adam_hyper": [P, c_double, c_double, c_double, c_double, c_double, c_int, c_double],
+    "dfhip_adam_step_dev": [c_int, PP, PP, PP, PP, I64P, P],
     "dfhip_sgd_step": [c_int, PP, PP, PP, I64P, c_double, c_double, c_double, c_int, c_double],
     "dfhip_pack": [c_int, PP, I64P, P],
     "dfhip_unpack": [c_int, PP, I64P, P],

@@ -68,6 +68,10 @@ struct Geo {
   int dbg;                     // diagnostics: 1 = loaders idle in the main loop, 2 = no MFMAs
   unsigned m_perimg, m_pc, m_sd;   // exact division by multiplication (magic = ceil(2^32/d), 0 = divide by 1)
   unsigned m_brbc, m_bc, m_birl4, m_rl4, m_run4;
+  // forward only: per-workgroup BatchNorm partials of the output, [gridDim.x][CD][3] = (count, mean,
+  // centred second moment) over the workgroup's pixels, or null
+  float* stats;
+  int vec_store;   // 1: destination pixels of a tile are contiguous and 16-byte aligned in runs of 4
 };
 
 __device__ __forceinline__ void decode_pixel(const Geo& g, int q, int& img, int& r, int& col) {
@@ -473,17 +477,102 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
     }
   }
 
-  if (ks == 0 && pvalid) {
+  // ---- epilogue: every finished tile goes through LDS as T[32 channels][36] so that it leaves
+  // with 16-byte stores along the pixels (4 stores per lane instead of 16) and, for the forward
+  // pass, so that its BatchNorm partials are row sums instead of cross-lane shuffles ----
+  constexpr int TS = 36;
+  const bool vec_ok = g.vec_store != 0;          // pixels of a tile are contiguous in runs of 4
+  if (ks == 0 && g.bias) {
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) {
+      int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+      acc[rr] += g.bias[min(d, g.CD - 1)];
+    }
+  }
+  const bool want_stats = MODE == 0 && g.stats != nullptr;
+  if (vec_ok || want_stats) {
+    __syncthreads();                             // staging buffers / k-split sums are dead
+    float* Tt = smem + pt * (32 * TS);
+    if (ks == 0) {
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) Tt[((rr & 3) + 8 * (rr >> 2) + 4 * half) * TS + l31] = acc[rr];
+    }
+    __syncthreads();
+    if (ks == 0 && vec_ok) {
+      const int64_t dplane = (int64_t)g.HD * g.WD;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int f = lane + 64 * u;
+        const int o = f >> 3, q4 = f & 7;
+        const int qq = pt * 32 + 4 * q4;
+        const int im = (int)fast_div((unsigned)qq, g.m_brbc);
+        const int rem = qq - im * (g.BR * g.BC);
+        const int rr_ = (int)fast_div((unsigned)rem, g.m_bc), cc_ = rem - rr_ * g.BC;
+        const bool ok = qq < g.BI * g.BR * g.BC && n0 + im < g.N && r0 + rr_ < g.HD && d0 + o < g.CD;
+        if (ok) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(Tt + o * TS + 4 * q4);
+          *reinterpret_cast<f32x4*>(g.dst + ((int64_t)(n0 + im) * g.CD + d0 + o) * dplane + (int64_t)(r0 + rr_) * g.WD + cc_) = v;
+        }
+      }
+    }
+  }
+  if (ks == 0 && !vec_ok && pvalid) {
     const int64_t dplane = (int64_t)g.HD * g.WD;
     float* out = g.dst + (int64_t)(n0 + img) * g.CD * dplane + (int64_t)(r0 + r) * g.WD + col;
 #pragma unroll
     for (int rr = 0; rr < 16; rr++) {
       int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-      if (d < g.CD) {
-        float v = acc[rr];
-        if (g.bias) v += g.bias[d];
-        out[(int64_t)d * dplane] = v;
+      if (d < g.CD) out[(int64_t)d * dplane] = acc[rr];
+    }
+  }
+  if (want_stats) {
+    // BatchNorm partials of this workgroup's output: lane (channel = lane & 31, half) walks 16 of
+    // the tile's 32 pixels, the halves meet through one swap; exact two-pass (mean, centred
+    // second moment) per tile, then Chan's combination of the PT tiles.
+    float* sb = smem + PT * (32 * TS);           // [PT][32 channels][3]
+    if (ks == 0) {
+      const unsigned vm = (unsigned)__ballot(pvalid);          // validity of the tile's 32 pixels
+      const float cnt = (float)__popc(vm);
+      const float* row = smem + pt * (32 * TS) + l31 * TS + 16 * half;
+      float vals[16];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; q4++) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(row + 4 * q4);
+        vals[4 * q4] = t.x; vals[4 * q4 + 1] = t.y; vals[4 * q4 + 2] = t.z; vals[4 * q4 + 3] = t.w;
       }
+      const unsigned hm = vm >> (16 * half);
+      float t = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; i++) t += ((hm >> i) & 1u) ? vals[i] : 0.0f;
+      t += __shfl_xor(t, 32);
+      const float mean_t = cnt > 0.0f ? t / cnt : 0.0f;
+      float q = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const float dlt = ((hm >> i) & 1u) ? vals[i] - mean_t : 0.0f;
+        q += dlt * dlt;
+      }
+      q += __shfl_xor(q, 32);
+      if (half == 0) {
+        float* o = sb + (pt * 32 + l31) * 3;
+        o[0] = cnt; o[1] = mean_t; o[2] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < 32 && d0 + tid < g.CD) {
+      float n = 0.0f, mu = 0.0f, m2 = 0.0f;
+      for (int t = 0; t < PT; t++) {
+        const float* o = sb + (t * 32 + tid) * 3;
+        const float nb = o[0];
+        if (nb > 0.0f) {
+          const float nn = n + nb, delta = o[1] - mu;
+          mu += delta * (nb / nn);
+          m2 += o[2] + delta * delta * (n * nb / nn);
+          n = nn;
+        }
+      }
+      float* o = g.stats + ((int64_t)blockIdx.x * g.CD + d0 + tid) * 3;
+      o[0] = n; o[1] = mu; o[2] = m2;
     }
   }
   DF_STAMP();
@@ -1734,7 +1823,8 @@ int finish_slabs(const Geo& g, int splits, float* final_dst, const float* bias, 
 static int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
 // main kernel; returns -1 when the shape is not eligible (the generic kernel takes it then)
-int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias) {
+int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, float* partials = nullptr,
+                 int cap_rows = 0, int* rows_out = nullptr) {
   if (g.CS % 8 != 0 || !(g.k == 1 || g.k == 3)) return -1;
   if (g.mode != 0 && g.CD % 32 != 0) return -1;    // dgrad weight rows are staged as whole 32-channel runs
   if ((g.HS * g.WS) % 4 != 0) return -1;            // channel planes must stay 16-byte aligned
@@ -1792,6 +1882,15 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias) 
   g.bias = bias;
   dim3 grid((unsigned)(gi * g.gr), (unsigned)dtiles, 1);
   int st = DFHIP_OK;
+  g.stats = nullptr;
+  static int vec_store = getenv("DFHIP_VEC_STORE") ? atoi(getenv("DFHIP_VEC_STORE")) : 1;
+  g.vec_store = (vec_store && (g.BR * g.BC) % 4 == 0 && (g.HD * g.WD) % 4 == 0) ? 1 : 0;
+  if (partials) {
+    if ((int)grid.x > cap_rows) return -1;
+    g.stats = partials;
+    if (rows_out) *rows_out = (int)grid.x;
+  }
+  lds = std::max(lds, (size_t)chosen * (32 * 36 + 32 * 3) * sizeof(float));
   g.stamps = nullptr;
   static int stamp_mode = -1;
   if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
@@ -2306,9 +2405,9 @@ int deferred_scratch_slot() { return g_def.active ? g_def.slot : -1; }
 
 extern "C" {
 
-int dfhip_conv2d_forward(const float* x, const float* w, const float* bias, float* y, int N, int C,
-                         int H, int W, int O, int k, int stride, int pad) {
-  DF_INIT();
+static int conv2d_forward_impl(const float* x, const float* w, const float* bias, float* y, int N, int C, int H,
+                               int W, int O, int k, int stride, int pad, float* partials, int cap_rows,
+                               int* rows_out) {
   int oh, ow;
   int s = check_conv_args("conv2d_forward", N, C, H, W, O, k, stride, pad, oh, ow);
   if (s != DFHIP_OK) return s;
@@ -2322,7 +2421,33 @@ int dfhip_conv2d_forward(const float* x, const float* w, const float* bias, floa
   g.CD = O; g.HD = oh; g.WD = ow;
   g.k = k; g.so = stride; g.sd = 1; g.u0 = -pad;
   g.mode = 0; g.wC = C; g.pad = pad; g.stride = stride; g.oh = oh; g.ow = ow;
+  if (rows_out) *rows_out = 0;
+  if (partials && rows_out) {
+    int rows = 0;
+    int st = run_igemm_v4(g, O, y, bias, partials, cap_rows, &rows);
+    if (st >= 0) {
+      *rows_out = rows;
+      return st;
+    }
+  }
   return run_igemm(g, O, y, bias);
+}
+
+int dfhip_conv2d_forward(const float* x, const float* w, const float* bias, float* y, int N, int C,
+                         int H, int W, int O, int k, int stride, int pad) {
+  DF_INIT();
+  return conv2d_forward_impl(x, w, bias, y, N, C, H, W, O, k, stride, pad, nullptr, 0, nullptr);
+}
+
+// forward + BatchNorm partials of y: partials[rows][O][3] = (count, mean, centred second moment) of
+// each output channel over the pixels of one workgroup; *rows_out = 0 when the shape took a kernel
+// that does not produce them (the caller then uses dfhip_bn2d_forward_train)
+int dfhip_conv2d_forward_stats(const float* x, const float* w, const float* bias, float* y, int N, int C,
+                               int H, int W, int O, int k, int stride, int pad, float* partials,
+                               int cap_rows, int* rows_out) {
+  DF_INIT();
+  DF_CHECK_ARG(partials && rows_out && cap_rows > 0, "conv2d_forward_stats: null partials / rows_out");
+  return conv2d_forward_impl(x, w, bias, y, N, C, H, W, O, k, stride, pad, partials, cap_rows, rows_out);
 }
 
 int dfhip_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int H, int W,

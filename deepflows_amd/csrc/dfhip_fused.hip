@@ -269,6 +269,78 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(
   });
 }
 
+// ---- BatchNorm forward from the partials a convolution left behind ------------------------------
+// partials[rows][C][3] = (count, mean, centred second moment) per convolution workgroup.  Every
+// block of channel c combines the rows with Chan's update (a tree over 256 threads), then
+// normalises its slice of images; y = (x - mean) / sqrt(var + eps) * gamma + beta (+ residual).
+__global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
+    const float* __restrict__ x, const float* __restrict__ partials, int rows, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ residual, float* __restrict__ y,
+    float* __restrict__ save_mean, float* __restrict__ save_var, float* __restrict__ running_mean,
+    float* __restrict__ running_var, int N, int C, int HW, int ipb, float eps, float momentum) {
+  __shared__ float sn[kThreads], sm[kThreads], sq[kThreads];
+  const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  float n = 0.0f, mu = 0.0f, m2 = 0.0f;
+  for (int r = tid; r < rows; r += kThreads) {
+    const float* p = partials + ((int64_t)r * C + c) * 3;
+    const float nb = p[0];
+    if (nb > 0.0f) {
+      const float nn = n + nb, delta = p[1] - mu;
+      mu += delta * (nb / nn);
+      m2 += p[2] + delta * delta * (n * nb / nn);
+      n = nn;
+    }
+  }
+  sn[tid] = n; sm[tid] = mu; sq[tid] = m2;
+  __syncthreads();
+  for (int stp = kThreads / 2; stp >= 1; stp >>= 1) {
+    if (tid < stp) {
+      const float nb = sn[tid + stp];
+      if (nb > 0.0f) {
+        const float na = sn[tid], nn = na + nb, delta = sm[tid + stp] - sm[tid];
+        sm[tid] += delta * (nb / nn);
+        sq[tid] += sq[tid + stp] + delta * delta * (na * nb / nn);
+        sn[tid] = nn;
+      }
+    }
+    __syncthreads();
+  }
+  const float mean = sm[0];
+  const float var = sn[0] > 0.0f ? sq[0] / sn[0] : 0.0f;   // biased variance (batchnorm.py:41-42)
+  if (s == 0 && tid == 0) {
+    if (save_mean) save_mean[c] = mean;
+    if (save_var) save_var[c] = var;
+    if (running_mean) running_mean[c] = running_mean[c] * (1.0f - momentum) + mean * momentum;
+    if (running_var) running_var[c] = running_var[c] * (1.0f - momentum) + var * momentum;
+  }
+  const float sd = sqrtf(var + eps);
+  const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+  const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
+  const int64_t img_stride = (int64_t)C * HW;
+  const float* base = x + (int64_t)c * HW;
+  float* ybase = y + (int64_t)c * HW;
+  const float* rbase = residual ? residual + (int64_t)c * HW : nullptr;
+  for_each_chunk(base, img_stride, n_lo, n_hi, HW, [&](const float* p, int wdt) {
+    const int64_t off = p - base;
+    if (wdt == 4) {
+      float4 v = *reinterpret_cast<const float4*>(p), r;
+      r.x = (v.x - mean) / sd * w + b;
+      r.y = (v.y - mean) / sd * w + b;
+      r.z = (v.z - mean) / sd * w + b;
+      r.w = (v.w - mean) / sd * w + b;
+      if (rbase) {
+        float4 t = *reinterpret_cast<const float4*>(rbase + off);
+        r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+      }
+      *reinterpret_cast<float4*>(ybase + off) = r;
+    } else {
+      float r = (p[0] - mean) / sd * w + b;
+      if (rbase) r += rbase[off];
+      ybase[off] = r;
+    }
+  });
+}
+
 // ---- single-launch BatchNorm for channels of at most 16 384 elements (N*HW) ------------------
 // One 512-thread workgroup owns a channel and keeps its elements in registers (<= 8 float4 per
 // thread): x is read from HBM once (8 B per element instead of 12), mean and the centred second
@@ -716,6 +788,36 @@ __global__ __launch_bounds__(kThreads) void k_adam(TensorBatch tb, AdamHyper h) 
   }
 }
 
+// the same update with the hyper-parameters read from device memory: a captured training step
+// (hipGraph) replays this launch unchanged while dfhip_adam_hyper refreshes the scalars (bias
+// corrections change every step) with a one-thread launch in front of the replay
+__global__ __launch_bounds__(kThreads) void k_adam_dev(TensorBatch tb, const AdamHyper* __restrict__ hp) {
+  const AdamHyper h = *hp;
+  int t = find_tensor(tb, blockIdx.x);
+  int64_t lo = (int64_t)(blockIdx.x - tb.blk_start[t]) * kChunk;
+  int64_t hi = min(tb.size[t], lo + kChunk);
+  float* p = tb.p[t];
+  const float* g = tb.g[t];
+  float* m = tb.s1[t];
+  float* v = tb.s2[t];
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+    float gi = g[i];
+    if (h.gscale != 1.0f) gi = gi * h.gscale;
+    float pi = p[i];
+    if (h.wd > 0.0f) gi = gi + pi * h.wd;
+    float mi = m[i] * h.b1 + gi * h.omb1;
+    float vi = v[i] * h.b2 + (gi * gi) * h.omb2;
+    m[i] = mi;
+    v[i] = vi;
+    float mh = mi / h.bc1;
+    float vh = vi / h.bc2;
+    float upd = mh / (sqrtf(vh) + h.eps) * h.lr;
+    p[i] = pi + upd * -1.0f;
+  }
+}
+
+__global__ void k_set_adam_hyper(AdamHyper* dst, AdamHyper h) { *dst = h; }
+
 struct SgdHyper {
   float lr, mu, wd, gscale;
   int nesterov, use_momentum;
@@ -806,6 +908,24 @@ int dfhip_bn2d_forward_train(const float* x, const float* gamma, const float* be
   DF_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bn_apply, grid, dim3(kThreads), 0, stream(), x, gamma, beta, y, partial,
                      save_mean, save_var, running_mean, running_var, N, C, HW, S, ipb, eps, momentum);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+int dfhip_bn2d_forward_partials(const float* x, const float* partials, int rows, const float* gamma,
+                                const float* beta, const float* residual, float* y, float* save_mean,
+                                float* save_var, float* running_mean, float* running_var, int N, int C,
+                                int HW, float eps, float momentum) {
+  DF_INIT();
+  DF_CHECK_ARG(N > 0 && C > 0 && HW > 0 && rows > 0, "bn2d_forward_partials: non-positive dimension");
+  DF_CHECK_ARG(x && y && partials, "bn2d_forward_partials: null array");
+  double n = (double)N * C * HW;
+  ProfScope prof("bn2d_fwd", 0.0, (residual ? 12.0 : 8.0) * n);
+  int S, ipb;
+  bn_split(N, C, S, ipb);
+  hipLaunchKernelGGL(k_bn_apply_partials, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), x, partials,
+                     rows, gamma, beta, residual, y, save_mean, save_var, running_mean, running_var, N, C, HW, ipb,
+                     eps, momentum);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -1048,6 +1168,53 @@ int dfhip_adam_step(int n_tensors, float* const* params, const float* const* gra
     TensorBatch tb;
     int blocks = fill_batch(tb, n, first, params, grads, exp_avg, exp_avg_sq, sizes);
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(kThreads), 0, stream(), tb, h);
+    DF_LAUNCH_CHECK();
+  }
+  return DFHIP_OK;
+}
+
+static AdamHyper make_adam_hyper(double lr, double beta1, double beta2, double eps, double weight_decay,
+                                 int step, double grad_scale) {
+  // scalars are rounded to fp32 exactly where the reference's NumPy device rounds them
+  AdamHyper h;
+  h.lr = (float)lr;
+  h.b1 = (float)beta1;
+  h.b2 = (float)beta2;
+  h.omb1 = (float)(1.0 - beta1);
+  h.omb2 = (float)(1.0 - beta2);
+  h.bc1 = (float)(1.0 - pow(beta1, (double)step));
+  h.bc2 = (float)(1.0 - pow(beta2, (double)step));
+  h.eps = (float)eps;
+  h.wd = (float)weight_decay;
+  h.gscale = (float)grad_scale;
+  return h;
+}
+
+int dfhip_adam_hyper(float* hyper_dev, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, int step, double grad_scale) {
+  DF_INIT();
+  DF_CHECK_ARG(hyper_dev && step >= 1, "adam_hyper: bad arguments");
+  AdamHyper h = make_adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+  hipLaunchKernelGGL(k_set_adam_hyper, dim3(1), dim3(1), 0, stream(), (AdamHyper*)hyper_dev, h);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+int dfhip_adam_step_dev(int n_tensors, float* const* params, const float* const* grads,
+                        float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
+                        const float* hyper_dev) {
+  DF_INIT();
+  DF_CHECK_ARG(n_tensors >= 0 && hyper_dev, "adam_step_dev: bad arguments");
+  if (n_tensors == 0) return DFHIP_OK;
+  DF_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && sizes, "adam_step_dev: null table");
+  double total = 0;
+  for (int i = 0; i < n_tensors; i++) total += (double)sizes[i];
+  ProfScope prof("adam_step", 0.0, 28.0 * total);
+  for (int first = 0; first < n_tensors; first += kBatch) {
+    int n = std::min(kBatch, n_tensors - first);
+    TensorBatch tb;
+    int blocks = fill_batch(tb, n, first, params, grads, exp_avg, exp_avg_sq, sizes);
+    hipLaunchKernelGGL(k_adam_dev, dim3(blocks), dim3(kThreads), 0, stream(), tb, (const AdamHyper*)hyper_dev);
     DF_LAUNCH_CHECK();
   }
   return DFHIP_OK;

@@ -199,6 +199,22 @@ class HipModule:
         _lib.check(self._lib.dfhip_conv2d_forward(x.ptr, w.ptr, bias.ptr if bias is not None else None,
                                                   y.ptr, N, C, H, W, O, k, stride, pad))
 
+    def conv2d_forward_stats(self, x, w, bias, y, N, C, H, W, O, k, stride, pad, partials, cap_rows):
+        """conv2d_forward that also fills `partials` (cap_rows x O x 3) with BatchNorm partials of y;
+        returns the number of rows written (0: the shape took a kernel without that epilogue)."""
+        rows = ctypes.c_int(0)
+        _lib.check(self._lib.dfhip_conv2d_forward_stats(
+            x.ptr, w.ptr, bias.ptr if bias is not None else None, y.ptr, N, C, H, W, O, k, stride, pad,
+            partials.ptr, int(cap_rows), ctypes.byref(rows)))
+        return int(rows.value)
+
+    def bn2d_forward_partials(self, x, partials, rows, gamma, beta, residual, y, save_mean, save_var,
+                              running_mean, running_var, N, C, HW, eps, momentum):
+        g = lambda h: h.ptr if h is not None else None
+        _lib.check(self._lib.dfhip_bn2d_forward_partials(
+            x.ptr, partials.ptr, int(rows), g(gamma), g(beta), g(residual), y.ptr, g(save_mean), g(save_var),
+            g(running_mean), g(running_var), N, C, HW, float(eps), float(momentum)))
+
     def conv2d_wgrad(self, x, dy, dw, N, C, H, W, O, k, stride, pad):
         _lib.check(self._lib.dfhip_conv2d_wgrad(x.ptr, dy.ptr, dw.ptr, N, C, H, W, O, k, stride, pad))
 
@@ -269,6 +285,17 @@ class HipModule:
         _lib.check(self._lib.dfhip_adam_step(n, _ptr_table(params), _ptr_table(grads), _ptr_table(exp_avg),
                                              _ptr_table(exp_avg_sq), sizes, lr, beta1, beta2, eps,
                                              weight_decay, int(step), grad_scale))
+
+    def adam_hyper(self, hyper, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+        """Write the scalars of Adam step `step` into the device array `hyper` (>= 16 floats)."""
+        _lib.check(self._lib.dfhip_adam_hyper(hyper.ptr, lr, beta1, beta2, eps, weight_decay, int(step),
+                                              grad_scale))
+
+    def adam_step_dev(self, params, grads, exp_avg, exp_avg_sq, hyper):
+        n = len(params)
+        sizes = (c_int64 * n)(*[p.size for p in params])
+        _lib.check(self._lib.dfhip_adam_step_dev(n, _ptr_table(params), _ptr_table(grads), _ptr_table(exp_avg),
+                                                 _ptr_table(exp_avg_sq), sizes, hyper.ptr))
 
     def sgd_step(self, params, grads, momentum_buf, lr, momentum, weight_decay, nesterov, grad_scale=1.0):
         n = len(params)

@@ -11,6 +11,7 @@ Every function keeps the reference's name and argument meaning.  Each has two bo
     window receives the gradient, and the conv input gradient is "last writer wins"
     (functional.py:285-294) unless the device is switched to conv_dgrad_mode="accumulate".
 """
+import os
 import numpy as np
 
 from .. import backend_api, tensor
@@ -25,6 +26,11 @@ def _fused(t):
 
 def _new(shape, device):
     return BackendTensor.make(tuple(int(s) for s in shape), device=device)
+
+
+# rows of the BatchNorm partials buffer a fused convolution may fill (one per workgroup)
+_BN_PARTIAL_ROWS = 512
+_CONV_BN_STATS = os.environ.get("DF_CONV_BN_STATS", "1") != "0"
 
 
 class _FusedNode(Tensor):
@@ -234,9 +240,20 @@ class _Conv2dFused(_FusedNode):
         self.geo = (N, C, H, W, O, k, int(stride), int(padding))
         self.xd, self.wd = x.data.compact(), w.data.compact()
         out = _new((N, O, oh, ow), x.device)
-        x.device.conv2d_forward(self.xd._handle, self.wd._handle,
-                                bias.data.compact()._handle if bias is not None else None,
-                                out._handle, *self.geo)
+        bh = bias.data.compact()._handle if bias is not None else None
+        # BatchNorm partials of the output, left behind by the convolution's epilogue: a
+        # BatchNorm2d that consumes this node skips its statistics pass (bn_partials = None when
+        # the shape was served by a kernel without that epilogue)
+        self.bn_partials = None
+        stats_fn = getattr(x.device.mod, "conv2d_forward_stats", None)
+        if stats_fn is not None and _CONV_BN_STATS and is_grad_enable():
+            part = _new((_BN_PARTIAL_ROWS, O, 3), x.device)
+            rows = stats_fn(self.xd._handle, self.wd._handle, bh, out._handle, *self.geo,
+                            part._handle, _BN_PARTIAL_ROWS)
+            if rows > 0:
+                self.bn_partials = (part, rows)
+        else:
+            x.device.conv2d_forward(self.xd._handle, self.wd._handle, bh, out._handle, *self.geo)
         super().__init__(out, [x, w, bias])
 
     def grad_fn(self, node, grad):
@@ -311,8 +328,12 @@ def avg_pool2d(x: Tensor, kernel_size: int, stride: int, padding=0):
 
 # ---- batch norm (used by nn.BatchNorm2d; the reference inlines it in batchnorm.py:30-55) ----------------
 class _BatchNorm2dFused(_FusedNode):
-    def __init__(self, x, weight, bias, running_mean, running_var, eps, momentum):
-        self.x, self.weight, self.bias = x, weight, bias
+    """Training-mode BatchNorm2d (+ optional residual add: y = bn(x) + residual, the tail of a
+    residual block).  When x is a convolution output that carries BatchNorm partials the
+    statistics come from those and x is read once."""
+
+    def __init__(self, x, weight, bias, running_mean, running_var, eps, momentum, residual=None):
+        self.x, self.weight, self.bias, self.residual = x, weight, bias, residual
         N, C, H, W = (int(v) for v in x.shape)
         self.geo = (N, C, H * W)
         self.eps = float(eps)
@@ -322,14 +343,23 @@ class _BatchNorm2dFused(_FusedNode):
         out = _new(x.shape, dev)
         self.mean, self.var = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
         h = lambda t: t._handle if t is not None else None
-        dev.bn2d_forward_train(self.xd._handle, h(self.wd),
-                               h(bias.data.compact()) if bias is not None else None, out._handle,
-                               self.mean._handle, self.var._handle,
-                               h(running_mean.data) if running_mean is not None else None,
-                               h(running_var.data) if running_var is not None else None,
-                               N, C, H * W, self.eps, float(momentum))
+        bh = h(bias.data.compact()) if bias is not None else None
+        rm = h(running_mean.data) if running_mean is not None else None
+        rv = h(running_var.data) if running_var is not None else None
+        partials = getattr(x, "bn_partials", None)
+        if partials is not None and hasattr(dev.mod, "bn2d_forward_partials"):
+            part, rows = partials
+            rd = residual.data.compact() if residual is not None else None
+            dev.bn2d_forward_partials(self.xd._handle, part._handle, rows, h(self.wd), bh, h(rd), out._handle,
+                                      self.mean._handle, self.var._handle, rm, rv, N, C, H * W, self.eps,
+                                      float(momentum))
+        else:
+            dev.bn2d_forward_train(self.xd._handle, h(self.wd), bh, out._handle, self.mean._handle,
+                                   self.var._handle, rm, rv, N, C, H * W, self.eps, float(momentum))
+            if residual is not None:
+                out = out + residual.data
         self._grads = None
-        super().__init__(out, [x, weight, bias])
+        super().__init__(out, [x, weight, bias, residual])
 
     def grad_fn(self, node, grad):
         if self._grads is None or self._grads[0] is not grad:
@@ -345,11 +375,13 @@ class _BatchNorm2dFused(_FusedNode):
         _, dx, dg, db = self._grads
         if node is self.x:
             return dx
+        if node is self.residual:
+            return grad
         return dg if node is self.weight else db
 
 
-def batch_norm2d_train(x, weight, bias, running_mean, running_var, eps, momentum):
-    return _BatchNorm2dFused(x, weight, bias, running_mean, running_var, eps, momentum)
+def batch_norm2d_train(x, weight, bias, running_mean, running_var, eps, momentum, residual=None):
+    return _BatchNorm2dFused(x, weight, bias, running_mean, running_var, eps, momentum, residual)
 
 
 class _BatchNorm2dEvalFused(_FusedNode):

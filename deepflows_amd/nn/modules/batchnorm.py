@@ -24,7 +24,14 @@ class BatchNorm2d(Module):
         self.running_mean = tensor.zeros(shape, **kw) if track_running_stats else None
         self.running_var = tensor.ones(shape, **kw) if track_running_stats else None
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, residual: Tensor = None) -> Tensor:
+        """`residual` (extension): returns bn(x) + residual; on a fused device in training mode the
+        add happens inside the normalisation kernel."""
+        if residual is not None:
+            if self.training and bool(getattr(x.device.mod, "fused", False)):
+                return F.batch_norm2d_train(x, self.weight, self.bias, self.running_mean,
+                                            self.running_var, self.eps, self.momentum, residual)
+            return self.forward(x) + residual
         fused = bool(getattr(x.device.mod, "fused", False))
         if self.training:
             if fused:

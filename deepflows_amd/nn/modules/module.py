@@ -26,8 +26,8 @@ class Module:
         object.__setattr__(self, '_modules', OrderedDict())
         object.__setattr__(self, 'device', None)
 
-    def __call__(self, *inputs):
-        return self.forward(*inputs)
+    def __call__(self, *inputs, **kwargs):
+        return self.forward(*inputs, **kwargs)
 
     def forward(self, *inputs):
         raise NotImplementedError(f"{type(self).__name__} has no forward()")

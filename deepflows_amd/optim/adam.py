@@ -19,8 +19,39 @@ class Adam(Optimizer):
         self.s = [backend_api.zeros_like(p.data) for p in self.params]
         self.t = 1
 
+    # ---- fused device ---------------------------------------------------------------------------
+    # device_hyper = True (set by graph_step.CapturedTrainStep): the scalars of the update live in a
+    # small device array that push_hyper() refreshes and apply() reads, so that apply() can sit in
+    # a captured hipGraph while the bias corrections keep advancing from the host.
+    device_hyper = False
+    _hyper = None
+
+    def push_hyper(self):
+        mod = self._fused_mod()
+        if self._hyper is None:
+            self._hyper = mod.Array(16)
+        mod.adam_hyper(self._hyper, self.lr, self.beta1, self.beta2, self.eps, self.weight_decay, self.t,
+                       self.grad_scale)
+
+    def apply(self):
+        """The in-place multi-tensor update with the scalars push_hyper() wrote (no host state)."""
+        mod = self._fused_mod()
+        live = [i for i, p in enumerate(self.params) if p.grad is not None]
+        if live:
+            for i in live:
+                self.params[i].data = self.params[i].data.compact()
+            mod.adam_step_dev([self.params[i].data._handle for i in live],
+                              [self.params[i].grad.compact()._handle for i in live],
+                              [self.v[i]._handle for i in live], [self.s[i]._handle for i in live],
+                              self._hyper)
+
     def step(self):
         mod = self._fused_mod()
+        if mod is not None and self.device_hyper:
+            self.push_hyper()
+            self.apply()
+            self.t += 1
+            return
         if mod is not None:
             live = [i for i, p in enumerate(self.params) if p.grad is not None]
             if live:

@@ -87,12 +87,12 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = self.bn1(self.conv1(x))
-        out = self.bn2(self.conv2(out))
         if self.downsample is not None:
             for layer in self.downsample:
                 identity = layer(identity)
-        return out + identity
+        out = self.bn1(self.conv1(x))
+        # bn2(...) + identity; one kernel on a fused device, the reference's "out + identity" otherwise
+        return self.bn2(self.conv2(out), residual=identity)
 
 
 class ResNet(nn.Module):

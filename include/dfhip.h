@@ -124,12 +124,30 @@ int dfhip_conv2d_forward(const float* x, const float* w, const float* bias, floa
 /* weight gradient: tensor.py:716 (A^T . dC) for the conv GEMM; dw (O,C,k,k)            */
 int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw,
                        int N, int C, int H, int W, int O, int k, int stride, int pad);
+/* conv2d_forward that also leaves BatchNorm partials of y behind: partials[rows][O][3] =
+ * (count, mean, centred second moment) of every output channel over the pixels of one workgroup
+ * (rows <= cap_rows).  *rows_out = 0 when the shape was served by a kernel without this epilogue;
+ * the caller then falls back to dfhip_bn2d_forward_train.  Fuses the first pass of
+ * nn/modules/batchnorm.py:36-42 (batch mean / variance) into nn/functional.py:conv2d. */
+int dfhip_conv2d_forward_stats(const float* x, const float* w, const float* bias, float* y, int N, int C,
+                               int H, int W, int O, int k, int stride, int pad, float* partials,
+                               int cap_rows, int* rows_out);
+
 /* input gradient: tensor.py:708 (dC . B^T) followed by __im2col2d.grad_fn
  * (nn/functional.py:285-294) and __pad2d.grad_fn (:307-313).
  * mode 0 = "overwrite": reference-exact last-writer-wins col2im (functional.py:292-293);
  * mode 1 = "accumulate": the mathematically correct sum over overlapping windows.      */
 int dfhip_conv2d_dgrad(const float* dy, const float* w, float* dx,
                        int N, int C, int H, int W, int O, int k, int stride, int pad, int mode);
+
+/* BatchNorm2d training forward from the partials of dfhip_conv2d_forward_stats (x is that
+ * convolution's output): statistics by Chan's combination of the partial rows, then
+ * y = (x - mean) / sqrt(var + eps) * gamma + beta (+ residual, the shortcut of a residual block:
+ * test/ResNet_CIFAR10_cuda.py BasicBlock.forward "out + shortcut(x)").  residual may be NULL. */
+int dfhip_bn2d_forward_partials(const float* x, const float* partials, int rows, const float* gamma,
+                                const float* beta, const float* residual, float* y, float* save_mean,
+                                float* save_var, float* running_mean, float* running_var, int N, int C,
+                                int HW, float eps, float momentum);
 
 /* BatchNorm2d training forward: nn/modules/batchnorm.py:30-55.  Biased variance; running
  * stats r = r*(1-momentum) + batch*momentum (both may be NULL).  save_mean / save_var
@@ -180,6 +198,17 @@ int dfhip_broadcast_axis(const float* src, float* dst, int64_t outer, int64_t re
                          int64_t inner, float scale);
 /* dst += alpha * src (gradient accumulation, tensor.py:486-493).                        */
 int dfhip_axpy(float* dst, const float* src, float alpha, int64_t n);
+
+/* Adam for a captured (hipGraph) training step: dfhip_adam_step with the ten fp32 scalars of the
+ * update (lr, beta1, beta2, 1-beta1, 1-beta2, 1-beta1^t, 1-beta2^t, eps, weight_decay, grad_scale;
+ * optim/adam.py:42-60) read from `hyper_dev` (>= 16 floats of device memory) instead of the kernel
+ * arguments, and the one-thread launch that writes them for step t.  The graph replays
+ * dfhip_adam_step_dev unchanged; the host calls dfhip_adam_hyper in front of every replay. */
+int dfhip_adam_hyper(float* hyper_dev, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, int step, double grad_scale);
+int dfhip_adam_step_dev(int n_tensors, float* const* params, const float* const* grads,
+                        float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
+                        const float* hyper_dev);
 
 /* Multi-tensor optimizer steps.  ptr tables are HOST arrays of device pointers, sizes in
  * elements.  grad_scale multiplies every gradient first (1/world for data parallel).

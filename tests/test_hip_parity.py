@@ -1,9 +1,11 @@
 """GPU parity tests (pytest -m gpu): the `hip` device — primitives and fused kernels, all
 called through the C ABI of libdfhip.so — against the golden vectors generated from the
 reference, with the same assertions the oracle passes on CPU."""
+import numpy as np
 import pytest
 
 import parity_cases as pc
+from conftest import assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -65,3 +67,86 @@ def test_cnn_two_adam_steps(hip_device):
 @pytest.mark.parametrize("mode", ["f6", "all"])
 def test_resnet18_one_adam_step(hip_device, mode):
     pc.check_resnet18(hip_device, mode)
+
+
+@pytest.mark.parametrize("shape", [(8, 32, 16, 16, 32, 3, 1, 1), (6, 32, 16, 16, 64, 3, 2, 1), (4, 64, 8, 8, 64, 3, 1, 1),
+                                   (16, 128, 4, 4, 128, 3, 1, 1), (32, 256, 2, 2, 256, 3, 1, 1), (5, 32, 16, 16, 64, 1, 2, 0),
+                                   (3, 16, 12, 12, 40, 3, 1, 1)])
+def test_conv_bn_partials_and_residual(hip_device, shape):
+    """conv2d -> BatchNorm2d(train) (+ residual): the statistics come from the partials the
+    convolution's epilogue leaves behind; checked against the NumPy restatement of
+    nn/modules/batchnorm.py:36-46 on the convolution output (oracle/ref_ops.py)."""
+    from oracle import ref_ops
+    from deepflows_amd import tensor
+    from deepflows_amd.nn import functional as F
+    N, C, H, W, O, k, s, p = shape
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((O, C, k, k)) * 0.2).astype(np.float32)
+    gamma = rng.standard_normal((1, O, 1, 1)).astype(np.float32)
+    beta = rng.standard_normal((1, O, 1, 1)).astype(np.float32)
+    y_ref = ref_ops.conv2d_forward(x, w, np.full(O, 0.75, np.float32), s, p)    # non-zero channel means
+    res = rng.standard_normal(y_ref.shape).astype(np.float32)
+    out_ref, mean_ref, var_ref = ref_ops.batchnorm2d_train(y_ref, gamma, beta, 1e-5)
+    dev = hip_device
+    mk = lambda a, rg=False: tensor.Tensor(a, device=dev, requires_grad=rg)
+    bias = mk(np.full((1, O, 1, 1), 0.75, np.float32))
+    xt, wt, gt, bt, rt = mk(x, True), mk(w, True), mk(gamma, True), mk(beta, True), mk(res, True)
+    rm, rv = mk(np.zeros((1, O, 1, 1), np.float32)), mk(np.ones((1, O, 1, 1), np.float32))
+    y = F.conv2d(xt, wt, padding=p, stride=s, bias=bias)
+    eligible = C % 8 == 0 and (H * W) % 4 == 0
+    if eligible:
+        assert y.bn_partials is not None, "the main forward kernel should leave partials behind"
+    for residual in (None, rt):
+        out = F.batch_norm2d_train(y, gt, bt, rm, rv, 1e-5, 0.1, residual)
+        want = out_ref if residual is None else out_ref + res
+        assert_close(out.numpy(), want, 1e-4, "bn(conv)")
+        assert_close(out.mean.numpy().reshape(-1), mean_ref.reshape(-1), 1e-4, "mean")
+        assert_close(out.var.numpy().reshape(-1), var_ref.reshape(-1), 1e-4, "var")
+    # backward through bn(+residual) and the convolution
+    g = rng.standard_normal(out_ref.shape).astype(np.float32)
+    (out * mk(g)).sum().backward()
+    dxh, dgam, dbet = ref_ops.batchnorm2d_backward(g, y_ref, gamma, mean_ref, var_ref, 1e-5)
+    assert_close(rt.grad.numpy(), g, 1e-6, "residual grad")
+    assert_close(gt.grad.numpy().reshape(-1), dgam.reshape(-1), 1e-4, "dgamma")
+    assert_close(bt.grad.numpy().reshape(-1), dbet.reshape(-1), 1e-4, "dbeta")
+    assert_close(wt.grad.numpy(), ref_ops.conv2d_wgrad(x, dxh, k, s, p), 2e-4, "dW")
+
+
+def test_captured_step_matches_eager_steps(hip_device):
+    """graph_step.CapturedTrainStep: 1 eager + 3 replayed Adam steps of ResNet-18 leave exactly
+    the parameters of 4 eager steps (same kernels in the same order)."""
+    import numpy as np
+    from deepflows_amd import nn, optim, tensor, workloads
+    from deepflows_amd.graph_step import CapturedTrainStep
+    from deepflows_amd.tensor import Graph
+
+    def run(captured):
+        np.random.seed(5)
+        model = workloads.ResNet18(device=hip_device, register_blocks=True)
+        opt = optim.Adam(workloads.all_block_parameters(model), lr=1e-3)
+        crit = nn.CrossEntropyLoss()
+        rng = np.random.default_rng(9)
+        x = tensor.Tensor(rng.standard_normal((8, 3, 32, 32)).astype(np.float32), device=hip_device)
+        y = tensor.Tensor(np.eye(10, dtype=np.float32)[rng.integers(0, 10, 8)], device=hip_device)
+        losses = []
+        loss, _ = workloads.train_step(model, crit, opt, x, y)
+        losses.append(float(loss.numpy().reshape(-1)[0]))
+        Graph.free_graph()
+        if captured:
+            cs = CapturedTrainStep(model, crit, opt, x, y)
+            for _ in range(3):
+                losses.append(float(cs.replay().numpy().reshape(-1)[0]))
+        else:
+            for _ in range(3):
+                loss, _ = workloads.train_step(model, crit, opt, x, y)
+                losses.append(float(loss.numpy().reshape(-1)[0]))
+                Graph.free_graph()
+        return losses, [p.numpy().copy() for p in opt.params], opt.t
+
+    l0, p0, t0 = run(False)
+    l1, p1, t1 = run(True)
+    assert t0 == t1 == 5
+    assert l0 == l1, (l0, l1)
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)
