@@ -1848,13 +1848,16 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, 
     int64_t jobs = (int64_t)gi * g.gr * dtiles;
     static int jobmul = getenv("DFHIP_JOBMUL") ? atoi(getenv("DFHIP_JOBMUL")) : 1;
     if (jobs < (int64_t)num_cus() * jobmul && pt > 1) continue;
+    static size_t lds_cap_single = (size_t)(getenv("DFHIP_LDS_SINGLE") ? atoi(getenv("DFHIP_LDS_SINGLE")) : 150) * 1024;
     auto fits = [&](int cc) {
       size_t wl = g.mode == 0 ? (size_t)32 * (cc * k2 + 4) : (size_t)cc * 32 * k2;
       size_t stage_b = 2 * ((size_t)cc * g.PE + wl) * 4;
       size_t red_b = (size_t)pt * (ksplit - 1) * 16 * 64 * 4;
       lds = std::max(stage_b, red_b);
       int pvecs = cc * g.PE / 4, wvecs = 8 * cc * k2;
-      return lds <= 76 * 1024 && pvecs <= 512 * kPV && wvecs <= 512 * kWV;
+      // two workgroups per CU only pay when there are more jobs than CUs; otherwise take the LDS
+      const size_t cap = jobs > (int64_t)num_cus() ? 76 * 1024 : lds_cap_single;
+      return lds <= cap && pvecs <= 512 * kPV && wvecs <= 512 * kWV;
     };
     static int maxchunks = getenv("DFHIP_MAXCHUNKS") ? atoi(getenv("DFHIP_MAXCHUNKS")) : 2;
     int c = std::max(8, 2 * ksplit);

@@ -383,7 +383,9 @@ int dfhip_fill(float* out, int64_t n, float val) {
 
 int dfhip_compact(const float* a, float* out, int64_t n_out, int ndim, const int64_t* shape,
                   const int64_t* strides, int64_t offset) {
-  DF_INIT();
+  DF_INIT_KEEP();          // gradients are compacted between two weight gradients of a backward pass
+  DF_TOUCH(a);
+  DF_TOUCH(out);
   View v;
   int s = make_view("compact", ndim, shape, strides, offset, n_out, &v);
   if (s != DFHIP_OK) return s;
