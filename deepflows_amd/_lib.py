@@ -47,6 +47,7 @@ _SIGS = {
     "dfhip_bn2d_forward_partials": [P, P, c_int] + [P] * 8 + [c_int, c_int, c_int, c_float, c_float],
     "dfhip_conv2d_wgrad": [P, P, P] + [c_int] * 8,
     "dfhip_conv2d_dgrad": [P, P, P] + [c_int] * 9,
+    "dfhip_conv2d_dgrad_add": [P, P, P, P] + [c_int] * 9,
     "dfhip_bn2d_forward_train": [P] * 8 + [c_int, c_int, c_int, c_float, c_float],
     "dfhip_bn2d_forward_eval": [P] * 6 + [c_int, c_int, c_int, c_float],
     "dfhip_bn2d_backward": [P] * 8 + [c_int, c_int, c_int, c_float],

@@ -72,6 +72,7 @@ struct Geo {
   // centred second moment) over the workgroup's pixels, or null
   float* stats;
   int vec_store;   // 1: destination pixels of a tile are contiguous and 16-byte aligned in runs of 4
+  const float* addsrc;   // dgrad: tensor of the destination's shape added to the result (gradient accumulation), or null
 };
 
 __device__ __forceinline__ void decode_pixel(const Geo& g, int q, int& img, int& r, int& col) {
@@ -510,19 +511,25 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
         const int rr_ = (int)fast_div((unsigned)rem, g.m_bc), cc_ = rem - rr_ * g.BC;
         const bool ok = qq < g.BI * g.BR * g.BC && n0 + im < g.N && r0 + rr_ < g.HD && d0 + o < g.CD;
         if (ok) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(Tt + o * TS + 4 * q4);
-          *reinterpret_cast<f32x4*>(g.dst + ((int64_t)(n0 + im) * g.CD + d0 + o) * dplane + (int64_t)(r0 + rr_) * g.WD + cc_) = v;
+          f32x4 v = *reinterpret_cast<const f32x4*>(Tt + o * TS + 4 * q4);
+          const int64_t at = ((int64_t)(n0 + im) * g.CD + d0 + o) * dplane + (int64_t)(r0 + rr_) * g.WD + cc_;
+          if (g.addsrc) v += *reinterpret_cast<const f32x4*>(g.addsrc + at);
+          *reinterpret_cast<f32x4*>(g.dst + at) = v;
         }
       }
     }
   }
   if (ks == 0 && !vec_ok && pvalid) {
     const int64_t dplane = (int64_t)g.HD * g.WD;
-    float* out = g.dst + (int64_t)(n0 + img) * g.CD * dplane + (int64_t)(r0 + r) * g.WD + col;
+    const int64_t at0 = (int64_t)(n0 + img) * g.CD * dplane + (int64_t)(r0 + r) * g.WD + col;
 #pragma unroll
     for (int rr = 0; rr < 16; rr++) {
       int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-      if (d < g.CD) out[(int64_t)d * dplane] = acc[rr];
+      if (d < g.CD) {
+        float v = acc[rr];
+        if (g.addsrc) v += g.addsrc[at0 + (int64_t)d * dplane];
+        g.dst[at0 + (int64_t)d * dplane] = v;
+      }
     }
   }
   if (want_stats) {
@@ -1446,6 +1453,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
 #define RG_STAMP() do { } while (0)
 #endif
   RG_STAMP();
+  if (g.dbg == 2) return;                     // diagnostics: launch + teardown cost of this configuration
   const int c0 = blockIdx.y * 32, o0 = blockIdx.z * 32;
   const int cn = min(32, g.C - c0), on = min(32, g.O - o0);
   const int RL = g.RLr * W;                   // staged floats per (image, channel)
@@ -2453,19 +2461,15 @@ int dfhip_conv2d_forward_stats(const float* x, const float* w, const float* bias
   return conv2d_forward_impl(x, w, bias, y, N, C, H, W, O, k, stride, pad, partials, cap_rows, rows_out);
 }
 
-int dfhip_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int H, int W,
-                       int O, int k, int stride, int pad, int mode) {
-  DF_INIT_KEEP();          // sits between two weight gradients of a backward pass
-  DF_TOUCH(dy);
-  DF_TOUCH(w);
-  DF_TOUCH(dx);
+static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, float* dx, int N, int C, int H,
+                             int W, int O, int k, int stride, int pad, int mode) {
   int oh, ow;
   int s = check_conv_args("conv2d_dgrad", N, C, H, W, O, k, stride, pad, oh, ow);
   if (s != DFHIP_OK) return s;
   DF_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null array");
   DF_CHECK_ARG(mode == 0 || mode == 1, "conv2d_dgrad: mode must be 0 (overwrite) or 1 (accumulate)");
   double flops = 2.0 * N * oh * ow * (double)C * k * k * O;
-  double bytes = 4.0 * ((double)N * C * H * W + (double)O * C * k * k + (double)N * O * oh * ow);
+  double bytes = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * k * k + (double)N * O * oh * ow);
   ProfScope prof(mode == 0 ? "conv2d_dgrad_overwrite_igemm" : "conv2d_dgrad_igemm", flops, bytes);
   Geo g = {};
   g.src = dy; g.wgt = w;
@@ -2473,7 +2477,38 @@ int dfhip_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C,
   g.CD = C; g.HD = H; g.WD = W;
   g.k = k; g.so = 1; g.sd = stride; g.u0 = pad - (k - 1);
   g.mode = mode == 0 ? 2 : 1; g.wC = C; g.pad = pad; g.stride = stride; g.oh = oh; g.ow = ow;
+  if (add) {
+    g.addsrc = add;
+    int st = run_igemm_v4(g, C, dx, nullptr);
+    if (st >= 0) return st;
+    g.addsrc = nullptr;                      // the generic kernel has no such epilogue: add afterwards
+    st = run_igemm(g, C, dx, nullptr);
+    if (st != DFHIP_OK) return st;
+    return dfhip_ewise_add(dx, add, dx, (int64_t)N * C * H * W);
+  }
   return run_igemm(g, C, dx, nullptr);
+}
+
+int dfhip_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int H, int W,
+                       int O, int k, int stride, int pad, int mode) {
+  DF_INIT_KEEP();          // sits between two weight gradients of a backward pass
+  DF_TOUCH(dy);
+  DF_TOUCH(w);
+  DF_TOUCH(dx);
+  return conv2d_dgrad_impl(dy, w, nullptr, dx, N, C, H, W, O, k, stride, pad, mode);
+}
+
+// dx = conv2d_dgrad(dy, w) + add: the gradient accumulation of a tensor with two consumers
+// (tensor.py:444 "parent.grad + contrib") done in the epilogue of the input-gradient kernel
+int dfhip_conv2d_dgrad_add(const float* dy, const float* w, const float* add, float* dx, int N, int C,
+                           int H, int W, int O, int k, int stride, int pad, int mode) {
+  DF_INIT_KEEP();
+  DF_TOUCH(dy);
+  DF_TOUCH(w);
+  DF_TOUCH(add);
+  DF_TOUCH(dx);
+  DF_CHECK_ARG(add, "conv2d_dgrad_add: null addend");
+  return conv2d_dgrad_impl(dy, w, add, dx, N, C, H, W, O, k, stride, pad, mode);
 }
 
 int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W,

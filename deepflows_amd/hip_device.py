@@ -223,6 +223,12 @@ class HipModule:
         m = {"overwrite": 0, "accumulate": 1}[mode]
         _lib.check(self._lib.dfhip_conv2d_dgrad(dy.ptr, w.ptr, dx.ptr, N, C, H, W, O, k, stride, pad, m))
 
+    def conv2d_dgrad_add(self, dy, w, add, dx, N, C, H, W, O, k, stride, pad, mode=None):
+        """dx = conv2d_dgrad(dy, w) + add (gradient accumulation in the kernel's epilogue)."""
+        mode = self.conv_dgrad_mode if mode is None else mode
+        m = {"overwrite": 0, "accumulate": 1}[mode]
+        _lib.check(self._lib.dfhip_conv2d_dgrad_add(dy.ptr, w.ptr, add.ptr, dx.ptr, N, C, H, W, O, k, stride, pad, m))
+
     def bn2d_forward_train(self, x, gamma, beta, y, save_mean, save_var, running_mean, running_var,
                            N, C, HW, eps, momentum):
         g = lambda h: h.ptr if h is not None else None

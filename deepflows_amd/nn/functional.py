@@ -256,12 +256,20 @@ class _Conv2dFused(_FusedNode):
             x.device.conv2d_forward(self.xd._handle, self.wd._handle, bh, out._handle, *self.geo)
         super().__init__(out, [x, w, bias])
 
-    def grad_fn(self, node, grad):
+    # the engine may hand over the gradient the input already holds (tensor.py backward): the sum
+    # is then formed in the epilogue of the input-gradient kernel
+    fuses_accumulation = True
+
+    def grad_fn(self, node, grad, accumulated=None):
         g = grad.compact()
         dev = g.device
         if node is self.x:
             out = _new(self.xd.shape, dev)
-            dev.conv2d_dgrad(g._handle, self.wd._handle, out._handle, *self.geo)
+            if accumulated is not None:
+                dev.conv2d_dgrad_add(g._handle, self.wd._handle, accumulated.compact()._handle, out._handle,
+                                     *self.geo)
+            else:
+                dev.conv2d_dgrad(g._handle, self.wd._handle, out._handle, *self.geo)
             return out
         if node is self.w:
             out = _new(self.wd.shape, dev)

@@ -214,6 +214,12 @@ class Tensor:
                 if isinstance(grad, Tensor):
                     grad = grad.data
                 for parent in [p for p in node.parents if p.requires_grad]:
+                    held = parent.grad
+                    if (held is not None and getattr(node, "fuses_accumulation", False)
+                            and node.x is parent and hasattr(held.device.mod, "conv2d_dgrad_add")):
+                        # a fused node adds the gradient the parent already holds in its own kernel
+                        parent.grad = node.grad_fn(parent, grad, held)
+                        continue
                     contrib = node.grad_fn(parent, grad)
                     if isinstance(contrib, Tensor):
                         contrib = contrib.data

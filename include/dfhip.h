@@ -121,6 +121,12 @@ int dfhip_gemm(const float* a, const float* b, const float* bias, float* out,
  * (bias (1,O,1,1), may be NULL).  x (N,C,H,W), w (O,C,k,k), y (N,O,oh,ow), all NCHW.  */
 int dfhip_conv2d_forward(const float* x, const float* w, const float* bias, float* y,
                          int N, int C, int H, int W, int O, int k, int stride, int pad);
+/* dx = dfhip_conv2d_dgrad(dy, w) + add (add has dx's shape): the autograd accumulation
+ * "parent.grad + contrib" (tensor.py:444) of a tensor with two consumers, e.g. the input of a
+ * residual block, done in the epilogue of the input-gradient kernel instead of a separate pass. */
+int dfhip_conv2d_dgrad_add(const float* dy, const float* w, const float* add, float* dx, int N, int C,
+                           int H, int W, int O, int k, int stride, int pad, int mode);
+
 /* weight gradient: tensor.py:716 (A^T . dC) for the conv GEMM; dw (O,C,k,k)            */
 int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw,
                        int N, int C, int H, int W, int O, int k, int stride, int pad);
