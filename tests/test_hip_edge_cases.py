@@ -134,3 +134,54 @@ def test_split_k_gemm_long_reduction(hip_device):
     mod.gemm(_arr(mod, A), _arr(mod, D), None, out, 27, 65536, 32, True, False)
     want = A.astype(np.float64).T @ D.astype(np.float64)
     assert np.abs(_back(mod, out).reshape(27, 32) - want).max() <= 1e-4 * np.abs(want).max()
+
+
+def test_deferred_slab_sum_is_invisible(hip_device):
+    """The slab sum of a weight gradient is deferred onto the next weight-gradient launch; every
+    way of looking at dW in between must still see the finished gradient."""
+    from oracle import ref_ops
+    mod = hip_device.mod
+    rng = np.random.default_rng(21)
+    shapes = [(8, 32, 16, 16, 32, 3, 1, 1), (8, 64, 8, 8, 64, 3, 1, 1), (8, 32, 16, 16, 64, 1, 2, 0)]
+    want, arrs = [], []
+    for (N, C, H, W, O, k, s, p) in shapes:
+        oh = (H + 2 * p - k) // s + 1
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        dy = rng.standard_normal((N, O, oh, oh)).astype(np.float32)
+        want.append(ref_ops.conv2d_wgrad(x, dy, k, s, p))
+        arrs.append((_arr(mod, x), _arr(mod, dy), mod.Array(O * C * k * k), (N, C, H, W, O, k, s, p)))
+    # back to back (each launch takes the previous sum along), then read in reverse order
+    for xa, da, dw, geo in arrs:
+        mod.conv2d_wgrad(xa, da, dw, *geo)
+    for (xa, da, dw, geo), w in reversed(list(zip(arrs, want))):
+        got = _back(mod, dw).reshape(w.shape)
+        assert np.abs(got - w).max() <= 2e-4 * np.abs(w).max()
+    # a consumer on the device right after the launch (ewise on dW), and free + reuse of dW
+    xa, da, dw, geo = arrs[0]
+    mod.conv2d_wgrad(xa, da, dw, *geo)
+    out = mod.Array(dw.size)
+    mod.scalar_mul(dw, 2.0, out)
+    assert np.abs(_back(mod, out).reshape(want[0].shape) - 2 * want[0]).max() <= 4e-4 * np.abs(want[0]).max()
+    mod.conv2d_wgrad(xa, da, dw, *geo)
+    del dw
+    z = mod.Array(want[0].size)
+    mod.fill(z, 0.0)
+    assert not _back(mod, z).any()
+
+
+def test_dgrad_add_epilogue(hip_device):
+    from oracle import ref_ops
+    mod = hip_device.mod
+    rng = np.random.default_rng(22)
+    for (N, C, H, W, O, k, s, p) in [(8, 32, 16, 16, 32, 3, 1, 1), (6, 64, 8, 8, 128, 3, 2, 1), (4, 3, 12, 12, 8, 3, 1, 1),
+                                     (5, 32, 16, 16, 64, 1, 2, 0)]:
+        oh = (H + 2 * p - k) // s + 1
+        dy = rng.standard_normal((N, O, oh, oh)).astype(np.float32)
+        w = rng.standard_normal((O, C, k, k)).astype(np.float32)
+        add = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        for mode in ("overwrite", "accumulate"):
+            want = ref_ops.conv2d_dgrad(dy, w, (N, C, H, W), s, p, mode) + add
+            dx = mod.Array(add.size)
+            mod.conv2d_dgrad_add(_arr(mod, dy), _arr(mod, w), _arr(mod, add), dx, N, C, H, W, O, k, s, p, mode=mode)
+            got = _back(mod, dx).reshape(want.shape)
+            assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), (N, C, H, W, O, k, s, p, mode)
