@@ -198,6 +198,21 @@ def main():
                             "unit": "GB/s", "frac": d["gbs"] / PEAK_HBM_GBS, "traffic": None}
             roofline["avg_launch_us"] = d["avg_us"]
             roofline["launches_per_step"] = d["calls_per_step"]
+            # HBM bytes per launch of that family from the committed PMC passes (rocprofv3 --pmc
+            # FETCH_SIZE / WRITE_SIZE on this same command, FETCH_SIZE x2 per the gfx950 note);
+            # counters cannot be read from inside this process, so the number is the one on file
+            try:
+                import json as _json
+                pmc = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                                   "r01c_pmc_traffic.json")))
+                fam = pmc["families"].get(dom)
+                if fam:
+                    roofline["traffic"] = fam["hbm_bytes_per_step"] / d["calls_per_step"]
+                    roofline["traffic_source"] = "profiles/r01c_pmc_traffic.json"
+            except Exception:
+                pass
+            roofline["algorithmic_bytes_per_launch"] = prof[dom]["bytes"] / prof[dom]["calls"]
+            roofline["algorithmic_flops_per_launch"] = prof[dom]["flops"] / prof[dom]["calls"]
         out = {
             "metric": "training-step images/sec, ResNet-18 CIFAR-10 bs=256",
             "value": value, "unit": "images/s", "n_gpus": comm.world, "steps": args.steps,

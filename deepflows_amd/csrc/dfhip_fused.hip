@@ -901,7 +901,7 @@ int dfhip_bn2d_forward_train(const float* x, const float* gamma, const float* be
   }
   int S, ipb;
   bn_split(N, C, S, ipb);
-  float* partial = workspace((size_t)C * S * 3 * sizeof(float));
+  float* partial = workspace_small((size_t)C * S * 3 * sizeof(float));
   if (!partial) return DFHIP_OUT_OF_MEMORY;
   dim3 grid((unsigned)C, (unsigned)S);
   hipLaunchKernelGGL(k_bn_stats, grid, dim3(kThreads), 0, stream(), x, partial, N, C, HW, S, ipb);
@@ -968,7 +968,7 @@ int dfhip_bn2d_backward(const float* dy, const float* x, const float* gamma, con
   }
   int S, ipb;
   bn_split(N, C, S, ipb);
-  float* partial = workspace((size_t)C * S * 2 * sizeof(float));
+  float* partial = workspace_small((size_t)C * S * 2 * sizeof(float));
   if (!partial) return DFHIP_OUT_OF_MEMORY;
   dim3 grid((unsigned)C, (unsigned)S);
   hipLaunchKernelGGL(k_bn_bwd_stats, grid, dim3(kThreads), 0, stream(), dy, x, save_mean, save_var,
@@ -1042,7 +1042,7 @@ int dfhip_softmax_ce_forward(const float* logits, const float* target, float* lo
   DF_INIT();
   DF_CHECK_ARG(rows > 0 && cols > 0, "softmax_ce: non-positive dimension");
   DF_CHECK_ARG(logits && target && loss, "softmax_ce: null array");
-  float* row_loss = workspace((size_t)rows * sizeof(float));
+  float* row_loss = workspace_small((size_t)rows * sizeof(float));
   if (!row_loss) return DFHIP_OUT_OF_MEMORY;
   ProfScope prof("softmax_ce_fwd", 0.0, 8.0 * (double)rows * cols);
   hipLaunchKernelGGL(k_ce_rows, dim3(grid_for((int64_t)rows * 64)), dim3(kThreads), 0, stream(), logits,

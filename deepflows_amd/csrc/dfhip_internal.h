@@ -29,6 +29,8 @@ float* workspace(size_t bytes);
 // second, independent scratch area (for kernels that need two live scratch buffers)
 float* workspace2(size_t bytes);
 float* workspace_slot(int slot, size_t bytes);
+// third area for small per-channel partials (never holds deferred slabs, so using it flushes nothing)
+float* workspace_small(size_t bytes);
 
 // Deferred work: the slab sum of a weight gradient rides on the NEXT weight-gradient launch (its
 // blocks add the slabs while their own first loads are in flight).  Every C entry point flushes it

@@ -164,7 +164,7 @@ struct ScratchSlot {
   void* p = nullptr;
   size_t bytes = 0;
 };
-static ScratchSlot g_ws[2];
+static ScratchSlot g_ws[3];
 static float* scratch(int i, size_t bytes) {
   // A scratch area is simply a pool block that is returned to the pool as soon as a
   // bigger one is needed; stream order makes the hand-over safe.
@@ -189,6 +189,7 @@ static float* scratch(int i, size_t bytes) {
 float* workspace(size_t bytes) { return scratch(0, bytes); }
 float* workspace2(size_t bytes) { return scratch(1, bytes); }
 float* workspace_slot(int slot, size_t bytes) { return scratch(slot & 1, bytes); }
+float* workspace_small(size_t bytes) { return scratch(2, bytes); }
 
 // ---------------------------------------------------------------------------------------
 // profiling: HIP events around kernel families on the library stream
