@@ -9,6 +9,7 @@
 // parallel mean/M2 combination for the batch statistics (one pass over HBM, no E[x^2]-E[x]^2
 // cancellation).
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -278,35 +279,35 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
     const float* __restrict__ beta, const float* __restrict__ residual, float* __restrict__ y,
     float* __restrict__ save_mean, float* __restrict__ save_var, float* __restrict__ running_mean,
     float* __restrict__ running_var, int N, int C, int HW, int ipb, float eps, float momentum) {
-  __shared__ float sn[kThreads], sm[kThreads], sq[kThreads];
+  __shared__ float sw[4][3];
   const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  // Chan's update: (n, mu, m2) <- (n, mu, m2) (+) (nb, mub, m2b); rows per thread, then a shuffle
+  // tree inside the wave, then the four waves in order (the same sequence in every block)
+  auto chan = [](float& n, float& mu, float& m2, float nb, float mub, float m2b) {
+    if (nb > 0.0f) {
+      const float nn = n + nb, delta = mub - mu;
+      mu += delta * (nb / nn);
+      m2 += m2b + delta * delta * (n * nb / nn);
+      n = nn;
+    }
+  };
   float n = 0.0f, mu = 0.0f, m2 = 0.0f;
   for (int r = tid; r < rows; r += kThreads) {
     const float* p = partials + ((int64_t)r * C + c) * 3;
-    const float nb = p[0];
-    if (nb > 0.0f) {
-      const float nn = n + nb, delta = p[1] - mu;
-      mu += delta * (nb / nn);
-      m2 += p[2] + delta * delta * (n * nb / nn);
-      n = nn;
-    }
+    chan(n, mu, m2, p[0], p[1], p[2]);
   }
-  sn[tid] = n; sm[tid] = mu; sq[tid] = m2;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_down(n, o, 64), mub = __shfl_down(mu, o, 64), m2b = __shfl_down(m2, o, 64);
+    chan(n, mu, m2, nb, mub, m2b);
+  }
+  if ((tid & 63) == 0) { sw[tid >> 6][0] = n; sw[tid >> 6][1] = mu; sw[tid >> 6][2] = m2; }
   __syncthreads();
-  for (int stp = kThreads / 2; stp >= 1; stp >>= 1) {
-    if (tid < stp) {
-      const float nb = sn[tid + stp];
-      if (nb > 0.0f) {
-        const float na = sn[tid], nn = na + nb, delta = sm[tid + stp] - sm[tid];
-        sm[tid] += delta * (nb / nn);
-        sq[tid] += sq[tid + stp] + delta * delta * (na * nb / nn);
-        sn[tid] = nn;
-      }
-    }
-    __syncthreads();
-  }
-  const float mean = sm[0];
-  const float var = sn[0] > 0.0f ? sq[0] / sn[0] : 0.0f;   // biased variance (batchnorm.py:41-42)
+  n = sw[0][0]; mu = sw[0][1]; m2 = sw[0][2];
+#pragma unroll
+  for (int w4 = 1; w4 < 4; w4++) chan(n, mu, m2, sw[w4][0], sw[w4][1], sw[w4][2]);
+  const float mean = mu;
+  const float var = n > 0.0f ? m2 / n : 0.0f;   // biased variance (batchnorm.py:41-42)
   if (s == 0 && tid == 0) {
     if (save_mean) save_mean[c] = mean;
     if (save_var) save_var[c] = var;
