@@ -51,6 +51,8 @@ _SIGS = {
     "dfhip_bn2d_forward_train": [P] * 8 + [c_int, c_int, c_int, c_float, c_float],
     "dfhip_bn2d_forward_eval": [P] * 6 + [c_int, c_int, c_int, c_float],
     "dfhip_bn2d_backward": [P] * 8 + [c_int, c_int, c_int, c_float],
+    "dfhip_bn_relu_maxpool2_forward": [P] * 8 + [c_int] * 4 + [c_float, c_float],
+    "dfhip_bn_relu_maxpool2_backward": [P] * 10 + [c_int] * 4 + [c_float],
     "dfhip_maxpool2d_forward": [P, P, c_int, c_int, c_int, c_int],
     "dfhip_maxpool2d_backward": [P, P, P, P, c_int, c_int, c_int, c_int],
     "dfhip_relu_forward": [P, P, c_int64],

@@ -342,6 +342,146 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
   });
 }
 
+// ---- BatchNorm2d -> ReLU -> MaxPool2d(2) as one forward kernel and one backward pair --------------
+// (the stem of the CIFAR models: the largest activation of the network goes through three
+// element-wise passes forward and three backward in the reference).  Forward reads the convolution
+// output once and writes only the pooled tensor; backward recomputes bn / relu from the convolution
+// output with the SAME rounded operations (no fma contraction), so the reference's equality tests
+//   max-pool: every element equal to the window maximum gets the gradient (tensor.py:779-791)
+//   relu:     gradient passes where output == input                        (tensor.py:872-877)
+// see the values the forward produced.  Block (c, s) owns images [s*ipb, (s+1)*ipb) of channel c;
+// a thread item is a 2 x 8 input patch = 4 pooled outputs.  W % 8 == 0, H % 2 == 0.
+__device__ __forceinline__ float bn_point(float v, float mean, float sd, float w, float b) {
+  return __fadd_rn(__fmul_rn(__fdiv_rn(__fsub_rn(v, mean), sd), w), b);
+}
+__device__ __forceinline__ float relu_point(float a) { return (a != a) ? a : (a > 0.0f ? a : 0.0f); }
+__device__ __forceinline__ float max_nan(float m, float v) { return (m != m) ? m : ((v != v) ? v : (v > m ? v : m)); }
+
+__global__ __launch_bounds__(kThreads) void k_bn_relu_pool_fwd(
+    const float* __restrict__ x, const float* __restrict__ partial, int S, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ save_mean,
+    float* __restrict__ save_var, float* __restrict__ running_mean, float* __restrict__ running_var, int N,
+    int C, int H, int W, int ipb, float eps, float momentum) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  float mean, var;
+  bn_combine(partial, c, S, mean, var);
+  if (s == 0 && threadIdx.x == 0) {
+    if (save_mean) save_mean[c] = mean;
+    if (save_var) save_var[c] = var;
+    if (running_mean) running_mean[c] = running_mean[c] * (1.0f - momentum) + mean * momentum;
+    if (running_var) running_var[c] = running_var[c] * (1.0f - momentum) + var * momentum;
+  }
+  const float sd = sqrtf(var + eps);
+  const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+  const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
+  const int oh = H >> 1, ow = W >> 1, ow4 = ow >> 2;
+  const int items = (n_hi - n_lo) * oh * ow4;
+  for (int e = threadIdx.x; e < items; e += kThreads) {
+    const int q = e % ow4;
+    const int t = e / ow4;
+    const int oy = t % oh, img = n_lo + t / oh;
+    const float* p = x + (((int64_t)img * C + c) * H + 2 * oy) * W + 8 * q;
+    const float4 a0 = *reinterpret_cast<const float4*>(p), a1 = *reinterpret_cast<const float4*>(p + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(p + W), b1 = *reinterpret_cast<const float4*>(p + W + 4);
+    const float r0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float r1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float m = relu_point(bn_point(r0[2 * j], mean, sd, w, b));
+      m = max_nan(m, relu_point(bn_point(r0[2 * j + 1], mean, sd, w, b)));
+      m = max_nan(m, relu_point(bn_point(r1[2 * j], mean, sd, w, b)));
+      m = max_nan(m, relu_point(bn_point(r1[2 * j + 1], mean, sd, w, b)));
+      o[j] = m;
+    }
+    *reinterpret_cast<float4*>(y + (((int64_t)img * C + c) * oh + oy) * ow + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// gradient that reaches the BatchNorm output at one input position
+__device__ __forceinline__ float stem_dy(float v, float pooled, float g, float mean, float sd, float w, float b) {
+  const float bo = bn_point(v, mean, sd, w, b);
+  const float r = relu_point(bo);
+  const float gp = (pooled == r ? 1.0f : 0.0f) * g;
+  return (r == bo ? 1.0f : 0.0f) * gp;
+}
+
+template <bool APPLY>
+__global__ __launch_bounds__(kThreads) void k_bn_relu_pool_bwd(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ save_mean,
+    const float* __restrict__ save_var, float* __restrict__ partial, float* __restrict__ dx,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, int H, int W, int S, int ipb, float eps) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const float mean = save_mean[c], sd = sqrtf(save_var[c] + eps);
+  const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+  float k1 = 0.0f, k2 = 0.0f;
+  if (APPLY) {
+    float sdy = 0.0f, sdyx = 0.0f;
+    for (int i = 0; i < S; i++) {
+      sdy += partial[((int64_t)c * S + i) * 2];
+      sdyx += partial[((int64_t)c * S + i) * 2 + 1];
+    }
+    if (s == 0 && threadIdx.x == 0) {
+      if (dgamma) dgamma[c] = sdyx;
+      if (dbeta) dbeta[c] = sdy;
+    }
+    if (!dx) return;
+    const float m = (float)N * (float)H * (float)W;
+    k1 = sdy / m;
+    k2 = sdyx / m;
+  }
+  const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
+  const int oh = H >> 1, ow = W >> 1, ow4 = ow >> 2;
+  const int items = (n_hi - n_lo) * oh * ow4;
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int e = threadIdx.x; e < items; e += kThreads) {
+    const int q = e % ow4;
+    const int t = e / ow4;
+    const int oy = t % oh, img = n_lo + t / oh;
+    const int64_t at = (((int64_t)img * C + c) * H + 2 * oy) * W + 8 * q;
+    const float* p = x + at;
+    const float4 a0 = *reinterpret_cast<const float4*>(p), a1 = *reinterpret_cast<const float4*>(p + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(p + W), b1 = *reinterpret_cast<const float4*>(p + W + 4);
+    const int64_t ao = (((int64_t)img * C + c) * oh + oy) * ow + 4 * q;
+    const float4 yv = *reinterpret_cast<const float4*>(y + ao), gv = *reinterpret_cast<const float4*>(g + ao);
+    const float r0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float r1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+    float d0[8], d1[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float dy0 = stem_dy(r0[j], yy[j >> 1], gg[j >> 1], mean, sd, w, b);
+      const float dy1 = stem_dy(r1[j], yy[j >> 1], gg[j >> 1], mean, sd, w, b);
+      const float xh0 = (r0[j] - mean) / sd, xh1 = (r1[j] - mean) / sd;
+      if (APPLY) {
+        d0[j] = (dy0 - k1 - xh0 * k2) * w / sd;
+        d1[j] = (dy1 - k1 - xh1 * k2) * w / sd;
+      } else {
+        s1 += dy0 + dy1;
+        s2 += dy0 * xh0 + dy1 * xh1;
+      }
+    }
+    if (APPLY) {
+      float* q0 = dx + at;
+      *reinterpret_cast<float4*>(q0) = make_float4(d0[0], d0[1], d0[2], d0[3]);
+      *reinterpret_cast<float4*>(q0 + 4) = make_float4(d0[4], d0[5], d0[6], d0[7]);
+      *reinterpret_cast<float4*>(q0 + W) = make_float4(d1[0], d1[1], d1[2], d1[3]);
+      *reinterpret_cast<float4*>(q0 + W + 4) = make_float4(d1[4], d1[5], d1[6], d1[7]);
+    }
+  }
+  if (!APPLY) {
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) {
+      float* o = partial + ((int64_t)c * S + s) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
+  }
+}
+
 // ---- single-launch BatchNorm for channels of at most 16 384 elements (N*HW) ------------------
 // One 512-thread workgroup owns a channel and keeps its elements in registers (<= 8 float4 per
 // thread): x is read from HBM once (8 B per element instead of 12), mean and the centred second
@@ -977,6 +1117,53 @@ int dfhip_bn2d_backward(const float* dy, const float* x, const float* gamma, con
   DF_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bn_bwd_apply, grid, dim3(kThreads), 0, stream(), dy, x, gamma, save_mean,
                      save_var, partial, dx, dgamma, dbeta, N, C, HW, S, ipb, eps);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+int dfhip_bn_relu_maxpool2_forward(const float* x, const float* gamma, const float* beta, float* y,
+                                   float* save_mean, float* save_var, float* running_mean,
+                                   float* running_var, int N, int C, int H, int W, float eps, float momentum) {
+  DF_INIT();
+  DF_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 7) == 0,
+               "bn_relu_maxpool2_forward: needs H even and W a multiple of 8");
+  DF_CHECK_ARG(x && y && save_mean && save_var, "bn_relu_maxpool2_forward: null array");
+  const int HW = H * W;
+  ProfScope prof("bn_relu_pool_fwd", 0.0, (12.0 + 1.0) * (double)N * C * HW);
+  int S, ipb;
+  bn_split(N, C, S, ipb);
+  float* partial = workspace_small((size_t)C * S * 3 * sizeof(float));
+  if (!partial) return DFHIP_OUT_OF_MEMORY;
+  dim3 grid((unsigned)C, (unsigned)S);
+  hipLaunchKernelGGL(k_bn_stats, grid, dim3(kThreads), 0, stream(), x, partial, N, C, HW, S, ipb);
+  DF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bn_relu_pool_fwd, grid, dim3(kThreads), 0, stream(), x, partial, S, gamma, beta, y, save_mean,
+                     save_var, running_mean, running_var, N, C, H, W, ipb, eps, momentum);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+int dfhip_bn_relu_maxpool2_backward(const float* x, const float* y, const float* g, const float* gamma,
+                                    const float* beta, const float* save_mean, const float* save_var,
+                                    float* dx, float* dgamma, float* dbeta, int N, int C, int H, int W,
+                                    float eps) {
+  DF_INIT_KEEP();
+  DF_TOUCH(x); DF_TOUCH(y); DF_TOUCH(g); DF_TOUCH(gamma); DF_TOUCH(beta); DF_TOUCH(save_mean); DF_TOUCH(save_var);
+  DF_TOUCH(dx); DF_TOUCH(dgamma); DF_TOUCH(dbeta);
+  DF_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 7) == 0,
+               "bn_relu_maxpool2_backward: needs H even and W a multiple of 8");
+  DF_CHECK_ARG(x && y && g && save_mean && save_var, "bn_relu_maxpool2_backward: null array");
+  ProfScope prof("bn_relu_pool_bwd", 0.0, (12.0 + 4.0) * (double)N * C * H * W);
+  int S, ipb;
+  bn_split(N, C, S, ipb);
+  float* partial = workspace_small((size_t)C * S * 2 * sizeof(float));
+  if (!partial) return DFHIP_OUT_OF_MEMORY;
+  dim3 grid((unsigned)C, (unsigned)S);
+  hipLaunchKernelGGL((k_bn_relu_pool_bwd<false>), grid, dim3(kThreads), 0, stream(), x, y, g, gamma, beta, save_mean,
+                     save_var, partial, dx, dgamma, dbeta, N, C, H, W, S, ipb, eps);
+  DF_LAUNCH_CHECK();
+  hipLaunchKernelGGL((k_bn_relu_pool_bwd<true>), grid, dim3(kThreads), 0, stream(), x, y, g, gamma, beta, save_mean,
+                     save_var, partial, dx, dgamma, dbeta, N, C, H, W, S, ipb, eps);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }

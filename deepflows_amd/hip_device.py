@@ -246,6 +246,20 @@ class HipModule:
         _lib.check(self._lib.dfhip_bn2d_backward(dy.ptr, x.ptr, g(gamma), save_mean.ptr, save_var.ptr,
                                                  g(dx), g(dgamma), g(dbeta), N, C, HW, float(eps)))
 
+    def bn_relu_maxpool2_forward(self, x, gamma, beta, y, save_mean, save_var, running_mean, running_var,
+                                 N, C, H, W, eps, momentum):
+        g = lambda h: h.ptr if h is not None else None
+        _lib.check(self._lib.dfhip_bn_relu_maxpool2_forward(x.ptr, g(gamma), g(beta), y.ptr, save_mean.ptr,
+                                                            save_var.ptr, g(running_mean), g(running_var),
+                                                            N, C, H, W, float(eps), float(momentum)))
+
+    def bn_relu_maxpool2_backward(self, x, y, grad, gamma, beta, save_mean, save_var, dx, dgamma, dbeta,
+                                  N, C, H, W, eps):
+        g = lambda h: h.ptr if h is not None else None
+        _lib.check(self._lib.dfhip_bn_relu_maxpool2_backward(x.ptr, y.ptr, grad.ptr, g(gamma), g(beta),
+                                                             save_mean.ptr, save_var.ptr, g(dx), g(dgamma),
+                                                             g(dbeta), N, C, H, W, float(eps)))
+
     def maxpool2d_forward(self, x, y, NC, H, W, k):
         _lib.check(self._lib.dfhip_maxpool2d_forward(x.ptr, y.ptr, NC, H, W, k))
 

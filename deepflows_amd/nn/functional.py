@@ -392,6 +392,64 @@ def batch_norm2d_train(x, weight, bias, running_mean, running_var, eps, momentum
     return _BatchNorm2dFused(x, weight, bias, running_mean, running_var, eps, momentum, residual)
 
 
+class _BnReluPoolFused(_FusedNode):
+    """maxpool2d(relu(batch_norm2d_train(x)), 2) as one node: one forward launch after the
+    statistics pass, two backward launches; the intermediate full-resolution tensors of the three
+    operators are never written (they are recomputed from x in the backward)."""
+
+    def __init__(self, x, weight, bias, running_mean, running_var, eps, momentum):
+        self.x, self.weight, self.bias = x, weight, bias
+        N, C, H, W = (int(v) for v in x.shape)
+        self.geo = (N, C, H, W)
+        self.eps = float(eps)
+        dev = x.device
+        self.xd = x.data.compact()
+        self.wd = weight.data.compact() if weight is not None else None
+        self.bd = bias.data.compact() if bias is not None else None
+        out = _new((N, C, H // 2, W // 2), dev)
+        self.mean, self.var = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+        h = lambda t: t._handle if t is not None else None
+        dev.bn_relu_maxpool2_forward(self.xd._handle, h(self.wd), h(self.bd), out._handle, self.mean._handle,
+                                     self.var._handle,
+                                     h(running_mean.data) if running_mean is not None else None,
+                                     h(running_var.data) if running_var is not None else None,
+                                     N, C, H, W, self.eps, float(momentum))
+        self._grads = None
+        super().__init__(out, [x, weight, bias])
+
+    def grad_fn(self, node, grad):
+        if self._grads is None or self._grads[0] is not grad:
+            dev = grad.device
+            N, C, H, W = self.geo
+            dx = _new(self.xd.shape, dev) if self.x.requires_grad else None
+            dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+            h = lambda t: t._handle if t is not None else None
+            dev.bn_relu_maxpool2_backward(self.xd._handle, self.data._handle, grad.compact()._handle, h(self.wd),
+                                          h(self.bd), self.mean._handle, self.var._handle, h(dx), dg._handle,
+                                          db._handle, N, C, H, W, self.eps)
+            self._grads = (grad, dx, dg, db)
+        _, dx, dg, db = self._grads
+        if node is self.x:
+            return dx
+        return dg if node is self.weight else db
+
+
+def bn_relu_maxpool2_fusable(x, bn, pool):
+    """True when pool(relu(bn(x))) can run as the fused stem node: fused device, training mode,
+    2x2 / stride-2 / unpadded pooling, even height, width a multiple of 8."""
+    if not (_fused(x) and bn.training and hasattr(x.device.mod, "bn_relu_maxpool2_forward")):
+        return False
+    k = getattr(pool, "kernel_size", None)
+    st = getattr(pool, "stride", k)
+    if k != 2 or (st not in (None, 0, 2)) or getattr(pool, "padding", 0) not in (0, None):
+        return False
+    return len(x.shape) == 4 and int(x.shape[2]) % 2 == 0 and int(x.shape[3]) % 8 == 0
+
+
+def bn_relu_maxpool2_train(x, bn):
+    return _BnReluPoolFused(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+
+
 class _BatchNorm2dEvalFused(_FusedNode):
     def __init__(self, x, weight, bias, running_mean, running_var, eps):
         N, C, H, W = (int(v) for v in x.shape)

@@ -128,7 +128,11 @@ class ResNet(nn.Module):
     def forward(self, x):
         if not isinstance(x, Tensor):
             x = Tensor(x)
-        x = self.pool1(self.relu(self.bn1(self.conv1(x))))
+        x = self.conv1(x)
+        if nn.functional.bn_relu_maxpool2_fusable(x, self.bn1, self.pool1):
+            x = nn.functional.bn_relu_maxpool2_train(x, self.bn1)     # one node on the hip device
+        else:
+            x = self.pool1(self.relu(self.bn1(x)))
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in stage:
                 x = blk(x)

@@ -170,6 +170,21 @@ int dfhip_bn2d_backward(const float* dy, const float* x, const float* gamma,
                         const float* save_mean, const float* save_var, float* dx,
                         float* dgamma, float* dbeta, int N, int C, int HW, float eps);
 
+/* BatchNorm2d (training) -> ReLU -> MaxPool2d(2) in one forward launch after the statistics pass,
+ * and its backward (statistics + apply), for the stem of the CIFAR models
+ * (test/ResNet_CIFAR10_cuda.py: pool1(relu(bn1(conv1(x))))).  x (N,C,H,W) is the convolution
+ * output, y (N,C,H/2,W/2) the pooled tensor, g its gradient; dx the gradient w.r.t. x.  Same
+ * values as the three separate operators: batchnorm.py:30-55, functional.py:15-16 / tensor.py:872-877
+ * (gradient where output == input), functional.py:347-374 / tensor.py:779-791 (every tied
+ * maximum gets the gradient).  H even, W a multiple of 8. */
+int dfhip_bn_relu_maxpool2_forward(const float* x, const float* gamma, const float* beta, float* y,
+                                   float* save_mean, float* save_var, float* running_mean,
+                                   float* running_var, int N, int C, int H, int W, float eps, float momentum);
+int dfhip_bn_relu_maxpool2_backward(const float* x, const float* y, const float* g, const float* gamma,
+                                    const float* beta, const float* save_mean, const float* save_var,
+                                    float* dx, float* dgamma, float* dbeta, int N, int C, int H, int W,
+                                    float eps);
+
 /* MaxPool2d with kernel == stride, no padding: nn/functional.py:347-374; backward is
  * tensor.max.grad_fn (tensor.py:779-791): every tied maximum receives the gradient.     */
 int dfhip_maxpool2d_forward(const float* x, float* y, int NC, int H, int W, int k);

@@ -150,3 +150,37 @@ def test_captured_step_matches_eager_steps(hip_device):
     assert l0 == l1, (l0, l1)
     for a, b in zip(p0, p1):
         assert np.array_equal(a, b)
+
+
+def test_fused_stem_matches_the_three_operators(hip_device):
+    """bn_relu_maxpool2_train(x) == max_pool2d(relu(batch_norm2d_train(x)), 2) forward and backward
+    (the tie rules of the reference: every tied window maximum gets the gradient — whole windows
+    of ReLU zeros — and ReLU passes the gradient where output == input)."""
+    from deepflows_amd import nn, tensor
+    from deepflows_amd.nn import functional as F
+    rng = np.random.default_rng(17)
+    for (N, C, H, W) in [(8, 32, 32, 32), (3, 5, 6, 8), (16, 64, 16, 16)]:
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        x[0, 0, :2, :2] = -3.0                      # a window of ReLU zeros: four-way tie
+        x[1 % N, 1 % C, 0, 0] = x[1 % N, 1 % C, 0, 1]   # a two-way tie of positive values
+        gam = rng.standard_normal((1, C, 1, 1)).astype(np.float32)
+        bet = rng.standard_normal((1, C, 1, 1)).astype(np.float32)
+        gout = rng.standard_normal((N, C, H // 2, W // 2)).astype(np.float32)
+        res = []
+        for fused in (False, True):
+            bn = nn.BatchNorm2d(C, device=hip_device)
+            bn.weight.data = tensor.Tensor(gam, device=hip_device).data
+            bn.bias.data = tensor.Tensor(bet, device=hip_device).data
+            pool = nn.MaxPool2d(2, 2)
+            xt = tensor.Tensor(x, device=hip_device, requires_grad=True)
+            if fused:
+                assert F.bn_relu_maxpool2_fusable(xt, bn, pool)
+                out = F.bn_relu_maxpool2_train(xt, bn)
+            else:
+                out = pool(F.relu(bn(xt)))
+            (out * tensor.Tensor(gout, device=hip_device)).sum().backward()
+            res.append((out.numpy(), xt.grad.numpy(), bn.weight.grad.numpy(), bn.bias.grad.numpy(),
+                        bn.running_mean.numpy(), bn.running_var.numpy()))
+        names = ("y", "dx", "dgamma", "dbeta", "running_mean", "running_var")
+        for a, b, nme in zip(res[0], res[1], names):
+            assert_close(b, a, 2e-5, f"{nme} {N, C, H, W}")
