@@ -310,35 +310,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   // rows never run past the image
   const int su_lo = min(max(0, (r0 * g.so + g.u0 >= 0 ? (r0 * g.so + g.u0) / g.sd : 0)), g.HS - RL / g.WS);
 
-  // ---- per-lane, per-tap read descriptors of this wave's pixel tile ----
-  const int q = pt * 32 + l31;
-  const int img = (int)fast_div((unsigned)q, g.m_brbc);
-  const int qrem = q - img * (g.BR * g.BC);
-  const int r = (int)fast_div((unsigned)qrem, g.m_bc), col = qrem - r * g.BC;
-  const bool pvalid = q < g.BI * g.BR * g.BC && n0 + img < g.N && r0 + r < g.HD;
-  int poff[k2];
-  unsigned vmask = 0;
-  {
-    int tapsel = -2;
-    if (MODE == 2 && pvalid) {
-      int ti = last_tap(r0 + r + g.pad, k, g.stride, g.oh);
-      int tj = last_tap(col + g.pad, k, g.stride, g.ow);
-      tapsel = (ti < 0 || tj < 0) ? -1 : ti * k + tj;
-    }
-#pragma unroll
-    for (int t = 0; t < k2; t++) {
-      const int i = t / k, j = t - i * k;
-      const int ti = MODE == 0 ? i : k - 1 - i, tj = MODE == 0 ? j : k - 1 - j;
-      int un = (r0 + r) * g.so + g.u0 + ti, vn = col * g.so + g.u0 + tj;
-      bool ok = pvalid && un >= 0 && vn >= 0;
-      int su = ok ? (int)fast_div((unsigned)un, g.m_sd) : 0, sv = ok ? (int)fast_div((unsigned)vn, g.m_sd) : 0;
-      ok = ok && su * g.sd == un && sv * g.sd == vn && su < g.HS && sv < g.WS;
-      if (MODE == 2) ok = ok && tapsel == t;
-      poff[t] = ok ? img * RL + (su - su_lo) * g.WS + sv : 0;
-      vmask |= ok ? (1u << t) : 0u;
-    }
-  }
-
   // ---- staging descriptors (chunk-invariant) ----
   // patch: vector v of the chunk image -> (channel c, image, q4); LDS float index = 4 * v
   const int RL4 = RL >> 2;
@@ -409,6 +380,36 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   DF_STAMP();
   DF_ISSUE(0);
   DF_STAMP();
+  // (computed while the first chunk is in flight)
+  // ---- per-lane, per-tap read descriptors of this wave's pixel tile ----
+  const int q = pt * 32 + l31;
+  const int img = (int)fast_div((unsigned)q, g.m_brbc);
+  const int qrem = q - img * (g.BR * g.BC);
+  const int r = (int)fast_div((unsigned)qrem, g.m_bc), col = qrem - r * g.BC;
+  const bool pvalid = q < g.BI * g.BR * g.BC && n0 + img < g.N && r0 + r < g.HD;
+  int poff[k2];
+  unsigned vmask = 0;
+  {
+    int tapsel = -2;
+    if (MODE == 2 && pvalid) {
+      int ti = last_tap(r0 + r + g.pad, k, g.stride, g.oh);
+      int tj = last_tap(col + g.pad, k, g.stride, g.ow);
+      tapsel = (ti < 0 || tj < 0) ? -1 : ti * k + tj;
+    }
+#pragma unroll
+    for (int t = 0; t < k2; t++) {
+      const int i = t / k, j = t - i * k;
+      const int ti = MODE == 0 ? i : k - 1 - i, tj = MODE == 0 ? j : k - 1 - j;
+      int un = (r0 + r) * g.so + g.u0 + ti, vn = col * g.so + g.u0 + tj;
+      bool ok = pvalid && un >= 0 && vn >= 0;
+      int su = ok ? (int)fast_div((unsigned)un, g.m_sd) : 0, sv = ok ? (int)fast_div((unsigned)vn, g.m_sd) : 0;
+      ok = ok && su * g.sd == un && sv * g.sd == vn && su < g.HS && sv < g.WS;
+      if (MODE == 2) ok = ok && tapsel == t;
+      poff[t] = ok ? img * RL + (su - su_lo) * g.WS + sv : 0;
+      vmask |= ok ? (1u << t) : 0u;
+    }
+  }
+
   DF_COMMIT(0);
   DF_STAMP();
   __syncthreads();
