@@ -53,6 +53,10 @@ _SIGS = {
     "dfhip_bn2d_backward": [P] * 8 + [c_int, c_int, c_int, c_float],
     "dfhip_bn_relu_maxpool2_forward": [P] * 8 + [c_int] * 4 + [c_float, c_float],
     "dfhip_bn_relu_maxpool2_backward": [P] * 10 + [c_int] * 4 + [c_float],
+    "dfhip_upload_async": [P, P, c_int64, c_int],
+    "dfhip_upload_wait": [c_int],
+    "dfhip_augment_batch": [P, P, P, c_int, c_int, c_int, c_int, c_int],
+    "dfhip_onehot_smooth": [P, P, c_int, c_int, c_double],
     "dfhip_maxpool2d_forward": [P, P, c_int, c_int, c_int, c_int],
     "dfhip_maxpool2d_backward": [P, P, P, P, c_int, c_int, c_int, c_int],
     "dfhip_relu_forward": [P, P, c_int64],

@@ -342,6 +342,43 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
   });
 }
 
+// ---- input pipeline on the device (test/ResNet_CIFAR10_cuda.py:129-148, 180-184) -----------------
+// augment_batch: reflect-pad by `pad`, crop at (ys, xs), horizontal flip, optional erase rectangle,
+// clip to [-1, 1] — pure data movement, bit-exact.  The per-image decisions (drawn on the host in
+// the reference's RNG order) arrive as `dec[n] = {ys, xs, flip, ey, ex, eh, ew, 0}`.
+__device__ __forceinline__ int reflect_index(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+__global__ __launch_bounds__(kThreads) void k_augment_batch(const float* __restrict__ in, float* __restrict__ out,
+                                                            const int* __restrict__ dec, int N, int C, int H, int W,
+                                                            int pad) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)N * C * H * W, step = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += step) {
+    const int x = (int)(i % W);
+    int64_t t = i / W;
+    const int y = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % C), n = (int)(t / C);
+    const int* d = dec + (int64_t)n * 8;
+    const int xc = d[2] ? W - 1 - x : x;                  // column of the cropped image before the flip
+    const int sy = reflect_index(y + d[0] - pad, H), sx = reflect_index(xc + d[1] - pad, W);
+    float v = in[(((int64_t)n * C + c) * H + sy) * W + sx];
+    if (d[5] > 0 && y >= d[3] && y < d[3] + d[5] && x >= d[4] && x < d[4] + d[6]) v = 0.0f;
+    out[i] = fminf(fmaxf(v, -1.0f), 1.0f);
+  }
+}
+
+// labels -> one-hot * (1 - eps) + eps / K   (the scripts' label smoothing; eps = 0: plain one-hot)
+__global__ __launch_bounds__(kThreads) void k_onehot_smooth(const int* __restrict__ labels, float* __restrict__ out,
+                                                            int N, int K, float on, float off) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N * K) out[i] = (i % K == labels[i / K]) ? on : off;
+}
+
 // ---- BatchNorm2d -> ReLU -> MaxPool2d(2) as one forward kernel and one backward pair --------------
 // (the stem of the CIFAR models: the largest activation of the network goes through three
 // element-wise passes forward and three backward in the reference).  Forward reads the convolution
@@ -1164,6 +1201,30 @@ int dfhip_bn_relu_maxpool2_backward(const float* x, const float* y, const float*
   DF_LAUNCH_CHECK();
   hipLaunchKernelGGL((k_bn_relu_pool_bwd<true>), grid, dim3(kThreads), 0, stream(), x, y, g, gamma, beta, save_mean,
                      save_var, partial, dx, dgamma, dbeta, N, C, H, W, S, ipb, eps);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+int dfhip_augment_batch(const float* in, float* out, const int* decisions, int N, int C, int H, int W, int pad) {
+  DF_INIT();
+  DF_CHECK_ARG(N > 0 && C > 0 && H > 1 && W > 1 && pad >= 0 && pad < H && pad < W, "augment_batch: bad geometry");
+  DF_CHECK_ARG(in && out && decisions, "augment_batch: null array");
+  const int64_t n = (int64_t)N * C * H * W;
+  ProfScope prof("augment_batch", 0.0, 8.0 * (double)n);
+  hipLaunchKernelGGL(k_augment_batch, dim3(grid_for(n)), dim3(kThreads), 0, stream(), in, out, decisions, N, C, H, W,
+                     pad);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+int dfhip_onehot_smooth(const int* labels, float* out, int N, int K, double eps) {
+  DF_INIT();
+  DF_CHECK_ARG(N > 0 && K > 0 && labels && out, "onehot_smooth: bad arguments");
+  // (1 - eps) + eps / K and eps / K in the reference's float32 arithmetic: onehot * (1 - eps) + eps / K
+  const float scale = (float)(1.0 - eps), add = (float)(eps / K);
+  const float on = 1.0f * scale + add, off = 0.0f * scale + add;
+  hipLaunchKernelGGL(k_onehot_smooth, dim3((unsigned)df_ceil_div((int64_t)N * K, kThreads)), dim3(kThreads), 0, stream(),
+                     labels, out, N, K, on, off);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }

@@ -377,6 +377,59 @@ int dfhip_d2h(const float* src, float* host, int64_t n) {
   return DFHIP_OK;
 }
 
+// ---- asynchronous, double-buffered upload (input pipeline) -------------------------------------
+// Two pinned slots and a copy stream: dfhip_upload_async(slot) copies the host bytes into the
+// slot's pinned buffer and enqueues the H2D on the copy stream (it returns as soon as the memcpy
+// into pinned memory is done); dfhip_upload_wait(slot) makes the library stream wait for that
+// copy.  The host fills slot k+1 while the GPU trains on slot k; a slot is reused only after the
+// copy that last read it has finished (event wait on the host, normally already signalled).
+struct UploadSlot {
+  void* pinned = nullptr;
+  size_t bytes = 0;
+  hipEvent_t done = nullptr;     // H2D of this slot finished
+  hipEvent_t consumed = nullptr; // the library stream has passed the kernels that read the destination
+  bool in_flight = false;
+};
+static UploadSlot g_up[2];
+static hipStream_t g_copy_stream = nullptr;
+
+int dfhip_upload_async(const void* host, float* dst, int64_t bytes, int slot) {
+  DF_INIT_KEEP();
+  DF_CHECK_ARG(slot == 0 || slot == 1, "upload_async: slot must be 0 or 1");
+  DF_CHECK_ARG(bytes >= 0 && (bytes == 0 || (host && dst)), "upload_async: null pointer");
+  if (bytes == 0) return DFHIP_OK;
+  if (!g_copy_stream) DF_HIP(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
+  UploadSlot& u = g_up[slot];
+  if (!u.done) {
+    DF_HIP(hipEventCreateWithFlags(&u.done, hipEventDisableTiming));
+    DF_HIP(hipEventCreateWithFlags(&u.consumed, hipEventDisableTiming));
+  }
+  if (u.in_flight) DF_HIP(hipEventSynchronize(u.done));      // the pinned buffer is free again
+  if (u.bytes < (size_t)bytes) {
+    if (u.pinned) (void)hipHostFree(u.pinned);
+    u.pinned = nullptr;
+    u.bytes = 0;
+    DF_HIP(hipHostMalloc(&u.pinned, (size_t)bytes, hipHostMallocDefault));
+    u.bytes = (size_t)bytes;
+  }
+  memcpy(u.pinned, host, (size_t)bytes);
+  // the destination may still be read by kernels the library stream has queued for the previous use
+  DF_HIP(hipEventRecord(u.consumed, g_stream));
+  DF_HIP(hipStreamWaitEvent(g_copy_stream, u.consumed, 0));
+  DF_HIP(hipMemcpyAsync(dst, u.pinned, (size_t)bytes, hipMemcpyHostToDevice, g_copy_stream));
+  DF_HIP(hipEventRecord(u.done, g_copy_stream));
+  u.in_flight = true;
+  return DFHIP_OK;
+}
+
+int dfhip_upload_wait(int slot) {
+  DF_INIT_KEEP();
+  DF_CHECK_ARG(slot == 0 || slot == 1, "upload_wait: slot must be 0 or 1");
+  UploadSlot& u = g_up[slot];
+  if (u.in_flight) DF_HIP(hipStreamWaitEvent(g_stream, u.done, 0));
+  return DFHIP_OK;
+}
+
 int dfhip_d2d(const float* src, float* dst, int64_t n) {
   DF_INIT();
   if (n == 0) return DFHIP_OK;

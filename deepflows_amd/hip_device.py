@@ -260,6 +260,25 @@ class HipModule:
                                                              save_mean.ptr, save_var.ptr, g(dx), g(dgamma),
                                                              g(dbeta), N, C, H, W, float(eps)))
 
+    # ---- input pipeline ----------------------------------------------------------------------------
+    def upload_async(self, host_array, dst, slot, dst_offset_floats=0):
+        """Enqueue host_array (any dtype, C-contiguous) into dst[dst_offset_floats:] through pinned slot `slot`
+        on the copy stream; returns at once."""
+        a = np.ascontiguousarray(host_array)
+        _lib.check(self._lib.dfhip_upload_async(a.ctypes.data, dst.ptr + 4 * int(dst_offset_floats), a.nbytes,
+                                                int(slot)))
+
+    def upload_wait(self, slot):
+        _lib.check(self._lib.dfhip_upload_wait(int(slot)))
+
+    def augment_batch(self, src, out, decisions, N, C, H, W, pad, src_offset_floats=0, dec_offset_floats=0):
+        _lib.check(self._lib.dfhip_augment_batch(src.ptr + 4 * int(src_offset_floats), out.ptr,
+                                                 decisions.ptr + 4 * int(dec_offset_floats), N, C, H, W, pad))
+
+    def onehot_smooth(self, labels, out, N, K, eps, labels_offset_floats=0):
+        _lib.check(self._lib.dfhip_onehot_smooth(labels.ptr + 4 * int(labels_offset_floats), out.ptr, N, K,
+                                                 float(eps)))
+
     def maxpool2d_forward(self, x, y, NC, H, W, k):
         _lib.check(self._lib.dfhip_maxpool2d_forward(x.ptr, y.ptr, NC, H, W, k))
 

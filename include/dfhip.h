@@ -185,6 +185,19 @@ int dfhip_bn_relu_maxpool2_backward(const float* x, const float* y, const float*
                                     float* dx, float* dgamma, float* dbeta, int N, int C, int H, int W,
                                     float eps);
 
+/* Input pipeline on the device.
+ * dfhip_upload_async / dfhip_upload_wait: double-buffered pinned upload on a copy stream, so the
+ * H2D of batch k+1 overlaps the training step of batch k (utils/data/dataloader.py:60-139 hands
+ * over pageable NumPy arrays; Tensor(..., device='cuda') copies them synchronously).
+ * dfhip_augment_batch: test/ResNet_CIFAR10_cuda.py:129-148 augment_batch — reflect pad, random crop,
+ * horizontal flip, optional erase rectangle, clip to [-1, 1]; decisions[n] = {ys, xs, flip, erase_y,
+ * erase_x, erase_h (0 = none), erase_w, 0} as int32 in device memory (drawn on the host).
+ * dfhip_onehot_smooth: :180-184, onehot * (1 - eps) + eps / K from int32 labels. */
+int dfhip_upload_async(const void* host, float* dst, int64_t bytes, int slot);
+int dfhip_upload_wait(int slot);
+int dfhip_augment_batch(const float* in, float* out, const int* decisions, int N, int C, int H, int W, int pad);
+int dfhip_onehot_smooth(const int* labels, float* out, int N, int K, double eps);
+
 /* MaxPool2d with kernel == stride, no padding: nn/functional.py:347-374; backward is
  * tensor.max.grad_fn (tensor.py:779-791): every tied maximum receives the gradient.     */
 int dfhip_maxpool2d_forward(const float* x, float* y, int NC, int H, int W, int k);

@@ -121,3 +121,25 @@ def adam_step(p, g, v, s, t, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
     sh = s / f(1 - b2 ** t)
     p = p + (vh / (sh ** f(0.5) + f(eps)) * f(lr)) * f(-1)
     return p.astype(np.float32), v.astype(np.float32), s.astype(np.float32)
+
+
+def augment_batch(inputs, dec, pad=4):
+    """test/ResNet_CIFAR10_cuda.py:129-148 with the random decisions passed in
+    (dec[n] = ys, xs, flip, erase_y, erase_x, erase_h, erase_w, 0): reflect pad, crop, flip, erase, clip."""
+    bs, c, h, w = inputs.shape
+    padded = np.pad(inputs, ((0, 0), (0, 0), (pad, pad), (pad, pad)), mode='reflect')
+    out = np.empty_like(inputs)
+    for i in range(bs):
+        ys, xs = int(dec[i, 0]), int(dec[i, 1])
+        out[i] = padded[i, :, ys:ys + h, xs:xs + w]
+        if dec[i, 2]:
+            out[i] = out[i][:, :, ::-1]
+        if dec[i, 5] > 0:
+            out[i, :, dec[i, 3]:dec[i, 3] + dec[i, 5], dec[i, 4]:dec[i, 4] + dec[i, 6]] = 0.0
+    return np.clip(out, -1.0, 1.0)
+
+
+def smooth_onehot(labels, num_classes, eps):
+    """test/ResNet_CIFAR10_cuda.py:180-184."""
+    onehot = np.eye(num_classes, dtype=np.float32)[np.asarray(labels).reshape(-1)]
+    return (onehot * (1 - eps) + eps / num_classes).astype(np.float32)
