@@ -135,6 +135,12 @@ static int pool_alloc(size_t bytes, void** out) {
       }
     }
     g_n_hipmalloc++;
+    {
+      static int trace = getenv("DFHIP_POOL_TRACE") ? atoi(getenv("DFHIP_POOL_TRACE")) : 0;
+      if (trace && g_n_hipmalloc > trace)
+        fprintf(stderr, "[pool] hipMalloc #%lld of %zu bytes (in use %.1f MB, reserved %.1f MB)\n",
+                (long long)g_n_hipmalloc, bytes, g_in_use / 1e6, g_reserved / 1e6);
+    }
     g_reserved += (int64_t)bytes;
     g_blocks[p] = Block{bytes, 0};
   }

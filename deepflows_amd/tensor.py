@@ -145,7 +145,12 @@ class Tensor:
         return mean(self, axis, keepdims)
 
     def build_edge(self, node):
-        self.children.append(node)
+        # A tensor that does not require grad is never on the tape, so free_graph() never clears its
+        # children: a long-lived input (the fixed batch of a benchmark, a captured step's input)
+        # would keep every step's first node — and its activations — alive.  It gets no child link;
+        # the node still lists it as a parent (backward skips parents that do not require grad).
+        if self.requires_grad:
+            self.children.append(node)
         node.parents.append(self)
 
     # operator overloads
