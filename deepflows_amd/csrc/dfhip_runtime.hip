@@ -469,13 +469,28 @@ int dfhip_graph_begin(void) {
 
 int dfhip_graph_end(void** graph_exec) {
   DF_CHECK_ARG(g_capture_open, "no capture open");
-  { int f__ = flush_deferred(); if (f__ != DFHIP_OK) return f__; }
+  // the capture must be closed even when it has been invalidated (an illegal call inside it, e.g. a
+  // blocking copy): otherwise every later launch on the stream fails
+  const int f__ = flush_deferred();
   int id = g_capture_open;
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamEndCapture(g_stream, &graph);
   g_capture_open = 0;
-  if (e != hipSuccess || !graph) {
-    set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  (void)hipGetLastError();                       // clear the sticky capture error
+  if (e != hipSuccess || !graph || f__ != DFHIP_OK) {
+    if (graph) (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+      // an invalidated capture leaves the stream unusable: nothing was executed since
+      // dfhip_graph_begin synchronised it, so it is simply replaced
+      (void)hipStreamDestroy(g_stream);
+      g_stream = nullptr;
+      (void)hipGetLastError();
+      if (hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("capture failed and the library stream could not be re-created");
+        return DFHIP_RUNTIME_ERROR;
+      }
+    }
+    set_error("capture failed: %s", e != hipSuccess ? hipGetErrorString(e) : "a call inside the capture failed");
     return DFHIP_RUNTIME_ERROR;
   }
   hipGraphExec_t exec = nullptr;

@@ -184,3 +184,31 @@ def test_fused_stem_matches_the_three_operators(hip_device):
         names = ("y", "dx", "dgamma", "dbeta", "running_mean", "running_var")
         for a, b, nme in zip(res[0], res[1], names):
             assert_close(b, a, 2e-5, f"{nme} {N, C, H, W}")
+
+
+def test_failed_capture_leaves_the_device_usable(hip_device):
+    """A model that draws host random numbers per step (Dropout: mask generated on the host and
+    uploaded) cannot be captured; the attempt must raise, end the capture and leave eager training
+    intact."""
+    from deepflows_amd import nn, optim, tensor, workloads
+    from deepflows_amd.graph_step import CapturedTrainStep
+    from deepflows_amd.tensor import Graph
+    np.random.seed(3)
+    model = workloads.CIFAR10_CNN(10, device=hip_device)
+    opt = optim.Adam(model.parameters(), lr=1e-3)
+    crit = nn.CrossEntropyLoss()
+    rng = np.random.default_rng(4)
+    x = tensor.Tensor(rng.standard_normal((8, 3, 32, 32)).astype(np.float32), device=hip_device)
+    y = tensor.Tensor(np.eye(10, dtype=np.float32)[rng.integers(0, 10, 8)], device=hip_device)
+    l0, _ = workloads.train_step(model, crit, opt, x, y)
+    Graph.free_graph()
+    with pytest.raises(RuntimeError):
+        CapturedTrainStep(model, crit, opt, x, y)
+    Graph.free_graph_all()
+    opt.device_hyper = False
+    losses = []
+    for _ in range(3):
+        l, _ = workloads.train_step(model, crit, opt, x, y)
+        Graph.free_graph()
+        losses.append(float(l.numpy()[0]))
+    assert all(np.isfinite(v) for v in losses)
