@@ -941,57 +941,64 @@ __device__ __forceinline__ int find_tensor(const TensorBatch& tb, int blk) {
   return t;
 }
 
-__global__ __launch_bounds__(kThreads) void k_adam(TensorBatch tb, AdamHyper h) {
-  int t = find_tensor(tb, blockIdx.x);
-  int64_t lo = (int64_t)(blockIdx.x - tb.blk_start[t]) * kChunk;
-  int64_t hi = min(tb.size[t], lo + kChunk);
+// one element of the update — optim/adam.py:42-60, same operation order
+__device__ __forceinline__ void adam_element(float& p, float gi, float& m, float& v, const AdamHyper& h) {
+  if (h.gscale != 1.0f) gi = gi * h.gscale;
+  const float pi = p;
+  if (h.wd > 0.0f) gi = gi + pi * h.wd;
+  const float mi = m * h.b1 + gi * h.omb1;
+  const float vi = v * h.b2 + (gi * gi) * h.omb2;
+  m = mi;
+  v = vi;
+  const float mh = mi / h.bc1;
+  const float vh = vi / h.bc2;
+  const float upd = mh / (sqrtf(vh) + h.eps) * h.lr;
+  p = pi + upd * -1.0f;
+}
+
+// a block owns kChunk consecutive elements of one tensor; 16-byte accesses when the four arrays
+// are 16-byte aligned (pool blocks and bucket views are, except behind an odd-sized tensor)
+__device__ __forceinline__ void adam_block(const TensorBatch& tb, const AdamHyper& h) {
+  const int t = find_tensor(tb, blockIdx.x);
+  const int64_t lo = (int64_t)(blockIdx.x - tb.blk_start[t]) * kChunk;
+  const int64_t hi = min(tb.size[t], lo + kChunk);
   float* p = tb.p[t];
   const float* g = tb.g[t];
   float* m = tb.s1[t];
   float* v = tb.s2[t];
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
-    // optim/adam.py:42-60, same operation order
-    float gi = g[i];
-    if (h.gscale != 1.0f) gi = gi * h.gscale;
-    float pi = p[i];
-    if (h.wd > 0.0f) gi = gi + pi * h.wd;
-    float mi = m[i] * h.b1 + gi * h.omb1;
-    float vi = v[i] * h.b2 + (gi * gi) * h.omb2;
-    m[i] = mi;
-    v[i] = vi;
-    float mh = mi / h.bc1;
-    float vh = vi / h.bc2;
-    float upd = mh / (sqrtf(vh) + h.eps) * h.lr;
-    p[i] = pi + upd * -1.0f;
+  const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+  int64_t i = lo + threadIdx.x;
+  if (vec) {
+    const int64_t hi4 = lo + ((hi - lo) & ~(int64_t)3);
+    for (int64_t j = lo + 4 * (int64_t)threadIdx.x; j < hi4; j += 4 * kThreads) {
+      float4 pv = *reinterpret_cast<float4*>(p + j), mv = *reinterpret_cast<float4*>(m + j);
+      float4 vv = *reinterpret_cast<float4*>(v + j);
+      const float4 gv = *reinterpret_cast<const float4*>(g + j);
+      adam_element(pv.x, gv.x, mv.x, vv.x, h);
+      adam_element(pv.y, gv.y, mv.y, vv.y, h);
+      adam_element(pv.z, gv.z, mv.z, vv.z, h);
+      adam_element(pv.w, gv.w, mv.w, vv.w, h);
+      *reinterpret_cast<float4*>(p + j) = pv;
+      *reinterpret_cast<float4*>(m + j) = mv;
+      *reinterpret_cast<float4*>(v + j) = vv;
+    }
+    i = hi4 + threadIdx.x;                         // the (< 4 element) tail
+  }
+  for (; i < hi; i += kThreads) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_element(pi, g[i], mi, vi, h);
+    p[i] = pi; m[i] = mi; v[i] = vi;
   }
 }
+
+__global__ __launch_bounds__(kThreads) void k_adam(TensorBatch tb, AdamHyper h) { adam_block(tb, h); }
 
 // the same update with the hyper-parameters read from device memory: a captured training step
 // (hipGraph) replays this launch unchanged while dfhip_adam_hyper refreshes the scalars (bias
 // corrections change every step) with a one-thread launch in front of the replay
 __global__ __launch_bounds__(kThreads) void k_adam_dev(TensorBatch tb, const AdamHyper* __restrict__ hp) {
   const AdamHyper h = *hp;
-  int t = find_tensor(tb, blockIdx.x);
-  int64_t lo = (int64_t)(blockIdx.x - tb.blk_start[t]) * kChunk;
-  int64_t hi = min(tb.size[t], lo + kChunk);
-  float* p = tb.p[t];
-  const float* g = tb.g[t];
-  float* m = tb.s1[t];
-  float* v = tb.s2[t];
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
-    float gi = g[i];
-    if (h.gscale != 1.0f) gi = gi * h.gscale;
-    float pi = p[i];
-    if (h.wd > 0.0f) gi = gi + pi * h.wd;
-    float mi = m[i] * h.b1 + gi * h.omb1;
-    float vi = v[i] * h.b2 + (gi * gi) * h.omb2;
-    m[i] = mi;
-    v[i] = vi;
-    float mh = mi / h.bc1;
-    float vh = vi / h.bc2;
-    float upd = mh / (sqrtf(vh) + h.eps) * h.lr;
-    p[i] = pi + upd * -1.0f;
-  }
+  adam_block(tb, h);
 }
 
 __global__ void k_set_adam_hyper(AdamHyper* dst, AdamHyper h) { *dst = h; }
