@@ -296,6 +296,36 @@ def conv2d(x: Tensor, kernel: Tensor, padding: int = 0, stride: int = 1, bias=No
     return out if bias is None else out + bias
 
 
+class _MeanHWFused(_FusedNode):
+    """tensor.mean(tensor.mean(x, axis=2), axis=2) of an (N, C, H, W) tensor as one reduction and one
+    broadcast: the two means of the reference divide by the TOTAL element count of their input
+    (SURVEY F5), so the value is sum_hw(x) / (N*C*H*W) / (N*C*W) and the gradient is g / (H*W)."""
+
+    def __init__(self, x):
+        self.x = x
+        N, C, H, W = (int(v) for v in x.shape)
+        self.geo = (N, C, H, W)
+        out = _new((N, C), x.device)
+        scale = 1.0 / (float(N * C * H * W) * float(N * C * W))
+        x.device.reduce_axis(x.data.compact()._handle, out._handle, N * C, H * W, 1, "sum", scale)
+        super().__init__(out, [x])
+
+    def grad_fn(self, node, grad):
+        N, C, H, W = self.geo
+        out = _new((N, C, H, W), grad.device)
+        # mean.grad_fn scales by out.size / in.size at each of the two steps: (N*C*W)/(N*C*H*W) * (N*C)/(N*C*W)
+        grad.device.broadcast_axis(grad.compact()._handle, out._handle, N * C, H * W, 1, 1.0 / float(H * W))
+        return out
+
+
+def mean_hw(x: Tensor) -> Tensor:
+    """mean over H then over W with the reference's `mean(axis)` semantics (two calls of
+    tensor.mean(x, axis=2)); one kernel each way on a fused device."""
+    if _fused(x) and len(x.shape) == 4 and hasattr(x.device.mod, "reduce_axis"):
+        return _MeanHWFused(x)
+    return tensor.mean(tensor.mean(x, axis=2), axis=2)
+
+
 # ---- pooling ------------------------------------------------------------------------------------------
 class _MaxPool2dFused(_FusedNode):
     def __init__(self, x, k):

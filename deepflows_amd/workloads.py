@@ -136,8 +136,7 @@ class ResNet(nn.Module):
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in stage:
                 x = blk(x)
-        x = tensor.mean(x, axis=2)     # divides by the TOTAL element count
-        x = tensor.mean(x, axis=2)
+        x = nn.functional.mean_hw(x)   # mean(axis=2) twice: each divides by the TOTAL element count
         return self.fc(x)
 
 
