@@ -115,7 +115,8 @@ def main():
     model, opt, crit, xt, yt = build_job(dev, rank, BATCH, register_blocks=(args.registration == "all"))
     bucket = parallel.GradientBucket(opt.params, comm)
     opt.grad_scale = 1.0 / comm.world
-    sync = bucket.sync if comm.world > 1 else None
+    # DF_FORCE_SYNC=1 (with DF_FORCE_COMM=1): exercise the exchange path of a multi-GPU run on one GPU
+    sync = bucket.sync if (comm.world > 1 or os.environ.get("DF_FORCE_SYNC") == "1") else None
 
     def step():
         loss, _ = workloads.train_step(model, crit, opt, xt, yt, sync=sync)
