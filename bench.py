@@ -234,9 +234,21 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     comm.barrier()
     comm.close()
+    # RCCL writes a version banner to the C stdout buffer, which is flushed at process exit — after
+    # anything Python printed.  Drain it first so that the JSON line is the last line of stdout.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
