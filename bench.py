@@ -96,6 +96,9 @@ def main():
                     help="all = every block registered (62 tensors); f6 = the reference script's 5 tensors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
+    ap.add_argument("--overlap", action="store_true",
+                    help="data parallel: two graphs, the all-reduce of layer4 + fc beside the rest of the backward "
+                         "pass (costs ~0.1 ms of split / event overhead per step: only pays for slow links)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,7 +133,25 @@ def main():
     # the timed steps replay one captured step (hipGraph) unless --no-graph; same kernels, same
     # order, one host call per step instead of ~170
     captured = None
-    if not args.no_graph:
+    overlapped = False
+    if not args.no_graph and sync is not None and args.overlap:
+        # data parallel: two graphs split where layer4's gradients are complete, the all-reduce of
+        # that bucket runs on the communication stream beside the rest of the backward pass
+        try:
+            from deepflows_amd.graph_step import OverlappedCapturedTrainStep
+            late, early = workloads.late_and_early_parameters(model, opt.params)
+            captured = OverlappedCapturedTrainStep(model, crit, opt, xt, yt,
+                                                   parallel.GradientBucket(late, comm),
+                                                   parallel.GradientBucket(early, comm))
+            for _ in range(2):
+                loss = captured.replay()
+            mod.synchronize()
+            overlapped = True
+        except Exception as e:
+            print(f"[bench] overlapped capture failed ({type(e).__name__}: {e}); single-bucket path", file=sys.stderr)
+            captured = None
+            opt.device_hyper = False
+    if captured is None and not args.no_graph:
         try:
             from deepflows_amd.graph_step import CapturedTrainStep
             captured = CapturedTrainStep(model, crit, opt, xt, yt, sync=sync)
@@ -222,7 +243,7 @@ def main():
             "config": {"workload": "ResNet-18 (CIFAR variant 32/64/128/256, test/ResNet_CIFAR10_cuda.py) "
                                    "train step: fwd + CE + bwd + Adam, bs 256 per GPU, fp32",
                        "global_batch": BATCH * comm.world, "parallelism": f"dp{comm.world}",
-                       "conv_dgrad": args.dgrad, "dispatch": "hipgraph" if captured is not None else "eager", "registered_params": args.registration,
+                       "conv_dgrad": args.dgrad, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,
                        "allreduce_elems": bucket.total if comm.world > 1 else 0},
             "gpu_ms_per_step": gpu_ms / args.steps, "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
             "final_loss": final_loss,

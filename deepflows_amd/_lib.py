@@ -77,6 +77,8 @@ _SIGS = {
     "dfhip_comm_unique_id": [c_char_p],
     "dfhip_comm_init": [c_int, c_int, c_char_p],
     "dfhip_allreduce_sum": [P, c_int64],
+    "dfhip_allreduce_sum_async": [P, c_int64],
+    "dfhip_comm_wait": [],
     "dfhip_comm_destroy": [],
     "dfhip_graph_begin": [],
     "dfhip_graph_end": [POINTER(c_void_p)],

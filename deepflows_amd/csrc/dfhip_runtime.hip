@@ -664,9 +664,44 @@ int dfhip_allreduce_sum(float* buf, int64_t n) {
   return DFHIP_OK;
 }
 
+// Overlapped exchange: the all-reduce is enqueued on a communication stream that waits for
+// everything already queued on the library stream (the packed gradients) and runs beside the rest
+// of the backward pass; dfhip_comm_wait makes the library stream wait for every all-reduce issued
+// this way (before the optimizer reads the bucket).
+static hipStream_t g_comm_stream = nullptr;
+static hipEvent_t g_comm_ready = nullptr, g_comm_done = nullptr;
+static bool g_comm_pending = false;
+
+int dfhip_allreduce_sum_async(float* buf, int64_t n) {
+  DF_INIT();
+  DF_CHECK_ARG(g_comm, "dfhip_comm_init has not been called");
+  if (n == 0) return DFHIP_OK;
+  if (!g_comm_stream) {
+    DF_HIP(hipStreamCreateWithFlags(&g_comm_stream, hipStreamNonBlocking));
+    DF_HIP(hipEventCreateWithFlags(&g_comm_ready, hipEventDisableTiming));
+    DF_HIP(hipEventCreateWithFlags(&g_comm_done, hipEventDisableTiming));
+  }
+  DF_HIP(hipEventRecord(g_comm_ready, g_stream));
+  DF_HIP(hipStreamWaitEvent(g_comm_stream, g_comm_ready, 0));
+  DF_NCCL(p_ncclAllReduce(buf, buf, (size_t)n, 7, 0, g_comm, g_comm_stream));
+  DF_HIP(hipEventRecord(g_comm_done, g_comm_stream));
+  g_comm_pending = true;
+  return DFHIP_OK;
+}
+
+int dfhip_comm_wait(void) {
+  DF_INIT();
+  if (g_comm_pending) {
+    DF_HIP(hipStreamWaitEvent(g_stream, g_comm_done, 0));
+    g_comm_pending = false;
+  }
+  return DFHIP_OK;
+}
+
 int dfhip_comm_destroy(void) {
   (void)flush_deferred();
   if (g_comm) {
+    if (g_comm_stream) (void)hipStreamSynchronize(g_comm_stream);
     (void)hipStreamSynchronize(g_stream);
     p_ncclCommDestroy(g_comm);
     g_comm = nullptr;

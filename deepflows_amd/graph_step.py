@@ -67,3 +67,83 @@ class CapturedTrainStep:
 
     def destroy(self):
         self.graph.destroy()
+
+
+class OverlappedCapturedTrainStep:
+    """Data-parallel step with the gradient exchange overlapped with the backward pass.
+
+    The backward sweep is captured as TWO graphs split at `model.backward_milestone` (for the CIFAR
+    ResNet: the input of layer4 — behind it sit 2.4 M of the 2.8 M parameters, and their gradients
+    are final first).  A replay is
+
+        graph A (forward, loss, backward down to the milestone)
+        pack + all-reduce of the late bucket      -> communication stream
+        graph B (the rest of backward)            -> library stream, beside the all-reduce
+        pack + all-reduce of the early bucket     -> communication stream
+        wait, Adam
+
+    so the 11 MB exchange of a step hides behind ~0.6 ms of backward instead of extending the step.
+    No collective is inside a graph.  `late_bucket` / `early_bucket` are GradientBuckets over the two
+    halves of optimizer.params (workloads.late_and_early_parameters)."""
+
+    def __init__(self, model, criterion, optimizer, inputs, targets, late_bucket, early_bucket):
+        mod = inputs.device.mod
+        if not (getattr(mod, "fused", False) and hasattr(mod, "capture_begin")):
+            raise RuntimeError("OverlappedCapturedTrainStep needs the hip device")
+        self.mod, self.optimizer = mod, optimizer
+        self.late, self.early = late_bucket, early_bucket
+        optimizer.device_hyper = True
+        optimizer.push_hyper()
+        self.graph_a = None
+
+        def split():
+            self.graph_a = mod.capture_end()
+            mod.capture_begin()
+
+        mod.capture_begin()
+        try:
+            outputs = model(inputs)
+            loss = criterion(outputs, targets)
+            optimizer.zero_grad()
+            node = getattr(model, "backward_milestone", None)
+            if node is None or not node.requires_grad:
+                raise RuntimeError("the model did not record a backward milestone")
+            loss.backward(milestone=(node, split))
+            if self.graph_a is None:
+                raise RuntimeError("the backward sweep never reached the milestone")
+            Graph.free_graph()
+        except BaseException:
+            try:
+                mod.capture_end().destroy()
+            except Exception:
+                pass
+            if self.graph_a is not None:
+                self.graph_a.destroy()
+            raise
+        self.graph_b = mod.capture_end()
+        self.loss, self.outputs = loss, outputs
+        self._keep = (inputs, targets)
+        self.late_grads = [p.grad for p in self.late.params]
+        self.early_grads = [p.grad for p in self.early.params]
+        if any(g is None for g in self.late_grads + self.early_grads):
+            raise RuntimeError("a parameter received no gradient in the captured step")
+
+    def replay(self):
+        opt = self.optimizer
+        opt.push_hyper()
+        self.graph_a.replay()
+        for p, g in zip(self.late.params, self.late_grads):
+            p.grad = g
+        self.late.sync(overlap=True)
+        self.graph_b.replay()
+        for p, g in zip(self.early.params, self.early_grads):
+            p.grad = g
+        self.early.sync(overlap=True)
+        self.late.comm.wait()
+        opt.apply()
+        opt.t += 1
+        return self.loss
+
+    def destroy(self):
+        self.graph_a.destroy()
+        self.graph_b.destroy()

@@ -365,6 +365,12 @@ class HipModule:
     def allreduce_sum(self, handle, count=None):
         _lib.check(self._lib.dfhip_allreduce_sum(handle.ptr, handle.size if count is None else int(count)))
 
+    def allreduce_sum_async(self, handle, count=None):
+        _lib.check(self._lib.dfhip_allreduce_sum_async(handle.ptr, handle.size if count is None else int(count)))
+
+    def comm_wait(self):
+        _lib.check(self._lib.dfhip_comm_wait())
+
     def comm_destroy(self):
         self._lib.dfhip_comm_destroy()
 

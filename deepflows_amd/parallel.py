@@ -47,6 +47,9 @@ class Communicator:
     def max_float(self, x):
         return x
 
+    def wait(self):
+        pass
+
     def close(self):
         pass
 
@@ -101,9 +104,16 @@ class RcclCommunicator(TorchHostCommunicator):
         self._dist.broadcast(t, src=0)
         hip_mod.comm_init(self.rank, self.world, bytes(t.tolist()))
 
-    def allreduce_sum(self, flat):
-        self._mod.allreduce_sum(flat._handle)
+    def allreduce_sum(self, flat, overlap=False):
+        if overlap:
+            self._mod.allreduce_sum_async(flat._handle)   # communication stream, see wait()
+        else:
+            self._mod.allreduce_sum(flat._handle)
         return flat
+
+    def wait(self):
+        """The library stream waits for every overlapped all-reduce issued so far."""
+        self._mod.comm_wait()
 
     def close(self):
         self._mod.comm_destroy()
@@ -147,9 +157,11 @@ class GradientBucket:
             handle = _ArrayView(h, offset, int(p.size))
         return BackendTensor.make(p.shape, device=p.device, handle=handle)
 
-    def sync(self):
+    def sync(self, overlap=False):
         """pack -> all-reduce(sum) -> point every p.grad at its slice of the reduced bucket.
-        The optimizer must then be stepped with grad_scale = 1/world."""
+        The optimizer must then be stepped with grad_scale = 1/world.  overlap=True: the all-reduce
+        runs on the communication stream beside whatever is enqueued next; call comm.wait() before
+        the optimizer."""
         if self.flat is None:
             return
         dev = self.params[0].device
@@ -166,7 +178,10 @@ class GradientBucket:
             for g, n in zip(grads, self.sizes):
                 self.flat._handle[off:off + n] = g._handle
                 off += n
-        self.comm.allreduce_sum(self.flat)
+        if overlap and isinstance(self.comm, RcclCommunicator):
+            self.comm.allreduce_sum(self.flat, overlap=True)
+        else:
+            self.comm.allreduce_sum(self.flat)
         off = 0
         for p, n in zip(self.params, self.sizes):
             p.grad = self._view(off, p)

@@ -202,7 +202,10 @@ class Tensor:
     def __ge__(self, o): return self._compare(o, lambda a, b: a >= b)
 
     # ---- reverse sweep (tensor.py:421-499) ---------------------------------------------------
-    def backward(self, retain_graph: bool = False):
+    def backward(self, retain_graph: bool = False, milestone=None):
+        """milestone = (node, callback) (extension): callback() runs when the reverse sweep reaches
+        `node`, i.e. when every node created after it has been processed — the gradients of all
+        parameters used only behind it are final (data-parallel overlap, graph_step.py)."""
         if self not in Graph.node_list:
             return
         if self.data.ndim != 1:
@@ -213,6 +216,9 @@ class Tensor:
             while Graph.node_list[start] is not self:
                 start -= 1
             for node in Graph.node_list[start::-1]:
+                if milestone is not None and node is milestone[0]:
+                    milestone[1]()
+                    milestone = None
                 grad = node.grad
                 if grad is None:
                     continue

@@ -133,11 +133,36 @@ class ResNet(nn.Module):
             x = nn.functional.bn_relu_maxpool2_train(x, self.bn1)     # one node on the hip device
         else:
             x = self.pool1(self.relu(self.bn1(x)))
-        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+        for stage in (self.layer1, self.layer2, self.layer3):
             for blk in stage:
                 x = blk(x)
+        # everything created after this tensor is layer4 + the classifier: 2.4 M of the 2.8 M
+        # parameters, whose gradients are final when the backward sweep gets back here
+        self.backward_milestone = x
+        for blk in self.layer4:
+            x = blk(x)
         x = nn.functional.mean_hw(x)   # mean(axis=2) twice: each divides by the TOTAL element count
         return self.fc(x)
+
+
+def late_and_early_parameters(model, params):
+    """Split `params` (an optimizer's list) into those used only behind model.backward_milestone
+    (layer4 and fc of a ResNet: their gradients are complete first) and the rest, keeping order."""
+    late_ids = set()
+    for m in list(model.layer4) + [model.fc]:
+        stack = [m]
+        while stack:
+            mod = stack.pop()
+            for p in mod._parameters.values():
+                if p is not None:
+                    late_ids.add(id(p))
+            stack.extend(c for c in mod._modules.values() if c is not None)
+            ds = getattr(mod, "downsample", None)
+            if isinstance(ds, (list, tuple)):
+                stack.extend(ds)
+    late = [p for p in params if id(p) in late_ids]
+    early = [p for p in params if id(p) not in late_ids]
+    return late, early
 
 
 def ResNet18(num_classes=10, device="hip", register_blocks=True):

@@ -266,7 +266,13 @@ int dfhip_unpack(int n_tensors, float* const* dsts, const int64_t* sizes, const 
  *      collective) ---------------------------------------------------- */
 int dfhip_comm_unique_id(char* out128);                       /* ncclGetUniqueId          */
 int dfhip_comm_init(int rank, int world, const char* id128);  /* ncclCommInitRank         */
-int dfhip_allreduce_sum(float* buf, int64_t n);               /* in place, library stream */
+int dfhip_allreduce_sum(float* buf, int64_t n);               /* The same all-reduce on a communication stream: it waits for the work already queued on the
+ * library stream and then runs beside whatever is queued afterwards (the rest of the backward pass);
+ * dfhip_comm_wait makes the library stream wait for all of them (call it before the optimizer). */
+int dfhip_allreduce_sum_async(float* buf, int64_t n);
+int dfhip_comm_wait(void);
+
+/* in place, library stream */
 int dfhip_comm_destroy(void);
 
 /* ---- whole-step capture (hipGraph) -------------------------------------------------- */

@@ -96,3 +96,41 @@ def test_captured_step_with_gradient_exchange(rccl_comm):
     assert o1.t == o2.t == 4
     for a, b in zip(o1.params, o2.params):
         assert np.array_equal(a.data.numpy(), b.data.numpy())
+
+
+def test_overlapped_step_matches_eager_exchange(rccl_comm):
+    """OverlappedCapturedTrainStep (two graphs, all-reduce of the late bucket on the communication
+    stream) continues exactly like eager steps with a single bucket."""
+    from deepflows_amd import nn, optim, parallel, workloads
+    from deepflows_amd.graph_step import OverlappedCapturedTrainStep
+    from deepflows_amd.tensor import Graph, Tensor
+    dev, comm = rccl_comm
+    rng = np.random.default_rng(3)
+    xs = Tensor(rng.standard_normal((8, 3, 32, 32)).astype(np.float32), device=dev)
+    ys = Tensor(np.eye(10, dtype=np.float32)[rng.integers(0, 10, 8)], device=dev)
+    crit = nn.CrossEntropyLoss()
+
+    def twin():
+        np.random.seed(1)
+        m = workloads.ResNet18(device=dev, register_blocks=True)
+        return m, optim.Adam(workloads.all_block_parameters(m), lr=1e-3)
+
+    m1, o1 = twin()
+    b1 = parallel.GradientBucket(o1.params, comm)
+    for _ in range(4):
+        workloads.train_step(m1, crit, o1, xs, ys, sync=b1.sync)
+        Graph.free_graph()
+    m2, o2 = twin()
+    b2 = parallel.GradientBucket(o2.params, comm)
+    workloads.train_step(m2, crit, o2, xs, ys, sync=b2.sync)
+    Graph.free_graph()
+    late, early = workloads.late_and_early_parameters(m2, o2.params)
+    assert len(late) > 0 and len(early) > 0 and len(late) + len(early) == len(o2.params)
+    assert sum(int(p.size) for p in late) > 2 * sum(int(p.size) for p in early)
+    step = OverlappedCapturedTrainStep(m2, crit, o2, xs, ys, parallel.GradientBucket(late, comm),
+                                       parallel.GradientBucket(early, comm))
+    for _ in range(3):
+        step.replay()
+    assert o1.t == o2.t == 5
+    for a, b in zip(o1.params, o2.params):
+        assert np.array_equal(a.data.numpy(), b.data.numpy())
