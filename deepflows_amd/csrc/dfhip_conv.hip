@@ -65,7 +65,6 @@ struct Geo {
   int64_t slab_stride;
   int PT;                  // v3: 32-pixel tiles per workgroup (8 / PT k-split slices)
   unsigned long long* stamps;  // diagnostic builds only (DFHIP_CONV_STAMP): per-block time stamps
-  int dbg;                     // diagnostics: 1 = loaders idle in the main loop, 2 = no MFMAs
   unsigned m_perimg, m_pc, m_sd;   // exact division by multiplication (magic = ceil(2^32/d), 0 = divide by 1)
   unsigned m_brbc, m_bc, m_birl4, m_rl4, m_run4;
   // forward only: per-workgroup BatchNorm partials of the output, [gridDim.x][CD][3] = (count, mean,
@@ -1401,7 +1400,6 @@ struct RGeo {
   unsigned m_br;             // magic divider: BR
   unsigned m_xc, m_xi;       // staging x: BI*RL4, RL4
   unsigned m_dc, m_di;       // staging dY: BI*B4, B4
-  int dbg;
   SlabSum pend;              // slab sum of the previous weight gradient, done by this launch's blocks
   unsigned long long* stamps;
 };
@@ -1454,7 +1452,6 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
 #define RG_STAMP() do { } while (0)
 #endif
   RG_STAMP();
-  if (g.dbg == 2) return;                     // diagnostics: launch + teardown cost of this configuration
   const int c0 = blockIdx.y * 32, o0 = blockIdx.z * 32;
   const int cn = min(32, g.C - c0), on = min(32, g.O - o0);
   const int RL = g.RLr * W;                   // staged floats per (image, channel)
@@ -1599,7 +1596,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
   for (int gi_ = 0; gi_ < my_groups; gi_++) {
     const int buf = gi_ & 1;
     const bool more = gi_ + 1 < my_groups;
-    if (more && !g.dbg) {
+    if (more) {
       group_base(gi_ + 1);
 #pragma unroll
       for (int u = 0; u < SVD; u++) dsv[u] = *reinterpret_cast<const f32x4*>(yg_nxt + ds_src[u]);
@@ -1665,10 +1662,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
 #undef RG_LOAD
     }
     RG_STAMP();
-    if (more && g.dbg) {
-      group_base(gi_ + 1);
-      stage_rest(smem + (buf ^ 1) * buf_floats, 0, 0);
-    } else if (more) {
+    if (more) {
       float* B_ = smem + (buf ^ 1) * buf_floats;
 #pragma unroll
       for (int u = 0; u < SVD; u++)
@@ -2256,7 +2250,6 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
   g.m_dc = magic_u32((unsigned)(g.BI * B4));
   g.m_di = magic_u32((unsigned)B4);
   const int ps = std::max(1, std::min(g.ngroups, ps0));
-  g.dbg = getenv("DFHIP_WGRAD_DBG") ? atoi(getenv("DFHIP_WGRAD_DBG")) : 0;
 #define DF_ROWS(KSV, PADV, SV, WV, OWV, URV) \
   if (k == KSV && stride == SV && W == WV && UR == URV)  \
     return launch_wgrad_rows<KSV, PADV, SV, WV, OWV, URV>(g, dw, best_lds, ps, CT, OT);
