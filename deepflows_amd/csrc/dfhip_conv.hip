@@ -261,7 +261,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(Geo g) {
 // barrier: a thread moves ~1 patch vector and ~1-5 weight vectors per chunk.
 //
 // Weights keep their GLOBAL order in LDS (a commit is a plain float4 store):
-//   forward:  W[d0+d][cb+c][t] -> Wl[d * RS + c*k2 + t], RS = CCP*k2 + 4  (A-operand lanes run
+//   forward:  W[d0+d][cb+c][t] -> Wl[(c*k2 + t) * 33 + d]: transposed, row stride 33, so that the 32
+//             A-operand lanes (d) of a read and the 64 lanes of a staging store (consecutive (c,t)
+//             of one d) both fall into distinct banks (PMC: the [d][c*k2+t] image with a 16-byte
+//             row pitch had as many bank-conflict cycles as active LDS cycles)
+//   (was)     W[d0+d][cb+c][t] -> Wl[d * RS + c*k2 + t], RS = CCP*k2 + 4  (A-operand lanes run
 //             along d: 4-way bank conflict on one ds_read_b32 per MFMA, well inside LDS budget)
 //   dgrad:    W[cb+c][d0+d][t] -> Wl[c * 32*k2 + d*k2 + t]                (stride k2: conflict-free)
 // ---------------------------------------------------------------------------------------
@@ -276,7 +280,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   const int RS = MODE == 0 ? CCP * k2 + 4 : 32 * k2;
   const int PEp = g.PE;                       // floats per channel in the LDS image: BI * RL
   const int xs_floats = CCP * PEp;
-  const int ws_floats = (MODE == 0 ? 32 : CCP) * RS;
+  constexpr int WT = 33;                      // forward: row pitch of the transposed weight image
+  const int ws_floats = MODE == 0 ? CCP * k2 * WT : CCP * RS;
   float* Xs0 = smem;
   float* Ws0 = Xs0 + 2 * xs_floats;
 
@@ -356,12 +361,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   } while (0)
 #define DF_WSTORE(u, val)                                                                        \
   do {                                                                                           \
-    if (w_lx[u] >= 0) *reinterpret_cast<f32x4*>(Wl_ + w_lx[u]) = (val);                          \
-    else if (w_lx[u] == -2) {                                                                    \
-      int f_ = tid + 512 * (u);                                                                  \
-      int row_ = f_ / run4, e4_ = f_ - row_ * run4;                                              \
-      *reinterpret_cast<f32x4*>(Wl_ + row_ * RS + 4 * e4_) = (f32x4){0.f, 0.f, 0.f, 0.f};        \
-    }                                                                                            \
+    if (MODE == 0) {                                                                             \
+      if (w_lx[u] != -1) {                     /* transposed image: four scalar stores */        \
+        int f_ = tid + 512 * (u);                                                                \
+        int row_ = (int)fast_div((unsigned)f_, g.m_run4), e4_ = f_ - row_ * run4;                \
+        const f32x4 v_ = w_lx[u] >= 0 ? (val) : (f32x4){0.f, 0.f, 0.f, 0.f};                     \
+        float* q_ = Wl_ + (4 * e4_) * WT + row_;                                                 \
+        q_[0] = v_.x; q_[WT] = v_.y; q_[2 * WT] = v_.z; q_[3 * WT] = v_.w;                       \
+      }                                                                                          \
+    } else if (w_lx[u] >= 0) *reinterpret_cast<f32x4*>(Wl_ + w_lx[u]) = (val);                   \
   } while (0)
 #define DF_COMMIT(buf)                                                                           \
   do {                                                                                           \
@@ -418,19 +426,19 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   // unroll into straight-line code whose LDS reads are hoisted ahead of the MFMAs
   const int npk = NPK ? NPK : (CCP >> 1) / KSPLIT;
   const int c_first = 2 * ks * npk + half;    // this lane's first channel inside a chunk
-  const int astep = MODE == 0 ? 2 * k2 : 2 * RS;
+  const int astep = MODE == 0 ? 2 * k2 * WT : 2 * RS;
   const int bstep = 2 * PEp;
   for (int ch = 0; ch < nchunks; ch++) {
     const int buf = ch & 1;
     if (ch + 1 < nchunks) DF_ISSUE(ch + 1);    // lands while this chunk is in the matrix cores
     const float* Xb = Xs0 + buf * xs_floats + c_first * PEp;
-    const float* aq = Ws0 + buf * ws_floats + (MODE == 0 ? l31 * RS + c_first * k2 : c_first * RS + l31 * k2);
+    const float* aq = Ws0 + buf * ws_floats + (MODE == 0 ? c_first * k2 * WT + l31 : c_first * RS + l31 * k2);
 #pragma unroll
     for (int t = 0; t < k2; t++) {
       const bool ok = (vmask >> t) & 1u;
       if (__ballot(ok) != 0ull) {              // else: nobody in the wave reads through this tap
         const float* bp = Xb + poff[t];
-        const float* ap = aq + t;
+        const float* ap = aq + (MODE == 0 ? t * WT : t);
         if (NPK) {
 #pragma unroll
           for (int p = 0; p < (NPK ? NPK : 1); p++) {
@@ -1853,7 +1861,7 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, 
     if (jobs < (int64_t)num_cus() * jobmul && pt > 1) continue;
     static size_t lds_cap_single = (size_t)(getenv("DFHIP_LDS_SINGLE") ? atoi(getenv("DFHIP_LDS_SINGLE")) : 150) * 1024;
     auto fits = [&](int cc) {
-      size_t wl = g.mode == 0 ? (size_t)32 * (cc * k2 + 4) : (size_t)cc * 32 * k2;
+      size_t wl = g.mode == 0 ? (size_t)33 * cc * k2 : (size_t)cc * 32 * k2;
       size_t stage_b = 2 * ((size_t)cc * g.PE + wl) * 4;
       size_t red_b = (size_t)pt * (ksplit - 1) * 16 * 64 * 4;
       lds = std::max(stage_b, red_b);
