@@ -864,6 +864,37 @@ __global__ __launch_bounds__(kThreads) void k_reduce_to_shape(const float* __res
   }
 }
 
+// (N, C, H, W) -> (1, C, 1, 1): the bias gradient of a convolution (conv.py:104-108 adds the bias
+// by broadcasting, so its gradient is un-broadcast by the engine).  Block (c, s) sums its images of
+// channel c with 16-byte loads; a second tiny launch adds the S partials in order.
+__global__ __launch_bounds__(kThreads) void k_channel_sum(const float* __restrict__ x, float* __restrict__ partial,
+                                                          int N, int C, int HW, int S, int ipb) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
+  const float* base = x + (int64_t)c * HW;
+  float sum = 0.0f;
+  for_each_chunk(base, (int64_t)C * HW, n_lo, n_hi, HW, [&](const float* p, int w) {
+    if (w == 4) {
+      float4 v = *reinterpret_cast<const float4*>(p);
+      sum += (v.x + v.y) + (v.z + v.w);
+    } else {
+      sum += p[0];
+    }
+  });
+  sum = block_sum(sum, sh);
+  if (threadIdx.x == 0) partial[(int64_t)c * S + s] = sum;
+}
+
+__global__ __launch_bounds__(kThreads) void k_channel_sum_finish(const float* __restrict__ partial,
+                                                                 float* __restrict__ dst, int C, int S) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.0f;
+  for (int i = 0; i < S; i++) s += partial[(int64_t)c * S + i];
+  dst[c] = s;
+}
+
 // dst[o][i] = scale * reduce_r src[o][r][i]
 template <bool IS_MAX>
 __global__ __launch_bounds__(kThreads) void k_reduce_axis(const float* __restrict__ src,
@@ -1344,6 +1375,21 @@ int dfhip_reduce_to_shape(const float* src, float* dst, int src_ndim, const int6
   }
   if (n_dst * n_red == 0) return DFHIP_OK;
   ProfScope prof("reduce_to_shape", 0.0, 4.0 * (double)(n_dst * n_red + n_dst));
+  if (src_ndim == 4 && rs.keep[0] == 0 && rs.keep[1] == 1 && rs.keep[2] == 0 && rs.keep[3] == 0 &&
+      n_red >= 4096 && src_shape[1] < (1 << 20)) {
+    const int N = (int)src_shape[0], C = (int)src_shape[1], HW = (int)(src_shape[2] * src_shape[3]);
+    int S, ipb;
+    bn_split(N, C, S, ipb);
+    float* partial = workspace_small((size_t)C * S * sizeof(float));
+    if (!partial) return DFHIP_OUT_OF_MEMORY;
+    hipLaunchKernelGGL(k_channel_sum, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), src, partial, N, C,
+                       HW, S, ipb);
+    DF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_channel_sum_finish, dim3((unsigned)df_ceil_div(C, kThreads)), dim3(kThreads), 0, stream(),
+                       partial, dst, C, S);
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
   int blocks = (int)std::min<int64_t>(n_dst, (int64_t)num_cus() * 8);
   hipLaunchKernelGGL(k_reduce_to_shape, dim3(blocks), dim3(kThreads), 0, stream(), src, dst, rs, n_dst,
                      n_red);

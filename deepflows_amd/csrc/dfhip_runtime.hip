@@ -347,6 +347,18 @@ static int pinned(size_t bytes, void** out) {
   return DFHIP_OK;
 }
 
+// Host -> device without draining the stream: a ring of pinned staging slots, each guarded by an
+// event recorded behind its copy; the host blocks only when it laps the ring (the reference's
+// per-step uploads — dropout masks, batches — used to stall the whole pipeline here).
+struct H2dSlot {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipEvent_t done = nullptr;
+  bool busy = false;
+};
+static H2dSlot g_h2d[4];
+static int g_h2d_next = 0;
+
 int dfhip_h2d(const float* host, float* dst, int64_t n) {
   DF_INIT();
   DF_CHECK_ARG(n >= 0 && (n == 0 || (host && dst)), "h2d: null pointer");
@@ -355,12 +367,27 @@ int dfhip_h2d(const float* host, float* dst, int64_t n) {
   const size_t chunk = (size_t)64 << 20;
   for (size_t off = 0; off < bytes; off += chunk) {
     size_t b = bytes - off < chunk ? bytes - off : chunk;
-    void* stage = nullptr;
-    int s = pinned(b, &stage);
-    if (s != DFHIP_OK) return s;
-    memcpy(stage, (const char*)host + off, b);
-    DF_HIP(hipMemcpyAsync((char*)dst + off, stage, b, hipMemcpyHostToDevice, g_stream));
-    DF_HIP(hipStreamSynchronize(g_stream));  // the pinned stage is reused by the next chunk
+    H2dSlot& sl = g_h2d[g_h2d_next];
+    g_h2d_next = (g_h2d_next + 1) & 3;
+    if (!sl.done) DF_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (sl.busy) {
+      DF_HIP(hipEventSynchronize(sl.done));
+      sl.busy = false;
+    }
+    if (sl.bytes < b) {
+      if (sl.p) (void)hipHostFree(sl.p);
+      sl.p = nullptr;
+      sl.bytes = 0;
+      size_t want = b < (size_t)(1 << 20) ? (size_t)(1 << 20) : b;
+      DF_HIP(hipHostMalloc(&sl.p, want, hipHostMallocDefault));
+      sl.bytes = want;
+    }
+    memcpy(sl.p, (const char*)host + off, b);
+    DF_HIP(hipMemcpyAsync((char*)dst + off, sl.p, b, hipMemcpyHostToDevice, g_stream));
+    if (!g_capture_open) {
+      DF_HIP(hipEventRecord(sl.done, g_stream));
+      sl.busy = true;
+    }
   }
   return DFHIP_OK;
 }

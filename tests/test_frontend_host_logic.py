@@ -112,3 +112,20 @@ def test_state_dict_roundtrip_excludes_bn_running_stats(cpu_oracle):
     m2.load_state_dict({k: v.numpy() for k, v in sd.items()})
     for k, v in m2.state_dict().items():
         assert np.array_equal(v.numpy(), sd[k].numpy()), k
+
+
+def test_dropout_mask_equals_numpy_binomial():
+    """Dropout draws its mask with a vectorised threshold instead of np.random.binomial; values and
+    generator state must match the reference's call (dropout.py:15-20) exactly."""
+    import numpy as np
+    from deepflows_amd.nn.modules.dropout import bernoulli_mask
+    for keep in (0.5, 0.1, 0.3, 0.7, 0.9, 0.25, 0.8, 0.999, 0.001):
+        for seed in range(4):
+            np.random.seed(seed)
+            a = np.random.binomial(1, keep, (37, 129)).astype(np.float32)
+            sa = np.random.get_state()
+            np.random.seed(seed)
+            b = bernoulli_mask(keep, (37, 129))
+            sb = np.random.get_state()
+            assert np.array_equal(a, b), (keep, seed)
+            assert sa[2] == sb[2] and np.array_equal(sa[1], sb[1]), (keep, seed)
