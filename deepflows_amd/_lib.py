@@ -46,6 +46,8 @@ _SIGS = {
     "dfhip_conv2d_forward_stats": [P, P, P, P] + [c_int] * 8 + [P, c_int, POINTER(c_int)],
     "dfhip_bn2d_forward_partials": [P, P, c_int] + [P] * 8 + [c_int, c_int, c_int, c_float, c_float],
     "dfhip_conv2d_wgrad": [P, P, P] + [c_int] * 8,
+    "dfhip_wgrad_group_begin": [],
+    "dfhip_wgrad_group_end": [],
     "dfhip_conv2d_dgrad": [P, P, P] + [c_int] * 9,
     "dfhip_conv2d_dgrad_add": [P, P, P, P] + [c_int] * 9,
     "dfhip_bn2d_forward_train": [P] * 8 + [c_int, c_int, c_int, c_float, c_float],

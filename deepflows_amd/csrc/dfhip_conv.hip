@@ -1410,6 +1410,7 @@ struct RGeo {
   unsigned m_dc, m_di;       // staging dY: BI*B4, B4
   SlabSum pend;              // slab sum of the previous weight gradient, done by this launch's blocks
   unsigned long long* stamps;
+  int single;                // grouped launches: one staging buffer instead of two
 };
 
 template <int NV>
@@ -1436,9 +1437,9 @@ __device__ __forceinline__ void lds_read_row(const float* p, float (&v)[NV]) {
 // and the final cross-wave sum moves half the bytes of an 8-wave block (one LDS round).
 constexpr int kRowsWaves = 4;
 
-template <int KS, int PAD, int STRIDE, int W, int OW, int UR>
-__global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int KS, int PAD, int STRIDE, int W, int OW, int UR, bool GROUPED>
+__device__ __forceinline__ void wgrad_rows_body(const RGeo& g, float* smem, const int bx, const int by, const int bz,
+                                                const int gdx, const int gdy, const int gdz) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   constexpr int T = KS * KS;
@@ -1452,15 +1453,15 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
 #ifdef DFHIP_STAMPS
 #define RG_STAMP()                                                                              \
   do {                                                                                          \
-    if (g.stamps && tid == 0 && stamp_i < 16)                                                   \
-      g.stamps[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + stamp_i++] = \
+    if (!GROUPED && g.stamps && tid == 0 && stamp_i < 16)                                       \
+      g.stamps[(((size_t)bz * gdy + by) * gdx + bx) * 32 + stamp_i++] =                         \
           __builtin_readcyclecounter();                                                         \
   } while (0)
 #else
 #define RG_STAMP() do { } while (0)
 #endif
   RG_STAMP();
-  const int c0 = blockIdx.y * 32, o0 = blockIdx.z * 32;
+  const int c0 = by * 32, o0 = bz * 32;
   const int cn = min(32, g.C - c0), on = min(32, g.O - o0);
   const int RL = g.RLr * W;                   // staged floats per (image, channel)
   const int BRBC = g.BR * OW;
@@ -1504,7 +1505,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
   const float* xg_nxt = nullptr;
   const float* yg_nxt = nullptr;
   auto group_base = [&](int gi) {
-    int grp = blockIdx.x + gi * gridDim.x;
+    int grp = bx + gi * gdx;
     int gimg = grp / g.gr;
     int n0 = gimg * g.BI;
     r0_nxt = (grp - gimg * g.gr) * g.BR;
@@ -1561,7 +1562,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
     }
   };
 
-  const int my_groups = (g.ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int my_groups = (g.ngroups - bx + gdx - 1) / gdx;
   RG_STAMP();
   f32x4 xsv[SVX], dsv[SVD];
   if (my_groups > 0) {
@@ -1576,9 +1577,9 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
   // ones are done on the spot.
   constexpr int PVB = 2;
   float4 pv[PVB][8];
-  const int nblk = gridDim.x * gridDim.y * gridDim.z;
-  const int me = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  if (g.pend.nvb > 0) {
+  const int nblk = gdx * gdy * gdz;
+  const int me = (bz * gdy + by) * gdx + bx;
+  if (!GROUPED && g.pend.nvb > 0) {
 #pragma unroll
     for (int j = 0; j < PVB; j++)
       if (me + j * nblk < g.pend.nvb) slab_sum_load(g.pend, me + j * nblk, pv[j]);
@@ -1601,8 +1602,11 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
   const int lane_d = l31 * g.DST + half * BRBC;
   const int lane_x = xbase + l31 * g.XST + half * RL;
 
+  // grouped launches may run on ONE staging buffer (two workgroups share a CU's LDS): the commit of
+  // the next group then waits for a barrier after the MFMAs instead of going to the other buffer
+  const bool single = GROUPED && g.single;
   for (int gi_ = 0; gi_ < my_groups; gi_++) {
-    const int buf = gi_ & 1;
+    const int buf = single ? 0 : (gi_ & 1);
     const bool more = gi_ + 1 < my_groups;
     if (more) {
       group_base(gi_ + 1);
@@ -1670,8 +1674,9 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
 #undef RG_LOAD
     }
     RG_STAMP();
+    if (single) __syncthreads();                   // every wave is done reading the only buffer
     if (more) {
-      float* B_ = smem + (buf ^ 1) * buf_floats;
+      float* B_ = smem + (single ? 0 : (buf ^ 1)) * buf_floats;
 #pragma unroll
       for (int u = 0; u < SVD; u++)
         if (ds_lx[u] >= 0) lds_put(B_, ds_lx[u], dsv[u]);
@@ -1685,38 +1690,128 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
     RG_STAMP();
   }
 
-  if (g.pend.nvb > 0) {
+  if (!GROUPED && g.pend.nvb > 0) {
 #pragma unroll
     for (int j = 0; j < PVB; j++)
       if (me + j * nblk < g.pend.nvb) slab_sum_finish(g.pend, me + j * nblk, pv[j], reinterpret_cast<float4*>(smem));
   }
 
-  // cross-wave sum through LDS in one round: red[t][wave][q][lane] (float4 = accumulator registers
-  // 4q..4q+3); wave w then sums the T (tap, q) combinations w, w + NW, ...
+  // cross-wave sum through LDS: red[t][wave][q][lane] (float4 = accumulator registers 4q..4q+3); wave w
+  // then sums the (tap, q = w) combinations.  One round for the stand-alone kernel; RR taps per
+  // round for grouped launches (the buffer is 16 KB per tap and two workgroups share the LDS).
   f32x4* red = reinterpret_cast<f32x4*>(smem);
-  float* slab = g.slabs + (((int64_t)blockIdx.x * gridDim.z + blockIdx.z) * gridDim.y + blockIdx.y) * (T * 1024);
+  float* slab = g.slabs + (((int64_t)bx * gdz + bz) * gdy + by) * (T * 1024);
+  constexpr int RR = GROUPED ? (T >= 3 ? 3 : 1) : T;
 #pragma unroll
-  for (int t = 0; t < T; t++)
+  for (int t0 = 0; t0 < T; t0 += RR) {
+    if (t0 > 0) __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-      red[((t * NW + wave) * 4 + q) * 64 + lane] = (f32x4){acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-  __syncthreads();
+    for (int t = t0; t < t0 + RR && t < T; t++)
 #pragma unroll
-  for (int cc = 0; cc < T; cc++) {
-    const int combo = cc * NW + wave;
-    const int t = combo >> 2, q = combo & 3;
-    f32x4 v = red[((t * NW + 0) * 4 + q) * 64 + lane];
+      for (int q = 0; q < 4; q++)
+        red[(((t - t0) * NW + wave) * 4 + q) * 64 + lane] =
+            (f32x4){acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+    __syncthreads();
 #pragma unroll
-    for (int w = 1; w < NW; w++) {
-      f32x4 u = red[((t * NW + w) * 4 + q) * 64 + lane];
-      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    for (int t = t0; t < t0 + RR && t < T; t++) {
+      const int q = wave;
+      f32x4 v = red[(((t - t0) * NW + 0) * 4 + q) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < NW; w++) {
+        f32x4 u = red[(((t - t0) * NW + w) * 4 + q) * 64 + lane];
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      *reinterpret_cast<f32x4*>(slab + (int64_t)t * 1024 + (q * 64 + lane) * 4) = v;
     }
-    *reinterpret_cast<f32x4*>(slab + (int64_t)t * 1024 + (q * 64 + lane) * 4) = v;
   }
   RG_STAMP();
 #undef RG_STAMP
 }
 
+
+
+template <int KS, int PAD, int STRIDE, int W, int OW, int UR>
+__global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  wgrad_rows_body<KS, PAD, STRIDE, W, OW, UR, false>(g, smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y,
+                                                    gridDim.z);
+}
+
+// ---------------------------------------------------------------------------------------
+// grouped weight gradient: ONE launch for the weight gradients of many layers (they depend only on
+// tensors the backward sweep has already produced, so the front end may queue them and flush at the
+// end of backward()).  A layer's (pixel slab, channel tile, output tile) workgroups are the row-unit
+// kernel above; the launch concatenates the layers' workgroups.  What this buys over one launch per
+// layer: no launch floor per layer, and with two workgroups resident per CU (LDS <= 80 KB, <= 256
+// registers) one workgroup's first loads / cross-wave sum / slab stores hide behind the other's
+// MFMAs -- neighbours are at different phases because they start at different times.  Each layer is
+// cut into fewer, longer workgroups than a stand-alone launch would need to fill the chip, which
+// also divides the slab traffic.  k_wgrad_group_sum then sums every layer's slabs in one launch.
+// ---------------------------------------------------------------------------------------
+constexpr int kMaxGroup = 24;
+struct GDesc {
+  const float* x;
+  const float* dy;
+  float* slabs;
+  int N, C, H, O, oh;
+  int BI, BR, gr, ngroups, RLr, XST, DST, units;
+  unsigned m_br, m_xc, m_xi, m_dc, m_di;
+  int single, kind, ps, CT, OT;
+  int wg_end;                // workgroups of layers 0..this one (exclusive end of this layer's range)
+};
+struct WGroup {
+  int n;
+  GDesc d[kMaxGroup];
+};
+struct SGroup {
+  int n;
+  int vb_end[kMaxGroup];
+  SlabSum s[kMaxGroup];
+};
+
+#define DF_ROWS_KINDS(X) \
+  X(0, 3, 1, 1, 16, 16, 1) X(1, 3, 1, 1, 8, 8, 2) X(2, 3, 1, 1, 4, 4, 4) X(3, 3, 1, 1, 2, 2, 2)      \
+  X(4, 3, 1, 2, 16, 8, 1) X(5, 3, 1, 2, 8, 4, 2) X(6, 3, 1, 2, 4, 2, 2)                              \
+  X(7, 1, 0, 2, 16, 8, 1) X(8, 1, 0, 2, 8, 4, 1) X(9, 1, 0, 2, 4, 2, 1)
+
+// (one wave per SIMD, like the stand-alone kernel: the row-unit body needs ~470 registers, and built
+// for two resident workgroups -- 256 registers -- it spills 120-210 of them)
+__global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  int li = 0;
+  while (li + 1 < a.n && b >= a.d[li].wg_end) li++;
+  const GDesc& d = a.d[li];
+  const int local = b - (li ? a.d[li - 1].wg_end : 0);
+  const int bx = local % d.ps, rest = local / d.ps;
+  const int by = rest % d.CT, bz = rest / d.CT;
+  RGeo g;
+  g.x = d.x; g.dy = d.dy; g.slabs = d.slabs;
+  g.N = d.N; g.C = d.C; g.H = d.H; g.O = d.O; g.oh = d.oh;
+  g.BI = d.BI; g.BR = d.BR; g.gr = d.gr; g.ngroups = d.ngroups; g.RLr = d.RLr;
+  g.XST = d.XST; g.DST = d.DST; g.units = d.units;
+  g.m_br = d.m_br; g.m_xc = d.m_xc; g.m_xi = d.m_xi; g.m_dc = d.m_dc; g.m_di = d.m_di;
+  g.pend.nvb = 0;
+  g.stamps = nullptr;
+  g.single = d.single;
+  switch (d.kind) {
+#define DF_CASE(ID, KSV, PADV, SV, WV, OWV, URV)                                                   \
+  case ID:                                                                                         \
+    wgrad_rows_body<KSV, PADV, SV, WV, OWV, URV, true>(g, smem, bx, by, bz, d.ps, d.CT, d.OT);     \
+    break;
+    DF_ROWS_KINDS(DF_CASE)
+#undef DF_CASE
+    default: break;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_group_sum(SGroup a) {
+  __shared__ float4 part[256];
+  const int b = blockIdx.x;
+  int li = 0;
+  while (li + 1 < a.n && b >= a.vb_end[li]) li++;
+  slab_sum_vblock(a.s[li], b - (li ? a.vb_end[li - 1] : 0), part);
+}
 
 // out[i] = sum_s slabs[s][i], summed in a fixed order.  A block owns 256 consecutive elements
 // (64 lanes x float4); its 16 waves take the slabs s = w, w+16, ... with 8 loads in flight,
@@ -2188,8 +2283,36 @@ int launch_wgrad_rows(RGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
     g_def.active = false;
     g_def.slot = -1;
   }
+  static int stamp_mode = -1;
+  if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
+  const size_t nb = (size_t)ps * CT * OT;
+  if (stamp_mode) {
+    g.stamps = (unsigned long long*)workspace2(nb * 32 * 8);
+    (void)hipMemsetAsync(g.stamps, 0, nb * 32 * 8, stream());
+  }
   hipLaunchKernelGGL((k_conv_wgrad_rows<KS, PAD, STRIDE, W, OW, UR>), grid, dim3(64 * kRowsWaves), lds, stream(), g);
   DF_LAUNCH_CHECK();
+  if (stamp_mode) {
+    std::vector<unsigned long long> h(nb * 32);
+    (void)hipStreamSynchronize(stream());
+    (void)hipMemcpy(h.data(), g.stamps, nb * 32 * 8, hipMemcpyDeviceToHost);
+    unsigned long long tmin = ~0ull, tmax = 0, smax = 0;
+    double seg[32] = {0};
+    int nseg = 0;
+    for (size_t b = 0; b < nb; b++) {
+      const unsigned long long* r = &h[b * 32];
+      int n = 0;
+      while (n < 32 && r[n]) n++;
+      if (!n) continue;
+      tmin = std::min(tmin, r[0]); smax = std::max(smax, r[0]); tmax = std::max(tmax, r[n - 1]);
+      for (int i = 1; i < n; i++) seg[i] += (double)(r[i] - r[i - 1]);
+      nseg = std::max(nseg, n);
+    }
+    fprintf(stderr, "[stampr] k %d W %d UR %d grid %d x %d x %d groups %d units %d (BI %d BR %d) lds %zu pend %d; span %lld last start +%lld; mean segments:",
+            KS, W, UR, ps, CT, OT, g.ngroups, g.units, g.BI, g.BR, lds, g.pend.nvb, (long long)(tmax - tmin), (long long)(smax - tmin));
+    for (int i = 1; i < nseg; i++) fprintf(stderr, " %.0f", seg[i] / nb);
+    fprintf(stderr, "\n");
+  }
   SlabSum mine = make_slab_sum(g.slabs, dw, ps, OT, CT, T, g.O, g.C);
   if (!defer) return launch_slab_sum(mine);
   g_def.a = mine;
@@ -2200,6 +2323,68 @@ int launch_wgrad_rows(RGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
 
 // LDS channel stride: the smallest value >= n that is r (mod 64)
 static int bank_stride_r(int n, int r) { return ((n - r + 63) / 64) * 64 + r; }
+
+// ---- grouped weight gradients (dfhip_wgrad_group_begin / _end): queue + one launch ----
+struct GQueued {
+  GDesc d;
+  float* dw;
+  int T;
+  size_t lds;
+  double flops, bytes;
+};
+std::vector<GQueued> g_queue;
+bool g_group_on = false;
+
+int group_flush() {
+  if (g_queue.empty()) return DFHIP_OK;
+  std::vector<GQueued> q;
+  q.swap(g_queue);                                  // (re-entrancy: scratch() may ask for a flush)
+  size_t total = 0, lds = 0;
+  for (auto& e : q) {
+    total += (size_t)e.d.ps * e.d.OT * e.d.CT * e.T * 1024 * sizeof(float);
+    lds = std::max(lds, e.lds);
+  }
+  float* base = workspace_slot(0, total);
+  if (!base) return DFHIP_OUT_OF_MEMORY;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    DF_HIP(hipFuncSetAttribute((const void*)k_wgrad_group, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)std::max(lds, (size_t)65536)));
+    attr_lds = std::max(lds, (size_t)65536);
+  }
+  for (size_t i0 = 0; i0 < q.size(); i0 += kMaxGroup) {
+    const int n = (int)std::min<size_t>(kMaxGroup, q.size() - i0);
+    WGroup wg = {};
+    SGroup sg = {};
+    wg.n = sg.n = n;
+    int wgs = 0, vbs = 0;
+    double flops = 0, bytes = 0, sbytes = 0;
+    for (int i = 0; i < n; i++) {
+      GQueued& e = q[i0 + i];
+      e.d.slabs = base;
+      base += (size_t)e.d.ps * e.d.OT * e.d.CT * e.T * 1024;
+      wgs += e.d.ps * e.d.CT * e.d.OT;
+      e.d.wg_end = wgs;
+      wg.d[i] = e.d;
+      sg.s[i] = make_slab_sum(e.d.slabs, e.dw, e.d.ps, e.d.OT, e.d.CT, e.T, e.d.O, e.d.C);
+      vbs += sg.s[i].nvb;
+      sg.vb_end[i] = vbs;
+      flops += e.flops; bytes += e.bytes;
+      sbytes += (double)(e.d.ps + 1) * e.d.OT * e.d.CT * e.T * 4096.0;
+    }
+    {
+      ProfScope prof("conv2d_wgrad_grouped", flops, bytes);
+      hipLaunchKernelGGL(k_wgrad_group, dim3((unsigned)wgs), dim3(64 * kRowsWaves), lds, stream(), wg);
+      DF_LAUNCH_CHECK();
+    }
+    {
+      ProfScope prof("wgrad_slab_sum", 0.0, sbytes);
+      hipLaunchKernelGGL(k_wgrad_group_sum, dim3((unsigned)vbs), dim3(256), 0, stream(), sg);
+      DF_LAUNCH_CHECK();
+    }
+  }
+  return DFHIP_OK;
+}
 
 // returns -1 when the shape is not one the row-unit kernel is built for
 int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
@@ -2212,14 +2397,21 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
   if (!(W == 16 || W == 8 || W == 4 || (W == 2 && stride == 1))) return -1;
   if (ow != (W + 2 * pad - k) / stride + 1 || (stride == 2 && ow * 2 != W) || stride > 2) return -1;
   if ((H * W) % 4 != 0 || (oh * ow) % 4 != 0) return -1;
+  const bool grouped = g_group_on;
   const int CT = (int)df_ceil_div(C, 32), OT = (int)df_ceil_div(O, 32);
-  const int ps0 = std::max(1, num_cus() / (CT * OT));
-  static int gpb = getenv("DFHIP_WGRAD_GPB") ? atoi(getenv("DFHIP_WGRAD_GPB")) : 2;   // groups per block aimed at
-  const int UR0 = k == 1 ? 1 : (stride == 1 ? (W == 16 ? 1 : (W == 8 ? 2 : (W == 4 ? 4 : 2))) : (W == 16 ? 1 : 2));
-  const double per_block = (double)(N / 2) * (oh / UR0) / ps0;
-  const double target = std::max((double)kRowsWaves, per_block / std::max(1, gpb));
-  // output rows per unit (must match the instantiations below)
+  // pixel slabs per (channel tile, output tile): a stand-alone launch needs one workgroup per CU;
+  // a grouped launch has the other layers to fill the chip with and takes longer workgroups
+  static int gdiv = getenv("DFHIP_WGRAD_GROUP_DIV") ? atoi(getenv("DFHIP_WGRAD_GROUP_DIV")) : 4;
+  const int ps0 = std::max(1, num_cus() / (CT * OT) / (grouped ? std::max(1, gdiv) : 1));
+  static int gpb1 = getenv("DFHIP_WGRAD_GPB") ? atoi(getenv("DFHIP_WGRAD_GPB")) : 2;   // groups per block aimed at
+  static int gpbg = getenv("DFHIP_WGRAD_GROUP_GPB") ? atoi(getenv("DFHIP_WGRAD_GROUP_GPB")) : 2;
+  const int gpb = grouped ? gpbg : gpb1;
+  // output rows per unit (must match the instantiations)
   const int UR = k == 1 ? 1 : (stride == 1 ? (W == 16 ? 1 : (W == 8 ? 2 : (W == 4 ? 4 : 2))) : (W == 16 ? 1 : 2));
+  const double per_block = (double)(N / 2) * (oh / UR) / ps0;
+  const double target = std::max((double)kRowsWaves, per_block / std::max(1, gpb));
+  static int gcap = getenv("DFHIP_WGRAD_GROUP_LDS") ? atoi(getenv("DFHIP_WGRAD_GROUP_LDS")) : 160;
+  const size_t lds_cap = grouped ? (size_t)gcap * 1024 : 160 * 1024;
   RGeo g = {};
   double best = 1e30;
   size_t best_lds = 0;
@@ -2237,13 +2429,21 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
       const int xv = (int)df_ceil_div(32 * BI * (RL / 4), 64 * kRowsWaves), dv = (int)df_ceil_div(32 * BI * (BRBC / 4), 64 * kRowsWaves);
       if ((xv > 10 || dv > 4) && (N / BI) * gr > ps0) continue;  // later groups must fit the in-flight vectors
       const int XST = bank_stride_r(BI * RL, W >= 4 ? 4 : 2), DST = bank_stride_r(BI * BRBC, ow >= 4 ? 4 : 2);
-      const size_t red = (size_t)k * k * kRowsWaves * 4 * 64 * 16;
-      const size_t lds = std::max((size_t)2 * 32 * (XST + DST) * 4, red);
-      if (lds > 160 * 1024) break;
-      double score = std::fabs(std::log((double)units / target)) - 1e-3 * BR;
+      const size_t stage = (size_t)32 * (XST + DST) * 4;
+      const size_t red = grouped ? (size_t)(k == 3 ? 3 : 1) * kRowsWaves * 4 * 64 * 16
+                                 : (size_t)k * k * kRowsWaves * 4 * 64 * 16;
+      int single = 0;
+      size_t lds = std::max(2 * stage, red);
+      if (grouped && lds > lds_cap) {
+        single = 1;
+        lds = std::max(stage, red);
+      }
+      if (lds > lds_cap) break;
+      double score = std::fabs(std::log((double)units / target)) - 1e-3 * BR + (single ? 0.05 : 0.0);
       if (score < best) {
         best = score; best_lds = lds;
         g.BI = BI; g.BR = BR; g.gr = gr; g.RLr = RLr; g.XST = XST; g.DST = DST; g.units = units;
+        g.single = single;
       }
     }
   }
@@ -2258,12 +2458,31 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
   g.m_dc = magic_u32((unsigned)(g.BI * B4));
   g.m_di = magic_u32((unsigned)B4);
   const int ps = std::max(1, std::min(g.ngroups, ps0));
-#define DF_ROWS(KSV, PADV, SV, WV, OWV, URV) \
+  if (grouped) {
+    int kind = -1;
+#define DF_KIND(ID, KSV, PADV, SV, WV, OWV, URV) \
+  if (k == KSV && stride == SV && W == WV && UR == URV) kind = ID;
+    DF_ROWS_KINDS(DF_KIND)
+#undef DF_KIND
+    if (kind < 0) return -1;
+    GQueued e = {};
+    GDesc& d = e.d;
+    d.x = x; d.dy = dy; d.slabs = nullptr;
+    d.N = N; d.C = C; d.H = H; d.O = O; d.oh = oh;
+    d.BI = g.BI; d.BR = g.BR; d.gr = g.gr; d.ngroups = g.ngroups; d.RLr = g.RLr;
+    d.XST = g.XST; d.DST = g.DST; d.units = g.units;
+    d.m_br = g.m_br; d.m_xc = g.m_xc; d.m_xi = g.m_xi; d.m_dc = g.m_dc; d.m_di = g.m_di;
+    d.single = g.single; d.kind = kind; d.ps = ps; d.CT = CT; d.OT = OT;
+    e.dw = dw; e.T = k * k; e.lds = best_lds;
+    e.flops = 2.0 * N * oh * ow * (double)C * k * k * O;
+    e.bytes = 4.0 * ((double)N * C * H * W + (double)O * C * k * k + (double)N * O * oh * ow);
+    g_queue.push_back(e);
+    return DFHIP_OK;
+  }
+#define DF_ROWS(ID, KSV, PADV, SV, WV, OWV, URV) \
   if (k == KSV && stride == SV && W == WV && UR == URV)  \
     return launch_wgrad_rows<KSV, PADV, SV, WV, OWV, URV>(g, dw, best_lds, ps, CT, OT);
-  DF_ROWS(3, 1, 1, 16, 16, 1) DF_ROWS(3, 1, 1, 8, 8, 2) DF_ROWS(3, 1, 1, 4, 4, 4) DF_ROWS(3, 1, 1, 2, 2, 2)
-  DF_ROWS(3, 1, 2, 16, 8, 1) DF_ROWS(3, 1, 2, 8, 4, 2) DF_ROWS(3, 1, 2, 4, 2, 2)
-  DF_ROWS(1, 0, 2, 16, 8, 1) DF_ROWS(1, 0, 2, 8, 4, 1) DF_ROWS(1, 0, 2, 4, 2, 1)
+  DF_ROWS_KINDS(DF_ROWS)
 #undef DF_ROWS
   return -1;
 }
@@ -2402,14 +2621,21 @@ int run_wgrad_tap(const float* x, const float* dy, float* dw, int N, int C, int 
 
 namespace dfhip {
 int flush_deferred() {
+  if (!g_queue.empty()) {
+    int st = group_flush();
+    if (st != DFHIP_OK) return st;
+  }
   if (!g_def.active) return DFHIP_OK;
   g_def.active = false;
   g_def.slot = -1;
   return launch_slab_sum(g_def.a);
 }
 bool deferred_touches(const void* p) {
-  if (!g_def.active || !p) return false;
+  if (!p) return false;
   const float* q = (const float*)p;
+  for (const auto& e : g_queue)
+    if (q >= e.dw && q < e.dw + (int64_t)e.d.O * e.d.C * e.T) return true;
+  if (!g_def.active) return false;
   const float* lo = g_def.a.dw;
   return q >= lo && q < lo + (int64_t)g_def.a.O * g_def.a.C * g_def.a.T;
 }
@@ -2523,6 +2749,12 @@ int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C,
   int s = check_conv_args("conv2d_wgrad", N, C, H, W, O, k, stride, pad, oh, ow);
   if (s != DFHIP_OK) return s;
   DF_CHECK_ARG(x && dy && dw, "conv2d_wgrad: null array");
+  if (g_group_on) {        // queued for the grouped launch (shapes the row-unit kernel does not take run now)
+    int st = run_wgrad_rows(x, dy, dw, N, C, H, W, O, oh, ow, k, stride, pad);
+    if (st >= 0) return st;
+    st = flush_deferred();   // (outside this call's profiling bracket)
+    if (st != DFHIP_OK) return st;
+  }
   double flops = 2.0 * N * oh * ow * (double)C * k * k * O;
   double bytes = 4.0 * ((double)N * C * H * W + (double)O * C * k * k + (double)N * O * oh * ow);
   ProfScope prof("conv2d_wgrad_igemm", flops, bytes);
@@ -2569,6 +2801,23 @@ int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C,
   if (OT == 1) return launch_wgrad<1, 1>(g, dw);
   if (KT == 4) return launch_wgrad<2, 4>(g, dw);
   return launch_wgrad<2, 1>(g, dw);
+}
+
+// Grouped weight gradients.  Between _begin and _end, dfhip_conv2d_wgrad calls whose shape the
+// row-unit kernel takes are QUEUED instead of launched; _end (or any entry point that flushes
+// deferred work, or that touches a queued dw) runs all of them as one launch plus one slab-sum
+// launch.  Contract: the x and dy arrays of a queued call stay allocated and unmodified until the
+// flush; dw holds the gradient only after it.
+int dfhip_wgrad_group_begin(void) {
+  DF_INIT();
+  g_group_on = true;
+  return DFHIP_OK;
+}
+
+int dfhip_wgrad_group_end(void) {
+  DF_INIT_KEEP();
+  g_group_on = false;
+  return flush_deferred();
 }
 
 }  // extern "C"

@@ -15,6 +15,7 @@ backend_src/ndarray_backend_cuda.cu:515-717).
 Every method is a thin ctypes call into libdfhip.so; nothing is computed in Python.
 """
 import ctypes
+import os
 from ctypes import byref, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 import numpy as np
@@ -217,6 +218,28 @@ class HipModule:
 
     def conv2d_wgrad(self, x, dy, dw, N, C, H, W, O, k, stride, pad):
         _lib.check(self._lib.dfhip_conv2d_wgrad(x.ptr, dy.ptr, dw.ptr, N, C, H, W, O, k, stride, pad))
+        if self._wgrad_hold is not None:
+            # the call may only have been queued: x and dy must outlive the grouped launch
+            self._wgrad_hold.append((x, dy, dw))
+
+    # Grouped weight gradients (dfhip_wgrad_group_begin / _end): Tensor.backward() brackets its
+    # sweep with these, so the weight gradients of all layers run as one launch when it ends.
+    _wgrad_hold = None
+
+    def wgrad_group_begin(self):
+        if not self.wgrad_grouping:
+            return False
+        _lib.check(self._lib.dfhip_wgrad_group_begin())
+        self._wgrad_hold = []
+        return True
+
+    def wgrad_group_end(self):
+        try:
+            _lib.check(self._lib.dfhip_wgrad_group_end())
+        finally:
+            self._wgrad_hold = None
+
+    wgrad_grouping = os.environ.get("DF_WGRAD_GROUP", "1") != "0"
 
     def conv2d_dgrad(self, dy, w, dx, N, C, H, W, O, k, stride, pad, mode=None):
         mode = self.conv_dgrad_mode if mode is None else mode

@@ -210,6 +210,19 @@ class Tensor:
             return
         if self.data.ndim != 1:
             raise ValueError("backward should be called only on a scalar.")
+        # a device may queue the weight gradients of the sweep and run them as one launch at its
+        # end (hip: dfhip_wgrad_group_begin/_end); nothing reads a parameter's .grad before that
+        group_begin = getattr(self.device.mod, "wgrad_group_begin", None)
+        grouping = bool(group_begin()) if group_begin is not None else False
+        try:
+            self._backward_sweep(milestone)
+        finally:
+            if grouping:
+                self.device.mod.wgrad_group_end()
+        if not retain_graph:
+            Graph.free_graph()
+
+    def _backward_sweep(self, milestone):
         with no_grad():
             self.grad = backend_api.ones_like(self.data)
             start = len(Graph.node_list) - 1
@@ -239,8 +252,6 @@ class Tensor:
                     parent.grad = contrib if parent.grad is None else parent.grad + contrib
                 if not node.is_leaf:
                     node.grad = None
-        if not retain_graph:
-            Graph.free_graph()
 
     def zero_grad(self):
         self.grad = None

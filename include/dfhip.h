@@ -130,6 +130,16 @@ int dfhip_conv2d_dgrad_add(const float* dy, const float* w, const float* add, fl
 /* weight gradient: tensor.py:716 (A^T . dC) for the conv GEMM; dw (O,C,k,k)            */
 int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw,
                        int N, int C, int H, int W, int O, int k, int stride, int pad);
+
+/* Grouped weight gradients (extension; the reference computes A^T . dC inside each node's grad_fn,
+ * tensor.py:716, but nothing reads a weight's .grad before backward() returns, tensor.py:421-499).
+ * Between _begin and _end, dfhip_conv2d_wgrad calls are queued where the fast kernel takes the
+ * shape, and _end -- or any call that touches a queued dw -- runs all of them as ONE launch plus
+ * one slab-sum launch.  The x and dy arrays of a queued call must stay allocated and unmodified
+ * until then.                                                                                   */
+int dfhip_wgrad_group_begin(void);
+int dfhip_wgrad_group_end(void);
+
 /* conv2d_forward that also leaves BatchNorm partials of y behind: partials[rows][O][3] =
  * (count, mean, centred second moment) of every output channel over the pixels of one workgroup
  * (rows <= cap_rows).  *rows_out = 0 when the shape was served by a kernel without this epilogue;

@@ -147,3 +147,62 @@ def test_elementwise_checksum_at_scale(hip_device):
     s = mod.Array(1)
     mod.reduce_sum(ah, s, n)
     assert abs(float(_back(mod, s, (1,))[0]) - float(a.astype(np.float64).sum())) < 1e-4 * np.abs(a).sum()
+
+
+def test_grouped_wgrad_all_layers(hip_device):
+    """dfhip_wgrad_group_begin/_end: the weight gradients of every ResNet-18 layer shape queued and
+    run as one launch equal the stand-alone launches (fp32 summation order differs) and the oracle;
+    a call that touches a queued dw (here: reading it back) flushes the queue by itself."""
+    mod = hip_device.mod
+    rng = np.random.default_rng(11)
+    jobs = []
+    for name, (C, H, W, O, k, s, p) in LAYERS.items():
+        n = 64 if name == "cnn2" else N
+        oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        x = rng.standard_normal((n, C, H, W)).astype(np.float32)
+        dy = rng.standard_normal((n, O, oh, ow)).astype(np.float32)
+        geo = (n, C, H, W, O, k, s, p)
+        xh, dyh = _arr(mod, x), _arr(mod, dy)
+        alone = mod.Array(O * C * k * k)
+        mod.conv2d_wgrad(xh, dyh, alone, *geo)
+        jobs.append((name, x, dy, geo, xh, dyh, _back(mod, alone, (O, C, k, k)).copy()))
+    assert mod.wgrad_group_begin()
+    outs = []
+    for name, x, dy, geo, xh, dyh, _ in jobs:
+        dwh = mod.Array(geo[4] * geo[1] * geo[5] * geo[5])
+        mod.conv2d_wgrad(xh, dyh, dwh, *geo)
+        outs.append(dwh)
+    mod.wgrad_group_end()
+    for (name, x, dy, geo, xh, dyh, alone), dwh in zip(jobs, outs):
+        got = _back(mod, dwh, alone.shape)
+        assert_close(got, alone, 2e-5, name + " grouped vs stand-alone")
+        if name in ("l1", "l3", "l4d", "l2a"):
+            assert_close(got, R.conv2d_wgrad(x, dy, geo[5], geo[6], geo[7]), 1e-4, name + " grouped vs oracle")
+    # a second group, flushed implicitly by the read-back of one of its results
+    assert mod.wgrad_group_begin()
+    name, x, dy, geo, xh, dyh, alone = jobs[1]
+    dwh = mod.Array(alone.size)
+    mod.conv2d_wgrad(xh, dyh, dwh, *geo)
+    got = _back(mod, dwh, alone.shape)              # to_numpy touches dw -> flush
+    mod.wgrad_group_end()
+    assert_close(got, alone, 2e-5, "implicit flush")
+
+
+def test_grouped_wgrad_small_batches(hip_device):
+    """ragged / small batches through the grouped path (N = 2, 6, 10: fewer groups than slabs)."""
+    mod = hip_device.mod
+    rng = np.random.default_rng(12)
+    for n in (2, 6, 10):
+        assert mod.wgrad_group_begin()
+        held = []
+        for name in ("l1", "l2a", "l3", "l4", "l3d"):
+            C, H, W, O, k, s, p = LAYERS[name]
+            oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+            x = rng.standard_normal((n, C, H, W)).astype(np.float32)
+            dy = rng.standard_normal((n, O, oh, ow)).astype(np.float32)
+            xh, dyh, dwh = _arr(mod, x), _arr(mod, dy), mod.Array(O * C * k * k)
+            mod.conv2d_wgrad(xh, dyh, dwh, n, C, H, W, O, k, s, p)
+            held.append((name, x, dy, k, s, p, xh, dyh, dwh, (O, C, k, k)))
+        mod.wgrad_group_end()
+        for name, x, dy, k, s, p, xh, dyh, dwh, shape in held:
+            assert_close(_back(mod, dwh, shape), R.conv2d_wgrad(x, dy, k, s, p), 1e-4, f"{name} n={n} grouped")

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--only", default="")
+    ap.add_argument("--grouped", action="store_true")
     args = ap.parse_args()
     dev = backend_api.Device("hip")
     mod = dev.mod
@@ -58,6 +59,31 @@ def main():
             if not (name == "stem" and op.startswith("dgrad")):
                 total[op] = total.get(op, 0.0) + us * COUNT[name]
     print("per-step totals (us):", {k: round(v, 1) for k, v in total.items()})
+    if args.grouped:
+        # the weight gradients of one backward sweep (every layer, with multiplicity) as ONE grouped launch
+        jobs, flops = [], 0.0
+        for name, C, H, W, O, k, s, p in LAYERS:
+            oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+            for _ in range(COUNT[name]):
+                h = [mod.Array(N * C * H * W), mod.Array(N * O * oh * ow), mod.Array(O * C * k * k)]
+                mod.from_numpy(rng.standard_normal((N, C, H, W)).astype(np.float32), h[0])
+                mod.from_numpy(rng.standard_normal((N, O, oh, ow)).astype(np.float32), h[1])
+                jobs.append((h, (N, C, H, W, O, k, s, p)))
+                flops += 2.0 * N * oh * ow * C * k * k * O
+        def sweep():
+            mod.wgrad_group_begin()
+            for h, geo in jobs:
+                mod.conv2d_wgrad(h[0], h[1], h[2], *geo)
+            mod.wgrad_group_end()
+        for _ in range(3):
+            sweep()
+        e0, e1 = mod.event(), mod.event()
+        mod.event_record(e0)
+        for _ in range(args.iters):
+            sweep()
+        mod.event_record(e1)
+        us = mod.event_elapsed_ms(e0, e1) * 1e3 / args.iters
+        print(f"grouped wgrad sweep (20 layers incl. stem stand-alone): {us:.1f} us, {flops / us / 1e6:.2f} TFLOP/s")
 
 
 if __name__ == "__main__":
