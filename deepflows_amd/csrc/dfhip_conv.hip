@@ -433,10 +433,41 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
     if (ch + 1 < nchunks) DF_ISSUE(ch + 1);    // lands while this chunk is in the matrix cores
     const float* Xb = Xs0 + buf * xs_floats + c_first * PEp;
     const float* aq = Ws0 + buf * ws_floats + (MODE == 0 ? c_first * k2 * WT + l31 : c_first * RS + l31 * k2);
+    if constexpr (MODE != 2 && NPK > 0) {
+      // forward / accumulate: all taps straight-line (whole-wave-invalid taps are rare here), the
+      // operands of tap t+1 are read into a second register set before the MFMAs of tap t issue
+      float av[2][NPK ? NPK : 1], bv[2][NPK ? NPK : 1];
+#pragma unroll
+      for (int p = 0; p < NPK; p++) {
+        av[0][p] = aq[p * astep];
+        bv[0][p] = (Xb + poff[0])[p * bstep];
+      }
+#pragma unroll
+      for (int t = 0; t < k2; t++) {
+        if (t + 1 < k2) {
+          const float* bp = Xb + poff[t + 1];
+          const float* ap = aq + (MODE == 0 ? (t + 1) * WT : (t + 1));
+#pragma unroll
+          for (int p = 0; p < NPK; p++) {
+            av[(t + 1) & 1][p] = ap[p * astep];
+            bv[(t + 1) & 1][p] = bp[p * bstep];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool ok = (vmask >> t) & 1u;
+#pragma unroll
+        for (int p = 0; p < NPK; p++) {
+          const float b = ok ? bv[t & 1][p] : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][p], b, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else
 #pragma unroll
     for (int t = 0; t < k2; t++) {
       const bool ok = (vmask >> t) & 1u;
-      if (__ballot(ok) != 0ull) {              // else: nobody in the wave reads through this tap
+      // overwrite mode: a tap nobody in the wave selected is skipped (most are)
+      if (MODE != 2 || __ballot(ok) != 0ull) {
         const float* bp = Xb + poff[t];
         const float* ap = aq + (MODE == 0 ? t * WT : t);
         if (NPK) {
@@ -1478,6 +1509,10 @@ __device__ __forceinline__ void wgrad_rows_body(const RGeo& g, float* smem, cons
     for (int rr = 0; rr < 16; rr++) acc[t][rr] = 0.0f;
 
   // ---- staging: 16-byte copies, item v -> (channel, image, float4 of the contiguous run) ----
+  // A thread without an item (v >= items) takes item 0 again: same source, same LDS destination,
+  // same value as its owner writes.  Every load then has an UNCONDITIONAL consumer -- with the store
+  // under a branch the compiler's wait-count pass leaves the load "pending" on the skipped path and
+  // makes the first LDS read of the next group wait for the prefetch that was just issued.
   auto x_item = [&](int v, unsigned& src, int& lx) {
     int c = (int)fast_div((unsigned)v, g.m_xc);
     int rem = v - c * (g.BI * RL4);
@@ -1520,13 +1555,11 @@ __device__ __forceinline__ void wgrad_rows_body(const RGeo& g, float* smem, cons
   for (int u = 0; u < SVX; u++) {
     int v = tid + NT * u;
     x_item(v < xitems ? v : 0, xs_src[u], xs_lx[u]);
-    if (v >= xitems) xs_lx[u] = -1;
   }
 #pragma unroll
   for (int u = 0; u < SVD; u++) {
     int v = tid + NT * u;
     d_item(v < ditems ? v : 0, ds_src[u], ds_lx[u]);
-    if (v >= ditems) ds_lx[u] = -1;
   }
   // everything beyond SV vectors per thread is copied synchronously, six X and four dY vectors
   // per thread in flight per pass (host: groups after the first fit the SV vectors)
@@ -1540,7 +1573,6 @@ __device__ __forceinline__ void wgrad_rows_body(const RGeo& g, float* smem, cons
         int v = vx + NT * u;
         unsigned src;
         x_item(v < xitems ? v : 0, src, lx[u]);
-        if (v >= xitems) lx[u] = -1;
         tx[u] = *reinterpret_cast<const f32x4*>(xg_nxt + src);
       }
 #pragma unroll
@@ -1548,15 +1580,12 @@ __device__ __forceinline__ void wgrad_rows_body(const RGeo& g, float* smem, cons
         int v = vd + NT * u;
         unsigned src;
         d_item(v < ditems ? v : 0, src, ld[u]);
-        if (v >= ditems) ld[u] = -1;
         td[u] = *reinterpret_cast<const f32x4*>(yg_nxt + src);
       }
 #pragma unroll
-      for (int u = 0; u < 6; u++)
-        if (lx[u] >= 0) lds_put(base, lx[u], tx[u]);
+      for (int u = 0; u < 6; u++) lds_put(base, lx[u], tx[u]);
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (ld[u] >= 0) lds_put(base, ld[u], td[u]);
+      for (int u = 0; u < 4; u++) lds_put(base, ld[u], td[u]);
       vx += NT * 6;
       vd += NT * 4;
     }
@@ -1588,12 +1617,10 @@ __device__ __forceinline__ void wgrad_rows_body(const RGeo& g, float* smem, cons
   }
   if (my_groups > 0) {
 #pragma unroll
-    for (int u = 0; u < SVD; u++)
-      if (ds_lx[u] >= 0) lds_put(smem, ds_lx[u], dsv[u]);
+    for (int u = 0; u < SVD; u++) lds_put(smem, ds_lx[u], dsv[u]);
 #pragma unroll
-    for (int u = 0; u < SVX; u++)
-      if (xs_lx[u] >= 0) lds_put(smem, xs_lx[u], xsv[u]);
-    stage_rest(smem, SVX, SVD);
+    for (int u = 0; u < SVX; u++) lds_put(smem, xs_lx[u], xsv[u]);
+    if constexpr (!GROUPED) stage_rest(smem, SVX, SVD);   // grouped plans always fit the SV vectors
   }
   su_lo_cur = su_lo_nxt; r0_cur = r0_nxt;
   __syncthreads();
@@ -1608,6 +1635,7 @@ __device__ __forceinline__ void wgrad_rows_body(const RGeo& g, float* smem, cons
   for (int gi_ = 0; gi_ < my_groups; gi_++) {
     const int buf = single ? 0 : (gi_ & 1);
     const bool more = gi_ + 1 < my_groups;
+    bool committed = false;
     if (more) {
       group_base(gi_ + 1);
 #pragma unroll
@@ -1621,6 +1649,7 @@ __device__ __forceinline__ void wgrad_rows_body(const RGeo& g, float* smem, cons
       // a source row (of the NXR under a unit) is read only if some (output row, tap row) uses it
       float a_n[UR][OW], b_n[NXR][W];
       int rs_n = 0;
+      committed = false;
 #define RG_LOAD(u_)                                                                              \
   do {                                                                                           \
     const int uu_ = (u_);                                                                        \
@@ -1667,6 +1696,17 @@ __device__ __forceinline__ void wgrad_rows_body(const RGeo& g, float* smem, cons
                           a[ur][s], b[ur * STRIDE + i][col >= 0 && col < W ? col : 0], acc[i * KS + j], 0, 0, 0);
                   }
               }
+              // grouped launches: the prefetched group goes to the other LDS buffer before the last
+              // tap row of the wave's last unit (the loads have landed by then, the LDS writes run
+              // under that row's MFMAs) instead of after it
+              if (GROUPED && KS == 3 && ur == UR - 1 && i == KS - 2 && more && !single && u + NW >= g.units) {
+                float* B_ = smem + (buf ^ 1) * buf_floats;
+#pragma unroll
+                for (int v = 0; v < SVD; v++) lds_put(B_, ds_lx[v], dsv[v]);
+#pragma unroll
+                for (int v = 0; v < SVX; v++) lds_put(B_, xs_lx[v], xsv[v]);
+                committed = true;
+              }
             }
           }
         }
@@ -1675,15 +1715,13 @@ __device__ __forceinline__ void wgrad_rows_body(const RGeo& g, float* smem, cons
     }
     RG_STAMP();
     if (single) __syncthreads();                   // every wave is done reading the only buffer
-    if (more) {
+    if (more && !committed) {
       float* B_ = smem + (single ? 0 : (buf ^ 1)) * buf_floats;
 #pragma unroll
-      for (int u = 0; u < SVD; u++)
-        if (ds_lx[u] >= 0) lds_put(B_, ds_lx[u], dsv[u]);
+      for (int u = 0; u < SVD; u++) lds_put(B_, ds_lx[u], dsv[u]);
 #pragma unroll
-      for (int u = 0; u < SVX; u++)
-        if (xs_lx[u] >= 0) lds_put(B_, xs_lx[u], xsv[u]);
-      stage_rest(B_, SVX, SVD);
+      for (int u = 0; u < SVX; u++) lds_put(B_, xs_lx[u], xsv[u]);
+      if constexpr (!GROUPED) stage_rest(B_, SVX, SVD);
     }
     su_lo_cur = su_lo_nxt; r0_cur = r0_nxt;
     __syncthreads();
@@ -2346,6 +2384,11 @@ int group_flush() {
   }
   float* base = workspace_slot(0, total);
   if (!base) return DFHIP_OUT_OF_MEMORY;
+  // longest workgroups first (they are dispatched in grid order): the launch ends on short ones
+  std::stable_sort(q.begin(), q.end(), [](const GQueued& a, const GQueued& b) {
+    auto work = [](const GQueued& e) { return (double)e.d.N * e.d.oh * e.d.oh * e.T / e.d.ps; };
+    return work(a) > work(b);
+  });
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     DF_HIP(hipFuncSetAttribute((const void*)k_wgrad_group, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2401,7 +2444,7 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
   const int CT = (int)df_ceil_div(C, 32), OT = (int)df_ceil_div(O, 32);
   // pixel slabs per (channel tile, output tile): a stand-alone launch needs one workgroup per CU;
   // a grouped launch has the other layers to fill the chip with and takes longer workgroups
-  static int gdiv = getenv("DFHIP_WGRAD_GROUP_DIV") ? atoi(getenv("DFHIP_WGRAD_GROUP_DIV")) : 4;
+  static int gdiv = getenv("DFHIP_WGRAD_GROUP_DIV") ? atoi(getenv("DFHIP_WGRAD_GROUP_DIV")) : 8;
   const int ps0 = std::max(1, num_cus() / (CT * OT) / (grouped ? std::max(1, gdiv) : 1));
   static int gpb1 = getenv("DFHIP_WGRAD_GPB") ? atoi(getenv("DFHIP_WGRAD_GPB")) : 2;   // groups per block aimed at
   static int gpbg = getenv("DFHIP_WGRAD_GROUP_GPB") ? atoi(getenv("DFHIP_WGRAD_GROUP_GPB")) : 2;
@@ -2427,7 +2470,7 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
       const int units = BI / 2 * (BR / UR);
       if (units % kRowsWaves) continue;
       const int xv = (int)df_ceil_div(32 * BI * (RL / 4), 64 * kRowsWaves), dv = (int)df_ceil_div(32 * BI * (BRBC / 4), 64 * kRowsWaves);
-      if ((xv > 10 || dv > 4) && (N / BI) * gr > ps0) continue;  // later groups must fit the in-flight vectors
+      if ((xv > 10 || dv > 4) && (grouped || (N / BI) * gr > ps0)) continue;  // later groups must fit the in-flight vectors
       const int XST = bank_stride_r(BI * RL, W >= 4 ? 4 : 2), DST = bank_stride_r(BI * BRBC, ow >= 4 ? 4 : 2);
       const size_t stage = (size_t)32 * (XST + DST) * 4;
       const size_t red = grouped ? (size_t)(k == 3 ? 3 : 1) * kRowsWaves * 4 * 64 * 16

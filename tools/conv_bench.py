@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--only", default="")
     ap.add_argument("--grouped", action="store_true")
+    ap.add_argument("--reverse", action="store_true")
     args = ap.parse_args()
     dev = backend_api.Device("hip")
     mod = dev.mod
@@ -70,6 +71,8 @@ def main():
                 mod.from_numpy(rng.standard_normal((N, O, oh, ow)).astype(np.float32), h[1])
                 jobs.append((h, (N, C, H, W, O, k, s, p)))
                 flops += 2.0 * N * oh * ow * C * k * k * O
+        if args.reverse:
+            jobs.reverse()                     # the order a backward sweep queues them in
         def sweep():
             mod.wgrad_group_begin()
             for h, geo in jobs:
