@@ -785,6 +785,38 @@ __global__ __launch_bounds__(kThreads) void k_ce_finish(const float* __restrict_
   if (threadIdx.x == 0) loss[0] = s * inv_rows;
 }
 
+// rows <= 4096: rows and the mean in ONE launch (one workgroup of 16 waves; wave w sums rows
+// w, w+16, ... in order, the 16 partials are added in wave order)
+__global__ __launch_bounds__(1024) void k_ce_small(const float* __restrict__ logits,
+                                                   const float* __restrict__ target,
+                                                   float* __restrict__ loss, int rows, int cols,
+                                                   float inv_rows) {
+  __shared__ float part[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float tot = 0.0f;
+  for (int r = wave; r < rows; r += 16) {
+    const float* x = logits + (int64_t)r * cols;
+    const float* t = target + (int64_t)r * cols;
+    float m = -INFINITY;
+    for (int j = lane; j < cols; j += 64) m = fmaxf(m, x[j]);
+    m = __shfl(wave_max(m), 0, 64);
+    float se = 0.0f;
+    for (int j = lane; j < cols; j += 64) se += expf(x[j] - m);
+    se = __shfl(wave_sum(se), 0, 64);
+    const float lse = logf(se);
+    float acc = 0.0f;
+    for (int j = lane; j < cols; j += 64) acc += -((x[j] - m) - lse) * t[j];
+    tot += __shfl(wave_sum(acc), 0, 64);
+  }
+  if (lane == 0) part[wave] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.0f;
+    for (int w = 0; w < 16; w++) s += part[w];
+    loss[0] = s * inv_rows;
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_ce_bwd(const float* __restrict__ logits,
                                                      const float* __restrict__ target,
                                                      const float* __restrict__ gloss,
@@ -949,7 +981,7 @@ __global__ __launch_bounds__(kThreads) void k_axpy(float* __restrict__ dst,
 // multi-tensor optimizers: up to kBatch tensors per launch, descriptors passed by value in
 // the kernel argument block (captured by value in a hipGraph, no device-side table upload)
 // ---------------------------------------------------------------------------------------
-constexpr int kBatch = 40;
+constexpr int kBatch = 64;   // 64 x 44 B of descriptors: inside the 4 KB kernel-argument block
 constexpr int kChunk = 4096;  // elements per block
 
 struct TensorBatch {
@@ -1329,9 +1361,15 @@ int dfhip_softmax_ce_forward(const float* logits, const float* target, float* lo
   DF_INIT();
   DF_CHECK_ARG(rows > 0 && cols > 0, "softmax_ce: non-positive dimension");
   DF_CHECK_ARG(logits && target && loss, "softmax_ce: null array");
+  ProfScope prof("softmax_ce_fwd", 0.0, 8.0 * (double)rows * cols);
+  if (rows <= 4096) {
+    hipLaunchKernelGGL(k_ce_small, dim3(1), dim3(1024), 0, stream(), logits, target, loss, rows, cols,
+                       (float)(1.0 / (double)rows));
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
   float* row_loss = workspace_small((size_t)rows * sizeof(float));
   if (!row_loss) return DFHIP_OUT_OF_MEMORY;
-  ProfScope prof("softmax_ce_fwd", 0.0, 8.0 * (double)rows * cols);
   hipLaunchKernelGGL(k_ce_rows, dim3(grid_for((int64_t)rows * 64)), dim3(kThreads), 0, stream(), logits,
                      target, row_loss, rows, cols);
   DF_LAUNCH_CHECK();
