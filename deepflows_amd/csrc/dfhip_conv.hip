@@ -1843,12 +1843,77 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
   }
 }
 
+// Slab sum of a grouped launch, tap-major per thread: a thread owns one (tile, q, lane) position --
+// four output channels x one source channel -- and ALL taps of it, so that what it stores is T
+// consecutive floats per output channel and a wave stores 32 x T x 4 contiguous bytes (the per-tap
+// version above leaves 4-byte stores 4*T bytes apart: PMC 7x write amplification).  SL slices of
+// the slabs are summed in a fixed order and combined through LDS.
 __global__ __launch_bounds__(256) void k_wgrad_group_sum(SGroup a) {
-  __shared__ float4 part[256];
+  __shared__ float4 part[256 * 9];
   const int b = blockIdx.x;
   int li = 0;
   while (li + 1 < a.n && b >= a.vb_end[li]) li++;
-  slab_sum_vblock(a.s[li], b - (li ? a.vb_end[li - 1] : 0), part);
+  const SlabSum& d = a.s[li];
+  const int vb = b - (li ? a.vb_end[li - 1] : 0);
+  const int T = d.T;
+  const int ipb = 256 / d.SL;
+  const int it = threadIdx.x % ipb, sl = threadIdx.x / ipb;
+  const int item = vb * ipb + it;                         // (tile, q, lane)
+  const int nitem = d.OT * d.CT * 256;
+  const int64_t slab_f4 = (int64_t)nitem * T;             // float4s per slab
+  float4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; t++) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (item < nitem) {
+    const float4* src = reinterpret_cast<const float4*>(d.slabs) + (int64_t)(item >> 8) * T * 256 + (item & 255);
+    for (int s0 = sl; s0 < d.ps; s0 += 4 * d.SL) {       // four slabs' loads in flight
+      float4 v[4][9];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int s = s0 + u * d.SL;
+        const float4* p = src + (int64_t)(s < d.ps ? s : s0) * slab_f4;
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+          if (t < T) v[u][t] = p[t * 256];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (s0 + u * d.SL < d.ps) {
+#pragma unroll
+          for (int t = 0; t < 9; t++)
+            if (t < T) { acc[t].x += v[u][t].x; acc[t].y += v[u][t].y; acc[t].z += v[u][t].z; acc[t].w += v[u][t].w; }
+        }
+    }
+  }
+  if (d.SL > 1) {
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+      if (t < T) part[t * 256 + threadIdx.x] = acc[t];
+    __syncthreads();
+  }
+  if (sl == 0 && item < nitem) {
+    for (int k = 1; k < d.SL; k++)
+#pragma unroll
+      for (int t = 0; t < 9; t++)
+        if (t < T) {
+          const float4 v = part[t * 256 + k * ipb + it];
+          acc[t].x += v.x; acc[t].y += v.y; acc[t].z += v.z; acc[t].w += v.w;
+        }
+    const int lane = item & 63, q = (item >> 6) & 3, tile = item >> 8;
+    const int ct = tile % d.CT, ot = tile / d.CT;
+    const int c = ct * 32 + (lane & 31);
+    const int o = ot * 32 + 8 * q + 4 * (lane >> 5);
+    if (c < d.C) {
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (o + e < d.O) {
+          float* dst = d.dw + ((int64_t)(o + e) * d.C + c) * T;
+#pragma unroll
+          for (int t = 0; t < 9; t++)
+            if (t < T) dst[t] = e == 0 ? acc[t].x : (e == 1 ? acc[t].y : (e == 2 ? acc[t].z : acc[t].w));
+        }
+    }
+  }
 }
 
 // out[i] = sum_s slabs[s][i], summed in a fixed order.  A block owns 256 consecutive elements
@@ -2410,6 +2475,10 @@ int group_flush() {
       e.d.wg_end = wgs;
       wg.d[i] = e.d;
       sg.s[i] = make_slab_sum(e.d.slabs, e.dw, e.d.ps, e.d.OT, e.d.CT, e.T, e.d.O, e.d.C);
+      // tap-major items: (tile, q, lane) positions, 256 / SL of them per block
+      sg.s[i].SL = 1;
+      while (sg.s[i].SL < 8 && sg.s[i].SL * 2 <= e.d.ps) sg.s[i].SL *= 2;
+      sg.s[i].nvb = (int)df_ceil_div((int64_t)e.d.OT * e.d.CT * 256, 256 / sg.s[i].SL);
       vbs += sg.s[i].nvb;
       sg.vb_end[i] = vbs;
       flops += e.flops; bytes += e.bytes;

@@ -129,3 +129,41 @@ def test_dropout_mask_equals_numpy_binomial():
             sb = np.random.get_state()
             assert np.array_equal(a, b), (keep, seed)
             assert sa[2] == sb[2] and np.array_equal(sa[1], sb[1]), (keep, seed)
+
+
+def test_backward_brackets_the_sweep_with_the_wgrad_group(cpu_oracle):
+    """Tensor.backward() opens a device's weight-gradient group before the reverse sweep and closes it
+    after it -- also when a grad_fn raises -- and leaves devices without the hooks alone."""
+    calls = []
+    mod = cpu_oracle.mod
+    mod.wgrad_group_begin = lambda: calls.append("begin") or True
+    mod.wgrad_group_end = lambda: calls.append("end")
+    try:
+        w = Tensor(np.ones((3, 2), np.float32), requires_grad=True, device=cpu_oracle)
+        x = Tensor(np.arange(6, dtype=np.float32).reshape(2, 3), device=cpu_oracle)
+        loss = tensor.sum(x @ w)
+        loss.backward()
+        assert calls == ["begin", "end"]
+        assert np.allclose(w.grad.numpy(), np.arange(6).reshape(2, 3).sum(0)[:, None] * np.ones((1, 2)))
+        # a failing grad_fn still closes the group
+        calls.clear()
+        w2 = Tensor(np.ones((3, 2), np.float32), requires_grad=True, device=cpu_oracle)
+        y = x @ w2
+        loss2 = tensor.sum(y)
+
+        def boom(*a, **k):
+            raise RuntimeError("grad_fn failed")
+        y.grad_fn = boom
+        with pytest.raises(RuntimeError):
+            loss2.backward()
+        assert calls == ["begin", "end"]
+        Graph.free_graph_all()                     # the failed sweep left its tape behind
+        # begin() returning False (grouping switched off): end is not called
+        calls.clear()
+        mod.wgrad_group_begin = lambda: calls.append("begin") and False
+        w3 = Tensor(np.ones((3, 2), np.float32), requires_grad=True, device=cpu_oracle)
+        tensor.sum(x @ w3).backward()
+        assert calls == ["begin"]
+    finally:
+        del mod.wgrad_group_begin, mod.wgrad_group_end
+        Graph.free_graph_all()

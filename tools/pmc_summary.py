@@ -40,11 +40,16 @@ def main(paths):
 
 
 FAMILIES = {
-    # kernel-name prefix -> the family bench.py reports (dfhip ProfScope names)
+    # kernel-name prefix (a trailing $ = exact name) -> the family bench.py reports (dfhip ProfScope names);
+    # first match wins
+    "wgrad_slab_sum": ("k_wgrad_group_sum",),
+    "conv2d_wgrad_grouped": ("k_wgrad_group",),
     "conv2d_wgrad_igemm": ("k_conv_wgrad_rows", "k_conv_wgrad_v3", "k_conv_wgrad_tap", "k_conv_wgrad<", "k_wgrad_tap_sum",
                            "k_flat_slab_sum"),
-    "conv2d_fwd_igemm": ("k_conv_igemm_v4<3, 0", "k_conv_igemm_v4<1, 0"),
+    "conv2d_fwd_igemm": ("k_conv_igemm_v4<3, 0", "k_conv_igemm_v4<1, 0", "k_conv_igemm$"),
     "conv2d_dgrad_overwrite_igemm": ("k_conv_igemm_v4<3, 2", "k_conv_igemm_v4<1, 2"),
+    "bn2d_fwd": ("k_bn_apply_partials", "k_bn_stats", "k_bn_apply"),
+    "bn2d_bwd": ("k_bn_fused_bwd", "k_bn_bwd_stats", "k_bn_bwd_apply"),
 }
 
 
@@ -57,13 +62,14 @@ def family_json(paths, steps, out_path):
             for row in csv.DictReader(f):
                 k = short(row["Kernel_Name"])
                 for fam, prefixes in FAMILIES.items():
-                    if any(k.startswith(pr) for pr in prefixes):
+                    if any((k == pr[:-1]) if pr.endswith("$") else k.startswith(pr) for pr in prefixes):
                         c = row["Counter_Name"]
                         if c == "FETCH_SIZE":
                             tot[fam]["fetch_kib"] += float(row["Counter_Value"])
                             tot[fam]["launches"] += 1
                         elif c == "WRITE_SIZE":
                             tot[fam]["write_kib"] += float(row["Counter_Value"])
+                        break
     out = {}
     for fam, t in tot.items():
         out[fam] = {"hbm_bytes_per_step": (2.0 * t["fetch_kib"] + t["write_kib"]) * 1024.0 / steps,
