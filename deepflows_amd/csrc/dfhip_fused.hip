@@ -785,36 +785,45 @@ __global__ __launch_bounds__(kThreads) void k_ce_finish(const float* __restrict_
   if (threadIdx.x == 0) loss[0] = s * inv_rows;
 }
 
-// rows <= 4096: rows and the mean in ONE launch (one workgroup of 16 waves; wave w sums rows
-// w, w+16, ... in order, the 16 partials are added in wave order)
+// rows <= 4096, cols <= 32 (a classifier head): rows and the mean in ONE launch of one workgroup.
+// A THREAD owns a row (its few logits live in registers, one round of loads), the row losses are
+// summed by a fixed-shape tree in LDS.
 __global__ __launch_bounds__(1024) void k_ce_small(const float* __restrict__ logits,
                                                    const float* __restrict__ target,
                                                    float* __restrict__ loss, int rows, int cols,
                                                    float inv_rows) {
-  __shared__ float part[16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float part[1024];
   float tot = 0.0f;
-  for (int r = wave; r < rows; r += 16) {
+  for (int r = threadIdx.x; r < rows; r += 1024) {
     const float* x = logits + (int64_t)r * cols;
     const float* t = target + (int64_t)r * cols;
+    float xv[32], tv[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+      xv[j] = j < cols ? x[j] : -INFINITY;
+      tv[j] = j < cols ? t[j] : 0.0f;
+    }
     float m = -INFINITY;
-    for (int j = lane; j < cols; j += 64) m = fmaxf(m, x[j]);
-    m = __shfl(wave_max(m), 0, 64);
+#pragma unroll
+    for (int j = 0; j < 32; j++) m = fmaxf(m, xv[j]);
     float se = 0.0f;
-    for (int j = lane; j < cols; j += 64) se += expf(x[j] - m);
-    se = __shfl(wave_sum(se), 0, 64);
+#pragma unroll
+    for (int j = 0; j < 32; j++)
+      if (j < cols) se += expf(xv[j] - m);
     const float lse = logf(se);
     float acc = 0.0f;
-    for (int j = lane; j < cols; j += 64) acc += -((x[j] - m) - lse) * t[j];
-    tot += __shfl(wave_sum(acc), 0, 64);
+#pragma unroll
+    for (int j = 0; j < 32; j++)
+      if (j < cols) acc += -((xv[j] - m) - lse) * tv[j];
+    tot += acc;
   }
-  if (lane == 0) part[wave] = tot;
+  part[threadIdx.x] = tot;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float s = 0.0f;
-    for (int w = 0; w < 16; w++) s += part[w];
-    loss[0] = s * inv_rows;
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) loss[0] = part[0] * inv_rows;
 }
 
 __global__ __launch_bounds__(kThreads) void k_ce_bwd(const float* __restrict__ logits,
@@ -1362,7 +1371,7 @@ int dfhip_softmax_ce_forward(const float* logits, const float* target, float* lo
   DF_CHECK_ARG(rows > 0 && cols > 0, "softmax_ce: non-positive dimension");
   DF_CHECK_ARG(logits && target && loss, "softmax_ce: null array");
   ProfScope prof("softmax_ce_fwd", 0.0, 8.0 * (double)rows * cols);
-  if (rows <= 4096) {
+  if (rows <= 4096 && cols <= 32) {
     hipLaunchKernelGGL(k_ce_small, dim3(1), dim3(1024), 0, stream(), logits, target, loss, rows, cols,
                        (float)(1.0 / (double)rows));
     DF_LAUNCH_CHECK();

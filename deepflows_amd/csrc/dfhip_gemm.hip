@@ -218,10 +218,7 @@ int gemm_dispatch(const float* a, const float* b, const float* bias, float* out,
   if (P <= 64 && df_ceil_div(M, 128) >= 2 * (int64_t)cus)
     return launch_cfg<2, 1>(a, b, bias, out, M, K, P, ta, tb, 1);
   int splits = 1;
-  // (a contraction this small is launch-bound: the slab-sum launch would cost more than the
-  // k-split saves -- ResNet's 256 x 256 x 10 classifier)
-  const bool tiny = 2.0 * (double)m * (double)k * (double)p < 8.0e6;
-  if (t64 < (int64_t)cus * 2 && K >= 256 && !tiny) {
+  if (t64 < (int64_t)cus * 2 && K >= 256) {
     int64_t want = df_ceil_div((int64_t)cus * 4, t64);
     int64_t maxs = K / 128;
     splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, maxs));
