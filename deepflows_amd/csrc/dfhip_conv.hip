@@ -625,6 +625,67 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
 #undef DF_STAMP
 }
 
+// ---------------------------------------------------------------------------------------
+// forward, few-channel 3x3 / stride 1 / pad 1 convolution on 32-wide images (the ResNet stem:
+// 3 -> 32 channels on 32 x 32): K = C*9 <= 36, so a 32-pixel tile is ceil(K/2) <= 18 MFMAs and the
+// layer is bound by its 33.5 MB of output, not by the matrix cores.  A wave owns one image ROW (its
+// 32 lanes are the row's pixels, W == 32): the weight operand of its 32 output channels sits in
+// registers for the whole kernel, the pixel operand of a (channel, tap) is ONE coalesced global
+// load per row (the input is 3 MB and lives in L2; row / column padding by predication), and the
+// 32 x 32 result leaves as sixteen 128-byte stores per half-wave.  No LDS, no barriers: the
+// generic kernel spent 26 us per launch on per-workgroup gather tables for 14 MFMAs of work.
+// ---------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ y,
+                                                    int N, int H, int O, unsigned m_h) {
+  constexpr int KK = C * 9, NP = (KK + 1) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int d0 = blockIdx.y * 32;
+  const int o = d0 + l31;
+  float a[NP];
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    const int kk = 2 * p + half;
+    a[p] = (kk < KK && o < O) ? w[(int64_t)o * KK + kk] : 0.0f;
+  }
+  float bv[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; rr++) {
+    const int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+    bv[rr] = (bias && d < O) ? bias[d] : 0.0f;
+  }
+  const int rows = N * H;
+  for (int R = blockIdx.x * 4 + wave; R < rows; R += gridDim.x * 4) {
+    const int n = (int)fast_div((unsigned)R, m_h), r = R - n * H;
+    const float* xn = x + (int64_t)n * C * H * 32;
+    float b[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      // k index 2p (lower half-wave) / 2p+1 (upper): (channel, tap row, tap column)
+      const int k0 = 2 * p, k1 = 2 * p + 1;
+      const int c0 = k0 / 9, i0 = (k0 % 9) / 3, j0 = k0 % 3;
+      const int c1 = k1 / 9, i1 = (k1 % 9) / 3, j1 = k1 % 3;
+      const int cc = half ? c1 : c0, ii = half ? i1 : i0, jj = half ? j1 : j0;
+      const int rr = r + ii - 1, col = l31 + jj - 1;
+      const bool ok = (half ? k1 < KK : k0 < KK) && (unsigned)rr < (unsigned)H && (unsigned)col < 32u;
+      b[p] = ok ? xn[((int64_t)cc * H + rr) * 32 + col] : 0.0f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) acc[rr] = bv[rr];
+#pragma unroll
+    for (int p = 0; p < NP; p++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], b[p], acc, 0, 0, 0);
+    float* yo = y + ((int64_t)n * O * H + r) * 32 + l31;
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) {
+      const int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+      if (d < O) yo[(int64_t)d * H * 32] = acc[rr];
+    }
+  }
+}
+
 // out[i] = sum_s slabs[s][i] (+ bias[(i / plane) % CD])
 __global__ __launch_bounds__(256) void k_conv_slab_sum(const float* __restrict__ slabs,
                                                        const float* __restrict__ bias,
@@ -2153,9 +2214,31 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, 
   return DFHIP_OK;
 }
 
+// few-channel 3x3 stem on 32-wide images; returns -1 when the shape is not one it takes
+int run_conv_rows3(const Geo& g, int dest_channels, float* final_dst, const float* bias) {
+  static int enabled = getenv("DFHIP_STEM_ROWS") ? atoi(getenv("DFHIP_STEM_ROWS")) : 1;
+  if (!enabled || g.mode != 0 || g.k != 3 || g.so != 1 || g.sd != 1 || g.u0 != -1) return -1;
+  if (g.CS < 1 || g.CS > 4 || g.WS != 32 || g.WD != 32 || g.HS != g.HD) return -1;
+  const int rows = g.N * g.HS;
+  dim3 grid((unsigned)std::min<int64_t>(df_ceil_div(rows, 4), (int64_t)num_cus() * 8),
+            (unsigned)df_ceil_div(dest_channels, 32));
+  const unsigned m_h = magic_u32((unsigned)g.HS);
+#define DF_STEM(CV)                                                                                   \
+  case CV:                                                                                            \
+    hipLaunchKernelGGL(k_conv_rows3<CV>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, final_dst, g.N, g.HS, \
+                       dest_channels, m_h);                                                           \
+    break;
+  switch (g.CS) { DF_STEM(1) DF_STEM(2) DF_STEM(3) DF_STEM(4) default: return -1; }
+#undef DF_STEM
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
 int run_igemm(Geo g, int dest_channels, float* final_dst, const float* bias) {
   {
     int st = run_igemm_v4(g, dest_channels, final_dst, bias);
+    if (st >= 0) return st;
+    st = run_conv_rows3(g, dest_channels, final_dst, bias);
     if (st >= 0) return st;
   }
   const int k2 = g.k * g.k;

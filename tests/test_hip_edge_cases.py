@@ -185,3 +185,29 @@ def test_dgrad_add_epilogue(hip_device):
             mod.conv2d_dgrad_add(_arr(mod, dy), _arr(mod, w), _arr(mod, add), dx, N, C, H, W, O, k, s, p, mode=mode)
             got = _back(mod, dx).reshape(want.shape)
             assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), (N, C, H, W, O, k, s, p, mode)
+
+
+@pytest.mark.parametrize("C,H,O,N,with_bias", [(1, 32, 8, 3, False), (2, 5, 40, 2, True), (3, 32, 32, 5, True),
+                                               (4, 7, 33, 1, False)])
+def test_few_channel_stem_kernel(hip_device, C, H, O, N, with_bias):
+    """k_conv_rows3: 3x3 / stride 1 / pad 1 on 32-wide images with 1-4 source channels (the ResNet stem),
+    ragged output-channel tiles, odd heights, bias."""
+    from conftest import assert_close
+    from oracle import ref_ops as R
+    mod = hip_device.mod
+    rng = np.random.default_rng(100 + C)
+    x = rng.standard_normal((N, C, H, 32)).astype(np.float32)
+    w = rng.standard_normal((O, C, 3, 3)).astype(np.float32)
+    b = rng.standard_normal(O).astype(np.float32) if with_bias else None
+    xh, wh = mod.Array(x.size), mod.Array(w.size)
+    mod.from_numpy(x, xh)
+    mod.from_numpy(w, wh)
+    bh = None
+    if with_bias:
+        bh = mod.Array(O)
+        mod.from_numpy(b, bh)
+    yh = mod.Array(N * O * H * 32)
+    mod.conv2d_forward(xh, wh, bh, yh, N, C, H, 32, O, 3, 1, 1)
+    got = mod.to_numpy(yh, (yh.size,), (1,), 0).reshape(N, O, H, 32)
+    want = R.conv2d_forward(x, w, b.reshape(1, O, 1, 1) if with_bias else None, 1, 1)
+    assert_close(got, want, 1e-4, f"stem kernel C={C} H={H} O={O}")
