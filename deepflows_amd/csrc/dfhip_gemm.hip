@@ -139,6 +139,58 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A,
     }
 }
 
+// Launch-bound contractions (a 256 x 256 x 10 classifier and its gradients): one launch, no LDS
+// staging, no slab kernel.  A workgroup owns a 32 x 32 output tile, its eight waves split K into
+// eight contiguous ranges and read their operands straight from global memory (everything is
+// L2-resident at these sizes; all loads of a wave are independent), the eight partial tiles are
+// summed through LDS in wave order.
+__global__ __launch_bounds__(512) void k_gemm_small(const float* __restrict__ A, const float* __restrict__ B,
+                                                    const float* __restrict__ bias, float* __restrict__ C,
+                                                    int M, int K, int P, int64_t a_sm, int64_t a_sk,
+                                                    int64_t b_sk, int64_t b_sp) {
+  __shared__ float red[7][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int m = blockIdx.y * 32 + l31, p = blockIdx.x * 32 + l31;
+  const int kq = (((K + 7) / 8) + 1) & ~1;                 // even number of k per wave
+  const int kbeg = wave * kq, kend = min(K, kbeg + kq);
+  const float* ap = A + (int64_t)min(m, M - 1) * a_sm;
+  const float* bp = B + (int64_t)min(p, P - 1) * b_sp;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int k = k0 + 2 * u + half;
+      const bool ok = k < kend;
+      a[u] = (ok && m < M) ? ap[(int64_t)k * a_sk] : 0.0f;
+      b[u] = (ok && p < P) ? bp[(int64_t)k * b_sk] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 0; w < 7; w++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] += red[w][r][lane];
+    if (p < P) {
+      const float bb = bias ? bias[p] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < M) C[(int64_t)row * P + p] = acc[r] + bb;
+      }
+    }
+  }
+}
+
 // out[i] = sum_s slabs[s][i] (+ bias[i % P]) in slab order
 __global__ __launch_bounds__(256) void k_slab_sum(const float* __restrict__ slabs,
                                                   const float* __restrict__ bias,
@@ -212,6 +264,13 @@ int gemm_dispatch(const float* a, const float* b, const float* bias, float* out,
                  4.0 * ((double)m * k + (double)k * p + (double)m * p));
   int M = (int)m, K = (int)k, P = (int)p;
   int cus = num_cus();
+  if (2.0 * (double)m * (double)k * (double)p < 8.0e6 && K >= 64 && K <= 4096) {
+    hipLaunchKernelGGL(k_gemm_small, dim3((unsigned)df_ceil_div(P, 32), (unsigned)df_ceil_div(M, 32)), dim3(512), 0,
+                       stream(), a, b, bias, out, M, K, P, ta ? (int64_t)1 : (int64_t)K, ta ? (int64_t)M : (int64_t)1,
+                       tb ? (int64_t)1 : (int64_t)P, tb ? (int64_t)K : (int64_t)1);
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
   int64_t t128 = df_ceil_div(M, 128) * df_ceil_div(P, 128);
   int64_t t64 = df_ceil_div(M, 64) * df_ceil_div(P, 64);
   if (t128 >= 2 * (int64_t)cus && P > 64) return launch_cfg<2, 2>(a, b, bias, out, M, K, P, ta, tb, 1);

@@ -106,7 +106,8 @@ def test_pool_reuses_blocks_without_new_hipmalloc(hip_device):
 def test_transposed_gemm_operands_and_bias(hip_device):
     mod = hip_device.mod
     rng = np.random.default_rng(2)
-    for (m, k, p) in ((128, 784, 256), (256, 256, 10), (37, 19, 5), (1, 300, 1), (300, 1, 7)):
+    for (m, k, p) in ((128, 784, 256), (256, 256, 10), (37, 19, 5), (1, 300, 1), (300, 1, 7),
+                      (70, 65, 33), (5, 1000, 3), (33, 4096, 2)):   # the last three: single-launch small-GEMM kernel
         A = rng.standard_normal((m, k)).astype(np.float32)
         B = rng.standard_normal((k, p)).astype(np.float32)
         bias = rng.standard_normal(p).astype(np.float32)
