@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--grouped", action="store_true")
     ap.add_argument("--reverse", action="store_true")
+    ap.add_argument("--group-only", default="")
+    ap.add_argument("--group-count", type=int, default=0)
     args = ap.parse_args()
     dev = backend_api.Device("hip")
     mod = dev.mod
@@ -64,8 +66,10 @@ def main():
         # the weight gradients of one backward sweep (every layer, with multiplicity) as ONE grouped launch
         jobs, flops = [], 0.0
         for name, C, H, W, O, k, s, p in LAYERS:
+            if args.group_only and name not in args.group_only.split(","):
+                continue
             oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-            for _ in range(COUNT[name]):
+            for _ in range(COUNT[name] if not args.group_count else args.group_count):
                 h = [mod.Array(N * C * H * W), mod.Array(N * O * oh * ow), mod.Array(O * C * k * k)]
                 mod.from_numpy(rng.standard_normal((N, C, H, W)).astype(np.float32), h[0])
                 mod.from_numpy(rng.standard_normal((N, O, oh, ow)).astype(np.float32), h[1])
