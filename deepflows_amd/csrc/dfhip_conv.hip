@@ -1860,6 +1860,7 @@ struct GDesc {
 };
 struct WGroup {
   int n;
+  unsigned long long* ticks;   // diagnostic builds (-DDFHIP_STAMPS): cycles per workgroup
   GDesc d[kMaxGroup];
 };
 struct SGroup {
@@ -1878,6 +1879,9 @@ struct SGroup {
 __global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x;
+#ifdef DFHIP_STAMPS
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
   int li = 0;
   while (li + 1 < a.n && b >= a.d[li].wg_end) li++;
   const GDesc& d = a.d[li];
@@ -1902,6 +1906,9 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
 #undef DF_CASE
     default: break;
   }
+#ifdef DFHIP_STAMPS
+  if (a.ticks && threadIdx.x == 0) a.ticks[b] = __builtin_readcyclecounter() - t_begin;
+#endif
 }
 
 // Slab sum of a grouped launch, tap-major per thread: a thread owns one (tile, q, lane) position --
@@ -2567,10 +2574,32 @@ int group_flush() {
       flops += e.flops; bytes += e.bytes;
       sbytes += (double)(e.d.ps + 1) * e.d.OT * e.d.CT * e.T * 4096.0;
     }
+    static int stamp_mode = -1;
+    if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
+    hipEvent_t se0 = nullptr, se1 = nullptr;
+    if (stamp_mode) {
+      wg.ticks = (unsigned long long*)workspace2((size_t)wgs * 8);
+      (void)hipMemsetAsync(wg.ticks, 0, (size_t)wgs * 8, stream());
+      (void)hipEventCreate(&se0); (void)hipEventCreate(&se1);
+      (void)hipEventRecord(se0, stream());
+    }
     {
       ProfScope prof("conv2d_wgrad_grouped", flops, bytes);
       hipLaunchKernelGGL(k_wgrad_group, dim3((unsigned)wgs), dim3(64 * kRowsWaves), lds, stream(), wg);
       DF_LAUNCH_CHECK();
+    }
+    if (stamp_mode) {      // cycles of a workgroup against the launch's wall time: the clock under this kernel
+      (void)hipEventRecord(se1, stream());
+      (void)hipEventSynchronize(se1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, se0, se1);
+      std::vector<unsigned long long> h(wgs);
+      (void)hipMemcpy(h.data(), wg.ticks, (size_t)wgs * 8, hipMemcpyDeviceToHost);
+      unsigned long long mx = 0; double sum = 0;
+      for (auto v : h) { mx = std::max(mx, v); sum += (double)v; }
+      fprintf(stderr, "[stampg] %d workgroups, launch %.1f us; cycles per workgroup: mean %.0f max %llu -> >= %.2f GHz if the longest one spans the launch\n",
+              wgs, ms * 1e3, sum / wgs, mx, (double)mx / (ms * 1e3) * 1e-3);
+      (void)hipEventDestroy(se0); (void)hipEventDestroy(se1);
     }
     {
       ProfScope prof("wgrad_slab_sum", 0.0, sbytes);
