@@ -8,6 +8,8 @@ its training scripts define and the per-batch step they run.
   ResidualBlock / ResNet18   test/ResNet_CIFAR10_cuda.py:20-100 (channels 32/64/128/256,
                          max-pool after the stem, NO ReLU inside the blocks, global average
                          pool written as two `mean(axis=2)` calls)
+  VGG16                  test/VGG.py:7-152
+  ConvBlock / MobileNetV1    test/MobileNet.py:18-108
   train_step             the loop body of test/ResNet_CIFAR10_cuda.py:185-190
 
 `register_blocks`: the reference keeps its residual blocks in plain Python lists, which
@@ -142,6 +144,100 @@ class ResNet(nn.Module):
         for blk in self.layer4:
             x = blk(x)
         x = nn.functional.mean_hw(x)   # mean(axis=2) twice: each divides by the TOTAL element count
+        return self.fc(x)
+
+
+# ---- the other convolutional models of the example scripts -----------------------
+_VGG16_STAGES = ((64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512))
+
+
+class VGG16(nn.Module):
+    """test/VGG.py:7-152: 13 x (3x3 conv, no bias -> BatchNorm2d -> ReLU), a 2x2 max-pool after each of
+    the five stages, then Linear(512*s*s, 4096) - ReLU - Dropout - Linear(4096, 4096) - ReLU - Dropout -
+    Linear(4096, classes).  Layers are created in the script's order (conv, bn, conv, bn, ..., fc1-3), so
+    the seeded initialisation and `parameters()` line up with the reference's."""
+
+    def __init__(self, num_classes=10, device="hip", img_size=(32, 32)):
+        super().__init__()
+        cin = 3
+        for si, widths in enumerate(_VGG16_STAGES, 1):
+            for ci, cout in enumerate(widths, 1):
+                setattr(self, f"conv{si}_{ci}", nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1,
+                                                         bias=False, device=device))
+                setattr(self, f"bn{si}_{ci}", nn.BatchNorm2d(cout, device=device))
+                cin = cout
+            setattr(self, f"pool{si}", nn.MaxPool2d(kernel_size=2, stride=2))
+        side = img_size[0] // 2 ** len(_VGG16_STAGES)
+        self.fc1 = nn.Linear(cin * side * side, 4096, device=device)
+        self.fc2 = nn.Linear(4096, 4096, device=device)
+        self.fc3 = nn.Linear(4096, num_classes, device=device)
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(0.5)
+
+    def forward(self, x):
+        if not isinstance(x, Tensor):
+            x = Tensor(x)
+        for si, widths in enumerate(_VGG16_STAGES, 1):
+            for ci in range(1, len(widths) + 1):
+                x = self.relu(getattr(self, f"bn{si}_{ci}")(getattr(self, f"conv{si}_{ci}")(x)))
+            x = getattr(self, f"pool{si}")(x)
+        x = x.reshape(x.shape[0], -1)
+        x = self.dropout(self.relu(self.fc1(x)))
+        x = self.dropout(self.relu(self.fc2(x)))
+        return self.fc3(x)
+
+
+def make_divisible(channels, divisor=8):
+    """test/MobileNet.py:37-43: round a scaled channel count to a multiple of `divisor`, never
+    dropping more than 10 %."""
+    rounded = int(channels + divisor / 2) // divisor * divisor
+    out = divisor if rounded < divisor else rounded
+    if out < 0.9 * channels:
+        out += divisor
+    return out
+
+
+class ConvBlock(nn.Module):
+    """test/MobileNet.py:18-35: 3x3 conv (no bias) -> BatchNorm2d -> maximum(x, 0)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size=3, stride=1, padding=1, device="hip"):
+        super().__init__()
+        self.conv = nn.Conv2d(in_ch, out_ch, kernel_size=kernel_size, stride=stride, padding=padding,
+                              bias=False, device=device)
+        self.bn = nn.BatchNorm2d(out_ch, device=device)
+
+    def forward(self, x):
+        return tensor.maximum(self.bn(self.conv(x)), 0)
+
+
+class MobileNetV1(nn.Module):
+    """test/MobileNet.py:48-108 ("simplified": plain conv blocks in place of the depthwise-separable
+    ones): stem conv+BN+ReLU, eight ConvBlocks (strides 1,2,1,2,1,1,1,1), two `mean(axis=2)` calls
+    (each divides by the total element count), Linear."""
+    _BLOCKS = ((64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 1), (512, 1), (512, 1))
+
+    def __init__(self, num_classes=10, width_multiplier=1.0, device="hip", img_size=(32, 32)):
+        super().__init__()
+        self.device, self.img_size = device, img_size
+
+        def c(ch):
+            return make_divisible(ch * width_multiplier)
+        self.conv1 = nn.Conv2d(3, c(32), kernel_size=3, stride=1, padding=1, bias=False, device=device)
+        self.bn1 = nn.BatchNorm2d(c(32), device=device)
+        cin = c(32)
+        for i, (ch, stride) in enumerate(self._BLOCKS, 1):
+            setattr(self, f"block{i}", ConvBlock(cin, c(ch), stride=stride, device=device))
+            cin = c(ch)
+        self.last_channels = cin
+        self.fc = nn.Linear(cin, num_classes, device=device)
+
+    def forward(self, x):
+        if not isinstance(x, Tensor):
+            x = Tensor(x)
+        x = tensor.maximum(self.bn1(self.conv1(x)), 0)
+        for i in range(1, len(self._BLOCKS) + 1):
+            x = getattr(self, f"block{i}")(x)
+        x = tensor.mean(tensor.mean(x, axis=2), axis=2)
         return self.fc(x)
 
 

@@ -327,3 +327,38 @@ def check_resnet18(dev, mode):
     assert_close(model.bn1.running_mean.numpy(), g[f"r18_{mode}_bn1_rm"], TOL, "R18 bn1 running mean")
     assert_close(model.bn1.running_var.numpy(), g[f"r18_{mode}_bn1_rv"], TOL, "R18 bn1 running var")
     Graph.free_graph_all()
+
+
+def check_model_step(dev, tag, tol_grad=2e-3):
+    """One seeded training step of VGG16 (tag 'vgg', Adam) or MobileNetV1 x0.25 (tag 'mbn', SGD with
+    momentum) against outputs of the reference's own classes (oracle/gen_models_golden.py)."""
+    g = load_golden("g10_models.npz")
+    np.random.seed(0)
+    if tag == "vgg":
+        model = workloads.VGG16(10, device=dev, img_size=(32, 32))
+        first = model.conv1_1
+    else:
+        model = workloads.MobileNetV1(num_classes=10, width_multiplier=0.25, device=dev, img_size=(32, 32))
+        first = model.conv1
+    model.train()
+    params = list(model.parameters())
+    n, numel = (int(v) for v in g[f"{tag}_n_params"])
+    assert len(params) == n and sum(int(np.prod(p.shape)) for p in params) == numel
+    init = np.array([float(np.abs(p.data.numpy()).sum()) for p in params])
+    assert_close(init, g[f"{tag}_init_abs_sum"], 1e-6, f"{tag}: seeded init reproduces the reference's weights")
+    if tag == "vgg":
+        opt = optim.Adam(params, lr=1e-3, weight_decay=5e-4)
+    else:
+        opt = optim.SGD(params, lr=0.01, momentum=0.9, weight_decay=0.0005)
+    out = model(Tensor(g["x"], device=dev))
+    loss = nn.CrossEntropyLoss()(out, Tensor(g["y"], device=dev))
+    opt.zero_grad(); loss.backward()
+    assert_close(out.numpy(), g[f"{tag}_logits"], 1e-3, f"{tag} logits")
+    assert_close(loss.numpy(), g[f"{tag}_loss"], 1e-3, f"{tag} loss")
+    gabs = np.array([float(np.abs(p.grad.numpy()).sum()) for p in params])
+    assert_close(gabs, g[f"{tag}_grad_abs_sum"], tol_grad, f"{tag} |grad| checksums")
+    assert_close(first.weight.grad.numpy(), g[f"{tag}_conv1_wgrad"], tol_grad, f"{tag} first conv wgrad")
+    opt.step()
+    after = np.array([float(np.abs(p.data.numpy()).sum()) for p in params])
+    assert_close(after, g[f"{tag}_param_abs_sum_after"], 1e-4, f"{tag} parameters after the step")
+    Graph.free_graph_all()

@@ -69,6 +69,13 @@ def test_resnet18_one_adam_step(hip_device, mode):
     pc.check_resnet18(hip_device, mode)
 
 
+@pytest.mark.parametrize("tag", ["vgg", "mbn"])
+def test_vgg16_and_mobilenet_one_step(hip_device, tag):
+    """VGG16 (test/VGG.py) and MobileNetV1 (test/MobileNet.py) on the fused hip path
+    against the reference's own outputs."""
+    pc.check_model_step(hip_device, tag)
+
+
 @pytest.mark.parametrize("shape", [(8, 32, 16, 16, 32, 3, 1, 1), (6, 32, 16, 16, 64, 3, 2, 1), (4, 64, 8, 8, 64, 3, 1, 1),
                                    (16, 128, 4, 4, 128, 3, 1, 1), (32, 256, 2, 2, 256, 3, 1, 1), (5, 32, 16, 16, 64, 1, 2, 0),
                                    (3, 16, 12, 12, 40, 3, 1, 1)])

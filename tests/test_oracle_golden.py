@@ -81,3 +81,9 @@ def test_ref_ops_match_goldens():
     for t in range(3):
         p_, v_, s_ = R.adam_step(p_, g[f"g{t}_0"], v_, s_, t + 1, 1e-3, wd=5e-4)
         assert_close(p_, g[f"adam_wd_step{t + 1}_0"], 1e-6, "adam")
+
+
+@pytest.mark.parametrize("tag", ["vgg", "mbn"])
+def test_vgg16_and_mobilenet_one_step(cpu_oracle, tag):
+    """the VGG16 / MobileNetV1 models of test/VGG.py and test/MobileNet.py."""
+    pc.check_model_step(cpu_oracle, tag)
