@@ -61,5 +61,30 @@ int main() {
       hipLaunchKernelGGL(k_read, dim3(1024), dim3(256), 0, 0, buf, out, mb * 262144);
     });
   }
+  // the same empty kernel 100 times: back to back on a stream vs one replayed hipGraph (stream capture)
+  {
+    hipStream_t st; hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; rep++) {
+      hipEventRecord(e0, st);
+      for (int r = 0; r < 10; r++)
+        for (int i = 0; i < 100; i++) hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, buf);
+      hipEventRecord(e1, st); hipEventSynchronize(e1);
+    }
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-48s %7.2f us per kernel\n", "stream, 100 empty 256x256 kernels", ms * 1e3 / 1000);
+    hipGraph_t g; hipGraphExec_t ge;
+    hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+    for (int i = 0; i < 100; i++) hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, buf);
+    hipStreamEndCapture(st, &g);
+    hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    for (int r = 0; r < 3; r++) hipGraphLaunch(ge, st);
+    hipStreamSynchronize(st);
+    hipEventRecord(e0, st);
+    for (int r = 0; r < 10; r++) hipGraphLaunch(ge, st);
+    hipEventRecord(e1, st); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-48s %7.2f us per kernel\n", "hipGraph replay, 100 empty 256x256 kernels", ms * 1e3 / 1000);
+  }
   return 0;
 }
