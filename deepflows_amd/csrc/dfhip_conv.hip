@@ -686,6 +686,86 @@ __global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x,
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// "overwrite" input gradient of a 3x3 / stride 1 / pad 1 convolution, as what it is: the reference's
+// k*k strided assignments (functional.py:285-294, last writer wins) leave, for input pixel (y, x),
+// only the tap (ti, tj) = (y >= 1 ? 2 : 1, x >= 1 ? 2 : 1) and with it the source pixel
+// (max(y-1, 0), max(x-1, 0)):
+//     dX[n][c][y][x] = sum_o dY[n][o][max(y-1,0)][max(x-1,0)] * W[o][c][ti][tj]
+// -- a 1x1 convolution of a shifted, edge-clamped dY with one of four weight slices (interior,
+// top row, left column, corner), 1/9 of the products of the true gradient.  With so little
+// arithmetic the staged kernel above is all fixed cost (12 us for 2.5 us of MFMAs); here a wave owns
+// a 32-pixel x 32-channel tile outright: the dY operand of its pixels is read ONCE from global
+// memory into registers (O/2 coalesced loads), each of the <= 4 weight slices present in the tile
+// is applied with the lanes of the other slices masked, and the tile leaves as sixteen 128-byte
+// stores per half-wave (plus the gradient the tensor already holds, tensor.py:444).  No LDS, no
+// barrier.  Used while O <= 64 (dY operand in registers) and a tile is 32 pixels of one image.
+// ---------------------------------------------------------------------------------------
+template <int O>
+__global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ dy, const float* __restrict__ w,
+                                                     const float* __restrict__ add, float* __restrict__ dx,
+                                                     int C, int H, int lw, int tiles) {
+  constexpr int NP = O / 2;
+  __shared__ float Wl[4][O][32];                    // the four weight slices of this channel tile: [slice][o][c]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int W = 1 << lw, HW = H << lw;
+  const int c0 = blockIdx.y * 32;
+  const int tile = min(blockIdx.x * 4 + wave, tiles - 1);   // 32 consecutive pixels of one image (clamped: a
+  const bool live = blockIdx.x * 4 + wave < tiles;          //  wave past the end still takes part in the barrier)
+  const int p = tile * 32 + l31;                    // flat (n, y, x)
+  const int n = p / HW, rem = p - n * HW;
+  const int y = rem >> lw, x = rem & (W - 1);
+  const int u = max(y - 1, 0), v = max(x - 1, 0);
+  const int cls = (y >= 1 ? 2 : 0) + (x >= 1 ? 1 : 0);   // slice q <-> tap (1 + (q >> 1), 1 + (q & 1))
+  // everything this wave needs from global memory is requested up front: its dY operand ...
+  float sv[NP];
+  {
+    const float* sp = dy + ((int64_t)n * O + half) * HW + (u << lw) + v;
+#pragma unroll
+    for (int kp = 0; kp < NP; kp++) sv[kp] = sp[(int64_t)(2 * kp) * HW];
+  }
+  // ... and its share of the weight slices (thread -> (o, c) pairs, the four taps 4, 5, 7, 8 of each)
+  constexpr int PAIRS = O * 32 / 256;
+  float wv[PAIRS][4];
+#pragma unroll
+  for (int i = 0; i < PAIRS; i++) {
+    const int e = threadIdx.x + 256 * i, o = e >> 5, c = e & 31;
+    const float* q = w + ((int64_t)o * C + c0 + c) * 9;
+    wv[i][0] = q[4]; wv[i][1] = q[5]; wv[i][2] = q[7]; wv[i][3] = q[8];
+  }
+#pragma unroll
+  for (int i = 0; i < PAIRS; i++) {
+    const int e = threadIdx.x + 256 * i, o = e >> 5, c = e & 31;
+#pragma unroll
+    for (int q = 0; q < 4; q++) Wl[q][o][c] = wv[i][q];
+  }
+  __syncthreads();
+  if (!live) return;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const bool mine = cls == q;
+    if (__ballot(mine) == 0ull) continue;
+    float a[NP];
+#pragma unroll
+    for (int kp = 0; kp < NP; kp++) a[kp] = Wl[q][2 * kp + half][l31];
+#pragma unroll
+    for (int kp = 0; kp < NP; kp++)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], mine ? sv[kp] : 0.0f, acc, 0, 0, 0);
+  }
+  const int64_t obase = ((int64_t)n * C + c0) * HW + rem;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int64_t at = obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW;
+    float val = acc[r];
+    if (add) val += add[at];
+    dx[at] = val;
+  }
+}
+
 // out[i] = sum_s slabs[s][i] (+ bias[(i / plane) % CD])
 __global__ __launch_bounds__(256) void k_conv_slab_sum(const float* __restrict__ slabs,
                                                        const float* __restrict__ bias,
@@ -2929,6 +3009,21 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
   g.CD = C; g.HD = H; g.WD = W;
   g.k = k; g.so = 1; g.sd = stride; g.u0 = pad - (k - 1);
   g.mode = mode == 0 ? 2 : 1; g.wC = C; g.pad = pad; g.stride = stride; g.oh = oh; g.ow = ow;
+  {
+    // overwrite mode, 3x3 / stride 1 / pad 1, few output channels: the shifted 1x1 kernel
+    static int lean = getenv("DFHIP_DGRAD_LEAN") ? atoi(getenv("DFHIP_DGRAD_LEAN")) : 1;
+    int lw = 0;
+    while ((1 << lw) < W) lw++;
+    if (lean && mode == 0 && k == 3 && stride == 1 && pad == 1 && (O == 32 || O == 64) && C % 32 == 0 &&
+        (1 << lw) == W && (H * W) % 32 == 0 && H >= 2 && W >= 2) {
+      const int tiles = (int)((int64_t)N * H * W / 32);
+      dim3 grid((unsigned)df_ceil_div(tiles, 4), (unsigned)(C / 32));
+      if (O == 32) hipLaunchKernelGGL(k_dgrad_ow_s1<32>, grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles);
+      else hipLaunchKernelGGL(k_dgrad_ow_s1<64>, grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles);
+      DF_LAUNCH_CHECK();
+      return DFHIP_OK;
+    }
+  }
   if (add) {
     g.addsrc = add;
     int st = run_igemm_v4(g, C, dx, nullptr);
