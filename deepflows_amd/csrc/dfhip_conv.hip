@@ -701,12 +701,31 @@ __global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x,
 // stores per half-wave (plus the gradient the tensor already holds, tensor.py:444).  No LDS, no
 // barrier.  Used while O <= 64 (dY operand in registers) and a tile is 32 pixels of one image.
 // ---------------------------------------------------------------------------------------
-template <int O>
+// GEO 0: 3x3 / stride 1 / pad 1 (above).  GEO 1: 3x3 / stride 2 / pad 1 -- the surviving tap of pixel
+// (y, x) is (1 + (y & 1), 1 + (x & 1)) and its source (y >> 1, x >> 1): a nearest-neighbour
+// up-sampling of dY followed by one of four 1x1 convolutions by pixel parity.  GEO 2: 1x1 / stride 2 /
+// pad 0 -- even (y, x) receive sum_o dY[o][y/2][x/2] W[o][c], the others stay zero.
+template <int GEO>
+struct OwGeo {
+  static constexpr int NSL = GEO == 2 ? 1 : 4;      // weight slices
+  __device__ static void pixel(int y, int x, int& u, int& v, int& cls) {
+    if (GEO == 0) { u = max(y - 1, 0); v = max(x - 1, 0); cls = (y >= 1 ? 2 : 0) + (x >= 1 ? 1 : 0); }
+    else if (GEO == 1) { u = y >> 1; v = x >> 1; cls = ((y & 1) << 1) + (x & 1); }
+    else { u = y >> 1; v = x >> 1; cls = ((y | x) & 1) ? -1 : 0; }
+  }
+  // the NSL weights of one (o, c) pair, from the (O, C, k, k) tensor
+  __device__ static void slices(const float* __restrict__ w, int64_t oc, float (&out)[4]) {
+    if (GEO == 2) { out[0] = w[oc]; out[1] = out[2] = out[3] = 0.0f; }
+    else { const float* q = w + oc * 9; out[0] = q[4]; out[1] = q[5]; out[2] = q[7]; out[3] = q[8]; }
+  }
+};
+
+template <int O, int GEO>
 __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ dy, const float* __restrict__ w,
                                                      const float* __restrict__ add, float* __restrict__ dx,
                                                      int C, int H, int lw, int tiles) {
-  constexpr int NP = O / 2;
-  __shared__ float Wl[4][O][32];                    // the four weight slices of this channel tile: [slice][o][c]
+  constexpr int NP = O / 2, NSL = OwGeo<GEO>::NSL;
+  __shared__ float Wl[NSL][O][32];                  // the weight slices of this channel tile: [slice][o][c]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int W = 1 << lw, HW = H << lw;
@@ -716,14 +735,16 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
   const int p = tile * 32 + l31;                    // flat (n, y, x)
   const int n = p / HW, rem = p - n * HW;
   const int y = rem >> lw, x = rem & (W - 1);
-  const int u = max(y - 1, 0), v = max(x - 1, 0);
-  const int cls = (y >= 1 ? 2 : 0) + (x >= 1 ? 1 : 0);   // slice q <-> tap (1 + (q >> 1), 1 + (q & 1))
+  int u, v, cls;                                    // source pixel, slice q <-> tap (1 + (q >> 1), 1 + (q & 1))
+  OwGeo<GEO>::pixel(y, x, u, v, cls);
+  const int slw = GEO == 0 ? lw : lw - 1;           // source plane: H x W, or H/2 x W/2
+  const int SHW = GEO == 0 ? HW : HW >> 2;
   // everything this wave needs from global memory is requested up front: its dY operand ...
   float sv[NP];
   {
-    const float* sp = dy + ((int64_t)n * O + half) * HW + (u << lw) + v;
+    const float* sp = dy + ((int64_t)n * O + half) * SHW + (u << slw) + v;
 #pragma unroll
-    for (int kp = 0; kp < NP; kp++) sv[kp] = sp[(int64_t)(2 * kp) * HW];
+    for (int kp = 0; kp < NP; kp++) sv[kp] = sp[(int64_t)(2 * kp) * SHW];
   }
   // ... and its share of the weight slices (thread -> (o, c) pairs, the four taps 4, 5, 7, 8 of each)
   constexpr int PAIRS = O * 32 / 256;
@@ -731,14 +752,13 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
 #pragma unroll
   for (int i = 0; i < PAIRS; i++) {
     const int e = threadIdx.x + 256 * i, o = e >> 5, c = e & 31;
-    const float* q = w + ((int64_t)o * C + c0 + c) * 9;
-    wv[i][0] = q[4]; wv[i][1] = q[5]; wv[i][2] = q[7]; wv[i][3] = q[8];
+    OwGeo<GEO>::slices(w, (int64_t)o * C + c0 + c, wv[i]);
   }
 #pragma unroll
   for (int i = 0; i < PAIRS; i++) {
     const int e = threadIdx.x + 256 * i, o = e >> 5, c = e & 31;
 #pragma unroll
-    for (int q = 0; q < 4; q++) Wl[q][o][c] = wv[i][q];
+    for (int q = 0; q < NSL; q++) Wl[q][o][c] = wv[i][q];
   }
   __syncthreads();
   if (!live) return;
@@ -746,7 +766,7 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
 #pragma unroll
   for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
+  for (int q = 0; q < NSL; q++) {
     const bool mine = cls == q;
     if (__ballot(mine) == 0ull) continue;
     float a[NP];
@@ -763,6 +783,91 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
     float val = acc[r];
     if (add) val += add[at];
     dx[at] = val;
+  }
+}
+
+// The same for 128 / 256 output channels: ONE tile per workgroup, its four waves split the reduction
+// over o four ways (each keeps O/8 dY values per lane) and their partial tiles are summed through LDS
+// in wave order.  The weight slices (4 x O x 32 floats) sit in dynamic LDS.
+template <int O, int GEO>
+__global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict__ dy, const float* __restrict__ w,
+                                                        const float* __restrict__ add, float* __restrict__ dx,
+                                                        int C, int H, int lw, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int OQ = O / 4, NP = OQ / 2, NSL = OwGeo<GEO>::NSL;
+  float* Wl = smem;                                 // [NSL][O][32]
+  float* red = smem + NSL * O * 32;                 // [3][16][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int W = 1 << lw, HW = H << lw;
+  const int c0 = blockIdx.y * 32;
+  const int slw = GEO == 0 ? lw : lw - 1;           // source plane: H x W, or H/2 x W/2
+  const int SHW = GEO == 0 ? HW : HW >> 2;
+  const int ob = wave * OQ;                         // this wave's slice of the reduction
+  // the weight slices of this channel tile, once per workgroup (it walks several pixel tiles)
+  constexpr int PAIRS = O * 32 / 256;
+  for (int i0 = 0; i0 < PAIRS; i0 += 8) {           // eight (o, c) pairs in flight per thread
+    float wv[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = threadIdx.x + 256 * (i0 + i), o = e >> 5, c = e & 31;
+      OwGeo<GEO>::slices(w, (int64_t)o * C + c0 + c, wv[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = threadIdx.x + 256 * (i0 + i), o = e >> 5, c = e & 31;
+#pragma unroll
+      for (int q = 0; q < NSL; q++) Wl[(q * O + o) * 32 + c] = wv[i][q];
+    }
+  }
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int p = tile * 32 + l31;
+    const int n = p / HW, rem = p - n * HW;
+    const int y = rem >> lw, x = rem & (W - 1);
+    int u, v, cls;
+    OwGeo<GEO>::pixel(y, x, u, v, cls);
+    float sv[NP];
+    {
+      const float* sp = dy + ((int64_t)n * O + ob + half) * SHW + (u << slw) + v;
+#pragma unroll
+      for (int kp = 0; kp < NP; kp++) sv[kp] = sp[(int64_t)(2 * kp) * SHW];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NSL; q++) {
+      const bool mine = cls == q;
+      if (__ballot(mine) == 0ull) continue;
+      const float* wq = Wl + (q * O + ob + half) * 32 + l31;
+      float a[NP];
+#pragma unroll
+      for (int kp = 0; kp < NP; kp++) a[kp] = wq[2 * kp * 32];
+#pragma unroll
+      for (int kp = 0; kp < NP; kp++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], mine ? sv[kp] : 0.0f, acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int ww = 0; ww < 3; ww++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] += red[(ww * 16 + r) * 64 + lane];
+      const int64_t obase = ((int64_t)n * C + c0) * HW + rem;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int64_t at = obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW;
+        float val = acc[r];
+        if (add) val += add[at];
+        dx[at] = val;
+      }
+    }
+    __syncthreads();                                // red is reused by the next tile
   }
 }
 
@@ -3014,12 +3119,40 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
     static int lean = getenv("DFHIP_DGRAD_LEAN") ? atoi(getenv("DFHIP_DGRAD_LEAN")) : 1;
     int lw = 0;
     while ((1 << lw) < W) lw++;
-    if (lean && mode == 0 && k == 3 && stride == 1 && pad == 1 && (O == 32 || O == 64) && C % 32 == 0 &&
-        (1 << lw) == W && (H * W) % 32 == 0 && H >= 2 && W >= 2) {
-      const int tiles = (int)((int64_t)N * H * W / 32);
+    // (a tile is 32 consecutive pixels of the flattened (n, y, x) space; every lane decodes its own pixel)
+    const int geo = (k == 3 && stride == 1 && pad == 1) ? 0 : (k == 3 && stride == 2 && pad == 1) ? 1
+                    : (k == 1 && stride == 2 && pad == 0) ? 2 : -1;
+    const bool lean_ok = lean && mode == 0 && geo >= 0 && C % 32 == 0 && (1 << lw) == W && H >= 2 && W >= 2 &&
+                         ((int64_t)N * H * W) % 32 == 0 && (geo == 0 || (H % 2 == 0 && oh * 2 == H && ow * 2 == W));
+    const int tiles = lean_ok ? (int)((int64_t)N * H * W / 32) : 0;
+    if (lean_ok && (O == 128 || O == 256)) {
+      // about two workgroups per CU (one at 256 channels: 140 KB of LDS); each walks tiles / grid.x tiles
+      // (1x1: the slice is small, one tile per workgroup)
+      const int want = geo == 2 ? tiles : std::max(1, num_cus() * (O == 128 ? 2 : 1) / (C / 32));
+      dim3 grid((unsigned)std::min(tiles, want), (unsigned)(C / 32));
+      const size_t lds = ((size_t)(geo == 2 ? 1 : 4) * O * 32 + 3 * 16 * 64) * sizeof(float);
+#define DF_KS(OV, GV)                                                                                         \
+  do {                                                                                                        \
+    static bool attr = false;                                                                                 \
+    if (!attr) {                                                                                              \
+      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_s1_ks<OV, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)std::max(lds, (size_t)65536)));                                         \
+      attr = true;                                                                                            \
+    }                                                                                                         \
+    hipLaunchKernelGGL((k_dgrad_ow_s1_ks<OV, GV>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, H, lw, tiles); \
+  } while (0)
+      if (O == 128) { if (geo == 0) DF_KS(128, 0); else if (geo == 1) DF_KS(128, 1); else DF_KS(128, 2); }
+      else { if (geo == 0) DF_KS(256, 0); else if (geo == 1) DF_KS(256, 1); else DF_KS(256, 2); }
+#undef DF_KS
+      DF_LAUNCH_CHECK();
+      return DFHIP_OK;
+    }
+    if (lean_ok && (O == 32 || O == 64)) {
       dim3 grid((unsigned)df_ceil_div(tiles, 4), (unsigned)(C / 32));
-      if (O == 32) hipLaunchKernelGGL(k_dgrad_ow_s1<32>, grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles);
-      else hipLaunchKernelGGL(k_dgrad_ow_s1<64>, grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles);
+#define DF_A(OV, GV) hipLaunchKernelGGL((k_dgrad_ow_s1<OV, GV>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles)
+      if (O == 32) { if (geo == 0) DF_A(32, 0); else if (geo == 1) DF_A(32, 1); else DF_A(32, 2); }
+      else { if (geo == 0) DF_A(64, 0); else if (geo == 1) DF_A(64, 1); else DF_A(64, 2); }
+#undef DF_A
       DF_LAUNCH_CHECK();
       return DFHIP_OK;
     }

@@ -214,23 +214,29 @@ def test_few_channel_stem_kernel(hip_device, C, H, O, N, with_bias):
     assert_close(got, want, 1e-4, f"stem kernel C={C} H={H} O={O}")
 
 
-@pytest.mark.parametrize("N,C,O,H,W", [(3, 32, 32, 4, 8), (2, 64, 64, 8, 8), (1, 96, 32, 2, 16), (5, 32, 64, 16, 16),
-                                       (2, 32, 32, 32, 32)])
-def test_lean_overwrite_dgrad(hip_device, N, C, O, H, W):
-    """k_dgrad_ow_s1: the overwrite-mode input gradient of a 3x3 / stride 1 / pad 1 convolution as a
-    shifted 1x1 convolution (every image border class present), with and without the held gradient."""
+@pytest.mark.parametrize("N,C,O,H,W,k,s,p", [
+    (3, 32, 32, 4, 8, 3, 1, 1), (2, 64, 64, 8, 8, 3, 1, 1), (1, 96, 32, 2, 16, 3, 1, 1), (5, 32, 64, 16, 16, 3, 1, 1),
+    (2, 32, 32, 32, 32, 3, 1, 1), (8, 128, 128, 4, 4, 3, 1, 1), (16, 64, 256, 2, 2, 3, 1, 1), (6, 32, 128, 4, 4, 3, 1, 1),
+    (4, 32, 32, 2, 4, 3, 1, 1),
+    (2, 32, 64, 16, 16, 3, 2, 1), (4, 64, 128, 8, 8, 3, 2, 1), (8, 128, 256, 4, 4, 3, 2, 1), (2, 32, 32, 4, 8, 3, 2, 1),
+    (2, 32, 64, 16, 16, 1, 2, 0), (4, 64, 128, 8, 8, 1, 2, 0), (8, 128, 256, 4, 4, 1, 2, 0), (16, 32, 32, 2, 2, 1, 2, 0)])
+def test_lean_overwrite_dgrad(hip_device, N, C, O, H, W, k, s, p):
+    """k_dgrad_ow_s1 / _ks: the overwrite-mode input gradient as the 1x1 convolution it is (3x3 stride 1:
+    shifted, edge-clamped dY, four border classes; 3x3 stride 2: up-sampled dY, four parity classes;
+    1x1 stride 2: even pixels only), with and without the held gradient."""
     from conftest import assert_close
     from oracle import ref_ops as R
     mod = hip_device.mod
-    rng = np.random.default_rng(N * 1000 + C + O)
-    dy = rng.standard_normal((N, O, H, W)).astype(np.float32)
-    w = rng.standard_normal((O, C, 3, 3)).astype(np.float32)
+    rng = np.random.default_rng(N * 1000 + C + O + 7 * k + s)
+    oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = rng.standard_normal((N, O, oh, ow)).astype(np.float32)
+    w = rng.standard_normal((O, C, k, k)).astype(np.float32)
     held = rng.standard_normal((N, C, H, W)).astype(np.float32)
-    want = R.conv2d_dgrad(dy, w, (N, C, H, W), 1, 1, "overwrite")
+    want = R.conv2d_dgrad(dy, w, (N, C, H, W), s, p, "overwrite")
     dyh, wh, hh = _arr(mod, dy), _arr(mod, w), _arr(mod, held)
     dx = mod.Array(N * C * H * W)
-    mod.conv2d_dgrad(dyh, wh, dx, N, C, H, W, O, 3, 1, 1, mode="overwrite")
+    mod.conv2d_dgrad(dyh, wh, dx, N, C, H, W, O, k, s, p, mode="overwrite")
     assert_close(_back(mod, dx).reshape(N, C, H, W), want, 1e-4, "lean dgrad")
     dx2 = mod.Array(N * C * H * W)
-    mod.conv2d_dgrad_add(dyh, wh, hh, dx2, N, C, H, W, O, 3, 1, 1, mode="overwrite")
+    mod.conv2d_dgrad_add(dyh, wh, hh, dx2, N, C, H, W, O, k, s, p, mode="overwrite")
     assert_close(_back(mod, dx2).reshape(N, C, H, W), want + held, 1e-4, "lean dgrad + held gradient")
