@@ -713,6 +713,23 @@ struct OwGeo {
     else if (GEO == 1) { u = y >> 1; v = x >> 1; cls = ((y & 1) << 1) + (x & 1); }
     else { u = y >> 1; v = x >> 1; cls = ((y | x) & 1) ? -1 : 0; }
   }
+  // lane -> pixel of tile t.  Default: 32 consecutive pixels of the flattened (n, y, x) space.  Stride 2
+  // with pg: the four tiles 4b..4b+3 are the four parity classes of one block of 128 flat pixels (128/W
+  // flat rows), so a tile holds ONE class -- a quarter of the MFMAs of a mixed tile -- and its lanes read
+  // a dense run of dY; the classes' stride-2 stores complete each other's cache lines.
+  __device__ static void decode(int t, int l31, int lw, int H, int pg, int& n, int& y, int& x) {
+    if (GEO == 1 && pg) {
+      const int b = t >> 2, py = (t >> 1) & 1, px = t & 1;
+      const int ry = l31 >> (lw - 1), rx = l31 & ((1 << (lw - 1)) - 1);
+      const int R = b * (128 >> lw) + 2 * ry + py;          // flat row (n * H + y); H is even
+      n = R / H; y = R - n * H; x = 2 * rx + px;
+    } else {
+      const int HW = H << lw, p = t * 32 + l31;
+      n = p / HW;
+      const int rem = p - n * HW;
+      y = rem >> lw; x = rem & ((1 << lw) - 1);
+    }
+  }
   // the NSL weights of one (o, c) pair, from the (O, C, k, k) tensor
   __device__ static void slices(const float* __restrict__ w, int64_t oc, float (&out)[4]) {
     if (GEO == 2) { out[0] = w[oc]; out[1] = out[2] = out[3] = 0.0f; }
@@ -723,7 +740,7 @@ struct OwGeo {
 template <int O, int GEO>
 __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ dy, const float* __restrict__ w,
                                                      const float* __restrict__ add, float* __restrict__ dx,
-                                                     int C, int H, int lw, int tiles) {
+                                                     int C, int H, int lw, int tiles, int pg) {
   constexpr int NP = O / 2, NSL = OwGeo<GEO>::NSL;
   __shared__ float Wl[NSL][O][32];                  // the weight slices of this channel tile: [slice][o][c]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -732,9 +749,9 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
   const int c0 = blockIdx.y * 32;
   const int tile = min(blockIdx.x * 4 + wave, tiles - 1);   // 32 consecutive pixels of one image (clamped: a
   const bool live = blockIdx.x * 4 + wave < tiles;          //  wave past the end still takes part in the barrier)
-  const int p = tile * 32 + l31;                    // flat (n, y, x)
-  const int n = p / HW, rem = p - n * HW;
-  const int y = rem >> lw, x = rem & (W - 1);
+  int n, y, x;
+  OwGeo<GEO>::decode(tile, l31, lw, H, pg, n, y, x);
+  const int rem = (y << lw) + x;
   int u, v, cls;                                    // source pixel, slice q <-> tap (1 + (q >> 1), 1 + (q & 1))
   OwGeo<GEO>::pixel(y, x, u, v, cls);
   const int slw = GEO == 0 ? lw : lw - 1;           // source plane: H x W, or H/2 x W/2
@@ -792,7 +809,7 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
 template <int O, int GEO>
 __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict__ dy, const float* __restrict__ w,
                                                         const float* __restrict__ add, float* __restrict__ dx,
-                                                        int C, int H, int lw, int tiles) {
+                                                        int C, int H, int lw, int tiles, int pg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int OQ = O / 4, NP = OQ / 2, NSL = OwGeo<GEO>::NSL;
   float* Wl = smem;                                 // [NSL][O][32]
@@ -822,9 +839,9 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict_
   }
   __syncthreads();
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int p = tile * 32 + l31;
-    const int n = p / HW, rem = p - n * HW;
-    const int y = rem >> lw, x = rem & (W - 1);
+    int n, y, x;
+    OwGeo<GEO>::decode(tile, l31, lw, H, pg, n, y, x);
+    const int rem = (y << lw) + x;
     int u, v, cls;
     OwGeo<GEO>::pixel(y, x, u, v, cls);
     float sv[NP];
@@ -3125,6 +3142,8 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
     const bool lean_ok = lean && mode == 0 && geo >= 0 && C % 32 == 0 && (1 << lw) == W && H >= 2 && W >= 2 &&
                          ((int64_t)N * H * W) % 32 == 0 && (geo == 0 || (H % 2 == 0 && oh * 2 == H && ow * 2 == W));
     const int tiles = lean_ok ? (int)((int64_t)N * H * W / 32) : 0;
+    // stride 2: parity-grouped tiles when whole 128-pixel blocks tile the tensor
+    const int pg = (geo == 1 && ((int64_t)N * H * W) % 128 == 0 && W <= 64) ? 1 : 0;
     if (lean_ok && (O == 128 || O == 256)) {
       // about two workgroups per CU (one at 256 channels: 140 KB of LDS); each walks tiles / grid.x tiles
       // (1x1: the slice is small, one tile per workgroup)
@@ -3139,7 +3158,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
                                  (int)std::max(lds, (size_t)65536)));                                         \
       attr = true;                                                                                            \
     }                                                                                                         \
-    hipLaunchKernelGGL((k_dgrad_ow_s1_ks<OV, GV>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, H, lw, tiles); \
+    hipLaunchKernelGGL((k_dgrad_ow_s1_ks<OV, GV>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, H, lw, tiles, pg); \
   } while (0)
       if (O == 128) { if (geo == 0) DF_KS(128, 0); else if (geo == 1) DF_KS(128, 1); else DF_KS(128, 2); }
       else { if (geo == 0) DF_KS(256, 0); else if (geo == 1) DF_KS(256, 1); else DF_KS(256, 2); }
@@ -3149,7 +3168,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
     }
     if (lean_ok && (O == 32 || O == 64)) {
       dim3 grid((unsigned)df_ceil_div(tiles, 4), (unsigned)(C / 32));
-#define DF_A(OV, GV) hipLaunchKernelGGL((k_dgrad_ow_s1<OV, GV>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles)
+#define DF_A(OV, GV) hipLaunchKernelGGL((k_dgrad_ow_s1<OV, GV>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg)
       if (O == 32) { if (geo == 0) DF_A(32, 0); else if (geo == 1) DF_A(32, 1); else DF_A(32, 2); }
       else { if (geo == 0) DF_A(64, 0); else if (geo == 1) DF_A(64, 1); else DF_A(64, 2); }
 #undef DF_A
