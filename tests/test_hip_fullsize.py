@@ -154,6 +154,8 @@ def test_grouped_wgrad_all_layers(hip_device):
     run as one launch equal the stand-alone launches (fp32 summation order differs) and the oracle;
     a call that touches a queued dw (here: reading it back) flushes the queue by itself."""
     mod = hip_device.mod
+    if not mod.wgrad_grouping:
+        pytest.skip("DF_WGRAD_GROUP=0")
     rng = np.random.default_rng(11)
     jobs = []
     for name, (C, H, W, O, k, s, p) in LAYERS.items():
@@ -191,6 +193,8 @@ def test_grouped_wgrad_all_layers(hip_device):
 def test_grouped_wgrad_small_batches(hip_device):
     """ragged / small batches through the grouped path (N = 2, 6, 10: fewer groups than slabs)."""
     mod = hip_device.mod
+    if not mod.wgrad_grouping:
+        pytest.skip("DF_WGRAD_GROUP=0")
     rng = np.random.default_rng(12)
     for n in (2, 6, 10):
         assert mod.wgrad_group_begin()
