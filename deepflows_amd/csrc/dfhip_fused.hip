@@ -151,6 +151,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const float* __restrict__
     if (running_var) running_var[c] = running_var[c] * (1.0f - momentum) + var * momentum;
   }
   const float sd = sqrtf(var + eps);
+  const float rsd = 1.0f / sd;   // one division per thread: (x - mean) / sd becomes a multiply
   const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
   const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
   const int64_t img_stride = (int64_t)C * HW;
@@ -160,13 +161,13 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply(const float* __restrict__
     float* q = ybase + (p - base);
     if (wdt == 4) {
       float4 v = *reinterpret_cast<const float4*>(p), r;
-      r.x = (v.x - mean) / sd * w + b;
-      r.y = (v.y - mean) / sd * w + b;
-      r.z = (v.z - mean) / sd * w + b;
-      r.w = (v.w - mean) / sd * w + b;
+      r.x = (v.x - mean) * rsd * w + b;
+      r.y = (v.y - mean) * rsd * w + b;
+      r.z = (v.z - mean) * rsd * w + b;
+      r.w = (v.w - mean) * rsd * w + b;
       *reinterpret_cast<float4*>(q) = r;
     } else {
-      q[0] = (p[0] - mean) / sd * w + b;
+      q[0] = (p[0] - mean) * rsd * w + b;
     }
   });
 }
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_eval(const float* __restrict__ 
                                                       int HW, int ipb, float eps) {
   const int c = blockIdx.x, s = blockIdx.y;
   const float mean = rmean[c], sd = sqrtf(rvar[c] + eps);
+  const float rsd = 1.0f / sd;   // one division per thread: (x - mean) / sd becomes a multiply
   const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
   const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
   const int64_t img_stride = (int64_t)C * HW;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_eval(const float* __restrict__ 
   float* ybase = y + (int64_t)c * HW;
   for_each_chunk(base, img_stride, n_lo, n_hi, HW, [&](const float* p, int wdt) {
     float* q = ybase + (p - base);
-    for (int i = 0; i < wdt; i++) q[i] = (p[i] - mean) / sd * w + b;
+    for (int i = 0; i < wdt; i++) q[i] = (p[i] - mean) * rsd * w + b;
   });
 }
 
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_stats(const float* __restri
   __shared__ float sh[4];
   const int c = blockIdx.x, s = blockIdx.y;
   const float mean = save_mean[c], sd = sqrtf(save_var[c] + eps);
+  const float rsd = 1.0f / sd;   // one division per thread: (x - mean) / sd becomes a multiply
   const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
   const int64_t img_stride = (int64_t)C * HW;
   const float* xb = x + (int64_t)c * HW;
@@ -212,11 +215,11 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_stats(const float* __restri
       float4 v = *reinterpret_cast<const float4*>(p);
       float4 gv = *reinterpret_cast<const float4*>(gq);
       s1 += (gv.x + gv.y) + (gv.z + gv.w);
-      s2 += (gv.x * ((v.x - mean) / sd) + gv.y * ((v.y - mean) / sd)) +
-            (gv.z * ((v.z - mean) / sd) + gv.w * ((v.w - mean) / sd));
+      s2 += (gv.x * ((v.x - mean) * rsd) + gv.y * ((v.y - mean) * rsd)) +
+            (gv.z * ((v.z - mean) * rsd) + gv.w * ((v.w - mean) * rsd));
     } else {
       s1 += gq[0];
-      s2 += gq[0] * ((p[0] - mean) / sd);
+      s2 += gq[0] * ((p[0] - mean) * rsd);
     }
   });
   s1 = block_sum(s1, sh);
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(
   }
   if (!dx) return;
   const float mean = save_mean[c], sd = sqrtf(save_var[c] + eps);
+  const float rsd = 1.0f / sd;   // one division per thread: (x - mean) / sd becomes a multiply
   const float w = gamma ? gamma[c] : 1.0f;
   const float m = (float)N * (float)HW;
   const float k1 = sdy / m, k2 = sdyx / m;
@@ -259,13 +263,13 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(
     if (wdt == 4) {
       float4 v = *reinterpret_cast<const float4*>(p);
       float4 gv = *reinterpret_cast<const float4*>(gq), r;
-      r.x = (gv.x - k1 - ((v.x - mean) / sd) * k2) * w / sd;
-      r.y = (gv.y - k1 - ((v.y - mean) / sd) * k2) * w / sd;
-      r.z = (gv.z - k1 - ((v.z - mean) / sd) * k2) * w / sd;
-      r.w = (gv.w - k1 - ((v.w - mean) / sd) * k2) * w / sd;
+      r.x = (gv.x - k1 - ((v.x - mean) * rsd) * k2) * w * rsd;
+      r.y = (gv.y - k1 - ((v.y - mean) * rsd) * k2) * w * rsd;
+      r.z = (gv.z - k1 - ((v.z - mean) * rsd) * k2) * w * rsd;
+      r.w = (gv.w - k1 - ((v.w - mean) * rsd) * k2) * w * rsd;
       *reinterpret_cast<float4*>(dq) = r;
     } else {
-      dq[0] = (gq[0] - k1 - ((p[0] - mean) / sd) * k2) * w / sd;
+      dq[0] = (gq[0] - k1 - ((p[0] - mean) * rsd) * k2) * w * rsd;
     }
   });
 }
@@ -315,6 +319,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
     if (running_var) running_var[c] = running_var[c] * (1.0f - momentum) + var * momentum;
   }
   const float sd = sqrtf(var + eps);
+  const float rsd = 1.0f / sd;   // one division per thread: (x - mean) / sd becomes a multiply
   const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
   const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
   const int64_t img_stride = (int64_t)C * HW;
@@ -325,17 +330,17 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
     const int64_t off = p - base;
     if (wdt == 4) {
       float4 v = *reinterpret_cast<const float4*>(p), r;
-      r.x = (v.x - mean) / sd * w + b;
-      r.y = (v.y - mean) / sd * w + b;
-      r.z = (v.z - mean) / sd * w + b;
-      r.w = (v.w - mean) / sd * w + b;
+      r.x = (v.x - mean) * rsd * w + b;
+      r.y = (v.y - mean) * rsd * w + b;
+      r.z = (v.z - mean) * rsd * w + b;
+      r.w = (v.w - mean) * rsd * w + b;
       if (rbase) {
         float4 t = *reinterpret_cast<const float4*>(rbase + off);
         r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
       }
       *reinterpret_cast<float4*>(ybase + off) = r;
     } else {
-      float r = (p[0] - mean) / sd * w + b;
+      float r = (p[0] - mean) * rsd * w + b;
       if (rbase) r += rbase[off];
       ybase[off] = r;
     }
@@ -452,6 +457,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_pool_bwd(
   __shared__ float sh[4];
   const int c = blockIdx.x, s = blockIdx.y;
   const float mean = save_mean[c], sd = sqrtf(save_var[c] + eps);
+  const float rsd = 1.0f / sd;   // one division per thread: (x - mean) / sd becomes a multiply
   const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
   float k1 = 0.0f, k2 = 0.0f;
   if (APPLY) {
@@ -491,10 +497,10 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_pool_bwd(
     for (int j = 0; j < 8; j++) {
       const float dy0 = stem_dy(r0[j], yy[j >> 1], gg[j >> 1], mean, sd, w, b);
       const float dy1 = stem_dy(r1[j], yy[j >> 1], gg[j >> 1], mean, sd, w, b);
-      const float xh0 = (r0[j] - mean) / sd, xh1 = (r1[j] - mean) / sd;
+      const float xh0 = (r0[j] - mean) * rsd, xh1 = (r1[j] - mean) * rsd;
       if (APPLY) {
-        d0[j] = (dy0 - k1 - xh0 * k2) * w / sd;
-        d1[j] = (dy1 - k1 - xh1 * k2) * w / sd;
+        d0[j] = (dy0 - k1 - xh0 * k2) * w * rsd;
+        d1[j] = (dy1 - k1 - xh1 * k2) * w * rsd;
       } else {
         s1 += dy0 + dy1;
         s2 += dy0 * xh0 + dy1 * xh1;
@@ -578,16 +584,17 @@ __global__ __launch_bounds__(512) void k_bn_fused_fwd(const float* __restrict__ 
     if (running_var) running_var[c] = running_var[c] * (1.0f - momentum) + var * momentum;
   }
   const float sd = sqrtf(var + eps);
+  const float rsd = 1.0f / sd;   // one division per thread: (x - mean) / sd becomes a multiply
   const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
   float* ybase = y + (int64_t)c * HW;
 #pragma unroll
   for (int u = 0; u < kBnVec; u++)
     if (off[u] >= 0) {
       float4 r;
-      r.x = (v[u].x - mean) / sd * w + b;
-      r.y = (v[u].y - mean) / sd * w + b;
-      r.z = (v[u].z - mean) / sd * w + b;
-      r.w = (v[u].w - mean) / sd * w + b;
+      r.x = (v[u].x - mean) * rsd * w + b;
+      r.y = (v[u].y - mean) * rsd * w + b;
+      r.z = (v[u].z - mean) * rsd * w + b;
+      r.w = (v[u].w - mean) * rsd * w + b;
       *reinterpret_cast<float4*>(ybase + off[u]) = r;
     }
 }
@@ -605,6 +612,7 @@ __global__ __launch_bounds__(512) void k_bn_fused_bwd(const float* __restrict__ 
   const int hw4 = HW >> 2, nvec = N * hw4;
   const int64_t img_stride = (int64_t)C * HW;
   const float mean = save_mean[c], sd = sqrtf(save_var[c] + eps);
+  const float rsd = 1.0f / sd;   // one division per thread: (x - mean) / sd becomes a multiply
   const float* xb = x + (int64_t)c * HW;
   const float* gb = dy + (int64_t)c * HW;
   float4 xh[kBnVec], gv[kBnVec];
@@ -619,8 +627,8 @@ __global__ __launch_bounds__(512) void k_bn_fused_bwd(const float* __restrict__ 
       off[u] = (int64_t)n * img_stride + 4 * h4;
       float4 xv = *reinterpret_cast<const float4*>(xb + off[u]);
       gv[u] = *reinterpret_cast<const float4*>(gb + off[u]);
-      xh[u].x = (xv.x - mean) / sd; xh[u].y = (xv.y - mean) / sd;
-      xh[u].z = (xv.z - mean) / sd; xh[u].w = (xv.w - mean) / sd;
+      xh[u].x = (xv.x - mean) * rsd; xh[u].y = (xv.y - mean) * rsd;
+      xh[u].z = (xv.z - mean) * rsd; xh[u].w = (xv.w - mean) * rsd;
       s1 += (gv[u].x + gv[u].y) + (gv[u].z + gv[u].w);
       s2 += (gv[u].x * xh[u].x + gv[u].y * xh[u].y) + (gv[u].z * xh[u].z + gv[u].w * xh[u].w);
     }
@@ -645,10 +653,10 @@ __global__ __launch_bounds__(512) void k_bn_fused_bwd(const float* __restrict__ 
   for (int u = 0; u < kBnVec; u++)
     if (off[u] >= 0) {
       float4 r;
-      r.x = (gv[u].x - k1 - xh[u].x * k2) * w / sd;
-      r.y = (gv[u].y - k1 - xh[u].y * k2) * w / sd;
-      r.z = (gv[u].z - k1 - xh[u].z * k2) * w / sd;
-      r.w = (gv[u].w - k1 - xh[u].w * k2) * w / sd;
+      r.x = (gv[u].x - k1 - xh[u].x * k2) * w * rsd;
+      r.y = (gv[u].y - k1 - xh[u].y * k2) * w * rsd;
+      r.z = (gv[u].z - k1 - xh[u].z * k2) * w * rsd;
+      r.w = (gv[u].w - k1 - xh[u].w * k2) * w * rsd;
       *reinterpret_cast<float4*>(db + off[u]) = r;
     }
 }
