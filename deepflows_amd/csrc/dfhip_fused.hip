@@ -393,8 +393,9 @@ __global__ __launch_bounds__(kThreads) void k_onehot_smooth(const int* __restric
 //   relu:     gradient passes where output == input                        (tensor.py:872-877)
 // see the values the forward produced.  Block (c, s) owns images [s*ipb, (s+1)*ipb) of channel c;
 // a thread item is a 2 x 8 input patch = 4 pooled outputs.  W % 8 == 0, H % 2 == 0.
-__device__ __forceinline__ float bn_point(float v, float mean, float sd, float w, float b) {
-  return __fadd_rn(__fmul_rn(__fdiv_rn(__fsub_rn(v, mean), sd), w), b);
+__device__ __forceinline__ float bn_point(float v, float mean, float rsd, float w, float b) {
+  // (rsd = 1 / sd, the same value in the forward and in the backward kernel: both see the same outputs)
+  return __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v, mean), rsd), w), b);
 }
 __device__ __forceinline__ float relu_point(float a) { return (a != a) ? a : (a > 0.0f ? a : 0.0f); }
 __device__ __forceinline__ float max_nan(float m, float v) { return (m != m) ? m : ((v != v) ? v : (v > m ? v : m)); }
@@ -414,6 +415,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_pool_fwd(
     if (running_var) running_var[c] = running_var[c] * (1.0f - momentum) + var * momentum;
   }
   const float sd = sqrtf(var + eps);
+  const float rsd = 1.0f / sd;
   const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
   const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
   const int oh = H >> 1, ow = W >> 1, ow4 = ow >> 2;
@@ -430,10 +432,10 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_pool_fwd(
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      float m = relu_point(bn_point(r0[2 * j], mean, sd, w, b));
-      m = max_nan(m, relu_point(bn_point(r0[2 * j + 1], mean, sd, w, b)));
-      m = max_nan(m, relu_point(bn_point(r1[2 * j], mean, sd, w, b)));
-      m = max_nan(m, relu_point(bn_point(r1[2 * j + 1], mean, sd, w, b)));
+      float m = relu_point(bn_point(r0[2 * j], mean, rsd, w, b));
+      m = max_nan(m, relu_point(bn_point(r0[2 * j + 1], mean, rsd, w, b)));
+      m = max_nan(m, relu_point(bn_point(r1[2 * j], mean, rsd, w, b)));
+      m = max_nan(m, relu_point(bn_point(r1[2 * j + 1], mean, rsd, w, b)));
       o[j] = m;
     }
     *reinterpret_cast<float4*>(y + (((int64_t)img * C + c) * oh + oy) * ow + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
@@ -441,8 +443,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_pool_fwd(
 }
 
 // gradient that reaches the BatchNorm output at one input position
-__device__ __forceinline__ float stem_dy(float v, float pooled, float g, float mean, float sd, float w, float b) {
-  const float bo = bn_point(v, mean, sd, w, b);
+__device__ __forceinline__ float stem_dy(float v, float pooled, float g, float mean, float rsd, float w, float b) {
+  const float bo = bn_point(v, mean, rsd, w, b);
   const float r = relu_point(bo);
   const float gp = (pooled == r ? 1.0f : 0.0f) * g;
   return (r == bo ? 1.0f : 0.0f) * gp;
@@ -495,8 +497,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_pool_bwd(
     float d0[8], d1[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const float dy0 = stem_dy(r0[j], yy[j >> 1], gg[j >> 1], mean, sd, w, b);
-      const float dy1 = stem_dy(r1[j], yy[j >> 1], gg[j >> 1], mean, sd, w, b);
+      const float dy0 = stem_dy(r0[j], yy[j >> 1], gg[j >> 1], mean, rsd, w, b);
+      const float dy1 = stem_dy(r1[j], yy[j >> 1], gg[j >> 1], mean, rsd, w, b);
       const float xh0 = (r0[j] - mean) * rsd, xh1 = (r1[j] - mean) * rsd;
       if (APPLY) {
         d0[j] = (dy0 - k1 - xh0 * k2) * w * rsd;
