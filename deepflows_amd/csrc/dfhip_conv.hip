@@ -279,7 +279,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   const int CCP = g.CC;                       // channels per chunk: 8, 16 or 32
   const int RS = MODE == 0 ? CCP * k2 + 4 : 32 * k2;
   const int PEp = g.PE;                       // floats per channel in the LDS image: BI * RL
-  const int xs_floats = CCP * PEp;
+  // channel pitch: the image plus one 16-byte slot that stays ZERO -- an invalid (pixel, tap) reads that
+  // slot instead of being zeroed by a select in front of every MFMA
+  const int PEs = PEp + 4;
+  const int xs_floats = CCP * PEs;
   constexpr int WT = 33;                      // forward: row pitch of the transposed weight image
   const int ws_floats = MODE == 0 ? CCP * k2 * WT : CCP * RS;
   float* Xs0 = smem;
@@ -319,12 +322,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   const int RL4 = RL >> 2;
   const int pvecs = CCP * g.BI * RL4;
   unsigned p_src[kPV];
+  int p_lx[kPV];
 #pragma unroll
   for (int u = 0; u < kPV; u++) {
     int v = tid + 512 * u;
     v = v < pvecs ? v : 0;
     int c = (int)fast_div((unsigned)v, g.m_birl4);
     int rem = v - c * (g.BI * RL4);
+    p_lx[u] = c * PEs + 4 * rem;
     int im = (int)fast_div((unsigned)rem, g.m_rl4), q4 = rem - im * RL4;
     int imc = min(im, g.N - 1 - n0);            // images past the batch end are never read
     p_src[u] = (unsigned)(((int64_t)imc * g.CS + c) * src_plane + (int64_t)su_lo * g.WS + 4 * q4);
@@ -375,8 +380,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   do {                                                                                           \
     float* Xs_ = Xs0 + (buf) * xs_floats;                                                        \
     float* Wl_ = Ws0 + (buf) * ws_floats;                                                        \
-    if (tid < pvecs) *reinterpret_cast<f32x4*>(Xs_ + 4 * tid) = pv0;                             \
-    if (tid + 512 < pvecs) *reinterpret_cast<f32x4*>(Xs_ + 4 * (tid + 512)) = pv1;               \
+    if (tid < pvecs) *reinterpret_cast<f32x4*>(Xs_ + p_lx[0]) = pv0;                             \
+    if (tid + 512 < pvecs) *reinterpret_cast<f32x4*>(Xs_ + p_lx[1]) = pv1;                       \
     DF_WSTORE(0, wv0); DF_WSTORE(1, wv1); DF_WSTORE(2, wv2); DF_WSTORE(3, wv3); DF_WSTORE(4, wv4); \
   } while (0)
 
@@ -412,11 +417,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
       int su = ok ? (int)fast_div((unsigned)un, g.m_sd) : 0, sv = ok ? (int)fast_div((unsigned)vn, g.m_sd) : 0;
       ok = ok && su * g.sd == un && sv * g.sd == vn && su < g.HS && sv < g.WS;
       if (MODE == 2) ok = ok && tapsel == t;
-      poff[t] = ok ? img * RL + (su - su_lo) * g.WS + sv : 0;
+      poff[t] = ok ? img * RL + (su - su_lo) * g.WS + sv : PEp;      // PEp: the channel's zero slot
       vmask |= ok ? (1u << t) : 0u;
     }
   }
 
+  if (tid < 2 * CCP) {                           // the zero slot of every channel of both buffers
+    const int zb = tid >= CCP ? 1 : 0, zc = tid - zb * CCP;
+    *reinterpret_cast<f32x4*>(Xs0 + zb * xs_floats + zc * PEs + PEp) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   DF_COMMIT(0);
   DF_STAMP();
   __syncthreads();
@@ -427,11 +436,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   const int npk = NPK ? NPK : (CCP >> 1) / KSPLIT;
   const int c_first = 2 * ks * npk + half;    // this lane's first channel inside a chunk
   const int astep = MODE == 0 ? 2 * k2 * WT : 2 * RS;
-  const int bstep = 2 * PEp;
+  const int bstep = 2 * PEs;
   for (int ch = 0; ch < nchunks; ch++) {
     const int buf = ch & 1;
     if (ch + 1 < nchunks) DF_ISSUE(ch + 1);    // lands while this chunk is in the matrix cores
-    const float* Xb = Xs0 + buf * xs_floats + c_first * PEp;
+    const float* Xb = Xs0 + buf * xs_floats + c_first * PEs;
     const float* aq = Ws0 + buf * ws_floats + (MODE == 0 ? c_first * k2 * WT + l31 : c_first * RS + l31 * k2);
     if constexpr (MODE != 2 && NPK > 0) {
       // forward / accumulate: all taps straight-line (whole-wave-invalid taps are rare here), the
@@ -454,12 +463,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        const bool ok = (vmask >> t) & 1u;
 #pragma unroll
-        for (int p = 0; p < NPK; p++) {
-          const float b = ok ? bv[t & 1][p] : 0.0f;
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][p], b, acc, 0, 0, 0);
-        }
+        for (int p = 0; p < NPK; p++)      // (an invalid lane's operand came from the zero slot)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][p], bv[t & 1][p], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else
@@ -2437,7 +2443,7 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, 
     static size_t lds_cap_single = (size_t)(getenv("DFHIP_LDS_SINGLE") ? atoi(getenv("DFHIP_LDS_SINGLE")) : 150) * 1024;
     auto fits = [&](int cc) {
       size_t wl = g.mode == 0 ? (size_t)33 * cc * k2 : (size_t)cc * 32 * k2;
-      size_t stage_b = 2 * ((size_t)cc * g.PE + wl) * 4;
+      size_t stage_b = 2 * ((size_t)cc * (g.PE + 4) + wl) * 4;    // (+4: the zero slot of a channel)
       size_t red_b = (size_t)pt * (ksplit - 1) * 16 * 64 * 4;
       lds = std::max(stage_b, red_b);
       int pvecs = cc * g.PE / 4, wvecs = 8 * cc * k2;
