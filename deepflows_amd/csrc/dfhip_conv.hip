@@ -334,6 +334,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
     int imc = min(im, g.N - 1 - n0);            // images past the batch end are never read
     p_src[u] = (unsigned)(((int64_t)imc * g.CS + c) * src_plane + (int64_t)su_lo * g.WS + 4 * q4);
   }
+  // the first chunk's source planes are requested NOW (they come from HBM, the weights from L2): the
+  // weight descriptors below are computed while those loads are in flight
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 pv0, pv1, wv0, wv1, wv2, wv3, wv4;
+#define DF_ISSUE_X(chunk)                                                                        \
+  do {                                                                                           \
+    const float* xb = g.src + ((int64_t)n0 * g.CS + (int64_t)(chunk) * CCP) * src_plane;         \
+    pv0 = *reinterpret_cast<const f32x4*>(xb + p_src[0]);                                        \
+    pv1 = *reinterpret_cast<const f32x4*>(xb + p_src[1]);                                        \
+  } while (0)
+  DF_ISSUE_X(0);
+  __builtin_amdgcn_sched_barrier(0);
   const int run4 = (MODE == 0 ? CCP * k2 : 32 * k2) >> 2;
   const int wvecs = run4 * (MODE == 0 ? 32 : CCP);
   const int dmax = min(32, g.CD - d0);
@@ -350,9 +362,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
     w_lx[u] = live ? ((MODE == 0 && row >= dmax) ? -2 : row * RS + 4 * e4) : -1;
   }
 
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x4 pv0, pv1, wv0, wv1, wv2, wv3, wv4;
-#define DF_ISSUE(chunk)                                                                          \
+#define DF_ISSUE_W(chunk)                                                                        \
   do {                                                                                           \
     const float* wb = g.wgt + (int64_t)(chunk) * CCP * (MODE == 0 ? k2 : g.wC * k2);            \
     wv0 = *reinterpret_cast<const f32x4*>(wb + w_src[0]);                                        \
@@ -360,10 +370,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
     wv2 = *reinterpret_cast<const f32x4*>(wb + w_src[2]);                                        \
     wv3 = *reinterpret_cast<const f32x4*>(wb + w_src[3]);                                        \
     wv4 = *reinterpret_cast<const f32x4*>(wb + w_src[4]);                                        \
-    const float* xb = g.src + ((int64_t)n0 * g.CS + (int64_t)(chunk) * CCP) * src_plane;         \
-    pv0 = *reinterpret_cast<const f32x4*>(xb + p_src[0]);                                        \
-    pv1 = *reinterpret_cast<const f32x4*>(xb + p_src[1]);                                        \
   } while (0)
+#define DF_ISSUE(chunk) do { DF_ISSUE_W(chunk); DF_ISSUE_X(chunk); } while (0)
 #define DF_WSTORE(u, val)                                                                        \
   do {                                                                                           \
     if (MODE == 0) {                                                                             \
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   for (int rr = 0; rr < 16; rr++) acc[rr] = 0.0f;
 
   DF_STAMP();
-  DF_ISSUE(0);
+  DF_ISSUE_W(0);
   DF_STAMP();
   // (computed while the first chunk is in flight)
   // ---- per-lane, per-tap read descriptors of this wave's pixel tile ----
@@ -502,6 +510,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
     DF_STAMP();
   }
 #undef DF_ISSUE
+#undef DF_ISSUE_X
+#undef DF_ISSUE_W
 #undef DF_COMMIT
 #undef DF_WSTORE
 
