@@ -53,6 +53,8 @@ _SIGS = {
     "dfhip_bn2d_forward_train": [P] * 8 + [c_int, c_int, c_int, c_float, c_float],
     "dfhip_bn2d_forward_eval": [P] * 6 + [c_int, c_int, c_int, c_float],
     "dfhip_bn2d_backward": [P] * 8 + [c_int, c_int, c_int, c_float],
+    "dfhip_bn2d_forward_partials_pair": ([P, P, c_int] + [P] * 6 + [c_float, c_float]) * 2 + [P, c_int, c_int, c_int],
+    "dfhip_bn2d_backward_pair": [P] + ([P] * 7 + [c_float]) * 2 + [c_int, c_int, c_int],
     "dfhip_bn_relu_maxpool2_forward": [P] * 8 + [c_int] * 4 + [c_float, c_float],
     "dfhip_bn_relu_maxpool2_backward": [P] * 10 + [c_int] * 4 + [c_float],
     "dfhip_upload_async": [P, P, c_int64, c_int],

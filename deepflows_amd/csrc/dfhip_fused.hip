@@ -347,6 +347,86 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
   });
 }
 
+// y = bnA(xA) + bnB(xB): the tail of a residual block whose shortcut is itself convolution +
+// BatchNorm (batch statistics of both from their convolutions' partials).  One launch instead of
+// two, and bnB's output is never written and read back.
+struct BnFwdSet {
+  const float* x; const float* partials; int rows;
+  const float* gamma; const float* beta;
+  float* save_mean; float* save_var; float* running_mean; float* running_var;
+  float eps, momentum;
+};
+
+__device__ __forceinline__ void bn_partials_stats(const BnFwdSet& q, int c, int C, bool writer, float (*sw)[3],
+                                                  float& mean, float& rsd, float& w, float& b) {
+  const int tid = threadIdx.x;
+  auto chan = [](float& n, float& mu, float& m2, float nb, float mub, float m2b) {
+    if (nb > 0.0f) {
+      const float nn = n + nb, delta = mub - mu;
+      mu += delta * (nb / nn);
+      m2 += m2b + delta * delta * (n * nb / nn);
+      n = nn;
+    }
+  };
+  float n = 0.0f, mu = 0.0f, m2 = 0.0f;
+  for (int r = tid; r < q.rows; r += kThreads) {
+    const float* p = q.partials + ((int64_t)r * C + c) * 3;
+    chan(n, mu, m2, p[0], p[1], p[2]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_down(n, o, 64), mub = __shfl_down(mu, o, 64), m2b = __shfl_down(m2, o, 64);
+    chan(n, mu, m2, nb, mub, m2b);
+  }
+  __syncthreads();                                  // sw may still be read from the previous set
+  if ((tid & 63) == 0) { sw[tid >> 6][0] = n; sw[tid >> 6][1] = mu; sw[tid >> 6][2] = m2; }
+  __syncthreads();
+  n = sw[0][0]; mu = sw[0][1]; m2 = sw[0][2];
+#pragma unroll
+  for (int w4 = 1; w4 < 4; w4++) chan(n, mu, m2, sw[w4][0], sw[w4][1], sw[w4][2]);
+  mean = mu;
+  const float var = n > 0.0f ? m2 / n : 0.0f;      // biased variance (batchnorm.py:41-42)
+  if (writer) {
+    if (q.save_mean) q.save_mean[c] = mean;
+    if (q.save_var) q.save_var[c] = var;
+    if (q.running_mean) q.running_mean[c] = q.running_mean[c] * (1.0f - q.momentum) + mean * q.momentum;
+    if (q.running_var) q.running_var[c] = q.running_var[c] * (1.0f - q.momentum) + var * q.momentum;
+  }
+  rsd = 1.0f / sqrtf(var + q.eps);
+  w = q.gamma ? q.gamma[c] : 1.0f;
+  b = q.beta ? q.beta[c] : 0.0f;
+}
+
+__global__ __launch_bounds__(kThreads) void k_bn_apply_partials_pair(BnFwdSet A, BnFwdSet B, float* __restrict__ y,
+                                                                     int N, int C, int HW, int ipb) {
+  __shared__ float sw[4][3];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const bool writer = s == 0 && threadIdx.x == 0;
+  float ma, ra, wa, ba, mb, rb, wb, bb;
+  bn_partials_stats(A, c, C, writer, sw, ma, ra, wa, ba);
+  bn_partials_stats(B, c, C, writer, sw, mb, rb, wb, bb);
+  const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
+  const int64_t img_stride = (int64_t)C * HW;
+  const float* base = A.x + (int64_t)c * HW;
+  const float* bbase = B.x + (int64_t)c * HW;
+  float* ybase = y + (int64_t)c * HW;
+  for_each_chunk(base, img_stride, n_lo, n_hi, HW, [&](const float* p, int wdt) {
+    const int64_t off = p - base;
+    if (wdt == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      const float4 u = *reinterpret_cast<const float4*>(bbase + off);
+      float4 r;
+      r.x = ((v.x - ma) * ra * wa + ba) + ((u.x - mb) * rb * wb + bb);
+      r.y = ((v.y - ma) * ra * wa + ba) + ((u.y - mb) * rb * wb + bb);
+      r.z = ((v.z - ma) * ra * wa + ba) + ((u.z - mb) * rb * wb + bb);
+      r.w = ((v.w - ma) * ra * wa + ba) + ((u.w - mb) * rb * wb + bb);
+      *reinterpret_cast<float4*>(ybase + off) = r;
+    } else {
+      ybase[off] = ((p[0] - ma) * ra * wa + ba) + ((bbase[off] - mb) * rb * wb + bb);
+    }
+  });
+}
+
 // ---- input pipeline on the device (test/ResNet_CIFAR10_cuda.py:129-148, 180-184) -----------------
 // augment_batch: reflect-pad by `pad`, crop at (ys, xs), horizontal flip, optional erase rectangle,
 // clip to [-1, 1] — pure data movement, bit-exact.  The per-image decisions (drawn on the host in
@@ -601,7 +681,7 @@ __global__ __launch_bounds__(512) void k_bn_fused_fwd(const float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(512) void k_bn_fused_bwd(const float* __restrict__ dy,
+__device__ __forceinline__ void bn_fused_bwd_body(int c, const float* __restrict__ dy,
                                                       const float* __restrict__ x,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ save_mean,
@@ -610,7 +690,7 @@ __global__ __launch_bounds__(512) void k_bn_fused_bwd(const float* __restrict__ 
                                                       float* __restrict__ dbeta, int N, int C, int HW,
                                                       float eps) {
   __shared__ float sh[16];
-  const int c = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int hw4 = HW >> 2, nvec = N * hw4;
   const int64_t img_stride = (int64_t)C * HW;
   const float mean = save_mean[c], sd = sqrtf(save_var[c] + eps);
@@ -661,6 +741,26 @@ __global__ __launch_bounds__(512) void k_bn_fused_bwd(const float* __restrict__ 
       r.w = (gv[u].w - k1 - xh[u].w * k2) * w * rsd;
       *reinterpret_cast<float4*>(db + off[u]) = r;
     }
+}
+
+__global__ __launch_bounds__(512) void k_bn_fused_bwd(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ save_mean,
+                                                      const float* __restrict__ save_var, float* __restrict__ dx,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
+                                                      int C, int HW, float eps) {
+  bn_fused_bwd_body(blockIdx.x, dy, x, gamma, save_mean, save_var, dx, dgamma, dbeta, N, C, HW, eps);
+}
+
+// the two BatchNorms that feed one residual sum receive the same dy: one launch, blockIdx.y picks the set
+struct BnBwdSet {
+  const float* x; const float* gamma; const float* save_mean; const float* save_var;
+  float* dx; float* dgamma; float* dbeta; float eps;
+};
+__global__ __launch_bounds__(512) void k_bn_fused_bwd_pair(const float* __restrict__ dy, BnBwdSet A, BnBwdSet B, int N,
+                                                           int C, int HW) {
+  const BnBwdSet& q = blockIdx.y ? B : A;
+  bn_fused_bwd_body(blockIdx.x, dy, q.x, q.gamma, q.save_mean, q.save_var, q.dx, q.dgamma, q.dbeta, N, C, HW, q.eps);
 }
 
 inline bool bn_fused_ok(int N, int C, int HW) {
@@ -1243,6 +1343,54 @@ int dfhip_bn2d_backward(const float* dy, const float* x, const float* gamma, con
   DF_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bn_bwd_apply, grid, dim3(kThreads), 0, stream(), dy, x, gamma, save_mean,
                      save_var, partial, dx, dgamma, dbeta, N, C, HW, S, ipb, eps);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+// y = bnA(xA) + bnB(xB), both in training mode from their convolutions' partials (dfhip_conv2d_forward_stats)
+int dfhip_bn2d_forward_partials_pair(const float* xa, const float* partials_a, int rows_a, const float* gamma_a,
+                                     const float* beta_a, float* save_mean_a, float* save_var_a,
+                                     float* running_mean_a, float* running_var_a, float eps_a, float momentum_a,
+                                     const float* xb, const float* partials_b, int rows_b, const float* gamma_b,
+                                     const float* beta_b, float* save_mean_b, float* save_var_b,
+                                     float* running_mean_b, float* running_var_b, float eps_b, float momentum_b,
+                                     float* y, int N, int C, int HW) {
+  DF_INIT();
+  DF_CHECK_ARG(N > 0 && C > 0 && HW > 0 && rows_a > 0 && rows_b > 0, "bn2d_forward_partials_pair: non-positive dimension");
+  DF_CHECK_ARG(xa && xb && y && partials_a && partials_b, "bn2d_forward_partials_pair: null array");
+  ProfScope prof("bn2d_fwd", 0.0, 12.0 * (double)N * C * HW);
+  int S, ipb;
+  bn_split(N, C, S, ipb);
+  BnFwdSet A = {xa, partials_a, rows_a, gamma_a, beta_a, save_mean_a, save_var_a, running_mean_a, running_var_a, eps_a,
+                momentum_a};
+  BnFwdSet B = {xb, partials_b, rows_b, gamma_b, beta_b, save_mean_b, save_var_b, running_mean_b, running_var_b, eps_b,
+                momentum_b};
+  hipLaunchKernelGGL(k_bn_apply_partials_pair, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), A, B, y, N,
+                     C, HW, ipb);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+// backward of y = bnA(xA) + bnB(xB): both receive dy
+int dfhip_bn2d_backward_pair(const float* dy, const float* xa, const float* gamma_a, const float* save_mean_a,
+                             const float* save_var_a, float* dxa, float* dgamma_a, float* dbeta_a, float eps_a,
+                             const float* xb, const float* gamma_b, const float* save_mean_b,
+                             const float* save_var_b, float* dxb, float* dgamma_b, float* dbeta_b, float eps_b,
+                             int N, int C, int HW) {
+  DF_INIT_KEEP();
+  DF_TOUCH(dy); DF_TOUCH(xa); DF_TOUCH(xb); DF_TOUCH(gamma_a); DF_TOUCH(gamma_b);
+  DF_TOUCH(dxa); DF_TOUCH(dxb); DF_TOUCH(dgamma_a); DF_TOUCH(dgamma_b); DF_TOUCH(dbeta_a); DF_TOUCH(dbeta_b);
+  DF_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bn2d_backward_pair: non-positive dimension");
+  DF_CHECK_ARG(dy && xa && xb && save_mean_a && save_var_a && save_mean_b && save_var_b, "bn2d_backward_pair: null array");
+  if (!bn_fused_ok(N, C, HW)) {
+    int st = dfhip_bn2d_backward(dy, xa, gamma_a, save_mean_a, save_var_a, dxa, dgamma_a, dbeta_a, N, C, HW, eps_a);
+    if (st != DFHIP_OK) return st;
+    return dfhip_bn2d_backward(dy, xb, gamma_b, save_mean_b, save_var_b, dxb, dgamma_b, dbeta_b, N, C, HW, eps_b);
+  }
+  ProfScope prof("bn2d_bwd", 0.0, 36.0 * (double)N * C * HW);
+  BnBwdSet A = {xa, gamma_a, save_mean_a, save_var_a, dxa, dgamma_a, dbeta_a, eps_a};
+  BnBwdSet B = {xb, gamma_b, save_mean_b, save_var_b, dxb, dgamma_b, dbeta_b, eps_b};
+  hipLaunchKernelGGL(k_bn_fused_bwd_pair, dim3((unsigned)C, 2), dim3(512), 0, stream(), dy, A, B, N, C, HW);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }

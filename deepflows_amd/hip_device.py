@@ -269,6 +269,22 @@ class HipModule:
         _lib.check(self._lib.dfhip_bn2d_backward(dy.ptr, x.ptr, g(gamma), save_mean.ptr, save_var.ptr,
                                                  g(dx), g(dgamma), g(dbeta), N, C, HW, float(eps)))
 
+    def bn2d_forward_partials_pair(self, a, b, y, N, C, HW):
+        """a, b = (x, partials, rows, gamma, beta, save_mean, save_var, running_mean, running_var, eps, momentum)."""
+        g = lambda h: h.ptr if h is not None else None
+        flat = []
+        for (x, part, rows, gamma, beta, sm, sv, rm, rv, eps, mom) in (a, b):
+            flat += [x.ptr, part.ptr, int(rows), g(gamma), g(beta), g(sm), g(sv), g(rm), g(rv), float(eps), float(mom)]
+        _lib.check(self._lib.dfhip_bn2d_forward_partials_pair(*flat, y.ptr, N, C, HW))
+
+    def bn2d_backward_pair(self, dy, a, b, N, C, HW):
+        """a, b = (x, gamma, save_mean, save_var, dx, dgamma, dbeta, eps)."""
+        g = lambda h: h.ptr if h is not None else None
+        flat = []
+        for (x, gamma, sm, sv, dx, dg, db, eps) in (a, b):
+            flat += [x.ptr, g(gamma), sm.ptr, sv.ptr, g(dx), g(dg), g(db), float(eps)]
+        _lib.check(self._lib.dfhip_bn2d_backward_pair(dy.ptr, *flat, N, C, HW))
+
     def bn_relu_maxpool2_forward(self, x, gamma, beta, y, save_mean, save_var, running_mean, running_var,
                                  N, C, H, W, eps, momentum):
         g = lambda h: h.ptr if h is not None else None

@@ -422,6 +422,71 @@ def batch_norm2d_train(x, weight, bias, running_mean, running_var, eps, momentum
     return _BatchNorm2dFused(x, weight, bias, running_mean, running_var, eps, momentum, residual)
 
 
+class _BatchNorm2dPairFused(_FusedNode):
+    """y = bn_a(xa) + bn_b(xb), both in training mode on convolution outputs that carry BatchNorm partials:
+    the tail of a residual block whose shortcut is convolution + BatchNorm (batchnorm.py:30-55 twice and
+    the block's "out + identity").  One forward launch (bn_b's output is never materialised) and one
+    backward launch for both layers (they receive the same gradient)."""
+
+    def __init__(self, xa, bn_a, xb, bn_b):
+        self.xs, self.bns = (xa, xb), (bn_a, bn_b)
+        N, C, H, W = (int(v) for v in xa.shape)
+        self.geo = (N, C, H * W)
+        dev = xa.device
+        self.xd = [x.data.compact() for x in self.xs]
+        self.wd = [bn.weight.data.compact() if bn.weight is not None else None for bn in self.bns]
+        self.stats = [(_new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)) for _ in range(2)]
+        out = _new(xa.shape, dev)
+        h = lambda t: t._handle if t is not None else None
+        sets = []
+        for x, xd, wd, bn, (mean, var) in zip(self.xs, self.xd, self.wd, self.bns, self.stats):
+            part, rows = x.bn_partials
+            sets.append((xd._handle, part._handle, rows, h(wd),
+                         h(bn.bias.data.compact()) if bn.bias is not None else None, mean._handle, var._handle,
+                         h(bn.running_mean.data) if bn.running_mean is not None else None,
+                         h(bn.running_var.data) if bn.running_var is not None else None, bn.eps, bn.momentum))
+        dev.bn2d_forward_partials_pair(sets[0], sets[1], out._handle, N, C, H * W)
+        self._grads = None
+        super().__init__(out, [xa, bn_a.weight, bn_a.bias, xb, bn_b.weight, bn_b.bias])
+
+    def grad_fn(self, node, grad):
+        if self._grads is None or self._grads[0] is not grad:
+            dev = grad.device
+            N, C, HW = self.geo
+            h = lambda t: t._handle if t is not None else None
+            res, sets = [], []
+            for x, xd, wd, bn, (mean, var) in zip(self.xs, self.xd, self.wd, self.bns, self.stats):
+                dx = _new(xd.shape, dev) if x.requires_grad else None
+                dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+                res.append((dx, dg, db))
+                sets.append((xd._handle, h(wd), mean._handle, var._handle, h(dx), dg._handle, db._handle, bn.eps))
+            dev.bn2d_backward_pair(grad.compact()._handle, sets[0], sets[1], N, C, HW)
+            self._grads = (grad, res)
+        _, res = self._grads
+        for i in range(2):
+            if node is self.xs[i]:
+                return res[i][0]
+            if node is self.bns[i].weight:
+                return res[i][1]
+            if node is self.bns[i].bias:
+                return res[i][2]
+        raise RuntimeError("not a parent of this node")
+
+
+def batch_norm2d_pair_fusable(xa, bn_a, xb, bn_b):
+    """True when bn_a(xa) + bn_b(xb) can run as the paired node: fused device, both layers in training
+    mode with affine parameters, equal shapes, both inputs carry convolution partials."""
+    mod = xa.device.mod
+    return (_fused(xa) and hasattr(mod, "bn2d_forward_partials_pair") and bn_a.training and bn_b.training
+            and is_grad_enable() and tuple(xa.shape) == tuple(xb.shape) and len(xa.shape) == 4
+            and getattr(xa, "bn_partials", None) is not None and getattr(xb, "bn_partials", None) is not None
+            and bn_a.weight is not None and bn_b.weight is not None and xa.device == xb.device)
+
+
+def batch_norm2d_pair_train(xa, bn_a, xb, bn_b):
+    return _BatchNorm2dPairFused(xa, bn_a, xb, bn_b)
+
+
 class _BnReluPoolFused(_FusedNode):
     """maxpool2d(relu(batch_norm2d_train(x)), 2) as one node: one forward launch after the
     statistics pass, two backward launches; the intermediate full-resolution tensors of the three

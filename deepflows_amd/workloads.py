@@ -89,12 +89,22 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         identity = x
-        if self.downsample is not None:
-            for layer in self.downsample:
+        ds = self.downsample
+        pair = ds is not None and len(ds) == 2 and isinstance(ds[1], nn.BatchNorm2d)
+        if pair:
+            zd = ds[0](x)                      # the shortcut convolution; its BatchNorm joins bn2 below
+        elif ds is not None:
+            for layer in ds:
                 identity = layer(identity)
         out = self.bn1(self.conv1(x))
+        z2 = self.conv2(out)
+        if pair:
+            if nn.functional.batch_norm2d_pair_fusable(z2, self.bn2, zd, ds[1]):
+                # bn2(conv2) + bn_d(conv_d) as one node: one launch each way for the two BatchNorms
+                return nn.functional.batch_norm2d_pair_train(z2, self.bn2, zd, ds[1])
+            identity = ds[1](zd)
         # bn2(...) + identity; one kernel on a fused device, the reference's "out + identity" otherwise
-        return self.bn2(self.conv2(out), residual=identity)
+        return self.bn2(z2, residual=identity)
 
 
 class ResNet(nn.Module):

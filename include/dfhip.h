@@ -180,6 +180,24 @@ int dfhip_bn2d_backward(const float* dy, const float* x, const float* gamma,
                         const float* save_mean, const float* save_var, float* dx,
                         float* dgamma, float* dbeta, int N, int C, int HW, float eps);
 
+/* Two BatchNorm2d layers that meet in one sum -- y = bnA(xA) + bnB(xB), the tail of a residual block whose
+ * shortcut is convolution + BatchNorm (test/ResNet_CIFAR10_cuda.py:38-47): batchnorm.py:30-55 twice and the
+ * "out + identity" in one launch (bnB's output is never written), and the two backward passes, which
+ * receive the same dy, in one launch.  Statistics from the convolutions' partials as in
+ * dfhip_bn2d_forward_partials.                                                                      */
+int dfhip_bn2d_forward_partials_pair(const float* xa, const float* partials_a, int rows_a, const float* gamma_a,
+                                     const float* beta_a, float* save_mean_a, float* save_var_a,
+                                     float* running_mean_a, float* running_var_a, float eps_a, float momentum_a,
+                                     const float* xb, const float* partials_b, int rows_b, const float* gamma_b,
+                                     const float* beta_b, float* save_mean_b, float* save_var_b,
+                                     float* running_mean_b, float* running_var_b, float eps_b, float momentum_b,
+                                     float* y, int N, int C, int HW);
+int dfhip_bn2d_backward_pair(const float* dy, const float* xa, const float* gamma_a, const float* save_mean_a,
+                             const float* save_var_a, float* dxa, float* dgamma_a, float* dbeta_a, float eps_a,
+                             const float* xb, const float* gamma_b, const float* save_mean_b,
+                             const float* save_var_b, float* dxb, float* dgamma_b, float* dbeta_b, float eps_b,
+                             int N, int C, int HW);
+
 /* BatchNorm2d (training) -> ReLU -> MaxPool2d(2) in one forward launch after the statistics pass,
  * and its backward (statistics + apply), for the stem of the CIFAR models
  * (test/ResNet_CIFAR10_cuda.py: pool1(relu(bn1(conv1(x))))).  x (N,C,H,W) is the convolution

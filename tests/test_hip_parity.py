@@ -219,3 +219,41 @@ def test_failed_capture_leaves_the_device_usable(hip_device):
         Graph.free_graph()
         losses.append(float(l.numpy()[0]))
     assert all(np.isfinite(v) for v in losses)
+
+
+def test_paired_batchnorm_matches_two_layers(hip_device):
+    """bn_a(conv_a(x)) + bn_b(conv_b(x)) as the paired node (one launch each way) against the two separate
+    BatchNorm nodes + residual add: outputs, input / parameter gradients and running statistics."""
+    import numpy as np
+    from deepflows_amd import nn, tensor
+    from deepflows_amd.tensor import Graph, Tensor
+    F = nn.functional
+    dev = hip_device
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((8, 32, 16, 16)).astype(np.float32)
+    gy = rng.standard_normal((8, 64, 8, 8)).astype(np.float32)
+    results = []
+    for paired in (True, False):
+        np.random.seed(5)
+        conv_a = nn.Conv2d(32, 64, kernel_size=3, stride=2, padding=1, bias=False, device=dev)
+        conv_b = nn.Conv2d(32, 64, kernel_size=1, stride=2, padding=0, bias=False, device=dev)
+        bn_a, bn_b = nn.BatchNorm2d(64, device=dev), nn.BatchNorm2d(64, device=dev)
+        for bn, s in ((bn_a, 1.0), (bn_b, 2.0)):
+            bn.train()
+            bn.weight.data.device.from_numpy((rng.standard_normal((1, 64, 1, 1)) * 0 + s).astype(np.float32), bn.weight.data._handle)
+        xt = Tensor(x, device=dev, requires_grad=True)
+        za, zb = conv_a(xt), conv_b(xt)
+        if paired:
+            assert F.batch_norm2d_pair_fusable(za, bn_a, zb, bn_b)
+            y = F.batch_norm2d_pair_train(za, bn_a, zb, bn_b)
+        else:
+            y = bn_a(za, residual=bn_b(zb))
+        loss = tensor.sum(y * Tensor(gy, device=dev))
+        loss.backward()
+        results.append([y.numpy().copy(), xt.grad.numpy().copy(), conv_a.weight.grad.numpy().copy(),
+                        conv_b.weight.grad.numpy().copy(), bn_a.weight.grad.numpy().copy(), bn_b.bias.grad.numpy().copy(),
+                        bn_a.running_mean.numpy().copy(), bn_b.running_var.numpy().copy()])
+        Graph.free_graph_all()
+    names = ("y", "dx", "dw_a", "dw_b", "dgamma_a", "dbeta_b", "running_mean_a", "running_var_b")
+    for a, b, nm in zip(results[0], results[1], names):
+        assert_close(a, b, 2e-5, "paired BatchNorm: " + nm)
