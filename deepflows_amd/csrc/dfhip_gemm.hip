@@ -144,14 +144,13 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A,
 // eight contiguous ranges and read their operands straight from global memory (everything is
 // L2-resident at these sizes; all loads of a wave are independent), the eight partial tiles are
 // summed through LDS in wave order.
-__global__ __launch_bounds__(512) void k_gemm_small(const float* __restrict__ A, const float* __restrict__ B,
-                                                    const float* __restrict__ bias, float* __restrict__ C,
-                                                    int M, int K, int P, int64_t a_sm, int64_t a_sk,
-                                                    int64_t b_sk, int64_t b_sp) {
-  __shared__ float red[7][16][64];
+__device__ __forceinline__ void gemm_small_tile(const float* __restrict__ A, const float* __restrict__ B,
+                                                const float* __restrict__ bias, float* __restrict__ C, int M, int K,
+                                                int P, int64_t a_sm, int64_t a_sk, int64_t b_sk, int64_t b_sp,
+                                                int bx, int by, float (*red)[16][64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int m = blockIdx.y * 32 + l31, p = blockIdx.x * 32 + l31;
+  const int m = by * 32 + l31, p = bx * 32 + l31;
   const int kq = (((K + 7) / 8) + 1) & ~1;                 // even number of k per wave
   const int kbeg = wave * kq, kend = min(K, kbeg + kq);
   const float* ap = A + (int64_t)min(m, M - 1) * a_sm;
@@ -184,9 +183,51 @@ __global__ __launch_bounds__(512) void k_gemm_small(const float* __restrict__ A,
       const float bb = bias ? bias[p] : 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int row = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int row = by * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (row < M) C[(int64_t)row * P + p] = acc[r] + bb;
       }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void k_gemm_small(const float* __restrict__ A, const float* __restrict__ B,
+                                                    const float* __restrict__ bias, float* __restrict__ C,
+                                                    int M, int K, int P, int64_t a_sm, int64_t a_sk,
+                                                    int64_t b_sk, int64_t b_sp) {
+  __shared__ float red[7][16][64];
+  gemm_small_tile(A, B, bias, C, M, K, P, a_sm, a_sk, b_sk, b_sp, blockIdx.x, blockIdx.y, red);
+}
+
+// Backward of a small Linear layer (y = x.W + b, linear.py:28-59 / tensor.py:699-716) as ONE launch:
+// blocks [0, nx) compute tiles of dX = dY.W^T, blocks [nx, nx + nw) tiles of dW = X^T.dY, the last
+// block db = column sums of dY (each output may be null).  Three launch-bound launches otherwise.
+__global__ __launch_bounds__(512) void k_linear_bwd_small(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ dy, float* __restrict__ dx,
+                                                          float* __restrict__ dw, float* __restrict__ db, int M, int K,
+                                                          int P, int nx, int nw) {
+  __shared__ float red[7][16][64];
+  const int b = blockIdx.x;
+  if (b < nx) {                                     // dX (M x K) = dY (M x P) . W^T (P x K);  W is (K, P)
+    const int tx = (K + 31) / 32;
+    gemm_small_tile(dy, w, nullptr, dx, M, P, K, P, 1, 1, P, b % tx, b / tx, red);
+  } else if (b < nx + nw) {                         // dW (K x P) = X^T (K x M) . dY (M x P);  X is (M, K)
+    const int t = b - nx, tx = (P + 31) / 32;
+    gemm_small_tile(x, dy, nullptr, dw, K, M, P, 1, K, P, 1, t % tx, t / tx, red);
+  } else {                                          // db[p] = sum_m dY[m][p]: 16 row groups x 32 columns per pass
+    const int pc = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    for (int p0 = 0; p0 < P; p0 += 32) {
+      const int p = p0 + pc;
+      float acc = 0.0f;
+      if (p < P)
+        for (int m = rg; m < M; m += 16) acc += dy[(int64_t)m * P + p];
+      red[0][rg][pc] = acc;
+      __syncthreads();
+      if (threadIdx.x < 32 && p < P) {
+        float t = 0.0f;
+        for (int r = 0; r < 16; r++) t += red[0][r][pc];
+        db[p] = t;
+      }
+      __syncthreads();
     }
   }
 }
@@ -296,6 +337,33 @@ int dfhip_matmul(const float* a, const float* b, float* out, int64_t m, int64_t 
 int dfhip_gemm(const float* a, const float* b, const float* bias, float* out, int64_t m, int64_t n,
                int64_t p, int ta, int tb) {
   return gemm_dispatch(a, b, bias, out, m, n, p, ta, tb);
+}
+
+int dfhip_linear_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                          int64_t m, int64_t k, int64_t p) {
+  DF_INIT();
+  DF_CHECK_ARG(m > 0 && k > 0 && p > 0, "linear_backward: non-positive dimension");
+  DF_CHECK_ARG(dy && (!dx || w) && (!dw || x), "linear_backward: null array");
+  if (2.0 * (double)m * (double)k * (double)p < 8.0e6 && m <= 4096) {
+    ProfScope prof("gemm_mfma_f32", 4.0 * (double)m * (double)k * (double)p,
+                   4.0 * (2.0 * (double)m * k + 2.0 * (double)k * p + 2.0 * (double)m * p));
+    const int nx = dx ? (int)(df_ceil_div(k, 32) * df_ceil_div(m, 32)) : 0;
+    const int nw = dw ? (int)(df_ceil_div(p, 32) * df_ceil_div(k, 32)) : 0;
+    const int nb = db ? 1 : 0;
+    if (nx + nw + nb == 0) return DFHIP_OK;
+    hipLaunchKernelGGL(k_linear_bwd_small, dim3((unsigned)(nx + nw + nb)), dim3(512), 0, stream(), x, w, dy, dx, dw, db,
+                       (int)m, (int)k, (int)p, nx, nw);
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
+  // larger layers: the three contractions on the tiled kernel
+  if (dx) { int st = gemm_dispatch(dy, w, nullptr, dx, m, p, k, 0, 1); if (st != DFHIP_OK) return st; }
+  if (dw) { int st = gemm_dispatch(x, dy, nullptr, dw, k, m, p, 1, 0); if (st != DFHIP_OK) return st; }
+  if (db) {
+    const int64_t src_shape[2] = {m, p}, dst_shape[2] = {1, p};
+    return dfhip_reduce_to_shape(dy, db, 2, src_shape, 2, dst_shape);
+  }
+  return DFHIP_OK;
 }
 
 }  // extern "C"

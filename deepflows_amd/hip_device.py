@@ -269,6 +269,10 @@ class HipModule:
         _lib.check(self._lib.dfhip_bn2d_backward(dy.ptr, x.ptr, g(gamma), save_mean.ptr, save_var.ptr,
                                                  g(dx), g(dgamma), g(dbeta), N, C, HW, float(eps)))
 
+    def linear_backward(self, x, w, dy, dx, dw, db, m, k, p):
+        g = lambda h: h.ptr if h is not None else None
+        _lib.check(self._lib.dfhip_linear_backward(g(x), g(w), dy.ptr, g(dx), g(dw), g(db), int(m), int(k), int(p)))
+
     def bn2d_forward_partials_pair(self, a, b, y, N, C, HW):
         """a, b = (x, partials, rows, gamma, beta, save_mean, save_var, running_mean, running_var, eps, momentum)."""
         g = lambda h: h.ptr if h is not None else None

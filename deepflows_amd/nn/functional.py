@@ -59,6 +59,7 @@ class _LinearFused(_FusedNode):
         x.device.gemm(xd._handle, wd._handle, b.data.compact()._handle if b is not None else None,
                       out._handle, m, k, p, False, False)
         self._saved = (xd, wd)
+        self._grads = None
         super().__init__(out, [x, w, b])
 
     def grad_fn(self, node, grad):
@@ -67,6 +68,17 @@ class _LinearFused(_FusedNode):
         m, k = xd.shape
         p = wd.shape[1]
         dev = g.device
+        if hasattr(dev.mod, "linear_backward"):
+            # dx, dw and db of the layer as one call (one launch for a classifier-sized layer)
+            if self._grads is None or self._grads[0] is not grad:
+                dx = _new((m, k), dev) if self.x.requires_grad else None
+                dw = _new((k, p), dev) if self.w.requires_grad else None
+                db = _new(self.b.shape, dev) if (self.b is not None and self.b.requires_grad) else None
+                h = lambda t: t._handle if t is not None else None
+                dev.linear_backward(xd._handle, wd._handle, g._handle, h(dx), h(dw), h(db), m, k, p)
+                self._grads = (grad, dx, dw, db)
+            _, dx, dw, db = self._grads
+            return dx if node is self.x else (dw if node is self.w else db)
         if node is self.x:
             out = _new((m, k), dev)
             dev.gemm(g._handle, wd._handle, None, out._handle, m, p, k, False, True)   # dY . W^T

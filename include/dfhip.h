@@ -117,6 +117,12 @@ int dfhip_reduce_max(const float* a, float* out, int64_t n_out, int64_t reduce_s
 int dfhip_gemm(const float* a, const float* b, const float* bias, float* out,
                int64_t m, int64_t n, int64_t p, int ta, int tb);
 
+/* Backward of y = x.W + b (linear.py:28-59; matmul.grad_fn tensor.py:699-716 and the bias un-broadcast
+ * tensor.py:462-483): dx (m,k) = dy.W^T, dw (k,p) = x^T.dy, db (p) = column sums of dy; any output may
+ * be NULL.  One launch when the layer is small (a classifier head), the three contractions otherwise. */
+int dfhip_linear_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                          int64_t m, int64_t k, int64_t p);
+
 /* Conv2d forward: nn/functional.py:316-344 (pad -> im2col -> GEMM) + conv.py:104-108
  * (bias (1,O,1,1), may be NULL).  x (N,C,H,W), w (O,C,k,k), y (N,O,oh,ow), all NCHW.  */
 int dfhip_conv2d_forward(const float* x, const float* w, const float* bias, float* y,

@@ -240,3 +240,23 @@ def test_lean_overwrite_dgrad(hip_device, N, C, O, H, W, k, s, p):
     dx2 = mod.Array(N * C * H * W)
     mod.conv2d_dgrad_add(dyh, wh, hh, dx2, N, C, H, W, O, k, s, p, mode="overwrite")
     assert_close(_back(mod, dx2).reshape(N, C, H, W), want + held, 1e-4, "lean dgrad + held gradient")
+
+
+@pytest.mark.parametrize("m,k,p", [(256, 256, 10), (37, 19, 5), (128, 784, 256), (5, 70, 33)])
+def test_linear_backward_one_call(hip_device, m, k, p):
+    """dfhip_linear_backward: dx, dw, db of y = x.W + b in one call (one launch for small layers), any output optional."""
+    from conftest import assert_close
+    mod = hip_device.mod
+    rng = np.random.default_rng(m + k + p)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = rng.standard_normal((k, p)).astype(np.float32)
+    dy = rng.standard_normal((m, p)).astype(np.float32)
+    xh, wh, dyh = _arr(mod, x), _arr(mod, w), _arr(mod, dy)
+    dx, dw, db = mod.Array(m * k), mod.Array(k * p), mod.Array(p)
+    mod.linear_backward(xh, wh, dyh, dx, dw, db, m, k, p)
+    assert_close(_back(mod, dx).reshape(m, k), dy @ w.T, 1e-4, "dx")
+    assert_close(_back(mod, dw).reshape(k, p), x.T @ dy, 1e-4, "dw")
+    assert_close(_back(mod, db), dy.sum(0), 1e-4, "db")
+    dw2 = mod.Array(k * p)
+    mod.linear_backward(xh, wh, dyh, None, dw2, None, m, k, p)     # frozen input / no bias
+    assert_close(_back(mod, dw2).reshape(k, p), x.T @ dy, 1e-4, "dw only")
