@@ -421,11 +421,15 @@ class HipModule:
     def synchronize(self):
         _lib.check(self._lib.dfhip_sync())
 
+    capturing = False      # a stream capture is open (arrays allocated now belong to that graph)
+
     def capture_begin(self):
         _lib.check(self._lib.dfhip_graph_begin())
+        self.capturing = True
 
     def capture_end(self, keep=None):
         h = c_void_p()
+        self.capturing = False
         _lib.check(self._lib.dfhip_graph_end(byref(h)))
         return HipGraph(self, h, keep)
 
