@@ -1011,6 +1011,131 @@ __global__ __launch_bounds__(256) void k_conv1x1s2_fwd(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// forward, 3x3 / stride 1 / pad 1 on 2 x 2 images (ResNet layer4): every output pixel p sees all four
+// input pixels q, each through the tap (qy - py + 1, qx - px + 1), so the layer is, per output
+// position, a dense contraction over K = 4 C -- and 5 of the 9 taps of a 3x3 window only ever meet
+// padding.  The staged kernel multiplies those zeros (56 % of its MFMAs) and streams all nine taps
+// through LDS in eight chunks.  Here a workgroup owns (32 images, one output position, 32 output
+// channels): the four taps it needs go to LDS once (4 x C x 32 floats), a lane is an IMAGE and reads
+// x[n][c][0..3] -- all four input pixels -- as one 16-byte load per channel, the eight waves split
+// the channels and are summed through LDS.  Epilogue: stores (a lane's outputs are 16 bytes apart in
+// memory; the other positions' workgroups fill the gaps) and the BatchNorm partials.
+// ---------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512) void k_conv3x3_img2_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          float* __restrict__ stats, int O) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CK = C / 8, NP = CK / 2, WT = 33, TS = 36;
+  float* Wl = smem;                                 // [q][c][WT]
+  const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int pos = blockIdx.x & 3, py = pos >> 1, px = pos & 1;
+  const int n = (blockIdx.x >> 2) * 32 + l31;       // this lane's image
+  const int d0 = blockIdx.y * 32;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  // the four taps this output position needs, for all channels: W[d0+o][c][tap(q)] -> Wl[(q*C + c)*WT + o]
+  // (eight (o, c) pairs = 32 loads in flight per thread; the pixel operand is requested after them,
+  // its latency runs under the LDS writes and the barrier)
+  {
+    int tap[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) tap[q] = ((q >> 1) - py + 1) * 3 + ((q & 1) - px + 1);
+    const int dmax = min(32, O - d0);
+    constexpr int PAIRS = 32 * C / 512;
+    for (int i0 = 0; i0 < PAIRS; i0 += 8) {
+      float wv[8][4];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int e = tid + 512 * (i0 + i), o = e / C, c = e - o * C;
+        const float* src = w + ((int64_t)(d0 + min(o, dmax - 1)) * C + c) * 9;
+#pragma unroll
+        for (int q = 0; q < 4; q++) wv[i][q] = o < dmax ? src[tap[q]] : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int e = tid + 512 * (i0 + i), o = e / C, c = e - o * C;
+#pragma unroll
+        for (int q = 0; q < 4; q++) Wl[(q * C + c) * WT + o] = wv[i][q];
+      }
+    }
+  }
+  // the pixel operand of this wave's channels: one float4 (the whole 2 x 2 plane) per channel pair
+  f32x4 xv[NP];
+  {
+    const float* xb = x + ((int64_t)n * C + ks * CK + half) * 4;
+#pragma unroll
+    for (int kp = 0; kp < NP; kp++) xv[kp] = *reinterpret_cast<const f32x4*>(xb + kp * 8);
+  }
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+  {
+    const float* aq = Wl + (ks * CK + half) * WT + l31;
+#pragma unroll
+    for (int kp = 0; kp < NP; kp++) {
+      const float bq[4] = {xv[kp].x, xv[kp].y, xv[kp].z, xv[kp].w};
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[(q * C + 2 * kp) * WT], bq[q], acc, 0, 0, 0);
+    }
+  }
+  __syncthreads();                                  // the weights are dead: their LDS becomes the epilogue's
+  float* red = smem;                                // [7][16][64]
+  if (ks > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[((ks - 1) * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (ks == 0) {
+#pragma unroll
+    for (int s2 = 0; s2 < 7; s2++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] += red[(s2 * 16 + r) * 64 + lane];
+    if (bias) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] += bias[min(d0 + (r & 3) + 8 * (r >> 2) + 4 * half, O - 1)];
+    }
+    float* yo = y + ((int64_t)n * O + d0) * 4 + pos;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int o = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (d0 + o < O) yo[o * 4] = acc[r];
+    }
+  }
+  if (stats) {
+    __syncthreads();                                // red is dead
+    float* Tt = smem;                               // [32 channels][TS]: the tile, images along the row
+    if (ks == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) Tt[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + l31] = acc[r];
+      // (same wave reads it back: lane (channel = l31, half) walks 16 of the 32 images)
+      const float* row = Tt + l31 * TS + 16 * half;
+      float vals[16];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; q4++) {
+        const float4 t4 = *reinterpret_cast<const float4*>(row + 4 * q4);
+        vals[4 * q4] = t4.x; vals[4 * q4 + 1] = t4.y; vals[4 * q4 + 2] = t4.z; vals[4 * q4 + 3] = t4.w;
+      }
+      float t = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; i++) t += vals[i];
+      t += __shfl_xor(t, 32);
+      const float mean_t = t * (1.0f / 32.0f);
+      float q = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; i++) { const float dlt = vals[i] - mean_t; q += dlt * dlt; }
+      q += __shfl_xor(q, 32);
+      if (half == 0 && d0 + l31 < O) {
+        float* o3 = stats + ((int64_t)blockIdx.x * O + d0 + l31) * 3;
+        o3[0] = 32.0f; o3[1] = mean_t; o3[2] = q;
+      }
+    }
+  }
+}
+
 // out[i] = sum_s slabs[s][i] (+ bias[(i / plane) % CD])
 __global__ __launch_bounds__(256) void k_conv_slab_sum(const float* __restrict__ slabs,
                                                        const float* __restrict__ bias,
@@ -2546,6 +2671,33 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, 
   return DFHIP_OK;
 }
 
+// 3x3 / stride 1 / pad 1 on 2 x 2 images (128 or 256 source channels, batch a multiple of 32); -1 when not eligible
+int run_conv_img2(const Geo& g, int O, float* y, const float* bias, float* partials, int cap_rows, int* rows_out) {
+  static int enabled = getenv("DFHIP_IMG2_LEAN") ? atoi(getenv("DFHIP_IMG2_LEAN")) : 1;
+  if (!enabled || g.mode != 0 || g.k != 3 || g.so != 1 || g.sd != 1 || g.u0 != -1) return -1;
+  if (g.HS != 2 || g.WS != 2 || g.HD != 2 || g.WD != 2 || (g.N % 32) != 0) return -1;
+  if (!(g.CS == 128 || g.CS == 256)) return -1;
+  const int rows = g.N / 32 * 4;
+  if (partials && rows > cap_rows) return -1;
+  if (rows_out) *rows_out = partials ? rows : 0;
+  dim3 grid((unsigned)rows, (unsigned)df_ceil_div(O, 32));
+  const size_t lds = std::max((size_t)4 * g.CS * 33, (size_t)7 * 16 * 64) * sizeof(float);
+#define DF_I2(CV)                                                                                                 \
+  do {                                                                                                            \
+    static bool attr = false;                                                                                     \
+    if (!attr) {                                                                                                  \
+      DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_img2_fwd<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)std::max(lds, (size_t)65536)));                                             \
+      attr = true;                                                                                                \
+    }                                                                                                             \
+    hipLaunchKernelGGL(k_conv3x3_img2_fwd<CV>, grid, dim3(512), lds, stream(), g.src, g.wgt, bias, y, partials, O); \
+  } while (0)
+  if (g.CS == 128) DF_I2(128); else DF_I2(256);
+#undef DF_I2
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
 // shortcut convolution (1x1 / stride 2 / pad 0, 32-128 source channels); -1 when not eligible
 int run_conv1x1s2(const Geo& g, int O, float* y, const float* bias, float* partials, int cap_rows, int* rows_out) {
   static int enabled = getenv("DFHIP_SHORTCUT_LEAN") ? atoi(getenv("DFHIP_SHORTCUT_LEAN")) : 1;
@@ -3237,6 +3389,7 @@ static int conv2d_forward_impl(const float* x, const float* w, const float* bias
     int rows = 0;
     const bool want = partials && rows_out;
     int st = run_conv1x1s2(g, O, y, bias, want ? partials : nullptr, cap_rows, &rows);
+    if (st < 0) st = run_conv_img2(g, O, y, bias, want ? partials : nullptr, cap_rows, &rows);
     if (st >= 0) {
       if (want) *rows_out = rows;
       return st;
