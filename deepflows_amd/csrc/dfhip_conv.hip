@@ -779,6 +779,12 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
 #pragma unroll
     for (int kp = 0; kp < NP; kp++) sv[kp] = sp[(int64_t)(2 * kp) * SHW];
   }
+  // ... the gradient the tensor already holds (added in the epilogue; requested now, not after the MFMAs) ...
+  const int64_t obase = ((int64_t)n * C + c0) * HW + rem;
+  float held[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++)
+    held[r] = add ? add[obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW] : 0.0f;
   // ... and its share of the weight slices (thread -> (o, c) pairs, the four taps 4, 5, 7, 8 of each)
   constexpr int PAIRS = O * 32 / 256;
   float wv[PAIRS][4];
@@ -809,14 +815,9 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
     for (int kp = 0; kp < NP; kp++)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], mine ? sv[kp] : 0.0f, acc, 0, 0, 0);
   }
-  const int64_t obase = ((int64_t)n * C + c0) * HW + rem;
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int64_t at = obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW;
-    float val = acc[r];
-    if (add) val += add[at];
-    dx[at] = val;
-  }
+  for (int r = 0; r < 16; r++)
+    dx[obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW] = acc[r] + held[r];
 }
 
 // The same for 128 / 256 output channels: ONE tile per workgroup, its four waves split the reduction
@@ -866,6 +867,11 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict_
 #pragma unroll
       for (int kp = 0; kp < NP; kp++) sv[kp] = sp[(int64_t)(2 * kp) * SHW];
     }
+    const int64_t obase = ((int64_t)n * C + c0) * HW + rem;
+    float held[16];                                 // (wave 0 stores the tile: it requests the held gradient now)
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+      held[r] = (add && wave == 0) ? add[obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW] : 0.0f;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
@@ -891,14 +897,9 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict_
       for (int ww = 0; ww < 3; ww++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] += red[(ww * 16 + r) * 64 + lane];
-      const int64_t obase = ((int64_t)n * C + c0) * HW + rem;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int64_t at = obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW;
-        float val = acc[r];
-        if (add) val += add[at];
-        dx[at] = val;
-      }
+      for (int r = 0; r < 16; r++)
+        dx[obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW] = acc[r] + held[r];
     }
     __syncthreads();                                // red is reused by the next tile
   }
