@@ -1987,7 +1987,7 @@ __device__ __forceinline__ void wgrad_rows_body(const RGeo& g, float* smem, cons
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   constexpr int T = KS * KS;
   constexpr int NW = kRowsWaves, NT = 64 * NW;
-  constexpr int SVX = 10, SVD = 4;             // X / dY vectors per thread in flight across a group
+  constexpr int SVX = 10, SVD = GROUPED ? 8 : 4;   // X / dY vectors per thread in flight across a group
   constexpr int NXR = (UR - 1) * STRIDE + KS;  // source rows under the UR output rows of a unit
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2308,6 +2308,8 @@ struct GDesc {
   unsigned m_br, m_xc, m_xi, m_dc, m_di;
   int single, kind, ps, CT, OT;
   int wg_end;                // workgroups of layers 0..this one (exclusive end of this layer's range)
+  int direct;                // operands straight from global memory (units = units per block, m_br = magic(oh / UR))
+  unsigned long long* dbg;   // diagnostic builds: per-workgroup cycles (load issue, MFMA section) of wave 0
 };
 struct WGroup {
   int n;
@@ -2319,6 +2321,201 @@ struct SGroup {
   int vb_end[kMaxGroup];
   SlabSum s[kMaxGroup];
 };
+
+// Row-unit weight gradient with the operands straight from global memory (grouped launches, channel
+// counts that are multiples of 32).  A lane's operand rows -- OW floats of dY, W floats of each source
+// row -- are contiguous 8-64 byte runs of its own (image, channel) plane: it reads them with 16-byte
+// global loads one unit ahead (a unit is 144 MFMAs = 4 us of matrix-core time, far more than the
+// latency), so the LDS staging of a group, its commit and its barrier do not exist: what remains per
+// unit is the MFMA stream.  Adjacent rows are taken by the four waves at the same time (their halo
+// rows meet in L1).  LDS is only the cross-wave sum at the end.
+template <int NV>
+__device__ __forceinline__ void gl_read_row(const float* __restrict__ p, float (&v)[NV]) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  if constexpr (NV % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < NV / 4; q++) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < NV / 2; q++) {
+      const f32x2 t = *reinterpret_cast<const f32x2*>(p + 2 * q);
+      v[2 * q] = t.x; v[2 * q + 1] = t.y;
+    }
+  }
+}
+
+template <int KS, int PAD, int STRIDE, int W, int OW, int UR>
+__device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, const int bx, const int by,
+                                                  const int bz) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int T = KS * KS, NW = kRowsWaves;
+  constexpr int NXR = (UR - 1) * STRIDE + KS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int H = d.H, oh = d.oh;
+  const int upr = oh / UR;                         // units per image pair
+  const int U = (d.N >> 1) * upr;
+  const int u_lo = bx * d.units, u_hi = min(U, u_lo + d.units);
+  const int64_t xplane = (int64_t)H * W, yplane = (int64_t)oh * OW;
+  const float* xl = d.x + ((int64_t)half * d.C + by * 32 + l31) * xplane;      // + pair * 2 * C * xplane
+  const float* yl = d.dy + ((int64_t)half * d.O + bz * 32 + l31) * yplane;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; t++)
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) acc[t][rr] = 0.0f;
+
+  auto row_used = [](int xr) {
+    for (int ur = 0; ur < UR; ur++)
+      for (int i = 0; i < KS; i++)
+        if (ur * STRIDE + i == xr) return true;
+    return false;
+  };
+  float a_n[UR][OW], b_n[NXR][W];
+  int rs_n = 0;
+#ifdef DFHIP_STAMPS
+  unsigned long long dbg_issue = 0, dbg_mfma = 0;
+#endif
+  // The operand rows of a unit are NV-float vectors ("pieces"): UR * OW/VA of dY, then W/VB per used source
+  // row.  A piece is one wave load that touches 64 different cache lines (a lane per channel plane), which
+  // the address unit takes ~64 cycles to accept: issued in one burst the sixteen of them hold the wave --
+  // and with it its MFMA stream -- for ~1 800 cycles per unit.  They are therefore spread over the MFMAs
+  // of the current unit, one piece every few MFMAs.
+  constexpr int VA = OW % 4 == 0 ? 4 : 2, VB = W % 4 == 0 ? 4 : 2;
+  constexpr int PA = UR * (OW / VA), PBR = W / VB;            // pieces of dY; pieces per source row
+  constexpr int NPIECE = PA + NXR * PBR;
+  const float* yp_n = yl;
+  const float* xp_n = xl;
+  auto piece = [&](int k) {                                  // k is a compile-time constant at every call
+    if (k < PA) {
+      const int ur = k / (OW / VA), q = k % (OW / VA);
+      if constexpr (VA == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(yp_n + ur * OW + 4 * q);
+        a_n[ur][4 * q] = t.x; a_n[ur][4 * q + 1] = t.y; a_n[ur][4 * q + 2] = t.z; a_n[ur][4 * q + 3] = t.w;
+      } else {
+        const f32x2 t = *reinterpret_cast<const f32x2*>(yp_n + ur * OW + 2 * q);
+        a_n[ur][2 * q] = t.x; a_n[ur][2 * q + 1] = t.y;
+      }
+    } else {
+      const int xr = (k - PA) / PBR, q = (k - PA) % PBR;
+      if (row_used(xr) && (unsigned)(rs_n + xr) < (unsigned)H) {
+        const float* src = xp_n + (int64_t)(rs_n + xr) * W;
+        if constexpr (VB == 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * q);
+          b_n[xr][4 * q] = t.x; b_n[xr][4 * q + 1] = t.y; b_n[xr][4 * q + 2] = t.z; b_n[xr][4 * q + 3] = t.w;
+        } else {
+          const f32x2 t = *reinterpret_cast<const f32x2*>(src + 2 * q);
+          b_n[xr][2 * q] = t.x; b_n[xr][2 * q + 1] = t.y;
+        }
+      }
+    }
+  };
+  auto next_unit = [&](int uu) {                             // row / pointers of the unit whose pieces follow
+    const int pr = (int)fast_div((unsigned)uu, d.m_br);
+    const int r = (uu - pr * upr) * UR;
+    rs_n = r * STRIDE - PAD;                                 // source row of (output row 0, tap row 0)
+    yp_n = yl + (int64_t)pr * 2 * d.O * yplane + (int64_t)r * OW;
+    xp_n = xl + (int64_t)pr * 2 * d.C * xplane;
+  };
+  if (u_lo + wave < u_hi) {
+    next_unit(u_lo + wave);
+#pragma unroll
+    for (int k = 0; k < NPIECE; k++) piece(k);
+  }
+  constexpr int NIT = UR * KS * OW;                          // (ur, i, s) iterations of a unit, <= KS MFMAs each
+  constexpr int STEP = NIT / NPIECE > 0 ? NIT / NPIECE : 1;
+  for (int u = u_lo + wave; u < u_hi; u += NW) {
+    float a[UR][OW], b[NXR][W];
+#pragma unroll
+    for (int ur = 0; ur < UR; ur++)
+#pragma unroll
+      for (int s = 0; s < OW; s++) a[ur][s] = a_n[ur][s];
+#pragma unroll
+    for (int xr = 0; xr < NXR; xr++)
+#pragma unroll
+      for (int c = 0; c < W; c++) b[xr][c] = b_n[xr][c];
+    const int rs = rs_n;
+    const bool more = u + NW < u_hi;
+    if (more) next_unit(u + NW);
+    // small planes (W <= 4): the lanes' rows share cache lines, a burst is cheap and schedules better
+    constexpr bool SPREAD = W >= 8;
+    if (!SPREAD && more) {
+#pragma unroll
+      for (int k = 0; k < NPIECE; k++) piece(k);
+    }
+#ifdef DFHIP_STAMPS
+    const unsigned long long tq1 = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+    for (int ur = 0; ur < UR; ur++) {
+#pragma unroll
+      for (int i = 0; i < KS; i++) {
+        const bool rowok = (unsigned)(rs + ur * STRIDE + i) < (unsigned)H;
+#pragma unroll
+        for (int s = 0; s < OW; s++) {
+          const int it = (ur * KS + i) * OW + s;
+          if (SPREAD && it % STEP == 0 && it / STEP < NPIECE) {
+            if (more) piece(it / STEP);                      // one operand piece of the next unit
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (rowok) {
+#pragma unroll
+            for (int j = 0; j < KS; j++) {
+              const int col = s * STRIDE + j - PAD;
+              if (col >= 0 && col < W)
+                acc[i * KS + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                    a[ur][s], b[ur * STRIDE + i][col >= 0 && col < W ? col : 0], acc[i * KS + j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    if (SPREAD && more) {                                    // pieces that did not get a slot (NPIECE > NIT)
+#pragma unroll
+      for (int k = (NIT + STEP - 1) / STEP; k < NPIECE; k++) piece(k);
+    }
+#ifdef DFHIP_STAMPS
+    const unsigned long long tq2 = __builtin_readcyclecounter();
+    dbg_mfma += tq2 - tq1;
+#endif
+  }
+#ifdef DFHIP_STAMPS
+  if (d.dbg && tid == 0) { d.dbg[2 * blockIdx.x] = dbg_issue; d.dbg[2 * blockIdx.x + 1] = dbg_mfma; }
+#endif
+  // cross-wave sum through LDS, RR taps per round (as the staged body of a grouped launch)
+  f32x4* red = reinterpret_cast<f32x4*>(smem);
+  float* slab = d.slabs + (((int64_t)bx * d.OT + bz) * d.CT + by) * (T * 1024);
+  constexpr int RR = T >= 3 ? 3 : 1;
+#pragma unroll
+  for (int t0 = 0; t0 < T; t0 += RR) {
+    if (t0 > 0) __syncthreads();
+#pragma unroll
+    for (int t = t0; t < t0 + RR && t < T; t++)
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        red[(((t - t0) * NW + wave) * 4 + q) * 64 + lane] =
+            (f32x4){acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+    __syncthreads();
+#pragma unroll
+    for (int t = t0; t < t0 + RR && t < T; t++) {
+      const int q = wave;
+      f32x4 v = red[(((t - t0) * NW + 0) * 4 + q) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < NW; w++) {
+        const f32x4 uu = red[(((t - t0) * NW + w) * 4 + q) * 64 + lane];
+        v.x += uu.x; v.y += uu.y; v.z += uu.z; v.w += uu.w;
+      }
+      *reinterpret_cast<f32x4*>(slab + (int64_t)t * 1024 + (q * 64 + lane) * 4) = v;
+    }
+  }
+}
 
 #define DF_ROWS_KINDS(X) \
   X(0, 3, 1, 1, 16, 16, 1) X(1, 3, 1, 1, 8, 8, 2) X(2, 3, 1, 1, 4, 4, 4) X(3, 3, 1, 1, 2, 2, 2)      \
@@ -2351,7 +2548,8 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
   switch (d.kind) {
 #define DF_CASE(ID, KSV, PADV, SV, WV, OWV, URV)                                                   \
   case ID:                                                                                         \
-    wgrad_rows_body<KSV, PADV, SV, WV, OWV, URV, true>(g, smem, bx, by, bz, d.ps, d.CT, d.OT);     \
+    if (d.direct) wgrad_rows_direct<KSV, PADV, SV, WV, OWV, URV>(d, smem, bx, by, bz);            \
+    else wgrad_rows_body<KSV, PADV, SV, WV, OWV, URV, true>(g, smem, bx, by, bz, d.ps, d.CT, d.OT); \
     break;
     DF_ROWS_KINDS(DF_CASE)
 #undef DF_CASE
@@ -3079,8 +3277,9 @@ int group_flush() {
     if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
     hipEvent_t se0 = nullptr, se1 = nullptr;
     if (stamp_mode) {
-      wg.ticks = (unsigned long long*)workspace2((size_t)wgs * 8);
-      (void)hipMemsetAsync(wg.ticks, 0, (size_t)wgs * 8, stream());
+      wg.ticks = (unsigned long long*)workspace2((size_t)wgs * 8 * 3);
+      (void)hipMemsetAsync(wg.ticks, 0, (size_t)wgs * 8 * 3, stream());
+      for (int i = 0; i < n; i++) wg.d[i].dbg = wg.ticks + wgs;
       (void)hipEventCreate(&se0); (void)hipEventCreate(&se1);
       (void)hipEventRecord(se0, stream());
     }
@@ -3094,10 +3293,13 @@ int group_flush() {
       (void)hipEventSynchronize(se1);
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, se0, se1);
-      std::vector<unsigned long long> h(wgs);
+      std::vector<unsigned long long> h(wgs), hd(2 * (size_t)wgs);
       (void)hipMemcpy(h.data(), wg.ticks, (size_t)wgs * 8, hipMemcpyDeviceToHost);
-      unsigned long long mx = 0; double sum = 0;
+      (void)hipMemcpy(hd.data(), wg.ticks + wgs, (size_t)wgs * 16, hipMemcpyDeviceToHost);
+      unsigned long long mx = 0; double sum = 0, si = 0, sm = 0;
       for (auto v : h) { mx = std::max(mx, v); sum += (double)v; }
+      for (int i = 0; i < wgs; i++) { si += (double)hd[2 * i]; sm += (double)hd[2 * i + 1]; }
+      fprintf(stderr, "[stampg]   wave 0 of a workgroup: load issue %.0f, MFMA sections %.0f cycles (mean)\n", si / wgs, sm / wgs);
       fprintf(stderr, "[stampg] %d workgroups, launch %.1f us; cycles per workgroup: mean %.0f max %llu -> >= %.2f GHz if the longest one spans the launch\n",
               wgs, ms * 1e3, sum / wgs, mx, (double)mx / (ms * 1e3) * 1e-3);
       (void)hipEventDestroy(se0); (void)hipEventDestroy(se1);
@@ -3126,7 +3328,7 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
   const int CT = (int)df_ceil_div(C, 32), OT = (int)df_ceil_div(O, 32);
   // pixel slabs per (channel tile, output tile): a stand-alone launch needs one workgroup per CU;
   // a grouped launch has the other layers to fill the chip with and takes longer workgroups
-  static int gdiv = getenv("DFHIP_WGRAD_GROUP_DIV") ? atoi(getenv("DFHIP_WGRAD_GROUP_DIV")) : 8;
+  static int gdiv = getenv("DFHIP_WGRAD_GROUP_DIV") ? atoi(getenv("DFHIP_WGRAD_GROUP_DIV")) : 16;
   const int ps0 = std::max(1, num_cus() / (CT * OT) / (grouped ? std::max(1, gdiv) : 1));
   static int gpb1 = getenv("DFHIP_WGRAD_GPB") ? atoi(getenv("DFHIP_WGRAD_GPB")) : 2;   // groups per block aimed at
   static int gpbg = getenv("DFHIP_WGRAD_GROUP_GPB") ? atoi(getenv("DFHIP_WGRAD_GROUP_GPB")) : 2;
@@ -3152,7 +3354,7 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
       const int units = BI / 2 * (BR / UR);
       if (units % kRowsWaves) continue;
       const int xv = (int)df_ceil_div(32 * BI * (RL / 4), 64 * kRowsWaves), dv = (int)df_ceil_div(32 * BI * (BRBC / 4), 64 * kRowsWaves);
-      if ((xv > 10 || dv > 4) && (grouped || (N / BI) * gr > ps0)) continue;  // later groups must fit the in-flight vectors
+      if ((xv > 10 || dv > (grouped ? 8 : 4)) && (grouped || (N / BI) * gr > ps0)) continue;  // later groups must fit the in-flight vectors
       const int XST = bank_stride_r(BI * RL, W >= 4 ? 4 : 2), DST = bank_stride_r(BI * BRBC, ow >= 4 ? 4 : 2);
       const size_t stage = (size_t)32 * (XST + DST) * 4;
       const size_t red = grouped ? (size_t)(k == 3 ? 3 : 1) * kRowsWaves * 4 * 64 * 16
@@ -3199,6 +3401,18 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
     d.m_br = g.m_br; d.m_xc = g.m_xc; d.m_xi = g.m_xi; d.m_dc = g.m_dc; d.m_di = g.m_di;
     d.single = g.single; d.kind = kind; d.ps = ps; d.CT = CT; d.OT = OT;
     e.dw = dw; e.T = k * k; e.lds = best_lds;
+    static int direct_on = getenv("DFHIP_WGRAD_DIRECT") ? atoi(getenv("DFHIP_WGRAD_DIRECT")) : 1;
+    if (direct_on && C % 32 == 0 && O % 32 == 0) {
+      // operands straight from global memory: a block takes a contiguous run of units (a multiple of 4)
+      const int upr = oh / UR, U = (N / 2) * upr;
+      int upb = (int)df_ceil_div(U, ps0);
+      upb = std::max(4, (upb + 3) & ~3);
+      d.direct = 1;
+      d.units = upb;
+      d.ps = (int)df_ceil_div(U, upb);
+      d.m_br = magic_u32((unsigned)upr);
+      e.lds = (size_t)(k == 3 ? 3 : 1) * kRowsWaves * 4 * 64 * 16;
+    }
     e.flops = 2.0 * N * oh * ow * (double)C * k * k * O;
     e.bytes = 4.0 * ((double)N * C * H * W + (double)O * C * k * k + (double)N * O * oh * ow);
     g_queue.push_back(e);
