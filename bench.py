@@ -69,7 +69,7 @@ def cpu_baseline(seconds_budget=25.0):
         workloads.train_step(model, crit, opt, xt, yt)
         Graph.free_graph()
         first = time.perf_counter() - t_first
-        n = int(max(1, min(4, (seconds_budget - first) // max(first, 1e-3))))
+        n = int(max(1, min(12, (seconds_budget - first) // max(first, 1e-3))))
         t0 = time.perf_counter()
         for _ in range(n):
             workloads.train_step(model, crit, opt, xt, yt)

@@ -840,15 +840,15 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict_
   const int ob = wave * OQ;                         // this wave's slice of the reduction
   // the weight slices of this channel tile, once per workgroup (it walks several pixel tiles)
   constexpr int PAIRS = O * 32 / 256;
-  for (int i0 = 0; i0 < PAIRS; i0 += 8) {           // eight (o, c) pairs in flight per thread
-    float wv[8][4];
+  for (int i0 = 0; i0 < PAIRS; i0 += 16) {          // sixteen (o, c) pairs in flight per thread
+    float wv[16][4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 16; i++) {
       const int e = threadIdx.x + 256 * (i0 + i), o = e >> 5, c = e & 31;
       OwGeo<GEO>::slices(w, (int64_t)o * C + c0 + c, wv[i]);
     }
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 16; i++) {
       const int e = threadIdx.x + 256 * (i0 + i), o = e >> 5, c = e & 31;
 #pragma unroll
       for (int q = 0; q < NSL; q++) Wl[(q * O + o) * 32 + c] = wv[i][q];
@@ -1037,25 +1037,26 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_fwd(const float* __restric
   const int d0 = blockIdx.y * 32;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   // the four taps this output position needs, for all channels: W[d0+o][c][tap(q)] -> Wl[(q*C + c)*WT + o]
-  // (eight (o, c) pairs = 32 loads in flight per thread; the pixel operand is requested after them,
+  // (sixteen (o, c) pairs = 32 loads in flight per thread; the pixel operand is requested after them,
   // its latency runs under the LDS writes and the barrier)
+  // The taps of q = 0..3 are t0, t0 + 1, t0 + 3, t0 + 4 with t0 = 3 (1 - py) + (1 - px): two adjacent
+  // pairs, requested as two 8-byte loads (the address unit's cost of a gather is per cache line touched,
+  // and a wave's 64 records of 36 bytes touch 36 of them per request whatever its width).
   {
-    int tap[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) tap[q] = ((q >> 1) - py + 1) * 3 + ((q & 1) - px + 1);
+    const int t0 = (1 - py) * 3 + (1 - px);
     const int dmax = min(32, O - d0);
-    constexpr int PAIRS = 32 * C / 512;
-    for (int i0 = 0; i0 < PAIRS; i0 += 8) {
-      float wv[8][4];
+    constexpr int PAIRS = 32 * C / 512, NB = PAIRS < 16 ? PAIRS : 16;
+    for (int i0 = 0; i0 < PAIRS; i0 += NB) {
+      float wv[NB][4];
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
+      for (int i = 0; i < NB; i++) {
         const int e = tid + 512 * (i0 + i), o = e / C, c = e - o * C;
-        const float* src = w + ((int64_t)(d0 + min(o, dmax - 1)) * C + c) * 9;
-#pragma unroll
-        for (int q = 0; q < 4; q++) wv[i][q] = o < dmax ? src[tap[q]] : 0.0f;
+        const float* src = w + ((int64_t)(d0 + min(o, dmax - 1)) * C + c) * 9 + t0;
+        const float m = o < dmax ? 1.0f : 0.0f;     // (the address is clamped: load first, mask after)
+        wv[i][0] = src[0] * m; wv[i][1] = src[1] * m; wv[i][2] = src[3] * m; wv[i][3] = src[4] * m;
       }
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
+      for (int i = 0; i < NB; i++) {
         const int e = tid + 512 * (i0 + i), o = e / C, c = e - o * C;
 #pragma unroll
         for (int q = 0; q < 4; q++) Wl[(q * C + c) * WT + o] = wv[i][q];
@@ -1074,13 +1075,21 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_fwd(const float* __restric
 #pragma unroll
   for (int r = 0; r < 16; r++) acc[r] = 0.0f;
   {
+    // the weight operand of all 4 NP MFMAs is read up front: with two waves per SIMD a read per MFMA
+    // leaves its LDS latency exposed on every other one (the phase ran at 40 % of the pipe rate)
     const float* aq = Wl + (ks * CK + half) * WT + l31;
+    float av[NP][4];
+#pragma unroll
+    for (int kp = 0; kp < NP; kp++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) av[kp][q] = aq[(q * C + 2 * kp) * WT];
+    __builtin_amdgcn_sched_barrier(0);              // (the scheduler would sink the reads back to their uses)
 #pragma unroll
     for (int kp = 0; kp < NP; kp++) {
       const float bq[4] = {xv[kp].x, xv[kp].y, xv[kp].z, xv[kp].w};
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[(q * C + 2 * kp) * WT], bq[q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp][q], bq[q], acc, 0, 0, 0);
     }
   }
   __syncthreads();                                  // the weights are dead: their LDS becomes the epilogue's
