@@ -1063,12 +1063,38 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_fwd(const float* __restric
       }
     }
   }
-  // the pixel operand of this wave's channels: one float4 (the whole 2 x 2 plane) per channel pair
+  // The pixel operand of this wave's channels: lane (image, half) needs the whole 2 x 2 plane of channel
+  // 2 kp + half as one float4.  Read that way a request is 64 pieces of 16 bytes 4 KB apart and the
+  // address unit takes them one lane per cycle (4.1 us of the launch); instead the wave reads its slice
+  // in runs -- four lanes cover the 64 contiguous bytes of one image's four channels, 16 images per
+  // request -- and turns it through a wave-private LDS strip (XS floats per image: conflict-free 16-byte
+  // reads) four channels at a time.
   f32x4 xv[NP];
   {
-    const float* xb = x + ((int64_t)n * C + ks * CK + half) * 4;
+    constexpr int NCH = CK / 4, XS = 20;
+    float* Xt = smem + 4 * C * WT + ks * (32 * XS);
+    f32x4 xg[NCH][2];
+    const float* xb = x + ((int64_t)((blockIdx.x >> 2) * 32 + (lane >> 2)) * C + ks * CK + (lane & 3)) * 4;
 #pragma unroll
-    for (int kp = 0; kp < NP; kp++) xv[kp] = *reinterpret_cast<const f32x4*>(xb + kp * 8);
+    for (int j = 0; j < NCH; j++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+        xg[j][i] = *reinterpret_cast<const f32x4*>(xb + (int64_t)16 * i * C * 4 + j * 16);
+    float* wr = Xt + (lane >> 2) * XS + (lane & 3) * 4;
+    const float* rd = Xt + l31 * XS + half * 4;
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+      *reinterpret_cast<f32x4*>(wr) = xg[j][0];
+      *reinterpret_cast<f32x4*>(wr + 16 * XS) = xg[j][1];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      xv[2 * j] = *reinterpret_cast<const f32x4*>(rd);
+      xv[2 * j + 1] = *reinterpret_cast<const f32x4*>(rd + 8);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
   }
   __syncthreads();
   f32x16 acc;
@@ -2889,7 +2915,7 @@ int run_conv_img2(const Geo& g, int O, float* y, const float* bias, float* parti
   if (partials && rows > cap_rows) return -1;
   if (rows_out) *rows_out = partials ? rows : 0;
   dim3 grid((unsigned)rows, (unsigned)df_ceil_div(O, 32));
-  const size_t lds = std::max((size_t)4 * g.CS * 33, (size_t)7 * 16 * 64) * sizeof(float);
+  const size_t lds = std::max((size_t)4 * g.CS * 33 + 8 * 32 * 20, (size_t)7 * 16 * 64) * sizeof(float);   // weights + the waves' x strips
 #define DF_I2(CV)                                                                                                 \
   do {                                                                                                            \
     static bool attr = false;                                                                                     \
