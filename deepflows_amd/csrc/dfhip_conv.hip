@@ -659,12 +659,19 @@ __global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int d0 = blockIdx.y * 32;
-  const int o = d0 + l31;
+  // the weight operand goes through LDS once per workgroup: read per wave it is NP requests of 32
+  // pieces KK floats apart, and with a wave per image row that was 7 us of address-unit time per launch
+  __shared__ float Wl[32 * KK];
+  {
+    const int nw = min(32, O - d0) * KK;
+    for (int i = threadIdx.x; i < 32 * KK; i += 256) Wl[i] = i < nw ? w[(int64_t)d0 * KK + i] : 0.0f;
+  }
+  __syncthreads();
   float a[NP];
 #pragma unroll
   for (int p = 0; p < NP; p++) {
     const int kk = 2 * p + half;
-    a[p] = (kk < KK && o < O) ? w[(int64_t)o * KK + kk] : 0.0f;
+    a[p] = kk < KK ? Wl[l31 * KK + kk] : 0.0f;
   }
   float bv[16];
 #pragma unroll
