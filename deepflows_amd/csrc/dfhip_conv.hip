@@ -648,8 +648,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
 // 32 lanes are the row's pixels, W == 32): the weight operand of its 32 output channels sits in
 // registers for the whole kernel, the pixel operand of a (channel, tap) is ONE coalesced global
 // load per row (the input is 3 MB and lives in L2; row / column padding by predication), and the
-// 32 x 32 result leaves as sixteen 128-byte stores per half-wave.  No LDS, no barriers: the
-// generic kernel spent 26 us per launch on per-workgroup gather tables for 14 MFMAs of work.
+// 32 x 32 result leaves as sixteen 128-byte stores per half-wave.  No staging phases (the weight tile
+// goes through LDS once per workgroup): the generic kernel spent 26 us per launch on per-workgroup
+// gather tables for 14 MFMAs of work.
 // ---------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x, const float* __restrict__ w,
@@ -680,10 +681,11 @@ __global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x,
     bv[rr] = (bias && d < O) ? bias[d] : 0.0f;
   }
   const int rows = N * H;
-  for (int R = blockIdx.x * 4 + wave; R < rows; R += gridDim.x * 4) {
+  // a wave walks several rows; the pixel operand of the next row is requested before the MFMAs and the
+  // stores of the current one
+  auto load_row = [&](int R, float (&b)[NP]) {
     const int n = (int)fast_div((unsigned)R, m_h), r = R - n * H;
     const float* xn = x + (int64_t)n * C * H * 32;
-    float b[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++) {
       // k index 2p (lower half-wave) / 2p+1 (upper): (channel, tap row, tap column)
@@ -695,6 +697,13 @@ __global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x,
       const bool ok = (half ? k1 < KK : k0 < KK) && (unsigned)rr < (unsigned)H && (unsigned)col < 32u;
       b[p] = ok ? xn[((int64_t)cc * H + rr) * 32 + col] : 0.0f;
     }
+  };
+  const int R0 = blockIdx.x * 4 + wave, RS = gridDim.x * 4;
+  float b[NP], bn[NP];
+  if (R0 < rows) load_row(R0, b);
+  for (int R = R0; R < rows; R += RS) {
+    const int n = (int)fast_div((unsigned)R, m_h), r = R - n * H;
+    if (R + RS < rows) load_row(R + RS, bn);
     f32x16 acc;
 #pragma unroll
     for (int rr = 0; rr < 16; rr++) acc[rr] = bv[rr];
@@ -706,6 +715,8 @@ __global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x,
       const int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
       if (d < O) yo[(int64_t)d * H * 32] = acc[rr];
     }
+#pragma unroll
+    for (int p = 0; p < NP; p++) b[p] = bn[p];
   }
 }
 
@@ -2968,7 +2979,9 @@ int run_conv_rows3(const Geo& g, int dest_channels, float* final_dst, const floa
   if (!enabled || g.mode != 0 || g.k != 3 || g.so != 1 || g.sd != 1 || g.u0 != -1) return -1;
   if (g.CS < 1 || g.CS > 4 || g.WS != 32 || g.WD != 32 || g.HS != g.HD) return -1;
   const int rows = g.N * g.HS;
-  dim3 grid((unsigned)std::min<int64_t>(df_ceil_div(rows, 4), (int64_t)num_cus() * 8),
+  // two workgroups per CU, each wave walks rows / (8 CUs) rows: 15.3 us per launch at batch 256 against 17.4 with
+  // eight (one row per wave) -- fewer weight tiles staged, and the next row's loads run under the current row
+  dim3 grid((unsigned)std::min<int64_t>(df_ceil_div(rows, 4), (int64_t)num_cus() * 2),
             (unsigned)df_ceil_div(dest_channels, 32));
   const unsigned m_h = magic_u32((unsigned)g.HS);
 #define DF_STEM(CV)                                                                                   \
