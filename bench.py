@@ -226,11 +226,11 @@ def main():
             try:
                 import json as _json
                 pmc = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                                   "r01o_pmc_traffic.json")))
+                                                   "r01p_pmc_traffic.json")))
                 fam = pmc["families"].get(dom)
                 if fam:
                     roofline["traffic"] = fam["hbm_bytes_per_step"] / d["calls_per_step"]
-                    roofline["traffic_source"] = "profiles/r01o_pmc_traffic.json"
+                    roofline["traffic_source"] = "profiles/r01p_pmc_traffic.json"
             except Exception:
                 pass
             roofline["algorithmic_bytes_per_launch"] = prof[dom]["bytes"] / prof[dom]["calls"]
