@@ -189,10 +189,12 @@ def test_dgrad_add_epilogue(hip_device):
 
 
 @pytest.mark.parametrize("C,H,O,N,with_bias", [(1, 32, 8, 3, False), (2, 5, 40, 2, True), (3, 32, 32, 5, True),
-                                               (4, 7, 33, 1, False)])
+                                               (4, 7, 33, 1, False),
+                                               # more rows than waves: a wave walks 2-3 rows (read-ahead loop), ragged end
+                                               (3, 31, 40, 70, True), (3, 32, 32, 160, False)])
 def test_few_channel_stem_kernel(hip_device, C, H, O, N, with_bias):
     """k_conv_rows3: 3x3 / stride 1 / pad 1 on 32-wide images with 1-4 source channels (the ResNet stem),
-    ragged output-channel tiles, odd heights, bias."""
+    ragged output-channel tiles, odd heights, bias, batches where a wave walks several rows."""
     from conftest import assert_close
     from oracle import ref_ops as R
     mod = hip_device.mod
