@@ -715,8 +715,10 @@ __global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x,
       const int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
       if (d < O) yo[(int64_t)d * H * 32] = acc[rr];
     }
+    if (R + RS < rows) {
 #pragma unroll
-    for (int p = 0; p < NP; p++) b[p] = bn[p];
+      for (int p = 0; p < NP; p++) b[p] = bn[p];
+    }
   }
 }
 
