@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfhip.so")
+# DFHIP_LIBRARY: a diagnostic build of the same library (tools/probes/build/*), never a different implementation
+LIB_PATH = os.environ.get("DFHIP_LIBRARY") or os.path.join(_HERE, "libdfhip.so")
 
 _lib = None
 

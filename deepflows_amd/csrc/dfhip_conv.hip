@@ -3660,7 +3660,8 @@ static int conv2d_forward_impl(const float* x, const float* w, const float* bias
   {
     int rows = 0;
     const bool want = partials && rows_out;
-    int st = run_conv1x1s2(g, O, y, bias, want ? partials : nullptr, cap_rows, &rows);
+    int st = run_conv_rowmma(x, w, bias, y, N, C, H, W, O, k, stride, pad, want ? partials : nullptr, cap_rows, &rows);
+    if (st < 0) st = run_conv1x1s2(g, O, y, bias, want ? partials : nullptr, cap_rows, &rows);
     if (st < 0) st = run_conv_img2(g, O, y, bias, want ? partials : nullptr, cap_rows, &rows);
     if (st >= 0) {
       if (want) *rows_out = rows;

@@ -1,0 +1,445 @@
+// Conv2d forward, 3x3 / stride 1 / pad 1 on 16-, 8- and 4-wide images with 32-128 source channels
+// (ResNet layer1-3; reference path nn/functional.py:316-344: pad -> im2col -> matmul): every operand
+// of the matrix cores comes out of REGISTERS, there is no staged image, no chunk pipeline and no
+// barrier inside the reduction.
+//
+// v_mfma_f32_16x16x4_f32: D[16 output channels][16 pixels] += A[16][4 source channels] . B[4][16].
+// The 16 pixels of a tile are 16 consecutive pixels of the flattened (n, y, x) space: one row of a
+// 16-wide image, two rows of an 8-wide one, a whole 4 x 4 image.  Lane (kk = lane / 16, n = lane % 16)
+// of the B operand holds x[img][4p + kk][y + i - 1][x + j - 1] for tap (i, j):
+//   * the centre column (j = 1) of a vertical variant is ONE coalesced global load (4 channel rows of
+//     64 B); a 16-wide image re-uses the row registers of the neighbouring output rows, a 4 x 4 image
+//     gets its vertical variants with a 4-lane DPP shift (the zero fill IS the padding);
+//   * the left / right columns are the same register shifted by one lane (`row_shr:1` / `row_shl:1`,
+//     16-lane DPP rows = pixel tiles, zero fill = the padding of a 16-wide image; narrower images
+//     clear the lanes that would read across a row end).
+// The weight operand of the workgroup's 16 output channels goes to LDS once, already in MFMA lane
+// order (a wave reads four consecutive (channel group, tap) operands with one conflict-free
+// ds_read_b128); a wave owns NT pixel tiles, so an operand read feeds NT MFMAs.  Four waves per
+// workgroup share the weight image, two workgroups per CU; the waves never meet again until the
+// BatchNorm partials (count, mean, centred second moment per workgroup and channel, the layout of
+// dfhip_conv2d_forward_stats) are combined at the very end.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "dfhip_internal.h"
+
+using namespace dfhip;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+#ifdef DFHIP_ROWS_NODPP
+  return v;      // diagnostic build (timing only, wrong results): no shifts
+#endif
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kShr1 = 0x111, kShl1 = 0x101, kShr4 = 0x114, kShl4 = 0x104;
+// LDS pitch (floats) of one block of four operands x 64 lanes: 4 floats of padding put the 16 blocks a staging
+// store instruction touches on different banks (256 would put them all on the same four)
+constexpr int kBlk = 260;
+constexpr int kRor1 = 0x121, kRor2 = 0x122, kRor4 = 0x124, kRor8 = 0x128;
+
+// sum over the 16 lanes of a DPP row, result in every lane
+__device__ __forceinline__ float row_sum16(float v) {
+  v += dpp_mov<kRor8>(v);
+  v += dpp_mov<kRor4>(v);
+  v += dpp_mov<kRor2>(v);
+  v += dpp_mov<kRor1>(v);
+  return v;
+}
+
+#ifdef DFHIP_ROWS_STAMPS
+// diagnostic build only: per-wave cycle stamps (s_memtime) and one real-time stamp pair per wave
+__device__ unsigned long long g_rows_stamps[512 * 8 * 8];
+#define RS_STAMP(i)                                                                                        \
+  do {                                                                                                     \
+    if (lane == 0) g_rows_stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + (i)] =          \
+        (i) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();                        \
+  } while (0)
+#else
+#define RS_STAMP(i) do { } while (0)
+#endif
+
+// LW: log2 of the image width (4, 3, 2); C: source channels; NT: pixel tiles per wave; VDPP: the tile is the
+// whole image (H * W == 16): vertical variants by DPP instead of loads.  A workgroup is 8 waves = TS tile sets x
+// OW output-channel tiles; the weights of its OW tiles go through LDS in chunks of CG channel groups (chunk
+// k + 1 is requested before and committed after the MFMAs of chunk k: one barrier per chunk, every chunk has
+// LDS space of its own); the pixel operands of chunk k + XA are requested at the same point.
+template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, int XA>
+__global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       float* __restrict__ partials, int H, int O) {
+  static_assert(TS * OW == 8, "a workgroup is eight waves");
+  extern __shared__ __attribute__((aligned(16))) float Wl[];   // [OW][C/4*9/4 blocks][64 lanes][4] at pitch kBlk
+  __shared__ float sred[8][16][2];
+  constexpr int W = 1 << LW;
+  constexpr int NG = C / 4;                    // channel groups (one MFMA k-step each)
+  constexpr int NCH = NG / CG;                 // weight chunks
+  constexpr int NBLK = NG * 9 / 4;             // operand blocks per output-channel tile
+  constexpr int CBLK = CG * 9 / 4;             // ... per chunk
+  constexpr int NL = LW == 4 ? NT + 2 : (VDPP ? NT : 3 * NT);   // global loads per group and wave
+  static_assert(NG % CG == 0 && (CG * 9) % 4 == 0, "chunks are whole operand blocks");
+  const int HW = H << LW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 4, n = lane & 15;
+  const int ts = wave % TS, otl = wave / TS;
+  const int o0 = (blockIdx.y * OW + otl) * 16;
+  const int T0 = (blockIdx.x * TS + ts) * NT;  // first pixel tile of this wave
+  RS_STAMP(6);
+  RS_STAMP(0);
+
+  // ---- weight chunk staging: thread -> (tile, row m, 16-byte piece) of a chunk's OW x 16 rows of 36 * CG floats ----
+  constexpr int ROW4 = 9 * CG, TOT4 = OW * 16 * ROW4, PER = (TOT4 + 511) / 512;
+  const float* wsrc[PER];
+  int wdst[PER];                               // LDS float index of (tile, row m)
+  int we4[PER];
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    // (threads past the end re-do the piece 512 places back: every load has an UNCONDITIONAL consumer -- under a
+    // condition the compiler sinks the load into the commit, behind the MFMAs it was meant to overlap)
+    const int q = tid + 512 * u;
+    const int qq = q < TOT4 ? q : q - 512;
+    const int tl = qq / (16 * ROW4), r = qq - tl * (16 * ROW4);
+    const int m = r / ROW4, e4 = r - m * ROW4;
+    wsrc[u] = w + ((int64_t)((blockIdx.y * OW + tl) * 16 + m) * C * 9) + 4 * e4;
+    wdst[u] = tl * (NBLK * kBlk) + m * 4;
+    we4[u] = e4;
+  }
+  f32x4 wv[2][PER];                            // two chunks in flight
+#define RM_WLOAD(chunk)                                                                         \
+  do {                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < PER; u++)                                             \
+      wv[(chunk) & 1][u] = *reinterpret_cast<const f32x4*>(wsrc[u] + (chunk) * (36 * CG));                   \
+  } while (0)
+  // operand f = p * 9 + t of lane (kk, m) lives at block (f / 4), slot (kk * 16 + m) * 4 + f % 4
+#define RM_WCOMMIT(chunk)                                                                       \
+  do {                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < PER; u++) {                                           \
+      _Pragma("unroll") for (int e = 0; e < 4; e++) {                                           \
+        const int idx = 4 * we4[u] + e;                                                         \
+        const int c = idx / 9, t = idx - 9 * c;                                                 \
+        const int f = (c >> 2) * 9 + t;                                                         \
+        Wl[wdst[u] + ((chunk) * CBLK + (f >> 2)) * kBlk + (c & 3) * 64 + (f & 3)] = wv[(chunk) & 1][u][e]; \
+      }                                                                                         \
+    }                                                                                           \
+  } while (0)
+  RM_WLOAD(0);
+  if (NCH > 1) RM_WLOAD(1);
+  __builtin_amdgcn_sched_barrier(0);           // the weight loads stay in front of the pixel loads
+
+  // ---- per-lane source offsets (elements from x, channel group 0) and validity of every load ----
+  // (a load whose source row is outside the image gets an offset past the buffer's size: the buffer load
+  // returns zero for it, which is the padding)
+  constexpr unsigned kOut = 0x80000000u;
+  unsigned xo[NL];
+  float m_l[NT], m_r[NT];                     // narrower images: 0 for the lanes whose left / right neighbour is across a row end
+  int img_t[NT], rem_t[NT];
+  if constexpr (LW == 4) {
+    const int img = T0 / H, y0 = T0 - img * H;           // NT consecutive rows of one image (H % NT == 0)
+#pragma unroll
+    for (int r = 0; r < NT + 2; r++) {
+      const int yy = y0 - 1 + r;
+      xo[r] = (yy >= 0 && yy < H) ? (unsigned)((((int64_t)img * C + kk) * H + yy) * W + n) * 4u : kOut;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) { img_t[t] = img; rem_t[t] = (y0 + t) * W; m_l[t] = 1.0f; m_r[t] = 1.0f; }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const int P = (T0 + t) * 16;                         // first pixel of the tile: never straddles images
+      const int img = P / HW, rem0 = P - img * HW;
+      img_t[t] = img; rem_t[t] = rem0;
+      const int rem = rem0 + n, yy = rem >> LW, xx = rem & (W - 1);
+      m_l[t] = xx == 0 ? 0.0f : 1.0f; m_r[t] = xx == W - 1 ? 0.0f : 1.0f;
+      if constexpr (VDPP) {
+        xo[t] = (unsigned)(((int64_t)img * C + kk) * HW + rem) * 4u;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const int ys = yy + i - 1;
+          xo[t * 3 + i] = (ys >= 0 && ys < H) ? (unsigned)((((int64_t)img * C + kk) * H + ys) * W + xx) * 4u : kOut;
+        }
+      }
+    }
+  }
+  // pixel operands: buffer loads, the lane's offset is one VGPR per load kind, the channel group's a scalar
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7fffffff, 0x00020000);   // (tensors are < 2^31 bytes: check_conv_args)
+  float raw[NG][NL];
+#define RM_XLOAD(chunk)                                                                                          \
+  do {                                                                                                           \
+    _Pragma("unroll") for (int g_ = 0; g_ < CG; g_++) {                                                          \
+      const int p_ = (chunk) * CG + g_;                                                                          \
+      _Pragma("unroll") for (int u = 0; u < NL; u++)                                                             \
+        raw[p_][u] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)xo[u], p_ * (16 * HW), 0)); \
+      __builtin_amdgcn_sched_barrier(0);       /* group by group: the first group lands first */                 \
+    }                                                                                                            \
+  } while (0)
+#pragma unroll
+  for (int c0 = 0; c0 < XA && c0 < NCH; c0++) RM_XLOAD(c0);
+  RS_STAMP(1);
+  RM_WCOMMIT(0);
+  RS_STAMP(2);
+  __syncthreads();
+  RS_STAMP(3);
+
+  // four accumulation chains per wave whatever NT is (the taps of a tile go round its 4 / NT chains): with two,
+  // the matrix pipe of a SIMD idled a third of the time
+  constexpr int NCN = NT >= 4 ? 1 : 4 / NT;
+  f32x4 acc[NT][NCN];
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+#pragma unroll
+    for (int c = 0; c < NCN; c++) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const f32x4* Wl4 = reinterpret_cast<const f32x4*>(Wl + otl * (NBLK * kBlk)) + lane;
+  f32x4 a4[2][CBLK];                                       // weight operands of two chunks: CG groups x 9 taps each
+#pragma unroll
+  for (int q = 0; q < CBLK; q++) a4[0][q] = Wl4[q * (kBlk / 4)];
+  float bsh[2][NT][3][3];
+  auto make_shifts = [&](float (&b)[NT][3][3], const float (&rw)[NL]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      if constexpr (VDPP) {
+        // a 4 x 4 image per tile: tap (i, j) is the register shifted by 4 (i - 1) + (j - 1) lanes, ONE DPP
+        // move each (the zero fill is the vertical padding), times the lane mask of the column
+        const float v = rw[t];
+        b[t][0][0] = dpp_mov<0x115>(v) * m_l[t];   // row_shr:5
+        b[t][0][1] = dpp_mov<kShr4>(v);
+        b[t][0][2] = dpp_mov<0x113>(v) * m_r[t];   // row_shr:3
+        b[t][1][0] = dpp_mov<kShr1>(v) * m_l[t];
+        b[t][1][1] = v;
+        b[t][1][2] = dpp_mov<kShl1>(v) * m_r[t];
+        b[t][2][0] = dpp_mov<0x103>(v) * m_l[t];   // row_shl:3
+        b[t][2][1] = dpp_mov<kShl4>(v);
+        b[t][2][2] = dpp_mov<0x105>(v) * m_r[t];   // row_shl:5
+      } else if constexpr (LW < 4) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const float v = rw[t * 3 + i];
+          b[t][i][0] = dpp_mov<kShr1>(v) * m_l[t];
+          b[t][i][1] = v;
+          b[t][i][2] = dpp_mov<kShl1>(v) * m_r[t];
+        }
+      }
+    }
+  };
+  if constexpr (LW < 4) make_shifts(bsh[0], raw[0]);
+#pragma unroll
+  for (int ch = 0; ch < NCH; ch++) {
+    // chunk ch + 1 (requested a chunk ago) is committed now and made visible by a barrier in the MIDDLE of this
+    // chunk's MFMAs, where no wave waits for anything else; chunk ch + 2 and the pixels of ch + XA are requested
+    if (ch + 1 < NCH) RM_WCOMMIT(ch + 1);
+    if (ch + 2 < NCH) RM_WLOAD(ch + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ch + XA < NCH) RM_XLOAD(ch + XA);
+    for (int g = 0; g < CG; g++) {
+      const int p = ch * CG + g;
+      if (g == CG / 2 && ch + 1 < NCH) {
+        __syncthreads();
+        // the next chunk's operands are visible now: read them here, half a chunk before their first use
+#pragma unroll
+        for (int q = 0; q < CBLK; q++) a4[(ch + 1) & 1][q] = Wl4[((ch + 1) * CBLK + q) * (kBlk / 4)];
+      }
+      // the nine pixel operands of every tile from this group's registers
+      if constexpr (LW == 4) {
+        float c1[NT + 2], c0[NT + 2], c2[NT + 2];
+#pragma unroll
+        for (int r = 0; r < NT + 2; r++) {
+          c1[r] = raw[p][r];
+          c0[r] = dpp_mov<kShr1>(c1[r]);
+          c2[r] = dpp_mov<kShl1>(c1[r]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            const int f = g * 9 + i * 3 + j;
+            const float a = a4[ch & 1][f >> 2][f & 3];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+              const float b = j == 0 ? c0[t + i] : (j == 1 ? c1[t + i] : c2[t + i]);
+              acc[t][(i * 3 + j) % NCN] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t][(i * 3 + j) % NCN], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+        // the shifted operands of group p + 1 are made WHILE the MFMAs of group p issue (they read only registers
+        // that were loaded a chunk ago): an MFMA whose operand comes from the instruction in front of it stalls the
+        // wave's issue, and with it the matrix pipe, for the latency of that instruction
+        __builtin_amdgcn_sched_barrier(0);
+        if (p + 1 < NG) make_shifts(bsh[(p + 1) & 1], raw[p + 1]);
+        float (&b)[NT][3][3] = bsh[p & 1];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            const int f = g * 9 + i * 3 + j;
+            const float a = a4[ch & 1][f >> 2][f & 3];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+              acc[t][(i * 3 + j) % NCN] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t][i][j], acc[t][(i * 3 + j) % NCN], 0, 0, 0);
+            }
+          }
+        }
+        // issue order of the group: one shift behind every MFMA
+#pragma unroll
+        for (int k2 = 0; k2 < 9 * NT; k2++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+      }
+    }
+  }
+#undef RM_WLOAD
+#undef RM_WCOMMIT
+#undef RM_XLOAD
+
+  f32x4 res[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    res[t] = acc[t][0];
+#pragma unroll
+    for (int c = 1; c < NCN; c++) res[t] += acc[t][c];
+  }
+  RS_STAMP(4);
+  // ---- epilogue: accumulator register v of lane (kk, n) is channel o0 + 4 * kk + v, pixel n of the tile ----
+  if (bias) {
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const float bv = bias[o0 + 4 * kk + v];
+#pragma unroll
+      for (int t = 0; t < NT; t++) res[t][v] += bv;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    float* yt = y + ((int64_t)img_t[t] * O + o0 + 4 * kk) * HW + rem_t[t] + n;
+#pragma unroll
+    for (int v = 0; v < 4; v++) yt[(int64_t)v * HW] = res[t][v];
+  }
+  if (partials) {
+    // BatchNorm partials: exact two-pass over the wave's NT * 16 pixels per channel, then Chan's
+    // combination of the TS waves that share the output channels
+    constexpr float cnt_w = 16.0f * NT;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      float s = 0.0f;
+#pragma unroll
+      for (int t = 0; t < NT; t++) s += res[t][v];
+      const float mean_w = row_sum16(s) * (1.0f / cnt_w);
+      float q = 0.0f;
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const float d = res[t][v] - mean_w;
+        q += d * d;
+      }
+      q = row_sum16(q);
+      if (n == 0) {
+        sred[wave][4 * kk + v][0] = mean_w;
+        sred[wave][4 * kk + v][1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < 16 * OW) {
+      const int tl = tid >> 4, ch = tid & 15;
+      float nn = cnt_w, mu = sred[tl * TS][ch][0], m2 = sred[tl * TS][ch][1];
+#pragma unroll
+      for (int w4 = 1; w4 < TS; w4++) {
+        const float tot = nn + cnt_w, delta = sred[tl * TS + w4][ch][0] - mu;
+        mu += delta * (cnt_w / tot);
+        m2 += sred[tl * TS + w4][ch][1] + delta * delta * (nn * cnt_w / tot);
+        nn = tot;
+      }
+      float* o = partials + ((int64_t)blockIdx.x * O + (blockIdx.y * OW + tl) * 16 + ch) * 3;
+      o[0] = nn; o[1] = mu; o[2] = m2;
+    }
+  }
+  RS_STAMP(5);
+  RS_STAMP(7);
+}
+
+template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, int XA>
+int launch_rowmma(const float* x, const float* w, const float* bias, float* y, float* partials, int H, int O,
+                  dim3 grid) {
+  const size_t lds = (size_t)OW * (C / 4 * 9 / 4) * kBlk * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536)));
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA>), grid, dim3(512), lds, stream(), x, w, bias, y,
+                     partials, H, O);
+  DF_LAUNCH_CHECK();
+#ifdef DFHIP_ROWS_STAMPS
+  {
+    static int calls = 0;
+    if (++calls % 20 == 0) {
+      const size_t nw = (size_t)grid.x * grid.y * 8;
+      std::vector<unsigned long long> h(nw * 8);
+      (void)hipStreamSynchronize(stream());
+      (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_rows_stamps), nw * 8 * sizeof(unsigned long long));
+      double seg[6] = {0};
+      unsigned long long r0 = ~0ull, r1 = 0, rs = 0;
+      for (size_t i = 0; i < nw; i++) {
+        const unsigned long long* r = &h[i * 8];
+        for (int k = 1; k <= 5; k++) seg[k] += (double)(r[k] - r[k - 1]);
+        r0 = std::min(r0, r[6]); r1 = std::max(r1, r[7]); rs = std::max(rs, r[6]);
+      }
+      fprintf(stderr, "[rows-stamp] LW %d C %d NT %d TS %d OW %d CG %d XA %d grid %u x %u: first start -> last end %.2f us, last "
+              "wave starts +%.2f us; mean cycles per wave: issue %.0f, w-commit %.0f, barrier %.0f, mfma-loop %.0f, epilogue %.0f\n",
+              LW, C, NT, TS, OW, CG, XA, grid.x, grid.y, (double)(r1 - r0) / 100.0, (double)(rs - r0) / 100.0,
+              seg[1] / nw, seg[2] / nw, seg[3] / nw, seg[4] / nw, seg[5] / nw);
+    }
+  }
+#endif
+  return DFHIP_OK;
+}
+
+}  // namespace
+
+namespace dfhip {
+
+// returns -1 when the shape is not one this kernel takes
+int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int O,
+                    int k, int stride, int pad, float* partials, int cap_rows, int* rows_out) {
+  static int enabled = getenv("DFHIP_ROWMMA") ? atoi(getenv("DFHIP_ROWMMA")) : 1;
+  static int variant = getenv("DFHIP_ROWMMA_VARIANT") ? atoi(getenv("DFHIP_ROWMMA_VARIANT")) : 0;
+  if (!enabled || k != 3 || stride != 1 || pad != 1) return -1;
+  const int64_t HW = (int64_t)H * W;
+  if (HW % 16 != 0) return -1;
+  const int64_t tiles = (int64_t)N * HW / 16;
+  // (width, channels) -> tiles per wave, tile sets x channel tiles per workgroup
+  int nt, ts, ow;
+  if (W == 16 && C == 32) { nt = 4; ts = 4; ow = 2; }
+  else if (W == 8 && C == 64) { nt = 2; ts = 4; ow = 2; }
+  else if (W == 4 && H == 4 && C == 128) { nt = 1; ts = 8; ow = 1; }
+  else return -1;
+  if (O % (16 * ow) != 0 || tiles % (ts * nt) != 0 || (W == 16 && H % nt != 0)) return -1;
+  const int64_t gx = tiles / (ts * nt);
+  if (partials && gx > cap_rows) return -1;
+  if (gx * (O / (16 * ow)) < num_cus() / 2) return -1;   // too few workgroups: the staged kernel's k-split wins
+  if (rows_out) *rows_out = partials ? (int)gx : 0;
+  dim3 grid((unsigned)gx, (unsigned)(O / (16 * ow)));
+  if (W == 16) {
+    if (variant == 1) return launch_rowmma<4, 32, 4, false, 4, 2, 8, 1>(x, w, bias, y, partials, H, O, grid);
+    if (variant == 2) return launch_rowmma<4, 32, 4, false, 4, 2, 4, 2>(x, w, bias, y, partials, H, O, grid);
+    return launch_rowmma<4, 32, 4, false, 4, 2, 4, 1>(x, w, bias, y, partials, H, O, grid);
+  }
+  if (W == 8) {
+    if (variant == 1) return launch_rowmma<3, 64, 2, false, 4, 2, 8, 1>(x, w, bias, y, partials, H, O, grid);
+    if (variant == 2) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 2>(x, w, bias, y, partials, H, O, grid);
+    return launch_rowmma<3, 64, 2, false, 4, 2, 4, 1>(x, w, bias, y, partials, H, O, grid);
+  }
+  if (variant == 1) return launch_rowmma<2, 128, 1, true, 8, 1, 4, 2>(x, w, bias, y, partials, H, O, grid);
+  if (variant == 2) return launch_rowmma<2, 128, 1, true, 8, 1, 8, 2>(x, w, bias, y, partials, H, O, grid);
+  return launch_rowmma<2, 128, 1, true, 8, 1, 8, 1>(x, w, bias, y, partials, H, O, grid);
+}
+
+}  // namespace dfhip

@@ -41,6 +41,10 @@ int flush_deferred();
 bool deferred_touches(const void* p);
 int deferred_scratch_slot();          // scratch slot holding the pending slabs, -1 if none
 
+// dfhip_conv_rows.hip: register-operand 3x3 / stride 1 / pad 1 forward kernel; -1 when the shape is not eligible
+int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int O,
+                    int k, int stride, int pad, float* partials, int cap_rows, int* rows_out);
+
 }  // namespace dfhip
 
 #define DF_CHECK_ARG(cond, ...)                      \

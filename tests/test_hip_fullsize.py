@@ -210,3 +210,35 @@ def test_grouped_wgrad_small_batches(hip_device):
         mod.wgrad_group_end()
         for name, x, dy, k, s, p, xh, dyh, dwh, shape in held:
             assert_close(_back(mod, dwh, shape), R.conv2d_wgrad(x, dy, k, s, p), 1e-4, f"{name} n={n} grouped")
+
+
+@pytest.mark.parametrize("name,bias", [("l1", False), ("l2", True), ("l3", False), ("l1", True)])
+def test_register_operand_forward_with_partials(hip_device, name, bias):
+    """3x3 / stride 1 forward on the register-operand kernel (dfhip_conv_rows.hip) at batch 256: the output
+    against the oracle, and the BatchNorm partials it leaves behind (count, mean, centred second moment per
+    workgroup and channel) combined with Chan's formula against the mean / biased variance of the output."""
+    mod = hip_device.mod
+    C, H, W, O, k, s, p = LAYERS[name]
+    rng = np.random.default_rng(41)
+    x = (rng.standard_normal((N, C, H, W)) + 0.25).astype(np.float32)
+    w = (rng.standard_normal((O, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+    b = rng.standard_normal(O).astype(np.float32) if bias else None
+    yh, ph = mod.Array(N * O * H * W), mod.Array(512 * O * 3)
+    rows = mod.conv2d_forward_stats(_arr(mod, x), _arr(mod, w), _arr(mod, b) if bias else None, yh,
+                                    N, C, H, W, O, k, s, p, ph, 512)
+    y_ref = R.conv2d_forward(x, w, b, s, p)
+    assert_close(_back(mod, yh, y_ref.shape), y_ref, 1e-4, name + " forward")
+    assert rows > 0
+    part = _back(mod, ph, (512, O, 3))[:rows].astype(np.float64)
+    cnt, mu, m2 = np.zeros(O), np.zeros(O), np.zeros(O)
+    for r in range(rows):
+        nb, mb, qb = part[r, :, 0], part[r, :, 1], part[r, :, 2]
+        tot = cnt + nb
+        d = mb - mu
+        mu = mu + d * nb / tot
+        m2 = m2 + qb + d * d * cnt * nb / tot
+        cnt = tot
+    assert np.all(cnt == N * H * W)
+    y64 = y_ref.astype(np.float64)
+    assert_close(mu, y64.mean(axis=(0, 2, 3)), 1e-5, "partials mean")
+    assert_close(m2 / cnt, y64.var(axis=(0, 2, 3)), 1e-5, "partials variance")
