@@ -35,15 +35,32 @@ _ALLOWED = {
     ("builtins", "int"), ("builtins", "str"), ("builtins", "bool"), ("builtins", "complex"), ("builtins", "bytes"),
     ("builtins", "bytearray"), ("collections", "OrderedDict"),
     ("dill._dill", "_load_type"),       # dill writes `dict`/`list` type references through this helper
+    ("dill._dill", "_create_array"),    # ... and every ndarray through this one (the reference saves with dill when it is installed)
 }
+
+
+def _dill_create_array(f, args, state, npdict=None):
+    """What dill._dill._create_array does for a plain ndarray, without importing dill: `f` must be NumPy's
+    _reconstruct (it came through find_class, so it is), the array is rebuilt from (args, state); an attached
+    __dict__ (ndarray subclasses) is refused."""
+    if getattr(f, "__name__", "") != "_reconstruct":
+        raise pickle.UnpicklingError("checkpoint: dill array record does not use numpy's _reconstruct")
+    if npdict:
+        raise pickle.UnpicklingError("checkpoint: ndarray subclasses with attributes are not loaded")
+    array = f(*args)
+    array.__setstate__(state)
+    return array
+
+
+_DILL_TYPES = {"dict": dict, "list": list, "tuple": tuple, "float": float, "int": int, "str": str, "bool": bool,
+               "NoneType": type(None)}
 
 
 class _ArrayUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if (module, name) in _ALLOWED:
-            if module == "dill._dill":
-                return lambda type_name: {"dict": dict, "list": list, "tuple": tuple, "float": float, "int": int,
-                                          "str": str, "bool": bool, "NoneType": type(None)}[type_name]
+            if module == "dill._dill":      # shims: dill itself is never imported by the loader
+                return _dill_create_array if name == "_create_array" else (lambda type_name: _DILL_TYPES[type_name])
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"checkpoint refers to {module}.{name}: only NumPy arrays and builtins are loaded")
 
@@ -106,6 +123,20 @@ def _device_array(arr, like):
         if hasattr(backend_api, "Btensor") else BackendTensor(np.ascontiguousarray(arr, dtype=np.float32), device=dev)
 
 
+def _assign(holder, arr, like=None):
+    """Put `arr` into the tensor `holder` (a Tensor: its .data is replaced or overwritten) IN PLACE when the existing
+    device array is a compact buffer of the same size -- a step captured in a hipGraph (graph_step.CapturedTrainStep)
+    has the raw pointers of parameters, Adam moments and running statistics baked in, so a load must not move them."""
+    arr = np.ascontiguousarray(arr, dtype=np.float32)
+    cur = holder.data if hasattr(holder, "data") and not isinstance(holder, BackendTensor) else holder
+    handle = getattr(cur, "_handle", None)
+    if (handle is not None and tuple(int(s) for s in cur.shape) == tuple(arr.shape) and
+            getattr(cur, "_offset", 0) == 0 and getattr(handle, "size", -1) == arr.size and cur.is_compact()):
+        cur.device.from_numpy(arr, handle)
+        return cur
+    return _device_array(arr, like if like is not None else holder)
+
+
 def load_checkpoint(model, optimizer=None, save_path="checkpoint.pkl"):
     """Same signature and return value as the reference's load_checkpoint (:86-181)."""
     ck = read_checkpoint(save_path)
@@ -115,7 +146,7 @@ def load_checkpoint(model, optimizer=None, save_path="checkpoint.pkl"):
             a = np.asarray(stored[name], dtype=np.float32)
             if tuple(a.shape) != tuple(int(s) for s in p.shape):
                 raise ValueError(f"checkpoint parameter {name} has shape {a.shape}, model has {tuple(p.shape)}")
-            p.data = _device_array(a, p)
+            p.data = _assign(p, a)
     bufs = ck.get("buffers") or {}
     if bufs:
         mods = dict(model.named_modules())
@@ -124,7 +155,7 @@ def load_checkpoint(model, optimizer=None, save_path="checkpoint.pkl"):
             m = mods.get(mname)
             t = getattr(m, attr, None) if m is not None else None
             if t is not None:
-                t.data = _device_array(a, t)
+                t.data = _assign(t, a)
     if optimizer is not None and "optimizer_state" in ck:
         st = ck["optimizer_state"]
         for attr in ("lr", "momentum", "weight_decay"):
@@ -136,7 +167,7 @@ def load_checkpoint(model, optimizer=None, save_path="checkpoint.pkl"):
                 cur = getattr(optimizer, key)
                 for i, p in enumerate(params):
                     if i < len(st[key]) and isinstance(st[key][i], np.ndarray):
-                        cur[i] = _device_array(st[key][i], p)
+                        cur[i] = _assign(cur[i], st[key][i], like=p) if cur[i] is not None else _device_array(st[key][i], p)
         if hasattr(optimizer, "t") and "t" in st:
             optimizer.t = st["t"]
     return {"epoch": ck.get("epoch", 0), "loss": ck.get("loss")}

@@ -56,7 +56,11 @@ def reference_part():
         Graph.free_graph()
     path = os.path.join(OUT, "ck_reference_mlp.pkl")
     ref_mu.save_checkpoint(model, opt, epoch=3, loss=float(loss.data.numpy()[0]), save_path=path)
-    ck = pickle.load(open(path, "rb"))          # must be loadable without dill
+    # the file exactly as the reference wrote it (through dill when it is installed, as its requirements.txt
+    # asks): kept byte for byte as a second fixture, the loader must read it without importing dill
+    import shutil
+    shutil.copyfile(path, os.path.join(OUT, "ck_reference_mlp_dill.pkl"))
+    ck = pickle.load(open(path, "rb"))
     # re-write with the standard pickler so that the fixture does not depend on dill at all
     pickle.dump(ck, open(path, "wb"), protocol=4)
     exp = {"param." + k: v for k, v in ck["model_parameters"].items()}
@@ -75,6 +79,16 @@ def reference_part():
     for n, p in model.named_parameters():
         exp["next." + n] = p.data.numpy()
     np.savez(os.path.join(OUT, "ck_reference_mlp_expect.npz"), **exp)
+    # the checkpoint the reference ships (test/checkpoints-cifar10cuda_70%/, written by its CUDA run through
+    # dill): per-entry shapes and float64 sums, so that a test can check a direct load of that file where it exists
+    shipped = "/root/reference/test/checkpoints-cifar10cuda_70%/cifar10_cnn_cuda_checkpoint.pkl"
+    if os.path.exists(shipped):
+        import dill
+        sk = dill.load(open(shipped, "rb"))
+        summ = {"epoch": sk.get("epoch"), "loss": sk.get("loss"), "optimizer_type": sk.get("optimizer_state", {}).get("type"),
+                "parameters": {k: {"shape": list(v.shape), "sum": float(np.asarray(v, np.float64).sum())}
+                               for k, v in sk["model_parameters"].items()}}
+        json.dump(summ, open(os.path.join(OUT, "ck_shipped_cnn_summary.json"), "w"), indent=1)
     return MLP, ref_mu, dev
 
 
