@@ -2980,6 +2980,9 @@ int run_conv_rows3(const Geo& g, int dest_channels, float* final_dst, const floa
   static int enabled = getenv("DFHIP_STEM_ROWS") ? atoi(getenv("DFHIP_STEM_ROWS")) : 1;
   if (!enabled || g.mode != 0 || g.k != 3 || g.so != 1 || g.sd != 1 || g.u0 != -1) return -1;
   if (g.CS < 1 || g.CS > 4 || g.WS != 32 || g.WD != 32 || g.HS != g.HD) return -1;
+  // the kernel divides a row index < N * H by H with fast_div (magic = ceil(2^32 / H)): exact for every n < N * H
+  // only while n * (H - 1) < 2^32 when H is not a power of two
+  if ((g.HS & (g.HS - 1)) != 0 && (uint64_t)g.N * g.HS * g.HS >= ((uint64_t)1 << 32)) return -1;
   const int rows = g.N * g.HS;
   // two workgroups per CU, each wave walks rows / (8 CUs) rows: 15.3 us per launch at batch 256 against 17.4 with
   // eight (one row per wave) -- fewer weight tiles staged, and the next row's loads run under the current row

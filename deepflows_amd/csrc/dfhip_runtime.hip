@@ -363,6 +363,13 @@ int dfhip_h2d(const float* host, float* dst, int64_t n) {
   DF_INIT();
   DF_CHECK_ARG(n >= 0 && (n == 0 || (host && dst)), "h2d: null pointer");
   if (n == 0) return DFHIP_OK;
+  // A copy recorded into a graph would re-read one of the four RECYCLED pinned slots on every replay (whatever a
+  // later upload left there): refuse it.  Host data a captured step needs (e.g. Dropout masks) is written into
+  // graph-owned device arrays by eager uploads in front of each replay (graph_step.CapturedTrainStep).
+  if (g_capture_open) {
+    set_error("h2d inside a graph capture: upload into a graph-owned array before the replay instead");
+    return DFHIP_RUNTIME_ERROR;
+  }
   size_t bytes = (size_t)n * sizeof(float);
   const size_t chunk = (size_t)64 << 20;
   for (size_t off = 0; off < bytes; off += chunk) {
@@ -384,10 +391,8 @@ int dfhip_h2d(const float* host, float* dst, int64_t n) {
     }
     memcpy(sl.p, (const char*)host + off, b);
     DF_HIP(hipMemcpyAsync((char*)dst + off, sl.p, b, hipMemcpyHostToDevice, g_stream));
-    if (!g_capture_open) {
-      DF_HIP(hipEventRecord(sl.done, g_stream));
-      sl.busy = true;
-    }
+    DF_HIP(hipEventRecord(sl.done, g_stream));
+    sl.busy = true;
   }
   return DFHIP_OK;
 }
@@ -477,6 +482,19 @@ struct GraphExec {
   int capture_id;
 };
 
+// the blocks a capture owned go back to the general pool (graph destroyed, or the capture failed)
+static void release_capture_blocks(int capture_id) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& kv : g_blocks)
+    if (kv.second.owner == capture_id) kv.second.owner = 0;
+  auto it = g_cap_free.find(capture_id);
+  if (it != g_cap_free.end()) {
+    for (auto& kv : it->second)
+      for (void* p : kv.second) g_free[kv.first].push_back(p);
+    g_cap_free.erase(it);
+  }
+}
+
 int dfhip_graph_begin(void) {
   DF_INIT();
   DF_CHECK_ARG(!g_capture_open, "a capture is already open");
@@ -517,6 +535,7 @@ int dfhip_graph_end(void** graph_exec) {
         return DFHIP_RUNTIME_ERROR;
       }
     }
+    release_capture_blocks(id);                   // no GraphExec will ever own them
     set_error("capture failed: %s", e != hipSuccess ? hipGetErrorString(e) : "a call inside the capture failed");
     return DFHIP_RUNTIME_ERROR;
   }
@@ -524,6 +543,7 @@ int dfhip_graph_end(void** graph_exec) {
   e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   if (e != hipSuccess) {
     (void)hipGraphDestroy(graph);
+    release_capture_blocks(id);
     set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
     return DFHIP_RUNTIME_ERROR;
   }
@@ -546,18 +566,7 @@ int dfhip_graph_destroy(void* graph_exec) {
   (void)hipStreamSynchronize(g_stream);
   (void)hipGraphExecDestroy(g->exec);
   (void)hipGraphDestroy(g->graph);
-  {
-    // the capture's private blocks go back to the general pool
-    std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& kv : g_blocks)
-      if (kv.second.owner == g->capture_id) kv.second.owner = 0;
-    auto it = g_cap_free.find(g->capture_id);
-    if (it != g_cap_free.end()) {
-      for (auto& kv : it->second)
-        for (void* p : kv.second) g_free[kv.first].push_back(p);
-      g_cap_free.erase(it);
-    }
-  }
+  release_capture_blocks(g->capture_id);
   delete g;
   return DFHIP_OK;
 }

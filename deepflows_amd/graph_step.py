@@ -12,6 +12,8 @@ one-thread launch in front of every replay (optim/adam.py: push_hyper / apply).
 The reference has nothing comparable (it launches 8 575 device calls per step from Python,
 SURVEY F8); this is the MI355X-native replacement for that dispatch loop.
 """
+import numpy as np
+
 from .tensor import Graph
 
 
@@ -33,6 +35,7 @@ class CapturedTrainStep:
         self.mod, self.optimizer, self.sync = mod, optimizer, sync
         optimizer.device_hyper = True
         optimizer.push_hyper()                      # allocates the scalar array outside the capture
+        mod.capture_feeds = []                      # host-drawn inputs of the step (Dropout masks), in forward order
         mod.capture_begin()
         try:
             outputs = model(inputs)
@@ -43,19 +46,27 @@ class CapturedTrainStep:
                 optimizer.apply()
             Graph.free_graph()
         except BaseException:
+            mod.capture_feeds = None
             try:
                 mod.capture_end().destroy()
             except Exception:
                 pass
             raise
+        self.feeds, mod.capture_feeds = mod.capture_feeds, None
         self.loss, self.outputs = loss, outputs
         self.grads = [p.grad for p in optimizer.params]     # the buffers backward writes on a replay
-        self.graph = mod.capture_end(keep=(loss, outputs, inputs, targets, self.grads))
+        self.graph = mod.capture_end(keep=(loss, outputs, inputs, targets, self.grads, self.feeds))
         # the capture only recorded the step: nothing ran, the optimizer's step count is unchanged
 
     def replay(self):
         opt = self.optimizer
         opt.push_hyper()
+        if self.feeds:
+            # Dropout masks of this step: drawn on the host exactly as the eager forward pass would draw them
+            # (nn/modules/dropout.py), uploaded on the library stream in front of the graph
+            from .nn.modules.dropout import bernoulli_mask
+            for mask, keep in self.feeds:
+                self.mod.from_numpy(np.ascontiguousarray(bernoulli_mask(keep, mask.shape)), mask._handle)
         self.graph.replay()
         if self.sync is not None:
             for p, g in zip(opt.params, self.grads):

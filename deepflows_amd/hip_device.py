@@ -422,6 +422,7 @@ class HipModule:
         _lib.check(self._lib.dfhip_sync())
 
     capturing = False      # a stream capture is open (arrays allocated now belong to that graph)
+    capture_feeds = None   # list the capturing front end collects host-drawn graph inputs in (Dropout masks)
 
     def capture_begin(self):
         _lib.check(self._lib.dfhip_graph_begin())

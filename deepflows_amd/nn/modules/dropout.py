@@ -24,9 +24,17 @@ class Dropout(Module):
 
     def forward(self, x):
         if self.training:
-            mask_np = np.ascontiguousarray(bernoulli_mask(1 - self.p, x.shape))
             mask = x.device.empty(x.shape, dtype="float32")
-            x.device.from_numpy(mask_np, mask._handle)
+            feeds = getattr(x.device.mod, "capture_feeds", None)
+            if getattr(x.device.mod, "capturing", False) and feeds is not None:
+                # inside a step capture (graph_step.CapturedTrainStep) nothing runs and no host copy may be
+                # recorded: the mask array belongs to the graph and is a graph INPUT -- every replay draws the
+                # masks in this registration order (= the forward order = the reference's RNG order,
+                # dropout.py:16-18) and uploads them in front of the graph launch
+                feeds.append((mask, 1 - self.p))
+            else:
+                mask_np = np.ascontiguousarray(bernoulli_mask(1 - self.p, x.shape))
+                x.device.from_numpy(mask_np, mask._handle)
             return x * mask / (1 - self.p)
         return x * (1 - self.p)
 

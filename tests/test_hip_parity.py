@@ -194,25 +194,82 @@ def test_fused_stem_matches_the_three_operators(hip_device):
             assert_close(b, a, 2e-5, f"{nme} {N, C, H, W}")
 
 
-def test_failed_capture_leaves_the_device_usable(hip_device):
-    """A model that draws host random numbers per step (Dropout: mask generated on the host and
-    uploaded) cannot be captured; the attempt must raise, end the capture and leave eager training
-    intact."""
+def test_captured_step_with_dropout_matches_eager_steps(hip_device):
+    """The CNN workload has Dropout (mask drawn on the host, nn/modules/dropout.py): in a captured step the mask is
+    a graph INPUT, drawn in the reference's RNG order and uploaded in front of every replay -- 1 eager + 3 replayed
+    Adam steps leave exactly the losses and parameters of 4 eager steps, and the NumPy generator ends in the same
+    state."""
     from deepflows_amd import nn, optim, tensor, workloads
     from deepflows_amd.graph_step import CapturedTrainStep
     from deepflows_amd.tensor import Graph
+
+    def run(captured):
+        np.random.seed(3)
+        model = workloads.CIFAR10_CNN(10, device=hip_device)
+        opt = optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4)
+        crit = nn.CrossEntropyLoss()
+        rng = np.random.default_rng(4)
+        x = tensor.Tensor(rng.standard_normal((8, 3, 32, 32)).astype(np.float32), device=hip_device)
+        y = tensor.Tensor(np.eye(10, dtype=np.float32)[rng.integers(0, 10, 8)], device=hip_device)
+        loss, _ = workloads.train_step(model, crit, opt, x, y)
+        losses = [float(loss.numpy().reshape(-1)[0])]
+        Graph.free_graph()
+        if captured:
+            cs = CapturedTrainStep(model, crit, opt, x, y)
+            assert len(cs.feeds) >= 1
+            for _ in range(3):
+                losses.append(float(cs.replay().numpy().reshape(-1)[0]))
+        else:
+            for _ in range(3):
+                loss, _ = workloads.train_step(model, crit, opt, x, y)
+                losses.append(float(loss.numpy().reshape(-1)[0]))
+                Graph.free_graph()
+        return losses, [p.numpy().copy() for p in opt.params], float(np.random.random_sample())
+
+    l0, p0, r0 = run(False)
+    l1, p1, r1 = run(True)
+    assert l0 == l1, (l0, l1)
+    assert r0 == r1, "the captured step consumed the NumPy generator differently"
+    assert len(set(l0)) == 4                              # (the masks did change from step to step)
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)
+
+
+def test_failed_capture_leaves_the_device_usable(hip_device):
+    """A forward pass that uploads host data itself cannot be captured (a recorded copy would re-read a recycled
+    pinned slot on every replay: dfhip_h2d refuses it); the attempt must raise, end the capture, give the
+    capture's blocks back to the pool and leave eager training intact."""
+    from deepflows_amd import nn, optim, tensor, workloads
+    from deepflows_amd.graph_step import CapturedTrainStep
+    from deepflows_amd.tensor import Graph
+
+    class Noisy(nn.Module):
+        def __init__(self, dev):
+            super().__init__()
+            self.fc = nn.Linear(16, 10, device=dev)
+
+        def forward(self, x):
+            noise = x.device.empty(x.shape, dtype="float32")
+            x.device.from_numpy(np.ones(tuple(x.shape), np.float32), noise._handle)     # host copy in the step
+            return self.fc(x * noise)
+
     np.random.seed(3)
-    model = workloads.CIFAR10_CNN(10, device=hip_device)
+    model = Noisy(hip_device)
     opt = optim.Adam(model.parameters(), lr=1e-3)
     crit = nn.CrossEntropyLoss()
     rng = np.random.default_rng(4)
-    x = tensor.Tensor(rng.standard_normal((8, 3, 32, 32)).astype(np.float32), device=hip_device)
+    x = tensor.Tensor(rng.standard_normal((8, 16)).astype(np.float32), device=hip_device)
     y = tensor.Tensor(np.eye(10, dtype=np.float32)[rng.integers(0, 10, 8)], device=hip_device)
     l0, _ = workloads.train_step(model, crit, opt, x, y)
     Graph.free_graph()
-    with pytest.raises(RuntimeError):
-        CapturedTrainStep(model, crit, opt, x, y)
-    Graph.free_graph_all()
+    mod = hip_device.mod
+    for attempt in range(3):
+        with pytest.raises(RuntimeError):
+            CapturedTrainStep(model, crit, opt, x, y)
+        Graph.free_graph_all()
+        if attempt == 0:
+            mallocs = mod.pool_stats()["hipmalloc_calls"]
+    assert mod.pool_stats()["hipmalloc_calls"] == mallocs, "a failed capture leaked its blocks"
     opt.device_hyper = False
     losses = []
     for _ in range(3):
