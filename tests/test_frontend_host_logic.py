@@ -102,6 +102,44 @@ def test_schedulers_match_closed_forms(cpu_oracle):
     assert out == [0.1, 0.1, 0.05, 0.05, 0.025]
 
 
+def test_schedulers_reproduce_the_reference_sequences():
+    """25 epochs of every schedule against the learning rates the reference's own classes produced
+    (optim/scheduler.py:13-61 run by oracle/gen_f3_golden.py): equal to the last bit, same expression order."""
+    from conftest import load_golden
+    g = load_golden("g11_nn_surface.npz")
+
+    class Opt:
+        def __init__(self, lr):
+            self.lr = lr
+
+    def run(make, lr):
+        o = Opt(lr)
+        s = make(o)
+        seq = []
+        for _ in range(25):
+            s.step()
+            seq.append(o.lr)
+        return np.array(seq, dtype=np.float64)
+
+    assert np.array_equal(run(lambda o: optim.StepLR(o, step_size=3, gamma=0.5), 0.1), g["lr_step"])
+    assert np.array_equal(run(lambda o: optim.CosineAnnealingLR(o, T_max=7, eta_min=1e-5), 0.05), g["lr_cosine"])
+    assert np.array_equal(run(lambda o: optim.WarmupCosineLR(o, warmup_epochs=2, T_max=10, eta_min=1e-5), 1e-3),
+                          g["lr_warmcos"])
+    assert np.array_equal(run(lambda o: optim.WarmupCosineLR(o, warmup_epochs=4, T_max=6, base_lr=0.02,
+                                                             warmup_start_lr=1e-4, eta_min=0.0), 7.0),
+                          g["lr_warmcos_explicit"])
+    assert np.array_equal(run(lambda o: optim.WarmupCosineLR(o, warmup_epochs=0, T_max=5), 0.3), g["lr_warmcos_nowarm"])
+    # an optimizer without a learning rate is left alone
+    class NoLr:
+        pass
+    for make in (lambda o: optim.StepLR(o, 1), lambda o: optim.CosineAnnealingLR(o, 3),
+                 lambda o: optim.WarmupCosineLR(o, 1, 3)):
+        o = NoLr()
+        s = make(o)
+        s.step(); s.step()
+        assert not hasattr(o, "lr") and s.last_epoch == 1
+
+
 def test_state_dict_roundtrip_excludes_bn_running_stats(cpu_oracle):
     np.random.seed(1)
     m = workloads.CIFAR10_CNN(10, device=cpu_oracle)

@@ -315,3 +315,16 @@ def test_paired_batchnorm_matches_two_layers(hip_device):
     names = ("y", "dx", "dw_a", "dw_b", "dgamma_a", "dbeta_b", "running_mean_a", "running_var_b")
     for a, b, nm in zip(results[0], results[1], names):
         assert_close(a, b, 2e-5, "paired BatchNorm: " + nm)
+
+
+def test_avg_pool_activation_modules_and_nll(hip_device):
+    """SURVEY §8(f) row 3 on the hip device (26 hand-written primitives, no fused kernels): AvgPool2d incl. the
+    zero-padding divisor and the last-writer-wins backward, LeakyReLU / Tanh / Softmax / LogSoftmax, nll_loss."""
+    pc.check_avg_pool(hip_device)
+    pc.check_activation_modules(hip_device)
+    pc.check_nll_loss(hip_device)
+
+
+def test_frozen_parameter_step(hip_device):
+    """test/ResNet18_parameter_freezing_test.py:100-216 ('partial'): one Adam step with the stem and layer1-2 frozen."""
+    pc.check_frozen_parameter_step(hip_device)

@@ -87,3 +87,15 @@ def test_ref_ops_match_goldens():
 def test_vgg16_and_mobilenet_one_step(cpu_oracle, tag):
     """the VGG16 / MobileNetV1 models of test/VGG.py and test/MobileNet.py."""
     pc.check_model_step(cpu_oracle, tag)
+
+
+def test_avg_pool_activation_modules_and_nll(cpu_oracle):
+    """SURVEY §8(f) row 3 on the oracle device: AvgPool2d, LeakyReLU / Tanh / Softmax / LogSoftmax, nll_loss against
+    outputs of the reference's own code."""
+    pc.check_avg_pool(cpu_oracle)
+    pc.check_activation_modules(cpu_oracle)
+    pc.check_nll_loss(cpu_oracle)
+
+
+def test_frozen_parameter_step(cpu_oracle):
+    pc.check_frozen_parameter_step(cpu_oracle)
