@@ -16,6 +16,8 @@ class NumpyDevice:
     fused = False
     lazy_grad = False
     O1_PREFIX_SETITEM = False
+    DT = np.float32          # element type of every array (the reference: float32 only)
+    ITEM = 4
 
     def __init__(self):
         self.calls = {}          # primitive-call histogram
@@ -28,17 +30,17 @@ class NumpyDevice:
     # backend_tensor.py:67-68
     def Array(self, size):
         self._tick("Array")
-        return np.zeros(int(size), dtype=np.float32)
+        return np.zeros(int(size), dtype=self.DT)
 
     # :70-71
     def fill(self, handle, value):
         self._tick("fill")
-        handle[...] = np.float32(value)
+        handle[...] = self.DT(value)
 
     # :73-74
     def from_numpy(self, np_array, handle):
         self._tick("from_numpy")
-        handle[:] = np.asarray(np_array).reshape(-1).astype(np.float32)
+        handle[:] = np.asarray(np_array).reshape(-1).astype(self.DT)
 
     def _view(self, handle, shape, strides, offset, writeable=False):
         shape = tuple(int(s) for s in shape)
@@ -49,12 +51,12 @@ class NumpyDevice:
         lo = offset + sum((n - 1) * st for n, st in zip(shape, strides) if st < 0)
         hi = offset + sum((n - 1) * st for n, st in zip(shape, strides) if st > 0)
         if any(n == 0 for n in shape):
-            return np.zeros(shape, dtype=np.float32)
+            return np.zeros(shape, dtype=self.DT)
         if lo < 0 or hi >= handle.size:
             raise IndexError("view exceeds the array")
         if all(st >= 0 for st in strides):
             return np.lib.stride_tricks.as_strided(handle[offset:], shape=shape,
-                                                   strides=tuple(4 * s for s in strides),
+                                                   strides=tuple(self.ITEM * s for s in strides),
                                                    writeable=writeable)
         idx = np.indices(shape, dtype=np.int64)
         lin = offset + sum(idx[d] * strides[d] for d in range(len(shape)))
@@ -66,7 +68,7 @@ class NumpyDevice:
         v = self._view(handle, shape, strides, offset)
         if v.dtype == np.int64 and v.shape == tuple(int(s) for s in shape) and not np.issubdtype(v.dtype, np.floating):
             return handle[v].copy()
-        return np.array(v, dtype=np.float32, copy=True)
+        return np.array(v, dtype=self.DT, copy=True)
 
     # ndarray_backend_cuda.cu:178-198 (scatter); backend_tensor.py:92-95 when O1_PREFIX_SETITEM
     def ewise_setitem(self, other_handle, view_handle, shape, strides, offset):
@@ -87,14 +89,14 @@ class NumpyDevice:
         self._tick("scalar_setitem")
         if self.O1_PREFIX_SETITEM:
             view = self.to_numpy(view_handle, shape, strides, offset)
-            view[...] = np.float32(scalar)
+            view[...] = self.DT(scalar)
             view_handle[:view.size] = view.reshape(-1)
             return
         v = self._view(view_handle, shape, strides, offset, writeable=True)
         if np.issubdtype(v.dtype, np.floating):
-            v[...] = np.float32(scalar)
+            v[...] = self.DT(scalar)
         else:
-            view_handle[v.reshape(-1)] = np.float32(scalar)
+            view_handle[v.reshape(-1)] = self.DT(scalar)
 
     # :102-104
     def compact(self, src_handle, dst_handle, shape, strides, offset):
@@ -103,9 +105,9 @@ class NumpyDevice:
 
     # :106-143
     def ewise_add(self, a, b, out): self._tick("ewise_add"); out[:] = a + b
-    def scalar_add(self, a, s, out): self._tick("scalar_add"); out[:] = a + np.float32(s)
+    def scalar_add(self, a, s, out): self._tick("scalar_add"); out[:] = a + self.DT(s)
     def ewise_mul(self, a, b, out): self._tick("ewise_mul"); out[:] = a * b
-    def scalar_mul(self, a, s, out): self._tick("scalar_mul"); out[:] = a * np.float32(s)
+    def scalar_mul(self, a, s, out): self._tick("scalar_mul"); out[:] = a * self.DT(s)
 
     def ewise_div(self, a, b, out):
         self._tick("ewise_div")
@@ -115,19 +117,19 @@ class NumpyDevice:
     def scalar_div(self, a, s, out):
         self._tick("scalar_div")
         with np.errstate(divide="ignore", invalid="ignore"):
-            out[:] = a / np.float32(s)
+            out[:] = a / self.DT(s)
 
     def scalar_power(self, a, s, out):
         self._tick("scalar_power")
         with np.errstate(divide="ignore", invalid="ignore"):
-            out[:] = a ** np.float32(s)
+            out[:] = a ** self.DT(s)
 
     def ewise_maximum(self, a, b, out): self._tick("ewise_maximum"); out[:] = np.maximum(a, b)
-    def scalar_maximum(self, a, s, out): self._tick("scalar_maximum"); out[:] = np.maximum(a, np.float32(s))
-    def ewise_eq(self, a, b, out): self._tick("ewise_eq"); out[:] = (a == b).astype(np.float32)
-    def scalar_eq(self, a, s, out): self._tick("scalar_eq"); out[:] = (a == np.float32(s)).astype(np.float32)
-    def ewise_ge(self, a, b, out): self._tick("ewise_ge"); out[:] = (a >= b).astype(np.float32)
-    def scalar_ge(self, a, s, out): self._tick("scalar_ge"); out[:] = (a >= np.float32(s)).astype(np.float32)
+    def scalar_maximum(self, a, s, out): self._tick("scalar_maximum"); out[:] = np.maximum(a, self.DT(s))
+    def ewise_eq(self, a, b, out): self._tick("ewise_eq"); out[:] = (a == b).astype(self.DT)
+    def scalar_eq(self, a, s, out): self._tick("scalar_eq"); out[:] = (a == self.DT(s)).astype(self.DT)
+    def ewise_ge(self, a, b, out): self._tick("ewise_ge"); out[:] = (a >= b).astype(self.DT)
+    def scalar_ge(self, a, s, out): self._tick("scalar_ge"); out[:] = (a >= self.DT(s)).astype(self.DT)
 
     # :145-152
     def ewise_log(self, a, out):
@@ -152,10 +154,19 @@ class NumpyDevice:
         self._tick("reduce_sum")
         last = int(last_dim)
         outer = int(view_handle.size // last)
-        out_handle[:outer] = view_handle.reshape(outer, last).sum(axis=1).astype(np.float32)
+        out_handle[:outer] = view_handle.reshape(outer, last).sum(axis=1).astype(self.DT)
 
     def reduce_max(self, view_handle, out_handle, last_dim):
         self._tick("reduce_max")
         last = int(last_dim)
         outer = int(view_handle.size // last)
-        out_handle[:outer] = view_handle.reshape(outer, last).max(axis=1).astype(np.float32)
+        out_handle[:outer] = view_handle.reshape(outer, last).max(axis=1).astype(self.DT)
+
+
+class NumpyDevice64(NumpyDevice):
+    """The same device in float64: the reference's algorithm evaluated to double precision, the yardstick the
+    tolerance tests use to measure how far an fp32 evaluation (the reference's own, the oracle's, the hip
+    device's) sits from the exact result of the same arithmetic (tests/test_error_budget.py)."""
+    name = "cpu64"
+    DT = np.float64
+    ITEM = 8

@@ -1,0 +1,100 @@
+"""Measured error budgets for the end-to-end parity checks.
+
+The fp32 contract is 1e-4 relative (max|a-b| / max|b|).  At the end of a 20-convolution chain two CORRECT fp32
+evaluations of the same algorithm that only differ in summation order sit further apart than that, so a flat
+tolerance there is either too loose or fails on the reference itself.  These helpers run the reference's algorithm
+in float64 (oracle.numpy_device.NumpyDevice64: same front end, same primitive path, same overwrite semantics) and
+express every comparison as distances from that exact result:
+
+    err32  = |fp32 oracle (the reference's own arithmetic) - fp64|     what float32 itself costs
+    err    = |device under test - fp64|
+
+and the assertion is  err <= max(1e-4, 2 * err32)  per quantity -- never a flat number above 1e-4."""
+import numpy as np
+
+from conftest import load_golden, rel_err
+
+
+def resnet18_step(dev, mode="all", dgrad_mode=None):
+    """One Adam step of ResNet-18 (CIFAR variant) at batch 2 on the g8 golden inputs; returns the quantities the
+    parity tests look at, as float64 arrays."""
+    from deepflows_amd import nn, optim, workloads
+    from deepflows_amd.tensor import Graph, Tensor
+    g = load_golden("g8_end_to_end.npz")
+    np.random.seed(0)
+    model = workloads.ResNet18(10, device=dev, register_blocks=(mode == "all"))
+    model.train()
+    params_all = workloads.all_block_parameters(model)
+    opt = optim.Adam(list(model.parameters()), lr=1e-3, weight_decay=5e-4)
+    out = model(Tensor(g["r18_x"], device=dev))
+    loss = nn.CrossEntropyLoss()(out, Tensor(g["r18_y"], device=dev))
+    opt.zero_grad()
+    loss.backward()
+    res = {"loss": loss.numpy(), "logits": out.numpy(), "fc_wgrad": model.fc.weight.grad.numpy(),
+           "conv1_wgrad": model.conv1.weight.grad.numpy(),
+           "grad_abs_sum": np.array([float(np.abs(p.grad.numpy().astype(np.float64)).sum()) for p in params_all])}
+    opt.step()
+    res["param_abs_sum_after"] = np.array([float(np.abs(p.data.numpy().astype(np.float64)).sum()) for p in params_all])
+    res["conv1_w_after"] = model.conv1.weight.data.numpy()
+    Graph.free_graph_all()
+    return {k: np.asarray(v, dtype=np.float64) for k, v in res.items()}
+
+
+def cnn_steps(dev):
+    """Two Adam steps of the CNN workload on the g8 golden inputs (Dropout masks from the seeded global generator)."""
+    from deepflows_amd import nn, optim, workloads
+    from deepflows_amd.tensor import Graph, Tensor
+    g = load_golden("g8_end_to_end.npz")
+    np.random.seed(0)
+    model = workloads.CIFAR10_CNN(10, device=dev)
+    model.train()
+    opt = optim.Adam(model.parameters(), lr=0.005, weight_decay=5e-4)
+    crit = nn.CrossEntropyLoss()
+    res, losses = {}, []
+    for step in range(2):
+        out = model(Tensor(g["cnn_x"], device=dev))
+        loss = crit(out, Tensor(g["cnn_y"], device=dev))
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            res["logits0"] = out.numpy()
+            res["gnorms0"] = np.array([np.linalg.norm(p.grad.numpy().astype(np.float64)) for p in model.parameters()])
+            res["conv1_wgrad0"] = model.conv1.weight.grad.numpy()
+        opt.step()
+        losses.append(float(loss.numpy().reshape(-1)[0]))
+        Graph.free_graph()
+    res["losses"] = np.array(losses)
+    Graph.free_graph_all()
+    return {k: np.asarray(v, dtype=np.float64) for k, v in res.items()}
+
+
+def with_device(cls, fn):
+    """Run fn(device) on a freshly registered oracle device of class `cls` (NumpyDevice / NumpyDevice64)."""
+    from deepflows_amd import backend_api
+    from deepflows_amd.tensor import Graph
+    name = "cpu_budget"
+    dev = backend_api.register_device(name, cls())
+    try:
+        return fn(dev)
+    finally:
+        Graph.free_graph_all()
+        backend_api.unregister_device(name)
+
+
+def budget_table(got, exact, fp32):
+    """[(name, err(got, exact), err(fp32, exact), allowed)] with allowed = max(1e-4, 2 * err32)."""
+    rows = []
+    for k in exact:
+        e32 = rel_err(fp32[k], exact[k])
+        rows.append((k, rel_err(got[k], exact[k]), e32, max(1e-4, 2.0 * e32)))
+    return rows
+
+
+def assert_within_budget(got, exact, fp32, what):
+    rows = budget_table(got, exact, fp32)
+    print(f"\n{what}: distance from the float64 evaluation of the reference's algorithm")
+    print(f"  {'quantity':24s} {'under test':>12s} {'fp32 oracle':>12s} {'allowed':>12s}")
+    for k, e, e32, lim in rows:
+        print(f"  {k:24s} {e:12.3e} {e32:12.3e} {lim:12.3e}")
+    bad = [(k, e, lim) for k, e, _, lim in rows if e > lim]
+    assert not bad, f"{what}: outside max(1e-4, 2 x the fp32 oracle's own error): {bad}"

@@ -156,13 +156,13 @@ def test_deferred_slab_sum_is_invisible(hip_device):
         mod.conv2d_wgrad(xa, da, dw, *geo)
     for (xa, da, dw, geo), w in reversed(list(zip(arrs, want))):
         got = _back(mod, dw).reshape(w.shape)
-        assert np.abs(got - w).max() <= 2e-4 * np.abs(w).max()
+        assert np.abs(got - w).max() <= 1e-4 * np.abs(w).max()
     # a consumer on the device right after the launch (ewise on dW), and free + reuse of dW
     xa, da, dw, geo = arrs[0]
     mod.conv2d_wgrad(xa, da, dw, *geo)
     out = mod.Array(dw.size)
     mod.scalar_mul(dw, 2.0, out)
-    assert np.abs(_back(mod, out).reshape(want[0].shape) - 2 * want[0]).max() <= 4e-4 * np.abs(want[0]).max()
+    assert np.abs(_back(mod, out).reshape(want[0].shape) - 2 * want[0]).max() <= 2e-4 * np.abs(want[0]).max()       # (1e-4 of the doubled tensor)
     mod.conv2d_wgrad(xa, da, dw, *geo)
     del dw
     z = mod.Array(want[0].size)
