@@ -1,24 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py — training-step images/sec of the reference's ResNet-18 CIFAR-10 workload
-(test/ResNet_CIFAR10_cuda.py: bs 256, fp32, Adam lr 1e-3 wd 5e-4, label-smoothed one-hot
-targets) on the `hip` device, 1..8 MI355X (one process per GPU, weak scaling, gradients
-all-reduced over RCCL).
+"""bench.py — training-step images/sec of the reference's workloads on the `hip` device, 1..8 MI355X (one
+process per GPU, weak scaling, gradients all-reduced over RCCL).  Default = the BASELINE headline: ResNet-18
+CIFAR-10 (test/ResNet_CIFAR10_cuda.py: bs 256, fp32, Adam lr 1e-3 wd 5e-4, label-smoothed one-hot targets).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload resnet18|cnn|mlp] [--dgrad overwrite|accumulate]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        (the launcher only spawns the ranks and sets RANK / WORLD_SIZE / MASTER_*: nothing here imports torch)
 
-A "step" = forward + loss + zero_grad + backward + (bucket all-reduce) + Adam step on one
-batch of 256 synthetic images per GPU that is already resident in HBM.  Rank 0 prints ONE
-JSON line (contract in the task statement) including
-  roofline      live HIP-event timing of the dominant kernel family (events on the library
-                stream around every launch of each family, in a second pass over the same K
-                steps so the event records do not perturb the headline timing);
-  cpu_baseline  the NumPy oracle (reference algorithm, primitive path) timed on this host on a
-                bounded sample of the same workload (N=1, rank 0 only).
+A "step" = forward + loss + zero_grad + backward + (bucket all-reduce) + optimizer step on one batch of synthetic
+inputs per GPU that is already resident in HBM.  Rank 0 prints ONE JSON line (contract in the task statement) with
+  roofline      live HIP-event timing of the dominant kernel family (events on the library stream around every
+                launch of each family, in a second pass over the same K steps so the event records do not perturb
+                the headline timing); `kernels` carries the same per family, each against its own roofline;
+  cpu_baseline  the NumPy oracle (reference algorithm, primitive path) timed on this host on a bounded sample of
+                the same workload (N=1, rank 0 only).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,62 +29,171 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BATCH = 256
 PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak
 
+# families whose roofline is HBM bandwidth although they run MFMAs: the reference-exact ("overwrite") input
+# gradient keeps one tap per input pixel -- 1/k^2 of the GEMM -- and is bound by reading dY and writing dX
+HBM_BOUND_FAMILIES = {"conv2d_dgrad_overwrite_igemm"}
 
-def make_batch(rank, batch=BATCH):
-    """SURVEY §8d synthetic inputs: default_rng(1234+rank); images N(0,1) clipped to [-1,1];
-    labels uniform -> one-hot with eps = 0.05 smoothing."""
+WORKLOADS = {
+    "resnet18": {"batch": 256, "metric": "training-step images/sec, ResNet-18 CIFAR-10 bs=256",
+                 "text": "ResNet-18 (CIFAR variant 32/64/128/256, test/ResNet_CIFAR10_cuda.py) train step: "
+                         "fwd + CE + bwd + Adam, bs 256 per GPU, fp32"},
+    "cnn": {"batch": 256, "metric": "training-step images/sec, CNN-CIFAR10 bs=256",
+            "text": "CNN-CIFAR10 (3 x Conv2d k5 + BN + pool, Dropout, test/CNN_CIFAR10_cuda.py:61-113) train step: "
+                    "fwd + CE + bwd + Adam lr 5e-3 wd 5e-4, bs 256 per GPU, fp32"},
+    "mlp": {"batch": 128, "metric": "training-step samples/sec, MLP-MNIST 784-256-10 bs=128",
+            "text": "MLP 784->256->10 (test/MLP_MNIST_cuda.py:37-59) train step: fwd + CE + bwd + SGD lr .05, "
+                    "bs 128 per GPU, fp32"},
+}
+
+
+def make_batch(workload, rank, batch):
+    """SURVEY §8d synthetic inputs: default_rng(1234+rank); images N(0,1) clipped to [-1,1] (MLP: uniform [0,1));
+    labels uniform -> one-hot (ResNet-18: eps = 0.05 smoothing)."""
     rng = np.random.default_rng(1234 + rank)
-    x = np.clip(rng.standard_normal((batch, 3, 32, 32)).astype(np.float32), -1.0, 1.0)
-    labels = rng.integers(0, 10, batch)
-    y = np.eye(10, dtype=np.float32)[labels] * 0.95 + 0.05 / 10
+    if workload == "mlp":
+        x = rng.random((batch, 784), dtype=np.float32)
+    else:
+        x = np.clip(rng.standard_normal((batch, 3, 32, 32)).astype(np.float32), -1.0, 1.0)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, batch)]
+    if workload == "resnet18":
+        y = y * 0.95 + 0.05 / 10
     return x, y.astype(np.float32)
 
 
-def build_job(dev, rank, batch=BATCH, register_blocks=True):
+def build_job(workload, dev, rank, batch, register_blocks=True):
     from deepflows_amd import nn, optim, workloads
     from deepflows_amd.tensor import Tensor
     np.random.seed(0)                      # identical replicas on every rank
-    model = workloads.ResNet18(10, device=dev, register_blocks=register_blocks)
+    if workload == "resnet18":
+        model = workloads.ResNet18(10, device=dev, register_blocks=register_blocks)
+        opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    elif workload == "cnn":
+        model = workloads.CIFAR10_CNN(10, device=dev)
+        opt = optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4)
+    else:
+        model = workloads.MLP((784, 256, 10), device=dev)
+        opt = optim.SGD(model.parameters(), lr=0.05)
     model.train()
-    opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
     crit = nn.CrossEntropyLoss()
-    x, y = make_batch(rank, batch)
+    x, y = make_batch(workload, rank, batch)
     return model, opt, crit, Tensor(x, device=dev), Tensor(y, device=dev)
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle on this host: NumPy device + the front-end's primitive path = the
-    reference's algorithm (im2col by k*k strided copies + np.matmul, unfused BN / CE / Adam).
-    Bounded sample: ResNet-18 CIFAR step at batch 32 (1/8 of the GPU batch)."""
+def host_cores():
+    """(physical cores of one socket, logical CPUs) from lscpu; falls back to os.cpu_count()."""
+    logical = os.cpu_count() or 1
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        vals = {}
+        for line in out.splitlines():
+            k, _, v = line.partition(":")
+            vals[k.strip()] = v.strip()
+        per_socket = int(vals.get("Core(s) per socket", "0"))
+        if per_socket > 0:
+            return per_socket, logical
+    except Exception:
+        pass
+    return logical, logical
+
+
+def _oracle_steps(workload, batch, threads, max_steps, seconds_budget):
+    """(seconds per step, timed steps) of the oracle on `threads` BLAS/OpenMP threads."""
+    from threadpoolctl import threadpool_limits
     from deepflows_amd import backend_api, workloads
     from deepflows_amd.tensor import Graph
     from oracle.numpy_device import NumpyDevice
     dev = backend_api.register_device("cpu", NumpyDevice())
     try:
-        sample_batch = 32
-        model, opt, crit, xt, yt = build_job(dev, 0, sample_batch)
-        t_first = time.perf_counter()
-        workloads.train_step(model, crit, opt, xt, yt)
-        Graph.free_graph()
-        first = time.perf_counter() - t_first
-        n = int(max(1, min(12, (seconds_budget - first) // max(first, 1e-3))))
-        t0 = time.perf_counter()
-        for _ in range(n):
+        with threadpool_limits(limits=threads):
+            model, opt, crit, xt, yt = build_job(workload, dev, 0, batch)
+            t_first = time.perf_counter()
             workloads.train_step(model, crit, opt, xt, yt)
             Graph.free_graph()
-        dt = (time.perf_counter() - t0) / n
-        Graph.free_graph_all()
+            first = time.perf_counter() - t_first
+            n = int(max(1, min(max_steps, (seconds_budget - first) // max(first, 1e-3))))
+            t0 = time.perf_counter()
+            for _ in range(n):
+                workloads.train_step(model, crit, opt, xt, yt)
+                Graph.free_graph()
+            dt = (time.perf_counter() - t0) / n
+            Graph.free_graph_all()
     finally:
         backend_api.unregister_device("cpu")
-    threads = int(os.environ.get("OPENBLAS_NUM_THREADS") or os.environ.get("OMP_NUM_THREADS") or
-                  (os.cpu_count() or 1))
-    return {"value": sample_batch / dt, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"ResNet-18 CIFAR-10 train step at batch {sample_batch} (1/8 of the GPU batch), "
-                      f"{n} timed step(s) after 1 warm-up, {dt:.2f} s/step, NumPy {np.__version__}"}
+    return dt, n
+
+
+def cpu_baseline(workload, batch):
+    """The oracle on this host: NumPy device + the front end's primitive path = the reference's algorithm (im2col by
+    k*k strided copies + np.matmul, unfused BN / CE / optimizer).  Bounded sample of the SAME workload: the full
+    batch, 1 warm-up + 1-2 timed steps on the physical cores of one socket, plus the 8-thread figure
+    SURVEY §6 quotes for comparison (on 1/8 of the batch for the conv workloads so that the run stays bounded)."""
+    cores, logical = host_cores()
+    dt, n = _oracle_steps(workload, batch, cores, 2 if workload != "mlp" else 50, 22.0 if workload != "mlp" else 3.0)
+    small = batch if workload == "mlp" else batch // 8
+    dt8, n8 = _oracle_steps(workload, small, 8, 3 if workload != "mlp" else 50, 8.0 if workload != "mlp" else 3.0)
+    return {"value": batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{WORKLOADS[workload]['text'].split(' train step')[0]} train step at batch {batch} (the GPU "
+                      f"batch), {n} timed step(s) after 1 warm-up, {dt:.2f} s/step, {cores} threads = physical cores "
+                      f"of one socket ({logical} logical CPUs), NumPy {np.__version__}",
+            "threads8": {"value": small / dt8, "unit": "images/s", "cores": 8,
+                         "sample": f"batch {small}, {n8} timed step(s), {dt8:.2f} s/step"}}
+
+
+def csrc_fingerprint():
+    """sha256 over the kernel sources: a PMC traffic file is only quoted for the build it was measured on."""
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "deepflows_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "deepflows_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(family, calls_per_step, workload, dgrad):
+    """HBM bytes per launch of `family` from the newest committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    on this same command, FETCH_SIZE x2 per the gfx950 note) -- only if it was taken on THIS build of the kernels
+    and this workload; counters cannot be read from inside the process."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, "no PMC pass on file"
+    path = files[-1]
+    try:
+        pmc = json.load(open(path))
+    except Exception as e:
+        return None, f"{os.path.basename(path)} unreadable: {e}"
+    rel = os.path.relpath(path, ROOT)
+    if pmc.get("csrc_sha16") != csrc_fingerprint():
+        return None, f"{rel} was measured on kernel sources {pmc.get('csrc_sha16')} (git {pmc.get('git', '?')}), " \
+                     f"this build is {csrc_fingerprint()}: stale, not quoted"
+    if pmc.get("workload", "resnet18") != workload or pmc.get("dgrad", "overwrite") != dgrad:
+        return None, f"{rel} is a pass of another workload / mode"
+    fam = pmc.get("families", {}).get(family)
+    if not fam:
+        return None, f"{rel} has no entry for {family}"
+    return fam["hbm_bytes_per_step"] / calls_per_step, f"{rel} (git {pmc.get('git', '?')}, kernel sources {pmc['csrc_sha16']})"
+
+
+def family_rooflines(prof, steps):
+    fams = {}
+    for name, r in prof.items():
+        if r["calls"] == 0 or r["ms"] <= 0:
+            continue
+        avg_s = r["ms"] / r["calls"] * 1e-3
+        ent = {"calls_per_step": r["calls"] / steps, "avg_us": avg_s * 1e6, "ms_per_step": r["ms"] / steps,
+               "gbs": r["bytes"] / r["calls"] / avg_s / 1e9}
+        if r["flops"] > 0:
+            ent["tflops"] = r["flops"] / r["calls"] / avg_s / 1e12
+        if r["flops"] > 0 and name not in HBM_BOUND_FAMILIES:
+            ent["bound"], ent["frac"] = "mfma", ent["tflops"] / PEAK_MFMA_F32_TFLOPS
+        else:
+            ent["bound"], ent["frac"] = "hbm", ent["gbs"] / PEAK_HBM_GBS
+            if "tflops" in ent:                 # executed flops of an HBM-bound MFMA family, for the record
+                ent["executed_tflops"] = ent.pop("tflops")
+        fams[name] = ent
+    return fams
 
 
 def main():
@@ -90,6 +201,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="resnet18",
+                    help="resnet18 = the BASELINE headline (default); cnn / mlp = BASELINE.json configs 2-3")
     ap.add_argument("--dgrad", choices=["overwrite", "accumulate"], default="overwrite",
                     help="conv input-gradient mode: reference-exact (default) or mathematically correct")
     ap.add_argument("--registration", choices=["all", "f6"], default="all",
@@ -107,15 +220,16 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
 
-    import deepflows_amd as df
     from deepflows_amd import backend_api, parallel, workloads
     from deepflows_amd.tensor import Graph
 
+    wl = WORKLOADS[args.workload]
+    batch = wl["batch"]
     dev = backend_api.Device("hip")            # raises when the extension / GPU is missing
     mod = dev.mod
     mod.conv_dgrad_mode = args.dgrad
     comm = parallel.init_communicator(dev)
-    model, opt, crit, xt, yt = build_job(dev, rank, BATCH, register_blocks=(args.registration == "all"))
+    model, opt, crit, xt, yt = build_job(args.workload, dev, rank, batch, register_blocks=(args.registration == "all"))
     bucket = parallel.GradientBucket(opt.params, comm)
     opt.grad_scale = 1.0 / comm.world
     # DF_FORCE_SYNC=1 (with DF_FORCE_COMM=1): exercise the exchange path of a multi-GPU run on one GPU
@@ -131,10 +245,10 @@ def main():
     mod.synchronize()
 
     # the timed steps replay one captured step (hipGraph) unless --no-graph; same kernels, same
-    # order, one host call per step instead of ~170
+    # order, one host call per step instead of ~100
     captured = None
     overlapped = False
-    if not args.no_graph and sync is not None and args.overlap:
+    if not args.no_graph and sync is not None and args.overlap and args.workload == "resnet18":
         # data parallel: two graphs split where layer4's gradients are complete, the all-reduce of
         # that bucket runs on the communication stream beside the rest of the backward pass
         try:
@@ -196,63 +310,42 @@ def main():
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
-        value = BATCH * comm.world * args.steps / wall
-        fams = {}
-        for name, r in prof.items():
-            if r["calls"] == 0 or r["ms"] <= 0:
-                continue
-            avg_ms = r["ms"] / r["calls"]
-            ent = {"calls_per_step": r["calls"] / args.steps, "avg_us": avg_ms * 1e3,
-                   "ms_per_step": r["ms"] / args.steps}
-            if r["flops"] > 0:
-                ent["tflops"] = r["flops"] / r["calls"] / (avg_ms * 1e-3) / 1e12
-            ent["gbs"] = r["bytes"] / r["calls"] / (avg_ms * 1e-3) / 1e9
-            fams[name] = ent
+        value = batch * comm.world * args.steps / wall
+        fams = family_rooflines(prof, args.steps)
         dom = max(fams, key=lambda k: fams[k]["ms_per_step"]) if fams else None
         roofline = None
         if dom:
             d = fams[dom]
-            if "tflops" in d:
+            if d["bound"] == "mfma":
                 roofline = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": PEAK_MFMA_F32_TFLOPS,
-                            "unit": "TFLOP/s", "frac": d["tflops"] / PEAK_MFMA_F32_TFLOPS, "traffic": None}
+                            "unit": "TFLOP/s", "frac": d["frac"], "traffic": None}
             else:
                 roofline = {"kernel": dom, "bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS,
-                            "unit": "GB/s", "frac": d["gbs"] / PEAK_HBM_GBS, "traffic": None}
+                            "unit": "GB/s", "frac": d["frac"], "traffic": None}
             roofline["avg_launch_us"] = d["avg_us"]
             roofline["launches_per_step"] = d["calls_per_step"]
-            # HBM bytes per launch of that family from the committed PMC passes (rocprofv3 --pmc
-            # FETCH_SIZE / WRITE_SIZE on this same command, FETCH_SIZE x2 per the gfx950 note);
-            # counters cannot be read from inside this process, so the number is the one on file
-            try:
-                import json as _json
-                pmc = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                                   "r01p_pmc_traffic.json")))
-                fam = pmc["families"].get(dom)
-                if fam:
-                    roofline["traffic"] = fam["hbm_bytes_per_step"] / d["calls_per_step"]
-                    roofline["traffic_source"] = "profiles/r01p_pmc_traffic.json"
-            except Exception:
-                pass
+            roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom, d["calls_per_step"], args.workload, args.dgrad)
             roofline["algorithmic_bytes_per_launch"] = prof[dom]["bytes"] / prof[dom]["calls"]
             roofline["algorithmic_flops_per_launch"] = prof[dom]["flops"] / prof[dom]["calls"]
+        exchanged = bucket.total if sync is not None else 0
         out = {
-            "metric": "training-step images/sec, ResNet-18 CIFAR-10 bs=256",
+            "metric": wl["metric"],
             "value": value, "unit": "images/s", "n_gpus": comm.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ResNet-18 (CIFAR variant 32/64/128/256, test/ResNet_CIFAR10_cuda.py) "
-                                   "train step: fwd + CE + bwd + Adam, bs 256 per GPU, fp32",
-                       "global_batch": BATCH * comm.world, "parallelism": f"dp{comm.world}",
+            "config": {"workload": wl["text"],
+                       "global_batch": batch * comm.world, "parallelism": f"dp{comm.world}",
                        "conv_dgrad": args.dgrad, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,
-                       "allreduce_elems": bucket.total if comm.world > 1 else 0},
+                       "allreduce_elems": exchanged,
+                       "collective_library": mod.comm_rccl_path() if sync is not None else None},
             "gpu_ms_per_step": gpu_ms / args.steps, "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
             "final_loss": final_loss,
             "roofline": roofline,
-            "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in
+            "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in
                         sorted(fams.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         }
         if comm.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.workload, batch)
         else:
             out["cpu_baseline"] = None
         line = json.dumps(out)

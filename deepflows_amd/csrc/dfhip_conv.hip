@@ -3706,7 +3706,10 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
   if (s != DFHIP_OK) return s;
   DF_CHECK_ARG(dy && w && dx, "conv2d_dgrad: null array");
   DF_CHECK_ARG(mode == 0 || mode == 1, "conv2d_dgrad: mode must be 0 (overwrite) or 1 (accumulate)");
-  double flops = 2.0 * N * oh * ow * (double)C * k * k * O;
+  // accumulate mode: the implicit GEMM's 2 M K P.  overwrite mode: what the reference's k*k assignments leave is ONE
+  // tap per input pixel (functional.py:285-294), i.e. 2 N H W C O executed flops -- 1/k^2 of the GEMM the reference
+  // computes and then mostly discards; the family is bound by its bytes, not by the matrix cores.
+  double flops = mode == 0 ? 2.0 * N * H * W * (double)C * O : 2.0 * N * oh * ow * (double)C * k * k * O;
   double bytes = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * k * k + (double)N * O * oh * ow);
   ProfScope prof(mode == 0 ? "conv2d_dgrad_overwrite_igemm" : "conv2d_dgrad_igemm", flops, bytes);
   Geo g = {};

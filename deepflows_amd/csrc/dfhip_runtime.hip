@@ -638,8 +638,11 @@ static int g_world = 1;
 
 static int load_rccl() {
   if (g_rccl) return DFHIP_OK;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
-                         "/opt/rocm/lib/librccl.so"};
+  // ROCm's own RCCL first (by path), whatever the process has mapped under the soname only after that: a launcher
+  // that imported a framework with a bundled librccl must not decide which collective library the step uses.
+  // DFHIP_RCCL_PATH overrides.
+  const char* names[] = {getenv("DFHIP_RCCL_PATH") ? getenv("DFHIP_RCCL_PATH") : "/opt/rocm/lib/librccl.so.1",
+                         "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
   for (const char* n : names) {
     g_rccl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (g_rccl) break;
@@ -731,6 +734,30 @@ int dfhip_comm_wait(void) {
     DF_HIP(hipStreamWaitEvent(g_stream, g_comm_done, 0));
     g_comm_pending = false;
   }
+  return DFHIP_OK;
+}
+
+// max over ranks of one host float (step time of the slowest rank) / barrier: a one-element all-reduce on the
+// library stream followed by a stream synchronisation -- no host-side process group anywhere
+int dfhip_comm_allreduce_max(float* value) {
+  DF_INIT();
+  DF_CHECK_ARG(g_comm && value, "comm_allreduce_max: no communicator / null value");
+  static float* d = nullptr;
+  if (!d) DF_HIP(hipMalloc((void**)&d, sizeof(float)));
+  DF_HIP(hipMemcpyAsync(d, value, sizeof(float), hipMemcpyHostToDevice, g_stream));
+  // ncclFloat32 = 7, ncclMax = 2
+  DF_NCCL(p_ncclAllReduce(d, d, 1, 7, 2, g_comm, g_stream));
+  DF_HIP(hipMemcpyAsync(value, d, sizeof(float), hipMemcpyDeviceToHost, g_stream));
+  DF_HIP(hipStreamSynchronize(g_stream));
+  return DFHIP_OK;
+}
+
+int dfhip_comm_rccl_path(char* out, int cap) {
+  // which shared object the collective symbols came from (diagnostic: bench.py reports it)
+  if (!out || cap <= 0) return DFHIP_INVALID_ARGUMENT;
+  out[0] = 0;
+  Dl_info info;
+  if (p_ncclAllReduce && dladdr((void*)p_ncclAllReduce, &info) && info.dli_fname) snprintf(out, (size_t)cap, "%s", info.dli_fname);
   return DFHIP_OK;
 }
 

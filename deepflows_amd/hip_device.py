@@ -414,6 +414,16 @@ class HipModule:
     def comm_wait(self):
         _lib.check(self._lib.dfhip_comm_wait())
 
+    def comm_allreduce_max(self, value):
+        v = c_float(float(value))
+        _lib.check(self._lib.dfhip_comm_allreduce_max(byref(v)))
+        return float(v.value)
+
+    def comm_rccl_path(self):
+        buf = ctypes.create_string_buffer(512)
+        _lib.check(self._lib.dfhip_comm_rccl_path(buf, 512))
+        return buf.value.decode()
+
     def comm_destroy(self):
         self._lib.dfhip_comm_destroy()
 

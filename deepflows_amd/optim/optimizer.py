@@ -8,6 +8,7 @@ class Optimizer:
     def __init__(self, params: List[Tensor]) -> None:
         self.params: List[Tensor] = list(params)
         self.grad_scale = 1.0     # data-parallel: 1/world, applied inside the fused step
+        self.t = 0                # steps taken (Adam's bias correction; counted for every optimizer)
 
     def step(self):
         raise NotImplementedError

@@ -16,18 +16,29 @@ class SGD(Optimizer):
         self.lr, self.momentum, self.weight_decay, self.nesterov = lr, momentum, weight_decay, nesterov
         self.v = [backend_api.zeros(p.shape, device=p.device) for p in self.params]
 
-    def step(self):
+    # graph_step.CapturedTrainStep: SGD has no per-step host state (no bias correction), so its scalars are
+    # constants of the captured launch -- a changed learning rate needs a new capture
+    device_hyper = False
+
+    def push_hyper(self):
+        pass
+
+    def apply(self):
+        """The in-place multi-tensor update (one launch for the whole parameter list)."""
         mod = self._fused_mod()
-        if mod is not None:
-            live = [i for i, p in enumerate(self.params) if p.grad is not None]
-            if len(live) != len(self.params):
-                raise TypeError("SGD.step: a parameter has no gradient")   # as the reference would
-            for i in live:
-                self.params[i].data = self.params[i].data.compact()
-            mod.sgd_step([self.params[i].data._handle for i in live],
-                         [self.params[i].grad.compact()._handle for i in live],
-                         [self.v[i]._handle for i in live] if self.momentum > 0.0 else None,
-                         self.lr, self.momentum, self.weight_decay, self.nesterov, self.grad_scale)
+        live = [i for i, p in enumerate(self.params) if p.grad is not None]
+        if len(live) != len(self.params):
+            raise TypeError("SGD.step: a parameter has no gradient")   # as the reference would
+        for i in live:
+            self.params[i].data = self.params[i].data.compact()
+        mod.sgd_step([self.params[i].data._handle for i in live],
+                     [self.params[i].grad.compact()._handle for i in live],
+                     [self.v[i]._handle for i in live] if self.momentum > 0.0 else None,
+                     self.lr, self.momentum, self.weight_decay, self.nesterov, self.grad_scale)
+
+    def step(self):
+        if self._fused_mod() is not None:
+            self.apply()
             return
         for i, p in enumerate(self.params):
             grad = p.grad if self.grad_scale == 1.0 else p.grad * self.grad_scale

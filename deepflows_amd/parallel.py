@@ -37,6 +37,7 @@ class _ArrayView:
 class Communicator:
     rank = 0
     world = 1
+    exchanges = False      # True: gradients go through a flat bucket and allreduce_sum even when world == 1
 
     def allreduce_sum(self, flat):          # flat: BackendTensor, 1-D compact
         raise NotImplementedError
@@ -59,50 +60,21 @@ class LocalCommunicator(Communicator):
         return flat
 
 
-class TorchHostCommunicator(Communicator):
-    """gloo on host memory — used by the world_size-2 CPU tests with the NumPy oracle device
-    (its handles are numpy arrays, which torch wraps without copying)."""
+class RcclCommunicator(Communicator):
+    """RCCL communicator owned by libdfhip (dfhip_comm_init / dfhip_allreduce_sum).  Rank 0 draws the 128-byte
+    ncclUniqueId and serves it over a TCP socket (rendezvous.py, standard library); barrier and max-over-ranks are
+    one-element collectives on the communicator itself.  No host-side process group, no torch."""
+    exchanges = True
 
-    def __init__(self):
-        import torch.distributed as dist
-        self._dist = dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-
-    def allreduce_sum(self, flat):
-        import torch
-        h = flat._handle
-        if isinstance(h, np.ndarray):
-            self._dist.all_reduce(torch.from_numpy(h))
-        else:                                   # a device array: stage through the host
-            a = flat.numpy()
-            t = torch.from_numpy(a)
-            self._dist.all_reduce(t)
-            flat.device.from_numpy(a, h)
-        return flat
-
-    def barrier(self):
-        self._dist.barrier()
-
-    def max_float(self, x):
-        import torch
-        t = torch.tensor([float(x)], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
-        return float(t.item())
-
-
-class RcclCommunicator(TorchHostCommunicator):
-    """RCCL communicator owned by libdfhip (dfhip_comm_init / dfhip_allreduce_sum).  The
-    128-byte ncclUniqueId is broadcast through the already-initialised torch.distributed
-    (gloo) group — rendezvous plumbing only; the data path never touches torch."""
-
-    def __init__(self, hip_mod):
-        super().__init__()
-        import torch
+    def __init__(self, hip_mod, rank, world):
+        from . import rendezvous
         self._mod = hip_mod
-        uid = hip_mod.comm_unique_id() if self.rank == 0 else bytes(128)
-        t = torch.tensor(list(uid), dtype=torch.uint8)
-        self._dist.broadcast(t, src=0)
-        hip_mod.comm_init(self.rank, self.world, bytes(t.tolist()))
+        self.rank, self.world = int(rank), int(world)
+        uid = hip_mod.comm_unique_id() if self.rank == 0 else b""
+        uid = rendezvous.broadcast_from_rank0(uid, self.rank, self.world)
+        if len(uid) != 128:
+            raise RuntimeError(f"rendezvous returned {len(uid)} bytes instead of the 128-byte ncclUniqueId")
+        hip_mod.comm_init(self.rank, self.world, uid)
 
     def allreduce_sum(self, flat, overlap=False):
         if overlap:
@@ -115,24 +87,29 @@ class RcclCommunicator(TorchHostCommunicator):
         """The library stream waits for every overlapped all-reduce issued so far."""
         self._mod.comm_wait()
 
+    def barrier(self):
+        self._mod.comm_allreduce_max(0.0)
+
+    def max_float(self, x):
+        return self._mod.comm_allreduce_max(x)
+
     def close(self):
         self._mod.comm_destroy()
 
 
 def init_communicator(device):
-    """Build the communicator for the launch environment (RANK / WORLD_SIZE / MASTER_* as set
-    by torch.distributed.run).  world == 1 needs no process group."""
+    """Build the communicator for the launch environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as a
+    launcher such as torch.distributed.run sets them; the launcher only spawns the processes).  world == 1 needs no
+    communicator.  Only the hip device has collectives: anything else raises (the CPU tests bring their own gloo
+    communicator, tests/gloo_communicator.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
     force = os.environ.get("DF_FORCE_COMM", "") == "1"       # tests: exercise the collective with one rank
     if world <= 1 and not force:
         return LocalCommunicator()
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", init_method="env://")
     if getattr(device.mod, "fused", False) and hasattr(device.mod, "comm_init"):
-        return RcclCommunicator(device.mod)
-    return TorchHostCommunicator()
+        return RcclCommunicator(device.mod, rank, max(1, world))
+    raise RuntimeError("init_communicator: the device has no RCCL entry points (multi-GPU runs need the hip device)")
 
 
 class GradientBucket:
@@ -144,7 +121,7 @@ class GradientBucket:
         self.sizes = [int(p.size) for p in self.params]
         self.total = sum(self.sizes)
         self.flat = None
-        if (comm.world > 1 or isinstance(comm, TorchHostCommunicator)) and self.params:
+        if (comm.world > 1 or comm.exchanges) and self.params:
             dev = self.params[0].device
             self.flat = BackendTensor.make((self.total,), device=dev)
             self.flat.fill(0.0)

@@ -307,6 +307,11 @@ int dfhip_allreduce_sum_async(float* buf, int64_t n);
 int dfhip_comm_wait(void);
 
 /* in place, library stream */
+/* max over the ranks of one host float (one-element ncclAllReduce(max) + stream synchronisation): the barrier and
+ * the "slowest rank" reduction of a multi-GPU run without any host-side process group */
+int dfhip_comm_allreduce_max(float* value);
+/* path of the shared object the RCCL symbols were resolved from ("" before dfhip_comm_unique_id / _init) */
+int dfhip_comm_rccl_path(char* out, int cap);
 int dfhip_comm_destroy(void);
 
 /* ---- whole-step capture (hipGraph) -------------------------------------------------- */

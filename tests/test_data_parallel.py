@@ -13,14 +13,15 @@ WORKER = r'''
 import os, sys, json
 import numpy as np
 sys.path.insert(0, os.environ["DF_ROOT"])
-import torch.distributed as dist
+sys.path.insert(0, os.path.join(os.environ["DF_ROOT"], "tests"))
 from deepflows_amd import backend_api, nn, optim, parallel, workloads
+from gloo_communicator import GlooCommunicator
 from deepflows_amd.tensor import Graph, Tensor
 from oracle.numpy_device import NumpyDevice
 
 dev = backend_api.register_device("cpu", NumpyDevice())
 backend_api.set_default_device("cpu")
-comm = parallel.init_communicator(dev)
+comm = GlooCommunicator()
 rank, world = comm.rank, comm.world
 np.random.seed(0)
 model = workloads.MLP((12, 16, 4), device=dev)

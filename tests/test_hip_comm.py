@@ -22,12 +22,6 @@ def rccl_comm(request):
     assert isinstance(comm, parallel.RcclCommunicator), type(comm)
     yield dev, comm
     comm.close()
-    try:
-        import torch.distributed as dist
-        if dist.is_initialized():
-            dist.destroy_process_group()
-    except Exception:
-        pass
     for k, v in saved.items():
         if v is None:
             os.environ.pop(k, None)
@@ -134,3 +128,28 @@ def test_overlapped_step_matches_eager_exchange(rccl_comm):
     assert o1.t == o2.t == 5
     for a, b in zip(o1.params, o2.params):
         assert np.array_equal(a.data.numpy(), b.data.numpy())
+
+
+def test_bench_exchange_path_runs_on_one_gpu():
+    """bench.py exactly as the driver runs it on N > 1 GPUs, except that the world is one rank: RcclCommunicator
+    (rendezvous skipped at world 1, ncclCommInitRank, barrier and max-over-ranks as one-element collectives), the
+    captured step ending after backward, pack + ncclAllReduce + Adam behind it.  All 2 797 610 parameters go through
+    the bucket, the collective library is ROCm's own, and nothing imported torch."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", DF_FORCE_COMM="1", DF_FORCE_SYNC="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 1000))
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--steps', '3', '--warmup', '2', '--no-cpu-baseline']; "
+            "runpy.run_path(%r, run_name='__main__'); assert 'torch' not in sys.modules, 'torch was imported'"
+            % os.path.join(ROOT, "bench.py"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["config"]["allreduce_elems"] == 2797610
+    assert d["config"]["dispatch"] == "hipgraph" and d["n_gpus"] == 1
+    assert d["config"]["collective_library"].startswith("/opt/rocm"), d["config"]["collective_library"]
+    assert "rccl_allreduce" in d["kernels"]
+    assert d["value"] > 0 and np.isfinite(d["final_loss"])

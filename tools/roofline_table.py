@@ -13,10 +13,11 @@ print("|---|---|---|---|---|---|---|")
 tot = 0.0
 for k, v in d["kernels"].items():
     tot += v["ms_per_step"]
-    if "tflops" in v and v["tflops"] > 1.0:
+    if v.get("bound", "mfma" if v.get("tflops", 0) > 1.0 else "hbm") == "mfma":
         bound, ach, frac = "fp32 MFMA", f"{v['tflops']:.1f} TFLOP/s", v["tflops"] / PEAK_TF
     else:
-        bound, ach, frac = "HBM", f"{v['gbs']:.0f} GB/s", v["gbs"] / PEAK_GBS
+        ex = f" ({v['executed_tflops']:.1f} TFLOP/s executed)" if "executed_tflops" in v else ""
+        bound, ach, frac = "HBM", f"{v['gbs']:.0f} GB/s{ex}", v["gbs"] / PEAK_GBS
     print(f"| {k} | {v['calls_per_step']:.0f} | {v['avg_us']:.1f} | {v['ms_per_step']:.3f} | {bound} | {ach} | {100 * frac:.1f} |")
 print(f"\nSum of families {tot:.3f} ms (eager, with event overhead); replayed step {d['ms_per_step']:.3f} ms = "
       f"{d['value']:.0f} images/s.")
