@@ -3287,6 +3287,19 @@ struct GQueued {
 std::vector<GQueued> g_queue;
 bool g_group_on = false;
 
+// Side-stream flushes (DFHIP_WGRAD_SIDE=n): while a backward sweep is running, every n queued weight gradients are
+// launched on a second stream that forks off the library stream at that point -- the matrix-core-bound grouped
+// launch then runs BESIDE the rest of the sweep (input gradients and BatchNorm backward: latency / HBM bound) instead
+// of after it.  dfhip_wgrad_group_end (and any flush) joins the side stream back.  Inside a capture the fork / join
+// become graph edges.
+hipStream_t g_side = nullptr;
+hipEvent_t g_side_fork = nullptr;
+struct SidePending { hipEvent_t done; float* slabs; std::vector<std::pair<const float*, const float*>> dws; };
+std::vector<SidePending> g_side_pending;
+std::vector<hipEvent_t> g_side_events;            // recycled join events
+hipStream_t g_group_stream = nullptr;             // stream the group kernels go to (nullptr: the library stream)
+float* g_group_slabs = nullptr;                   // slab area supplied by the side flush (nullptr: scratch slot 0)
+
 int group_flush() {
   if (g_queue.empty()) return DFHIP_OK;
   std::vector<GQueued> q;
@@ -3296,7 +3309,15 @@ int group_flush() {
     total += (size_t)e.d.ps * e.d.OT * e.d.CT * e.T * 1024 * sizeof(float);
     lds = std::max(lds, e.lds);
   }
-  float* base = workspace_slot(0, total);
+  hipStream_t gst = g_group_stream ? g_group_stream : stream();
+  float* base = nullptr;
+  if (g_group_stream) {
+    void* blk = nullptr;
+    if (dfhip_malloc((int64_t)((total + 3) / 4), (float**)&blk) != DFHIP_OK) return DFHIP_OUT_OF_MEMORY;
+    base = g_group_slabs = (float*)blk;
+  } else {
+    base = workspace_slot(0, total);
+  }
   if (!base) return DFHIP_OUT_OF_MEMORY;
   // longest workgroups first (they are dispatched in grid order): the launch ends on short ones
   std::stable_sort(q.begin(), q.end(), [](const GQueued& a, const GQueued& b) {
@@ -3338,18 +3359,18 @@ int group_flush() {
     hipEvent_t se0 = nullptr, se1 = nullptr;
     if (stamp_mode) {
       wg.ticks = (unsigned long long*)workspace2((size_t)wgs * 8 * 3);
-      (void)hipMemsetAsync(wg.ticks, 0, (size_t)wgs * 8 * 3, stream());
+      (void)hipMemsetAsync(wg.ticks, 0, (size_t)wgs * 8 * 3, gst);
       for (int i = 0; i < n; i++) wg.d[i].dbg = wg.ticks + wgs;
       (void)hipEventCreate(&se0); (void)hipEventCreate(&se1);
-      (void)hipEventRecord(se0, stream());
+      (void)hipEventRecord(se0, gst);
     }
     {
       ProfScope prof("conv2d_wgrad_grouped", flops, bytes);
-      hipLaunchKernelGGL(k_wgrad_group, dim3((unsigned)wgs), dim3(64 * kRowsWaves), lds, stream(), wg);
+      hipLaunchKernelGGL(k_wgrad_group, dim3((unsigned)wgs), dim3(64 * kRowsWaves), lds, gst, wg);
       DF_LAUNCH_CHECK();
     }
     if (stamp_mode) {      // cycles of a workgroup against the launch's wall time: the clock under this kernel
-      (void)hipEventRecord(se1, stream());
+      (void)hipEventRecord(se1, gst);
       (void)hipEventSynchronize(se1);
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, se0, se1);
@@ -3366,10 +3387,44 @@ int group_flush() {
     }
     {
       ProfScope prof("wgrad_slab_sum", 0.0, sbytes);
-      hipLaunchKernelGGL(k_wgrad_group_sum, dim3((unsigned)vbs), dim3(256), 0, stream(), sg);
+      hipLaunchKernelGGL(k_wgrad_group_sum, dim3((unsigned)vbs), dim3(256), 0, gst, sg);
       DF_LAUNCH_CHECK();
     }
   }
+  return DFHIP_OK;
+}
+
+int side_flush() {
+  if (g_queue.empty()) return DFHIP_OK;
+  if (!g_side) {
+    DF_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+    DF_HIP(hipEventCreateWithFlags(&g_side_fork, hipEventDisableTiming));
+  }
+  hipEvent_t done = nullptr;
+  if (!g_side_events.empty()) { done = g_side_events.back(); g_side_events.pop_back(); }
+  else DF_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  std::vector<std::pair<const float*, const float*>> dws;
+  for (const auto& e : g_queue) dws.push_back({e.dw, e.dw + (int64_t)e.d.O * e.d.C * e.T});
+  DF_HIP(hipEventRecord(g_side_fork, stream()));
+  DF_HIP(hipStreamWaitEvent(g_side, g_side_fork, 0));
+  g_group_stream = g_side;
+  g_group_slabs = nullptr;
+  const int st = group_flush();
+  g_group_stream = nullptr;
+  if (st != DFHIP_OK) return st;
+  DF_HIP(hipEventRecord(done, g_side));
+  g_side_pending.push_back({done, g_group_slabs, dws});
+  g_group_slabs = nullptr;
+  return DFHIP_OK;
+}
+
+int side_join() {
+  for (auto& p : g_side_pending) {
+    DF_HIP(hipStreamWaitEvent(stream(), p.done, 0));
+    if (p.slabs) (void)dfhip_free(p.slabs);          // stream-ordered pool: later users run behind the join
+    g_side_events.push_back(p.done);
+  }
+  g_side_pending.clear();
   return DFHIP_OK;
 }
 
@@ -3476,6 +3531,8 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
     e.flops = 2.0 * N * oh * ow * (double)C * k * k * O;
     e.bytes = 4.0 * ((double)N * C * H * W + (double)O * C * k * k + (double)N * O * oh * ow);
     g_queue.push_back(e);
+    static int side_every = getenv("DFHIP_WGRAD_SIDE") ? atoi(getenv("DFHIP_WGRAD_SIDE")) : 0;
+    if (side_every > 0 && (int)g_queue.size() >= side_every && !profiling()) return side_flush();
     return DFHIP_OK;
   }
 #define DF_ROWS(ID, KSV, PADV, SV, WV, OWV, URV) \
@@ -3624,6 +3681,10 @@ int flush_deferred() {
     int st = group_flush();
     if (st != DFHIP_OK) return st;
   }
+  if (!g_side_pending.empty()) {
+    int st = side_join();
+    if (st != DFHIP_OK) return st;
+  }
   if (!g_def.active) return DFHIP_OK;
   g_def.active = false;
   g_def.slot = -1;
@@ -3631,6 +3692,9 @@ int flush_deferred() {
 }
 bool deferred_touches(const void* p) {
   if (!p) return false;
+  for (const auto& sp : g_side_pending)              // a gradient in flight on the side stream: join first
+    for (const auto& r : sp.dws)
+      if ((const float*)p >= r.first && (const float*)p < r.second) return true;
   const float* q = (const float*)p;
   for (const auto& e : g_queue)
     if (q >= e.dw && q < e.dw + (int64_t)e.d.O * e.d.C * e.T) return true;

@@ -12,6 +12,7 @@ namespace dfhip {
 void set_error(const char* fmt, ...);
 hipStream_t stream();          // the single library stream
 bool initialised();
+bool profiling();             // per-family HIP-event profiling is switched on (dfhip_prof_enable)
 int ensure_init();             // lazy dfhip_init(LOCAL_RANK or 0)
 int num_cus();
 

@@ -207,6 +207,7 @@ struct ProfSlot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 static bool g_prof_on = false;
+bool profiling() { return g_prof_on; }
 static std::vector<ProfSlot> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
 
