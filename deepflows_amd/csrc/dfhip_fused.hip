@@ -295,8 +295,41 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
       n = nn;
     }
   };
+  // The thread's first partial row and its (up to two) 16-byte pieces of x / residual are REQUESTED before anything
+  // is computed -- the row first, so that the combination below starts as soon as the rows are back (L2) while
+  // the pieces of x are still on their way from HBM; the kernel is one round of memory latency long instead of two.
+  const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
+  const int64_t img_stride = (int64_t)C * HW;
+  const float* base = x + (int64_t)c * HW;
+  float* ybase = y + (int64_t)c * HW;
+  const float* rbase = residual ? residual + (int64_t)c * HW : nullptr;
+  const int hw4 = HW >> 2;
+  const bool fast = (HW & 3) == 0 && (n_hi - n_lo) * hw4 <= 2 * kThreads;
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
+  if (tid < rows) {
+    const float* p = partials + ((int64_t)tid * C + c) * 3;
+    p0 = p[0]; p1 = p[1]; p2 = p[2];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  int64_t off[2] = {0, 0};
+  bool have[2] = {false, false};
+  float4 xv[2], rv[2];
+  if (fast) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int e = tid + u * kThreads;
+      have[u] = e < (n_hi - n_lo) * hw4;
+      const int ee = have[u] ? e : 0;
+      const int img = ee / hw4, h4 = ee - img * hw4;
+      off[u] = (int64_t)(n_lo + img) * img_stride + 4 * h4;
+      xv[u] = *reinterpret_cast<const float4*>(base + off[u]);
+      rv[u] = rbase ? *reinterpret_cast<const float4*>(rbase + off[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   float n = 0.0f, mu = 0.0f, m2 = 0.0f;
-  for (int r = tid; r < rows; r += kThreads) {
+  chan(n, mu, m2, p0, p1, p2);
+  for (int r = tid + kThreads; r < rows; r += kThreads) {
     const float* p = partials + ((int64_t)r * C + c) * 3;
     chan(n, mu, m2, p[0], p[1], p[2]);
   }
@@ -321,11 +354,21 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
   const float sd = sqrtf(var + eps);
   const float rsd = 1.0f / sd;   // one division per thread: (x - mean) / sd becomes a multiply
   const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
-  const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
-  const int64_t img_stride = (int64_t)C * HW;
-  const float* base = x + (int64_t)c * HW;
-  float* ybase = y + (int64_t)c * HW;
-  const float* rbase = residual ? residual + (int64_t)c * HW : nullptr;
+  if (fast) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (!have[u]) continue;
+      const float4 v = xv[u];
+      float4 r;
+      r.x = (v.x - mean) * rsd * w + b;
+      r.y = (v.y - mean) * rsd * w + b;
+      r.z = (v.z - mean) * rsd * w + b;
+      r.w = (v.w - mean) * rsd * w + b;
+      if (rbase) { r.x += rv[u].x; r.y += rv[u].y; r.z += rv[u].z; r.w += rv[u].w; }
+      *reinterpret_cast<float4*>(ybase + off[u]) = r;
+    }
+    return;
+  }
   for_each_chunk(base, img_stride, n_lo, n_hi, HW, [&](const float* p, int wdt) {
     const int64_t off = p - base;
     if (wdt == 4) {
