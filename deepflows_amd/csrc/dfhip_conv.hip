@@ -3827,6 +3827,10 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
       return DFHIP_OK;
     }
   }
+  if (mode == 1) {
+    int st = run_conv_rowmma_dgrad(dy, w, add, dx, N, C, H, W, O, k, stride, pad);
+    if (st >= 0) return st;
+  }
   if (add) {
     g.addsrc = add;
     int st = run_igemm_v4(g, C, dx, nullptr);

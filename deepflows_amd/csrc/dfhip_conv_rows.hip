@@ -71,7 +71,11 @@ __device__ unsigned long long g_rows_stamps[512 * 8 * 8];
 // OW output-channel tiles; the weights of its OW tiles go through LDS in chunks of CG channel groups (chunk
 // k + 1 is requested before and committed after the MFMAs of chunk k: one barrier per chunk, every chunk has
 // LDS space of its own); the pixel operands of chunk k + XA are requested at the same point.
-template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, int XA>
+// DG: the INPUT GRADIENT of the same convolution in its mathematically correct ("accumulate") form -- a 3x3 / stride
+// 1 / pad 1 convolution of dY with the weights transposed and flipped: x = dY (C = the convolution's output
+// channels), O = its input channels, operand (d, s, t) = w[s][d][8 - t]; `bias` is then a TENSOR of the output's
+// shape that is added to the result (the gradient the input already holds, tensor.py:444), not a vector.
+template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, int XA, bool DG>
 __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        float* __restrict__ partials, int H, int O) {
@@ -94,28 +98,42 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   RS_STAMP(6);
   RS_STAMP(0);
 
-  // ---- weight chunk staging: thread -> (tile, row m, 16-byte piece) of a chunk's OW x 16 rows of 36 * CG floats ----
+  // ---- weight chunk staging: thread -> a 16-byte piece of the chunk's weights; TOT4 pieces per chunk ----
+  //   forward: OW x 16 rows (output channels) of 36 * CG contiguous floats (CG groups of 4 source channels x 9 taps)
+  //   DG:      4 * CG source channels (rows of w) x OW runs of 144 contiguous floats (16 destination channels x 9 taps)
   constexpr int ROW4 = 9 * CG, TOT4 = OW * 16 * ROW4, PER = (TOT4 + 511) / 512;
   const float* wsrc[PER];
-  int wdst[PER];                               // LDS float index of (tile, row m)
-  int we4[PER];
+  int wdst[PER];                               // LDS float index of the piece's (tile, row) part
+  int we4[PER];                                // forward: piece within the row; DG: piece within the 144-float run
+  int wsl[PER];                                // DG: source channel within the chunk
 #pragma unroll
   for (int u = 0; u < PER; u++) {
     // (threads past the end re-do the piece 512 places back: every load has an UNCONDITIONAL consumer -- under a
     // condition the compiler sinks the load into the commit, behind the MFMAs it was meant to overlap)
     const int q = tid + 512 * u;
     const int qq = q < TOT4 ? q : q - 512;
-    const int tl = qq / (16 * ROW4), r = qq - tl * (16 * ROW4);
-    const int m = r / ROW4, e4 = r - m * ROW4;
-    wsrc[u] = w + ((int64_t)((blockIdx.y * OW + tl) * 16 + m) * C * 9) + 4 * e4;
-    wdst[u] = tl * (NBLK * kBlk) + m * 4;
-    we4[u] = e4;
+    if constexpr (!DG) {
+      const int tl = qq / (16 * ROW4), r = qq - tl * (16 * ROW4);
+      const int m = r / ROW4, e4 = r - m * ROW4;
+      wsrc[u] = w + ((int64_t)((blockIdx.y * OW + tl) * 16 + m) * C * 9) + 4 * e4;
+      wdst[u] = tl * (NBLK * kBlk) + m * 4;
+      we4[u] = e4;
+      wsl[u] = 0;
+    } else {
+      const int sl = qq / (OW * 36), r = qq - sl * (OW * 36);
+      const int tl = r / 36, e4 = r - tl * 36;
+      wsrc[u] = w + ((int64_t)sl * O + (blockIdx.y * OW + tl) * 16) * 9 + 4 * e4;
+      wdst[u] = tl * (NBLK * kBlk);
+      we4[u] = e4;
+      wsl[u] = sl;
+    }
   }
+  const int64_t wchunk = DG ? (int64_t)(4 * CG) * O * 9 : 36 * CG;     // floats between two chunks of a piece
   f32x4 wv[2][PER];                            // two chunks in flight
 #define RM_WLOAD(chunk)                                                                         \
   do {                                                                                          \
     _Pragma("unroll") for (int u = 0; u < PER; u++)                                             \
-      wv[(chunk) & 1][u] = *reinterpret_cast<const f32x4*>(wsrc[u] + (chunk) * (36 * CG));                   \
+      wv[(chunk) & 1][u] = *reinterpret_cast<const f32x4*>(wsrc[u] + (chunk) * wchunk);         \
   } while (0)
   // operand f = p * 9 + t of lane (kk, m) lives at block (f / 4), slot (kk * 16 + m) * 4 + f % 4
 #define RM_WCOMMIT(chunk)                                                                       \
@@ -123,9 +141,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
     _Pragma("unroll") for (int u = 0; u < PER; u++) {                                           \
       _Pragma("unroll") for (int e = 0; e < 4; e++) {                                           \
         const int idx = 4 * we4[u] + e;                                                         \
-        const int c = idx / 9, t = idx - 9 * c;                                                 \
-        const int f = (c >> 2) * 9 + t;                                                         \
-        Wl[wdst[u] + ((chunk) * CBLK + (f >> 2)) * kBlk + (c & 3) * 64 + (f & 3)] = wv[(chunk) & 1][u][e]; \
+        if constexpr (!DG) {                                                                    \
+          const int c = idx / 9, t = idx - 9 * c;                                               \
+          const int f = (c >> 2) * 9 + t;                                                       \
+          Wl[wdst[u] + ((chunk) * CBLK + (f >> 2)) * kBlk + (c & 3) * 64 + (f & 3)] = wv[(chunk) & 1][u][e]; \
+        } else {                                                                                \
+          const int m = idx / 9, t = idx - 9 * m;       /* destination channel in the tile, tap of w */ \
+          const int f = (wsl[u] >> 2) * 9 + (8 - t);    /* flipped tap */                       \
+          Wl[wdst[u] + ((chunk) * CBLK + (f >> 2)) * kBlk + (wsl[u] & 3) * 64 + m * 4 + (f & 3)] = wv[(chunk) & 1][u][e]; \
+        }                                                                                       \
       }                                                                                         \
     }                                                                                           \
   } while (0)
@@ -309,7 +333,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   }
   RS_STAMP(4);
   // ---- epilogue: accumulator register v of lane (kk, n) is channel o0 + 4 * kk + v, pixel n of the tile ----
-  if (bias) {
+  if (bias && !DG) {
 #pragma unroll
     for (int v = 0; v < 4; v++) {
       const float bv = bias[o0 + 4 * kk + v];
@@ -319,9 +343,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   }
 #pragma unroll
   for (int t = 0; t < NT; t++) {
-    float* yt = y + ((int64_t)img_t[t] * O + o0 + 4 * kk) * HW + rem_t[t] + n;
+    const int64_t at = ((int64_t)img_t[t] * O + o0 + 4 * kk) * HW + rem_t[t] + n;
+    if (DG && bias) {
 #pragma unroll
-    for (int v = 0; v < 4; v++) yt[(int64_t)v * HW] = res[t][v];
+      for (int v = 0; v < 4; v++) res[t][v] += bias[at + (int64_t)v * HW];
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) y[at + (int64_t)v * HW] = res[t][v];
   }
   if (partials) {
     // BatchNorm partials: exact two-pass over the wave's NT * 16 pixels per channel, then Chan's
@@ -364,17 +392,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   RS_STAMP(7);
 }
 
-template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, int XA>
+template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, int XA, bool DG = false>
 int launch_rowmma(const float* x, const float* w, const float* bias, float* y, float* partials, int H, int O,
                   dim3 grid) {
   const size_t lds = (size_t)OW * (C / 4 * 9 / 4) * kBlk * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA, DG>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536)));
     attr = true;
   }
-  hipLaunchKernelGGL((k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA>), grid, dim3(512), lds, stream(), x, w, bias, y,
+  hipLaunchKernelGGL((k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA, DG>), grid, dim3(512), lds, stream(), x, w, bias, y,
                      partials, H, O);
   DF_LAUNCH_CHECK();
 #ifdef DFHIP_ROWS_STAMPS
@@ -440,6 +468,30 @@ int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y,
   if (variant == 1) return launch_rowmma<2, 128, 1, true, 8, 1, 4, 2>(x, w, bias, y, partials, H, O, grid);
   if (variant == 2) return launch_rowmma<2, 128, 1, true, 8, 1, 8, 2>(x, w, bias, y, partials, H, O, grid);
   return launch_rowmma<2, 128, 1, true, 8, 1, 8, 1>(x, w, bias, y, partials, H, O, grid);
+}
+
+
+// the accumulate-mode input gradient of a 3x3 / stride 1 / pad 1 convolution on the same kernel (DG): dy (N, O, H, W),
+// w (O, C, 3, 3) -> dx (N, C, H, W) (+ add); -1 when the shape is not eligible
+int run_conv_rowmma_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int C, int H, int W,
+                          int O, int k, int stride, int pad) {
+  static int enabled = getenv("DFHIP_ROWMMA_DGRAD") ? atoi(getenv("DFHIP_ROWMMA_DGRAD")) : 1;
+  if (!enabled || k != 3 || stride != 1 || pad != 1) return -1;
+  const int64_t HW = (int64_t)H * W;
+  if (HW % 16 != 0) return -1;
+  const int64_t tiles = (int64_t)N * HW / 16;
+  int nt, ts, ow;
+  if (W == 16 && O == 32) { nt = 4; ts = 4; ow = 2; }
+  else if (W == 8 && O == 64) { nt = 2; ts = 4; ow = 2; }
+  else if (W == 4 && H == 4 && O == 128) { nt = 1; ts = 8; ow = 1; }
+  else return -1;
+  if (C % (16 * ow) != 0 || tiles % (ts * nt) != 0 || (W == 16 && H % nt != 0)) return -1;
+  const int64_t gx = tiles / (ts * nt);
+  if (gx * (C / (16 * ow)) < num_cus() / 2) return -1;
+  dim3 grid((unsigned)gx, (unsigned)(C / (16 * ow)));
+  if (W == 16) return launch_rowmma<4, 32, 4, false, 4, 2, 4, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
+  if (W == 8) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
+  return launch_rowmma<2, 128, 1, true, 8, 1, 8, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
 }
 
 }  // namespace dfhip

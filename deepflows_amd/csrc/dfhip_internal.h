@@ -46,6 +46,9 @@ int deferred_scratch_slot();          // scratch slot holding the pending slabs,
 int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int O,
                     int k, int stride, int pad, float* partials, int cap_rows, int* rows_out);
 
+int run_conv_rowmma_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int C, int H, int W,
+                          int O, int k, int stride, int pad);
+
 }  // namespace dfhip
 
 #define DF_CHECK_ARG(cond, ...)                      \

@@ -242,3 +242,21 @@ def test_register_operand_forward_with_partials(hip_device, name, bias):
     y64 = y_ref.astype(np.float64)
     assert_close(mu, y64.mean(axis=(0, 2, 3)), 1e-5, "partials mean")
     assert_close(m2 / cnt, y64.var(axis=(0, 2, 3)), 1e-5, "partials variance")
+
+
+@pytest.mark.parametrize("name", ["l1", "l2", "l3"])
+def test_register_operand_accumulate_dgrad_with_held_gradient(hip_device, name):
+    """The mathematically correct input gradient of the 3x3 / stride 1 layers on the register-operand kernel (weights
+    transposed and flipped while they are staged), with and without the gradient the tensor already holds."""
+    mod = hip_device.mod
+    C, H, W, O, k, s, p = LAYERS[name]
+    rng = np.random.default_rng(17)
+    dy = rng.standard_normal((N, O, H, W)).astype(np.float32)
+    w = (rng.standard_normal((O, C, k, k)) / np.sqrt(O * k * k)).astype(np.float32)
+    held = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    want = R.conv2d_dgrad(dy, w, (N, C, H, W), s, p, "accumulate")
+    dyh, wh, dxh = _arr(mod, dy), _arr(mod, w), mod.Array(N * C * H * W)
+    mod.conv2d_dgrad(dyh, wh, dxh, N, C, H, W, O, k, s, p, mode="accumulate")
+    assert_close(_back(mod, dxh, want.shape), want, 1e-4, name + " accumulate dgrad")
+    mod.conv2d_dgrad_add(dyh, wh, _arr(mod, held), dxh, N, C, H, W, O, k, s, p, mode="accumulate")
+    assert_close(_back(mod, dxh, want.shape), want + held, 1e-4, name + " accumulate dgrad + held gradient")
