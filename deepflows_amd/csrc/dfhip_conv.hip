@@ -3283,9 +3283,12 @@ struct GQueued {
   int T;
   size_t lds;
   double flops, bytes;
+  int W, ow, k, stride, pad;     // the rest of the call's arguments (a small group is re-planned as stand-alone launches)
 };
 std::vector<GQueued> g_queue;
 bool g_group_on = false;
+int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
+                   int k, int stride, int pad);
 
 // Side-stream flushes (DFHIP_WGRAD_SIDE=n): while a backward sweep is running, every n queued weight gradients are
 // launched on a second stream that forks off the library stream at that point -- the matrix-core-bound grouped
@@ -3308,6 +3311,24 @@ int group_flush() {
   for (auto& e : q) {
     total += (size_t)e.d.ps * e.d.OT * e.d.CT * e.T * 1024 * sizeof(float);
     lds = std::max(lds, e.lds);
+  }
+  // A grouped layer is cut into 16x fewer, longer workgroups than a stand-alone launch (the other layers of the
+  // sweep fill the chip).  A sweep that queued too little for that (the CNN workload: one eligible layer) would
+  // leave most CUs idle: its layers are re-planned and launched stand-alone instead.
+  if (!g_group_stream) {
+    int64_t wgs_total = 0;
+    for (auto& e : q) wgs_total += (int64_t)e.d.ps * e.d.CT * e.d.OT;
+    if (wgs_total < num_cus()) {
+      const bool was = g_group_on;
+      g_group_on = false;
+      int st = DFHIP_OK;
+      for (auto& e : q) {
+        st = run_wgrad_rows(e.d.x, e.d.dy, e.dw, e.d.N, e.d.C, e.d.H, e.W, e.d.O, e.d.oh, e.ow, e.k, e.stride, e.pad);
+        if (st != DFHIP_OK) break;
+      }
+      g_group_on = was;
+      return st < 0 ? DFHIP_RUNTIME_ERROR : st;
+    }
   }
   hipStream_t gst = g_group_stream ? g_group_stream : stream();
   float* base = nullptr;
@@ -3530,6 +3551,7 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
     }
     e.flops = 2.0 * N * oh * ow * (double)C * k * k * O;
     e.bytes = 4.0 * ((double)N * C * H * W + (double)O * C * k * k + (double)N * O * oh * ow);
+    e.W = W; e.ow = ow; e.k = k; e.stride = stride; e.pad = pad;
     g_queue.push_back(e);
     static int side_every = getenv("DFHIP_WGRAD_SIDE") ? atoi(getenv("DFHIP_WGRAD_SIDE")) : 0;
     if (side_every > 0 && (int)g_queue.size() >= side_every && !profiling()) return side_flush();
