@@ -67,9 +67,14 @@ class CIFAR10_CNN(nn.Module):
         self.fc = nn.Linear(128 * 4 * 4, num_classes, device=device)
 
     def forward(self, x):
-        x = self.pool1(self.relu1(self.bn1(self.conv1(x))))
-        x = self.pool2(self.relu2(self.bn2(self.conv2(x))))
-        x = self.pool3(self.relu3(self.bn3(self.conv3(x))))
+        for conv, bn, relu, pool in ((self.conv1, self.bn1, self.relu1, self.pool1),
+                                     (self.conv2, self.bn2, self.relu2, self.pool2),
+                                     (self.conv3, self.bn3, self.relu3, self.pool3)):
+            x = conv(x)
+            if nn.functional.bn_relu_maxpool2_fusable(x, bn, pool):
+                x = nn.functional.bn_relu_maxpool2_train(x, bn)     # pool(relu(bn(x))) as one node on the hip device
+            else:
+                x = pool(relu(bn(x)))
         x = x.reshape(x.shape[0], -1)
         x = self.drop(x)
         return self.fc(x)
