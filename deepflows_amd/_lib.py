@@ -98,6 +98,8 @@ _SIGS = {
     "dfhip_event_destroy": [P],
     "dfhip_prof_enable": [c_int],
     "dfhip_prof_reset": [],
+    "dfhip_prof_gate_close": [c_int],
+    "dfhip_prof_gate_open": [],
 }
 for _n in ("add", "mul", "div", "maximum", "eq", "ge"):
     _SIGS["dfhip_ewise_" + _n] = [P, P, P, c_int64]
@@ -133,7 +135,7 @@ def load():
     lib.dfhip_stream.argtypes = []
     lib.dfhip_stream.restype = c_void_p
     lib.dfhip_prof_read.argtypes = [c_int, POINTER(c_char_p), POINTER(c_double), I64P,
-                                    POINTER(c_double), POINTER(c_double)]
+                                    POINTER(c_double), POINTER(c_double), POINTER(c_double), I64P]
     lib.dfhip_prof_read.restype = c_int
     _lib = lib
     return lib

@@ -2777,7 +2777,7 @@ int launch_igemm_v4n(const Geo& g, dim3 grid, size_t lds) {
                                (int)std::max(lds, (size_t)65536)));
     attr_lds = std::max(lds, (size_t)65536);
   }
-  hipLaunchKernelGGL((k_conv_igemm_v4<KS, MODE, NPK>), grid, dim3(512), lds, stream(), g);
+  DF_LAUNCH((k_conv_igemm_v4<KS, MODE, NPK>), grid, dim3(512), lds, stream(), g);
   return DFHIP_OK;
 }
 
@@ -2794,7 +2794,7 @@ int launch_igemm_v4(const Geo& g, dim3 grid, size_t lds) {
 int finish_slabs(const Geo& g, int splits, float* final_dst, const float* bias, int64_t out_elems) {
   if (splits > 1) {
     int nb = (int)std::min<int64_t>(df_ceil_div(out_elems, 256), (int64_t)num_cus() * 8);
-    hipLaunchKernelGGL(k_conv_slab_sum, dim3(nb), dim3(256), 0, stream(), g.dst, bias, final_dst,
+    DF_LAUNCH(k_conv_slab_sum, dim3(nb), dim3(256), 0, stream(), g.dst, bias, final_dst,
                        out_elems, splits, (int64_t)g.HD * g.WD, g.CD);
     DF_LAUNCH_CHECK();
   }
@@ -2944,7 +2944,7 @@ int run_conv_img2(const Geo& g, int O, float* y, const float* bias, float* parti
                                  (int)std::max(lds, (size_t)65536)));                                             \
       attr = true;                                                                                                \
     }                                                                                                             \
-    hipLaunchKernelGGL(k_conv3x3_img2_fwd<CV>, grid, dim3(512), lds, stream(), g.src, g.wgt, bias, y, partials, O); \
+    DF_LAUNCH(k_conv3x3_img2_fwd<CV>, grid, dim3(512), lds, stream(), g.src, g.wgt, bias, y, partials, O); \
   } while (0)
   if (g.CS == 128) DF_I2(128); else DF_I2(256);
 #undef DF_I2
@@ -2968,9 +2968,9 @@ int run_conv1x1s2(const Geo& g, int O, float* y, const float* bias, float* parti
   if ((int64_t)rows * df_ceil_div(O, 32) < num_cus() / 2) return -1;   // too few workgroups: the k-split kernel wins
   if (rows_out) *rows_out = partials ? rows : 0;
   dim3 grid((unsigned)rows, (unsigned)df_ceil_div(O, 32));
-  if (g.CS == 32) hipLaunchKernelGGL(k_conv1x1s2_fwd<32>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O);
-  else if (g.CS == 64) hipLaunchKernelGGL(k_conv1x1s2_fwd<64>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O);
-  else hipLaunchKernelGGL(k_conv1x1s2_fwd<128>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O);
+  if (g.CS == 32) DF_LAUNCH(k_conv1x1s2_fwd<32>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O);
+  else if (g.CS == 64) DF_LAUNCH(k_conv1x1s2_fwd<64>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O);
+  else DF_LAUNCH(k_conv1x1s2_fwd<128>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -2991,7 +2991,7 @@ int run_conv_rows3(const Geo& g, int dest_channels, float* final_dst, const floa
   const unsigned m_h = magic_u32((unsigned)g.HS);
 #define DF_STEM(CV)                                                                                   \
   case CV:                                                                                            \
-    hipLaunchKernelGGL(k_conv_rows3<CV>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, final_dst, g.N, g.HS, \
+    DF_LAUNCH(k_conv_rows3<CV>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, final_dst, g.N, g.HS, \
                        dest_channels, m_h);                                                           \
     break;
   switch (g.CS) { DF_STEM(1) DF_STEM(2) DF_STEM(3) DF_STEM(4) default: return -1; }
@@ -3051,7 +3051,7 @@ int run_igemm(Geo g, int dest_channels, float* final_dst, const float* bias) {
     attr_lds = std::max(lds, (size_t)65536);
   }
   dim3 grid((unsigned)pixel_blocks, (unsigned)dtiles, (unsigned)splits);
-  hipLaunchKernelGGL(k_conv_igemm, grid, dim3(256), lds, stream(), g);
+  DF_LAUNCH(k_conv_igemm, grid, dim3(256), lds, stream(), g);
   DF_LAUNCH_CHECK();
   return finish_slabs(g, splits, final_dst, bias, out_elems);
 }
@@ -3085,10 +3085,10 @@ int launch_wgrad(WGeo g, float* dw) {
     attr_lds = std::max(lds, (size_t)65536);
   }
   dim3 grid((unsigned)gx, (unsigned)ktiles, (unsigned)otiles);
-  hipLaunchKernelGGL((k_conv_wgrad<OT, KT>), grid, dim3(256), lds, stream(), g);
+  DF_LAUNCH((k_conv_wgrad<OT, KT>), grid, dim3(256), lds, stream(), g);
   DF_LAUNCH_CHECK();
   if (gx > 1) {
-    hipLaunchKernelGGL(k_flat_slab_sum, dim3((unsigned)df_ceil_div(n, 256)), dim3(1024), 0, stream(), slabs,
+    DF_LAUNCH(k_flat_slab_sum, dim3((unsigned)df_ceil_div(n, 256)), dim3(1024), 0, stream(), slabs,
                        dw, n, gx);
     DF_LAUNCH_CHECK();
   }
@@ -3120,7 +3120,7 @@ int launch_wgrad_v3(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
     g.stamps = (unsigned long long*)workspace2(nb * 32 * 8);
     (void)hipMemsetAsync(g.stamps, 0, nb * 32 * 8, stream());
   }
-  hipLaunchKernelGGL((k_conv_wgrad_v3<OT, KT, DV>), grid, dim3(512), lds, stream(), g);
+  DF_LAUNCH((k_conv_wgrad_v3<OT, KT, DV>), grid, dim3(512), lds, stream(), g);
   DF_LAUNCH_CHECK();
   if (stamp_mode) {
     std::vector<unsigned long long> h(nb * 32);
@@ -3141,7 +3141,7 @@ int launch_wgrad_v3(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
     fprintf(stderr, "\n");
   }
   if (gx > 1) {
-    hipLaunchKernelGGL(k_flat_slab_sum, dim3((unsigned)df_ceil_div(n, 256)), dim3(1024), 0, stream(), slabs,
+    DF_LAUNCH(k_flat_slab_sum, dim3((unsigned)df_ceil_div(n, 256)), dim3(1024), 0, stream(), slabs,
                        dw, n, gx);
     DF_LAUNCH_CHECK();
   }
@@ -3207,7 +3207,7 @@ SlabSum make_slab_sum(const float* slabs, float* dw, int ps, int OT, int CT, int
 }
 
 int launch_slab_sum(const SlabSum& a) {
-  hipLaunchKernelGGL(k_wgrad_tap_sum, dim3((unsigned)a.nvb), dim3(256), 0, stream(), a);
+  DF_LAUNCH(k_wgrad_tap_sum, dim3((unsigned)a.nvb), dim3(256), 0, stream(), a);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -3242,7 +3242,7 @@ int launch_wgrad_rows(RGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
     g.stamps = (unsigned long long*)workspace2(nb * 32 * 8);
     (void)hipMemsetAsync(g.stamps, 0, nb * 32 * 8, stream());
   }
-  hipLaunchKernelGGL((k_conv_wgrad_rows<KS, PAD, STRIDE, W, OW, UR>), grid, dim3(64 * kRowsWaves), lds, stream(), g);
+  DF_LAUNCH((k_conv_wgrad_rows<KS, PAD, STRIDE, W, OW, UR>), grid, dim3(64 * kRowsWaves), lds, stream(), g);
   DF_LAUNCH_CHECK();
   if (stamp_mode) {
     std::vector<unsigned long long> h(nb * 32);
@@ -3314,11 +3314,13 @@ int group_flush() {
   }
   // A grouped layer is cut into 16x fewer, longer workgroups than a stand-alone launch (the other layers of the
   // sweep fill the chip).  A sweep that queued too little for that (the CNN workload: one eligible layer) would
-  // leave most CUs idle: its layers are re-planned and launched stand-alone instead.
+  // leave most CUs idle: its layers are re-planned and launched stand-alone instead.  (A quarter of the chip: the
+  // two half sweeps of the overlapped data-parallel step -- layer4 + classifier, then the rest, ~200 workgroups
+  // each -- stay grouped, so their sums are those of the single sweep bit for bit.)
   if (!g_group_stream) {
     int64_t wgs_total = 0;
     for (auto& e : q) wgs_total += (int64_t)e.d.ps * e.d.CT * e.d.OT;
-    if (wgs_total < num_cus()) {
+    if (wgs_total < num_cus() / 4) {
       const bool was = g_group_on;
       g_group_on = false;
       int st = DFHIP_OK;
@@ -3387,7 +3389,7 @@ int group_flush() {
     }
     {
       ProfScope prof("conv2d_wgrad_grouped", flops, bytes);
-      hipLaunchKernelGGL(k_wgrad_group, dim3((unsigned)wgs), dim3(64 * kRowsWaves), lds, gst, wg);
+      DF_LAUNCH(k_wgrad_group, dim3((unsigned)wgs), dim3(64 * kRowsWaves), lds, gst, wg);
       DF_LAUNCH_CHECK();
     }
     if (stamp_mode) {      // cycles of a workgroup against the launch's wall time: the clock under this kernel
@@ -3408,7 +3410,7 @@ int group_flush() {
     }
     {
       ProfScope prof("wgrad_slab_sum", 0.0, sbytes);
-      hipLaunchKernelGGL(k_wgrad_group_sum, dim3((unsigned)vbs), dim3(256), 0, gst, sg);
+      DF_LAUNCH(k_wgrad_group_sum, dim3((unsigned)vbs), dim3(256), 0, gst, sg);
       DF_LAUNCH_CHECK();
     }
   }
@@ -3586,7 +3588,7 @@ int launch_wgrad_tap(TGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
     g.stamps = (unsigned long long*)workspace2(nb * 32 * 8);
     (void)hipMemsetAsync(g.stamps, 0, nb * 32 * 8, stream());
   }
-  hipLaunchKernelGGL((k_conv_wgrad_tap<KS, XV, DV, DENSE>), grid, dim3(512), lds, stream(), g);
+  DF_LAUNCH((k_conv_wgrad_tap<KS, XV, DV, DENSE>), grid, dim3(512), lds, stream(), g);
   DF_LAUNCH_CHECK();
   {
     int st_ = launch_slab_sum(make_slab_sum(g.slabs, dw, ps, OT, CT, T, g.O, g.C));
@@ -3831,7 +3833,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
                                  (int)std::max(lds, (size_t)65536)));                                         \
       attr = true;                                                                                            \
     }                                                                                                         \
-    hipLaunchKernelGGL((k_dgrad_ow_s1_ks<OV, GV>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, H, lw, tiles, pg); \
+    DF_LAUNCH((k_dgrad_ow_s1_ks<OV, GV>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, H, lw, tiles, pg); \
   } while (0)
       if (O == 128) { if (geo == 0) DF_KS(128, 0); else if (geo == 1) DF_KS(128, 1); else DF_KS(128, 2); }
       else { if (geo == 0) DF_KS(256, 0); else if (geo == 1) DF_KS(256, 1); else DF_KS(256, 2); }
@@ -3841,7 +3843,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
     }
     if (lean_ok && (O == 32 || O == 64)) {
       dim3 grid((unsigned)df_ceil_div(tiles, 4), (unsigned)(C / 32));
-#define DF_A(OV, GV) hipLaunchKernelGGL((k_dgrad_ow_s1<OV, GV>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg)
+#define DF_A(OV, GV) DF_LAUNCH((k_dgrad_ow_s1<OV, GV>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg)
       if (O == 32) { if (geo == 0) DF_A(32, 0); else if (geo == 1) DF_A(32, 1); else DF_A(32, 2); }
       else { if (geo == 0) DF_A(64, 0); else if (geo == 1) DF_A(64, 1); else DF_A(64, 2); }
 #undef DF_A

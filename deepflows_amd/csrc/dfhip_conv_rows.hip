@@ -402,7 +402,7 @@ int launch_rowmma(const float* x, const float* w, const float* bias, float* y, f
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536)));
     attr = true;
   }
-  hipLaunchKernelGGL((k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA, DG>), grid, dim3(512), lds, stream(), x, w, bias, y,
+  DF_LAUNCH((k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA, DG>), grid, dim3(512), lds, stream(), x, w, bias, y,
                      partials, H, O);
   DF_LAUNCH_CHECK();
 #ifdef DFHIP_ROWS_STAMPS

@@ -1304,7 +1304,7 @@ int dfhip_bn2d_forward_train(const float* x, const float* gamma, const float* be
   double n = (double)N * C * HW;
   ProfScope prof("bn2d_fwd", 0.0, 12.0 * n);
   if (bn_fused_ok(N, C, HW)) {
-    hipLaunchKernelGGL(k_bn_fused_fwd, dim3((unsigned)C), dim3(512), 0, stream(), x, gamma, beta, y, save_mean,
+    DF_LAUNCH(k_bn_fused_fwd, dim3((unsigned)C), dim3(512), 0, stream(), x, gamma, beta, y, save_mean,
                        save_var, running_mean, running_var, N, C, HW, eps, momentum);
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
@@ -1314,9 +1314,9 @@ int dfhip_bn2d_forward_train(const float* x, const float* gamma, const float* be
   float* partial = workspace_small((size_t)C * S * 3 * sizeof(float));
   if (!partial) return DFHIP_OUT_OF_MEMORY;
   dim3 grid((unsigned)C, (unsigned)S);
-  hipLaunchKernelGGL(k_bn_stats, grid, dim3(kThreads), 0, stream(), x, partial, N, C, HW, S, ipb);
+  DF_LAUNCH(k_bn_stats, grid, dim3(kThreads), 0, stream(), x, partial, N, C, HW, S, ipb);
   DF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bn_apply, grid, dim3(kThreads), 0, stream(), x, gamma, beta, y, partial,
+  DF_LAUNCH(k_bn_apply, grid, dim3(kThreads), 0, stream(), x, gamma, beta, y, partial,
                      save_mean, save_var, running_mean, running_var, N, C, HW, S, ipb, eps, momentum);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1333,7 +1333,7 @@ int dfhip_bn2d_forward_partials(const float* x, const float* partials, int rows,
   ProfScope prof("bn2d_fwd", 0.0, (residual ? 12.0 : 8.0) * n);
   int S, ipb;
   bn_split(N, C, S, ipb);
-  hipLaunchKernelGGL(k_bn_apply_partials, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), x, partials,
+  DF_LAUNCH(k_bn_apply_partials, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), x, partials,
                      rows, gamma, beta, residual, y, save_mean, save_var, running_mean, running_var, N, C, HW, ipb,
                      eps, momentum);
   DF_LAUNCH_CHECK();
@@ -1349,7 +1349,7 @@ int dfhip_bn2d_forward_eval(const float* x, const float* gamma, const float* bet
   int S, ipb;
   bn_split(N, C, S, ipb);
   ProfScope prof("bn2d_eval", 0.0, 8.0 * (double)N * C * HW);
-  hipLaunchKernelGGL(k_bn_eval, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), x, gamma,
+  DF_LAUNCH(k_bn_eval, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), x, gamma,
                      beta, y, running_mean, running_var, N, C, HW, ipb, eps);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1371,7 +1371,7 @@ int dfhip_bn2d_backward(const float* dy, const float* x, const float* gamma, con
   DF_CHECK_ARG(dy && x && save_mean && save_var, "bn2d_backward: null array");
   ProfScope prof("bn2d_bwd", 0.0, 20.0 * (double)N * C * HW);
   if (bn_fused_ok(N, C, HW)) {
-    hipLaunchKernelGGL(k_bn_fused_bwd, dim3((unsigned)C), dim3(512), 0, stream(), dy, x, gamma, save_mean,
+    DF_LAUNCH(k_bn_fused_bwd, dim3((unsigned)C), dim3(512), 0, stream(), dy, x, gamma, save_mean,
                        save_var, dx, dgamma, dbeta, N, C, HW, eps);
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
@@ -1381,10 +1381,10 @@ int dfhip_bn2d_backward(const float* dy, const float* x, const float* gamma, con
   float* partial = workspace_small((size_t)C * S * 2 * sizeof(float));
   if (!partial) return DFHIP_OUT_OF_MEMORY;
   dim3 grid((unsigned)C, (unsigned)S);
-  hipLaunchKernelGGL(k_bn_bwd_stats, grid, dim3(kThreads), 0, stream(), dy, x, save_mean, save_var,
+  DF_LAUNCH(k_bn_bwd_stats, grid, dim3(kThreads), 0, stream(), dy, x, save_mean, save_var,
                      partial, N, C, HW, S, ipb, eps);
   DF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bn_bwd_apply, grid, dim3(kThreads), 0, stream(), dy, x, gamma, save_mean,
+  DF_LAUNCH(k_bn_bwd_apply, grid, dim3(kThreads), 0, stream(), dy, x, gamma, save_mean,
                      save_var, partial, dx, dgamma, dbeta, N, C, HW, S, ipb, eps);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1408,7 +1408,7 @@ int dfhip_bn2d_forward_partials_pair(const float* xa, const float* partials_a, i
                 momentum_a};
   BnFwdSet B = {xb, partials_b, rows_b, gamma_b, beta_b, save_mean_b, save_var_b, running_mean_b, running_var_b, eps_b,
                 momentum_b};
-  hipLaunchKernelGGL(k_bn_apply_partials_pair, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), A, B, y, N,
+  DF_LAUNCH(k_bn_apply_partials_pair, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), A, B, y, N,
                      C, HW, ipb);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1433,7 +1433,7 @@ int dfhip_bn2d_backward_pair(const float* dy, const float* xa, const float* gamm
   ProfScope prof("bn2d_bwd", 0.0, 36.0 * (double)N * C * HW);
   BnBwdSet A = {xa, gamma_a, save_mean_a, save_var_a, dxa, dgamma_a, dbeta_a, eps_a};
   BnBwdSet B = {xb, gamma_b, save_mean_b, save_var_b, dxb, dgamma_b, dbeta_b, eps_b};
-  hipLaunchKernelGGL(k_bn_fused_bwd_pair, dim3((unsigned)C, 2), dim3(512), 0, stream(), dy, A, B, N, C, HW);
+  DF_LAUNCH(k_bn_fused_bwd_pair, dim3((unsigned)C, 2), dim3(512), 0, stream(), dy, A, B, N, C, HW);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -1452,9 +1452,9 @@ int dfhip_bn_relu_maxpool2_forward(const float* x, const float* gamma, const flo
   float* partial = workspace_small((size_t)C * S * 3 * sizeof(float));
   if (!partial) return DFHIP_OUT_OF_MEMORY;
   dim3 grid((unsigned)C, (unsigned)S);
-  hipLaunchKernelGGL(k_bn_stats, grid, dim3(kThreads), 0, stream(), x, partial, N, C, HW, S, ipb);
+  DF_LAUNCH(k_bn_stats, grid, dim3(kThreads), 0, stream(), x, partial, N, C, HW, S, ipb);
   DF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bn_relu_pool_fwd, grid, dim3(kThreads), 0, stream(), x, partial, S, gamma, beta, y, save_mean,
+  DF_LAUNCH(k_bn_relu_pool_fwd, grid, dim3(kThreads), 0, stream(), x, partial, S, gamma, beta, y, save_mean,
                      save_var, running_mean, running_var, N, C, H, W, ipb, eps, momentum);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1476,10 +1476,10 @@ int dfhip_bn_relu_maxpool2_backward(const float* x, const float* y, const float*
   float* partial = workspace_small((size_t)C * S * 2 * sizeof(float));
   if (!partial) return DFHIP_OUT_OF_MEMORY;
   dim3 grid((unsigned)C, (unsigned)S);
-  hipLaunchKernelGGL((k_bn_relu_pool_bwd<false>), grid, dim3(kThreads), 0, stream(), x, y, g, gamma, beta, save_mean,
+  DF_LAUNCH((k_bn_relu_pool_bwd<false>), grid, dim3(kThreads), 0, stream(), x, y, g, gamma, beta, save_mean,
                      save_var, partial, dx, dgamma, dbeta, N, C, H, W, S, ipb, eps);
   DF_LAUNCH_CHECK();
-  hipLaunchKernelGGL((k_bn_relu_pool_bwd<true>), grid, dim3(kThreads), 0, stream(), x, y, g, gamma, beta, save_mean,
+  DF_LAUNCH((k_bn_relu_pool_bwd<true>), grid, dim3(kThreads), 0, stream(), x, y, g, gamma, beta, save_mean,
                      save_var, partial, dx, dgamma, dbeta, N, C, H, W, S, ipb, eps);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1491,7 +1491,7 @@ int dfhip_augment_batch(const float* in, float* out, const int* decisions, int N
   DF_CHECK_ARG(in && out && decisions, "augment_batch: null array");
   const int64_t n = (int64_t)N * C * H * W;
   ProfScope prof("augment_batch", 0.0, 8.0 * (double)n);
-  hipLaunchKernelGGL(k_augment_batch, dim3(grid_for(n)), dim3(kThreads), 0, stream(), in, out, decisions, N, C, H, W,
+  DF_LAUNCH(k_augment_batch, dim3(grid_for(n)), dim3(kThreads), 0, stream(), in, out, decisions, N, C, H, W,
                      pad);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1503,7 +1503,7 @@ int dfhip_onehot_smooth(const int* labels, float* out, int N, int K, double eps)
   // (1 - eps) + eps / K and eps / K in the reference's float32 arithmetic: onehot * (1 - eps) + eps / K
   const float scale = (float)(1.0 - eps), add = (float)(eps / K);
   const float on = 1.0f * scale + add, off = 0.0f * scale + add;
-  hipLaunchKernelGGL(k_onehot_smooth, dim3((unsigned)df_ceil_div((int64_t)N * K, kThreads)), dim3(kThreads), 0, stream(),
+  DF_LAUNCH(k_onehot_smooth, dim3((unsigned)df_ceil_div((int64_t)N * K, kThreads)), dim3(kThreads), 0, stream(),
                      labels, out, N, K, on, off);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1516,7 +1516,7 @@ int dfhip_maxpool2d_forward(const float* x, float* y, int NC, int H, int W, int 
   int oh = (H - k) / k + 1, ow = (W - k) / k + 1;
   int64_t n_out = (int64_t)NC * oh * ow;
   ProfScope prof("maxpool2d_fwd", 0.0, 4.0 * ((double)NC * H * W + (double)n_out));
-  hipLaunchKernelGGL(k_maxpool_fwd, dim3(grid_for(n_out)), dim3(kThreads), 0, stream(), x, y, n_out, H,
+  DF_LAUNCH(k_maxpool_fwd, dim3(grid_for(n_out)), dim3(kThreads), 0, stream(), x, y, n_out, H,
                      W, oh, ow, k);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1534,7 +1534,7 @@ int dfhip_maxpool2d_backward(const float* x, const float* y, const float* dy, fl
   int oh = (H - k) / k + 1, ow = (W - k) / k + 1;
   int64_t n_in = (int64_t)NC * H * W;
   ProfScope prof("maxpool2d_bwd", 0.0, 8.0 * (double)n_in + 8.0 * (double)NC * oh * ow);
-  hipLaunchKernelGGL(k_maxpool_bwd, dim3(grid_for(n_in)), dim3(kThreads), 0, stream(), x, y, dy, dx,
+  DF_LAUNCH(k_maxpool_bwd, dim3(grid_for(n_in)), dim3(kThreads), 0, stream(), x, y, dy, dx,
                      n_in, H, W, oh, ow, k);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1546,7 +1546,7 @@ int dfhip_relu_forward(const float* x, float* y, int64_t n) {
   if (n == 0) return DFHIP_OK;
   DF_CHECK_ARG(x && y, "relu: null array");
   ProfScope prof("relu_fwd", 0.0, 8.0 * (double)n);
-  hipLaunchKernelGGL(k_relu_fwd, dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), x, y, n);
+  DF_LAUNCH(k_relu_fwd, dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), x, y, n);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -1561,7 +1561,7 @@ int dfhip_relu_backward(const float* x, const float* y, const float* g, float* d
   if (n == 0) return DFHIP_OK;
   DF_CHECK_ARG(x && y && g && dx, "relu_backward: null array");
   ProfScope prof("relu_bwd", 0.0, 16.0 * (double)n);
-  hipLaunchKernelGGL(k_relu_bwd, dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), x, y, g, dx, n);
+  DF_LAUNCH(k_relu_bwd, dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), x, y, g, dx, n);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -1573,18 +1573,18 @@ int dfhip_softmax_ce_forward(const float* logits, const float* target, float* lo
   DF_CHECK_ARG(logits && target && loss, "softmax_ce: null array");
   ProfScope prof("softmax_ce_fwd", 0.0, 8.0 * (double)rows * cols);
   if (rows <= 4096 && cols <= 32) {
-    hipLaunchKernelGGL(k_ce_small, dim3(1), dim3(1024), 0, stream(), logits, target, loss, rows, cols,
+    DF_LAUNCH(k_ce_small, dim3(1), dim3(1024), 0, stream(), logits, target, loss, rows, cols,
                        (float)(1.0 / (double)rows));
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
   }
   float* row_loss = workspace_small((size_t)rows * sizeof(float));
   if (!row_loss) return DFHIP_OUT_OF_MEMORY;
-  hipLaunchKernelGGL(k_ce_rows, dim3(grid_for((int64_t)rows * 64)), dim3(kThreads), 0, stream(), logits,
+  DF_LAUNCH(k_ce_rows, dim3(grid_for((int64_t)rows * 64)), dim3(kThreads), 0, stream(), logits,
                      target, row_loss, rows, cols);
   DF_LAUNCH_CHECK();
   float inv = (float)(1.0 / (double)rows);
-  hipLaunchKernelGGL(k_ce_finish, dim3(1), dim3(kThreads), 0, stream(), row_loss, loss, rows, inv);
+  DF_LAUNCH(k_ce_finish, dim3(1), dim3(kThreads), 0, stream(), row_loss, loss, rows, inv);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -1596,7 +1596,7 @@ int dfhip_softmax_ce_backward(const float* logits, const float* target, const fl
   DF_CHECK_ARG(logits && target && gloss && dlogits, "softmax_ce_backward: null array");
   ProfScope prof("softmax_ce_bwd", 0.0, 12.0 * (double)rows * cols);
   float inv = (float)(1.0 / (double)rows);
-  hipLaunchKernelGGL(k_ce_bwd, dim3(grid_for((int64_t)rows * 64)), dim3(kThreads), 0, stream(), logits,
+  DF_LAUNCH(k_ce_bwd, dim3(grid_for((int64_t)rows * 64)), dim3(kThreads), 0, stream(), logits,
                      target, gloss, dlogits, rows, cols, inv);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1630,16 +1630,16 @@ int dfhip_reduce_to_shape(const float* src, float* dst, int src_ndim, const int6
     bn_split(N, C, S, ipb);
     float* partial = workspace_small((size_t)C * S * sizeof(float));
     if (!partial) return DFHIP_OUT_OF_MEMORY;
-    hipLaunchKernelGGL(k_channel_sum, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), src, partial, N, C,
+    DF_LAUNCH(k_channel_sum, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), src, partial, N, C,
                        HW, S, ipb);
     DF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_channel_sum_finish, dim3((unsigned)df_ceil_div(C, kThreads)), dim3(kThreads), 0, stream(),
+    DF_LAUNCH(k_channel_sum_finish, dim3((unsigned)df_ceil_div(C, kThreads)), dim3(kThreads), 0, stream(),
                        partial, dst, C, S);
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
   }
   int blocks = (int)std::min<int64_t>(n_dst, (int64_t)num_cus() * 8);
-  hipLaunchKernelGGL(k_reduce_to_shape, dim3(blocks), dim3(kThreads), 0, stream(), src, dst, rs, n_dst,
+  DF_LAUNCH(k_reduce_to_shape, dim3(blocks), dim3(kThreads), 0, stream(), src, dst, rs, n_dst,
                      n_red);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1655,10 +1655,10 @@ int dfhip_reduce_axis(const float* src, float* dst, int64_t outer, int64_t red, 
   DF_CHECK_ARG(src && dst, "reduce_axis: null array");
   ProfScope prof("reduce_axis", 0.0, 4.0 * (double)(n * red + n));
   if (op == 0)
-    hipLaunchKernelGGL((k_reduce_axis<false>), dim3(grid_for(n)), dim3(kThreads), 0, stream(), src, dst,
+    DF_LAUNCH((k_reduce_axis<false>), dim3(grid_for(n)), dim3(kThreads), 0, stream(), src, dst,
                        outer, red, inner, scale);
   else
-    hipLaunchKernelGGL((k_reduce_axis<true>), dim3(grid_for(n)), dim3(kThreads), 0, stream(), src, dst,
+    DF_LAUNCH((k_reduce_axis<true>), dim3(grid_for(n)), dim3(kThreads), 0, stream(), src, dst,
                        outer, red, inner, scale);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1672,7 +1672,7 @@ int dfhip_broadcast_axis(const float* src, float* dst, int64_t outer, int64_t re
   if (n == 0) return DFHIP_OK;
   DF_CHECK_ARG(src && dst, "broadcast_axis: null array");
   ProfScope prof("broadcast_axis", 0.0, 4.0 * (double)(n + outer * inner));
-  hipLaunchKernelGGL(k_broadcast_axis, dim3(grid_for(n)), dim3(kThreads), 0, stream(), src, dst, outer,
+  DF_LAUNCH(k_broadcast_axis, dim3(grid_for(n)), dim3(kThreads), 0, stream(), src, dst, outer,
                      red, inner, scale);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1684,7 +1684,7 @@ int dfhip_axpy(float* dst, const float* src, float alpha, int64_t n) {
   if (n == 0) return DFHIP_OK;
   DF_CHECK_ARG(dst && src, "axpy: null array");
   ProfScope prof("axpy", 0.0, 12.0 * (double)n);
-  hipLaunchKernelGGL(k_axpy, dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), dst, src, alpha, n);
+  DF_LAUNCH(k_axpy, dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), dst, src, alpha, n);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -1717,7 +1717,7 @@ int dfhip_adam_step(int n_tensors, float* const* params, const float* const* gra
     int n = std::min(kBatch, n_tensors - first);
     TensorBatch tb;
     int blocks = fill_batch(tb, n, first, params, grads, exp_avg, exp_avg_sq, sizes);
-    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(kThreads), 0, stream(), tb, h);
+    DF_LAUNCH(k_adam, dim3(blocks), dim3(kThreads), 0, stream(), tb, h);
     DF_LAUNCH_CHECK();
   }
   return DFHIP_OK;
@@ -1745,7 +1745,7 @@ int dfhip_adam_hyper(float* hyper_dev, double lr, double beta1, double beta2, do
   DF_INIT();
   DF_CHECK_ARG(hyper_dev && step >= 1, "adam_hyper: bad arguments");
   AdamHyper h = make_adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
-  hipLaunchKernelGGL(k_set_adam_hyper, dim3(1), dim3(1), 0, stream(), (AdamHyper*)hyper_dev, h);
+  DF_LAUNCH(k_set_adam_hyper, dim3(1), dim3(1), 0, stream(), (AdamHyper*)hyper_dev, h);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -1764,7 +1764,7 @@ int dfhip_adam_step_dev(int n_tensors, float* const* params, const float* const*
     int n = std::min(kBatch, n_tensors - first);
     TensorBatch tb;
     int blocks = fill_batch(tb, n, first, params, grads, exp_avg, exp_avg_sq, sizes);
-    hipLaunchKernelGGL(k_adam_dev, dim3(blocks), dim3(kThreads), 0, stream(), tb, (const AdamHyper*)hyper_dev);
+    DF_LAUNCH(k_adam_dev, dim3(blocks), dim3(kThreads), 0, stream(), tb, (const AdamHyper*)hyper_dev);
     DF_LAUNCH_CHECK();
   }
   return DFHIP_OK;
@@ -1793,7 +1793,7 @@ int dfhip_sgd_step(int n_tensors, float* const* params, const float* const* grad
     TensorBatch tb;
     int blocks = fill_batch(tb, n, first, params, grads, h.use_momentum ? momentum_buf : nullptr,
                             nullptr, sizes);
-    hipLaunchKernelGGL(k_sgd, dim3(blocks), dim3(kThreads), 0, stream(), tb, h);
+    DF_LAUNCH(k_sgd, dim3(blocks), dim3(kThreads), 0, stream(), tb, h);
     DF_LAUNCH_CHECK();
   }
   return DFHIP_OK;
@@ -1818,7 +1818,7 @@ static int pack_impl(int n_tensors, float* const* dsts, const float* const* srcs
       tb.s2[i] = (float*)(intptr_t)off;  // element offset inside this batch's span
       off += sizes[first + i];
     }
-    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(kThreads), 0, stream(), tb, flat, base, dir);
+    DF_LAUNCH(k_pack, dim3(blocks), dim3(kThreads), 0, stream(), tb, flat, base, dir);
     DF_LAUNCH_CHECK();
     base += off;
   }

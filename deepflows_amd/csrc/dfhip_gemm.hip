@@ -274,7 +274,7 @@ int launch_cfg(const float* a, const float* b, const float* bias, float* out, in
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
       attr_set = true;                                                                            \
     }                                                                                             \
-    hipLaunchKernelGGL((k_gemm<TM, TN, AK, BKC>), grid, dim3(256), lds, stream(), a, b, kbias,    \
+    DF_LAUNCH((k_gemm<TM, TN, AK, BKC>), grid, dim3(256), lds, stream(), a, b, kbias,    \
                        dst, M, K, P, a_sm, a_sk, b_sk, b_sp, k_per_split, slab);                  \
   } while (0)
   bool ak = !ta, bk = tb != 0;
@@ -287,7 +287,7 @@ int launch_cfg(const float* a, const float* b, const float* bias, float* out, in
   if (splits > 1) {
     int64_t n = slab;
     int blocks = (int)std::min<int64_t>(df_ceil_div(n, 256), (int64_t)num_cus() * 8);
-    hipLaunchKernelGGL(k_slab_sum, dim3(blocks), dim3(256), 0, stream(), dst, bias, out, n, splits, P);
+    DF_LAUNCH(k_slab_sum, dim3(blocks), dim3(256), 0, stream(), dst, bias, out, n, splits, P);
     DF_LAUNCH_CHECK();
   }
   return DFHIP_OK;
@@ -306,7 +306,7 @@ int gemm_dispatch(const float* a, const float* b, const float* bias, float* out,
   int M = (int)m, K = (int)k, P = (int)p;
   int cus = num_cus();
   if (2.0 * (double)m * (double)k * (double)p < 8.0e6 && K >= 64 && K <= 4096) {
-    hipLaunchKernelGGL(k_gemm_small, dim3((unsigned)df_ceil_div(P, 32), (unsigned)df_ceil_div(M, 32)), dim3(512), 0,
+    DF_LAUNCH(k_gemm_small, dim3((unsigned)df_ceil_div(P, 32), (unsigned)df_ceil_div(M, 32)), dim3(512), 0,
                        stream(), a, b, bias, out, M, K, P, ta ? (int64_t)1 : (int64_t)K, ta ? (int64_t)M : (int64_t)1,
                        tb ? (int64_t)1 : (int64_t)P, tb ? (int64_t)K : (int64_t)1);
     DF_LAUNCH_CHECK();
@@ -351,7 +351,7 @@ int dfhip_linear_backward(const float* x, const float* w, const float* dy, float
     const int nw = dw ? (int)(df_ceil_div(p, 32) * df_ceil_div(k, 32)) : 0;
     const int nb = db ? 1 : 0;
     if (nx + nw + nb == 0) return DFHIP_OK;
-    hipLaunchKernelGGL(k_linear_bwd_small, dim3((unsigned)(nx + nw + nb)), dim3(512), 0, stream(), x, w, dy, dx, dw, db,
+    DF_LAUNCH(k_linear_bwd_small, dim3((unsigned)(nx + nw + nb)), dim3(512), 0, stream(), x, w, dy, dx, dw, db,
                        (int)m, (int)k, (int)p, nx, nw);
     DF_LAUNCH_CHECK();
     return DFHIP_OK;

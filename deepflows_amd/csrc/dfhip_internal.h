@@ -1,6 +1,7 @@
 // Internal helpers shared by the libdfhip translation units (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -18,12 +19,17 @@ int num_cus();
 
 // RAII HIP-event bracket around one kernel family launch (active only if profiling on)
 struct ProfScope {
-  int slot;
+  int slot, prev;
   hipEvent_t e0, e1;
   bool on;
   ProfScope(const char* family, double flops, double bytes);
   ~ProfScope();
 };
+
+// Inside an active ProfScope every launch also gets an event pair BOUND TO ITS DISPATCH (hipExtLaunchKernelGGL:
+// the pair reads the kernel's own start / end time stamps, what rocprofv3's kernel trace reports); false when no
+// scope is active.
+bool prof_kernel_events(hipEvent_t* start, hipEvent_t* stop);
 
 // scratch workspace (grown on demand, never shrunk); stream-ordered reuse
 float* workspace(size_t bytes);
@@ -50,6 +56,16 @@ int run_conv_rowmma_dgrad(const float* dy, const float* w, const float* add, flo
                           int O, int k, int stride, int pad);
 
 }  // namespace dfhip
+
+// every kernel launch of the library
+#define DF_LAUNCH(kern, grid, block, lds, strm, ...)                                                  \
+  do {                                                                                                \
+    hipEvent_t pa__, pb__;                                                                            \
+    if (dfhip::prof_kernel_events(&pa__, &pb__))                                                      \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, strm, pa__, pb__, 0, __VA_ARGS__);                \
+    else                                                                                              \
+      hipLaunchKernelGGL(kern, grid, block, lds, strm, __VA_ARGS__);                                  \
+  } while (0)
 
 #define DF_CHECK_ARG(cond, ...)                      \
   do {                                               \

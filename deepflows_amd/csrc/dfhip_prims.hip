@@ -114,7 +114,7 @@ int launch_binary(const char* name, const float* a, const float* b, float* out, 
   DF_CHECK_ARG(a && b && out, "%s: null array", name);
   DF_CHECK_ARG(aligned16(a) && aligned16(b) && aligned16(out), "%s: arrays must be 16-byte aligned", name);
   ProfScope prof("ewise", 0.0, 12.0 * (double)n);
-  hipLaunchKernelGGL((k_ewise<Op>), dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), a, b, out, n, Op());
+  DF_LAUNCH((k_ewise<Op>), dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), a, b, out, n, Op());
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -127,7 +127,7 @@ int launch_scalar(const char* name, const float* a, float s, float* out, int64_t
   DF_CHECK_ARG(a && out, "%s: null array", name);
   DF_CHECK_ARG(aligned16(a) && aligned16(out), "%s: arrays must be 16-byte aligned", name);
   ProfScope prof("ewise", 0.0, 8.0 * (double)n);
-  hipLaunchKernelGGL((k_scalar<Op>), dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), a, s, out, n, Op());
+  DF_LAUNCH((k_scalar<Op>), dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), a, s, out, n, Op());
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -140,7 +140,7 @@ int launch_unary(const char* name, const float* a, float* out, int64_t n) {
   DF_CHECK_ARG(a && out, "%s: null array", name);
   DF_CHECK_ARG(aligned16(a) && aligned16(out), "%s: arrays must be 16-byte aligned", name);
   ProfScope prof("ewise", 0.0, 8.0 * (double)n);
-  hipLaunchKernelGGL((k_unary<Op>), dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), a, out, n, Op());
+  DF_LAUNCH((k_unary<Op>), dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), a, out, n, Op());
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -335,10 +335,10 @@ int reduce_rows(const char* name, const float* a, float* out, int64_t n_out, int
   DF_CHECK_ARG(rs > 0, "%s: reduce_size must be > 0", name);
   ProfScope prof("reduce", 0.0, 4.0 * (double)n_out * (double)(rs + 1));
   if (rs <= 16) {
-    hipLaunchKernelGGL((k_reduce_thread<IS_MAX>), dim3(grid_for(n_out)), dim3(kThreads), 0, stream(),
+    DF_LAUNCH((k_reduce_thread<IS_MAX>), dim3(grid_for(n_out)), dim3(kThreads), 0, stream(),
                        a, out, n_out, (int)rs);
   } else if (rs <= 4096 || n_out >= 4096) {
-    hipLaunchKernelGGL((k_reduce_wave<IS_MAX>), dim3(grid_for(n_out * 64)), dim3(kThreads), 0,
+    DF_LAUNCH((k_reduce_wave<IS_MAX>), dim3(grid_for(n_out * 64)), dim3(kThreads), 0,
                        stream(), a, out, n_out, rs);
   } else {
     int64_t want = df_ceil_div((int64_t)num_cus() * 4, n_out);
@@ -347,15 +347,15 @@ int reduce_rows(const char* name, const float* a, float* out, int64_t n_out, int
     if (splits < 1) splits = 1;
     int64_t chunk = (df_ceil_div(rs, (int64_t)splits) + 3) & ~(int64_t)3;
     if (splits == 1) {
-      hipLaunchKernelGGL((k_reduce_block<IS_MAX>), dim3((unsigned)n_out), dim3(kThreads), 0, stream(),
+      DF_LAUNCH((k_reduce_block<IS_MAX>), dim3((unsigned)n_out), dim3(kThreads), 0, stream(),
                          a, out, rs, 1, chunk);
     } else {
       float* tmp = workspace((size_t)n_out * splits * sizeof(float));
       if (!tmp) return DFHIP_OUT_OF_MEMORY;
-      hipLaunchKernelGGL((k_reduce_block<IS_MAX>), dim3((unsigned)(n_out * splits)), dim3(kThreads), 0,
+      DF_LAUNCH((k_reduce_block<IS_MAX>), dim3((unsigned)(n_out * splits)), dim3(kThreads), 0,
                          stream(), a, tmp, rs, splits, chunk);
       DF_LAUNCH_CHECK();
-      hipLaunchKernelGGL((k_reduce_wave<IS_MAX>), dim3(grid_for(n_out * 64)), dim3(kThreads), 0,
+      DF_LAUNCH((k_reduce_wave<IS_MAX>), dim3(grid_for(n_out * 64)), dim3(kThreads), 0,
                          stream(), tmp, out, n_out, (int64_t)splits);
     }
   }
@@ -376,7 +376,7 @@ int dfhip_fill(float* out, int64_t n, float val) {
   if (!aligned16(out)) {
     DF_CHECK_ARG(false, "fill: array must be 16-byte aligned");
   }
-  hipLaunchKernelGGL(k_fill, dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), out, n, val);
+  DF_LAUNCH(k_fill, dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), out, n, val);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -399,17 +399,17 @@ int dfhip_compact(const float* a, float* out, int64_t n_out, int ndim, const int
   if (v.ndim == 2 && v.strides[0] == 1 && v.strides[1] > 1 && v.shape[0] >= 32 && v.shape[1] >= 8) {
     dim3 grid((unsigned)df_ceil_div(v.shape[1], 32), (unsigned)df_ceil_div(v.shape[0], 32));
     if (grid.y <= 65535) {
-      hipLaunchKernelGGL(k_transpose2d, grid, dim3(kThreads), 0, stream(), a, out, v.shape[0],
+      DF_LAUNCH(k_transpose2d, grid, dim3(kThreads), 0, stream(), a, out, v.shape[0],
                          v.shape[1], v.strides[1], offset);
       DF_LAUNCH_CHECK();
       return DFHIP_OK;
     }
   }
   if (n_out < (int64_t)1 << 31)
-    hipLaunchKernelGGL((k_strided<0, true>), dim3(grid_for(n_out)), dim3(kThreads), 0, stream(), a, out,
+    DF_LAUNCH((k_strided<0, true>), dim3(grid_for(n_out)), dim3(kThreads), 0, stream(), a, out,
                        n_out, v, 0.0f);
   else
-    hipLaunchKernelGGL((k_strided<0, false>), dim3(grid_for(n_out)), dim3(kThreads), 0, stream(), a, out,
+    DF_LAUNCH((k_strided<0, false>), dim3(grid_for(n_out)), dim3(kThreads), 0, stream(), a, out,
                        n_out, v, 0.0f);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -425,9 +425,9 @@ int dfhip_ewise_setitem(const float* a, float* out, int64_t n, int ndim, const i
   DF_CHECK_ARG(a && out, "ewise_setitem: null array");
   ProfScope prof("setitem", 0.0, 8.0 * (double)n);
   if (n < (int64_t)1 << 31)
-    hipLaunchKernelGGL((k_strided<1, true>), dim3(grid_for(n)), dim3(kThreads), 0, stream(), a, out, n, v, 0.0f);
+    DF_LAUNCH((k_strided<1, true>), dim3(grid_for(n)), dim3(kThreads), 0, stream(), a, out, n, v, 0.0f);
   else
-    hipLaunchKernelGGL((k_strided<1, false>), dim3(grid_for(n)), dim3(kThreads), 0, stream(), a, out, n, v, 0.0f);
+    DF_LAUNCH((k_strided<1, false>), dim3(grid_for(n)), dim3(kThreads), 0, stream(), a, out, n, v, 0.0f);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -442,9 +442,9 @@ int dfhip_scalar_setitem(int64_t n, float val, float* out, int ndim, const int64
   DF_CHECK_ARG(out, "scalar_setitem: null array");
   ProfScope prof("setitem", 0.0, 4.0 * (double)n);
   if (n < (int64_t)1 << 31)
-    hipLaunchKernelGGL((k_strided<2, true>), dim3(grid_for(n)), dim3(kThreads), 0, stream(), nullptr, out, n, v, val);
+    DF_LAUNCH((k_strided<2, true>), dim3(grid_for(n)), dim3(kThreads), 0, stream(), nullptr, out, n, v, val);
   else
-    hipLaunchKernelGGL((k_strided<2, false>), dim3(grid_for(n)), dim3(kThreads), 0, stream(), nullptr, out, n, v, val);
+    DF_LAUNCH((k_strided<2, false>), dim3(grid_for(n)), dim3(kThreads), 0, stream(), nullptr, out, n, v, val);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }

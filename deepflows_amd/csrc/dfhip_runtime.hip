@@ -205,7 +205,12 @@ struct ProfSlot {
   double ms = 0, flops = 0, bytes = 0;
   int64_t calls = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  // event pairs bound to the dispatches themselves: kernel-only time of the family's launches
+  double kernel_ms = 0;
+  int64_t kernel_launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> kpending;
 };
+static int g_prof_scope = -1;           // slot of the innermost active ProfScope
 static bool g_prof_on = false;
 bool profiling() { return g_prof_on; }
 static std::vector<ProfSlot> g_prof;
@@ -231,6 +236,26 @@ static void prof_resolve(ProfSlot& s) {
     g_event_pool.push_back(pr.second);
   }
   s.pending.clear();
+  for (auto& pr : s.kpending) {
+    float ms = 0;
+    if (hipEventSynchronize(pr.second) == hipSuccess &&
+        hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      s.kernel_ms += ms;
+      s.kernel_launches++;
+    }
+    g_event_pool.push_back(pr.first);
+    g_event_pool.push_back(pr.second);
+  }
+  s.kpending.clear();
+}
+bool prof_kernel_events(hipEvent_t* start, hipEvent_t* stop) {
+  if (g_prof_scope < 0 || g_capture_open) return false;
+  hipEvent_t a = get_event(), b = get_event();
+  if (!a || !b) return false;
+  g_prof[g_prof_scope].kpending.emplace_back(a, b);
+  *start = a;
+  *stop = b;
+  return true;
 }
 ProfScope::ProfScope(const char* family, double flops, double bytes) : slot(-1), e0(nullptr), e1(nullptr), on(false) {
   if (!g_prof_on || g_capture_open) return;
@@ -249,14 +274,17 @@ ProfScope::ProfScope(const char* family, double flops, double bytes) : slot(-1),
   e1 = get_event();
   if (!e0 || !e1) return;
   on = true;
+  prev = g_prof_scope;
+  g_prof_scope = slot;
   (void)hipEventRecord(e0, g_stream);
 }
 ProfScope::~ProfScope() {
   if (!on) return;
+  g_prof_scope = prev;
   (void)hipEventRecord(e1, g_stream);
   ProfSlot& s = g_prof[slot];
   s.pending.emplace_back(e0, e1);
-  if (s.pending.size() > 2048) prof_resolve(s);
+  if (s.pending.size() > 2048 || s.kpending.size() > 4096) prof_resolve(s);
 }
 
 }  // namespace dfhip
@@ -599,16 +627,48 @@ int dfhip_prof_enable(int on) {
   g_prof_on = on != 0;
   return DFHIP_OK;
 }
+// A profiled eager step is issued through Python: the host needs about as long per launch as the kernels run, so
+// the queue runs dry and every event pair also measures the host's gap between the two records.  The gate holds the
+// stream (one thread polling a word of pinned host memory) while the host queues the whole step, events included;
+// opened, the launches run back to back as they do inside a replayed graph.  It gives up after `timeout_ms` (a
+// blocking call issued behind a closed gate must not hang the process).
+static int* g_gate_flag = nullptr;
+static int g_gate_gen = 0;
+__global__ void k_prof_gate(const int* flag, int gen, unsigned long long max_ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < gen) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) break;
+    __builtin_amdgcn_s_sleep(64);
+  }
+}
+int dfhip_prof_gate_close(int timeout_ms) {
+  if (g_capture_open) return DFHIP_OK;
+  if (!g_gate_flag) {
+    DF_HIP(hipHostMalloc((void**)&g_gate_flag, sizeof(int), hipHostMallocMapped));
+    *g_gate_flag = 0;
+  }
+  (void)flush_deferred();
+  if (timeout_ms <= 0 || timeout_ms > 200) timeout_ms = 200;
+  g_gate_gen++;
+  hipLaunchKernelGGL(k_prof_gate, dim3(1), dim3(1), 0, g_stream, (const int*)g_gate_flag, g_gate_gen,
+                     (unsigned long long)timeout_ms * 100000ull);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+int dfhip_prof_gate_open(void) {
+  if (g_gate_flag) __atomic_store_n(g_gate_flag, g_gate_gen, __ATOMIC_RELEASE);
+  return DFHIP_OK;
+}
 int dfhip_prof_reset(void) {
   for (auto& s : g_prof) {
     prof_resolve(s);
-    s.ms = s.flops = s.bytes = 0;
-    s.calls = 0;
+    s.ms = s.flops = s.bytes = s.kernel_ms = 0;
+    s.calls = s.kernel_launches = 0;
   }
   return DFHIP_OK;
 }
 int dfhip_prof_read(int cap, const char** names, double* total_ms, int64_t* calls,
-                    double* flops, double* bytes) {
+                    double* flops, double* bytes, double* kernel_ms, int64_t* kernel_launches) {
   (void)flush_deferred();
   int n = 0;
   for (auto& s : g_prof) {
@@ -620,6 +680,8 @@ int dfhip_prof_read(int cap, const char** names, double* total_ms, int64_t* call
     calls[n] = s.calls;
     flops[n] = s.flops;
     bytes[n] = s.bytes;
+    if (kernel_ms) kernel_ms[n] = s.kernel_ms;
+    if (kernel_launches) kernel_launches[n] = s.kernel_launches;
     n++;
   }
   return n;

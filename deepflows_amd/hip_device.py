@@ -468,6 +468,12 @@ class HipModule:
     def prof_reset(self):
         self._lib.dfhip_prof_reset()
 
+    def prof_gate_close(self, timeout_ms=100):
+        _lib.check(self._lib.dfhip_prof_gate_close(int(timeout_ms)))
+
+    def prof_gate_open(self):
+        self._lib.dfhip_prof_gate_open()
+
     def prof_read(self):
         cap = 64
         names = (c_char_p * cap)()
@@ -475,8 +481,11 @@ class HipModule:
         calls = (c_int64 * cap)()
         flops = (c_double * cap)()
         nbytes = (c_double * cap)()
-        n = self._lib.dfhip_prof_read(cap, names, ms, calls, flops, nbytes)
-        return {names[i].decode(): {"ms": ms[i], "calls": calls[i], "flops": flops[i], "bytes": nbytes[i]}
+        kms = (c_double * cap)()
+        klaunches = (c_int64 * cap)()
+        n = self._lib.dfhip_prof_read(cap, names, ms, calls, flops, nbytes, kms, klaunches)
+        return {names[i].decode(): {"ms": ms[i], "calls": calls[i], "flops": flops[i], "bytes": nbytes[i],
+                                    "kernel_ms": kms[i], "kernel_launches": klaunches[i]}
                 for i in range(n)}
 
 

@@ -329,9 +329,17 @@ int dfhip_event_destroy(void* ev);
  * bracketed by events on the library stream (used by bench.py for roofline.achieved).   */
 int dfhip_prof_enable(int on);
 int dfhip_prof_reset(void);
-/* returns number of families written; names are static strings */
+/* hold the library stream (a one-thread kernel polling pinned host memory, gives up after timeout_ms <= 200) while
+ * the host queues an eagerly issued step, then let it go: the event pairs then time launches that run back to back
+ * as in a replayed graph instead of the host's gaps between them.  No counterpart in the reference. */
+int dfhip_prof_gate_close(int timeout_ms);
+int dfhip_prof_gate_open(void);
+/* returns number of families written; names are static strings.  total_ms: between the two stream events
+ * around a family call (kernel + dispatch); kernel_ms / kernel_launches (may be NULL): sum and count of the
+ * family's kernels timed by event pairs bound to their dispatches (start / end stamps of the kernel itself, the
+ * figure rocprofv3's kernel trace reports) */
 int dfhip_prof_read(int cap, const char** names, double* total_ms, int64_t* calls,
-                    double* flops, double* bytes);
+                    double* flops, double* bytes, double* kernel_ms, int64_t* kernel_launches);
 
 #ifdef __cplusplus
 }
