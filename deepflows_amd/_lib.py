@@ -48,6 +48,9 @@ _SIGS = {
     "dfhip_conv2d_forward_stats": [P, P, P, P] + [c_int] * 8 + [P, c_int, POINTER(c_int)],
     "dfhip_bn2d_forward_partials": [P, P, c_int] + [P] * 8 + [c_int, c_int, c_int, c_float, c_float],
     "dfhip_conv2d_wgrad": [P, P, P] + [c_int] * 8,
+    "dfhip_conv2d_wgrad_affine": [P, P, P, P] + [c_int] * 8,
+    "dfhip_conv2d_forward_bn_input": [P, P, c_int, P, P, c_float, c_float, P, P, P, P, P, P, P, P] + [c_int] * 8 +
+                                     [P, c_int, POINTER(c_int), POINTER(c_int)],
     "dfhip_wgrad_group_begin": [],
     "dfhip_wgrad_group_end": [],
     "dfhip_conv2d_dgrad": [P, P, P] + [c_int] * 9,

@@ -2364,6 +2364,8 @@ struct GDesc {
   int single, kind, ps, CT, OT;
   int wg_end;                // workgroups of layers 0..this one (exclusive end of this layer's range)
   int direct;                // operands straight from global memory (units = units per block, m_br = magic(oh / UR))
+  const float* aff;          // direct only, or nullptr: C x (scale, shift), the source operand is x * scale + shift
+                             // (the BatchNorm a convolution applied to its input on load: dfhip_conv2d_forward_bn_input)
   unsigned long long* dbg;   // diagnostic builds: per-workgroup cycles (load issue, MFMA section) of wave 0
 };
 struct WGroup {
@@ -2486,16 +2488,28 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
   }
   constexpr int NIT = UR * KS * OW;                          // (ur, i, s) iterations of a unit, <= KS MFMAs each
   constexpr int STEP = NIT / NPIECE > 0 ? NIT / NPIECE : 1;
+  // affine source operand: a lane is a channel plane, so (scale, shift) are two registers of the lane; rows outside
+  // the image are never read by an MFMA (rowok), columns outside it do not exist in the code
+  const bool affine = d.aff != nullptr;
+  float aff_sc = 1.0f, aff_sh = 0.0f;
+  if (affine) { aff_sc = d.aff[2 * (by * 32 + l31)]; aff_sh = d.aff[2 * (by * 32 + l31) + 1]; }
   for (int u = u_lo + wave; u < u_hi; u += NW) {
     float a[UR][OW], b[NXR][W];
 #pragma unroll
     for (int ur = 0; ur < UR; ur++)
 #pragma unroll
       for (int s = 0; s < OW; s++) a[ur][s] = a_n[ur][s];
+    if (affine) {
 #pragma unroll
-    for (int xr = 0; xr < NXR; xr++)
+      for (int xr = 0; xr < NXR; xr++)
 #pragma unroll
-      for (int c = 0; c < W; c++) b[xr][c] = b_n[xr][c];
+        for (int c = 0; c < W; c++) b[xr][c] = fmaf(b_n[xr][c], aff_sc, aff_sh);
+    } else {
+#pragma unroll
+      for (int xr = 0; xr < NXR; xr++)
+#pragma unroll
+        for (int c = 0; c < W; c++) b[xr][c] = b_n[xr][c];
+    }
     const int rs = rs_n;
     const bool more = u + NW < u_hi;
     if (more) next_unit(u + NW);
@@ -3288,7 +3302,9 @@ struct GQueued {
 std::vector<GQueued> g_queue;
 bool g_group_on = false;
 int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
-                   int k, int stride, int pad);
+                   int k, int stride, int pad, const float* aff = nullptr);
+int wgrad_affine_materialised(const float* x, const float* aff, const float* dy, float* dw, int N, int C, int H, int W,
+                              int O, int oh, int ow, int k, int stride, int pad);
 
 // Side-stream flushes (DFHIP_WGRAD_SIDE=n): while a backward sweep is running, every n queued weight gradients are
 // launched on a second stream that forks off the library stream at that point -- the matrix-core-bound grouped
@@ -3325,7 +3341,11 @@ int group_flush() {
       g_group_on = false;
       int st = DFHIP_OK;
       for (auto& e : q) {
-        st = run_wgrad_rows(e.d.x, e.d.dy, e.dw, e.d.N, e.d.C, e.d.H, e.W, e.d.O, e.d.oh, e.ow, e.k, e.stride, e.pad);
+        if (e.d.aff)
+          st = wgrad_affine_materialised(e.d.x, e.d.aff, e.d.dy, e.dw, e.d.N, e.d.C, e.d.H, e.W, e.d.O, e.d.oh, e.ow,
+                                         e.k, e.stride, e.pad);
+        else
+          st = run_wgrad_rows(e.d.x, e.d.dy, e.dw, e.d.N, e.d.C, e.d.H, e.W, e.d.O, e.d.oh, e.ow, e.k, e.stride, e.pad);
         if (st != DFHIP_OK) break;
       }
       g_group_on = was;
@@ -3453,9 +3473,10 @@ int side_join() {
 
 // returns -1 when the shape is not one the row-unit kernel is built for
 int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
-                   int k, int stride, int pad) {
+                   int k, int stride, int pad, const float* aff) {
   static int enabled = getenv("DFHIP_WGRAD_ROWS") ? atoi(getenv("DFHIP_WGRAD_ROWS")) : 1;
   if (!enabled) return -1;
+  if (aff && !g_group_on) return -1;        // the affine operand exists in the grouped direct body only
   if (C < 16 || (N & 1)) return -1;
   const bool k3 = k == 3 && pad == 1, k1 = k == 1 && pad == 0 && stride == 2;
   if (!k3 && !k1) return -1;
@@ -3540,6 +3561,8 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
     d.single = g.single; d.kind = kind; d.ps = ps; d.CT = CT; d.OT = OT;
     e.dw = dw; e.T = k * k; e.lds = best_lds;
     static int direct_on = getenv("DFHIP_WGRAD_DIRECT") ? atoi(getenv("DFHIP_WGRAD_DIRECT")) : 1;
+    if (aff && !(direct_on && C % 32 == 0 && O % 32 == 0)) return -1;
+    d.aff = aff;
     if (direct_on && C % 32 == 0 && O % 32 == 0) {
       // operands straight from global memory: a block takes a contiguous run of units (a multiple of 4)
       const int upr = oh / UR, U = (N / 2) * upr;
@@ -3565,6 +3588,47 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
   DF_ROWS_KINDS(DF_ROWS)
 #undef DF_ROWS
   return -1;
+}
+
+// y[n][c][:] = x[n][c][:] * aff[c][0] + aff[c][1] (16-byte pieces; HW % 4 == 0)
+__global__ __launch_bounds__(256) void k_affine_nchw(const float* __restrict__ x, const float* __restrict__ aff,
+                                                    float* __restrict__ y, int C, int hw4, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i / hw4) % C);
+  const float sc = aff[2 * c], sh = aff[2 * c + 1];
+  float4 v = reinterpret_cast<const float4*>(x)[i];
+  v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+  reinterpret_cast<float4*>(y)[i] = v;
+}
+
+// fall-back of dfhip_conv2d_wgrad_affine: the operand is written out once and the weight gradient runs NOW on the
+// ordinary (ungrouped) paths -- a queued call would read the temporary after it has gone back to the pool
+int wgrad_affine_materialised(const float* x, const float* aff, const float* dy, float* dw, int N, int C, int H, int W,
+                              int O, int oh, int ow, int k, int stride, int pad) {
+  (void)oh; (void)ow;
+  if ((H * W) % 4 != 0) {
+    set_error("conv2d_wgrad_affine: H * W must be a multiple of 4");
+    return DFHIP_INVALID_ARGUMENT;
+  }
+  const int64_t n = (int64_t)N * C * H * W;
+  float* tmp = nullptr;
+  int st = dfhip_malloc(n, &tmp);
+  if (st != DFHIP_OK) return st;
+  DF_LAUNCH(k_affine_nchw, dim3((unsigned)df_ceil_div(n / 4, 256)), dim3(256), 0, stream(), x, aff, tmp, C, H * W / 4,
+            n / 4);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    (void)dfhip_free(tmp);
+    set_error("kernel launch failed: %s", hipGetErrorString(e));
+    return DFHIP_RUNTIME_ERROR;
+  }
+  const bool was = g_group_on;
+  g_group_on = false;
+  st = dfhip_conv2d_wgrad(tmp, dy, dw, N, C, H, W, O, k, stride, pad);
+  g_group_on = was;
+  (void)dfhip_free(tmp);                 // stream-ordered pool: later work on the stream may reuse it
+  return st;
 }
 
 // ---- tap-major weight gradient: plan + launch ----
@@ -3951,6 +4015,73 @@ int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C,
   if (OT == 1) return launch_wgrad<1, 1>(g, dw);
   if (KT == 4) return launch_wgrad<2, 4>(g, dw);
   return launch_wgrad<2, 1>(g, dw);
+}
+
+// dW of a convolution whose forward pass applied y = x * scale + shift (per source channel) to its operand on load
+// (dfhip_conv2d_forward_bn_input): the grouped direct body applies the same pair to its source rows; every other
+// situation writes the operand out once and takes the ordinary paths.
+int dfhip_conv2d_wgrad_affine(const float* x, const float* affine, const float* dy, float* dw, int N, int C, int H,
+                              int W, int O, int k, int stride, int pad) {
+  DF_INIT_KEEP();
+  DF_TOUCH(x);
+  DF_TOUCH(dy);
+  DF_TOUCH(dw);
+  int oh, ow;
+  int s = check_conv_args("conv2d_wgrad_affine", N, C, H, W, O, k, stride, pad, oh, ow);
+  if (s != DFHIP_OK) return s;
+  DF_CHECK_ARG(x && affine && dy && dw, "conv2d_wgrad_affine: null array");
+  if (g_group_on) {
+    int st = run_wgrad_rows(x, dy, dw, N, C, H, W, O, oh, ow, k, stride, pad, affine);
+    if (st >= 0) return st;
+  }
+  return wgrad_affine_materialised(x, affine, dy, dw, N, C, H, W, O, oh, ow, k, stride, pad);
+}
+
+// conv2d forward whose operand is the training-mode BatchNorm of x (no activation in between), x being the raw
+// output of the previous convolution and `partials_in` the BatchNorm partials that convolution left behind
+// (dfhip_conv2d_forward_stats).  Returns DFHIP_OK with *done = 1 when a kernel with that operand path took the
+// shape; *done = 0 (nothing launched, nothing written) otherwise -- the caller then runs BatchNorm and the
+// convolution separately.  By-products as dfhip_bn2d_forward_partials: save_mean / save_var (C), the running
+// statistics, plus affine_out (C x 2: scale, shift) for dfhip_conv2d_wgrad_affine.
+int dfhip_conv2d_forward_bn_input(const float* x, const float* partials_in, int rows_in, const float* gamma,
+                                  const float* beta, float eps, float momentum, float* save_mean, float* save_var,
+                                  float* running_mean, float* running_var, float* affine_out, const float* w,
+                                  const float* bias, float* y, int N, int C, int H, int W, int O, int k, int stride,
+                                  int pad, float* partials, int cap_rows, int* rows_out, int* done) {
+  DF_INIT();
+  int oh, ow;
+  int s = check_conv_args("conv2d_forward_bn_input", N, C, H, W, O, k, stride, pad, oh, ow);
+  if (s != DFHIP_OK) return s;
+  DF_CHECK_ARG(x && w && y && partials_in && save_mean && save_var && affine_out && done,
+               "conv2d_forward_bn_input: null array");
+  *done = 0;
+  if (rows_out) *rows_out = 0;
+  static int enabled = getenv("DFHIP_BN_INPUT") ? atoi(getenv("DFHIP_BN_INPUT")) : 1;
+  if (!enabled) return DFHIP_OK;
+  BnInput bn = {};
+  bn.part = partials_in; bn.rows = rows_in; bn.gamma = gamma; bn.beta = beta; bn.eps = eps; bn.momentum = momentum;
+  bn.save_mean = save_mean; bn.save_var = save_var; bn.running_mean = running_mean; bn.running_var = running_var;
+  bn.affine = affine_out;
+  double flops = 2.0 * N * oh * ow * (double)C * k * k * O;
+  double bytes = 4.0 * ((double)N * C * H * W + (double)O * C * k * k + (double)N * O * oh * ow);
+  // (shape test first: a call that launches nothing must not count as a launch of the family)
+  const bool want = partials && rows_out;
+  int rows = 0;
+  if (run_conv_rowmma(x, w, bias, y, N, C, H, W, O, k, stride, pad, want ? partials : nullptr, cap_rows, &rows, &bn, true) < 0)
+    return DFHIP_OK;
+  int st = bn_finalize_partials(bn, C);
+  if (st < 0) return DFHIP_OK;
+  if (st != DFHIP_OK) return st;
+  ProfScope prof("conv2d_fwd_igemm", flops, bytes);
+  st = run_conv_rowmma(x, w, bias, y, N, C, H, W, O, k, stride, pad, want ? partials : nullptr, cap_rows, &rows, &bn);
+  if (st < 0) {
+    set_error("conv2d_forward_bn_input: the shape test and the kernel's own disagree (N %d C %d H %d W %d O %d)", N, C, H, W, O);
+    return DFHIP_RUNTIME_ERROR;
+  }
+  if (st != DFHIP_OK) return st;
+  if (want) *rows_out = rows;
+  *done = 1;
+  return DFHIP_OK;
 }
 
 // Grouped weight gradients.  Between _begin and _end, dfhip_conv2d_wgrad calls whose shape the

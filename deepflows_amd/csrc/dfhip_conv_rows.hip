@@ -31,6 +31,8 @@ using namespace dfhip;
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -75,13 +77,23 @@ __device__ unsigned long long g_rows_stamps[512 * 8 * 8];
 // 1 / pad 1 convolution of dY with the weights transposed and flipped: x = dY (C = the convolution's output
 // channels), O = its input channels, operand (d, s, t) = w[s][d][8 - t]; `bias` is then a TENSOR of the output's
 // shape that is added to the result (the gradient the input already holds, tensor.py:444), not a vector.
-template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, int XA, bool DG>
+// EW: every weight chunk is requested in the prologue and committed during the first half of chunk 0's MFMAs: ONE
+// barrier inside the reduction instead of one per chunk (each cost the workgroup ~1 600 cycles of matrix-pipe time).
+// BNI: x is the RAW output of the previous convolution and the operand of this one is its training-mode BatchNorm
+// (batchnorm.py:30-55, no activation in between: test/ResNet_CIFAR10_cuda.py:31-35): bn.affine holds the per-channel
+// (scale, shift) of that BatchNorm (dfhip_bn2d_finalize_partials: a few-microsecond launch that combines the
+// partials the producer left behind), a workgroup copies it to LDS, and a pixel operand becomes
+// fma(raw, scale, shift) on its way out of the load registers -- the normalised tensor is never written or read.
+// (Combining the partials inside this kernel instead -- every workgroup for itself, 100 KB of rows each -- cost
+// 2-3.7 us per launch: 256 workgroups pulling the same lines through L2 at the same moment.)
+template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, int XA, bool DG, bool EW, bool BNI>
 __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                       float* __restrict__ partials, int H, int O) {
+                                                       float* __restrict__ partials, int H, int O, BnInput bn) {
   static_assert(TS * OW == 8, "a workgroup is eight waves");
   extern __shared__ __attribute__((aligned(16))) float Wl[];   // [OW][C/4*9/4 blocks][64 lanes][4] at pitch kBlk
   __shared__ float sred[8][16][2];
+  __shared__ __attribute__((aligned(8))) float bn_tab[BNI ? C : 1][2];
   constexpr int W = 1 << LW;
   constexpr int NG = C / 4;                    // channel groups (one MFMA k-step each)
   constexpr int NCH = NG / CG;                 // weight chunks
@@ -97,15 +109,24 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   const int T0 = (blockIdx.x * TS + ts) * NT;  // first pixel tile of this wave
   RS_STAMP(6);
   RS_STAMP(0);
+  // ---- BNI: the (scale, shift) pair of this thread's channel is requested first (dfhip_bn2d_finalize_partials wrote
+  // the table from the producer's partials) ----
+  f32x2 bn_pair = {1.0f, 0.0f};
+  if constexpr (BNI) {
+    if (tid < C) bn_pair = *reinterpret_cast<const f32x2*>(bn.affine + 2 * tid);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 
   // ---- weight chunk staging: thread -> a 16-byte piece of the chunk's weights; TOT4 pieces per chunk ----
   //   forward: OW x 16 rows (output channels) of 36 * CG contiguous floats (CG groups of 4 source channels x 9 taps)
   //   DG:      4 * CG source channels (rows of w) x OW runs of 144 contiguous floats (16 destination channels x 9 taps)
   constexpr int ROW4 = 9 * CG, TOT4 = OW * 16 * ROW4, PER = (TOT4 + 511) / 512;
   const float* wsrc[PER];
-  int wdst[PER];                               // LDS float index of the piece's (tile, row) part
-  int we4[PER];                                // forward: piece within the row; DG: piece within the 144-float run
-  int wsl[PER];                                // DG: source channel within the chunk
+  // LDS float index of every element of the piece within chunk 0 (operand f = p * 9 + t of lane (kk, m) lives at block
+  // f / 4, slot (kk * 16 + m) * 4 + f % 4); resolved ONCE: a commit is then PER * 4 plain ds_write_b32 at a compile-time
+  // chunk offset -- with the index arithmetic inside the commit both waves of a SIMD spent ~600 cycles per chunk on
+  // it at the same time, with nothing in the matrix pipe
+  int woff[PER][4];
 #pragma unroll
   for (int u = 0; u < PER; u++) {
     // (threads past the end re-do the piece 512 places back: every load has an UNCONDITIONAL consumer -- under a
@@ -116,45 +137,48 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
       const int tl = qq / (16 * ROW4), r = qq - tl * (16 * ROW4);
       const int m = r / ROW4, e4 = r - m * ROW4;
       wsrc[u] = w + ((int64_t)((blockIdx.y * OW + tl) * 16 + m) * C * 9) + 4 * e4;
-      wdst[u] = tl * (NBLK * kBlk) + m * 4;
-      we4[u] = e4;
-      wsl[u] = 0;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int idx = 4 * e4 + e;
+        const int c = idx / 9, t = idx - 9 * c;
+        const int f = (c >> 2) * 9 + t;
+        woff[u][e] = tl * (NBLK * kBlk) + (f >> 2) * kBlk + (c & 3) * 64 + m * 4 + (f & 3);
+      }
     } else {
       const int sl = qq / (OW * 36), r = qq - sl * (OW * 36);
       const int tl = r / 36, e4 = r - tl * 36;
       wsrc[u] = w + ((int64_t)sl * O + (blockIdx.y * OW + tl) * 16) * 9 + 4 * e4;
-      wdst[u] = tl * (NBLK * kBlk);
-      we4[u] = e4;
-      wsl[u] = sl;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int idx = 4 * e4 + e;
+        const int m = idx / 9, t = idx - 9 * m;          // destination channel in the tile, tap of w
+        const int f = (sl >> 2) * 9 + (8 - t);           // flipped tap
+        woff[u][e] = tl * (NBLK * kBlk) + (f >> 2) * kBlk + (sl & 3) * 64 + m * 4 + (f & 3);
+      }
     }
   }
   const int64_t wchunk = DG ? (int64_t)(4 * CG) * O * 9 : 36 * CG;     // floats between two chunks of a piece
-  f32x4 wv[2][PER];                            // two chunks in flight
+  f32x4 wv[EW ? NCH : 2][PER];                 // two chunks in flight (EW: all of them)
+#define RM_WSLOT(chunk) (EW ? (chunk) : (chunk) & 1)
 #define RM_WLOAD(chunk)                                                                         \
   do {                                                                                          \
     _Pragma("unroll") for (int u = 0; u < PER; u++)                                             \
-      wv[(chunk) & 1][u] = *reinterpret_cast<const f32x4*>(wsrc[u] + (chunk) * wchunk);         \
+      wv[RM_WSLOT(chunk)][u] = *reinterpret_cast<const f32x4*>(wsrc[u] + (chunk) * wchunk);     \
   } while (0)
-  // operand f = p * 9 + t of lane (kk, m) lives at block (f / 4), slot (kk * 16 + m) * 4 + f % 4
 #define RM_WCOMMIT(chunk)                                                                       \
   do {                                                                                          \
     _Pragma("unroll") for (int u = 0; u < PER; u++) {                                           \
-      _Pragma("unroll") for (int e = 0; e < 4; e++) {                                           \
-        const int idx = 4 * we4[u] + e;                                                         \
-        if constexpr (!DG) {                                                                    \
-          const int c = idx / 9, t = idx - 9 * c;                                               \
-          const int f = (c >> 2) * 9 + t;                                                       \
-          Wl[wdst[u] + ((chunk) * CBLK + (f >> 2)) * kBlk + (c & 3) * 64 + (f & 3)] = wv[(chunk) & 1][u][e]; \
-        } else {                                                                                \
-          const int m = idx / 9, t = idx - 9 * m;       /* destination channel in the tile, tap of w */ \
-          const int f = (wsl[u] >> 2) * 9 + (8 - t);    /* flipped tap */                       \
-          Wl[wdst[u] + ((chunk) * CBLK + (f >> 2)) * kBlk + (wsl[u] & 3) * 64 + m * 4 + (f & 3)] = wv[(chunk) & 1][u][e]; \
-        }                                                                                       \
-      }                                                                                         \
+      _Pragma("unroll") for (int e = 0; e < 4; e++)                                             \
+        Wl[woff[u][e] + (chunk) * (CBLK * kBlk)] = wv[RM_WSLOT(chunk)][u][e];                   \
     }                                                                                           \
   } while (0)
   RM_WLOAD(0);
-  if (NCH > 1) RM_WLOAD(1);
+  if constexpr (EW) {
+#pragma unroll
+    for (int c1 = 1; c1 < NCH; c1++) RM_WLOAD(c1);
+  } else {
+    if (NCH > 1) RM_WLOAD(1);
+  }
   __builtin_amdgcn_sched_barrier(0);           // the weight loads stay in front of the pixel loads
 
   // ---- per-lane source offsets (elements from x, channel group 0) and validity of every load ----
@@ -162,6 +186,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   // returns zero for it, which is the padding)
   constexpr unsigned kOut = 0x80000000u;
   unsigned xo[NL];
+  float vm[NL];                               // BNI: 1 / 0, the load's source row is inside the image
   float m_l[NT], m_r[NT];                     // narrower images: 0 for the lanes whose left / right neighbour is across a row end
   int img_t[NT], rem_t[NT];
   if constexpr (LW == 4) {
@@ -170,6 +195,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
     for (int r = 0; r < NT + 2; r++) {
       const int yy = y0 - 1 + r;
       xo[r] = (yy >= 0 && yy < H) ? (unsigned)((((int64_t)img * C + kk) * H + yy) * W + n) * 4u : kOut;
+      vm[r] = (yy >= 0 && yy < H) ? 1.0f : 0.0f;
     }
 #pragma unroll
     for (int t = 0; t < NT; t++) { img_t[t] = img; rem_t[t] = (y0 + t) * W; m_l[t] = 1.0f; m_r[t] = 1.0f; }
@@ -183,11 +209,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
       m_l[t] = xx == 0 ? 0.0f : 1.0f; m_r[t] = xx == W - 1 ? 0.0f : 1.0f;
       if constexpr (VDPP) {
         xo[t] = (unsigned)(((int64_t)img * C + kk) * HW + rem) * 4u;
+        vm[t] = 1.0f;
       } else {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
           const int ys = yy + i - 1;
           xo[t * 3 + i] = (ys >= 0 && ys < H) ? (unsigned)((((int64_t)img * C + kk) * H + ys) * W + xx) * 4u : kOut;
+          vm[t * 3 + i] = (ys >= 0 && ys < H) ? 1.0f : 0.0f;
         }
       }
     }
@@ -195,18 +223,27 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   // pixel operands: buffer loads, the lane's offset is one VGPR per load kind, the channel group's a scalar
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7fffffff, 0x00020000);   // (tensors are < 2^31 bytes: check_conv_args)
   float raw[NG][NL];
+#ifdef DFHIP_ROWS_NOXLOAD      // diagnostic build (timing only, wrong results): no pixel loads
+#define RM_XVALUE(u, p_) __int_as_float((int)xo[u] + (p_))
+#else
+#define RM_XVALUE(u, p_) __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)xo[u], (p_) * (16 * HW), 0))
+#endif
 #define RM_XLOAD(chunk)                                                                                          \
   do {                                                                                                           \
     _Pragma("unroll") for (int g_ = 0; g_ < CG; g_++) {                                                          \
       const int p_ = (chunk) * CG + g_;                                                                          \
       _Pragma("unroll") for (int u = 0; u < NL; u++)                                                             \
-        raw[p_][u] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)xo[u], p_ * (16 * HW), 0)); \
+        raw[p_][u] = RM_XVALUE(u, p_);                                                                           \
       __builtin_amdgcn_sched_barrier(0);       /* group by group: the first group lands first */                 \
     }                                                                                                            \
   } while (0)
 #pragma unroll
   for (int c0 = 0; c0 < XA && c0 < NCH; c0++) RM_XLOAD(c0);
   RS_STAMP(1);
+  if constexpr (BNI) {
+    if (tid < C) { bn_tab[tid][0] = bn_pair[0]; bn_tab[tid][1] = bn_pair[1]; }
+    // (the table becomes visible with the barrier behind the first weight commit)
+  }
   RM_WCOMMIT(0);
   RS_STAMP(2);
   __syncthreads();
@@ -253,29 +290,63 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
       }
     }
   };
-  if constexpr (LW < 4) make_shifts(bsh[0], raw[0]);
+  // BNI: the (scale, shift) pair of a lane's channel of group q, read from the LDS table two groups before its use;
+  // a load whose source row is outside the image returned 0 and must stay 0 (the padding is of the NORMALISED tensor)
+  f32x2 tabr[BNI ? NG : 1];
+  auto bn_apply = [&](float (&dst)[NL], const float (&rw)[NL], const f32x2 t2) {
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+      float v = BNI ? fmaf(rw[u], t2[0], t2[1]) : rw[u];
+      if constexpr (BNI && !VDPP) {
+        if (LW == 4 ? (u == 0 || u == NT + 1) : (u % 3 != 1)) v *= vm[u];
+      }
+      dst[u] = v;
+    }
+  };
+  if constexpr (BNI) {
+    tabr[0] = *reinterpret_cast<const f32x2*>(&bn_tab[kk][0]);
+    if (NG > 1) tabr[1] = *reinterpret_cast<const f32x2*>(&bn_tab[4 + kk][0]);
+  }
+  if constexpr (LW < 4) {
+    float nr[NL];
+    bn_apply(nr, raw[0], tabr[0]);
+    make_shifts(bsh[0], nr);
+  }
 #pragma unroll
   for (int ch = 0; ch < NCH; ch++) {
     // chunk ch + 1 (requested a chunk ago) is committed now and made visible by a barrier in the MIDDLE of this
     // chunk's MFMAs, where no wave waits for anything else; chunk ch + 2 and the pixels of ch + XA are requested
-    if (ch + 1 < NCH) RM_WCOMMIT(ch + 1);
-    if (ch + 2 < NCH) RM_WLOAD(ch + 2);
+    if constexpr (EW) {
+      if (ch == 0) {
+#pragma unroll
+        for (int c1 = 1; c1 < NCH; c1++) RM_WCOMMIT(c1);
+      }
+    } else {
+      if (ch + 1 < NCH) RM_WCOMMIT(ch + 1);
+      if (ch + 2 < NCH) RM_WLOAD(ch + 2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (ch + XA < NCH) RM_XLOAD(ch + XA);
     for (int g = 0; g < CG; g++) {
       const int p = ch * CG + g;
       if (g == CG / 2 && ch + 1 < NCH) {
-        __syncthreads();
+#ifndef DFHIP_ROWS_NOBAR        // (diagnostic build, timing only: no barrier inside the reduction)
+        if (!EW || ch == 0) __syncthreads();
+#endif
         // the next chunk's operands are visible now: read them here, half a chunk before their first use
 #pragma unroll
         for (int q = 0; q < CBLK; q++) a4[(ch + 1) & 1][q] = Wl4[((ch + 1) * CBLK + q) * (kBlk / 4)];
       }
+      if constexpr (BNI) {
+        if (p + 2 < NG) tabr[p + 2] = *reinterpret_cast<const f32x2*>(&bn_tab[4 * (p + 2) + kk][0]);
+      }
       // the nine pixel operands of every tile from this group's registers
       if constexpr (LW == 4) {
-        float c1[NT + 2], c0[NT + 2], c2[NT + 2];
+        float c1[NT + 2], c0[NT + 2], c2[NT + 2], nr[NL];
+        bn_apply(nr, raw[p], tabr[BNI ? p : 0]);
 #pragma unroll
         for (int r = 0; r < NT + 2; r++) {
-          c1[r] = raw[p][r];
+          c1[r] = nr[r];
           c0[r] = dpp_mov<kShr1>(c1[r]);
           c2[r] = dpp_mov<kShl1>(c1[r]);
         }
@@ -297,7 +368,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
         // that were loaded a chunk ago): an MFMA whose operand comes from the instruction in front of it stalls the
         // wave's issue, and with it the matrix pipe, for the latency of that instruction
         __builtin_amdgcn_sched_barrier(0);
-        if (p + 1 < NG) make_shifts(bsh[(p + 1) & 1], raw[p + 1]);
+        if (p + 1 < NG) {
+          float nr[NL];
+          bn_apply(nr, raw[p + 1], tabr[BNI ? p + 1 : 0]);
+          make_shifts(bsh[(p + 1) & 1], nr);
+        }
         float (&b)[NT][3][3] = bsh[p & 1];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
@@ -315,14 +390,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
 #pragma unroll
         for (int k2 = 0; k2 < 9 * NT; k2++) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, BNI ? 2 : 1, 0);
         }
       }
     }
   }
 #undef RM_WLOAD
+#undef RM_WSLOT
 #undef RM_WCOMMIT
 #undef RM_XLOAD
+#undef RM_XVALUE
 
   f32x4 res[NT];
 #pragma unroll
@@ -392,18 +469,21 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   RS_STAMP(7);
 }
 
-template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, int XA, bool DG = false>
+template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, int XA, bool DG = false, bool EW = false,
+          bool BNI = false>
 int launch_rowmma(const float* x, const float* w, const float* bias, float* y, float* partials, int H, int O,
-                  dim3 grid) {
+                  dim3 grid, const BnInput* bnp = nullptr) {
+  BnInput bn = {};
+  if (bnp) bn = *bnp;
   const size_t lds = (size_t)OW * (C / 4 * 9 / 4) * kBlk * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA, DG>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA, DG, EW, BNI>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536)));
     attr = true;
   }
-  DF_LAUNCH((k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA, DG>), grid, dim3(512), lds, stream(), x, w, bias, y,
-                     partials, H, O);
+  DF_LAUNCH((k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA, DG, EW, BNI>), grid, dim3(512), lds, stream(), x, w, bias, y,
+                     partials, H, O, bn);
   DF_LAUNCH_CHECK();
 #ifdef DFHIP_ROWS_STAMPS
   {
@@ -413,16 +493,20 @@ int launch_rowmma(const float* x, const float* w, const float* bias, float* y, f
       std::vector<unsigned long long> h(nw * 8);
       (void)hipStreamSynchronize(stream());
       (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_rows_stamps), nw * 8 * sizeof(unsigned long long));
-      double seg[6] = {0};
+      double seg[6] = {0}, cyc_sum = 0, cyc_max = 0, rt_sum = 0, rt_max = 0;
       unsigned long long r0 = ~0ull, r1 = 0, rs = 0;
       for (size_t i = 0; i < nw; i++) {
         const unsigned long long* r = &h[i * 8];
         for (int k = 1; k <= 5; k++) seg[k] += (double)(r[k] - r[k - 1]);
         r0 = std::min(r0, r[6]); r1 = std::max(r1, r[7]); rs = std::max(rs, r[6]);
+        const double cyc = (double)(r[5] - r[0]), rt = (double)(r[7] - r[6]);
+        cyc_sum += cyc; cyc_max = std::max(cyc_max, cyc); rt_sum += rt; rt_max = std::max(rt_max, rt);
       }
-      fprintf(stderr, "[rows-stamp] LW %d C %d NT %d TS %d OW %d CG %d XA %d grid %u x %u: first start -> last end %.2f us, last "
+      fprintf(stderr, "[rows-clock] cycles per wave mean %.0f max %.0f; wave life mean %.2f us max %.2f us -> %.3f GHz\n",
+              cyc_sum / nw, cyc_max, rt_sum / nw / 100.0, rt_max / 100.0, cyc_sum / rt_sum / 10.0);
+      fprintf(stderr, "[rows-stamp] LW %d C %d NT %d TS %d OW %d CG %d XA %d EW %d grid %u x %u: first start -> last end %.2f us, last "
               "wave starts +%.2f us; mean cycles per wave: issue %.0f, w-commit %.0f, barrier %.0f, mfma-loop %.0f, epilogue %.0f\n",
-              LW, C, NT, TS, OW, CG, XA, grid.x, grid.y, (double)(r1 - r0) / 100.0, (double)(rs - r0) / 100.0,
+              LW, C, NT, TS, OW, CG, XA, (int)EW, grid.x, grid.y, (double)(r1 - r0) / 100.0, (double)(rs - r0) / 100.0,
               seg[1] / nw, seg[2] / nw, seg[3] / nw, seg[4] / nw, seg[5] / nw);
     }
   }
@@ -436,7 +520,8 @@ namespace dfhip {
 
 // returns -1 when the shape is not one this kernel takes
 int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int O,
-                    int k, int stride, int pad, float* partials, int cap_rows, int* rows_out) {
+                    int k, int stride, int pad, float* partials, int cap_rows, int* rows_out, const BnInput* bn,
+                    bool dry_run) {
   static int enabled = getenv("DFHIP_ROWMMA") ? atoi(getenv("DFHIP_ROWMMA")) : 1;
   static int variant = getenv("DFHIP_ROWMMA_VARIANT") ? atoi(getenv("DFHIP_ROWMMA_VARIANT")) : 0;
   if (!enabled || k != 3 || stride != 1 || pad != 1) return -1;
@@ -455,6 +540,13 @@ int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y,
   if (gx * (O / (16 * ow)) < num_cus() / 2) return -1;   // too few workgroups: the staged kernel's k-split wins
   if (rows_out) *rows_out = partials ? (int)gx : 0;
   dim3 grid((unsigned)gx, (unsigned)(O / (16 * ow)));
+  if (dry_run) return DFHIP_OK;              // eligible: nothing launched
+  if (bn) {
+    if (!bn->affine) return -1;
+    if (W == 16) return launch_rowmma<4, 32, 4, false, 4, 2, 4, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
+    if (W == 8) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
+    return launch_rowmma<2, 128, 1, true, 8, 1, 8, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
+  }
   if (W == 16) {
     if (variant == 1) return launch_rowmma<4, 32, 4, false, 4, 2, 8, 1>(x, w, bias, y, partials, H, O, grid);
     if (variant == 2) return launch_rowmma<4, 32, 4, false, 4, 2, 4, 2>(x, w, bias, y, partials, H, O, grid);
@@ -463,10 +555,14 @@ int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y,
   if (W == 8) {
     if (variant == 1) return launch_rowmma<3, 64, 2, false, 4, 2, 8, 1>(x, w, bias, y, partials, H, O, grid);
     if (variant == 2) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 2>(x, w, bias, y, partials, H, O, grid);
+    if (variant == 3) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 1, false, true>(x, w, bias, y, partials, H, O, grid);
+    if (variant == 4) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 2, false, true>(x, w, bias, y, partials, H, O, grid);
     return launch_rowmma<3, 64, 2, false, 4, 2, 4, 1>(x, w, bias, y, partials, H, O, grid);
   }
   if (variant == 1) return launch_rowmma<2, 128, 1, true, 8, 1, 4, 2>(x, w, bias, y, partials, H, O, grid);
   if (variant == 2) return launch_rowmma<2, 128, 1, true, 8, 1, 8, 2>(x, w, bias, y, partials, H, O, grid);
+  if (variant == 3) return launch_rowmma<2, 128, 1, true, 8, 1, 8, 1, false, true>(x, w, bias, y, partials, H, O, grid);
+  if (variant == 4) return launch_rowmma<2, 128, 1, true, 8, 1, 4, 2, false, true>(x, w, bias, y, partials, H, O, grid);
   return launch_rowmma<2, 128, 1, true, 8, 1, 8, 1>(x, w, bias, y, partials, H, O, grid);
 }
 

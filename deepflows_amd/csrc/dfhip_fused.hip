@@ -1293,6 +1293,57 @@ int fill_batch(TensorBatch& tb, int n, int first, float* const* p, const float* 
 
 }  // namespace
 
+// (scale, shift) of a training-mode BatchNorm from convolution partials, nothing normalised: the consumer is a
+// convolution that applies the pair on its operand loads (dfhip_conv2d_forward_bn_input).  One wave per channel;
+// weighted mean first, then the centred second moment about it: two plain reductions, the same value in every lane.
+__global__ __launch_bounds__(256) void k_bn_finalize_partials(BnInput bn, int C) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  constexpr int RP = 8;                     // rows per lane: up to 512 rows
+  float pn[RP], pm[RP], pq[RP];
+#pragma unroll
+  for (int k = 0; k < RP; k++) {
+    const int r = lane + 64 * k;
+    pn[k] = 0.0f; pm[k] = 0.0f; pq[k] = 0.0f;
+    if (r < bn.rows) {
+      const float* p = bn.part + ((int64_t)r * C + c) * 3;
+      pn[k] = p[0]; pm[k] = p[1]; pq[k] = p[2];
+    }
+  }
+  float n = 0.0f, a = 0.0f;
+#pragma unroll
+  for (int k = 0; k < RP; k++) { n += pn[k]; a += pn[k] * pm[k]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { n += __shfl_xor(n, o, 64); a += __shfl_xor(a, o, 64); }
+  const float mu = n > 0.0f ? a / n : 0.0f;
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < RP; k++) { const float d = pm[k] - mu; q += pq[k] + pn[k] * d * d; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  if (lane != 0) return;
+  const float var = n > 0.0f ? q / n : 0.0f;           // biased variance (batchnorm.py:41-42)
+  const float rsd = 1.0f / sqrtf(var + bn.eps);
+  const float sc = (bn.gamma ? bn.gamma[c] : 1.0f) * rsd;
+  const float sh = (bn.beta ? bn.beta[c] : 0.0f) - mu * sc;
+  if (bn.save_mean) bn.save_mean[c] = mu;
+  if (bn.save_var) bn.save_var[c] = var;
+  if (bn.running_mean) bn.running_mean[c] = bn.running_mean[c] * (1.0f - bn.momentum) + mu * bn.momentum;
+  if (bn.running_var) bn.running_var[c] = bn.running_var[c] * (1.0f - bn.momentum) + var * bn.momentum;
+  bn.affine[2 * c] = sc;
+  bn.affine[2 * c + 1] = sh;
+}
+
+namespace dfhip {
+int bn_finalize_partials(const BnInput& bn, int C) {
+  if (bn.rows < 1 || bn.rows > 512 || !bn.part || !bn.affine) return -1;
+  ProfScope prof("bn2d_fwd", 0.0, 12.0 * (double)bn.rows * C);
+  DF_LAUNCH(k_bn_finalize_partials, dim3((unsigned)df_ceil_div(C, 4)), dim3(256), 0, stream(), bn, C);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+}  // namespace dfhip
+
 extern "C" {
 
 int dfhip_bn2d_forward_train(const float* x, const float* gamma, const float* beta, float* y,

@@ -48,9 +48,29 @@ int flush_deferred();
 bool deferred_touches(const void* p);
 int deferred_scratch_slot();          // scratch slot holding the pending slabs, -1 if none
 
+// A training-mode BatchNorm2d standing between two convolutions, applied by the SECOND one on its operand loads
+// (dfhip_conv2d_forward_bn_input): the partials the first convolution left behind and where the by-products go.
+struct BnInput {
+  const float* part;           // rows x C x (count, mean, centred second moment)
+  int rows;
+  const float* gamma;          // C (nullptr: 1)
+  const float* beta;           // C (nullptr: 0)
+  float eps, momentum;
+  float* save_mean;            // C: batch mean / biased variance for the backward pass
+  float* save_var;
+  float* running_mean;         // C or nullptr: updated in place (batchnorm.py:44-52)
+  float* running_var;
+  float* affine;               // C x (scale, shift): y = x * scale + shift, for the weight gradient
+};
+
+// dfhip_fused.hip: bn.part -> bn.affine (+ save_mean / save_var / running statistics); -1 when there is nothing to combine
+int bn_finalize_partials(const BnInput& bn, int C);
+
 // dfhip_conv_rows.hip: register-operand 3x3 / stride 1 / pad 1 forward kernel; -1 when the shape is not eligible
+// (bn: the operand is the BatchNorm of x, see BnInput)
 int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int O,
-                    int k, int stride, int pad, float* partials, int cap_rows, int* rows_out);
+                    int k, int stride, int pad, float* partials, int cap_rows, int* rows_out,
+                    const BnInput* bn = nullptr, bool dry_run = false);   // dry_run: only the shape test
 
 int run_conv_rowmma_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int C, int H, int W,
                           int O, int k, int stride, int pad);

@@ -222,6 +222,25 @@ class HipModule:
             # the call may only have been queued: x and dy must outlive the grouped launch
             self._wgrad_hold.append((x, dy, dw))
 
+    def conv2d_wgrad_affine(self, x, affine, dy, dw, N, C, H, W, O, k, stride, pad):
+        _lib.check(self._lib.dfhip_conv2d_wgrad_affine(x.ptr, affine.ptr, dy.ptr, dw.ptr, N, C, H, W, O, k, stride,
+                                                       pad))
+        if self._wgrad_hold is not None:
+            self._wgrad_hold.append((x, affine, dy, dw))
+
+    def conv2d_forward_bn_input(self, x, partials_in, rows_in, gamma, beta, eps, momentum, save_mean, save_var,
+                                running_mean, running_var, affine, w, bias, y, N, C, H, W, O, k, stride, pad,
+                                partials, cap_rows):
+        """conv2d(batch_norm_train(x)) with the normalisation applied on the operand loads; returns (done, rows):
+        done False = the shape has no such kernel (nothing was launched), rows = BatchNorm partial rows of y."""
+        g = lambda h: h.ptr if h is not None else None
+        rows, done = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._lib.dfhip_conv2d_forward_bn_input(
+            x.ptr, partials_in.ptr, int(rows_in), g(gamma), g(beta), float(eps), float(momentum), save_mean.ptr,
+            save_var.ptr, g(running_mean), g(running_var), affine.ptr, w.ptr, g(bias), y.ptr, N, C, H, W, O, k,
+            stride, pad, g(partials), int(cap_rows), ctypes.byref(rows), ctypes.byref(done)))
+        return bool(done.value), int(rows.value)
+
     # Grouped weight gradients (dfhip_wgrad_group_begin / _end): Tensor.backward() brackets its
     # sweep with these, so the weight gradients of all layers run as one launch when it ends.
     _wgrad_hold = None

@@ -485,6 +485,103 @@ class _BatchNorm2dPairFused(_FusedNode):
         raise RuntimeError("not a parent of this node")
 
 
+class _BnConv2dFused(_FusedNode):
+    """conv2d(batch_norm2d_train(x)) with NO activation in between -- `out = bn1(conv1(x)); out = conv2(out)` of
+    the reference's residual block (test/ResNet_CIFAR10_cuda.py:31-35) -- as one node.  x is conv1's raw output and
+    carries its BatchNorm partials; the convolution kernel combines them and normalises its operand on load, so the
+    normalised tensor is never written.  Backward = the reference's chain for the same graph: weight gradient of
+    the convolution (its A operand rebuilt from x and the saved scale / shift), input gradient of the convolution,
+    then BatchNorm backward from x and the saved batch statistics."""
+
+    @classmethod
+    def build(cls, x, bn, conv):
+        dev = x.device
+        part_in = getattr(x, "bn_partials", None)
+        if part_in is None or len(x.shape) != 4:
+            return None
+        N, C, H, W = (int(v) for v in x.shape)
+        w, cbias = conv.weight, conv.bias
+        O, _, k, _ = (int(v) for v in w.shape)
+        stride, padding = int(conv.stride), int(conv.padding)
+        oh = (H + 2 * padding - k) // stride + 1
+        ow = (W + 2 * padding - k) // stride + 1
+        geo = (N, C, H, W, O, k, stride, padding)
+        xd, wd = x.data.compact(), w.data.compact()
+        gd = bn.weight.data.compact() if bn.weight is not None else None
+        bd = bn.bias.data.compact() if bn.bias is not None else None
+        out = _new((N, O, oh, ow), dev)
+        mean, var = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+        affine = _new((C, 2), dev)
+        part_out = _new((_BN_PARTIAL_ROWS, O, 3), dev)
+        h = lambda t: t._handle if t is not None else None
+        rm = h(bn.running_mean.data) if bn.running_mean is not None else None
+        rv = h(bn.running_var.data) if bn.running_var is not None else None
+        done, rows = dev.conv2d_forward_bn_input(
+            xd._handle, part_in[0]._handle, part_in[1], h(gd), h(bd), float(bn.eps), float(bn.momentum),
+            mean._handle, var._handle, rm, rv, affine._handle, wd._handle,
+            h(cbias.data.compact()) if cbias is not None else None, out._handle, *geo, part_out._handle,
+            _BN_PARTIAL_ROWS)
+        if not done:
+            return None
+        node = cls.__new__(cls)
+        node.x, node.gamma, node.beta, node.w, node.cbias = x, bn.weight, bn.bias, w, cbias
+        node.xd, node.wd, node.gd = xd, wd, gd
+        node.mean, node.var, node.affine, node.eps, node.geo = mean, var, affine, float(bn.eps), geo
+        node.bn_partials = (part_out, rows) if rows > 0 else None
+        node._grads = None
+        _FusedNode.__init__(node, out, [x, bn.weight, bn.bias, w, cbias])
+        return node
+
+    def grad_fn(self, node, grad):
+        if self._grads is None or self._grads[0] is not grad:
+            g = grad.compact()
+            dev = g.device
+            N, C, H, W, O, k, stride, pad = self.geo
+            h = lambda t: t._handle if t is not None else None
+            dw = dcb = dx = dg = db = None
+            if self.w.requires_grad:
+                dw = _new(self.wd.shape, dev)
+                dev.conv2d_wgrad_affine(self.xd._handle, self.affine._handle, g._handle, dw._handle, *self.geo)
+            if self.cbias is not None and self.cbias.requires_grad:
+                dcb = _new(self.cbias.shape, dev)
+                dev.reduce_to_shape(g._handle, dcb._handle, g.shape, self.cbias.shape)
+            bn_needs = (self.x.requires_grad or (self.gamma is not None and self.gamma.requires_grad)
+                        or (self.beta is not None and self.beta.requires_grad))
+            if bn_needs:
+                da = _new(self.xd.shape, dev)                  # gradient of the (never materialised) normalised tensor
+                dev.conv2d_dgrad(g._handle, self.wd._handle, da._handle, *self.geo)
+                dx = _new(self.xd.shape, dev) if self.x.requires_grad else None
+                dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+                dev.bn2d_backward(da._handle, self.xd._handle, h(self.gd), self.mean._handle, self.var._handle,
+                                  h(dx), dg._handle, db._handle, N, C, H * W, self.eps)
+            self._grads = (grad, dx, dg, db, dw, dcb)
+        _, dx, dg, db, dw, dcb = self._grads
+        if node is self.x:
+            return dx
+        if node is self.gamma:
+            return dg
+        if node is self.beta:
+            return db
+        if node is self.w:
+            return dw
+        return dcb
+
+
+_BN_INPUT = os.environ.get("DF_BN_INPUT", "1") != "0"
+
+
+def bn_conv2d_train(x, bn, conv):
+    """conv(bn(x)) for a training-mode BatchNorm2d `bn` directly in front of the Conv2d `conv`, with the normalisation
+    applied on the convolution's operand loads (one node, no normalised tensor).  Returns None when that form does
+    not apply (not a fused device, evaluation mode, x carries no convolution partials, or the shape has no such
+    kernel): the caller then writes conv(bn(x))."""
+    mod = x.device.mod
+    if not (_BN_INPUT and _CONV_BN_STATS and _fused(x) and hasattr(mod, "conv2d_forward_bn_input") and bn.training
+            and is_grad_enable() and bn.weight is not None and bn.bias is not None):
+        return None
+    return _BnConv2dFused.build(x, bn, conv)
+
+
 def batch_norm2d_pair_fusable(xa, bn_a, xb, bn_b):
     """True when bn_a(xa) + bn_b(xb) can run as the paired node: fused device, both layers in training
     mode with affine parameters, equal shapes, both inputs carry convolution partials."""

@@ -101,8 +101,12 @@ class ResidualBlock(nn.Module):
         elif ds is not None:
             for layer in ds:
                 identity = layer(identity)
-        out = self.bn1(self.conv1(x))
-        z2 = self.conv2(out)
+        z1 = self.conv1(x)
+        # conv2(bn1(z1)): bn1 applied on conv2's operand loads (one node, bn1's output is never written); None when
+        # that form does not apply here
+        z2 = nn.functional.bn_conv2d_train(z1, self.bn1, self.conv2)
+        if z2 is None:
+            z2 = self.conv2(self.bn1(z1))
         if pair:
             if nn.functional.batch_norm2d_pair_fusable(z2, self.bn2, zd, ds[1]):
                 # bn2(conv2) + bn_d(conv_d) as one node: one launch each way for the two BatchNorms

@@ -137,6 +137,27 @@ int dfhip_conv2d_dgrad_add(const float* dy, const float* w, const float* add, fl
 int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw,
                        int N, int C, int H, int W, int O, int k, int stride, int pad);
 
+/* conv2d of the training-mode BatchNorm2d of x, with NO activation in between -- `out = bn1(conv1(x)); out =
+ * conv2(out)` of the reference's residual block (test/ResNet_CIFAR10_cuda.py:31-35; nn/modules/batchnorm.py:30-55
+ * followed by nn/functional.py:316-344): x is conv1's raw output, partials_in (rows_in x C x 3) the BatchNorm
+ * partials dfhip_conv2d_forward_stats left behind for it.  Every workgroup of the convolution combines the
+ * partials into a per-channel (scale, shift) table and applies it to its operand on load: the normalised tensor is
+ * never written or read.  By-products as dfhip_bn2d_forward_partials: save_mean / save_var (C; batch mean, biased
+ * variance), running_mean / running_var (C, updated in place, may be NULL), plus affine_out (C x 2: scale, shift).
+ * *done = 1 when a kernel with this operand path took the shape; 0 (nothing launched or written) otherwise -- the
+ * caller then runs dfhip_bn2d_forward_partials and dfhip_conv2d_forward_stats.  partials / cap_rows / rows_out:
+ * BatchNorm partials of y, as in dfhip_conv2d_forward_stats (partials may be NULL). */
+int dfhip_conv2d_forward_bn_input(const float* x, const float* partials_in, int rows_in, const float* gamma,
+                                  const float* beta, float eps, float momentum, float* save_mean, float* save_var,
+                                  float* running_mean, float* running_var, float* affine_out, const float* w,
+                                  const float* bias, float* y, int N, int C, int H, int W, int O, int k, int stride,
+                                  int pad, float* partials, int cap_rows, int* rows_out, int* done);
+/* weight gradient of that convolution: dw = A^T . dC (tensor.py:716) with A built from x * scale + shift per source
+ * channel (affine: C x 2, the table dfhip_conv2d_forward_bn_input wrote).  Queued like dfhip_conv2d_wgrad inside
+ * a group; x, affine and dy must then stay allocated until the group has run. */
+int dfhip_conv2d_wgrad_affine(const float* x, const float* affine, const float* dy, float* dw,
+                              int N, int C, int H, int W, int O, int k, int stride, int pad);
+
 /* Grouped weight gradients (extension; the reference computes A^T . dC inside each node's grad_fn,
  * tensor.py:716, but nothing reads a weight's .grad before backward() returns, tensor.py:421-499).
  * Between _begin and _end, dfhip_conv2d_wgrad calls are queued where the fast kernel takes the

@@ -317,6 +317,78 @@ def test_paired_batchnorm_matches_two_layers(hip_device):
         assert_close(a, b, 2e-5, "paired BatchNorm: " + nm)
 
 
+@pytest.mark.parametrize("C,HW,dgrad", [(32, 16, "overwrite"), (64, 8, "overwrite"), (128, 4, "overwrite"),
+                                         (64, 8, "accumulate")])
+def test_bn_applied_on_the_next_convolutions_loads(hip_device, C, HW, dgrad):
+    """conv2(bn1(conv1(x))) of a residual block (no activation in between) with bn1 applied on conv2's operand loads
+    (one node, bn1's output never written) against the three separate nodes: output, BatchNorm partials consumed by
+    the next BatchNorm, every gradient, running statistics.  Batch 128: the smallest the register-operand kernel takes."""
+    from deepflows_amd import nn, tensor
+    from deepflows_amd.tensor import Graph, Tensor
+    F = nn.functional
+    dev = hip_device
+    mod = dev.mod
+    rng = np.random.default_rng(11)
+    N = 128
+    x = rng.standard_normal((N, C, HW, HW)).astype(np.float32)
+    gy = rng.standard_normal((N, C, HW, HW)).astype(np.float32)
+    gam = (1.0 + 0.3 * rng.standard_normal((1, C, 1, 1))).astype(np.float32)
+    bet = (0.5 * rng.standard_normal((1, C, 1, 1))).astype(np.float32)
+    old_mode = mod.conv_dgrad_mode
+    mod.conv_dgrad_mode = dgrad
+    results = []
+    try:
+        for fused in (True, False):
+            np.random.seed(7)
+            conv1 = nn.Conv2d(C, C, kernel_size=3, stride=1, padding=1, bias=False, device=dev)
+            conv2 = nn.Conv2d(C, C, kernel_size=3, stride=1, padding=1, bias=False, device=dev)
+            bn1, bn2 = nn.BatchNorm2d(C, device=dev), nn.BatchNorm2d(C, device=dev)
+            bn1.train(); bn2.train()
+            mod.from_numpy(gam, bn1.weight.data._handle)
+            mod.from_numpy(bet, bn1.bias.data._handle)
+            xt = Tensor(x, device=dev, requires_grad=True)
+            z1 = conv1(xt)
+            if fused:
+                z2 = F.bn_conv2d_train(z1, bn1, conv2)
+                assert z2 is not None, "the fused form must take this shape"
+                assert getattr(z2, "bn_partials", None) is not None
+            else:
+                z2 = conv2(bn1(z1))
+            y = bn2(z2)                       # consumes z2's partials
+            loss = tensor.sum(y * Tensor(gy, device=dev))
+            loss.backward()
+            results.append([z2.numpy().copy(), y.numpy().copy(), xt.grad.numpy().copy(), conv1.weight.grad.numpy().copy(),
+                            conv2.weight.grad.numpy().copy(), bn1.weight.grad.numpy().copy(), bn1.bias.grad.numpy().copy(),
+                            bn2.weight.grad.numpy().copy(), bn1.running_mean.numpy().copy(),
+                            bn1.running_var.numpy().copy()])
+            Graph.free_graph_all()
+    finally:
+        mod.conv_dgrad_mode = old_mode
+    names = ("z2", "y", "dx", "dw1", "dw2", "dgamma1", "dbeta1", "dgamma2", "running_mean1", "running_var1")
+    for a, b, nm in zip(results[0], results[1], names):
+        assert_close(a, b, 3e-5, f"bn on conv loads C={C}: " + nm)
+
+
+def test_wgrad_affine_outside_a_group_writes_the_operand_out(hip_device):
+    """dfhip_conv2d_wgrad_affine called stand-alone (no grouped sweep open): the operand x * scale + shift is
+    materialised once and the ordinary kernels run; equal to the weight gradient of the explicit operand."""
+    mod = hip_device.mod
+    rng = np.random.default_rng(5)
+    N, C, H, W, O = 4, 8, 6, 6, 8
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    dy = rng.standard_normal((N, O, H, W)).astype(np.float32)
+    aff = rng.standard_normal((C, 2)).astype(np.float32)
+    def arr(a):
+        h = mod.Array(a.size); mod.from_numpy(a, h); return h
+    geo = (N, C, H, W, O, 3, 1, 1)
+    dw1, dw2 = mod.Array(O * C * 9), mod.Array(O * C * 9)
+    mod.conv2d_wgrad_affine(arr(x), arr(aff), arr(dy), dw1, *geo)
+    xa = x * aff[None, :, 0, None, None] + aff[None, :, 1, None, None]
+    mod.conv2d_wgrad(arr(xa.astype(np.float32)), arr(dy), dw2, *geo)
+    a, b = mod.to_numpy(dw1, (dw1.size,), (1,), 0), mod.to_numpy(dw2, (dw2.size,), (1,), 0)
+    assert_close(a, b, 1e-5, "wgrad_affine fall-back")
+
+
 def test_avg_pool_activation_modules_and_nll(hip_device):
     """SURVEY §8(f) row 3 on the hip device (26 hand-written primitives, no fused kernels): AvgPool2d incl. the
     zero-padding divisor and the last-writer-wins backward, LeakyReLU / Tanh / Softmax / LogSoftmax, nll_loss."""

@@ -49,6 +49,17 @@ def main():
                "wgrad": lambda: mod.conv2d_wgrad(x, y, dw, *geo),
                "dgrad_ow": lambda: mod.conv2d_dgrad(y, w, dx, *geo, mode="overwrite"),
                "dgrad_acc": lambda: mod.conv2d_dgrad(y, w, dx, *geo, mode="accumulate")}
+        if k == 3 and s == 1 and C == O and hasattr(mod, "conv2d_forward_bn_input"):
+            # the same convolution with the BatchNorm of its input applied on load (partials from a producer run)
+            part_in, part_out = mod.Array(512 * C * 3), mod.Array(512 * O * 3)
+            rows = mod.conv2d_forward_stats(x, w, None, y, *geo, part_in, 512)
+            gam, bet, mean, var, aff = arr((C,)), arr((C,)), mod.Array(C), mod.Array(C), mod.Array(2 * C)
+            if rows > 0:
+                def fwd_bn():
+                    done, _ = mod.conv2d_forward_bn_input(x, part_in, rows, gam, bet, 1e-5, 0.1, mean, var, None, None,
+                                                          aff, w, None, y, *geo, part_out, 512)
+                    assert done or N < 128
+                ops["fwd_bn_in"] = fwd_bn
         for op, fn in ops.items():
             for _ in range(3):
                 fn()
@@ -59,6 +70,8 @@ def main():
             mod.event_record(e1)
             us = mod.event_elapsed_ms(e0, e1) * 1e3 / args.iters
             print(f"{name:6s} {op:10s} {us:9.1f} {flops / us / 1e6:9.2f} {flops / 1e9:8.3f}")
+            if op == "fwd_bn_in":
+                continue
             if not (name == "stem" and op.startswith("dgrad")):
                 total[op] = total.get(op, 0.0) + us * COUNT[name]
     print("per-step totals (us):", {k: round(v, 1) for k, v in total.items()})
