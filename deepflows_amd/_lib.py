@@ -72,6 +72,9 @@ _SIGS = {
     "dfhip_relu_backward": [P, P, P, P, c_int64],
     "dfhip_softmax_ce_forward": [P, P, P, c_int, c_int],
     "dfhip_softmax_ce_backward": [P, P, P, P, c_int, c_int],
+    "dfhip_softmax_ce_forward_grad": [P, P, P, P, c_int, c_int, POINTER(c_int)],
+    "dfhip_pool_linear_forward": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float],
+    "dfhip_pool_linear_backward": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float],
     "dfhip_reduce_to_shape": [P, P, c_int, I64P, c_int, I64P],
     "dfhip_reduce_axis": [P, P, c_int64, c_int64, c_int64, c_int, c_float],
     "dfhip_broadcast_axis": [P, P, c_int64, c_int64, c_int64, c_float],

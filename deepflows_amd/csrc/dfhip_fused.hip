@@ -941,42 +941,70 @@ __global__ __launch_bounds__(kThreads) void k_ce_finish(const float* __restrict_
 // rows <= 4096, cols <= 32 (a classifier head): rows and the mean in ONE launch of one workgroup.
 // A THREAD owns a row (its few logits live in registers, one round of loads), the row losses are
 // summed by a fixed-shape tree in LDS.
+// GRAD: also d loss / d logits for an upstream gradient of exactly 1 (what loss.backward() seeds, tensor.py:428),
+// with k_ce_bwd's arithmetic: the backward pass of the usual training step then needs no launch for this node.
+// CM: compile-time bound of cols (16 or 32).  The row losses are summed by a fixed-shape tree: shuffles inside a
+// wave, then the sixteen waves in order.
+template <bool GRAD, int CM>
 __global__ __launch_bounds__(1024) void k_ce_small(const float* __restrict__ logits,
                                                    const float* __restrict__ target,
-                                                   float* __restrict__ loss, int rows, int cols,
-                                                   float inv_rows) {
-  __shared__ float part[1024];
+                                                   float* __restrict__ loss, float* __restrict__ dlogits, int rows,
+                                                   int cols, float inv_rows) {
+  __shared__ float part[16];
   float tot = 0.0f;
   for (int r = threadIdx.x; r < rows; r += 1024) {
     const float* x = logits + (int64_t)r * cols;
     const float* t = target + (int64_t)r * cols;
-    float xv[32], tv[32];
+    float xv[CM], tv[CM];
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
+    for (int j = 0; j < CM; j++) {
       xv[j] = j < cols ? x[j] : -INFINITY;
       tv[j] = j < cols ? t[j] : 0.0f;
     }
     float m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 32; j++) m = fmaxf(m, xv[j]);
-    float se = 0.0f;
+    for (int j = 0; j < CM; j++) m = fmaxf(m, xv[j]);
+    float ex[CM], se = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 32; j++)
-      if (j < cols) se += expf(xv[j] - m);
+    for (int j = 0; j < CM; j++) {
+      ex[j] = expf(xv[j] - m);                 // (exp(-inf) = 0 for the columns past the end)
+      if (j < cols) se += ex[j];
+    }
     const float lse = logf(se);
     float acc = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 32; j++)
+    for (int j = 0; j < CM; j++)
       if (j < cols) acc += -((xv[j] - m) - lse) * tv[j];
     tot += acc;
+    if constexpr (GRAD) {
+      const float gs = 1.0f * inv_rows;
+      float st = 0.0f;
+#pragma unroll
+      for (int j = 0; j < CM; j++)
+        if (j < cols) st += tv[j];
+      // g_u[j] = gs * (softmax_j * sum(t) - t_j); the max() node routes -sum_j g_u to the ties (as k_ce_bwd)
+      float gu[CM], gsum = 0.0f;
+#pragma unroll
+      for (int j = 0; j < CM; j++) {
+        gu[j] = gs * tv[j] * -1.0f + ex[j] * ((gs * st) / se);
+        if (j < cols) gsum += gu[j];
+      }
+      float* d = dlogits + (int64_t)r * cols;
+#pragma unroll
+      for (int j = 0; j < CM; j++)
+        if (j < cols) d[j] = gu[j] + (xv[j] == m ? -gsum : 0.0f);
+    }
   }
-  part[threadIdx.x] = tot;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = tot;
   __syncthreads();
-  for (int w = 512; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    float s2 = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 16; w++) s2 += part[w];
+    loss[0] = s2 * inv_rows;
   }
-  if (threadIdx.x == 0) loss[0] = part[0] * inv_rows;
 }
 
 __global__ __launch_bounds__(kThreads) void k_ce_bwd(const float* __restrict__ logits,
@@ -1334,6 +1362,190 @@ __global__ __launch_bounds__(256) void k_bn_finalize_partials(BnInput bn, int C)
   bn.affine[2 * c + 1] = sh;
 }
 
+// ---- classifier head: y = (scale * sum_hw x) . W + b, the two mean(axis=2) calls and the Linear of
+// test/ResNet_CIFAR10_cuda.py:96-99 as one launch each way.  A workgroup is an image; a thread walks channels.
+template <int P>
+__device__ __forceinline__ void head_block_sum(float (&acc)[P], float (*sh)[P]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < P; j++) {
+    float v = acc[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) sh[wave][j] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < P; j++) acc[j] = sh[0][j] + sh[1][j] + sh[2][j] + sh[3][j];
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_pool_linear_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ pooled,
+                                                        float* __restrict__ y, int C, int HW, int Pn, float scale) {
+  __shared__ float sh[4][P];
+  const int n = blockIdx.x;
+  float acc[P];
+#pragma unroll
+  for (int j = 0; j < P; j++) acc[j] = 0.0f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float* xp = x + ((int64_t)n * C + c) * HW;
+    float s = 0.0f;
+    if ((HW & 3) == 0) {
+      for (int i = 0; i < HW; i += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(xp + i);
+        s += v.x; s += v.y; s += v.z; s += v.w;
+      }
+    } else {
+      for (int i = 0; i < HW; i++) s += xp[i];
+    }
+    const float pv = s * scale;
+    pooled[(int64_t)n * C + c] = pv;
+    // (no `if (j < Pn)` around the multiply-adds: on the uniform Pn each becomes a branch; the columns past Pn
+    // re-read the last one and are never stored)
+    const float* wr = w + (int64_t)c * Pn;
+#pragma unroll
+    for (int j = 0; j < P; j++) acc[j] = fmaf(pv, wr[min(j, Pn - 1)], acc[j]);
+  }
+  head_block_sum<P>(acc, sh);
+  if ((int)threadIdx.x < Pn) {
+    float r = 0.0f;
+#pragma unroll
+    for (int j = 0; j < P; j++)
+      if (j == (int)threadIdx.x) r = acc[j];
+    y[(int64_t)n * Pn + threadIdx.x] = r + (b ? b[threadIdx.x] : 0.0f);
+  }
+}
+
+// 1024 threads.  Blocks [0, ceil(N / 4)): dx[n][c][:] = gscale * sum_j dy[n][j] w[c][j], four images per block;
+// blocks [.., + ceil(C / 64)): dw[c][j] = sum_n pooled[n][c] dy[n][j] for 64 channels (a lane is a channel: coalesced
+// rows of pooled; 256 images at a time: their dy rows go to LDS padded to P columns, a wave requests the pooled
+// values of its 16 images -- every sixteenth -- in one burst, the sixteen waves are summed through LDS in a fixed
+// order);  last block: db[j] = sum_n dy[n][j].  No `if (j < Pn)` around inner-loop arithmetic: on the uniform Pn each
+// becomes a branch, and a load under a condition a round trip of its own (the first version took 37 us).
+template <int P>
+__global__ __launch_bounds__(1024) void k_pool_linear_bwd(const float* __restrict__ dy, const float* __restrict__ pooled,
+                                                         const float* __restrict__ w, float* __restrict__ dx,
+                                                         float* __restrict__ dw, float* __restrict__ db, int N, int C,
+                                                         int HW, int Pn, float gscale) {
+  __shared__ float shw[8][64][P + 1];
+  __shared__ float sdy[256 * P];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int ndx = (N + 3) / 4, ndw = (C + 63) / 64;
+  if (b < ndx) {
+    const int n = b * 4 + (tid >> 8), t8 = tid & 255;
+    if (!dx || n >= N) return;
+    float g[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+      const float v = dy[(int64_t)n * Pn + min(j, Pn - 1)];
+      g[j] = j < Pn ? v : 0.0f;
+    }
+    for (int c = t8; c < C; c += 256) {
+      const float* wr = w + (int64_t)c * Pn;
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < P; j++) s = fmaf(g[j], wr[min(j, Pn - 1)], s);
+      s *= gscale;
+      float* o = dx + ((int64_t)n * C + c) * HW;
+      if ((HW & 3) == 0) {
+        const float4 v = make_float4(s, s, s, s);
+        for (int i = 0; i < HW; i += 4) *reinterpret_cast<float4*>(o + i) = v;
+      } else {
+        for (int i = 0; i < HW; i++) o[i] = s;
+      }
+    }
+    return;
+  }
+  if (b < ndx + ndw) {
+    if (!dw) return;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = (b - ndx) * 64 + lane;
+    const int cc = c < C ? c : C - 1;
+    float acc[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) acc[j] = 0.0f;
+    for (int n0 = 0; n0 < N; n0 += 256) {
+      const int nb = min(256, N - n0);
+      if (n0 > 0) __syncthreads();
+      float stg[P];
+      if (tid < 256) {
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+          const float v = dy[(int64_t)(n0 + min(tid, nb - 1)) * Pn + min(j, Pn - 1)];
+          stg[j] = (tid < nb && j < Pn) ? v : 0.0f;
+        }
+      }
+      float pv[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int n = wave + 16 * u;
+        const float v = pooled[(int64_t)(n0 + min(n, nb - 1)) * C + cc];
+        pv[u] = n < nb ? v : 0.0f;
+      }
+      if (tid < 256) {
+#pragma unroll
+        for (int j = 0; j < P; j++) sdy[tid * P + j] = stg[j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const float* g = sdy + (wave + 16 * u) * P;
+#pragma unroll
+        for (int j = 0; j < P; j++) acc[j] = fmaf(pv[u], g[j], acc[j]);
+      }
+    }
+    if (wave >= 8) {
+#pragma unroll
+      for (int j = 0; j < P; j++) shw[wave - 8][lane][j] = acc[j];
+    }
+    __syncthreads();
+    if (wave < 8) {
+#pragma unroll
+      for (int j = 0; j < P; j++) acc[j] += shw[wave][lane][j];
+    }
+    __syncthreads();
+    if (wave >= 1 && wave < 8) {
+#pragma unroll
+      for (int j = 0; j < P; j++) shw[wave][lane][j] = acc[j];
+    }
+    __syncthreads();
+    if (wave == 0 && c < C) {
+#pragma unroll
+      for (int j = 0; j < P; j++) {
+        float r = acc[j];
+#pragma unroll
+        for (int w2 = 1; w2 < 8; w2++) r += shw[w2][lane][j];
+        if (j < Pn) dw[(int64_t)c * Pn + j] = r;
+      }
+    }
+    return;
+  }
+  if (!db) return;
+  float acc[P];
+#pragma unroll
+  for (int j = 0; j < P; j++) acc[j] = 0.0f;
+  for (int n = tid; n < N; n += 1024) {
+    const float* g = dy + (int64_t)n * Pn;
+#pragma unroll
+    for (int j = 0; j < P; j++) acc[j] += g[min(j, Pn - 1)];
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < P; j++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+    if (lane == 0) sdy[wave * P + j] = acc[j];
+  }
+  __syncthreads();
+  if (tid < Pn) {
+    float r = 0.0f;
+#pragma unroll
+    for (int w2 = 0; w2 < 16; w2++) r += sdy[w2 * P + tid];
+    db[tid] = r;
+  }
+}
+
 namespace dfhip {
 int bn_finalize_partials(const BnInput& bn, int C) {
   if (bn.rows < 1 || bn.rows > 512 || !bn.part || !bn.affine) return -1;
@@ -1624,8 +1836,12 @@ int dfhip_softmax_ce_forward(const float* logits, const float* target, float* lo
   DF_CHECK_ARG(logits && target && loss, "softmax_ce: null array");
   ProfScope prof("softmax_ce_fwd", 0.0, 8.0 * (double)rows * cols);
   if (rows <= 4096 && cols <= 32) {
-    DF_LAUNCH(k_ce_small, dim3(1), dim3(1024), 0, stream(), logits, target, loss, rows, cols,
-                       (float)(1.0 / (double)rows));
+    if (cols <= 16)
+      DF_LAUNCH((k_ce_small<false, 16>), dim3(1), dim3(1024), 0, stream(), logits, target, loss, (float*)nullptr, rows,
+                cols, (float)(1.0 / (double)rows));
+    else
+      DF_LAUNCH((k_ce_small<false, 32>), dim3(1), dim3(1024), 0, stream(), logits, target, loss, (float*)nullptr, rows,
+                cols, (float)(1.0 / (double)rows));
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
   }
@@ -1636,6 +1852,55 @@ int dfhip_softmax_ce_forward(const float* logits, const float* target, float* lo
   DF_LAUNCH_CHECK();
   float inv = (float)(1.0 / (double)rows);
   DF_LAUNCH(k_ce_finish, dim3(1), dim3(kThreads), 0, stream(), row_loss, loss, rows, inv);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+// loss as dfhip_softmax_ce_forward, plus dlogits = d loss / d logits for an upstream gradient of 1 (the seed of
+// loss.backward(), tensor.py:428): *done = 0 (dlogits untouched) for shapes outside the one-workgroup kernel
+int dfhip_softmax_ce_forward_grad(const float* logits, const float* target, float* loss, float* dlogits, int rows,
+                                  int cols, int* done) {
+  DF_INIT();
+  DF_CHECK_ARG(rows > 0 && cols > 0, "softmax_ce: non-positive dimension");
+  DF_CHECK_ARG(logits && target && loss && dlogits && done, "softmax_ce_forward_grad: null array");
+  *done = 0;
+  if (!(rows <= 4096 && cols <= 32)) return dfhip_softmax_ce_forward(logits, target, loss, rows, cols);
+  ProfScope prof("softmax_ce_fwd", 0.0, 12.0 * (double)rows * cols);
+  if (cols <= 16)
+    DF_LAUNCH((k_ce_small<true, 16>), dim3(1), dim3(1024), 0, stream(), logits, target, loss, dlogits, rows, cols,
+              (float)(1.0 / (double)rows));
+  else
+    DF_LAUNCH((k_ce_small<true, 32>), dim3(1), dim3(1024), 0, stream(), logits, target, loss, dlogits, rows, cols,
+              (float)(1.0 / (double)rows));
+  DF_LAUNCH_CHECK();
+  *done = 1;
+  return DFHIP_OK;
+}
+
+// y (N, P) = (scale * sum over the HW pixels of x (N, C, HW)) . w (C, P) + b (P or NULL); pooled (N, C) is kept for
+// the backward pass.  P <= 16.  Replaces tensor.mean(axis=2) twice (tensor.py:752-769 via backend_tensor.py:659-662,
+// `scale` carries their divide-by-total-count rule) followed by nn/modules/linear.py:47-51.
+int dfhip_pool_linear_forward(const float* x, const float* w, const float* b, float* pooled, float* y, int N, int C,
+                              int HW, int P, float scale) {
+  DF_INIT();
+  DF_CHECK_ARG(N > 0 && C > 0 && HW > 0 && P > 0 && P <= 16, "pool_linear_forward: bad dimensions (P <= 16)");
+  DF_CHECK_ARG(x && w && pooled && y, "pool_linear_forward: null array");
+  ProfScope prof("pool_linear_fwd", 2.0 * N * (double)C * P, 4.0 * ((double)N * C * HW + (double)N * C + (double)C * P));
+  DF_LAUNCH(k_pool_linear_fwd<16>, dim3((unsigned)N), dim3(256), 0, stream(), x, w, b, pooled, y, C, HW, P, scale);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+// gradients of the above from dy (N, P): dx (N, C, HW) = gscale * (dy . w^T) broadcast over the pixels, dw (C, P) =
+// pooled^T . dy, db (P) = column sums of dy; any of the three may be NULL.  One launch.
+int dfhip_pool_linear_backward(const float* dy, const float* pooled, const float* w, float* dx, float* dw, float* db,
+                               int N, int C, int HW, int P, float gscale) {
+  DF_INIT();
+  DF_CHECK_ARG(N > 0 && C > 0 && HW > 0 && P > 0 && P <= 16, "pool_linear_backward: bad dimensions (P <= 16)");
+  DF_CHECK_ARG(dy && pooled && w, "pool_linear_backward: null array");
+  ProfScope prof("pool_linear_bwd", 4.0 * N * (double)C * P, 4.0 * ((double)N * C * HW + 2.0 * N * C + 2.0 * C * P));
+  const unsigned grid = (unsigned)((N + 3) / 4 + (C + 63) / 64 + 1);
+  DF_LAUNCH(k_pool_linear_bwd<16>, dim3(grid), dim3(1024), 0, stream(), dy, pooled, w, dx, dw, db, N, C, HW, P, gscale);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }

@@ -356,6 +356,22 @@ class HipModule:
     def softmax_ce_forward(self, logits, target, loss, rows, cols):
         _lib.check(self._lib.dfhip_softmax_ce_forward(logits.ptr, target.ptr, loss.ptr, rows, cols))
 
+    def softmax_ce_forward_grad(self, logits, target, loss, dlogits, rows, cols):
+        """loss + d loss / d logits for an upstream gradient of 1; False when only the loss was computed."""
+        done = ctypes.c_int(0)
+        _lib.check(self._lib.dfhip_softmax_ce_forward_grad(logits.ptr, target.ptr, loss.ptr, dlogits.ptr, rows, cols,
+                                                           ctypes.byref(done)))
+        return bool(done.value)
+
+    def pool_linear_forward(self, x, w, b, pooled, y, N, C, HW, P, scale):
+        _lib.check(self._lib.dfhip_pool_linear_forward(x.ptr, w.ptr, b.ptr if b is not None else None, pooled.ptr,
+                                                       y.ptr, N, C, HW, P, float(scale)))
+
+    def pool_linear_backward(self, dy, pooled, w, dx, dw, db, N, C, HW, P, gscale):
+        g = lambda h: h.ptr if h is not None else None
+        _lib.check(self._lib.dfhip_pool_linear_backward(dy.ptr, pooled.ptr, w.ptr, g(dx), g(dw), g(db), N, C, HW, P,
+                                                        float(gscale)))
+
     def softmax_ce_backward(self, logits, target, gloss, dlogits, rows, cols):
         _lib.check(self._lib.dfhip_softmax_ce_backward(logits.ptr, target.ptr, gloss.ptr, dlogits.ptr,
                                                        rows, cols))

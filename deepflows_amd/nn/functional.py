@@ -170,10 +170,21 @@ class _CrossEntropyFused(_FusedNode):
         self.td = target.data.compact()
         rows, cols = self.ld.shape
         out = _new((1,), logits.device)
-        logits.device.softmax_ce_forward(self.ld._handle, self.td._handle, out._handle, rows, cols)
+        # for a classifier-sized problem the forward kernel also leaves d loss / d logits for an upstream gradient
+        # of exactly 1 behind -- what loss.backward() seeds (tensor.py:428) -- and grad_fn then launches nothing
+        self.unit_grad = None
+        fg = getattr(logits.device.mod, "softmax_ce_forward_grad", None)
+        if fg is not None and is_grad_enable() and logits.requires_grad:
+            dl = _new((rows, cols), logits.device)
+            if fg(self.ld._handle, self.td._handle, out._handle, dl._handle, rows, cols):
+                self.unit_grad = dl
+        else:
+            logits.device.softmax_ce_forward(self.ld._handle, self.td._handle, out._handle, rows, cols)
         super().__init__(out, [logits])
 
     def grad_fn(self, node, grad):
+        if self.unit_grad is not None and getattr(grad, "is_unit_seed", False):
+            return self.unit_grad
         rows, cols = self.ld.shape
         out = _new((rows, cols), grad.device)
         grad.device.softmax_ce_backward(self.ld._handle, self.td._handle, grad.compact()._handle,
@@ -328,6 +339,52 @@ class _MeanHWFused(_FusedNode):
         # mean.grad_fn scales by out.size / in.size at each of the two steps: (N*C*W)/(N*C*H*W) * (N*C)/(N*C*W)
         grad.device.broadcast_axis(grad.compact()._handle, out._handle, N * C, H * W, 1, 1.0 / float(H * W))
         return out
+
+
+class _PoolLinearFused(_FusedNode):
+    """fc(mean(mean(x, axis=2), axis=2)) -- the classifier head of test/ResNet_CIFAR10_cuda.py:96-99 -- as one node:
+    one launch forward (pooled features kept for the backward pass), one launch backward (dx broadcast over the
+    pixels, dW, db).  Values as _MeanHWFused followed by _LinearFused: the means divide by the TOTAL element count
+    of their input and their gradients scale by out.size / in.size."""
+
+    def __init__(self, x, w, b):
+        self.x, self.w, self.b = x, w, b
+        N, C, H, W = (int(v) for v in x.shape)
+        P = int(w.shape[1])
+        self.geo = (N, C, H * W, P)
+        dev = x.device
+        self.wd = w.data.compact()
+        self.pooled = _new((N, C), dev)
+        out = _new((N, P), dev)
+        scale = 1.0 / (float(N * C * H * W) * float(N * C * W))
+        dev.pool_linear_forward(x.data.compact()._handle, self.wd._handle,
+                                b.data.compact()._handle if b is not None else None, self.pooled._handle,
+                                out._handle, N, C, H * W, P, scale)
+        self._grads = None
+        super().__init__(out, [x, w, b])
+
+    def grad_fn(self, node, grad):
+        if self._grads is None or self._grads[0] is not grad:
+            N, C, HW, P = self.geo
+            dev = grad.device
+            dx = _new(self.x.shape, dev) if self.x.requires_grad else None
+            dw = _new(self.wd.shape, dev) if self.w.requires_grad else None
+            db = _new(self.b.shape, dev) if (self.b is not None and self.b.requires_grad) else None
+            h = lambda t: t._handle if t is not None else None
+            dev.pool_linear_backward(grad.compact()._handle, self.pooled._handle, self.wd._handle, h(dx), h(dw), h(db),
+                                     N, C, HW, P, 1.0 / float(HW))
+            self._grads = (grad, dx, dw, db)
+        _, dx, dw, db = self._grads
+        return dx if node is self.x else (dw if node is self.w else db)
+
+
+def mean_hw_linear(x: Tensor, fc) -> Tensor:
+    """fc(mean_hw(x)) for an nn.Linear `fc`; one node on a fused device when the layer is classifier-sized."""
+    mod = x.device.mod
+    if (_fused(x) and len(x.shape) == 4 and hasattr(mod, "pool_linear_forward") and int(fc.weight.shape[1]) <= 16
+            and int(fc.weight.shape[0]) == int(x.shape[1]) and os.environ.get("DF_HEAD_FUSED", "1") != "0"):
+        return _PoolLinearFused(x, fc.weight, fc.bias)
+    return fc(mean_hw(x))
 
 
 def mean_hw(x: Tensor) -> Tensor:

@@ -294,6 +294,9 @@ def _grad_seed(data):
     seed = _SEEDS.get(id(mod))
     if seed is None:
         seed = backend_api.ones_like(data)
+        # a node that already knows its gradient for an upstream value of exactly 1 (cross-entropy on the hip
+        # device) recognises the seed by this mark and launches nothing
+        seed.is_unit_seed = True
         if not mod.capturing:
             _SEEDS[id(mod)] = seed
     return seed

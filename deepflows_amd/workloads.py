@@ -162,8 +162,9 @@ class ResNet(nn.Module):
         self.backward_milestone = x
         for blk in self.layer4:
             x = blk(x)
-        x = nn.functional.mean_hw(x)   # mean(axis=2) twice: each divides by the TOTAL element count
-        return self.fc(x)
+        # mean(axis=2) twice (each divides by the TOTAL element count), then the classifier: one node on
+        # the hip device
+        return nn.functional.mean_hw_linear(x, self.fc)
 
 
 # ---- the other convolutional models of the example scripts -----------------------

@@ -273,6 +273,22 @@ int dfhip_softmax_ce_forward(const float* logits, const float* target, float* lo
 int dfhip_softmax_ce_backward(const float* logits, const float* target, const float* gloss,
                               float* dlogits, int rows, int cols);
 
+/* dfhip_softmax_ce_forward that also writes dlogits for an upstream gradient of exactly 1 (what loss.backward()
+ * seeds, tensor.py:428), so the backward pass of a training step needs no launch for this node.  *done = 0 when the
+ * shape is outside the one-workgroup kernel (rows <= 4096, cols <= 32): only the loss was computed. */
+int dfhip_softmax_ce_forward_grad(const float* logits, const float* target, float* loss, float* dlogits,
+                                  int rows, int cols, int* done);
+
+/* Classifier head of test/ResNet_CIFAR10_cuda.py:96-99 as one launch each way: y (N, P) = (scale * sum over the HW
+ * pixels of x (N, C, HW)) . w (C, P) + b (P or NULL), P <= 16.  `scale` carries the divide-by-total-count rule of
+ * the two tensor.mean(axis=2) calls (backend_tensor.py:659-662); pooled (N, C) is kept for the backward pass:
+ * dx (N, C, HW) = gscale * (dy . w^T) broadcast over the pixels, dw (C, P) = pooled^T . dy (tensor.py:716),
+ * db (P) = column sums of dy; dx / dw / db may be NULL. */
+int dfhip_pool_linear_forward(const float* x, const float* w, const float* b, float* pooled, float* y,
+                              int N, int C, int HW, int P, float scale);
+int dfhip_pool_linear_backward(const float* dy, const float* pooled, const float* w, float* dx, float* dw,
+                               float* db, int N, int C, int HW, int P, float gscale);
+
 /* Sum `src` over the axes in which dst_shape is 1 (or missing leading axes): replaces
  * the host un-broadcast of tensor.py:462-483.  Shapes are right-aligned.                */
 int dfhip_reduce_to_shape(const float* src, float* dst, int src_ndim, const int64_t* src_shape,

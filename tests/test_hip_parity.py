@@ -389,6 +389,60 @@ def test_wgrad_affine_outside_a_group_writes_the_operand_out(hip_device):
     assert_close(a, b, 1e-5, "wgrad_affine fall-back")
 
 
+def test_classifier_head_as_one_node(hip_device):
+    """fc(mean(mean(x, 2), 2)) + cross-entropy: the pooled-linear node and the loss gradient left behind by the loss
+    kernel, against the separate nodes (mean_hw, Linear, cross-entropy with its own backward launch)."""
+    from deepflows_amd import nn, tensor
+    from deepflows_amd.tensor import Graph, Tensor
+    F = nn.functional
+    dev = hip_device
+    rng = np.random.default_rng(21)
+    for (N, C, H, W, P) in ((256, 256, 2, 2, 10), (6, 20, 3, 3, 7), (5, 300, 1, 1, 16), (300, 70, 2, 2, 3)):
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        y = np.eye(P, dtype=np.float32)[rng.integers(0, P, N)] * 0.95 + 0.05 / P
+        results = []
+        for fused in (True, False):
+            np.random.seed(3)
+            fc = nn.Linear(C, P, device=dev)
+            xt = Tensor(x, device=dev, requires_grad=True)
+            if fused:
+                out = F.mean_hw_linear(xt, fc)
+                assert type(out).__name__ == "_PoolLinearFused"
+                loss = F.cross_entropy(out, Tensor(y, device=dev))
+                assert loss.unit_grad is not None
+            else:
+                out = fc(F.mean_hw(xt))
+                loss = F.cross_entropy(out, Tensor(y, device=dev))
+                loss.unit_grad = None                      # the loss gradient from its own backward launch
+            loss.backward()
+            results.append([out.numpy().copy(), loss.numpy().copy(), xt.grad.numpy().copy(), fc.weight.grad.numpy().copy(),
+                            fc.bias.grad.numpy().copy()])
+            Graph.free_graph_all()
+        for a, b, nm in zip(results[0], results[1], ("logits", "loss", "dx", "dW", "db")):
+            assert_close(a, b, 2e-6, f"head {N, C, H, W, P}: " + nm)
+
+
+def test_loss_gradient_left_by_the_forward_kernel(hip_device):
+    """dfhip_softmax_ce_forward_grad: dlogits for an upstream gradient of 1 equals dfhip_softmax_ce_backward with a
+    unit seed, including rows whose maximum is tied (the reference routes -sum(g) to every tied maximum)."""
+    mod = hip_device.mod
+    rng = np.random.default_rng(9)
+    rows, cols = 37, 10
+    x = rng.standard_normal((rows, cols)).astype(np.float32)
+    x[3, 2] = x[3, 7] = x[3].max() + 1.0                    # a tie at the maximum
+    t = (np.eye(cols, dtype=np.float32)[rng.integers(0, cols, rows)] * 0.9 + 0.01).astype(np.float32)
+    def arr(a):
+        h = mod.Array(a.size); mod.from_numpy(a, h); return h
+    xl, tl = arr(x), arr(t)
+    loss1, loss2, d1, d2 = mod.Array(1), mod.Array(1), mod.Array(rows * cols), mod.Array(rows * cols)
+    assert mod.softmax_ce_forward_grad(xl, tl, loss1, d1, rows, cols)
+    mod.softmax_ce_forward(xl, tl, loss2, rows, cols)
+    mod.softmax_ce_backward(xl, tl, arr(np.ones(1, np.float32)), d2, rows, cols)
+    back = lambda h: mod.to_numpy(h, (h.size,), (1,), 0)
+    assert np.array_equal(back(loss1), back(loss2))
+    assert_close(back(d1), back(d2), 1e-6, "dlogits")
+
+
 def test_avg_pool_activation_modules_and_nll(hip_device):
     """SURVEY §8(f) row 3 on the hip device (26 hand-written primitives, no fused kernels): AvgPool2d incl. the
     zero-padding divisor and the last-writer-wins backward, LeakyReLU / Tanh / Softmax / LogSoftmax, nll_loss."""
