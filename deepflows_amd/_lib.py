@@ -82,6 +82,7 @@ _SIGS = {
     "dfhip_adam_step": [c_int, PP, PP, PP, PP, I64P, c_double, c_double, c_double, c_double,
                         c_double, c_int, c_double],
     "dfhip_adam_hyper": [P, c_double, c_double, c_double, c_double, c_double, c_int, c_double],
+    "dfhip_adam_hyper_table": [P, c_int, c_double, c_double, c_double, c_double, c_double, c_int, c_double],
     "dfhip_adam_step_dev": [c_int, PP, PP, PP, PP, I64P, P],
     "dfhip_sgd_step": [c_int, PP, PP, PP, I64P, c_double, c_double, c_double, c_int, c_double],
     "dfhip_pack": [c_int, PP, I64P, P],

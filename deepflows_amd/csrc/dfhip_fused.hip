@@ -10,6 +10,8 @@
 // cancellation).
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
+#include <vector>
 
 #include <algorithm>
 
@@ -1249,12 +1251,32 @@ __global__ __launch_bounds__(kThreads) void k_adam(TensorBatch tb, AdamHyper h) 
 // the same update with the hyper-parameters read from device memory: a captured training step
 // (hipGraph) replays this launch unchanged while dfhip_adam_hyper refreshes the scalars (bias
 // corrections change every step) with a one-thread launch in front of the replay
-__global__ __launch_bounds__(kThreads) void k_adam_dev(TensorBatch tb, const AdamHyper* __restrict__ hp) {
-  const AdamHyper h = *hp;
+// hyper_dev: int idx, int done, int cap, ... then from float 16 on `cap` entries of 16 floats (an AdamHyper each): the
+// scalars of steps first, first + 1, ...  (dfhip_adam_hyper_table).  Every block reads entry idx; with `advance`
+// the LAST block to finish moves idx on -- every block has read idx before it counts itself done, so none can see
+// the new value -- and the next replay of the captured step finds the next step's bias corrections without any
+// launch in between (the one-thread launch that used to write them cost 4.9 us per step).
+__global__ __launch_bounds__(kThreads) void k_adam_dev(TensorBatch tb, float* __restrict__ hyper_dev, int advance) {
+  int* ctl = reinterpret_cast<int*>(hyper_dev);
+  const int idx = ctl[0], cap = ctl[2];
+  const AdamHyper h = *reinterpret_cast<const AdamHyper*>(hyper_dev + 16 + 16 * min(idx, cap - 1));
   adam_block(tb, h);
+  if (!advance) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = atomicAdd(&ctl[1], 1);
+    if (old == (int)gridDim.x - 1) {
+      ctl[1] = 0;
+      ctl[0] = idx + 1;
+    }
+  }
 }
 
-__global__ void k_set_adam_hyper(AdamHyper* dst, AdamHyper h) { *dst = h; }
+__global__ void k_set_adam_hyper(float* hyper_dev, AdamHyper h) {
+  int* ctl = reinterpret_cast<int*>(hyper_dev);
+  ctl[0] = 0; ctl[1] = 0; ctl[2] = 1;
+  *reinterpret_cast<AdamHyper*>(hyper_dev + 16) = h;
+}
 
 struct SgdHyper {
   float lr, mu, wd, gscale;
@@ -2061,8 +2083,29 @@ int dfhip_adam_hyper(float* hyper_dev, double lr, double beta1, double beta2, do
   DF_INIT();
   DF_CHECK_ARG(hyper_dev && step >= 1, "adam_hyper: bad arguments");
   AdamHyper h = make_adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
-  DF_LAUNCH(k_set_adam_hyper, dim3(1), dim3(1), 0, stream(), (AdamHyper*)hyper_dev, h);
+  DF_LAUNCH(k_set_adam_hyper, dim3(1), dim3(1), 0, stream(), hyper_dev, h);
   DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+int dfhip_adam_hyper_table(float* hyper_dev, int cap, double lr, double beta1, double beta2, double eps,
+                           double weight_decay, int first_step, double grad_scale) {
+  DF_INIT();
+  DF_CHECK_ARG(hyper_dev && cap >= 1 && first_step >= 1, "adam_hyper_table: bad arguments");
+  if (capturing()) {
+    set_error("adam_hyper_table: a host-to-device copy cannot be part of a captured step");
+    return DFHIP_INVALID_ARGUMENT;
+  }
+  std::vector<float> host((size_t)16 + 16 * (size_t)cap, 0.0f);
+  int* ctl = reinterpret_cast<int*>(host.data());
+  ctl[0] = 0; ctl[1] = 0; ctl[2] = cap;
+  for (int i = 0; i < cap; i++) {
+    const AdamHyper h = make_adam_hyper(lr, beta1, beta2, eps, weight_decay, first_step + i, grad_scale);
+    memcpy(host.data() + 16 + 16 * (size_t)i, &h, sizeof(h));
+  }
+  // rare (once per `cap` steps, or when a scalar changes): the stream is drained, then a plain copy
+  DF_HIP(hipStreamSynchronize(stream()));
+  DF_HIP(hipMemcpy(hyper_dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
   return DFHIP_OK;
 }
 
@@ -2080,7 +2123,8 @@ int dfhip_adam_step_dev(int n_tensors, float* const* params, const float* const*
     int n = std::min(kBatch, n_tensors - first);
     TensorBatch tb;
     int blocks = fill_batch(tb, n, first, params, grads, exp_avg, exp_avg_sq, sizes);
-    DF_LAUNCH(k_adam_dev, dim3(blocks), dim3(kThreads), 0, stream(), tb, (const AdamHyper*)hyper_dev);
+    DF_LAUNCH(k_adam_dev, dim3(blocks), dim3(kThreads), 0, stream(), tb, const_cast<float*>(hyper_dev),
+              first + kBatch >= n_tensors ? 1 : 0);          // the last launch of the step moves the table on
     DF_LAUNCH_CHECK();
   }
   return DFHIP_OK;

@@ -14,6 +14,7 @@ void set_error(const char* fmt, ...);
 hipStream_t stream();          // the single library stream
 bool initialised();
 bool profiling();             // per-family HIP-event profiling is switched on (dfhip_prof_enable)
+bool capturing();             // a stream capture (dfhip_graph_begin) is open
 int ensure_init();             // lazy dfhip_init(LOCAL_RANK or 0)
 int num_cus();
 

@@ -213,6 +213,7 @@ struct ProfSlot {
 static int g_prof_scope = -1;           // slot of the innermost active ProfScope
 static bool g_prof_on = false;
 bool profiling() { return g_prof_on; }
+bool capturing() { return g_capture_open != 0; }
 static std::vector<ProfSlot> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
 

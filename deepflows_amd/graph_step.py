@@ -73,6 +73,8 @@ class CapturedTrainStep:
                 p.grad = g
             self.sync()
             opt.apply()
+        else:
+            opt.note_replayed_apply()               # the captured apply() moved the device's scalar table on
         opt.t += 1
         return self.loss
 

@@ -408,6 +408,11 @@ class HipModule:
         _lib.check(self._lib.dfhip_adam_hyper(hyper.ptr, lr, beta1, beta2, eps, weight_decay, int(step),
                                               grad_scale))
 
+    def adam_hyper_table(self, hyper, cap, lr, beta1, beta2, eps, weight_decay, first_step, grad_scale=1.0):
+        """Fill `hyper` (16 + 16 * cap floats) with the scalars of Adam steps first_step ... first_step + cap - 1."""
+        _lib.check(self._lib.dfhip_adam_hyper_table(hyper.ptr, int(cap), lr, beta1, beta2, eps, weight_decay,
+                                                    int(first_step), grad_scale))
+
     def adam_step_dev(self, params, grads, exp_avg, exp_avg_sq, hyper):
         n = len(params)
         sizes = (c_int64 * n)(*[p.size for p in params])

@@ -26,12 +26,27 @@ class Adam(Optimizer):
     device_hyper = False
     _hyper = None
 
+    _HYPER_STEPS = 1024          # steps of scalars kept on the device
+    _table_key = None            # (scalars, first step) of the table on the device
+    _table_used = 0              # apply() calls since it was written = the index the device is at
+
     def push_hyper(self):
+        """Make sure the device holds the scalars of step self.t at the position its index points to.  The table
+        covers _HYPER_STEPS steps and apply() moves the index on by itself, so in steady state this launches
+        nothing; it is rewritten when it runs out, when a scalar (lr, weight decay, ...) changed, or when steps
+        were taken on another path in between."""
         mod = self._fused_mod()
         if self._hyper is None:
-            self._hyper = mod.Array(16)
-        mod.adam_hyper(self._hyper, self.lr, self.beta1, self.beta2, self.eps, self.weight_decay, self.t,
-                       self.grad_scale)
+            self._hyper = mod.Array(16 + 16 * self._HYPER_STEPS)
+        scalars = (self.lr, self.beta1, self.beta2, self.eps, self.weight_decay, self.grad_scale)
+        if (self._table_key is not None and self._table_key[0] == scalars
+                and self._table_key[1] + self._table_used == self.t and self._table_used < self._HYPER_STEPS):
+            return
+        if getattr(mod, "capturing", False):
+            raise RuntimeError("Adam: the scalar table must be written before the capture starts")
+        mod.adam_hyper_table(self._hyper, self._HYPER_STEPS, self.lr, self.beta1, self.beta2, self.eps,
+                             self.weight_decay, self.t, self.grad_scale)
+        self._table_key, self._table_used = (scalars, self.t), 0
 
     def apply(self):
         """The in-place multi-tensor update with the scalars push_hyper() wrote (no host state)."""
@@ -44,6 +59,12 @@ class Adam(Optimizer):
                               [self.params[i].grad.compact()._handle for i in live],
                               [self.v[i]._handle for i in live], [self.s[i]._handle for i in live],
                               self._hyper)
+            if not getattr(mod, "capturing", False):
+                self._table_used += 1            # (a captured apply() runs on replay: note_replayed_apply())
+
+    def note_replayed_apply(self):
+        """A graph that contains apply() was replayed once: the device moved its table index on."""
+        self._table_used += 1
 
     def step(self):
         mod = self._fused_mod()

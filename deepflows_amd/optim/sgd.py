@@ -23,6 +23,9 @@ class SGD(Optimizer):
     def push_hyper(self):
         pass
 
+    def note_replayed_apply(self):
+        pass
+
     def apply(self):
         """The in-place multi-tensor update (one launch for the whole parameter list)."""
         mod = self._fused_mod()

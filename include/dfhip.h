@@ -306,11 +306,17 @@ int dfhip_axpy(float* dst, const float* src, float alpha, int64_t n);
 
 /* Adam for a captured (hipGraph) training step: dfhip_adam_step with the ten fp32 scalars of the
  * update (lr, beta1, beta2, 1-beta1, 1-beta2, 1-beta1^t, 1-beta2^t, eps, weight_decay, grad_scale;
- * optim/adam.py:42-60) read from `hyper_dev` (>= 16 floats of device memory) instead of the kernel
- * arguments, and the one-thread launch that writes them for step t.  The graph replays
- * dfhip_adam_step_dev unchanged; the host calls dfhip_adam_hyper in front of every replay. */
+ * optim/adam.py:42-60) read from device memory instead of the kernel arguments.  hyper_dev is
+ * 16 + 16 * cap floats: a header (entry index, a block counter, cap) and `cap` entries, the scalars of steps
+ * first_step, first_step + 1, ...  dfhip_adam_step_dev applies the entry the index points at and its last block
+ * moves the index on, so a graph replays it unchanged step after step with no launch in between;
+ * dfhip_adam_hyper_table (not inside a capture: it drains the stream and copies) is called once per `cap`
+ * steps or when a scalar changes.  dfhip_adam_hyper: the one-entry form (a one-thread launch that writes the
+ * scalars of step `step`; hyper_dev >= 32 floats). */
 int dfhip_adam_hyper(float* hyper_dev, double lr, double beta1, double beta2, double eps,
                      double weight_decay, int step, double grad_scale);
+int dfhip_adam_hyper_table(float* hyper_dev, int cap, double lr, double beta1, double beta2, double eps,
+                           double weight_decay, int first_step, double grad_scale);
 int dfhip_adam_step_dev(int n_tensors, float* const* params, const float* const* grads,
                         float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
                         const float* hyper_dev);
