@@ -652,10 +652,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
 // goes through LDS once per workgroup): the generic kernel spent 26 us per launch on per-workgroup
 // gather tables for 14 MFMAs of work.
 // ---------------------------------------------------------------------------------------
+// partials (or nullptr): BatchNorm partials of y, one row per workgroup (blockIdx.x) -- (count, mean, centred second
+// moment) per output channel, the layout of dfhip_conv2d_forward_stats.  A lane keeps sums of (y - s) and (y - s)^2
+// over the rows it walks, s = the channel's value at the wave's first pixel (a sample of the channel: the second
+// moment about it is as well conditioned as about the mean); the 32 pixels of a half-wave and the four waves are
+// combined once at the end.
 template <int C>
 __global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ y,
-                                                    int N, int H, int O, unsigned m_h) {
+                                                    int N, int H, int O, unsigned m_h, float* __restrict__ partials) {
   constexpr int KK = C * 9, NP = (KK + 1) / 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -701,6 +706,10 @@ __global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x,
   const int R0 = blockIdx.x * 4 + wave, RS = gridDim.x * 4;
   float b[NP], bn[NP];
   if (R0 < rows) load_row(R0, b);
+  float st_s[16], st_1[16], st_2[16];          // shift, sum of (y - shift), sum of (y - shift)^2
+  float st_n = 0.0f;
+#pragma unroll
+  for (int rr = 0; rr < 16; rr++) { st_s[rr] = 0.0f; st_1[rr] = 0.0f; st_2[rr] = 0.0f; }
   for (int R = R0; R < rows; R += RS) {
     const int n = (int)fast_div((unsigned)R, m_h), r = R - n * H;
     if (R + RS < rows) load_row(R + RS, bn);
@@ -715,9 +724,54 @@ __global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x,
       const int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
       if (d < O) yo[(int64_t)d * H * 32] = acc[rr];
     }
+    if (partials) {
+      if (R == R0) {
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) st_s[rr] = __shfl(acc[rr], half * 32, 64);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) {
+        const float dl = acc[rr] - st_s[rr];
+        st_1[rr] += dl;
+        st_2[rr] = fmaf(dl, dl, st_2[rr]);
+      }
+      st_n += 32.0f;
+    }
     if (R + RS < rows) {
 #pragma unroll
       for (int p = 0; p < NP; p++) b[p] = bn[p];
+    }
+  }
+  if (partials) {
+    __shared__ float sst[4][32][3];
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) {
+      float a1 = st_1[rr], a2 = st_2[rr];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+      if (l31 == 0) {
+        const int dl = (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        const float mu_s = st_n > 0.0f ? a1 / st_n : 0.0f;       // mean of (y - shift)
+        sst[wave][dl][0] = st_n;
+        sst[wave][dl][1] = st_s[rr] + mu_s;
+        sst[wave][dl][2] = st_n > 0.0f ? a2 - a1 * mu_s : 0.0f;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && d0 + (int)threadIdx.x < O) {
+      float n = 0.0f, mu = 0.0f, m2 = 0.0f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; w4++) {
+        const float nb = sst[w4][threadIdx.x][0], mub = sst[w4][threadIdx.x][1], m2b = sst[w4][threadIdx.x][2];
+        if (nb > 0.0f) {
+          const float nn = n + nb, delta = mub - mu;
+          mu += delta * (nb / nn);
+          m2 += m2b + delta * delta * (n * nb / nn);
+          n = nn;
+        }
+      }
+      float* o = partials + ((int64_t)blockIdx.x * O + d0 + threadIdx.x) * 3;
+      o[0] = n; o[1] = mu; o[2] = m2;
     }
   }
 }
@@ -2990,7 +3044,8 @@ int run_conv1x1s2(const Geo& g, int O, float* y, const float* bias, float* parti
 }
 
 // few-channel 3x3 stem on 32-wide images; returns -1 when the shape is not one it takes
-int run_conv_rows3(const Geo& g, int dest_channels, float* final_dst, const float* bias) {
+int run_conv_rows3(const Geo& g, int dest_channels, float* final_dst, const float* bias, float* partials = nullptr,
+                   int cap_rows = 0, int* rows_out = nullptr) {
   static int enabled = getenv("DFHIP_STEM_ROWS") ? atoi(getenv("DFHIP_STEM_ROWS")) : 1;
   if (!enabled || g.mode != 0 || g.k != 3 || g.so != 1 || g.sd != 1 || g.u0 != -1) return -1;
   if (g.CS < 1 || g.CS > 4 || g.WS != 32 || g.WD != 32 || g.HS != g.HD) return -1;
@@ -3003,10 +3058,12 @@ int run_conv_rows3(const Geo& g, int dest_channels, float* final_dst, const floa
   dim3 grid((unsigned)std::min<int64_t>(df_ceil_div(rows, 4), (int64_t)num_cus() * 2),
             (unsigned)df_ceil_div(dest_channels, 32));
   const unsigned m_h = magic_u32((unsigned)g.HS);
+  float* part = (partials && rows_out && (int)grid.x <= cap_rows) ? partials : nullptr;
+  if (rows_out) *rows_out = part ? (int)grid.x : 0;
 #define DF_STEM(CV)                                                                                   \
   case CV:                                                                                            \
     DF_LAUNCH(k_conv_rows3<CV>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, final_dst, g.N, g.HS, \
-                       dest_channels, m_h);                                                           \
+                       dest_channels, m_h, part);                                                     \
     break;
   switch (g.CS) { DF_STEM(1) DF_STEM(2) DF_STEM(3) DF_STEM(4) default: return -1; }
 #undef DF_STEM
@@ -3826,6 +3883,7 @@ static int conv2d_forward_impl(const float* x, const float* w, const float* bias
   if (partials && rows_out) {
     int rows = 0;
     int st = run_igemm_v4(g, O, y, bias, partials, cap_rows, &rows);
+    if (st < 0) st = run_conv_rows3(g, O, y, bias, partials, cap_rows, &rows);     // the 1-4 channel stem
     if (st >= 0) {
       *rows_out = rows;
       return st;

@@ -525,14 +525,50 @@ __device__ __forceinline__ float bn_point(float v, float mean, float rsd, float 
 __device__ __forceinline__ float relu_point(float a) { return (a != a) ? a : (a > 0.0f ? a : 0.0f); }
 __device__ __forceinline__ float max_nan(float m, float v) { return (m != m) ? m : ((v != v) ? v : (v > m ? v : m)); }
 
+// (mean, biased variance) of channel c from convolution partials[rows][C][3] = (count, mean, centred second moment):
+// a row per thread, Chan's update by a shuffle tree inside the wave, then the four waves in order -- the same
+// sequence in every block (as k_bn_apply_partials); sw: 12 floats of LDS
+__device__ __forceinline__ void bn_combine_rows(const float* __restrict__ partials, int rows, int C, int c,
+                                                float (*sw)[3], float& mean, float& var) {
+  auto chan = [](float& n, float& mu, float& m2, float nb, float mub, float m2b) {
+    if (nb > 0.0f) {
+      const float nn = n + nb, delta = mub - mu;
+      mu += delta * (nb / nn);
+      m2 += m2b + delta * delta * (n * nb / nn);
+      n = nn;
+    }
+  };
+  const int tid = threadIdx.x;
+  float n = 0.0f, mu = 0.0f, m2 = 0.0f;
+  for (int r = tid; r < rows; r += kThreads) {
+    const float* p = partials + ((int64_t)r * C + c) * 3;
+    chan(n, mu, m2, p[0], p[1], p[2]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_down(n, o, 64), mub = __shfl_down(mu, o, 64), m2b = __shfl_down(m2, o, 64);
+    chan(n, mu, m2, nb, mub, m2b);
+  }
+  if ((tid & 63) == 0) { sw[tid >> 6][0] = n; sw[tid >> 6][1] = mu; sw[tid >> 6][2] = m2; }
+  __syncthreads();
+  n = sw[0][0]; mu = sw[0][1]; m2 = sw[0][2];
+#pragma unroll
+  for (int w4 = 1; w4 < 4; w4++) chan(n, mu, m2, sw[w4][0], sw[w4][1], sw[w4][2]);
+  mean = mu;
+  var = n > 0.0f ? m2 / n : 0.0f;   // biased variance (batchnorm.py:41-42)
+}
+
+// S > 0: partial = this library's [C][S][3] statistics pass;  S < 0: partial = convolution partials [-S rows][C][3]
 __global__ __launch_bounds__(kThreads) void k_bn_relu_pool_fwd(
     const float* __restrict__ x, const float* __restrict__ partial, int S, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ save_mean,
     float* __restrict__ save_var, float* __restrict__ running_mean, float* __restrict__ running_var, int N,
     int C, int H, int W, int ipb, float eps, float momentum) {
+  __shared__ float sw[4][3];
   const int c = blockIdx.x, s = blockIdx.y;
   float mean, var;
-  bn_combine(partial, c, S, mean, var);
+  if (S < 0) bn_combine_rows(partial, -S, C, c, sw, mean, var);
+  else bn_combine(partial, c, S, mean, var);
   if (s == 0 && threadIdx.x == 0) {
     if (save_mean) save_mean[c] = mean;
     if (save_var) save_var[c] = var;
@@ -1741,6 +1777,26 @@ int dfhip_bn_relu_maxpool2_forward(const float* x, const float* gamma, const flo
   DF_LAUNCH_CHECK();
   DF_LAUNCH(k_bn_relu_pool_fwd, grid, dim3(kThreads), 0, stream(), x, partial, S, gamma, beta, y, save_mean,
                      save_var, running_mean, running_var, N, C, H, W, ipb, eps, momentum);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+// dfhip_bn_relu_maxpool2_forward with the batch statistics taken from the partials the convolution that produced x
+// left behind (dfhip_conv2d_forward_stats): no statistics pass over x
+int dfhip_bn_relu_maxpool2_forward_partials(const float* x, const float* partials, int rows, const float* gamma,
+                                            const float* beta, float* y, float* save_mean, float* save_var,
+                                            float* running_mean, float* running_var, int N, int C, int H, int W,
+                                            float eps, float momentum) {
+  DF_INIT();
+  DF_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 7) == 0 && rows > 0,
+               "bn_relu_maxpool2_forward_partials: needs H even, W a multiple of 8, rows > 0");
+  DF_CHECK_ARG(x && y && partials && save_mean && save_var, "bn_relu_maxpool2_forward_partials: null array");
+  ProfScope prof("bn_relu_pool_fwd", 0.0, (4.0 + 1.0) * (double)N * C * H * W);
+  int S, ipb;
+  bn_split(N, C, S, ipb);
+  dim3 grid((unsigned)C, (unsigned)S);
+  DF_LAUNCH(k_bn_relu_pool_fwd, grid, dim3(kThreads), 0, stream(), x, partials, -rows, gamma, beta, y, save_mean,
+            save_var, running_mean, running_var, N, C, H, W, ipb, eps, momentum);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }

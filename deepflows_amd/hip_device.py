@@ -308,6 +308,13 @@ class HipModule:
             flat += [x.ptr, g(gamma), sm.ptr, sv.ptr, g(dx), g(dg), g(db), float(eps)]
         _lib.check(self._lib.dfhip_bn2d_backward_pair(dy.ptr, *flat, N, C, HW))
 
+    def bn_relu_maxpool2_forward_partials(self, x, partials, rows, gamma, beta, y, save_mean, save_var, running_mean,
+                                          running_var, N, C, H, W, eps, momentum):
+        g = lambda h: h.ptr if h is not None else None
+        _lib.check(self._lib.dfhip_bn_relu_maxpool2_forward_partials(
+            x.ptr, partials.ptr, int(rows), g(gamma), g(beta), y.ptr, save_mean.ptr, save_var.ptr, g(running_mean),
+            g(running_var), N, C, H, W, float(eps), float(momentum)))
+
     def bn_relu_maxpool2_forward(self, x, gamma, beta, y, save_mean, save_var, running_mean, running_var,
                                  N, C, H, W, eps, momentum):
         g = lambda h: h.ptr if h is not None else None

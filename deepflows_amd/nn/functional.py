@@ -670,11 +670,17 @@ class _BnReluPoolFused(_FusedNode):
         out = _new((N, C, H // 2, W // 2), dev)
         self.mean, self.var = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
         h = lambda t: t._handle if t is not None else None
-        dev.bn_relu_maxpool2_forward(self.xd._handle, h(self.wd), h(self.bd), out._handle, self.mean._handle,
-                                     self.var._handle,
-                                     h(running_mean.data) if running_mean is not None else None,
-                                     h(running_var.data) if running_var is not None else None,
-                                     N, C, H, W, self.eps, float(momentum))
+        rm = h(running_mean.data) if running_mean is not None else None
+        rv = h(running_var.data) if running_var is not None else None
+        partials = getattr(x, "bn_partials", None)
+        if partials is not None and hasattr(dev.mod, "bn_relu_maxpool2_forward_partials"):
+            # x is a convolution output that carries BatchNorm partials: no statistics pass over it
+            dev.bn_relu_maxpool2_forward_partials(self.xd._handle, partials[0]._handle, partials[1], h(self.wd),
+                                                  h(self.bd), out._handle, self.mean._handle, self.var._handle,
+                                                  rm, rv, N, C, H, W, self.eps, float(momentum))
+        else:
+            dev.bn_relu_maxpool2_forward(self.xd._handle, h(self.wd), h(self.bd), out._handle, self.mean._handle,
+                                         self.var._handle, rm, rv, N, C, H, W, self.eps, float(momentum))
         self._grads = None
         super().__init__(out, [x, weight, bias])
 

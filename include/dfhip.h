@@ -235,6 +235,12 @@ int dfhip_bn2d_backward_pair(const float* dy, const float* xa, const float* gamm
 int dfhip_bn_relu_maxpool2_forward(const float* x, const float* gamma, const float* beta, float* y,
                                    float* save_mean, float* save_var, float* running_mean,
                                    float* running_var, int N, int C, int H, int W, float eps, float momentum);
+/* the same with the batch statistics from the partials the convolution that produced x left behind
+ * (dfhip_conv2d_forward_stats: partials[rows][C][3]): no statistics pass over x */
+int dfhip_bn_relu_maxpool2_forward_partials(const float* x, const float* partials, int rows, const float* gamma,
+                                            const float* beta, float* y, float* save_mean, float* save_var,
+                                            float* running_mean, float* running_var, int N, int C, int H, int W,
+                                            float eps, float momentum);
 int dfhip_bn_relu_maxpool2_backward(const float* x, const float* y, const float* g, const float* gamma,
                                     const float* beta, const float* save_mean, const float* save_var,
                                     float* dx, float* dgamma, float* dbeta, int N, int C, int H, int W,
