@@ -2688,57 +2688,52 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
 // consecutive floats per output channel and a wave stores 32 x T x 4 contiguous bytes (the per-tap
 // version above leaves 4-byte stores 4*T bytes apart: PMC 7x write amplification).  SL slices of
 // the slabs are summed in a fixed order and combined through LDS.
-__global__ __launch_bounds__(256) void k_wgrad_group_sum(SGroup a) {
-  __shared__ float4 part[256 * 9];
-  const int b = blockIdx.x;
-  int li = 0;
-  while (li + 1 < a.n && b >= a.vb_end[li]) li++;
-  const SlabSum& d = a.s[li];
-  const int vb = b - (li ? a.vb_end[li - 1] : 0);
-  const int T = d.T;
+// (TT = the number of taps as a compile-time constant: with `if (t < T)` on the run-time T every tap's load sat in a
+// basic block of its own and the 36 loads of a round became dependent round trips -- 16 us for 24 MB)
+template <int TT>
+__device__ __forceinline__ void wgrad_group_sum_body(const SlabSum& d, const int vb, float4* part) {
   const int ipb = 256 / d.SL;
   const int it = threadIdx.x % ipb, sl = threadIdx.x / ipb;
   const int item = vb * ipb + it;                         // (tile, q, lane)
   const int nitem = d.OT * d.CT * 256;
-  const int64_t slab_f4 = (int64_t)nitem * T;             // float4s per slab
-  float4 acc[9];
+  const int64_t slab_f4 = (int64_t)nitem * TT;            // float4s per slab
+  float4 acc[TT];
 #pragma unroll
-  for (int t = 0; t < 9; t++) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < TT; t++) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (item < nitem) {
-    const float4* src = reinterpret_cast<const float4*>(d.slabs) + (int64_t)(item >> 8) * T * 256 + (item & 255);
+    const float4* src = reinterpret_cast<const float4*>(d.slabs) + (int64_t)(item >> 8) * TT * 256 + (item & 255);
     for (int s0 = sl; s0 < d.ps; s0 += 4 * d.SL) {       // four slabs' loads in flight
-      float4 v[4][9];
+      float4 v[4][TT];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int s = s0 + u * d.SL;
         const float4* p = src + (int64_t)(s < d.ps ? s : s0) * slab_f4;
 #pragma unroll
-        for (int t = 0; t < 9; t++)
-          if (t < T) v[u][t] = p[t * 256];
+        for (int t = 0; t < TT; t++) v[u][t] = p[t * 256];
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (s0 + u * d.SL < d.ps) {
+      for (int u = 0; u < 4; u++) {
+        const float on = s0 + u * d.SL < d.ps ? 1.0f : 0.0f;     // (a slab past the end re-read slab s0: times 0)
 #pragma unroll
-          for (int t = 0; t < 9; t++)
-            if (t < T) { acc[t].x += v[u][t].x; acc[t].y += v[u][t].y; acc[t].z += v[u][t].z; acc[t].w += v[u][t].w; }
+        for (int t = 0; t < TT; t++) {
+          acc[t].x = fmaf(v[u][t].x, on, acc[t].x); acc[t].y = fmaf(v[u][t].y, on, acc[t].y);
+          acc[t].z = fmaf(v[u][t].z, on, acc[t].z); acc[t].w = fmaf(v[u][t].w, on, acc[t].w);
         }
+      }
     }
   }
   if (d.SL > 1) {
 #pragma unroll
-    for (int t = 0; t < 9; t++)
-      if (t < T) part[t * 256 + threadIdx.x] = acc[t];
+    for (int t = 0; t < TT; t++) part[t * 256 + threadIdx.x] = acc[t];
     __syncthreads();
   }
   if (sl == 0 && item < nitem) {
     for (int k = 1; k < d.SL; k++)
 #pragma unroll
-      for (int t = 0; t < 9; t++)
-        if (t < T) {
-          const float4 v = part[t * 256 + k * ipb + it];
-          acc[t].x += v.x; acc[t].y += v.y; acc[t].z += v.z; acc[t].w += v.w;
-        }
+      for (int t = 0; t < TT; t++) {
+        const float4 v = part[t * 256 + k * ipb + it];
+        acc[t].x += v.x; acc[t].y += v.y; acc[t].z += v.z; acc[t].w += v.w;
+      }
     const int lane = item & 63, q = (item >> 6) & 3, tile = item >> 8;
     const int ct = tile % d.CT, ot = tile / d.CT;
     const int c = ct * 32 + (lane & 31);
@@ -2747,13 +2742,24 @@ __global__ __launch_bounds__(256) void k_wgrad_group_sum(SGroup a) {
 #pragma unroll
       for (int e = 0; e < 4; e++)
         if (o + e < d.O) {
-          float* dst = d.dw + ((int64_t)(o + e) * d.C + c) * T;
+          float* dst = d.dw + ((int64_t)(o + e) * d.C + c) * TT;
 #pragma unroll
-          for (int t = 0; t < 9; t++)
-            if (t < T) dst[t] = e == 0 ? acc[t].x : (e == 1 ? acc[t].y : (e == 2 ? acc[t].z : acc[t].w));
+          for (int t = 0; t < TT; t++)
+            dst[t] = e == 0 ? acc[t].x : (e == 1 ? acc[t].y : (e == 2 ? acc[t].z : acc[t].w));
         }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_group_sum(SGroup a) {
+  __shared__ float4 part[256 * 9];
+  const int b = blockIdx.x;
+  int li = 0;
+  while (li + 1 < a.n && b >= a.vb_end[li]) li++;
+  const SlabSum& d = a.s[li];
+  const int vb = b - (li ? a.vb_end[li - 1] : 0);
+  if (d.T == 9) wgrad_group_sum_body<9>(d, vb, part);
+  else wgrad_group_sum_body<1>(d, vb, part);
 }
 
 // out[i] = sum_s slabs[s][i], summed in a fixed order.  A block owns 256 consecutive elements

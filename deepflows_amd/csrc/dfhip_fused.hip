@@ -1389,12 +1389,12 @@ __global__ __launch_bounds__(256) void k_bn_finalize_partials(BnInput bn, int C)
   float pn[RP], pm[RP], pq[RP];
 #pragma unroll
   for (int k = 0; k < RP; k++) {
+    // (unconditional loads at a clamped row, all in flight together: a load under `if (r < rows)` is a basic block
+    // of its own and a round trip of its own)
     const int r = lane + 64 * k;
-    pn[k] = 0.0f; pm[k] = 0.0f; pq[k] = 0.0f;
-    if (r < bn.rows) {
-      const float* p = bn.part + ((int64_t)r * C + c) * 3;
-      pn[k] = p[0]; pm[k] = p[1]; pq[k] = p[2];
-    }
+    const float* p = bn.part + ((int64_t)min(r, bn.rows - 1) * C + c) * 3;
+    const float a0 = p[0], a1 = p[1], a2 = p[2];
+    pn[k] = r < bn.rows ? a0 : 0.0f; pm[k] = a1; pq[k] = r < bn.rows ? a2 : 0.0f;
   }
   float n = 0.0f, a = 0.0f;
 #pragma unroll
