@@ -49,7 +49,13 @@ FAMILIES = {
     "conv2d_fwd_igemm": ("k_conv3x3_rowmma", "k_conv_igemm_v4<3, 0", "k_conv_igemm_v4<1, 0", "k_conv_igemm$", "k_conv_rows3", "k_conv1x1s2_fwd", "k_conv3x3_img2_fwd"),
     "conv2d_dgrad_igemm": ("k_conv_igemm_v4<3, 1", "k_conv_igemm_v4<1, 1"),
     "conv2d_dgrad_overwrite_igemm": ("k_conv_igemm_v4<3, 2", "k_conv_igemm_v4<1, 2", "k_dgrad_ow_s1"),
-    "bn2d_fwd": ("k_bn_apply_partials", "k_bn_stats", "k_bn_apply"),
+    "bn2d_fwd": ("k_bn_apply_partials", "k_bn_finalize_partials", "k_bn_stats", "k_bn_apply"),
+    "pool_linear_fwd": ("k_pool_linear_fwd",),
+    "pool_linear_bwd": ("k_pool_linear_bwd",),
+    "softmax_ce_fwd": ("k_ce_small", "k_ce_rows", "k_ce_finish"),
+    "adam_step": ("k_adam",),
+    "bn_relu_pool_fwd": ("k_bn_relu_pool_fwd",),
+    "bn_relu_pool_bwd": ("k_bn_relu_pool_bwd",),
     "bn2d_bwd": ("k_bn_fused_bwd", "k_bn_bwd_stats", "k_bn_bwd_apply"),
 }
 

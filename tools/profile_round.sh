@@ -15,10 +15,10 @@ python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --dgrad accumulate --no-cpu-baseline > $OUT/bench_accumulate.json 2> $OUT/bench_accumulate.err
 python3 bench.py --workload cnn > $OUT/bench_cnn.json 2> $OUT/bench_cnn.err
 python3 bench.py --workload mlp --steps 200 --warmup 20 > $OUT/bench_mlp.json 2> $OUT/bench_mlp.err
-CMD="python3 bench.py --steps $STEPS --warmup 3 --no-cpu-baseline"
+CMD="python3 bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-prof-gate"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $CMD > $OUT/stats.log 2>&1
 for wl in cnn mlp; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -o s -- python3 bench.py --workload $wl --steps $STEPS --warmup 3 --no-cpu-baseline > $OUT/stats_$wl.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -o s -- python3 bench.py --workload $wl --steps $STEPS --warmup 3 --no-cpu-baseline --no-prof-gate > $OUT/stats_$wl.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_acc -o s -- $CMD --dgrad accumulate > $OUT/stats_acc.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $CMD > $OUT/pmc_fetch.log 2>&1
