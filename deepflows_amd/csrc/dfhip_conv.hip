@@ -827,12 +827,19 @@ struct OwGeo {
   }
 };
 
-template <int O, int GEO>
+// PAIR (GEO 1 only): the block's 1x1 / stride 2 shortcut convolution reads the same input tensor, and its input
+// gradient lands on the pixels with even (y, x) -- parity class 0 of this kernel, same source pixel (y >> 1, x >> 1):
+// dy2 / w2 (O, C, 1, 1) are a FIFTH slice with an operand of its own, and the two gradients of the tensor leave as one
+// sum (tensor.py:444) instead of a second launch that re-reads and re-writes the even pixels.
+template <int O, int GEO, bool PAIR = false>
 __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ dy, const float* __restrict__ w,
                                                      const float* __restrict__ add, float* __restrict__ dx,
-                                                     int C, int H, int lw, int tiles, int pg) {
+                                                     int C, int H, int lw, int tiles, int pg,
+                                                     const float* __restrict__ dy2 = nullptr,
+                                                     const float* __restrict__ w2 = nullptr) {
+  static_assert(!PAIR || GEO == 1, "the shortcut rides on the stride-2 3x3 kernel");
   constexpr int NP = O / 2, NSL = OwGeo<GEO>::NSL;
-  __shared__ float Wl[NSL][O][32];                  // the weight slices of this channel tile: [slice][o][c]
+  __shared__ float Wl[NSL + (PAIR ? 1 : 0)][O][32]; // the weight slices of this channel tile: [slice][o][c]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int W = 1 << lw, HW = H << lw;
@@ -853,6 +860,12 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
 #pragma unroll
     for (int kp = 0; kp < NP; kp++) sv[kp] = sp[(int64_t)(2 * kp) * SHW];
   }
+  float sv2[PAIR ? NP : 1];
+  if constexpr (PAIR) {
+    const float* sp = dy2 + ((int64_t)n * O + half) * SHW + (u << slw) + v;
+#pragma unroll
+    for (int kp = 0; kp < NP; kp++) sv2[kp] = sp[(int64_t)(2 * kp) * SHW];
+  }
   // ... the gradient the tensor already holds (added in the epilogue; requested now, not after the MFMAs) ...
   const int64_t obase = ((int64_t)n * C + c0) * HW + rem;
   float held[16];
@@ -861,17 +874,19 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
     held[r] = add ? add[obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW] : 0.0f;
   // ... and its share of the weight slices (thread -> (o, c) pairs, the four taps 4, 5, 7, 8 of each)
   constexpr int PAIRS = O * 32 / 256;
-  float wv[PAIRS][4];
+  float wv[PAIRS][4], wv2[PAIRS];
 #pragma unroll
   for (int i = 0; i < PAIRS; i++) {
     const int e = threadIdx.x + 256 * i, o = e >> 5, c = e & 31;
     OwGeo<GEO>::slices(w, (int64_t)o * C + c0 + c, wv[i]);
+    wv2[i] = PAIR ? w2[(int64_t)o * C + c0 + c] : 0.0f;
   }
 #pragma unroll
   for (int i = 0; i < PAIRS; i++) {
     const int e = threadIdx.x + 256 * i, o = e >> 5, c = e & 31;
 #pragma unroll
     for (int q = 0; q < NSL; q++) Wl[q][o][c] = wv[i][q];
+    if constexpr (PAIR) Wl[NSL][o][c] = wv2[i];
   }
   __syncthreads();
   if (!live) return;
@@ -889,6 +904,17 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
     for (int kp = 0; kp < NP; kp++)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], mine ? sv[kp] : 0.0f, acc, 0, 0, 0);
   }
+  if constexpr (PAIR) {
+    const bool mine = cls == 0;
+    if (__ballot(mine) != 0ull) {
+      float a[NP];
+#pragma unroll
+      for (int kp = 0; kp < NP; kp++) a[kp] = Wl[NSL][2 * kp + half][l31];
+#pragma unroll
+      for (int kp = 0; kp < NP; kp++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], mine ? sv2[kp] : 0.0f, acc, 0, 0, 0);
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 16; r++)
     dx[obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW] = acc[r] + held[r];
@@ -897,14 +923,17 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
 // The same for 128 / 256 output channels: ONE tile per workgroup, its four waves split the reduction
 // over o four ways (each keeps O/8 dY values per lane) and their partial tiles are summed through LDS
 // in wave order.  The weight slices (4 x O x 32 floats) sit in dynamic LDS.
-template <int O, int GEO>
+template <int O, int GEO, bool PAIR = false>
 __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict__ dy, const float* __restrict__ w,
                                                         const float* __restrict__ add, float* __restrict__ dx,
-                                                        int C, int H, int lw, int tiles, int pg) {
+                                                        int C, int H, int lw, int tiles, int pg,
+                                                        const float* __restrict__ dy2 = nullptr,
+                                                        const float* __restrict__ w2 = nullptr) {
+  static_assert(!PAIR || GEO == 1, "the shortcut rides on the stride-2 3x3 kernel");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int OQ = O / 4, NP = OQ / 2, NSL = OwGeo<GEO>::NSL;
-  float* Wl = smem;                                 // [NSL][O][32]
-  float* red = smem + NSL * O * 32;                 // [3][16][64]
+  constexpr int OQ = O / 4, NP = OQ / 2, NSL = OwGeo<GEO>::NSL, NSLP = NSL + (PAIR ? 1 : 0);
+  float* Wl = smem;                                 // [NSLP][O][32]
+  float* red = smem + NSLP * O * 32;                // [3][16][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int W = 1 << lw, HW = H << lw;
@@ -915,17 +944,19 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict_
   // the weight slices of this channel tile, once per workgroup (it walks several pixel tiles)
   constexpr int PAIRS = O * 32 / 256;
   for (int i0 = 0; i0 < PAIRS; i0 += 16) {          // sixteen (o, c) pairs in flight per thread
-    float wv[16][4];
+    float wv[16][4], wv2[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int e = threadIdx.x + 256 * (i0 + i), o = e >> 5, c = e & 31;
       OwGeo<GEO>::slices(w, (int64_t)o * C + c0 + c, wv[i]);
+      wv2[i] = PAIR ? w2[(int64_t)o * C + c0 + c] : 0.0f;
     }
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int e = threadIdx.x + 256 * (i0 + i), o = e >> 5, c = e & 31;
 #pragma unroll
       for (int q = 0; q < NSL; q++) Wl[(q * O + o) * 32 + c] = wv[i][q];
+      if constexpr (PAIR) Wl[(NSL * O + o) * 32 + c] = wv2[i];
     }
   }
   __syncthreads();
@@ -940,6 +971,12 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict_
       const float* sp = dy + ((int64_t)n * O + ob + half) * SHW + (u << slw) + v;
 #pragma unroll
       for (int kp = 0; kp < NP; kp++) sv[kp] = sp[(int64_t)(2 * kp) * SHW];
+    }
+    float sv2[PAIR ? NP : 1];
+    if constexpr (PAIR) {
+      const float* sp = dy2 + ((int64_t)n * O + ob + half) * SHW + (u << slw) + v;
+#pragma unroll
+      for (int kp = 0; kp < NP; kp++) sv2[kp] = sp[(int64_t)(2 * kp) * SHW];
     }
     const int64_t obase = ((int64_t)n * C + c0) * HW + rem;
     float held[16];                                 // (wave 0 stores the tile: it requests the held gradient now)
@@ -960,6 +997,18 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict_
 #pragma unroll
       for (int kp = 0; kp < NP; kp++)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], mine ? sv[kp] : 0.0f, acc, 0, 0, 0);
+    }
+    if constexpr (PAIR) {
+      const bool mine = cls == 0;
+      if (__ballot(mine) != 0ull) {
+        const float* wq = Wl + (NSL * O + ob + half) * 32 + l31;
+        float a[NP];
+#pragma unroll
+        for (int kp = 0; kp < NP; kp++) a[kp] = wq[2 * kp * 32];
+#pragma unroll
+        for (int kp = 0; kp < NP; kp++)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], mine ? sv2[kp] : 0.0f, acc, 0, 0, 0);
+      }
     }
     if (wave > 0) {
 #pragma unroll
@@ -3961,7 +4010,8 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
                                  (int)std::max(lds, (size_t)65536)));                                         \
       attr = true;                                                                                            \
     }                                                                                                         \
-    DF_LAUNCH((k_dgrad_ow_s1_ks<OV, GV>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, H, lw, tiles, pg); \
+    DF_LAUNCH((k_dgrad_ow_s1_ks<OV, GV>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, H, lw, tiles, pg, \
+              (const float*)nullptr, (const float*)nullptr);                                                    \
   } while (0)
       if (O == 128) { if (geo == 0) DF_KS(128, 0); else if (geo == 1) DF_KS(128, 1); else DF_KS(128, 2); }
       else { if (geo == 0) DF_KS(256, 0); else if (geo == 1) DF_KS(256, 1); else DF_KS(256, 2); }
@@ -3971,7 +4021,8 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
     }
     if (lean_ok && (O == 32 || O == 64)) {
       dim3 grid((unsigned)df_ceil_div(tiles, 4), (unsigned)(C / 32));
-#define DF_A(OV, GV) DF_LAUNCH((k_dgrad_ow_s1<OV, GV>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg)
+#define DF_A(OV, GV) DF_LAUNCH((k_dgrad_ow_s1<OV, GV>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg, \
+                               (const float*)nullptr, (const float*)nullptr)
       if (O == 32) { if (geo == 0) DF_A(32, 0); else if (geo == 1) DF_A(32, 1); else DF_A(32, 2); }
       else { if (geo == 0) DF_A(64, 0); else if (geo == 1) DF_A(64, 1); else DF_A(64, 2); }
 #undef DF_A
@@ -4002,6 +4053,56 @@ int dfhip_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C,
   DF_TOUCH(w);
   DF_TOUCH(dx);
   return conv2d_dgrad_impl(dy, w, nullptr, dx, N, C, H, W, O, k, stride, pad, mode);
+}
+
+// dx = dgrad(3x3 / stride 2 / pad 1; dy, w) + dgrad(1x1 / stride 2 / pad 0; dy2, w2) (+ add): the two consumers of a
+// residual block's input whose shortcut is a convolution (test/ResNet_CIFAR10_cuda.py:58-63: conv1 and downsample[0]
+// both read x), reference-exact ("overwrite") mode, as ONE launch -- the shortcut's gradient lands on the even pixels,
+// parity class 0 of the stride-2 kernel.  *done = 0 (nothing launched) when the shape has no such kernel: the caller
+// then runs dfhip_conv2d_dgrad and dfhip_conv2d_dgrad_add.
+int dfhip_conv2d_dgrad_pair(const float* dy, const float* w, const float* dy2, const float* w2, const float* add,
+                            float* dx, int N, int C, int H, int W, int O, int mode, int* done) {
+  DF_INIT_KEEP();
+  DF_TOUCH(dy); DF_TOUCH(w); DF_TOUCH(dy2); DF_TOUCH(w2); DF_TOUCH(add); DF_TOUCH(dx);
+  DF_CHECK_ARG(dy && w && dy2 && w2 && dx && done, "conv2d_dgrad_pair: null array");
+  *done = 0;
+  int oh, ow;
+  int s = check_conv_args("conv2d_dgrad_pair", N, C, H, W, O, 3, 2, 1, oh, ow);
+  if (s != DFHIP_OK) return s;
+  static int lean = getenv("DFHIP_DGRAD_LEAN") ? atoi(getenv("DFHIP_DGRAD_LEAN")) : 1;
+  static int pair_on = getenv("DFHIP_DGRAD_PAIR") ? atoi(getenv("DFHIP_DGRAD_PAIR")) : 1;
+  int lw = 0;
+  while ((1 << lw) < W) lw++;
+  const bool ok = lean && pair_on && mode == 0 && C % 32 == 0 && (1 << lw) == W && H >= 2 && W >= 2 &&
+                  ((int64_t)N * H * W) % 32 == 0 && H % 2 == 0 && oh * 2 == H && ow * 2 == W &&
+                  (O == 32 || O == 64 || O == 128);          // (256: five slices do not fit the LDS)
+  if (!ok) return DFHIP_OK;
+  const int tiles = (int)((int64_t)N * H * W / 32);
+  const int pg = (((int64_t)N * H * W) % 128 == 0 && W <= 64) ? 1 : 0;
+  double flops = 2.0 * N * H * W * (double)C * O + 2.0 * N * oh * ow * (double)C * O;
+  double bytes = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * oh * ow);
+  ProfScope prof("conv2d_dgrad_overwrite_igemm", flops, bytes);
+  if (O == 128) {
+    const int want = std::max(1, num_cus() * 2 / (C / 32));
+    dim3 grid((unsigned)std::min(tiles, want), (unsigned)(C / 32));
+    const size_t lds = ((size_t)5 * O * 32 + 3 * 16 * 64) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_s1_ks<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)std::max(lds, (size_t)65536)));
+      attr = true;
+    }
+    DF_LAUNCH((k_dgrad_ow_s1_ks<128, 1, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, H, lw, tiles, pg, dy2, w2);
+  } else {
+    dim3 grid((unsigned)df_ceil_div(tiles, 4), (unsigned)(C / 32));
+    if (O == 32)
+      DF_LAUNCH((k_dgrad_ow_s1<32, 1, true>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg, dy2, w2);
+    else
+      DF_LAUNCH((k_dgrad_ow_s1<64, 1, true>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg, dy2, w2);
+  }
+  DF_LAUNCH_CHECK();
+  *done = 1;
+  return DFHIP_OK;
 }
 
 // dx = conv2d_dgrad(dy, w) + add: the gradient accumulation of a tensor with two consumers

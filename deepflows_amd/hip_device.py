@@ -260,6 +260,15 @@ class HipModule:
 
     wgrad_grouping = os.environ.get("DF_WGRAD_GROUP", "1") != "0"
 
+    def conv2d_dgrad_pair(self, dy, w, dy2, w2, add, dx, N, C, H, W, O, mode=None):
+        """dx = dgrad(3x3 s2 p1; dy, w) + dgrad(1x1 s2 p0; dy2, w2) (+ add) as one launch; False = no such kernel."""
+        mode = self.conv_dgrad_mode if mode is None else mode
+        m = {"overwrite": 0, "accumulate": 1}[mode]
+        done = ctypes.c_int(0)
+        _lib.check(self._lib.dfhip_conv2d_dgrad_pair(dy.ptr, w.ptr, dy2.ptr, w2.ptr, add.ptr if add is not None else None,
+                                                     dx.ptr, N, C, H, W, O, m, ctypes.byref(done)))
+        return bool(done.value)
+
     def conv2d_dgrad(self, dy, w, dx, N, C, H, W, O, k, stride, pad, mode=None):
         mode = self.conv_dgrad_mode if mode is None else mode
         m = {"overwrite": 0, "accumulate": 1}[mode]

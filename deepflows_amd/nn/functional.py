@@ -282,11 +282,30 @@ class _Conv2dFused(_FusedNode):
     # the engine may hand over the gradient the input already holds (tensor.py backward): the sum
     # is then formed in the epilogue of the input-gradient kernel
     fuses_accumulation = True
+    # residual block with a convolution shortcut: conv1's node points at the shortcut convolution's node (both read
+    # the block input).  The backward sweep reaches conv1 first; if the shortcut's output gradient is complete by
+    # then, ONE launch forms both input gradients and their sum, and the shortcut's node hands nothing back for x.
+    shortcut_sibling = None
+    _dx_delivered = False
 
     def grad_fn(self, node, grad, accumulated=None):
         g = grad.compact()
         dev = g.device
         if node is self.x:
+            if self._dx_delivered:
+                return None                       # conv1's launch already carried this node's input gradient
+            sib = self.shortcut_sibling
+            if (sib is not None and sib.x is self.x and sib.grad is not None and not sib._dx_delivered
+                    and hasattr(dev.mod, "conv2d_dgrad_pair") and self.geo[5:] == (3, 2, 1) and sib.geo[5:] == (1, 2, 0)
+                    and sib.geo[:5] == self.geo[:5]):
+                sg = sib.grad.data if isinstance(sib.grad, Tensor) else sib.grad
+                out = _new(self.xd.shape, dev)
+                N, C, H, W, O = self.geo[:5]
+                if dev.conv2d_dgrad_pair(g._handle, self.wd._handle, sg.compact()._handle, sib.wd._handle,
+                                         accumulated.compact()._handle if accumulated is not None else None,
+                                         out._handle, N, C, H, W, O):
+                    sib._dx_delivered = True
+                    return out
             out = _new(self.xd.shape, dev)
             if accumulated is not None:
                 dev.conv2d_dgrad_add(g._handle, self.wd._handle, accumulated.compact()._handle, out._handle,

@@ -242,9 +242,13 @@ class Tensor:
                     if (held is not None and getattr(node, "fuses_accumulation", False)
                             and node.x is parent and hasattr(held.device.mod, "conv2d_dgrad_add")):
                         # a fused node adds the gradient the parent already holds in its own kernel
-                        parent.grad = node.grad_fn(parent, grad, held)
+                        res = node.grad_fn(parent, grad, held)
+                        if res is not None:
+                            parent.grad = res
                         continue
                     contrib = node.grad_fn(parent, grad)
+                    if contrib is None:          # (a fused sibling node already delivered this contribution)
+                        continue
                     if isinstance(contrib, Tensor):
                         contrib = contrib.data
                     if tuple(contrib.shape) != tuple(parent.shape):

@@ -102,6 +102,8 @@ class ResidualBlock(nn.Module):
             for layer in ds:
                 identity = layer(identity)
         z1 = self.conv1(x)
+        if pair and hasattr(z1, "shortcut_sibling") and hasattr(zd, "shortcut_sibling"):
+            z1.shortcut_sibling = zd           # both read x: one launch forms both input gradients (nn.functional)
         # conv2(bn1(z1)): bn1 applied on conv2's operand loads (one node, bn1's output is never written); None when
         # that form does not apply here
         z2 = nn.functional.bn_conv2d_train(z1, self.bn1, self.conv2)

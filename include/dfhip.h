@@ -133,6 +133,15 @@ int dfhip_conv2d_forward(const float* x, const float* w, const float* bias, floa
 int dfhip_conv2d_dgrad_add(const float* dy, const float* w, const float* add, float* dx, int N, int C,
                            int H, int W, int O, int k, int stride, int pad, int mode);
 
+/* dx = dgrad(3x3 / stride 2 / pad 1; dy, w) + dgrad(1x1 / stride 2 / pad 0; dy2, w2) (+ add, may be NULL): the two
+ * gradients the input of a residual block receives when its shortcut is a convolution (test/ResNet_CIFAR10_cuda.py:
+ * 58-63: conv1 and downsample[0] both read x; tensor.py:444 sums them), each with the reference's last-writer-wins
+ * rule (functional.py:285-294), as one launch.  dy, dy2 (N, O, H/2, W/2); w (O, C, 3, 3); w2 (O, C, 1, 1); dx
+ * (N, C, H, W).  mode as dfhip_conv2d_dgrad; *done = 0 (nothing launched) when the shape / mode has no such kernel:
+ * the caller then runs dfhip_conv2d_dgrad followed by dfhip_conv2d_dgrad_add. */
+int dfhip_conv2d_dgrad_pair(const float* dy, const float* w, const float* dy2, const float* w2, const float* add,
+                            float* dx, int N, int C, int H, int W, int O, int mode, int* done);
+
 /* weight gradient: tensor.py:716 (A^T . dC) for the conv GEMM; dw (O,C,k,k)            */
 int dfhip_conv2d_wgrad(const float* x, const float* dy, float* dw,
                        int N, int C, int H, int W, int O, int k, int stride, int pad);

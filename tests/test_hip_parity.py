@@ -389,6 +389,61 @@ def test_wgrad_affine_outside_a_group_writes_the_operand_out(hip_device):
     assert_close(a, b, 1e-5, "wgrad_affine fall-back")
 
 
+@pytest.mark.parametrize("C,HW,O", [(32, 16, 64), (64, 8, 128), (32, 8, 32)])
+def test_shortcut_input_gradient_rides_on_the_stride2_kernel(hip_device, C, HW, O):
+    """dfhip_conv2d_dgrad_pair: the reference-exact input gradients of a block's stride-2 3x3 convolution and of its
+    1x1 / stride-2 shortcut (both read the block input) as one launch, against the two launches; and the same through
+    a residual block's autograd nodes (the shortcut's node then hands nothing back for the input)."""
+    mod = hip_device.mod
+    rng = np.random.default_rng(13)
+    N = 16
+    def arr(shape):
+        h = mod.Array(int(np.prod(shape))); mod.from_numpy(rng.standard_normal(shape).astype(np.float32), h); return h
+    dy, dy2 = arr((N, O, HW // 2, HW // 2)), arr((N, O, HW // 2, HW // 2))
+    w, w2, held = arr((O, C, 3, 3)), arr((O, C, 1, 1)), arr((N, C, HW, HW))
+    back = lambda h: mod.to_numpy(h, (h.size,), (1,), 0)
+    for add in (None, held):
+        a, b, t = mod.Array(N * C * HW * HW), mod.Array(N * C * HW * HW), mod.Array(N * C * HW * HW)
+        assert mod.conv2d_dgrad_pair(dy, w, dy2, w2, add, a, N, C, HW, HW, O, mode="overwrite")
+        if add is None:
+            mod.conv2d_dgrad(dy, w, t, N, C, HW, HW, O, 3, 2, 1, mode="overwrite")
+        else:
+            mod.conv2d_dgrad_add(dy, w, add, t, N, C, HW, HW, O, 3, 2, 1, mode="overwrite")
+        mod.conv2d_dgrad_add(dy2, w2, t, b, N, C, HW, HW, O, 1, 2, 0, mode="overwrite")
+        assert_close(back(a), back(b), 2e-6, f"dgrad pair C={C} O={O} add={add is not None}")
+    # accumulate mode has no such kernel: the call reports it and launches nothing
+    assert not mod.conv2d_dgrad_pair(dy, w, dy2, w2, None, mod.Array(N * C * HW * HW), N, C, HW, HW, O, mode="accumulate")
+
+
+def test_residual_block_with_convolution_shortcut_one_input_gradient_launch(hip_device):
+    from deepflows_amd import nn, tensor, workloads
+    from deepflows_amd.tensor import Graph, Tensor
+    dev = hip_device
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((16, 32, 16, 16)).astype(np.float32)
+    gy = rng.standard_normal((16, 64, 8, 8)).astype(np.float32)
+    results = []
+    for linked in (True, False):
+        np.random.seed(9)
+        down = nn.ModuleList([nn.Conv2d(32, 64, kernel_size=1, stride=2, bias=False, device=dev), nn.BatchNorm2d(64, device=dev)])
+        blk = workloads.ResidualBlock(32, 64, stride=2, downsample=down, device=dev)
+        blk.train()
+        xt = Tensor(x, device=dev, requires_grad=True)
+        xin = xt * 1.0                           # a non-leaf input, as inside the network
+        y = blk(xin)
+        if not linked:
+            for node in Graph.node_list:
+                if isinstance(node, nn.functional._Conv2dFused):
+                    node.shortcut_sibling = None
+        loss = tensor.sum(y * Tensor(gy, device=dev))
+        loss.backward()
+        results.append([y.numpy().copy(), xt.grad.numpy().copy(), blk.conv1.weight.grad.numpy().copy(),
+                        down[0].weight.grad.numpy().copy()])
+        Graph.free_graph_all()
+    for a, b, nm in zip(results[0], results[1], ("y", "dx", "dw1", "dw_shortcut")):
+        assert_close(a, b, 2e-6, "residual block, paired input gradient: " + nm)
+
+
 def test_classifier_head_as_one_node(hip_device):
     """fc(mean(mean(x, 2), 2)) + cross-entropy: the pooled-linear node and the loss gradient left behind by the loss
     kernel, against the separate nodes (mean_hw, Linear, cross-entropy with its own backward launch)."""
