@@ -2929,7 +2929,8 @@ static int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b)
 // main kernel; returns -1 when the shape is not eligible (the generic kernel takes it then)
 int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, float* partials = nullptr,
                  int cap_rows = 0, int* rows_out = nullptr) {
-  if (g.CS % 8 != 0 || !(g.k == 1 || g.k == 3)) return -1;
+  static int k5_on = getenv("DFHIP_IGEMM_K5") ? atoi(getenv("DFHIP_IGEMM_K5")) : 1;
+  if (g.CS % 8 != 0 || !(g.k == 1 || g.k == 3 || (g.k == 5 && k5_on))) return -1;
   if (g.mode != 0 && g.CD % 32 != 0) return -1;    // dgrad weight rows are staged as whole 32-channel runs
   if ((g.HS * g.WS) % 4 != 0) return -1;            // channel planes must stay 16-byte aligned
   const int k2 = g.k * g.k;
@@ -3011,7 +3012,10 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, 
                : (g.mode == 1 ? launch_igemm_v4<KSV, 1>(g, grid, lds)     \
                               : launch_igemm_v4<KSV, 2>(g, grid, lds)))
   if (g.k == 1) st = DF_V4(1);
-  else st = DF_V4(3);
+  else if (g.k == 3) st = DF_V4(3);
+  else      // 5x5 (the CNN workload's second convolution): the build with the run-time steps-per-wave count only
+    st = g.mode == 0 ? launch_igemm_v4n<5, 0, 0>(g, grid, lds)
+                     : (g.mode == 1 ? launch_igemm_v4n<5, 1, 0>(g, grid, lds) : launch_igemm_v4n<5, 2, 0>(g, grid, lds));
 #undef DF_V4
   if (st != DFHIP_OK) return st;
   DF_LAUNCH_CHECK();

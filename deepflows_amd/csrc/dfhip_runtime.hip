@@ -10,8 +10,10 @@
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -389,6 +391,15 @@ struct H2dSlot {
 static H2dSlot g_h2d[4];
 static int g_h2d_next = 0;
 
+// device-side copy out of pinned host memory (the kernel reads it over PCIe): stays on the compute queue of the
+// library stream -- an SDMA copy between two graph launches costs a hop to the copy engine's queue and back
+__global__ __launch_bounds__(256) void k_copy_from_host(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
+}
+
 int dfhip_h2d(const float* host, float* dst, int64_t n) {
   DF_INIT();
   DF_CHECK_ARG(n >= 0 && (n == 0 || (host && dst)), "h2d: null pointer");
@@ -420,10 +431,256 @@ int dfhip_h2d(const float* host, float* dst, int64_t n) {
       sl.bytes = want;
     }
     memcpy(sl.p, (const char*)host + off, b);
-    DF_HIP(hipMemcpyAsync((char*)dst + off, sl.p, b, hipMemcpyHostToDevice, g_stream));
+    // up to 32 MB: a kernel on the library stream reads the pinned slot (no hop to the copy engine's queue between
+    // two launches of the stream -- with per-step uploads in front of graph replays the SDMA path cost 0.1-0.7 ms per step)
+    static int by_kernel = getenv("DFHIP_UPLOAD_KERNEL") ? atoi(getenv("DFHIP_UPLOAD_KERNEL")) : 1;
+    if (by_kernel && b <= ((size_t)32 << 20) && ((((uintptr_t)dst) + off) & 15) == 0) {
+      const int64_t nf = (int64_t)(b / sizeof(float));
+      const int blocks = (int)std::min<int64_t>(1024, (nf / 4 + 255) / 256 + 1);
+      hipLaunchKernelGGL(k_copy_from_host, dim3(blocks), dim3(256), 0, g_stream, (const float*)sl.p,
+                         (float*)((char*)dst + off), nf);
+      DF_LAUNCH_CHECK();
+    } else {
+      DF_HIP(hipMemcpyAsync((char*)dst + off, sl.p, b, hipMemcpyHostToDevice, g_stream));
+    }
     DF_HIP(hipEventRecord(sl.done, g_stream));
     sl.busy = true;
   }
+  return DFHIP_OK;
+}
+
+// ---- Dropout masks: NumPy's global generator, continued in C ------------------------------------------------
+// The reference draws a mask with np.random.binomial(1, keep, shape) on the host (nn/modules/dropout.py:16-18).  For
+// n = 1 NumPy's sampler consumes ONE double of the legacy MT19937 stream per element and thresholds it, and a
+// double is (a >> 5) * 2^26 + (b >> 6) over 2^53 of two consecutive 32-bit outputs: the mask is a pure function of
+// the generator state.  dfhip_host_bernoulli_mask continues that stream from a copy of the state (key[624], pos) the
+// caller took with np.random.get_state() and hands the advanced state back -- same masks, same position of the
+// global generator afterwards -- in blocks the compiler vectorises (regenerate 624 words, temper 624 words, pair
+// them), about three times faster than the scalar generator; at 0.5 M elements per step the CNN workload's replayed
+// step was bound by exactly that.  Host code only: no device call.
+namespace {
+constexpr int kMtN = 624, kMtM = 397;
+inline void mt_regenerate(uint32_t* mt) {
+  constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MA = 0x9908b0dfu;
+  int i = 0;
+  for (; i < kMtN - kMtM; i++) {
+    const uint32_t y = (mt[i] & UP) | (mt[i + 1] & LO);
+    mt[i] = mt[i + kMtM] ^ (y >> 1) ^ ((0u - (y & 1u)) & MA);
+  }
+  for (; i < kMtN - 1; i++) {
+    const uint32_t y = (mt[i] & UP) | (mt[i + 1] & LO);
+    mt[i] = mt[i + (kMtM - kMtN)] ^ (y >> 1) ^ ((0u - (y & 1u)) & MA);
+  }
+  const uint32_t y = (mt[kMtN - 1] & UP) | (mt[0] & LO);
+  mt[kMtN - 1] = mt[kMtM - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & MA);
+}
+inline uint32_t mt_temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+}  // namespace
+
+// (the block loops are compiled twice: for the baseline x86-64 and for AVX2, picked at run time)
+#define DF_MT_BODY                                                                                   \
+  constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MA = 0x9908b0dfu;                          \
+  int i = 0;                                                                                         \
+  for (; i < kMtN - kMtM; i++) {                                                                     \
+    const uint32_t y = (mt[i] & UP) | (mt[i + 1] & LO);                                              \
+    mt[i] = mt[i + kMtM] ^ (y >> 1) ^ ((0u - (y & 1u)) & MA);                                        \
+  }                                                                                                  \
+  for (; i < kMtN - 1; i++) {                                                                        \
+    const uint32_t y = (mt[i] & UP) | (mt[i + 1] & LO);                                              \
+    mt[i] = mt[i + (kMtM - kMtN)] ^ (y >> 1) ^ ((0u - (y & 1u)) & MA);                               \
+  }                                                                                                  \
+  const uint32_t y = (mt[kMtN - 1] & UP) | (mt[0] & LO);                                             \
+  mt[kMtN - 1] = mt[kMtM - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & MA);
+namespace {
+__attribute__((target("avx2"))) inline void mt_regenerate_avx2(uint32_t* mt) { DF_MT_BODY }
+}
+#define DF_MASK_ATTR
+#define DF_MASK_NAME bernoulli_mask_base
+#define DF_MT_REGEN mt_regenerate
+DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64_t n, float* out) {
+  // tempered outputs are produced a block at a time into `buf`; `have` of them are not consumed yet
+  uint32_t buf[kMtN];
+  int p = *pos, have = 0, at = 0;
+  const bool low = keep <= 0.5;                     // NumPy's inversion sampler mirrors the test for keep > 0.5
+  const double thr = low ? 1.0 - keep : keep;
+  uint32_t carry_a = 0;
+  bool has_carry = false;
+  int64_t done = 0;
+  while (done < n) {
+    if (have == 0) {
+      if (p == kMtN) { DF_MT_REGEN(key); p = 0; }
+      have = kMtN - p;
+      for (int i = 0; i < have; i++) buf[i] = mt_temper(key[p + i]);
+      p = kMtN;
+      at = 0;
+    }
+    if (has_carry) {                                // a double straddling two blocks
+      const uint32_t a = carry_a >> 5, b = buf[at] >> 6;
+      const double u = (a * 67108864.0 + b) / 9007199254740992.0;
+      out[done++] = low ? (u > thr ? 1.0f : 0.0f) : (u > thr ? 0.0f : 1.0f);
+      at++; have--;
+      has_carry = false;
+      continue;
+    }
+    int64_t pairs = have / 2;
+    if (pairs > n - done) pairs = n - done;
+    const uint32_t* q = buf + at;
+    float* o = out + done;
+    if (low) {
+      for (int64_t i = 0; i < pairs; i++) {
+        const double u = ((q[2 * i] >> 5) * 67108864.0 + (q[2 * i + 1] >> 6)) / 9007199254740992.0;
+        o[i] = u > thr ? 1.0f : 0.0f;
+      }
+    } else {
+      for (int64_t i = 0; i < pairs; i++) {
+        const double u = ((q[2 * i] >> 5) * 67108864.0 + (q[2 * i + 1] >> 6)) / 9007199254740992.0;
+        o[i] = u > thr ? 0.0f : 1.0f;
+      }
+    }
+    done += pairs;
+    at += (int)(2 * pairs);
+    have -= (int)(2 * pairs);
+    if (done < n && have == 1) {                    // odd word left in the block: first half of the next double
+      carry_a = buf[at];
+      has_carry = true;
+      have = 0;
+    }
+  }
+  // words of the last block that were tempered but not consumed go back: the generator stands right behind the last
+  // word used
+  *pos = p - have;
+  return DFHIP_OK;
+}
+
+#undef DF_MASK_ATTR
+#undef DF_MASK_NAME
+#undef DF_MT_REGEN
+#define DF_MASK_ATTR __attribute__((target("avx2")))
+#define DF_MASK_NAME bernoulli_mask_avx2
+#define DF_MT_REGEN mt_regenerate_avx2
+DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64_t n, float* out) {
+  // tempered outputs are produced a block at a time into `buf`; `have` of them are not consumed yet
+  uint32_t buf[kMtN];
+  int p = *pos, have = 0, at = 0;
+  const bool low = keep <= 0.5;                     // NumPy's inversion sampler mirrors the test for keep > 0.5
+  const double thr = low ? 1.0 - keep : keep;
+  uint32_t carry_a = 0;
+  bool has_carry = false;
+  int64_t done = 0;
+  while (done < n) {
+    if (have == 0) {
+      if (p == kMtN) { DF_MT_REGEN(key); p = 0; }
+      have = kMtN - p;
+      for (int i = 0; i < have; i++) buf[i] = mt_temper(key[p + i]);
+      p = kMtN;
+      at = 0;
+    }
+    if (has_carry) {                                // a double straddling two blocks
+      const uint32_t a = carry_a >> 5, b = buf[at] >> 6;
+      const double u = (a * 67108864.0 + b) / 9007199254740992.0;
+      out[done++] = low ? (u > thr ? 1.0f : 0.0f) : (u > thr ? 0.0f : 1.0f);
+      at++; have--;
+      has_carry = false;
+      continue;
+    }
+    int64_t pairs = have / 2;
+    if (pairs > n - done) pairs = n - done;
+    const uint32_t* q = buf + at;
+    float* o = out + done;
+    if (low) {
+      for (int64_t i = 0; i < pairs; i++) {
+        const double u = ((q[2 * i] >> 5) * 67108864.0 + (q[2 * i + 1] >> 6)) / 9007199254740992.0;
+        o[i] = u > thr ? 1.0f : 0.0f;
+      }
+    } else {
+      for (int64_t i = 0; i < pairs; i++) {
+        const double u = ((q[2 * i] >> 5) * 67108864.0 + (q[2 * i + 1] >> 6)) / 9007199254740992.0;
+        o[i] = u > thr ? 0.0f : 1.0f;
+      }
+    }
+    done += pairs;
+    at += (int)(2 * pairs);
+    have -= (int)(2 * pairs);
+    if (done < n && have == 1) {                    // odd word left in the block: first half of the next double
+      carry_a = buf[at];
+      has_carry = true;
+      have = 0;
+    }
+  }
+  // words of the last block that were tempered but not consumed go back: the generator stands right behind the last
+  // word used
+  *pos = p - have;
+  return DFHIP_OK;
+}
+
+#undef DF_MASK_ATTR
+#undef DF_MASK_NAME
+#undef DF_MT_REGEN
+
+int dfhip_host_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n, float* out) {
+  if (!key || !pos || !out || n < 0 || *pos < 0 || *pos > kMtN) {
+    set_error("host_bernoulli_mask: bad arguments");
+    return DFHIP_INVALID_ARGUMENT;
+  }
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  return avx2 ? bernoulli_mask_avx2(key, pos, keep, n, out) : bernoulli_mask_base(key, pos, keep, n, out);
+}
+
+// the same mask generated straight into a pinned staging slot and sent to `dst` on the library stream: no
+// intermediate host array (a fresh 2 MB NumPy array per step is 512 first-touch page faults) and no second copy
+int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n, float* dst) {
+  DF_INIT();
+  DF_CHECK_ARG(key && pos && dst && n >= 0, "upload_bernoulli_mask: bad arguments");
+  if (n == 0) return DFHIP_OK;
+  if (g_capture_open) {
+    set_error("upload_bernoulli_mask inside a graph capture: register the mask as a graph input instead");
+    return DFHIP_RUNTIME_ERROR;
+  }
+  const size_t b = (size_t)n * sizeof(float);
+  static int trace = getenv("DFHIP_TRACE_UPLOAD") ? atoi(getenv("DFHIP_TRACE_UPLOAD")) : 0;
+  struct timespec tp, t0, t1, t2, t3;
+  if (trace) clock_gettime(CLOCK_MONOTONIC, &tp);
+  H2dSlot& sl = g_h2d[g_h2d_next];
+  g_h2d_next = (g_h2d_next + 1) & 3;
+  if (!sl.done) DF_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  if (sl.busy) {
+    DF_HIP(hipEventSynchronize(sl.done));
+    sl.busy = false;
+  }
+  if (sl.bytes < b) {
+    if (sl.p) (void)hipHostFree(sl.p);
+    sl.p = nullptr;
+    sl.bytes = 0;
+    size_t want = b < (size_t)(1 << 20) ? (size_t)(1 << 20) : b;
+    DF_HIP(hipHostMalloc(&sl.p, want, hipHostMallocDefault));
+    sl.bytes = want;
+  }
+  if (trace) clock_gettime(CLOCK_MONOTONIC, &t0);
+  int st = dfhip_host_bernoulli_mask(key, pos, keep, n, (float*)sl.p);
+  if (st != DFHIP_OK) return st;
+  if (trace) clock_gettime(CLOCK_MONOTONIC, &t1);
+  static int by_kernel = getenv("DFHIP_UPLOAD_KERNEL") ? atoi(getenv("DFHIP_UPLOAD_KERNEL")) : 1;
+  if (by_kernel && (((uintptr_t)dst) & 15) == 0) {
+    const int blocks = (int)std::min<int64_t>(1024, (n / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_copy_from_host, dim3(blocks), dim3(256), 0, g_stream, (const float*)sl.p, dst, n);
+    DF_LAUNCH_CHECK();
+  } else {
+    DF_HIP(hipMemcpyAsync(dst, sl.p, b, hipMemcpyHostToDevice, g_stream));
+  }
+  if (trace) clock_gettime(CLOCK_MONOTONIC, &t2);
+  DF_HIP(hipEventRecord(sl.done, g_stream));
+  if (trace) {
+    clock_gettime(CLOCK_MONOTONIC, &t3);
+    auto us = [](const timespec& a, const timespec& b2) { return (b2.tv_sec - a.tv_sec) * 1e6 + (b2.tv_nsec - a.tv_nsec) * 1e-3; };
+    if (trace-- > 0) fprintf(stderr, "[upload] slot %.0f us, mask %.0f us, hipMemcpyAsync %.0f us, event record %.0f us\n", us(tp, t0), us(t0, t1), us(t1, t2), us(t2, t3));
+  }
+  sl.busy = true;
   return DFHIP_OK;
 }
 

@@ -12,6 +12,8 @@ one-thread launch in front of every replay (optim/adam.py: push_hyper / apply).
 The reference has nothing comparable (it launches 8 575 device calls per step from Python,
 SURVEY F8); this is the MI355X-native replacement for that dispatch loop.
 """
+import os
+
 import numpy as np
 
 from .tensor import Graph
@@ -61,12 +63,14 @@ class CapturedTrainStep:
     def replay(self):
         opt = self.optimizer
         opt.push_hyper()
-        if self.feeds:
+        if self.feeds and os.environ.get("DF_DEBUG_SKIP_FEEDS") != "1":     # (diagnostic switch: timing without the uploads)
             # Dropout masks of this step: drawn on the host exactly as the eager forward pass would draw them
             # (nn/modules/dropout.py), uploaded on the library stream in front of the graph
             from .nn.modules.dropout import bernoulli_mask
             for mask, keep in self.feeds:
-                self.mod.from_numpy(np.ascontiguousarray(bernoulli_mask(keep, mask.shape)), mask._handle)
+                up = getattr(self.mod, "upload_bernoulli_mask", None)
+                if up is None or mask._handle.size < 8192 or not up(mask._handle, keep):
+                    self.mod.from_numpy(np.ascontiguousarray(bernoulli_mask(keep, mask.shape)), mask._handle)
         self.graph.replay()
         if self.sync is not None:
             for p, g in zip(opt.params, self.grads):

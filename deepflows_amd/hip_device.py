@@ -112,6 +112,20 @@ class HipModule:
             raise ValueError(f"from_numpy: array has {a.size} elements, handle has {handle.size}")
         _lib.check(self._lib.dfhip_h2d(a.ctypes.data, handle.ptr, a.size))
 
+    def upload_bernoulli_mask(self, handle, keep):
+        """The Dropout mask np.random.binomial(1, keep, handle.size) would draw next, as float32, generated in C
+        straight into pinned memory and sent to `handle` (NumPy's global generator is advanced exactly as that call
+        would advance it).  False when the generator is not the legacy MT19937: the caller draws with NumPy."""
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            return False
+        key = np.array(st[1], dtype=np.uint32, copy=True)
+        pos = ctypes.c_int(int(st[2]))
+        _lib.check(self._lib.dfhip_upload_bernoulli_mask(key.ctypes.data, ctypes.byref(pos), float(keep), handle.size,
+                                                         handle.ptr))
+        np.random.set_state(("MT19937", key, pos.value, st[3], st[4]))
+        return True
+
     def to_numpy(self, handle, shape, strides, offset):
         shape = tuple(int(s) for s in shape)
         strides = tuple(int(s) for s in strides)

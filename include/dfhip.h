@@ -372,6 +372,15 @@ int dfhip_comm_allreduce_max(float* value);
 int dfhip_comm_rccl_path(char* out, int cap);
 int dfhip_comm_destroy(void);
 
+/* Host helper (no device call): the float32 mask np.random.binomial(1, keep, n) would draw next from NumPy's legacy
+ * global generator (nn/modules/dropout.py:16-18 of the reference), continued from a copy of its state -- key[624]
+ * and pos as returned by np.random.get_state() -- and the state advanced exactly as NumPy would have advanced it
+ * (written back to key / pos; the caller hands it to np.random.set_state).  One double per element, thresholded. */
+int dfhip_host_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n, float* out);
+/* the same mask generated straight into a pinned staging slot and copied to the device array `dst` on the library
+ * stream (Dropout's from_numpy of nn/modules/dropout.py:28 without the intermediate host array) */
+int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n, float* dst);
+
 /* ---- whole-step capture (hipGraph) -------------------------------------------------- */
 int dfhip_graph_begin(void);                   /* hipStreamBeginCapture on the library stream */
 int dfhip_graph_end(void** graph_exec);        /* end capture + instantiate                  */

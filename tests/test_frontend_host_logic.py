@@ -169,6 +169,39 @@ def test_dropout_mask_equals_numpy_binomial():
             assert sa[2] == sb[2] and np.array_equal(sa[1], sb[1]), (keep, seed)
 
 
+def test_large_dropout_masks_continue_numpys_stream_in_c():
+    """Masks of 8 192 elements and more come from libdfhip's host helper (dfhip_host_bernoulli_mask: the MT19937
+    stream of NumPy's global generator continued in vectorised C): same values as np.random.binomial(1, keep, n) and
+    the same generator state afterwards, from even and odd stream positions and across block boundaries."""
+    import numpy as np
+    from deepflows_amd import _lib
+    from deepflows_amd.nn.modules.dropout import _continue_numpy_stream, bernoulli_mask
+    if not _lib.library_present():
+        pytest.skip("libdfhip.so is not built")
+    for keep in (0.5, 0.3, 0.8):
+        for n in (8192, 100001, 524288):
+            for pre, odd in ((0, False), (1, False), (311, True), (312, True), (625, False)):
+                def prep():
+                    np.random.seed(11)
+                    if pre:
+                        np.random.random_sample(pre)
+                    if odd:
+                        np.random.randint(0, 1000)       # one 32-bit word: the stream position becomes odd
+                prep()
+                a = np.random.binomial(1, keep, n).astype(np.float32)
+                nxt_a = np.random.random_sample(5)
+                prep()
+                b = _continue_numpy_stream(keep, (n,))
+                assert b is not None
+                nxt_b = np.random.random_sample(5)
+                assert np.array_equal(a, b), (keep, n, pre, odd)
+                assert np.array_equal(nxt_a, nxt_b), (keep, n, pre, odd)
+    np.random.seed(2)
+    a = np.random.binomial(1, 0.5, (256, 2048)).astype(np.float32)
+    np.random.seed(2)
+    assert np.array_equal(a, bernoulli_mask(0.5, (256, 2048)))
+
+
 def test_backward_brackets_the_sweep_with_the_wgrad_group(cpu_oracle):
     """Tensor.backward() opens a device's weight-gradient group before the reverse sweep and closes it
     after it -- also when a grad_fn raises -- and leaves devices without the hooks alone."""
