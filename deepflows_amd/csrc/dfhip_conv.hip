@@ -1328,6 +1328,7 @@ struct WGeo {
   // v2 (producer-consumer) only: exact division by multiplication, magic = ceil(2^32 / d)
   unsigned m_prpc, m_pc, m_brbc, m_bc, m_br;
   unsigned long long* stamps;   // diagnostics (DFHIP_CONV_STAMP)
+  StemBwd st;                   // k_conv_wgrad_v3<.., STEM>: dy is the convolution OUTPUT z, dY is rebuilt while staging
 };
 
 template <int OT, int KT>
@@ -1493,10 +1494,16 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WGeo g) {
 //     per pixel row / pixel pair two compares decide whether its element exists; a missing one
 //     reads a neighbouring in-range address and is zeroed by a select.
 // ---------------------------------------------------------------------------------------
-template <int OT, int KT, int DV>
+// STEM: the convolution is followed by BatchNorm -> ReLU -> MaxPool 2x2 (the stem of the CIFAR models) and g.dy is
+// its OUTPUT z: d loss / d z of a float4 is rebuilt from z, the pooled output and its gradient (two floats each)
+// and the channel's constants while the vector waits in registers between its load and its LDS commit -- the
+// 33.5 MB gradient tensor of the separate "apply" launch is never written or read.
+template <int OT, int KT, int DV, bool STEM = false>
 __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float stc[STEM ? OT * 32 : 1][6];     // (mean, 1/sd, gamma, beta, k1, k2) of the block's output channels
   typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int k2 = g.k * g.k;
   const int KW = g.C * k2;
   const int BRBC = g.BR * g.BC;
@@ -1562,6 +1569,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
   const int pvecs = chn * g.BI * RL4, dvecs = orows * g.BI * BRBC4;
   unsigned p_src[2], d_src[DV];
   int d_lx[DV];
+  int d_pool[DV], d_row[DV], d_o[DV];          // STEM: pooled-plane offset (group-invariant part), row in the band, channel
 #pragma unroll
   for (int u = 0; u < 2; u++) {
     int v = tid + 512 * u;
@@ -1581,10 +1589,40 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
     int im = rem / BRBC4, q4 = rem - im * BRBC4;
     d_src[u] = (unsigned)(((int64_t)im * g.O + o) * yplane + 4 * q4);
     d_lx[u] = live ? o * DLD + im * BRBC + 4 * q4 : -1;
+    if constexpr (STEM) {
+      const int f = 4 * q4, rl = f / g.ow, col = f - rl * g.ow;
+      d_row[u] = rl;
+      d_o[u] = o;
+      d_pool[u] = (int)(((int64_t)im * g.O + o) * (yplane >> 2)) + (col >> 1);
+    }
+  }
+  if constexpr (STEM) {
+    // the constants of this block's output channels: batch statistics, affine pair, and the two means of the
+    // BatchNorm backward formula from the statistics pass's per-slice sums
+    if (tid < orows) {
+      const int o = o0 + tid;
+      float sdy = 0.0f, sdyx = 0.0f;
+      for (int i = 0; i < g.st.S; i++) {
+        sdy += g.st.partial[((int64_t)o * g.st.S + i) * 2];
+        sdyx += g.st.partial[((int64_t)o * g.st.S + i) * 2 + 1];
+      }
+      if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (g.st.dgamma) g.st.dgamma[o] = sdyx;
+        if (g.st.dbeta) g.st.dbeta[o] = sdy;
+      }
+      const float m = (float)g.N * (float)g.oh * (float)g.ow;
+      stc[tid][0] = g.st.mean[o];
+      stc[tid][1] = 1.0f / sqrtf(g.st.var[o] + g.st.eps);
+      stc[tid][2] = g.st.gamma ? g.st.gamma[o] : 1.0f;
+      stc[tid][3] = g.st.beta ? g.st.beta[o] : 0.0f;
+      stc[tid][4] = sdy / m;
+      stc[tid][5] = sdyx / m;
+    }
   }
 
   const int my_groups = (g.ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   f32x4 pv0, pv1, dv[DV];
+  f32x2 yv[STEM ? DV : 1], gv[STEM ? DV : 1];
   int su_lo_cur = 0, r0_cur = 0, su_lo_nxt = 0, r0_nxt = 0;
 #define WG_ISSUE(gi_)                                                                            \
   do {                                                                                           \
@@ -1596,6 +1634,14 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
     const float* xb_ = g.x + ((int64_t)n0_ * g.C + cA) * xplane + (int64_t)su_lo_nxt * g.W;      \
     const float* yb_ = g.dy + ((int64_t)n0_ * g.O + o0) * yplane + (int64_t)r0_nxt * g.ow;       \
     _Pragma("unroll") for (int u_ = 0; u_ < DV; u_++) dv[u_] = *reinterpret_cast<const f32x4*>(yb_ + d_src[u_]); \
+    if constexpr (STEM) {                                                                        \
+      const int64_t pb_ = ((int64_t)n0_ * g.O + o0) * (yplane >> 2);                             \
+      _Pragma("unroll") for (int u_ = 0; u_ < DV; u_++) {                                        \
+        const int64_t at_ = pb_ + d_pool[u_] + (int64_t)((r0_nxt + d_row[u_]) >> 1) * (g.ow >> 1); \
+        yv[u_] = *reinterpret_cast<const f32x2*>(g.st.y + at_);                                  \
+        gv[u_] = *reinterpret_cast<const f32x2*>(g.st.g + at_);                                  \
+      }                                                                                          \
+    }                                                                                            \
     pv0 = *reinterpret_cast<const f32x4*>(xb_ + p_src[0]);                                       \
     pv1 = *reinterpret_cast<const f32x4*>(xb_ + p_src[1]);                                       \
   } while (0)
@@ -1604,7 +1650,20 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
     float* Ds_ = smem + (buf) * buf_floats;                                                      \
     float* Xs_ = Ds_ + dy_floats + guard;                                                        \
     _Pragma("unroll") for (int u_ = 0; u_ < DV; u_++)                                            \
-      if (d_lx[u_] >= 0) *reinterpret_cast<f32x4*>(Ds_ + d_lx[u_]) = dv[u_];                     \
+      if (d_lx[u_] >= 0) {                                                                       \
+        f32x4 t_ = dv[u_];                                                                       \
+        if constexpr (STEM) {                                                                    \
+          const float* c_ = stc[d_o[u_]];                                                        \
+          const float mean_ = c_[0], rsd_ = c_[1], w_ = c_[2], b_ = c_[3], k1_ = c_[4], k2_ = c_[5]; \
+          _Pragma("unroll") for (int e_ = 0; e_ < 4; e_++) {                                     \
+            const float z_ = dv[u_][e_];                                                         \
+            const float dy_ = stem_dy(z_, yv[u_][e_ >> 1], gv[u_][e_ >> 1], mean_, rsd_, w_, b_); \
+            const float xh_ = (z_ - mean_) * rsd_;                                               \
+            t_[e_] = (dy_ - k1_ - xh_ * k2_) * w_ * rsd_;                                        \
+          }                                                                                      \
+        }                                                                                        \
+        *reinterpret_cast<f32x4*>(Ds_ + d_lx[u_]) = t_;                                          \
+      }                                                                                          \
     if (tid < pvecs) *reinterpret_cast<f32x4*>(Xs_ + 4 * tid) = pv0;                             \
     if (tid + 512 < pvecs) *reinterpret_cast<f32x4*>(Xs_ + 4 * (tid + 512)) = pv1;               \
   } while (0)
@@ -3225,7 +3284,7 @@ int launch_wgrad(WGeo g, float* dw) {
   return DFHIP_OK;
 }
 
-template <int OT, int KT, int DV>
+template <int OT, int KT, int DV, bool STEM = false>
 int launch_wgrad_v3(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
   const int64_t n = (int64_t)g.O * g.C * g.k * g.k;
   float* slabs = dw;
@@ -3236,7 +3295,7 @@ int launch_wgrad_v3(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
   g.dst = slabs;
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_v3<OT, KT, DV>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv_wgrad_v3<OT, KT, DV, STEM>,
                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)std::max(lds, (size_t)65536)));
     attr_lds = std::max(lds, (size_t)65536);
@@ -3250,7 +3309,7 @@ int launch_wgrad_v3(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
     g.stamps = (unsigned long long*)workspace2(nb * 32 * 8);
     (void)hipMemsetAsync(g.stamps, 0, nb * 32 * 8, stream());
   }
-  DF_LAUNCH((k_conv_wgrad_v3<OT, KT, DV>), grid, dim3(512), lds, stream(), g);
+  DF_LAUNCH((k_conv_wgrad_v3<OT, KT, DV, STEM>), grid, dim3(512), lds, stream(), g);
   DF_LAUNCH_CHECK();
   if (stamp_mode) {
     std::vector<unsigned long long> h(nb * 32);
@@ -3279,7 +3338,7 @@ int launch_wgrad_v3(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
 }
 
 // returns -1 when the shape is not eligible for the main weight-gradient kernel
-int run_wgrad_v3(WGeo g, float* dw) {
+int run_wgrad_v3(WGeo g, float* dw, bool stem = false) {
   const int k2 = g.k * g.k;
   const int KW = g.C * k2;
   if (g.ow & 1) return -1;
@@ -3313,6 +3372,12 @@ int run_wgrad_v3(WGeo g, float* dw) {
   g.m_br = magic_u32(g.BR);
   const int ktg = (int)df_ceil_div(KW, KT * 32), otg = (int)df_ceil_div(g.O, OT * 32);
   int gx = (int)std::max<int64_t>(1, std::min<int64_t>(g.ngroups, (int64_t)num_cus() / ((int64_t)ktg * otg)));
+  if (stem) {
+    // (the stem form: one tile of output channels, whole-row bands so that a float4 never straddles a pooling row)
+    if (OT != 1 || (g.ow & 3) || (g.oh & 1)) return -1;
+    if (KT == 5) return launch_wgrad_v3<1, 5, 4, true>(g, dw, lds, gx, ktg, otg);
+    return launch_wgrad_v3<1, 1, 4, true>(g, dw, lds, gx, ktg, otg);
+  }
   if (OT == 1 && KT == 5) return launch_wgrad_v3<1, 5, 4>(g, dw, lds, gx, ktg, otg);
   if (OT == 1) return launch_wgrad_v3<1, 1, 4>(g, dw, lds, gx, ktg, otg);
   if (KT == 2) return launch_wgrad_v3<2, 2, 4>(g, dw, lds, gx, ktg, otg);
@@ -4249,6 +4314,74 @@ int dfhip_conv2d_forward_bn_input(const float* x, const float* partials_in, int 
   }
   if (st != DFHIP_OK) return st;
   if (want) *rows_out = rows;
+  *done = 1;
+  return DFHIP_OK;
+}
+
+// Backward pass of the stem pool(relu(bn(conv(x)))) of the CIFAR models (test/ResNet_CIFAR10_cuda.py:84-87) when
+// x needs no gradient: the statistics pass of dfhip_bn_relu_maxpool2_backward (dgamma, dbeta), then the weight
+// gradient of the convolution with d loss / d z rebuilt from z inside the kernel that consumes it.  z (N, O, oh, ow)
+// is the convolution output, y / g (N, O, oh/2, ow/2) the pooled output and its gradient.  *done = 0 (nothing
+// launched) when the shape has no such kernel: the caller then runs dfhip_bn_relu_maxpool2_backward and
+// dfhip_conv2d_wgrad.
+int dfhip_stem_backward(const float* x, const float* z, const float* y, const float* g, const float* gamma,
+                        const float* beta, const float* save_mean, const float* save_var, float* dw, float* dgamma,
+                        float* dbeta, int N, int C, int H, int W, int O, int k, int stride, int pad, float eps,
+                        int* done) {
+  DF_INIT();
+  DF_CHECK_ARG(x && z && y && g && save_mean && save_var && dw && done, "stem_backward: null array");
+  *done = 0;
+  int oh, ow;
+  int s = check_conv_args("stem_backward", N, C, H, W, O, k, stride, pad, oh, ow);
+  if (s != DFHIP_OK) return s;
+  static int enabled = getenv("DFHIP_STEM_FUSED_BWD") ? atoi(getenv("DFHIP_STEM_FUSED_BWD")) : 1;
+  if (!enabled || O > 32 || (oh & 1) || (ow & 7) || stride != 1 || C > 4) return DFHIP_OK;
+  WGeo wg = {};
+  wg.x = x; wg.dy = z;
+  wg.N = N; wg.C = C; wg.H = H; wg.W = W; wg.O = O; wg.oh = oh; wg.ow = ow;
+  wg.k = k; wg.stride = stride; wg.pad = pad;
+  {
+    // dry run of the plan: the statistics pass must not be launched for a shape the fused kernel then refuses
+    WGeo t = wg;
+    const int k2 = k * k, KW = C * k2;
+    if ((ow & 1) || (H * W) % 4 != 0 || (oh * ow) % 4 != 0) return DFHIP_OK;
+    const int KT = (k == 1 || KW <= 32) ? 1 : 5;
+    const int CH = std::min(C, (KT * 32 + k2 - 2) / k2 + 1);
+    bool ok = false;
+    int gi = 1;
+    for (int tp : {256, 128, 64, 32}) {
+      plan_groups(N, oh, ow, tp, t.BI, t.BR, t.BC, gi, t.gr, t.gc);
+      if (t.BC != ow || t.gc != 1 || N % t.BI != 0 || oh % t.BR != 0) continue;
+      if ((t.BI * t.BR) % 8) continue;
+      int RLr = t.gr == 1 ? H : std::min(H, (t.BR - 1) * stride + k);
+      int RL = RLr * W, BRBC = t.BR * t.BC;
+      if (RL % 4 || BRBC % 4) continue;
+      if (t.gr > 1 && (W % 4 || ow % 4)) continue;
+      int PE = t.BI * RL, BMP = t.BI * BRBC, guard = (k * W + k + 3) & ~3;
+      size_t buf = (size_t)32 * (BMP + 4) + 2 * guard + (size_t)CH * PE;
+      size_t lds = std::max(2 * buf, (size_t)2 * 8 * 16 * 64) * 4;
+      if (lds <= 150 * 1024 && CH * PE / 4 <= 1024 && 32 * BMP / 4 <= 512 * 4) { ok = true; break; }
+    }
+    if (!ok) return DFHIP_OK;
+  }
+  const float* partial = nullptr;
+  int S = 0;
+  {
+    ProfScope prof("bn_relu_pool_bwd", 0.0, (4.0 + 2.0) * (double)N * O * oh * ow);
+    int st = stem_bwd_stats(z, y, g, gamma, beta, save_mean, save_var, N, O, oh, ow, eps, &partial, &S);
+    if (st != DFHIP_OK) return st;
+  }
+  wg.st.y = y; wg.st.g = g; wg.st.gamma = gamma; wg.st.beta = beta; wg.st.mean = save_mean; wg.st.var = save_var;
+  wg.st.partial = partial; wg.st.S = S; wg.st.eps = eps; wg.st.dgamma = dgamma; wg.st.dbeta = dbeta;
+  double flops = 2.0 * N * oh * ow * (double)C * k * k * O;
+  double bytes = 4.0 * ((double)N * C * H * W + (double)O * C * k * k + 1.5 * (double)N * O * oh * ow);
+  ProfScope prof("conv2d_wgrad_igemm", flops, bytes);
+  int st = run_wgrad_v3(wg, dw, true);
+  if (st < 0) {
+    set_error("stem_backward: the plan test and the kernel's own disagree (N %d C %d H %d W %d O %d k %d)", N, C, H, W, O, k);
+    return DFHIP_RUNTIME_ERROR;
+  }
+  if (st != DFHIP_OK) return st;
   *done = 1;
   return DFHIP_OK;
 }

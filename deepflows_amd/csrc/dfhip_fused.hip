@@ -518,11 +518,6 @@ __global__ __launch_bounds__(kThreads) void k_onehot_smooth(const int* __restric
 //   relu:     gradient passes where output == input                        (tensor.py:872-877)
 // see the values the forward produced.  Block (c, s) owns images [s*ipb, (s+1)*ipb) of channel c;
 // a thread item is a 2 x 8 input patch = 4 pooled outputs.  W % 8 == 0, H % 2 == 0.
-__device__ __forceinline__ float bn_point(float v, float mean, float rsd, float w, float b) {
-  // (rsd = 1 / sd, the same value in the forward and in the backward kernel: both see the same outputs)
-  return __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v, mean), rsd), w), b);
-}
-__device__ __forceinline__ float relu_point(float a) { return (a != a) ? a : (a > 0.0f ? a : 0.0f); }
 __device__ __forceinline__ float max_nan(float m, float v) { return (m != m) ? m : ((v != v) ? v : (v > m ? v : m)); }
 
 // (mean, biased variance) of channel c from convolution partials[rows][C][3] = (count, mean, centred second moment):
@@ -604,12 +599,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_pool_fwd(
 }
 
 // gradient that reaches the BatchNorm output at one input position
-__device__ __forceinline__ float stem_dy(float v, float pooled, float g, float mean, float rsd, float w, float b) {
-  const float bo = bn_point(v, mean, rsd, w, b);
-  const float r = relu_point(bo);
-  const float gp = (pooled == r ? 1.0f : 0.0f) * g;
-  return (r == bo ? 1.0f : 0.0f) * gp;
-}
 
 template <bool APPLY>
 __global__ __launch_bounds__(kThreads) void k_bn_relu_pool_bwd(
@@ -1602,6 +1591,22 @@ __global__ __launch_bounds__(1024) void k_pool_linear_bwd(const float* __restric
     for (int w2 = 0; w2 < 16; w2++) r += sdy[w2 * P + tid];
     db[tid] = r;
   }
+}
+
+int stem_bwd_stats(const float* z, const float* y, const float* g, const float* gamma, const float* beta,
+                   const float* mean, const float* var, int N, int C, int H, int W, float eps, const float** partial,
+                   int* S_out) {
+  int S, ipb;
+  bn_split(N, C, S, ipb);
+  float* part = workspace_small((size_t)C * S * 2 * sizeof(float));
+  if (!part) return DFHIP_OUT_OF_MEMORY;
+  dim3 grid((unsigned)C, (unsigned)S);
+  DF_LAUNCH((k_bn_relu_pool_bwd<false>), grid, dim3(kThreads), 0, stream(), z, y, g, gamma, beta, mean, var, part,
+            (float*)nullptr, (float*)nullptr, (float*)nullptr, N, C, H, W, S, ipb, eps);
+  DF_LAUNCH_CHECK();
+  *partial = part;
+  *S_out = S;
+  return DFHIP_OK;
 }
 
 namespace dfhip {

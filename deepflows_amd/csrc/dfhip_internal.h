@@ -78,6 +78,42 @@ int run_conv_rowmma_dgrad(const float* dy, const float* w, const float* add, flo
 
 }  // namespace dfhip
 
+// ---- point-wise pieces of the stem (BatchNorm -> ReLU -> MaxPool 2x2) shared by its kernels ----
+#if defined(__HIPCC__)
+__device__ __forceinline__ float bn_point(float v, float mean, float rsd, float w, float b) {
+  // (rsd = 1 / sd, the same value in the forward and in the backward kernel: both see the same outputs)
+  return __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v, mean), rsd), w), b);
+}
+__device__ __forceinline__ float relu_point(float a) { return (a != a) ? a : (a > 0.0f ? a : 0.0f); }
+__device__ __forceinline__ float stem_dy(float v, float pooled, float g, float mean, float rsd, float w, float b) {
+  const float bo = bn_point(v, mean, rsd, w, b);
+  const float r = relu_point(bo);
+  const float gp = (pooled == r ? 1.0f : 0.0f) * g;
+  return (r == bo ? 1.0f : 0.0f) * gp;
+}
+#endif
+
+// backward pass of the stem fused into its weight gradient (dfhip_stem_backward): what the weight-gradient kernel needs
+// to rebuild d loss / d (convolution output) from the convolution output z itself while it stages its dY operand
+struct StemBwd {
+  const float* y;              // pooled output (N, O, oh/2, ow/2)
+  const float* g;              // its gradient
+  const float* gamma;          // O (nullptr: 1)
+  const float* beta;           // O (nullptr: 0)
+  const float* mean;           // O: batch mean / biased variance of z
+  const float* var;
+  const float* partial;        // [O][S][2]: per-slice sums of dy and dy * xhat (k_bn_relu_pool_bwd<false>)
+  int S;
+  float eps;
+  float* dgamma;               // O (may be nullptr)
+  float* dbeta;
+};
+// dfhip_fused.hip: the statistics pass of the stem's backward (sums of dy and dy * xhat per channel slice);
+// returns the partial array and its slice count
+int stem_bwd_stats(const float* z, const float* y, const float* g, const float* gamma, const float* beta,
+                   const float* mean, const float* var, int N, int C, int H, int W, float eps, const float** partial,
+                   int* S);
+
 // every kernel launch of the library
 #define DF_LAUNCH(kern, grid, block, lds, strm, ...)                                                  \
   do {                                                                                                \

@@ -331,6 +331,17 @@ class HipModule:
             flat += [x.ptr, g(gamma), sm.ptr, sv.ptr, g(dx), g(dg), g(db), float(eps)]
         _lib.check(self._lib.dfhip_bn2d_backward_pair(dy.ptr, *flat, N, C, HW))
 
+    def stem_backward(self, x, z, y, g, gamma, beta, save_mean, save_var, dw, dgamma, dbeta, N, C, H, W, O, k, stride,
+                      pad, eps):
+        """dgamma, dbeta and the convolution's dw of pool(relu(bn(conv(x)))) without the full-resolution gradient
+        tensor; False = no such kernel for the shape (nothing was launched)."""
+        gp = lambda h: h.ptr if h is not None else None
+        done = ctypes.c_int(0)
+        _lib.check(self._lib.dfhip_stem_backward(x.ptr, z.ptr, y.ptr, g.ptr, gp(gamma), gp(beta), save_mean.ptr,
+                                                 save_var.ptr, dw.ptr, gp(dgamma), gp(dbeta), N, C, H, W, O, k, stride,
+                                                 pad, float(eps), ctypes.byref(done)))
+        return bool(done.value)
+
     def bn_relu_maxpool2_forward_partials(self, x, partials, rows, gamma, beta, y, save_mean, save_var, running_mean,
                                           running_var, N, C, H, W, eps, momentum):
         g = lambda h: h.ptr if h is not None else None

@@ -287,6 +287,10 @@ class _Conv2dFused(_FusedNode):
     # then, ONE launch forms both input gradients and their sum, and the shortcut's node hands nothing back for x.
     shortcut_sibling = None
     _dx_delivered = False
+    # the stem's pooling node computed this node's weight gradient inside its own backward launch
+    # (_BnReluPoolFused.grad_fn -> dfhip_stem_backward): grad_fn hands it out, the gradient it is called with is a
+    # placeholder
+    _dw_ready = None
 
     def grad_fn(self, node, grad, accumulated=None):
         g = grad.compact()
@@ -314,6 +318,14 @@ class _Conv2dFused(_FusedNode):
                 dev.conv2d_dgrad(g._handle, self.wd._handle, out._handle, *self.geo)
             return out
         if node is self.w:
+            if self._dw_ready is not None:
+                dw, placeholder = self._dw_ready
+                if grad is not placeholder:
+                    # the output of this convolution had another consumer whose contribution was added to the
+                    # placeholder: the stored dw does not contain it
+                    raise RuntimeError("stem backward: the convolution output feeds more than the pooling node; "
+                                       "set DF_STEM_FUSED_BWD=0")
+                return dw
             out = _new(self.wd.shape, dev)
             dev.conv2d_wgrad(self.xd._handle, g._handle, out._handle, *self.geo)
             return out
@@ -707,17 +719,35 @@ class _BnReluPoolFused(_FusedNode):
         if self._grads is None or self._grads[0] is not grad:
             dev = grad.device
             N, C, H, W = self.geo
-            dx = _new(self.xd.shape, dev) if self.x.requires_grad else None
             dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
             h = lambda t: t._handle if t is not None else None
-            dev.bn_relu_maxpool2_backward(self.xd._handle, self.data._handle, grad.compact()._handle, h(self.wd),
-                                          h(self.bd), self.mean._handle, self.var._handle, h(dx), dg._handle,
-                                          db._handle, N, C, H, W, self.eps)
-            self._grads = (grad, dx, dg, db)
+            conv = self.x if isinstance(self.x, _Conv2dFused) else None
+            if (conv is not None and _STEM_FUSED_BWD and hasattr(dev.mod, "stem_backward") and self.x.requires_grad
+                    and not conv.x.requires_grad and conv.bias is None and conv.w.requires_grad
+                    and conv._dw_ready is None):
+                # the convolution in front needs only its weight gradient: one statistics launch, then the weight
+                # gradient rebuilds d loss / d x from x while it stages it -- that tensor is never written.  The
+                # convolution's node receives a placeholder as its output gradient and hands the stored dw out.
+                dw = _new(conv.wd.shape, dev)
+                if dev.stem_backward(conv.xd._handle, self.xd._handle, self.data._handle, grad.compact()._handle,
+                                     h(self.wd), h(self.bd), self.mean._handle, self.var._handle, dw._handle,
+                                     dg._handle, db._handle, *conv.geo, self.eps):
+                    placeholder = _new(self.xd.shape, dev)      # (a pool block: nothing is written to it)
+                    conv._dw_ready = (dw, placeholder)
+                    self._grads = (grad, placeholder, dg, db)
+            if self._grads is None or self._grads[0] is not grad:
+                dx = _new(self.xd.shape, dev) if self.x.requires_grad else None
+                dev.bn_relu_maxpool2_backward(self.xd._handle, self.data._handle, grad.compact()._handle, h(self.wd),
+                                              h(self.bd), self.mean._handle, self.var._handle, h(dx), dg._handle,
+                                              db._handle, N, C, H, W, self.eps)
+                self._grads = (grad, dx, dg, db)
         _, dx, dg, db = self._grads
         if node is self.x:
             return dx
         return dg if node is self.weight else db
+
+
+_STEM_FUSED_BWD = os.environ.get("DF_STEM_FUSED_BWD", "1") != "0"
 
 
 def bn_relu_maxpool2_fusable(x, bn, pool):

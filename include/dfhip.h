@@ -244,6 +244,16 @@ int dfhip_bn2d_backward_pair(const float* dy, const float* xa, const float* gamm
 int dfhip_bn_relu_maxpool2_forward(const float* x, const float* gamma, const float* beta, float* y,
                                    float* save_mean, float* save_var, float* running_mean,
                                    float* running_var, int N, int C, int H, int W, float eps, float momentum);
+/* Backward of the whole stem pool(relu(bn(conv(x)))) (test/ResNet_CIFAR10_cuda.py:84-87) when x needs no gradient:
+ * the statistics pass (dgamma, dbeta) and then the convolution's weight gradient (tensor.py:716) with
+ * d loss / d (convolution output) rebuilt from the convolution output z inside the kernel that consumes it -- the
+ * full-resolution gradient tensor is never written.  z (N, O, oh, ow); y, g (N, O, oh/2, ow/2) the pooled output
+ * and its gradient; dw (O, C, k, k); dgamma, dbeta (O).  *done = 0 (nothing launched) when the shape has no such
+ * kernel: the caller then runs dfhip_bn_relu_maxpool2_backward and dfhip_conv2d_wgrad. */
+int dfhip_stem_backward(const float* x, const float* z, const float* y, const float* g, const float* gamma,
+                        const float* beta, const float* save_mean, const float* save_var, float* dw, float* dgamma,
+                        float* dbeta, int N, int C, int H, int W, int O, int k, int stride, int pad, float eps,
+                        int* done);
 /* the same with the batch statistics from the partials the convolution that produced x left behind
  * (dfhip_conv2d_forward_stats: partials[rows][C][3]): no statistics pass over x */
 int dfhip_bn_relu_maxpool2_forward_partials(const float* x, const float* partials, int rows, const float* gamma,

@@ -444,6 +444,45 @@ def test_residual_block_with_convolution_shortcut_one_input_gradient_launch(hip_
         assert_close(a, b, 2e-6, "residual block, paired input gradient: " + nm)
 
 
+@pytest.mark.parametrize("k,pad", [(3, 1), (5, 2)])
+def test_stem_backward_without_the_full_resolution_gradient(hip_device, k, pad):
+    """pool(relu(bn(conv(x)))) with an input that needs no gradient: dfhip_stem_backward (statistics pass + the weight
+    gradient that rebuilds d loss / d conv-output while staging it) against the separate backward launches; integer
+    data so that ties at the maximum and exact zeros at the ReLU occur."""
+    from deepflows_amd import nn, tensor
+    from deepflows_amd.tensor import Graph, Tensor
+    F = nn.functional
+    dev = hip_device
+    rng = np.random.default_rng(17)
+    N = 32
+    x = rng.integers(-2, 3, size=(N, 3, 32, 32)).astype(np.float32)
+    gy = rng.standard_normal((N, 32, 16, 16)).astype(np.float32)
+    results = []
+    for fused in (True, False):
+        F._STEM_FUSED_BWD = fused
+        try:
+            np.random.seed(2)
+            conv = nn.Conv2d(3, 32, kernel_size=k, stride=1, padding=pad, bias=False, device=dev)
+            wq = np.round(conv.weight.numpy() * 8) / 8           # coarse weights: exact ties survive the convolution
+            dev.mod.from_numpy(wq.astype(np.float32), conv.weight.data._handle)
+            bn = nn.BatchNorm2d(32, device=dev)
+            bn.train()
+            xt = Tensor(x, device=dev)
+            z = conv(xt)
+            y = F.bn_relu_maxpool2_train(z, bn)
+            loss = tensor.sum(y * Tensor(gy, device=dev))
+            loss.backward()
+            if fused:
+                assert z._dw_ready is not None, "the fused backward must take this shape"
+            results.append([y.numpy().copy(), conv.weight.grad.numpy().copy(), bn.weight.grad.numpy().copy(),
+                            bn.bias.grad.numpy().copy()])
+            Graph.free_graph_all()
+        finally:
+            F._STEM_FUSED_BWD = True
+    for a, b, nm in zip(results[0], results[1], ("y", "dw", "dgamma", "dbeta")):
+        assert_close(a, b, 2e-6, f"stem backward k={k}: " + nm)
+
+
 def test_classifier_head_as_one_node(hip_device):
     """fc(mean(mean(x, 2), 2)) + cross-entropy: the pooled-linear node and the loss gradient left behind by the loss
     kernel, against the separate nodes (mean_hw, Linear, cross-entropy with its own backward launch)."""
