@@ -4152,7 +4152,8 @@ int dfhip_conv2d_dgrad_pair(const float* dy, const float* w, const float* dy2, c
   double bytes = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * oh * ow);
   ProfScope prof("conv2d_dgrad_overwrite_igemm", flops, bytes);
   if (O == 128) {
-    const int want = std::max(1, num_cus() * 2 / (C / 32));
+    // (five slices = 92 KB of LDS: ONE workgroup per CU, which walks twice the tiles of the unpaired launch)
+    const int want = std::max(1, num_cus() / (C / 32));
     dim3 grid((unsigned)std::min(tiles, want), (unsigned)(C / 32));
     const size_t lds = ((size_t)5 * O * 32 + 3 * 16 * 64) * sizeof(float);
     static bool attr = false;

@@ -444,30 +444,124 @@ __device__ __forceinline__ void bn_partials_stats(const BnFwdSet& q, int c, int 
 
 __global__ __launch_bounds__(kThreads) void k_bn_apply_partials_pair(BnFwdSet A, BnFwdSet B, float* __restrict__ y,
                                                                      int N, int C, int HW, int ipb) {
-  __shared__ float sw[4][3];
-  const int c = blockIdx.x, s = blockIdx.y;
-  const bool writer = s == 0 && threadIdx.x == 0;
-  float ma, ra, wa, ba, mb, rb, wb, bb;
-  bn_partials_stats(A, c, C, writer, sw, ma, ra, wa, ba);
-  bn_partials_stats(B, c, C, writer, sw, mb, rb, wb, bb);
+  __shared__ float sw[2][4][3];
+  const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  const bool writer = s == 0 && tid == 0;
+  auto chan = [](float& n, float& mu, float& m2, float nb, float mub, float m2b) {
+    if (nb > 0.0f) {
+      const float nn = n + nb, delta = mub - mu;
+      mu += delta * (nb / nn);
+      m2 += m2b + delta * delta * (n * nb / nn);
+      n = nn;
+    }
+  };
+  // everything the block needs from memory is requested up front -- its first partial row of BOTH sets, then its
+  // (up to two) 16-byte pieces of both tensors -- and the two sets are combined side by side with one barrier: the
+  // kernel is one round of memory latency long (it was three: set A, set B, then the data)
   const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
   const int64_t img_stride = (int64_t)C * HW;
   const float* base = A.x + (int64_t)c * HW;
   const float* bbase = B.x + (int64_t)c * HW;
   float* ybase = y + (int64_t)c * HW;
+  const int hw4 = HW >> 2;
+  const bool fast = (HW & 3) == 0 && (n_hi - n_lo) * hw4 <= 2 * kThreads;
+  float pa[3] = {0.0f, 0.0f, 0.0f}, pb[3] = {0.0f, 0.0f, 0.0f};
+  {
+    const float* qa = A.partials + ((int64_t)min(tid, A.rows - 1) * C + c) * 3;
+    const float* qb = B.partials + ((int64_t)min(tid, B.rows - 1) * C + c) * 3;
+    const float a0 = qa[0], a1 = qa[1], a2 = qa[2], b0 = qb[0], b1 = qb[1], b2 = qb[2];
+    if (tid < A.rows) { pa[0] = a0; pa[1] = a1; pa[2] = a2; }
+    if (tid < B.rows) { pb[0] = b0; pb[1] = b1; pb[2] = b2; }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  int64_t off[2] = {0, 0};
+  bool have[2] = {false, false};
+  float4 xv[2], uv[2];
+  if (fast) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int e = tid + u * kThreads;
+      have[u] = e < (n_hi - n_lo) * hw4;
+      const int ee = have[u] ? e : 0;
+      const int img = ee / hw4, h4 = ee - img * hw4;
+      off[u] = (int64_t)(n_lo + img) * img_stride + 4 * h4;
+      xv[u] = *reinterpret_cast<const float4*>(base + off[u]);
+      uv[u] = *reinterpret_cast<const float4*>(bbase + off[u]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float na = 0.0f, mua = 0.0f, m2a = 0.0f, nb = 0.0f, mub = 0.0f, m2b = 0.0f;
+  chan(na, mua, m2a, pa[0], pa[1], pa[2]);
+  chan(nb, mub, m2b, pb[0], pb[1], pb[2]);
+  for (int r = tid + kThreads; r < A.rows; r += kThreads) {
+    const float* q = A.partials + ((int64_t)r * C + c) * 3;
+    chan(na, mua, m2a, q[0], q[1], q[2]);
+  }
+  for (int r = tid + kThreads; r < B.rows; r += kThreads) {
+    const float* q = B.partials + ((int64_t)r * C + c) * 3;
+    chan(nb, mub, m2b, q[0], q[1], q[2]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float n1 = __shfl_down(na, o, 64), mu1 = __shfl_down(mua, o, 64), q1 = __shfl_down(m2a, o, 64);
+    const float n2 = __shfl_down(nb, o, 64), mu2 = __shfl_down(mub, o, 64), q2 = __shfl_down(m2b, o, 64);
+    chan(na, mua, m2a, n1, mu1, q1);
+    chan(nb, mub, m2b, n2, mu2, q2);
+  }
+  if ((tid & 63) == 0) {
+    sw[0][tid >> 6][0] = na; sw[0][tid >> 6][1] = mua; sw[0][tid >> 6][2] = m2a;
+    sw[1][tid >> 6][0] = nb; sw[1][tid >> 6][1] = mub; sw[1][tid >> 6][2] = m2b;
+  }
+  __syncthreads();
+  na = sw[0][0][0]; mua = sw[0][0][1]; m2a = sw[0][0][2];
+  nb = sw[1][0][0]; mub = sw[1][0][1]; m2b = sw[1][0][2];
+#pragma unroll
+  for (int w4 = 1; w4 < 4; w4++) {
+    chan(na, mua, m2a, sw[0][w4][0], sw[0][w4][1], sw[0][w4][2]);
+    chan(nb, mub, m2b, sw[1][w4][0], sw[1][w4][1], sw[1][w4][2]);
+  }
+  const float ma = mua, mb = mub;
+  const float vara = na > 0.0f ? m2a / na : 0.0f, varb = nb > 0.0f ? m2b / nb : 0.0f;   // biased (batchnorm.py:41-42)
+  if (writer) {
+    if (A.save_mean) A.save_mean[c] = ma;
+    if (A.save_var) A.save_var[c] = vara;
+    if (A.running_mean) A.running_mean[c] = A.running_mean[c] * (1.0f - A.momentum) + ma * A.momentum;
+    if (A.running_var) A.running_var[c] = A.running_var[c] * (1.0f - A.momentum) + vara * A.momentum;
+    if (B.save_mean) B.save_mean[c] = mb;
+    if (B.save_var) B.save_var[c] = varb;
+    if (B.running_mean) B.running_mean[c] = B.running_mean[c] * (1.0f - B.momentum) + mb * B.momentum;
+    if (B.running_var) B.running_var[c] = B.running_var[c] * (1.0f - B.momentum) + varb * B.momentum;
+  }
+  const float ra = 1.0f / sqrtf(vara + A.eps), rb = 1.0f / sqrtf(varb + B.eps);
+  const float wa = A.gamma ? A.gamma[c] : 1.0f, ba = A.beta ? A.beta[c] : 0.0f;
+  const float wb = B.gamma ? B.gamma[c] : 1.0f, bb = B.beta ? B.beta[c] : 0.0f;
+  if (fast) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (!have[u]) continue;
+      const float4 v = xv[u], q = uv[u];
+      float4 r;
+      r.x = ((v.x - ma) * ra * wa + ba) + ((q.x - mb) * rb * wb + bb);
+      r.y = ((v.y - ma) * ra * wa + ba) + ((q.y - mb) * rb * wb + bb);
+      r.z = ((v.z - ma) * ra * wa + ba) + ((q.z - mb) * rb * wb + bb);
+      r.w = ((v.w - ma) * ra * wa + ba) + ((q.w - mb) * rb * wb + bb);
+      *reinterpret_cast<float4*>(ybase + off[u]) = r;
+    }
+    return;
+  }
   for_each_chunk(base, img_stride, n_lo, n_hi, HW, [&](const float* p, int wdt) {
-    const int64_t off = p - base;
+    const int64_t off2 = p - base;
     if (wdt == 4) {
       const float4 v = *reinterpret_cast<const float4*>(p);
-      const float4 u = *reinterpret_cast<const float4*>(bbase + off);
+      const float4 u = *reinterpret_cast<const float4*>(bbase + off2);
       float4 r;
       r.x = ((v.x - ma) * ra * wa + ba) + ((u.x - mb) * rb * wb + bb);
       r.y = ((v.y - ma) * ra * wa + ba) + ((u.y - mb) * rb * wb + bb);
       r.z = ((v.z - ma) * ra * wa + ba) + ((u.z - mb) * rb * wb + bb);
       r.w = ((v.w - ma) * ra * wa + ba) + ((u.w - mb) * rb * wb + bb);
-      *reinterpret_cast<float4*>(ybase + off) = r;
+      *reinterpret_cast<float4*>(ybase + off2) = r;
     } else {
-      ybase[off] = ((p[0] - ma) * ra * wa + ba) + ((bbase[off] - mb) * rb * wb + bb);
+      ybase[off2] = ((p[0] - ma) * ra * wa + ba) + ((bbase[off2] - mb) * rb * wb + bb);
     }
   });
 }
