@@ -1029,6 +1029,95 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
+// The overwrite-mode input gradient of a 3x3 / stride 1 / pad 1 convolution on 2 x 2 IMAGES (ResNet layer4): all
+// four input pixels keep a tap whose source is output pixel (0, 0) -- (y, x) -> (max(y - 1, 0), max(x - 1, 0)) --
+// so dX[n][c][q] = sum_o dY[n][o][0][0] W[o][c][{4, 5, 7, 8}[q]]: a plain product of a 256 x O matrix with an
+// O x 4C one whose result IS the NCHW tensor.  The general kernel above gives a tile 8 images x 4 pixels and runs
+// four passes with three quarters of the lanes masked (12 us per launch for 0.13 GFLOP); here a workgroup owns 16
+// images x 16 channels x the four pixels: v_mfma_f32_16x16x4_f32 with an image on the lane, one accumulator per
+// pixel, the four waves split o and are summed through LDS, and a lane leaves with 16-byte stores (its four
+// pixels of a channel are adjacent in memory).
+// ---------------------------------------------------------------------------------------
+template <int O>
+__global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__ dy, const float* __restrict__ w,
+                                                       const float* __restrict__ add, float* __restrict__ dx, int C) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int OQ = O / 4, NK = OQ / 4;             // o per wave, MFMA k-steps per wave
+  float* Wl = smem;                                 // [4 slices][O][16 channels]
+  float* red = smem + 4 * O * 16;                   // [3 waves][16 values][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 4, n = lane & 15;
+  const int n0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
+  const int ob = wave * OQ;
+  // dY operand of this wave's o range: pixel (0, 0) of image n0 + n, channel ob + 4 p + kk
+  float sv[NK];
+  {
+    const float* sp = dy + ((int64_t)(n0 + n) * O + ob + kk) * 4;
+#pragma unroll
+    for (int p = 0; p < NK; p++) sv[p] = sp[(int64_t)p * 16];
+  }
+  // the gradient the tensor already holds: wave 0 stores the tile and requests its pieces now
+  f32x4 held[4];
+  const int64_t obase = ((int64_t)(n0 + n) * C + c0 + 4 * kk) * 4;
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    held[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (add && wave == 0) held[v] = *reinterpret_cast<const f32x4*>(add + obase + 4 * v);
+  }
+  // weight slices: (o, c) pairs, taps 4, 5, 7, 8 of each; 16 pairs per thread in two rounds of eight
+  constexpr int PAIRS = O * 16 / 256;
+#pragma unroll
+  for (int i0 = 0; i0 < PAIRS; i0 += 8) {
+    float wv[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = tid + 256 * (i0 + i), o = e >> 4, c = e & 15;
+      const float* q = w + ((int64_t)o * C + c0 + c) * 9;
+      wv[i][0] = q[4]; wv[i][1] = q[5]; wv[i][2] = q[7]; wv[i][3] = q[8];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = tid + 256 * (i0 + i), o = e >> 4, c = e & 15;
+#pragma unroll
+      for (int q = 0; q < 4; q++) Wl[(q * O + o) * 16 + c] = wv[i][q];
+    }
+  }
+  __syncthreads();
+  f32x4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < NK; p++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(q * O + ob + 4 * p + kk) * 16 + n], sv[p], acc[q], 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) red[((wave - 1) * 16 + q * 4 + v) * 64 + lane] = acc[q][v];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int ww = 0; ww < 3; ww++)
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[q][v] += red[(ww * 16 + q * 4 + v) * 64 + lane];
+    // register v of lane (kk, n) is channel c0 + 4 kk + v of image n0 + n; its four pixels are adjacent
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      f32x4 r = {acc[0][v], acc[1][v], acc[2][v], acc[3][v]};
+      r += held[v];
+      *reinterpret_cast<f32x4*>(dx + obase + 4 * v) = r;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // forward, 1x1 / stride 2 / pad 0 (the ResNet shortcut convolutions): K = C is 16-64 MFMAs per
 // 32 x 32 tile, so like the overwrite input gradient this is a kernel without staging phases.  A
 // wave owns 32 consecutive output pixels x 32 output channels: its pixel operand x[n][c][2r][2s] is
@@ -4065,6 +4154,27 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
     const int tiles = lean_ok ? (int)((int64_t)N * H * W / 32) : 0;
     // stride 2: parity-grouped tiles when whole 128-pixel blocks tile the tensor
     const int pg = (geo == 1 && ((int64_t)N * H * W) % 128 == 0 && W <= 64) ? 1 : 0;
+    static int img2 = getenv("DFHIP_DGRAD_IMG2") ? atoi(getenv("DFHIP_DGRAD_IMG2")) : 1;
+    if (lean && img2 && mode == 0 && geo == 0 && H == 2 && W == 2 && N % 16 == 0 && C % 16 == 0 &&
+        (O == 128 || O == 256 || O == 512)) {
+      // 2 x 2 images: a plain product (k_dgrad_ow_img2)
+      dim3 grid((unsigned)(N / 16), (unsigned)(C / 16));
+      const size_t lds = ((size_t)4 * O * 16 + 3 * 16 * 64) * sizeof(float);
+#define DF_I2(OV)                                                                                          \
+  do {                                                                                                     \
+    static bool attr = false;                                                                              \
+    if (!attr) {                                                                                           \
+      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img2<OV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)std::max(lds, (size_t)65536)));                                      \
+      attr = true;                                                                                         \
+    }                                                                                                      \
+    DF_LAUNCH(k_dgrad_ow_img2<OV>, grid, dim3(256), lds, stream(), dy, w, add, dx, C);                     \
+  } while (0)
+      if (O == 128) DF_I2(128); else if (O == 256) DF_I2(256); else DF_I2(512);
+#undef DF_I2
+      DF_LAUNCH_CHECK();
+      return DFHIP_OK;
+    }
     if (lean_ok && (O == 128 || O == 256)) {
       // about two workgroups per CU (one at 256 channels: 140 KB of LDS); each walks tiles / grid.x tiles
       // (1x1: the slice is small, one tile per workgroup)
