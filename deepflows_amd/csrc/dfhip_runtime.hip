@@ -643,9 +643,6 @@ int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n,
     return DFHIP_RUNTIME_ERROR;
   }
   const size_t b = (size_t)n * sizeof(float);
-  static int trace = getenv("DFHIP_TRACE_UPLOAD") ? atoi(getenv("DFHIP_TRACE_UPLOAD")) : 0;
-  struct timespec tp, t0, t1, t2, t3;
-  if (trace) clock_gettime(CLOCK_MONOTONIC, &tp);
   H2dSlot& sl = g_h2d[g_h2d_next];
   g_h2d_next = (g_h2d_next + 1) & 3;
   if (!sl.done) DF_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
@@ -661,10 +658,8 @@ int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n,
     DF_HIP(hipHostMalloc(&sl.p, want, hipHostMallocDefault));
     sl.bytes = want;
   }
-  if (trace) clock_gettime(CLOCK_MONOTONIC, &t0);
   int st = dfhip_host_bernoulli_mask(key, pos, keep, n, (float*)sl.p);
   if (st != DFHIP_OK) return st;
-  if (trace) clock_gettime(CLOCK_MONOTONIC, &t1);
   static int by_kernel = getenv("DFHIP_UPLOAD_KERNEL") ? atoi(getenv("DFHIP_UPLOAD_KERNEL")) : 1;
   if (by_kernel && (((uintptr_t)dst) & 15) == 0) {
     const int blocks = (int)std::min<int64_t>(1024, (n / 4 + 255) / 256 + 1);
@@ -673,13 +668,7 @@ int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n,
   } else {
     DF_HIP(hipMemcpyAsync(dst, sl.p, b, hipMemcpyHostToDevice, g_stream));
   }
-  if (trace) clock_gettime(CLOCK_MONOTONIC, &t2);
   DF_HIP(hipEventRecord(sl.done, g_stream));
-  if (trace) {
-    clock_gettime(CLOCK_MONOTONIC, &t3);
-    auto us = [](const timespec& a, const timespec& b2) { return (b2.tv_sec - a.tv_sec) * 1e6 + (b2.tv_nsec - a.tv_nsec) * 1e-3; };
-    if (trace-- > 0) fprintf(stderr, "[upload] slot %.0f us, mask %.0f us, hipMemcpyAsync %.0f us, event record %.0f us\n", us(tp, t0), us(t0, t1), us(t1, t2), us(t2, t3));
-  }
   sl.busy = true;
   return DFHIP_OK;
 }
