@@ -58,6 +58,7 @@ _SIGS = {
     "dfhip_conv2d_dgrad": [P, P, P] + [c_int] * 9,
     "dfhip_conv2d_dgrad_add": [P, P, P, P] + [c_int] * 9,
     "dfhip_conv2d_dgrad_pair": [P, P, P, P, P, P] + [c_int] * 6 + [POINTER(c_int)],
+    "dfhip_conv2d_forward_s2_pair": [P, P, P, P, P] + [c_int] * 5 + [P, P, c_int, POINTER(c_int), POINTER(c_int)],
     "dfhip_bn2d_forward_train": [P] * 8 + [c_int, c_int, c_int, c_float, c_float],
     "dfhip_bn2d_forward_eval": [P] * 6 + [c_int, c_int, c_int, c_float],
     "dfhip_bn2d_backward": [P] * 8 + [c_int, c_int, c_int, c_float],

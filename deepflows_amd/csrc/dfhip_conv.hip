@@ -4122,6 +4122,42 @@ int dfhip_conv2d_forward_stats(const float* x, const float* w, const float* bias
   return conv2d_forward_impl(x, w, bias, y, N, C, H, W, O, k, stride, pad, partials, cap_rows, rows_out);
 }
 
+// y = conv2d(x, w; 3x3, stride 2, pad 1) and yd = conv2d(x, wd; 1x1, stride 2, pad 0) -- conv1 and downsample[0] of a
+// residual block, which read the same tensor (test/ResNet_CIFAR10_cuda.py:31-47) -- as ONE launch: the shortcut reads
+// exactly the 3x3 convolution's centre-tap pixels and rides as a tenth tap.  BatchNorm partials of both outputs as
+// dfhip_conv2d_forward_stats (partials / partials_d: cap_rows x O x 3, same row count for both).  *done = 0 (nothing
+// launched) when the shape has no such kernel: the caller then runs the two convolutions separately.
+int dfhip_conv2d_forward_s2_pair(const float* x, const float* w, const float* wd, float* y, float* yd, int N, int C,
+                                 int H, int W, int O, float* partials, float* partials_d, int cap_rows, int* rows_out,
+                                 int* done) {
+  DF_INIT();
+  DF_CHECK_ARG(x && w && wd && y && yd && done, "conv2d_forward_s2_pair: null array");
+  DF_CHECK_ARG((partials == nullptr) == (partials_d == nullptr), "conv2d_forward_s2_pair: partials of both outputs or of none");
+  *done = 0;
+  if (rows_out) *rows_out = 0;
+  int oh, ow;
+  int s = check_conv_args("conv2d_forward_s2_pair", N, C, H, W, O, 3, 2, 1, oh, ow);
+  if (s != DFHIP_OK) return s;
+  int rows = 0;
+  const bool want = partials && rows_out;
+  if (run_conv3x3s2_pair(x, w, wd, y, yd, N, C, H, W, O, want ? partials : nullptr, want ? partials_d : nullptr,
+                         cap_rows, &rows, true) < 0)
+    return DFHIP_OK;
+  double flops = 2.0 * N * oh * ow * (double)C * 10 * O;
+  double bytes = 4.0 * ((double)N * C * H * W + (double)O * C * 10 + 2.0 * N * O * oh * ow);
+  ProfScope prof("conv2d_fwd_igemm", flops, bytes);
+  int st = run_conv3x3s2_pair(x, w, wd, y, yd, N, C, H, W, O, want ? partials : nullptr, want ? partials_d : nullptr,
+                              cap_rows, &rows);
+  if (st < 0) {
+    set_error("conv2d_forward_s2_pair: the shape test and the kernel's own disagree");
+    return DFHIP_RUNTIME_ERROR;
+  }
+  if (st != DFHIP_OK) return st;
+  if (want) *rows_out = rows;
+  *done = 1;
+  return DFHIP_OK;
+}
+
 static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, float* dx, int N, int C, int H,
                              int W, int O, int k, int stride, int pad, int mode) {
   int oh, ow;

@@ -1,0 +1,378 @@
+// Conv2d forward, 3x3 / stride 2 / pad 1 with 32-128 source channels TOGETHER WITH the 1x1 / stride 2 / pad 0
+// shortcut convolution of the same residual block (test/ResNet_CIFAR10_cuda.py:31-47: conv1 and downsample[0] both
+// read the block input; reference path nn/functional.py:316-344 twice): the shortcut reads exactly the pixels of the
+// 3x3 convolution's centre tap -- x[2r][2s] -- so it is a TENTH tap of the same register-operand loop with a weight
+// tensor and an accumulator of its own, not a second launch.
+//
+// v_mfma_f32_16x16x4_f32 as in dfhip_conv_rows.hip: D[16 output channels][16 pixels] += A[16][4 source channels] .
+// B[4][16].  A tile is 16 consecutive OUTPUT pixels of the flattened (n, r, s) space (two rows of an 8-wide output,
+// a whole 4 x 4 output image, four 2 x 2 output images).  Lane (kk, n) of the B operand of tap (i, j) holds
+// x[img][4p + kk][2r + i - 1][2s + j - 1]: with a stride of two nothing is shared between taps by a lane shift, so
+// every tap is a buffer load of its own (offsets resolved once per lane; a tap that falls into the padding gets an
+// offset past the buffer and reads as zero) -- nine loads per channel group, NO vector instruction in the loop
+// (beside fp32 MFMAs every VALU instruction costs matrix-pipe time).  The weight operand of the workgroup's output
+// channels goes to LDS in MFMA lane order, ten operands per channel group (nine taps + the shortcut), staged a
+// chunk ahead as in the stride-1 kernel.  A wave owns one pixel tile and OWW output-channel tiles; BatchNorm
+// partials of both outputs (count, mean, centred second moment per workgroup and channel).
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "dfhip_internal.h"
+
+using namespace dfhip;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov2(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16b(float v) {
+  v += dpp_mov2<0x128>(v);   // row_ror:8
+  v += dpp_mov2<0x124>(v);   // row_ror:4
+  v += dpp_mov2<0x122>(v);   // row_ror:2
+  v += dpp_mov2<0x121>(v);   // row_ror:1
+  return v;
+}
+#ifdef DFHIP_S2_STAMPS
+__device__ unsigned long long g_s2_stamps[1024 * 8 * 8];
+#define S2_STAMP(i)                                                                                     \
+  do {                                                                                                  \
+    if (lane == 0) g_s2_stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + (i)] =          \
+        (i) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();                     \
+  } while (0)
+#else
+#define S2_STAMP(i) do { } while (0)
+#endif
+constexpr int kBlk2 = 260;   // LDS pitch (floats) of a block of four operands x 64 lanes (+4: bank spread of the commits)
+
+// C: source channels; OWW: output-channel tiles (16 channels) per wave; TS: pixel tiles per workgroup; OWG: groups of
+// OWW channel tiles per workgroup (a workgroup is TS x OWG waves); CG: channel groups per weight chunk (even); XA:
+// chunks of pixel operands requested ahead (the loads of a chunk must be back before its MFMAs: with one chunk of
+// read-ahead a chunk's ~1 300 cycles of MFMAs did not cover the memory latency and the loop ran at a third of the pipe rate).
+// lwo: log2 of the OUTPUT width (3, 2, 1); H: input height = width = 2 << lwo.
+template <int C, int OWW, int TS, int OWG, int CG, int XA>
+__global__ __launch_bounds__(64 * TS * OWG) void k_conv3x3s2_pair(const float* __restrict__ x,
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ wd,
+                                                                 float* __restrict__ y, float* __restrict__ yd,
+                                                                 float* __restrict__ partials,
+                                                                 float* __restrict__ partials_d, int lwo, int O) {
+  constexpr int NWAVE = TS * OWG, NTHR = 64 * NWAVE;
+  constexpr int OT = OWG * OWW;                // output-channel tiles of the workgroup
+  constexpr int NG = C / 4;                    // channel groups (one MFMA k-step per tap each)
+  constexpr int TAPS = 10;                     // nine taps + the shortcut
+  constexpr int NCH = NG / CG;                 // weight chunks
+  constexpr int NBLK = NG * TAPS / 4;          // operand blocks per output-channel tile
+  constexpr int CBLK = CG * TAPS / 4;          // ... per chunk
+  static_assert(NG % CG == 0 && (CG * TAPS) % 4 == 0, "chunks are whole operand blocks");
+  extern __shared__ __attribute__((aligned(16))) float Wl[];   // [OT][NBLK blocks][64 lanes][4] at pitch kBlk2
+  __shared__ float sred[2][NWAVE][16 * OWW][2];
+  const int WO = 1 << lwo, HWO = WO << lwo;    // output plane
+  const int W = WO << 1, HW = HWO << 2;        // input plane (H = W)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 4, n = lane & 15;
+  const int ts = wave % TS, og = wave / TS;
+  const int ot0 = og * OWW;                    // first channel tile of this wave within the workgroup
+  const int o_wg = blockIdx.y * (OT * 16);     // first output channel of the workgroup
+  const int T = blockIdx.x * TS + ts;          // this wave's pixel tile
+  S2_STAMP(6);
+  S2_STAMP(0);
+
+  // ---- weight chunk staging ----
+  // main: OT x 16 rows (output channels) of 36 * CG contiguous floats per chunk; shortcut: OT x 16 rows of 4 * CG.
+  // thread -> 16-byte pieces; LDS float index of every element resolved once (operand f = p * 10 + t of lane
+  // (kk, m) lives at block f / 4, slot (kk * 16 + m) * 4 + f % 4)
+  constexpr int ROW4 = 9 * CG, TOT4 = OT * 16 * ROW4, PER = (TOT4 + NTHR - 1) / NTHR;
+  constexpr int ROWD4 = CG, TOTD4 = OT * 16 * ROWD4, PERD = (TOTD4 + NTHR - 1) / NTHR;
+  const float* wsrc[PER];
+  const float* dsrc[PERD];
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int q = tid + NTHR * u;
+    const int qq = q < TOT4 ? q : q - NTHR;    // (threads past the end re-do a piece: every load keeps a consumer)
+    const int tl = qq / (16 * ROW4), r = qq - tl * (16 * ROW4);
+    const int m = r / ROW4, e4 = r - m * ROW4;
+    wsrc[u] = w + ((int64_t)(o_wg + tl * 16 + m) * C * 9) + 4 * e4;
+  }
+#pragma unroll
+  for (int u = 0; u < PERD; u++) {
+    const int q = tid + NTHR * u;
+    const int qq = q < TOTD4 ? q : q % TOTD4;
+    const int tl = qq / (16 * ROWD4), r = qq - tl * (16 * ROWD4);
+    const int m = r / ROWD4, e4 = r - m * ROWD4;
+    dsrc[u] = wd + ((int64_t)(o_wg + tl * 16 + m) * C) + 4 * e4;
+  }
+  f32x4 wv[2][PER], dv[2][PERD];
+#define S2_WLOAD(chunk)                                                                                   \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < PER; u++)                                                       \
+      wv[(chunk) & 1][u] = *reinterpret_cast<const f32x4*>(wsrc[u] + (chunk) * (36 * CG));                \
+    _Pragma("unroll") for (int u = 0; u < PERD; u++)                                                      \
+      dv[(chunk) & 1][u] = *reinterpret_cast<const f32x4*>(dsrc[u] + (chunk) * (4 * CG));                 \
+  } while (0)
+#define S2_WCOMMIT(chunk)                                                                                 \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < PER; u++) {                                                     \
+      _Pragma("unroll") for (int e = 0; e < 4; e++)                                                       \
+        Wl[woff[u][e] + (chunk) * (CBLK * kBlk2)] = wv[(chunk) & 1][u][e];                                \
+    }                                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < PERD; u++) {                                                    \
+      _Pragma("unroll") for (int e = 0; e < 4; e++)                                                       \
+        Wl[doff[u][e] + (chunk) * (CBLK * kBlk2)] = dv[(chunk) & 1][u][e];                                \
+    }                                                                                                     \
+  } while (0)
+  S2_WLOAD(0);
+  if (NCH > 1) S2_WLOAD(1);
+  __builtin_amdgcn_sched_barrier(0);           // the weight loads stay in front of the pixel loads
+
+  // ---- per-lane source offsets of the nine taps (bytes from x, channel group 0) ----
+  constexpr unsigned kOut = 0x80000000u;
+  const int P = T * 16 + n;                    // flat output pixel (n, r, s)
+  const int img = P / HWO, rem = P - img * HWO;
+  const int r = rem >> lwo, s = rem & (WO - 1);
+  // per source row i: the taps j = 1, 2 are the adjacent pixels (2s, 2s + 1) -- ONE 8-byte load -- and j = 0 is pixel
+  // 2s - 1 (the address unit takes ~24 cycles per wave load of this kernel's shape whatever its width: nine 4-byte
+  // loads per channel group kept it busier than the matrix cores)
+  unsigned xo2[3], xo0[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int yy = 2 * r + i - 1;
+    const bool rowok = yy >= 0 && yy < W;
+    xo2[i] = rowok ? (unsigned)((((int64_t)img * C + kk) * W + yy) * W + 2 * s) * 4u : kOut;
+    xo0[i] = (rowok && s > 0) ? (unsigned)((((int64_t)img * C + kk) * W + yy) * W + 2 * s - 1) * 4u : kOut;
+  }
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7fffffff, 0x00020000);
+  float raw[NG][9];
+#define S2_XLOAD(chunk)                                                                                   \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int g_ = 0; g_ < CG; g_++) {                                                   \
+      const int p_ = (chunk) * CG + g_;                                                                   \
+      _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) {                                                  \
+        const f32x2 t2_ = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)xo2[i_], p_ * (16 * HW), 0)); \
+        raw[p_][i_ * 3 + 1] = t2_[0]; raw[p_][i_ * 3 + 2] = t2_[1];                                       \
+        raw[p_][i_ * 3] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)xo0[i_], p_ * (16 * HW), 0)); \
+      }                                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }                                                                                                     \
+  } while (0)
+#pragma unroll
+  for (int c0 = 0; c0 < XA && c0 < NCH; c0++) S2_XLOAD(c0);
+  S2_STAMP(1);
+  // LDS positions of the staged weights: resolved while the first loads are in flight
+  int woff[PER][4], doff[PERD][4];
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int q = tid + NTHR * u;
+    const int qq = q < TOT4 ? q : q - NTHR;
+    const int tl = qq / (16 * ROW4), r = qq - tl * (16 * ROW4);
+    const int m = r / ROW4, e4 = r - m * ROW4;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int idx = 4 * e4 + e;
+      const int c = idx / 9, t = idx - 9 * c;
+      const int f = (c >> 2) * TAPS + t;
+      woff[u][e] = tl * (NBLK * kBlk2) + (f >> 2) * kBlk2 + (c & 3) * 64 + m * 4 + (f & 3);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PERD; u++) {
+    const int q = tid + NTHR * u;
+    const int qq = q < TOTD4 ? q : q % TOTD4;
+    const int tl = qq / (16 * ROWD4), r = qq - tl * (16 * ROWD4);
+    const int m = r / ROWD4, e4 = r - m * ROWD4;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int c = 4 * e4 + e;                // channel within the chunk
+      const int f = (c >> 2) * TAPS + 9;
+      doff[u][e] = tl * (NBLK * kBlk2) + (f >> 2) * kBlk2 + (c & 3) * 64 + m * 4 + (f & 3);
+    }
+  }
+  S2_WCOMMIT(0);
+  S2_STAMP(2);
+  __syncthreads();
+  S2_STAMP(3);
+
+  f32x4 acc[OWW][4], accd[OWW];
+#pragma unroll
+  for (int a = 0; a < OWW; a++) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    accd[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const f32x4* Wl4 = reinterpret_cast<const f32x4*>(Wl + ot0 * (NBLK * kBlk2)) + lane;
+  f32x4 a4[2][OWW][CBLK];
+#pragma unroll
+  for (int a = 0; a < OWW; a++)
+#pragma unroll
+    for (int q = 0; q < CBLK; q++) a4[0][a][q] = Wl4[a * (NBLK * kBlk2 / 4) + q * (kBlk2 / 4)];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ch++) {
+    // chunk ch + 1 (requested a chunk ago) is committed now and made visible by a barrier in the middle of this
+    // chunk's MFMAs; chunk ch + 2 and the pixels of chunk ch + 1 are requested
+    if (ch + 1 < NCH) S2_WCOMMIT(ch + 1);
+    if (ch + 2 < NCH) S2_WLOAD(ch + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ch + XA < NCH) S2_XLOAD(ch + XA);
+#pragma unroll
+    for (int g = 0; g < CG; g++) {
+      const int p = ch * CG + g;
+      if (g == CG / 2 && ch + 1 < NCH) {
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < OWW; a++)
+#pragma unroll
+          for (int q = 0; q < CBLK; q++)
+            a4[(ch + 1) & 1][a][q] = Wl4[a * (NBLK * kBlk2 / 4) + ((ch + 1) * CBLK + q) * (kBlk2 / 4)];
+      }
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int f = g * TAPS + t;
+#pragma unroll
+        for (int a = 0; a < OWW; a++)
+          acc[a][t & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[ch & 1][a][f >> 2][f & 3], raw[p][t], acc[a][t & 3], 0, 0, 0);
+      }
+      {
+        const int f = g * TAPS + 9;              // the shortcut: the centre tap's pixels, its own weights
+#pragma unroll
+        for (int a = 0; a < OWW; a++)
+          accd[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[ch & 1][a][f >> 2][f & 3], raw[p][4], accd[a], 0, 0, 0);
+      }
+    }
+  }
+#undef S2_WLOAD
+#undef S2_WCOMMIT
+#undef S2_XLOAD
+
+  S2_STAMP(4);
+  // ---- epilogue: accumulator register v of lane (kk, n) is channel o + 4 kk + v of the tile's pixel n ----
+#pragma unroll
+  for (int a = 0; a < OWW; a++) {
+    f32x4 res = acc[a][0];
+    res += acc[a][1]; res += acc[a][2]; res += acc[a][3];
+    const f32x4 resd = accd[a];
+    const int o0 = o_wg + (ot0 + a) * 16;
+    const int64_t at = ((int64_t)img * O + o0 + 4 * kk) * HWO + rem;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      y[at + (int64_t)v * HWO] = res[v];
+      yd[at + (int64_t)v * HWO] = resd[v];
+    }
+    if (partials) {
+      // exact two-pass over the wave's 16 pixels per channel (both outputs), Chan's combination across the TS waves
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const float m1 = row_sum16b(res[v]) * (1.0f / 16.0f), m2 = row_sum16b(resd[v]) * (1.0f / 16.0f);
+        const float d1 = res[v] - m1, d2 = resd[v] - m2;
+        const float q1 = row_sum16b(d1 * d1), q2 = row_sum16b(d2 * d2);
+        if (n == 0) {
+          sred[0][wave][a * 16 + 4 * kk + v][0] = m1; sred[0][wave][a * 16 + 4 * kk + v][1] = q1;
+          sred[1][wave][a * 16 + 4 * kk + v][0] = m2; sred[1][wave][a * 16 + 4 * kk + v][1] = q2;
+        }
+      }
+    }
+  }
+  if (partials) {
+    __syncthreads();
+    if (tid < 2 * OT * 16) {
+      const int which = tid / (OT * 16), e = tid - which * (OT * 16);
+      const int tl = e >> 4, chn = e & 15;       // channel tile of the workgroup, channel in it
+      const int og2 = tl / OWW, a = tl - og2 * OWW;
+      float nn = 16.0f, mu = sred[which][og2 * TS][a * 16 + chn][0], m2 = sred[which][og2 * TS][a * 16 + chn][1];
+#pragma unroll
+      for (int w4 = 1; w4 < TS; w4++) {
+        const float tot = nn + 16.0f, delta = sred[which][og2 * TS + w4][a * 16 + chn][0] - mu;
+        mu += delta * (16.0f / tot);
+        m2 += sred[which][og2 * TS + w4][a * 16 + chn][1] + delta * delta * (nn * 16.0f / tot);
+        nn = tot;
+      }
+      float* o = (which ? partials_d : partials) + ((int64_t)blockIdx.x * O + o_wg + tl * 16 + chn) * 3;
+      o[0] = nn; o[1] = mu; o[2] = m2;
+    }
+  }
+  S2_STAMP(5);
+  S2_STAMP(7);
+}
+
+template <int C, int OWW, int TS, int OWG, int CG, int XA>
+int launch_s2(const float* x, const float* w, const float* wd, float* y, float* yd, float* partials, float* partials_d,
+              int lwo, int O, dim3 grid) {
+  const size_t lds = (size_t)(OWG * OWW) * (C / 4 * 10 / 4) * kBlk2 * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536)));
+    attr = true;
+  }
+  DF_LAUNCH((k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA>), grid, dim3(64 * TS * OWG), lds, stream(), x, w, wd, y, yd, partials,
+            partials_d, lwo, O);
+  DF_LAUNCH_CHECK();
+#ifdef DFHIP_S2_STAMPS
+  {
+    static int calls = 0;
+    if (++calls % 20 == 0) {
+      const size_t nw = (size_t)grid.x * grid.y * TS * OWG;
+      std::vector<unsigned long long> h((size_t)grid.x * grid.y * 8 * 8);
+      (void)hipStreamSynchronize(stream());
+      (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_s2_stamps), h.size() * sizeof(unsigned long long));
+      double seg[6] = {0}, cmax = 0;
+      unsigned long long r0 = ~0ull, r1 = 0;
+      for (size_t b = 0; b < (size_t)grid.x * grid.y; b++)
+        for (int wv2 = 0; wv2 < TS * OWG; wv2++) {
+          const unsigned long long* r = &h[(b * 8 + wv2) * 8];
+          for (int k = 1; k <= 5; k++) seg[k] += (double)(r[k] - r[k - 1]);
+          cmax = std::max(cmax, (double)(r[5] - r[0]));
+          r0 = std::min(r0, r[6]); r1 = std::max(r1, r[7]);
+        }
+      fprintf(stderr, "[s2-stamp] C %d OWW %d TS %d OWG %d CG %d XA %d grid %u x %u: span %.2f us; mean cycles per wave: issue %.0f, "
+              "w-commit %.0f, barrier %.0f, mfma-loop %.0f, epilogue %.0f; slowest wave %.0f\n",
+              C, OWW, TS, OWG, CG, XA, grid.x, grid.y, (double)(r1 - r0) / 100.0, seg[1] / nw, seg[2] / nw, seg[3] / nw,
+              seg[4] / nw, seg[5] / nw, cmax);
+    }
+  }
+#endif
+  return DFHIP_OK;
+}
+
+}  // namespace
+
+namespace dfhip {
+
+// x (N, C, H, H) -> y = conv3x3/s2/p1(x, w) and yd = conv1x1/s2/p0(x, wd), both (N, O, H/2, H/2); -1 when the shape is
+// not one this kernel takes (dry_run: only the shape test)
+int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y, float* yd, int N, int C, int H, int W,
+                       int O, float* partials, float* partials_d, int cap_rows, int* rows_out, bool dry_run) {
+  static int enabled = getenv("DFHIP_S2_PAIR") ? atoi(getenv("DFHIP_S2_PAIR")) : 1;
+  if (!enabled || H != W) return -1;
+  static int variant = getenv("DFHIP_S2_VARIANT") ? atoi(getenv("DFHIP_S2_VARIANT")) : 0;
+  int otw, ts, owg, lwo;
+  if (C == 32 && H == 16) { otw = 2; ts = 4; owg = 2; lwo = 3; }
+  else if (C == 64 && H == 8) { otw = variant == 1 ? 1 : 2; ts = 4; owg = variant == 1 ? 2 : 1; lwo = 2; }
+  else if (C == 128 && H == 4) { otw = 1; ts = 4; owg = 1; lwo = 1; }
+  else return -1;
+  const int ocw = otw * owg * 16;              // output channels per workgroup
+  const int64_t opix = (int64_t)N * (H / 2) * (W / 2);
+  if (O % ocw != 0 || opix % (16 * ts) != 0) return -1;
+  const int64_t gx = opix / (16 * ts);
+  if (partials && gx > cap_rows) return -1;
+  if (gx * (O / ocw) < num_cus() / 2) return -1;
+  if (rows_out) *rows_out = partials ? (int)gx : 0;
+  if (dry_run) return DFHIP_OK;
+  dim3 grid((unsigned)gx, (unsigned)(O / ocw));
+  if (C == 32) return launch_s2<32, 2, 4, 2, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  if (C == 64) {
+    // (two channel tiles per wave, four waves: the two waves of a tile otherwise request the same pixels twice --
+    // 13.1 against 15.5 us)
+    if (variant == 1) return launch_s2<64, 1, 4, 2, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+    return launch_s2<64, 2, 4, 1, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  }
+  if (variant == 1) return launch_s2<128, 1, 4, 1, 4, 3>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  return launch_s2<128, 1, 4, 1, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+}
+
+}  // namespace dfhip

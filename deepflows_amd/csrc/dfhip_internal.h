@@ -73,6 +73,11 @@ int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y,
                     int k, int stride, int pad, float* partials, int cap_rows, int* rows_out,
                     const BnInput* bn = nullptr, bool dry_run = false);   // dry_run: only the shape test
 
+// dfhip_conv_s2.hip: 3x3 / stride 2 / pad 1 forward together with the block's 1x1 / stride 2 shortcut convolution
+// (one launch, two outputs, BatchNorm partials of both); -1 when the shape is not eligible
+int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y, float* yd, int N, int C, int H, int W,
+                       int O, float* partials, float* partials_d, int cap_rows, int* rows_out, bool dry_run = false);
+
 int run_conv_rowmma_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int C, int H, int W,
                           int O, int k, int stride, int pad);
 

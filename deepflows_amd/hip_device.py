@@ -274,6 +274,15 @@ class HipModule:
 
     wgrad_grouping = os.environ.get("DF_WGRAD_GROUP", "1") != "0"
 
+    def conv2d_forward_s2_pair(self, x, w, wd, y, yd, N, C, H, W, O, partials, partials_d, cap_rows):
+        """y = conv3x3/s2/p1(x, w), yd = conv1x1/s2/p0(x, wd) as one launch; returns (done, rows of BatchNorm partials)."""
+        g = lambda h: h.ptr if h is not None else None
+        rows, done = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self._lib.dfhip_conv2d_forward_s2_pair(x.ptr, w.ptr, wd.ptr, y.ptr, yd.ptr, N, C, H, W, O, g(partials),
+                                                          g(partials_d), int(cap_rows), ctypes.byref(rows),
+                                                          ctypes.byref(done)))
+        return bool(done.value), int(rows.value)
+
     def conv2d_dgrad_pair(self, dy, w, dy2, w2, add, dx, N, C, H, W, O, mode=None):
         """dx = dgrad(3x3 s2 p1; dy, w) + dgrad(1x1 s2 p0; dy2, w2) (+ add) as one launch; False = no such kernel."""
         mode = self.conv_dgrad_mode if mode is None else mode

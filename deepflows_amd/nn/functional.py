@@ -279,6 +279,47 @@ class _Conv2dFused(_FusedNode):
             x.device.conv2d_forward(self.xd._handle, self.wd._handle, bh, out._handle, *self.geo)
         super().__init__(out, [x, w, bias])
 
+    @classmethod
+    def pair_s2(cls, x, conv1, conv_d):
+        """(conv1(x), conv_d(x)) for a 3x3 / stride 2 / pad 1 `conv1` and a 1x1 / stride 2 / pad 0 `conv_d` without
+        biases that read the same tensor -- a residual block and its shortcut (test/ResNet_CIFAR10_cuda.py:31-47) -- from
+        ONE launch (the shortcut rides as a tenth tap of the 3x3 loop); two ordinary nodes come back, each with its own
+        grad_fn.  None when that form does not apply: the caller then calls the two modules."""
+        dev = x.device
+        fn = getattr(dev.mod, "conv2d_forward_s2_pair", None)
+        if (fn is None or not _S2_PAIR or len(x.shape) != 4 or conv1.bias is not None or conv_d.bias is not None
+                or (int(conv1.kernel_size), int(conv1.stride), int(conv1.padding)) != (3, 2, 1)
+                or (int(conv_d.kernel_size), int(conv_d.stride), int(conv_d.padding)) != (1, 2, 0)
+                or tuple(conv1.weight.shape[:2]) != tuple(conv_d.weight.shape[:2])):
+            return None
+        N, C, H, W = (int(v) for v in x.shape)
+        O = int(conv1.weight.shape[0])
+        if H % 2 or W % 2:
+            return None
+        xd = x.data.compact()
+        w1, wd = conv1.weight.data.compact(), conv_d.weight.data.compact()
+        y1, yd = _new((N, O, H // 2, W // 2), dev), _new((N, O, H // 2, W // 2), dev)
+        stats = _CONV_BN_STATS and is_grad_enable()
+        p1 = _new((_BN_PARTIAL_ROWS, O, 3), dev) if stats else None
+        pd = _new((_BN_PARTIAL_ROWS, O, 3), dev) if stats else None
+        h = lambda t: t._handle if t is not None else None
+        done, rows = fn(xd._handle, w1._handle, wd._handle, y1._handle, yd._handle, N, C, H, W, O, h(p1), h(pd),
+                        _BN_PARTIAL_ROWS)
+        if not done:
+            return None
+        nodes = []
+        # (the shortcut's node first: the backward sweep then reaches conv1's node first, which forms both input
+        # gradients in one launch -- shortcut_sibling)
+        for out, wt, wdat, part, geo in ((yd, conv_d.weight, wd, pd, (N, C, H, W, O, 1, 2, 0)),
+                                         (y1, conv1.weight, w1, p1, (N, C, H, W, O, 3, 2, 1))):
+            node = cls.__new__(cls)
+            node.x, node.w, node.bias = x, wt, None
+            node.geo, node.xd, node.wd = geo, xd, wdat
+            node.bn_partials = (part, rows) if (part is not None and rows > 0) else None
+            _FusedNode.__init__(node, out, [x, wt, None])
+            nodes.append(node)
+        return nodes[1], nodes[0]
+
     # the engine may hand over the gradient the input already holds (tensor.py backward): the sum
     # is then formed in the epilogue of the input-gradient kernel
     fuses_accumulation = True
@@ -656,6 +697,7 @@ class _BnConv2dFused(_FusedNode):
 
 
 _BN_INPUT = os.environ.get("DF_BN_INPUT", "1") != "0"
+_S2_PAIR = os.environ.get("DF_S2_PAIR", "1") != "0"
 
 
 def bn_conv2d_train(x, bn, conv):

@@ -96,12 +96,21 @@ class ResidualBlock(nn.Module):
         identity = x
         ds = self.downsample
         pair = ds is not None and len(ds) == 2 and isinstance(ds[1], nn.BatchNorm2d)
+        z1 = None
         if pair:
-            zd = ds[0](x)                      # the shortcut convolution; its BatchNorm joins bn2 below
+            # conv1 and the shortcut convolution read the same tensor: one launch for both where the device has it
+            both = None
+            if bool(getattr(x.device.mod, "fused", False)) and isinstance(ds[0], nn.Conv2d):
+                both = nn.functional._Conv2dFused.pair_s2(x, self.conv1, ds[0])
+            if both is not None:
+                z1, zd = both
+            else:
+                zd = ds[0](x)                  # the shortcut convolution; its BatchNorm joins bn2 below
         elif ds is not None:
             for layer in ds:
                 identity = layer(identity)
-        z1 = self.conv1(x)
+        if z1 is None:
+            z1 = self.conv1(x)
         if pair and hasattr(z1, "shortcut_sibling") and hasattr(zd, "shortcut_sibling"):
             z1.shortcut_sibling = zd           # both read x: one launch forms both input gradients (nn.functional)
         # conv2(bn1(z1)): bn1 applied on conv2's operand loads (one node, bn1's output is never written); None when

@@ -133,6 +133,16 @@ int dfhip_conv2d_forward(const float* x, const float* w, const float* bias, floa
 int dfhip_conv2d_dgrad_add(const float* dy, const float* w, const float* add, float* dx, int N, int C,
                            int H, int W, int O, int k, int stride, int pad, int mode);
 
+/* y = conv2d(x, w; 3x3 / stride 2 / pad 1) and yd = conv2d(x, wd; 1x1 / stride 2 / pad 0): conv1 and downsample[0] of
+ * a residual block read the same tensor (test/ResNet_CIFAR10_cuda.py:31-47; nn/functional.py:316-344 twice) -- one
+ * launch, the shortcut as a tenth tap of the 3x3 loop (it reads that convolution's centre-tap pixels).  x (N,C,H,W);
+ * w (O,C,3,3); wd (O,C,1,1); y, yd (N,O,H/2,W/2).  partials / partials_d (both or neither): BatchNorm partials of y /
+ * yd as dfhip_conv2d_forward_stats, *rows_out rows each.  *done = 0 (nothing launched) when the shape has no such
+ * kernel: the caller then runs dfhip_conv2d_forward_stats twice. */
+int dfhip_conv2d_forward_s2_pair(const float* x, const float* w, const float* wd, float* y, float* yd, int N, int C,
+                                 int H, int W, int O, float* partials, float* partials_d, int cap_rows, int* rows_out,
+                                 int* done);
+
 /* dx = dgrad(3x3 / stride 2 / pad 1; dy, w) + dgrad(1x1 / stride 2 / pad 0; dy2, w2) (+ add, may be NULL): the two
  * gradients the input of a residual block receives when its shortcut is a convolution (test/ResNet_CIFAR10_cuda.py:
  * 58-63: conv1 and downsample[0] both read x; tensor.py:444 sums them), each with the reference's last-writer-wins

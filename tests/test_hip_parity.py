@@ -415,6 +415,52 @@ def test_shortcut_input_gradient_rides_on_the_stride2_kernel(hip_device, C, HW, 
     assert not mod.conv2d_dgrad_pair(dy, w, dy2, w2, None, mod.Array(N * C * HW * HW), N, C, HW, HW, O, mode="accumulate")
 
 
+@pytest.mark.parametrize("C,HW,O", [(32, 16, 64), (64, 8, 128), (128, 4, 256)])
+def test_stride2_convolution_and_its_shortcut_from_one_launch(hip_device, C, HW, O):
+    """dfhip_conv2d_forward_s2_pair (the 1x1 / stride-2 shortcut as a tenth tap of the block's 3x3 / stride-2
+    convolution) against the two separate convolutions: both outputs and both sets of BatchNorm partials (through the
+    BatchNorm that consumes them), then a whole residual block forward + backward with and without it."""
+    from deepflows_amd import nn, tensor, workloads
+    from deepflows_amd.tensor import Graph, Tensor
+    F = nn.functional
+    dev = hip_device
+    rng = np.random.default_rng(23)
+    N = 256
+    x = rng.standard_normal((N, C, HW, HW)).astype(np.float32)
+    gy = rng.standard_normal((N, O, HW // 2, HW // 2)).astype(np.float32)
+    results = []
+    for paired in (True, False):
+        F._S2_PAIR = paired
+        try:
+            np.random.seed(19)
+            down = nn.ModuleList([nn.Conv2d(C, O, kernel_size=1, stride=2, bias=False, device=dev), nn.BatchNorm2d(O, device=dev)])
+            blk = workloads.ResidualBlock(C, O, stride=2, downsample=down, device=dev)
+            blk.train()
+            xt = Tensor(x, device=dev, requires_grad=True)
+            xin = xt * 1.0
+            if paired:
+                both = F._Conv2dFused.pair_s2(xin, blk.conv1, down[0])
+                assert both is not None, "the paired launch must take this shape"
+                z1p, zdp = both[0].numpy().copy(), both[1].numpy().copy()
+            else:
+                z1p, zdp = blk.conv1(xin).numpy().copy(), down[0](xin).numpy().copy()
+            Graph.free_graph_all()
+            xt = Tensor(x, device=dev, requires_grad=True)
+            xin = xt * 1.0
+            y = blk(xin)
+            loss = tensor.sum(y * Tensor(gy, device=dev))
+            loss.backward()
+            results.append([z1p, zdp, y.numpy().copy(), xt.grad.numpy().copy(), blk.conv1.weight.grad.numpy().copy(),
+                            down[0].weight.grad.numpy().copy(), blk.bn1.running_var.numpy().copy(),
+                            down[1].running_mean.numpy().copy()])
+            Graph.free_graph_all()
+        finally:
+            F._S2_PAIR = True
+    names = ("conv1 out", "shortcut out", "block out", "dx", "dw1", "dw_shortcut", "running_var bn1", "running_mean bn_d")
+    for a, b, nm in zip(results[0], results[1], names):
+        assert_close(a, b, 3e-5, f"s2 pair C={C}: " + nm)
+
+
 def test_residual_block_with_convolution_shortcut_one_input_gradient_launch(hip_device):
     from deepflows_amd import nn, tensor, workloads
     from deepflows_amd.tensor import Graph, Tensor

@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/tools/probes/build/$name
 mkdir -p $out
 cd $root/deepflows_amd/csrc
-for f in dfhip_runtime dfhip_prims dfhip_gemm dfhip_conv dfhip_conv_rows dfhip_fused; do
+for f in dfhip_runtime dfhip_prims dfhip_gemm dfhip_conv dfhip_conv_rows dfhip_conv_s2 dfhip_fused; do
   if [ "$f" = dfhip_conv_rows ] || [ ! -f build/$f.o ] || [ -n "$ALL" ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed "$@" -c $f.hip -o $out/$f.o
   else
