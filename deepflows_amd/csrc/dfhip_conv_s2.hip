@@ -56,14 +56,19 @@ constexpr int kBlk2 = 260;   // LDS pitch (floats) of a block of four operands x
 // chunks of pixel operands requested ahead (the loads of a chunk must be back before its MFMAs: with one chunk of
 // read-ahead a chunk's ~1 300 cycles of MFMAs did not cover the memory latency and the loop ran at a third of the pipe rate).
 // lwo: log2 of the OUTPUT width (3, 2, 1); H: input height = width = 2 << lwo.
-template <int C, int OWW, int TS, int OWG, int CG, int XA>
-__global__ __launch_bounds__(64 * TS * OWG) void k_conv3x3s2_pair(const float* __restrict__ x,
+// KS: waves that share a tile and split every chunk's channel groups between them (1 or 2; their accumulators are
+// summed through LDS at the end): two waves per SIMD where the problem has only 1 024 tile x channel-tile units, and
+// each wave requests only its own groups' pixels.
+template <int C, int OWW, int TS, int OWG, int CG, int XA, int KS>
+__global__ __launch_bounds__(64 * TS * OWG * KS) void k_conv3x3s2_pair(const float* __restrict__ x,
                                                                  const float* __restrict__ w,
                                                                  const float* __restrict__ wd,
                                                                  float* __restrict__ y, float* __restrict__ yd,
                                                                  float* __restrict__ partials,
                                                                  float* __restrict__ partials_d, int lwo, int O) {
-  constexpr int NWAVE = TS * OWG, NTHR = 64 * NWAVE;
+  constexpr int NWAVE = TS * OWG * KS, NTHR = 64 * NWAVE;
+  constexpr int CGW = CG / KS;                 // channel groups of a chunk per wave
+  static_assert(CG % KS == 0 && (CGW * 10) % 4 == 0, "a wave's share of a chunk is whole operand blocks");
   constexpr int OT = OWG * OWW;                // output-channel tiles of the workgroup
   constexpr int NG = C / 4;                    // channel groups (one MFMA k-step per tap each)
   constexpr int TAPS = 10;                     // nine taps + the shortcut
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(64 * TS * OWG) void k_conv3x3s2_pair(const float* _
   const int W = WO << 1, HW = HWO << 2;        // input plane (H = W)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, n = lane & 15;
-  const int ts = wave % TS, og = wave / TS;
+  const int ts = wave % TS, og = (wave / TS) % OWG, ksp = wave / (TS * OWG);
   const int ot0 = og * OWW;                    // first channel tile of this wave within the workgroup
   const int o_wg = blockIdx.y * (OT * 16);     // first output channel of the workgroup
   const int T = blockIdx.x * TS + ts;          // this wave's pixel tile
@@ -148,15 +153,16 @@ __global__ __launch_bounds__(64 * TS * OWG) void k_conv3x3s2_pair(const float* _
     xo0[i] = (rowok && s > 0) ? (unsigned)((((int64_t)img * C + kk) * W + yy) * W + 2 * s - 1) * 4u : kOut;
   }
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7fffffff, 0x00020000);
-  float raw[NG][9];
+  float raw[NG / KS][9];                       // this wave's groups: chunk ch holds raw[ch * CGW ..]
 #define S2_XLOAD(chunk)                                                                                   \
   do {                                                                                                    \
-    _Pragma("unroll") for (int g_ = 0; g_ < CG; g_++) {                                                   \
-      const int p_ = (chunk) * CG + g_;                                                                   \
+    _Pragma("unroll") for (int g_ = 0; g_ < CGW; g_++) {                                                  \
+      const int q_ = (chunk) * CGW + g_;                    /* slot in raw */                             \
+      const int p_ = (chunk) * CG + ksp * CGW + g_;         /* channel group */                           \
       _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) {                                                  \
         const f32x2 t2_ = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)xo2[i_], p_ * (16 * HW), 0)); \
-        raw[p_][i_ * 3 + 1] = t2_[0]; raw[p_][i_ * 3 + 2] = t2_[1];                                       \
-        raw[p_][i_ * 3] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)xo0[i_], p_ * (16 * HW), 0)); \
+        raw[q_][i_ * 3 + 1] = t2_[0]; raw[q_][i_ * 3 + 2] = t2_[1];                                       \
+        raw[q_][i_ * 3] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)xo0[i_], p_ * (16 * HW), 0)); \
       }                                                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                                  \
     }                                                                                                     \
@@ -205,12 +211,13 @@ __global__ __launch_bounds__(64 * TS * OWG) void k_conv3x3s2_pair(const float* _
     for (int c = 0; c < 4; c++) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     accd[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const f32x4* Wl4 = reinterpret_cast<const f32x4*>(Wl + ot0 * (NBLK * kBlk2)) + lane;
-  f32x4 a4[2][OWW][CBLK];
+  constexpr int WBLK = CBLK / KS;              // operand blocks of a chunk this wave reads
+  const f32x4* Wl4 = reinterpret_cast<const f32x4*>(Wl + ot0 * (NBLK * kBlk2)) + ksp * WBLK * (kBlk2 / 4) + lane;
+  f32x4 a4[2][OWW][WBLK];
 #pragma unroll
   for (int a = 0; a < OWW; a++)
 #pragma unroll
-    for (int q = 0; q < CBLK; q++) a4[0][a][q] = Wl4[a * (NBLK * kBlk2 / 4) + q * (kBlk2 / 4)];
+    for (int q = 0; q < WBLK; q++) a4[0][a][q] = Wl4[a * (NBLK * kBlk2 / 4) + q * (kBlk2 / 4)];
 #pragma unroll
   for (int ch = 0; ch < NCH; ch++) {
     // chunk ch + 1 (requested a chunk ago) is committed now and made visible by a barrier in the middle of this
@@ -220,14 +227,14 @@ __global__ __launch_bounds__(64 * TS * OWG) void k_conv3x3s2_pair(const float* _
     __builtin_amdgcn_sched_barrier(0);
     if (ch + XA < NCH) S2_XLOAD(ch + XA);
 #pragma unroll
-    for (int g = 0; g < CG; g++) {
-      const int p = ch * CG + g;
-      if (g == CG / 2 && ch + 1 < NCH) {
+    for (int g = 0; g < CGW; g++) {
+      const int p = ch * CGW + g;                // slot in raw
+      if (g == CGW / 2 && ch + 1 < NCH) {
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < OWW; a++)
 #pragma unroll
-          for (int q = 0; q < CBLK; q++)
+          for (int q = 0; q < WBLK; q++)
             a4[(ch + 1) & 1][a][q] = Wl4[a * (NBLK * kBlk2 / 4) + ((ch + 1) * CBLK + q) * (kBlk2 / 4)];
       }
 #pragma unroll
@@ -250,12 +257,35 @@ __global__ __launch_bounds__(64 * TS * OWG) void k_conv3x3s2_pair(const float* _
 #undef S2_XLOAD
 
   S2_STAMP(4);
+  // ---- the waves that split a tile's channel groups: the second one hands its sums over through LDS ----
+  f32x4 resv[OWW], resdv[OWW];
+#pragma unroll
+  for (int a = 0; a < OWW; a++) {
+    resv[a] = acc[a][0];
+    resv[a] += acc[a][1]; resv[a] += acc[a][2]; resv[a] += acc[a][3];
+    resdv[a] = accd[a];
+  }
+  if constexpr (KS == 2) {
+    __syncthreads();                           // every wave is done with the weight image: it becomes the exchange area
+    f32x4* ex = reinterpret_cast<f32x4*>(Wl) + ((ts + TS * og) * OWW * 2) * 64 + lane;
+    if (ksp == 1) {
+#pragma unroll
+      for (int a = 0; a < OWW; a++) { ex[(2 * a) * 64] = resv[a]; ex[(2 * a + 1) * 64] = resdv[a]; }
+    }
+    __syncthreads();
+    if (ksp == 0) {
+#pragma unroll
+      for (int a = 0; a < OWW; a++) { resv[a] += ex[(2 * a) * 64]; resdv[a] += ex[(2 * a + 1) * 64]; }
+    }
+  }
+  const bool owner = ksp == 0;                 // stores and statistics of the tile
+  const int swave = ts + TS * og;              // row of the statistics exchange
   // ---- epilogue: accumulator register v of lane (kk, n) is channel o + 4 kk + v of the tile's pixel n ----
 #pragma unroll
   for (int a = 0; a < OWW; a++) {
-    f32x4 res = acc[a][0];
-    res += acc[a][1]; res += acc[a][2]; res += acc[a][3];
-    const f32x4 resd = accd[a];
+    if (!owner) break;
+    const f32x4 res = resv[a];
+    const f32x4 resd = resdv[a];
     const int o0 = o_wg + (ot0 + a) * 16;
     const int64_t at = ((int64_t)img * O + o0 + 4 * kk) * HWO + rem;
 #pragma unroll
@@ -271,8 +301,8 @@ __global__ __launch_bounds__(64 * TS * OWG) void k_conv3x3s2_pair(const float* _
         const float d1 = res[v] - m1, d2 = resd[v] - m2;
         const float q1 = row_sum16b(d1 * d1), q2 = row_sum16b(d2 * d2);
         if (n == 0) {
-          sred[0][wave][a * 16 + 4 * kk + v][0] = m1; sred[0][wave][a * 16 + 4 * kk + v][1] = q1;
-          sred[1][wave][a * 16 + 4 * kk + v][0] = m2; sred[1][wave][a * 16 + 4 * kk + v][1] = q2;
+          sred[0][swave][a * 16 + 4 * kk + v][0] = m1; sred[0][swave][a * 16 + 4 * kk + v][1] = q1;
+          sred[1][swave][a * 16 + 4 * kk + v][0] = m2; sred[1][swave][a * 16 + 4 * kk + v][1] = q2;
         }
       }
     }
@@ -299,39 +329,39 @@ __global__ __launch_bounds__(64 * TS * OWG) void k_conv3x3s2_pair(const float* _
   S2_STAMP(7);
 }
 
-template <int C, int OWW, int TS, int OWG, int CG, int XA>
+template <int C, int OWW, int TS, int OWG, int CG, int XA, int KS = 1>
 int launch_s2(const float* x, const float* w, const float* wd, float* y, float* yd, float* partials, float* partials_d,
               int lwo, int O, dim3 grid) {
   const size_t lds = (size_t)(OWG * OWW) * (C / 4 * 10 / 4) * kBlk2 * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA, KS>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536)));
     attr = true;
   }
-  DF_LAUNCH((k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA>), grid, dim3(64 * TS * OWG), lds, stream(), x, w, wd, y, yd, partials,
+  DF_LAUNCH((k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA, KS>), grid, dim3(64 * TS * OWG * KS), lds, stream(), x, w, wd, y, yd, partials,
             partials_d, lwo, O);
   DF_LAUNCH_CHECK();
 #ifdef DFHIP_S2_STAMPS
   {
     static int calls = 0;
     if (++calls % 20 == 0) {
-      const size_t nw = (size_t)grid.x * grid.y * TS * OWG;
+      const size_t nw = (size_t)grid.x * grid.y * TS * OWG * KS;
       std::vector<unsigned long long> h((size_t)grid.x * grid.y * 8 * 8);
       (void)hipStreamSynchronize(stream());
       (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_s2_stamps), h.size() * sizeof(unsigned long long));
       double seg[6] = {0}, cmax = 0;
       unsigned long long r0 = ~0ull, r1 = 0;
       for (size_t b = 0; b < (size_t)grid.x * grid.y; b++)
-        for (int wv2 = 0; wv2 < TS * OWG; wv2++) {
+        for (int wv2 = 0; wv2 < TS * OWG * KS; wv2++) {
           const unsigned long long* r = &h[(b * 8 + wv2) * 8];
           for (int k = 1; k <= 5; k++) seg[k] += (double)(r[k] - r[k - 1]);
           cmax = std::max(cmax, (double)(r[5] - r[0]));
           r0 = std::min(r0, r[6]); r1 = std::max(r1, r[7]);
         }
-      fprintf(stderr, "[s2-stamp] C %d OWW %d TS %d OWG %d CG %d XA %d grid %u x %u: span %.2f us; mean cycles per wave: issue %.0f, "
+      fprintf(stderr, "[s2-stamp] C %d OWW %d TS %d OWG %d CG %d XA %d KS %d grid %u x %u: span %.2f us; mean cycles per wave: issue %.0f, "
               "w-commit %.0f, barrier %.0f, mfma-loop %.0f, epilogue %.0f; slowest wave %.0f\n",
-              C, OWW, TS, OWG, CG, XA, grid.x, grid.y, (double)(r1 - r0) / 100.0, seg[1] / nw, seg[2] / nw, seg[3] / nw,
+              C, OWW, TS, OWG, CG, XA, KS, grid.x, grid.y, (double)(r1 - r0) / 100.0, seg[1] / nw, seg[2] / nw, seg[3] / nw,
               seg[4] / nw, seg[5] / nw, cmax);
     }
   }
@@ -352,7 +382,7 @@ int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y
   static int variant = getenv("DFHIP_S2_VARIANT") ? atoi(getenv("DFHIP_S2_VARIANT")) : 0;
   int otw, ts, owg, lwo;
   if (C == 32 && H == 16) { otw = 2; ts = 4; owg = 2; lwo = 3; }
-  else if (C == 64 && H == 8) { otw = variant == 1 ? 1 : 2; ts = 4; owg = variant == 1 ? 2 : 1; lwo = 2; }
+  else if (C == 64 && H == 8) { otw = variant == 1 ? 1 : 2; ts = 4; owg = variant == 1 ? 2 : 1; lwo = 2; }   // (+ KS)
   else if (C == 128 && H == 4) { otw = 1; ts = 4; owg = 1; lwo = 1; }
   else return -1;
   const int ocw = otw * owg * 16;              // output channels per workgroup
@@ -366,12 +396,14 @@ int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y
   dim3 grid((unsigned)gx, (unsigned)(O / ocw));
   if (C == 32) return launch_s2<32, 2, 4, 2, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
   if (C == 64) {
-    // (two channel tiles per wave, four waves: the two waves of a tile otherwise request the same pixels twice --
-    // 13.1 against 15.5 us)
+    // (two channel tiles per wave: the two waves of a tile otherwise request the same pixels twice -- 12.8 against
+    // 15.5 us; splitting the channel groups over two waves per tile, variant 3, changes nothing: 13.0)
     if (variant == 1) return launch_s2<64, 1, 4, 2, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+    if (variant == 3) return launch_s2<64, 2, 4, 1, 4, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
     return launch_s2<64, 2, 4, 1, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
   }
   if (variant == 1) return launch_s2<128, 1, 4, 1, 4, 3>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  if (variant == 3) return launch_s2<128, 1, 4, 1, 4, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
   return launch_s2<128, 1, 4, 1, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
 }
 
