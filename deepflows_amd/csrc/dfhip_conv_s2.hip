@@ -382,7 +382,7 @@ int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y
   static int variant = getenv("DFHIP_S2_VARIANT") ? atoi(getenv("DFHIP_S2_VARIANT")) : 0;
   int otw, ts, owg, lwo;
   if (C == 32 && H == 16) { otw = 2; ts = 4; owg = 2; lwo = 3; }
-  else if (C == 64 && H == 8) { otw = variant == 1 ? 1 : 2; ts = 4; owg = variant == 1 ? 2 : 1; lwo = 2; }   // (+ KS)
+  else if (C == 64 && H == 8) { otw = 2; ts = 4; owg = 1; lwo = 2; }
   else if (C == 128 && H == 4) { otw = 1; ts = 4; owg = 1; lwo = 1; }
   else return -1;
   const int ocw = otw * owg * 16;              // output channels per workgroup
@@ -394,17 +394,23 @@ int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y
   if (rows_out) *rows_out = partials ? (int)gx : 0;
   if (dry_run) return DFHIP_OK;
   dim3 grid((unsigned)gx, (unsigned)(O / ocw));
-  if (C == 32) return launch_s2<32, 2, 4, 2, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  if (C == 32) {
+    // (chunks of two channel groups, two chunks of pixels ahead: the first MFMA waits for a quarter of the operands
+    // instead of half -- 13.4 us against 14.9 with chunks of four)
+    if (variant == 1) return launch_s2<32, 2, 4, 2, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+    if (variant == 3) return launch_s2<32, 2, 4, 2, 2, 3>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+    return launch_s2<32, 2, 4, 2, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  }
   if (C == 64) {
     // (two channel tiles per wave: the two waves of a tile otherwise request the same pixels twice -- 12.8 against
-    // 15.5 us; splitting the channel groups over two waves per tile, variant 3, changes nothing: 13.0)
-    if (variant == 1) return launch_s2<64, 1, 4, 2, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-    if (variant == 3) return launch_s2<64, 2, 4, 1, 4, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-    return launch_s2<64, 2, 4, 1, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+    // 15.5 us; splitting the channel groups over two waves per tile changes nothing: 13.0)
+    if (variant == 1) return launch_s2<64, 2, 4, 1, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+    if (variant == 3) return launch_s2<64, 2, 4, 1, 2, 3>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+    return launch_s2<64, 2, 4, 1, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
   }
-  if (variant == 1) return launch_s2<128, 1, 4, 1, 4, 3>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-  if (variant == 3) return launch_s2<128, 1, 4, 1, 4, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-  return launch_s2<128, 1, 4, 1, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  if (variant == 1) return launch_s2<128, 1, 4, 1, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  if (variant == 3) return launch_s2<128, 1, 4, 1, 2, 3>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  return launch_s2<128, 1, 4, 1, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
 }
 
 }  // namespace dfhip
