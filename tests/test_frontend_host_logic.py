@@ -169,6 +169,36 @@ def test_dropout_mask_equals_numpy_binomial():
             assert sa[2] == sb[2] and np.array_equal(sa[1], sb[1]), (keep, seed)
 
 
+def test_engine_skips_a_contribution_a_sibling_node_already_delivered(cpu_oracle):
+    """A fused node may return None from grad_fn for a parent whose gradient another node's launch already carried
+    (the shortcut convolution of a residual block): the sweep leaves the parent's gradient as it is -- with and
+    without a gradient already held."""
+    from deepflows_amd.nn.functional import _FusedNode
+
+    class _Delivers(_FusedNode):
+        fuses_accumulation = True
+
+        def __init__(self, x, factor):
+            self.x, self.factor = x, factor
+            super().__init__(x.data * 1.0, [x])
+
+        def grad_fn(self, node, grad, accumulated=None):
+            if self.factor is None:
+                return None                                  # "already delivered"
+            out = grad * self.factor
+            return out if accumulated is None else out + accumulated
+
+    x = Tensor(np.arange(4, dtype=np.float32), requires_grad=True, device=cpu_oracle)
+    xin = x * 1.0
+    a = _Delivers(xin, 2.0)            # created first: visited last
+    b = _Delivers(xin, None)           # visited first, returns None with no gradient held
+    c = _Delivers(xin, 3.0)
+    d = _Delivers(xin, None)           # returns None while a gradient is already held (the accumulation branch)
+    loss = tensor.sum(a + b + c + d)
+    loss.backward()
+    assert np.allclose(x.grad.numpy(), 5.0 * np.ones(4))
+
+
 def test_large_dropout_masks_continue_numpys_stream_in_c():
     """Masks of 8 192 elements and more come from libdfhip's host helper (dfhip_host_bernoulli_mask: the MT19937
     stream of NumPy's global generator continued in vectorised C): same values as np.random.binomial(1, keep, n) and
