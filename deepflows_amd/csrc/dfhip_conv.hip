@@ -1117,6 +1117,94 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__
   }
 }
 
+// The same idea on 4 x 4 IMAGES (ResNet layer3): input pixel (y, x) keeps the tap whose source is output pixel
+// (max(y - 1, 0), max(x - 1, 0)) -- one of nine -- with one of four weight slices.  The general kernel's 32-pixel tile
+// (two images) holds all four slices and runs four passes with most lanes masked; here a workgroup owns 16 images x
+// 16 channels x the sixteen pixels: an image on the lane, one accumulator per pixel (16 MFMAs per k-step, none of
+// them masked), the nine source pixels of a k-step are nine loads, the four waves split o and are summed through
+// LDS, and a lane leaves with 16-byte stores (the pixels of a channel are adjacent in memory).
+template <int O>
+__global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__ dy, const float* __restrict__ w,
+                                                       const float* __restrict__ add, float* __restrict__ dx, int C) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int OQ = O / 4, NK = OQ / 4;             // o per wave, MFMA k-steps per wave
+  float* Wl = smem;                                 // [4 slices][O][16 channels]; later the exchange area [3][64][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 4, n = lane & 15;
+  const int n0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
+  const int ob = wave * OQ;
+  // dY operands of this wave's o range: the nine source pixels (u, v) in {0, 1, 2}^2 of image n0 + n, channel ob + 4 p + kk
+  float sv[NK][9];
+  {
+    const float* sp = dy + ((int64_t)(n0 + n) * O + ob + kk) * 16;
+#pragma unroll
+    for (int p = 0; p < NK; p++)
+#pragma unroll
+      for (int u = 0; u < 3; u++)
+#pragma unroll
+        for (int v = 0; v < 3; v++) sv[p][u * 3 + v] = sp[(int64_t)p * 64 + u * 4 + v];
+  }
+  // weight slices: (o, c) pairs, taps 4, 5, 7, 8 of each
+  constexpr int PAIRS = O * 16 / 256;
+#pragma unroll
+  for (int i0 = 0; i0 < PAIRS; i0 += 8) {
+    float wv[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = tid + 256 * (i0 + i), o = e >> 4, c = e & 15;
+      const float* q = w + ((int64_t)o * C + c0 + c) * 9;
+      wv[i][0] = q[4]; wv[i][1] = q[5]; wv[i][2] = q[7]; wv[i][3] = q[8];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = tid + 256 * (i0 + i), o = e >> 4, c = e & 15;
+#pragma unroll
+      for (int q = 0; q < 4; q++) Wl[(q * O + o) * 16 + c] = wv[i][q];
+    }
+  }
+  __syncthreads();
+  f32x4 acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < NK; p++) {
+    float a[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) a[q] = Wl[(q * O + ob + 4 * p + kk) * 16 + n];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        const int u = y >= 1 ? y - 1 : 0, v = x >= 1 ? x - 1 : 0, cls = (y >= 1 ? 2 : 0) + (x >= 1 ? 1 : 0);
+        acc[y * 4 + x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cls], sv[p][u * 3 + v], acc[y * 4 + x], 0, 0, 0);
+      }
+  }
+  __syncthreads();                                  // the weight image is dead: it becomes the exchange area
+  f32x4* ex = reinterpret_cast<f32x4*>(smem);
+  if (wave > 0) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) ex[((wave - 1) * 16 + q) * 64 + lane] = acc[q];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int ww = 0; ww < 3; ww++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) acc[q] += ex[(ww * 16 + q) * 64 + lane];
+    // register v of lane (kk, n) is channel c0 + 4 kk + v of image n0 + n; its sixteen pixels are adjacent
+    const int64_t obase = ((int64_t)(n0 + n) * C + c0 + 4 * kk) * 16;
+#pragma unroll
+    for (int v = 0; v < 4; v++)
+#pragma unroll
+      for (int y = 0; y < 4; y++) {
+        f32x4 r = {acc[y * 4][v], acc[y * 4 + 1][v], acc[y * 4 + 2][v], acc[y * 4 + 3][v]};
+        if (add) r += *reinterpret_cast<const f32x4*>(add + obase + 16 * v + 4 * y);
+        *reinterpret_cast<f32x4*>(dx + obase + 16 * v + 4 * y) = r;
+      }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // forward, 1x1 / stride 2 / pad 0 (the ResNet shortcut convolutions): K = C is 16-64 MFMAs per
 // 32 x 32 tile, so like the overwrite input gradient this is a kernel without staging phases.  A
@@ -4208,6 +4296,26 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
   } while (0)
       if (O == 128) DF_I2(128); else if (O == 256) DF_I2(256); else DF_I2(512);
 #undef DF_I2
+      DF_LAUNCH_CHECK();
+      return DFHIP_OK;
+    }
+    static int img4 = getenv("DFHIP_DGRAD_IMG4") ? atoi(getenv("DFHIP_DGRAD_IMG4")) : 1;
+    if (lean && img4 && mode == 0 && geo == 0 && H == 4 && W == 4 && N % 16 == 0 && C % 16 == 0 && (O == 64 || O == 128)) {
+      // 4 x 4 images: 16 images x 16 channels x 16 pixels per workgroup, no masked lanes (k_dgrad_ow_img4)
+      dim3 grid((unsigned)(N / 16), (unsigned)(C / 16));
+      const size_t lds = std::max((size_t)4 * O * 16, (size_t)3 * 16 * 64 * 4) * sizeof(float);
+#define DF_I4(OV)                                                                                          \
+  do {                                                                                                     \
+    static bool attr = false;                                                                              \
+    if (!attr) {                                                                                           \
+      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<OV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                 (int)std::max(lds, (size_t)65536)));                                      \
+      attr = true;                                                                                         \
+    }                                                                                                      \
+    DF_LAUNCH(k_dgrad_ow_img4<OV>, grid, dim3(256), lds, stream(), dy, w, add, dx, C);                     \
+  } while (0)
+      if (O == 64) DF_I4(64); else DF_I4(128);
+#undef DF_I4
       DF_LAUNCH_CHECK();
       return DFHIP_OK;
     }
