@@ -1123,44 +1123,69 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__
 // 16 channels x the sixteen pixels: an image on the lane, one accumulator per pixel (16 MFMAs per k-step, none of
 // them masked), the nine source pixels of a k-step are nine loads, the four waves split o and are summed through
 // LDS, and a lane leaves with 16-byte stores (the pixels of a channel are adjacent in memory).
-template <int O>
+// GEO 0: 3x3 / stride 1 / pad 1, dY is 4 x 4 (nine sources).  GEO 1: 3x3 / stride 2 / pad 1, dY is 2 x 2: pixel (y, x)
+// keeps tap (1 + (y & 1), 1 + (x & 1)) of source (y >> 1, x >> 1) (four sources); PAIR (GEO 1): the block's 1x1 /
+// stride 2 shortcut adds sum_o dY2[o][y/2][x/2] W2[o][c] on the pixels with even (y, x) -- a fifth slice.
+template <int O, int GEO, bool PAIR>
 __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       const float* __restrict__ add, float* __restrict__ dx, int C) {
+                                                       const float* __restrict__ add, float* __restrict__ dx, int C,
+                                                       const float* __restrict__ dy2, const float* __restrict__ w2) {
+  static_assert(!PAIR || GEO == 1, "the shortcut rides on the stride-2 form");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int OQ = O / 4, NK = OQ / 4;             // o per wave, MFMA k-steps per wave
-  float* Wl = smem;                                 // [4 slices][O][16 channels]; later the exchange area [3][64][64]
+  constexpr int SW = GEO == 0 ? 3 : 2, NS = SW * SW;  // sources per image: SW x SW of a (GEO 0: 4, GEO 1: 2)-wide plane
+  constexpr int PW = GEO == 0 ? 4 : 2, SP = PW * PW;  // dY plane
+  constexpr int NSL = PAIR ? 5 : 4;
+  float* Wl = smem;                                 // [NSL slices][O][16 channels]; later the exchange area [3][16][64] f32x4
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, n = lane & 15;
   const int n0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
   const int ob = wave * OQ;
-  // dY operands of this wave's o range: the nine source pixels (u, v) in {0, 1, 2}^2 of image n0 + n, channel ob + 4 p + kk
-  float sv[NK][9];
+  // dY operands of this wave's o range: the sources of image n0 + n, channel ob + 4 p + kk
+  float sv[NK][NS], sv2[PAIR ? NK : 1][4];
   {
-    const float* sp = dy + ((int64_t)(n0 + n) * O + ob + kk) * 16;
+    const float* sp = dy + ((int64_t)(n0 + n) * O + ob + kk) * SP;
 #pragma unroll
-    for (int p = 0; p < NK; p++)
+    for (int p = 0; p < NK; p++) {
+      if constexpr (GEO == 1) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(sp + (int64_t)p * 4 * SP);       // the 2 x 2 plane
+        sv[p][0] = t[0]; sv[p][1] = t[1]; sv[p][2] = t[2]; sv[p][3] = t[3];
+      } else {
 #pragma unroll
-      for (int u = 0; u < 3; u++)
+        for (int u = 0; u < SW; u++)
 #pragma unroll
-        for (int v = 0; v < 3; v++) sv[p][u * 3 + v] = sp[(int64_t)p * 64 + u * 4 + v];
+          for (int v = 0; v < SW; v++) sv[p][u * SW + v] = sp[(int64_t)p * 4 * SP + u * PW + v];
+      }
+    }
+    if constexpr (PAIR) {
+      const float* sp2 = dy2 + ((int64_t)(n0 + n) * O + ob + kk) * SP;
+#pragma unroll
+      for (int p = 0; p < NK; p++) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(sp2 + (int64_t)p * 4 * SP);     // the 2 x 2 plane
+        sv2[p][0] = t[0]; sv2[p][1] = t[1]; sv2[p][2] = t[2]; sv2[p][3] = t[3];
+      }
+    }
   }
-  // weight slices: (o, c) pairs, taps 4, 5, 7, 8 of each
-  constexpr int PAIRS = O * 16 / 256;
+  // weight slices: (o, c) pairs, taps 4, 5, 7, 8 of each (+ the shortcut's weight)
+  constexpr int PAIRS = O * 16 / 256, PB = PAIRS < 8 ? PAIRS : 8;
+  static_assert(PAIRS % PB == 0, "weight staging rounds");
 #pragma unroll
-  for (int i0 = 0; i0 < PAIRS; i0 += 8) {
-    float wv[8][4];
+  for (int i0 = 0; i0 < PAIRS; i0 += PB) {
+    float wv[PB][4], wv2[PB];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < PB; i++) {
       const int e = tid + 256 * (i0 + i), o = e >> 4, c = e & 15;
       const float* q = w + ((int64_t)o * C + c0 + c) * 9;
       wv[i][0] = q[4]; wv[i][1] = q[5]; wv[i][2] = q[7]; wv[i][3] = q[8];
+      wv2[i] = PAIR ? w2[(int64_t)o * C + c0 + c] : 0.0f;
     }
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < PB; i++) {
       const int e = tid + 256 * (i0 + i), o = e >> 4, c = e & 15;
 #pragma unroll
       for (int q = 0; q < 4; q++) Wl[(q * O + o) * 16 + c] = wv[i][q];
+      if constexpr (PAIR) Wl[(4 * O + o) * 16 + c] = wv2[i];
     }
   }
   __syncthreads();
@@ -1169,16 +1194,30 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
   for (int q = 0; q < 16; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int p = 0; p < NK; p++) {
-    float a[4];
+    float a[NSL];
 #pragma unroll
-    for (int q = 0; q < 4; q++) a[q] = Wl[(q * O + ob + 4 * p + kk) * 16 + n];
+    for (int q = 0; q < NSL; q++) a[q] = Wl[(q * O + ob + 4 * p + kk) * 16 + n];
 #pragma unroll
     for (int y = 0; y < 4; y++)
 #pragma unroll
       for (int x = 0; x < 4; x++) {
-        const int u = y >= 1 ? y - 1 : 0, v = x >= 1 ? x - 1 : 0, cls = (y >= 1 ? 2 : 0) + (x >= 1 ? 1 : 0);
-        acc[y * 4 + x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cls], sv[p][u * 3 + v], acc[y * 4 + x], 0, 0, 0);
+        int u, v, cls;
+        if (GEO == 0) { u = y >= 1 ? y - 1 : 0; v = x >= 1 ? x - 1 : 0; cls = (y >= 1 ? 2 : 0) + (x >= 1 ? 1 : 0); }
+        else { u = y >> 1; v = x >> 1; cls = ((y & 1) << 1) + (x & 1); }
+        acc[y * 4 + x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cls], sv[p][u * SW + v], acc[y * 4 + x], 0, 0, 0);
       }
+  }
+  if constexpr (PAIR) {
+    // the shortcut's gradient: pixel (2u, 2v) <- dY2[u][v]
+#pragma unroll
+    for (int p = 0; p < NK; p++) {
+      const float a5 = Wl[(4 * O + ob + 4 * p + kk) * 16 + n];
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int v = 0; v < 2; v++)
+          acc[(2 * u) * 4 + 2 * v] = __builtin_amdgcn_mfma_f32_16x16x4f32(a5, sv2[p][u * 2 + v], acc[(2 * u) * 4 + 2 * v], 0, 0, 0);
+    }
   }
   __syncthreads();                                  // the weight image is dead: it becomes the exchange area
   f32x4* ex = reinterpret_cast<f32x4*>(smem);
@@ -4300,21 +4339,24 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
       return DFHIP_OK;
     }
     static int img4 = getenv("DFHIP_DGRAD_IMG4") ? atoi(getenv("DFHIP_DGRAD_IMG4")) : 1;
-    if (lean && img4 && mode == 0 && geo == 0 && H == 4 && W == 4 && N % 16 == 0 && C % 16 == 0 && (O == 64 || O == 128)) {
+    if (lean && img4 && mode == 0 && (geo == 0 || geo == 1) && H == 4 && W == 4 && N % 16 == 0 && C % 16 == 0 &&
+        ((geo == 0 && (O == 64 || O == 128)) || (geo == 1 && (O == 128 || O == 256)))) {
       // 4 x 4 images: 16 images x 16 channels x 16 pixels per workgroup, no masked lanes (k_dgrad_ow_img4)
       dim3 grid((unsigned)(N / 16), (unsigned)(C / 16));
       const size_t lds = std::max((size_t)4 * O * 16, (size_t)3 * 16 * 64 * 4) * sizeof(float);
-#define DF_I4(OV)                                                                                          \
+#define DF_I4(OV, GV)                                                                                      \
   do {                                                                                                     \
     static bool attr = false;                                                                              \
     if (!attr) {                                                                                           \
-      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<OV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<OV, GV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                  (int)std::max(lds, (size_t)65536)));                                      \
       attr = true;                                                                                         \
     }                                                                                                      \
-    DF_LAUNCH(k_dgrad_ow_img4<OV>, grid, dim3(256), lds, stream(), dy, w, add, dx, C);                     \
+    DF_LAUNCH((k_dgrad_ow_img4<OV, GV, false>), grid, dim3(256), lds, stream(), dy, w, add, dx, C,         \
+              (const float*)nullptr, (const float*)nullptr);                                               \
   } while (0)
-      if (O == 64) DF_I4(64); else DF_I4(128);
+      if (geo == 0) { if (O == 64) DF_I4(64, 0); else DF_I4(128, 0); }
+      else { if (O == 128) DF_I4(128, 1); else DF_I4(256, 1); }
 #undef DF_I4
       DF_LAUNCH_CHECK();
       return DFHIP_OK;
@@ -4396,6 +4438,35 @@ int dfhip_conv2d_dgrad_pair(const float* dy, const float* w, const float* dy2, c
   static int pair_on = getenv("DFHIP_DGRAD_PAIR") ? atoi(getenv("DFHIP_DGRAD_PAIR")) : 1;
   int lw = 0;
   while ((1 << lw) < W) lw++;
+  static int img4 = getenv("DFHIP_DGRAD_IMG4") ? atoi(getenv("DFHIP_DGRAD_IMG4")) : 1;
+  if (lean && pair_on && img4 && mode == 0 && H == 4 && W == 4 && N % 16 == 0 && C % 16 == 0 && (O == 128 || O == 256)) {
+    // 4 x 4 images (layer4's first block): the image-per-lane kernel with the shortcut as a fifth slice
+    double flops4 = 2.0 * N * H * W * (double)C * O + 2.0 * N * 4 * (double)C * O;
+    double bytes4 = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * 4);
+    ProfScope prof4("conv2d_dgrad_overwrite_igemm", flops4, bytes4);
+    dim3 grid((unsigned)(N / 16), (unsigned)(C / 16));
+    const size_t lds = std::max((size_t)5 * O * 16, (size_t)3 * 16 * 64 * 4) * sizeof(float);
+    if (O == 128) {
+      static bool attr = false;
+      if (!attr) {
+        DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)std::max(lds, (size_t)65536)));
+        attr = true;
+      }
+      DF_LAUNCH((k_dgrad_ow_img4<128, 1, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2);
+    } else {
+      static bool attr = false;
+      if (!attr) {
+        DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<256, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)std::max(lds, (size_t)65536)));
+        attr = true;
+      }
+      DF_LAUNCH((k_dgrad_ow_img4<256, 1, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2);
+    }
+    DF_LAUNCH_CHECK();
+    *done = 1;
+    return DFHIP_OK;
+  }
   const bool ok = lean && pair_on && mode == 0 && C % 32 == 0 && (1 << lw) == W && H >= 2 && W >= 2 &&
                   ((int64_t)N * H * W) % 32 == 0 && H % 2 == 0 && oh * 2 == H && ow * 2 == W &&
                   (O == 32 || O == 64 || O == 128);          // (256: five slices do not fit the LDS)

@@ -220,10 +220,11 @@ def test_few_channel_stem_kernel(hip_device, C, H, O, N, with_bias):
     (3, 32, 32, 4, 8, 3, 1, 1), (2, 64, 64, 8, 8, 3, 1, 1), (1, 96, 32, 2, 16, 3, 1, 1), (5, 32, 64, 16, 16, 3, 1, 1),
     (2, 32, 32, 32, 32, 3, 1, 1), (8, 128, 128, 4, 4, 3, 1, 1), (16, 64, 256, 2, 2, 3, 1, 1), (6, 32, 128, 4, 4, 3, 1, 1),
     (4, 32, 32, 2, 4, 3, 1, 1),
+    (16, 128, 128, 4, 4, 3, 1, 1), (32, 48, 64, 4, 4, 3, 1, 1), (16, 128, 256, 4, 4, 3, 2, 1), (32, 48, 128, 4, 4, 3, 2, 1),
     (2, 32, 64, 16, 16, 3, 2, 1), (4, 64, 128, 8, 8, 3, 2, 1), (8, 128, 256, 4, 4, 3, 2, 1), (2, 32, 32, 4, 8, 3, 2, 1),
     (2, 32, 64, 16, 16, 1, 2, 0), (4, 64, 128, 8, 8, 1, 2, 0), (8, 128, 256, 4, 4, 1, 2, 0), (16, 32, 32, 2, 2, 1, 2, 0)])
 def test_lean_overwrite_dgrad(hip_device, N, C, O, H, W, k, s, p):
-    """k_dgrad_ow_s1 / _ks: the overwrite-mode input gradient as the 1x1 convolution it is (3x3 stride 1:
+    """k_dgrad_ow_s1 / _ks / _img2 / _img4: the overwrite-mode input gradient as the 1x1 convolution it is (3x3 stride 1:
     shifted, edge-clamped dY, four border classes; 3x3 stride 2: up-sampled dY, four parity classes;
     1x1 stride 2: even pixels only), with and without the held gradient."""
     from conftest import assert_close

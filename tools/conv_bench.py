@@ -59,6 +59,12 @@ def main():
                                                    aff, w, None, y, *geo, part_out, 512)[0]
             if rows > 0 and fwd_bn():          # (only shapes that have the operand path)
                 ops["fwd_bn_in"] = fwd_bn
+        if k == 3 and s == 2 and p == 1 and hasattr(mod, "conv2d_dgrad_pair"):
+            # the block's 1x1 / stride-2 shortcut gradient on the same launch (both read the block input)
+            w2, held = arr((O, C, 1, 1)), arr((N, C, H, W))
+            pair = lambda: mod.conv2d_dgrad_pair(y, w, y, w2, held, dx, N, C, H, W, O, mode="overwrite")
+            if pair():
+                ops["dgrad_pair"] = pair
         for op, fn in ops.items():
             for _ in range(3):
                 fn()
@@ -69,7 +75,7 @@ def main():
             mod.event_record(e1)
             us = mod.event_elapsed_ms(e0, e1) * 1e3 / args.iters
             print(f"{name:6s} {op:10s} {us:9.1f} {flops / us / 1e6:9.2f} {flops / 1e9:8.3f}")
-            if op == "fwd_bn_in":
+            if op in ("fwd_bn_in", "dgrad_pair"):
                 continue
             if not (name == "stem" and op.startswith("dgrad")):
                 total[op] = total.get(op, 0.0) + us * COUNT[name]
