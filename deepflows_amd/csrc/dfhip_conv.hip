@@ -643,137 +643,230 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
 
 // ---------------------------------------------------------------------------------------
 // forward, few-channel 3x3 / stride 1 / pad 1 convolution on 32-wide images (the ResNet stem:
-// 3 -> 32 channels on 32 x 32): K = C*9 <= 36, so a 32-pixel tile is ceil(K/2) <= 18 MFMAs and the
-// layer is bound by its 33.5 MB of output, not by the matrix cores.  A wave owns one image ROW (its
-// 32 lanes are the row's pixels, W == 32): the weight operand of its 32 output channels sits in
-// registers for the whole kernel, the pixel operand of a (channel, tap) is ONE coalesced global
-// load per row (the input is 3 MB and lives in L2; row / column padding by predication), and the
-// 32 x 32 result leaves as sixteen 128-byte stores per half-wave.  No staging phases (the weight tile
-// goes through LDS once per workgroup): the generic kernel spent 26 us per launch on per-workgroup
-// gather tables for 14 MFMAs of work.
+// 3 -> 32 channels on 32 x 32): K = C*9 <= 36, so a 32-pixel row is ceil(K/2) <= 18 MFMAs and the
+// layer is bound by its 33.5 MB of output, not by the matrix cores.  A workgroup (8 waves) takes a band
+// of up to 32 rows of one image: the band's input rows (+ one above and below, + one column either side,
+// all zero outside the image) go to LDS with one 16-byte load per thread and round, and a wave owns an
+// image ROW at a time (its 32 lanes are the row's pixels, W == 32): the weight operand of its 32 output
+// channels sits in registers for the whole kernel, the pixel operand of a (channel, tap) is one LDS read
+// (no masks: the padding is in the tile), and the 32 x 32 result leaves as sixteen 128-byte stores per
+// half-wave.  The address unit then sees the stores and little else: with the operands as global loads
+// (14 per row, 2-4 lines each) the kernel spent 2 us waiting for its first row and 12.5 us in all.
 // ---------------------------------------------------------------------------------------
 // partials (or nullptr): BatchNorm partials of y, one row per workgroup (blockIdx.x) -- (count, mean, centred second
 // moment) per output channel, the layout of dfhip_conv2d_forward_stats.  A lane keeps sums of (y - s) and (y - s)^2
 // over the rows it walks, s = the channel's value at the wave's first pixel (a sample of the channel: the second
-// moment about it is as well conditioned as about the mean); the 32 pixels of a half-wave and the four waves are
-// combined once at the end.
+// moment about it is as well conditioned as about the mean); the 32 pixels of a half-wave are combined by a halving
+// butterfly (31 exchanges for the 32 sums of a lane, each lane ends with one of them), the eight waves through LDS.
+#ifdef DFHIP_STEM_STAMPS
+__device__ unsigned long long g_stem_stamps[1024 * 8 * 8];
+#define STEM_STAMP(i)                                                                                   \
+  do {                                                                                                  \
+    if (lane == 0) g_stem_stamps[(blockIdx.x * 8 + wave) * 8 + (i)] =                                    \
+        (i) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();                     \
+  } while (0)
+#else
+#define STEM_STAMP(i) do { } while (0)
+#endif
+constexpr int kStemPitch = 40, kStemRows = 34;     // LDS tile of a channel: 34 rows of 40 floats, image column c at 4 + c
+template <int XM>
+__device__ __forceinline__ float stem_swz(float v) {     // the value of lane (l ^ XM) of the same 32-lane group
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (XM << 10) | 0x1f));
+}
 template <int C>
-__global__ __launch_bounds__(256) void k_conv_rows3(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(512) void k_conv_rows3(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ y,
-                                                    int N, int H, int O, unsigned m_h, float* __restrict__ partials) {
+                                                    int N, int H, int O, int rb, int bands, float* __restrict__ partials) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int KK = C * 9, NP = (KK + 1) / 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int CH = kStemRows * kStemPitch;            // floats per channel tile
+  constexpr int NQ = C * kStemRows * 8, QR = (NQ + 511) / 512;      // 16-byte pieces of the tile, rounds
+  constexpr int NWR = (32 * KK + 511) / 512;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int d0 = blockIdx.y * 32;
-  // the weight operand goes through LDS once per workgroup: read per wave it is NP requests of 32
-  // pieces KK floats apart, and with a wave per image row that was 7 us of address-unit time per launch
   __shared__ float Wl[32 * KK];
+  __shared__ __attribute__((aligned(16))) float Xl[C * CH];
+  __shared__ float sred[8][2][32], sshift[8][2][16], scount[8], Bl[32];
+  STEM_STAMP(6); STEM_STAMP(0);
+  const int items = N * bands;
+  int item = blockIdx.x;
+  // requests of the first tile and of the weights leave together
+  auto tile_request = [&](int it, f32x4 (&v)[QR]) {
+    const int n = it / bands, r0 = (it - n * bands) * rb;
+    const float* xn = x + (int64_t)n * C * H * 32;
+#pragma unroll
+    for (int q0 = 0; q0 < QR; q0++) {
+      const int q = min(tid + 512 * q0, NQ - 1);
+      const int pc = q & 7, t = q >> 3, lr = t % kStemRows, c = t / kStemRows;
+      const int row = min(max(r0 - 1 + lr, 0), H - 1);                      // (clamped: the commit zeroes what is outside)
+      v[q0] = *reinterpret_cast<const f32x4*>(xn + ((int64_t)c * H + row) * 32 + pc * 4);
+    }
+  };
+  auto tile_commit = [&](int it, const f32x4 (&v)[QR]) {
+    const int n = it / bands, r0 = (it - n * bands) * rb;
+    const int nr = min(rb, H - r0);
+#pragma unroll
+    for (int q0 = 0; q0 < QR; q0++) {
+      const int q = tid + 512 * q0;
+      const int pc = q & 7, t = q >> 3, lr = t % kStemRows, c = t / kStemRows;
+      const int row = r0 - 1 + lr;
+      const bool in = lr < nr + 2 && row >= 0 && row < H;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      if (q < NQ) *reinterpret_cast<f32x4*>(&Xl[c * CH + lr * kStemPitch + 4 + pc * 4]) = in ? v[q0] : z;
+    }
+  };
+  f32x4 tv[QR];
+  float wv[NWR];
+  if (item < items) tile_request(item, tv);
   {
     const int nw = min(32, O - d0) * KK;
-    for (int i = threadIdx.x; i < 32 * KK; i += 256) Wl[i] = i < nw ? w[(int64_t)d0 * KK + i] : 0.0f;
+#pragma unroll
+    for (int i0 = 0; i0 < NWR; i0++) {
+      const int i = tid + 512 * i0;
+      const float t = w[(int64_t)d0 * KK + min(i, nw - 1)];
+      wv[i0] = i < nw ? t : 0.0f;
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < NWR; i0++) {
+      const int i = tid + 512 * i0;
+      if (i < 32 * KK) Wl[i] = wv[i0];
+    }
+    if (tid >= 480) {                                   // (the last lanes: they have the fewest weight pieces)
+      const int dl = tid - 480;
+      float t = 0.0f;
+      if (bias) t = bias[min(d0 + dl, O - 1)];
+      Bl[dl] = t;
+    }
+    // the columns either side of the image (never written again)
+    if (tid < C * kStemRows * 2) {
+      const int t = tid >> 1;
+      Xl[(t / kStemRows) * CH + (t % kStemRows) * kStemPitch + ((tid & 1) ? 36 : 3)] = 0.0f;
+    }
   }
+  if (item < items) tile_commit(item, tv);
   __syncthreads();
+  STEM_STAMP(1);
   float a[NP];
+  int koff[NP];                                      // LDS index of (channel, tap) for output row 0 of the band
 #pragma unroll
   for (int p = 0; p < NP; p++) {
+    // k index 2p (lower half-wave) / 2p+1 (upper): (channel, tap row, tap column); a k beyond K reads tap 0 against a
+    // zero weight
     const int kk = 2 * p + half;
     a[p] = kk < KK ? Wl[l31 * KK + kk] : 0.0f;
+    const int ke = kk < KK ? kk : 0;
+    const int cc = ke / 9, ii = (ke % 9) / 3, jj = ke % 3;
+    koff[p] = cc * CH + ii * kStemPitch + jj + 3 + l31;
   }
   float bv[16];
 #pragma unroll
   for (int rr = 0; rr < 16; rr++) {
-    const int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-    bv[rr] = (bias && d < O) ? bias[d] : 0.0f;
+    bv[rr] = Bl[(rr & 3) + 8 * (rr >> 2) + 4 * half];
   }
-  const int rows = N * H;
-  // a wave walks several rows; the pixel operand of the next row is requested before the MFMAs and the
-  // stores of the current one
-  auto load_row = [&](int R, float (&b)[NP]) {
-    const int n = (int)fast_div((unsigned)R, m_h), r = R - n * H;
-    const float* xn = x + (int64_t)n * C * H * 32;
-#pragma unroll
-    for (int p = 0; p < NP; p++) {
-      // k index 2p (lower half-wave) / 2p+1 (upper): (channel, tap row, tap column)
-      const int k0 = 2 * p, k1 = 2 * p + 1;
-      const int c0 = k0 / 9, i0 = (k0 % 9) / 3, j0 = k0 % 3;
-      const int c1 = k1 / 9, i1 = (k1 % 9) / 3, j1 = k1 % 3;
-      const int cc = half ? c1 : c0, ii = half ? i1 : i0, jj = half ? j1 : j0;
-      const int rr = r + ii - 1, col = l31 + jj - 1;
-      const bool ok = (half ? k1 < KK : k0 < KK) && (unsigned)rr < (unsigned)H && (unsigned)col < 32u;
-      b[p] = ok ? xn[((int64_t)cc * H + rr) * 32 + col] : 0.0f;
-    }
-  };
-  const int R0 = blockIdx.x * 4 + wave, RS = gridDim.x * 4;
-  float b[NP], bn[NP];
-  if (R0 < rows) load_row(R0, b);
   float st_s[16], st_1[16], st_2[16];          // shift, sum of (y - shift), sum of (y - shift)^2
   float st_n = 0.0f;
+  bool first = true;
 #pragma unroll
   for (int rr = 0; rr < 16; rr++) { st_s[rr] = 0.0f; st_1[rr] = 0.0f; st_2[rr] = 0.0f; }
-  for (int R = R0; R < rows; R += RS) {
-    const int n = (int)fast_div((unsigned)R, m_h), r = R - n * H;
-    if (R + RS < rows) load_row(R + RS, bn);
-    f32x16 acc;
+  STEM_STAMP(2);
+  while (item < items) {
+    const int n = item / bands, r0 = (item - n * bands) * rb;
+    const int nr = min(rb, H - r0);
+    const int next = item + gridDim.x;
+    if (next < items) tile_request(next, tv);
+    float b[NP], bn[NP];
+    if (wave < nr) {
 #pragma unroll
-    for (int rr = 0; rr < 16; rr++) acc[rr] = bv[rr];
-#pragma unroll
-    for (int p = 0; p < NP; p++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], b[p], acc, 0, 0, 0);
-    float* yo = y + ((int64_t)n * O * H + r) * 32 + l31;
-#pragma unroll
-    for (int rr = 0; rr < 16; rr++) {
-      const int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-      if (d < O) yo[(int64_t)d * H * 32] = acc[rr];
+      for (int p = 0; p < NP; p++) b[p] = Xl[koff[p] + wave * kStemPitch];
     }
-    if (partials) {
-      if (R == R0) {
+    for (int r = wave; r < nr; r += 8) {
+      if (r + 8 < nr) {
 #pragma unroll
-        for (int rr = 0; rr < 16; rr++) st_s[rr] = __shfl(acc[rr], half * 32, 64);
+        for (int p = 0; p < NP; p++) bn[p] = Xl[koff[p] + (r + 8) * kStemPitch];
       }
+      f32x16 acc;
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) acc[rr] = bv[rr];
+#pragma unroll
+      for (int p = 0; p < NP; p++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], b[p], acc, 0, 0, 0);
+      float* yo = y + ((int64_t)n * O * H + r0 + r) * 32 + l31;
 #pragma unroll
       for (int rr = 0; rr < 16; rr++) {
-        const float dl = acc[rr] - st_s[rr];
-        st_1[rr] += dl;
-        st_2[rr] = fmaf(dl, dl, st_2[rr]);
+        const int d = d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        if (d < O) yo[(int64_t)d * H * 32] = acc[rr];
       }
-      st_n += 32.0f;
-    }
-    if (R + RS < rows) {
+      if (partials) {
+        if (first) {
 #pragma unroll
-      for (int p = 0; p < NP; p++) b[p] = bn[p];
+          for (int rr = 0; rr < 16; rr++)
+            st_s[rr] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(acc[rr]), 0));   // lane 0 of the half
+          first = false;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) {
+          const float dl = acc[rr] - st_s[rr];
+          st_1[rr] += dl;
+          st_2[rr] = fmaf(dl, dl, st_2[rr]);
+        }
+        st_n += 32.0f;
+      }
+      if (r + 8 < nr) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) b[p] = bn[p];
+      }
+    }
+    item = next;
+    if (item < items) {
+      __syncthreads();                           // every wave has read its rows of the tile
+      tile_commit(item, tv);
+      __syncthreads();
     }
   }
+  STEM_STAMP(3); STEM_STAMP(4);
   if (partials) {
-    __shared__ float sst[4][32][3];
+    // 32 sums per lane -> one per lane: at each step a lane hands one half of what it holds to its partner
+    float v[32];
 #pragma unroll
-    for (int rr = 0; rr < 16; rr++) {
-      float a1 = st_1[rr], a2 = st_2[rr];
+    for (int rr = 0; rr < 16; rr++) { v[rr] = st_1[rr]; v[16 + rr] = st_2[rr]; }
+#define DF_STEM_HALVE(XM, CNT)                                                         \
+    {                                                                                  \
+      const bool up = (l31 & XM) != 0;                                                 \
+      _Pragma("unroll") for (int i = 0; i < CNT / 2; i++) {                            \
+        const float lo = v[i], hi = v[i + CNT / 2];                                    \
+        v[i] = (up ? hi : lo) + stem_swz<XM>(up ? lo : hi);                            \
+      }                                                                                \
+    }
+    DF_STEM_HALVE(16, 32) DF_STEM_HALVE(8, 16) DF_STEM_HALVE(4, 8) DF_STEM_HALVE(2, 4) DF_STEM_HALVE(1, 2)
+#undef DF_STEM_HALVE
+    sred[wave][half][l31] = v[0];                // lane l holds sum number l: (y - s) of register l, (y - s)^2 of l - 16
+    if (l31 == 0) {
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
-      if (l31 == 0) {
-        const int dl = (rr & 3) + 8 * (rr >> 2) + 4 * half;
-        const float mu_s = st_n > 0.0f ? a1 / st_n : 0.0f;       // mean of (y - shift)
-        sst[wave][dl][0] = st_n;
-        sst[wave][dl][1] = st_s[rr] + mu_s;
-        sst[wave][dl][2] = st_n > 0.0f ? a2 - a1 * mu_s : 0.0f;
-      }
+      for (int rr = 0; rr < 16; rr++) sshift[wave][half][rr] = st_s[rr];
+      if (half == 0) scount[wave] = st_n;
     }
     __syncthreads();
-    if (threadIdx.x < 32 && d0 + (int)threadIdx.x < O) {
-      float n = 0.0f, mu = 0.0f, m2 = 0.0f;
+    if (tid < 32 && d0 + tid < O) {
+      const int hh = (tid >> 2) & 1, rr = (tid & 3) + 4 * (tid >> 3);
+      // the waves' sums are moved to one shift (wave 0's: every shift is a sample of the channel, so their distances
+      // are of the size of its spread): sum (y - S) = a1 + n d, sum (y - S)^2 = a2 + 2 d a1 + n d^2 with d = s - S
+      const float S = sshift[0][hh][rr];                 // (wave 0 has a row whenever the workgroup has an item)
+      float n = 0.0f, A1 = 0.0f, A2 = 0.0f;
 #pragma unroll
-      for (int w4 = 0; w4 < 4; w4++) {
-        const float nb = sst[w4][threadIdx.x][0], mub = sst[w4][threadIdx.x][1], m2b = sst[w4][threadIdx.x][2];
-        if (nb > 0.0f) {
-          const float nn = n + nb, delta = mub - mu;
-          mu += delta * (nb / nn);
-          m2 += m2b + delta * delta * (n * nb / nn);
-          n = nn;
-        }
+      for (int w8 = 0; w8 < 8; w8++) {
+        const float nb = scount[w8];
+        const float a1 = sred[w8][hh][rr], a2 = sred[w8][hh][16 + rr];
+        const float d = nb > 0.0f ? sshift[w8][hh][rr] - S : 0.0f;
+        n += nb;
+        A1 += fmaf(nb, d, a1);
+        A2 += fmaf(d, fmaf(nb, d, 2.0f * a1), a2);
       }
-      float* o = partials + ((int64_t)blockIdx.x * O + d0 + threadIdx.x) * 3;
-      o[0] = n; o[1] = mu; o[2] = m2;
+      const float mu_s = n > 0.0f ? A1 / n : 0.0f;
+      float* o = partials + ((int64_t)blockIdx.x * O + d0 + tid) * 3;
+      o[0] = n; o[1] = S + mu_s; o[2] = n > 0.0f ? A2 - A1 * mu_s : 0.0f;
     }
   }
+  STEM_STAMP(5); STEM_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -3383,25 +3476,51 @@ int run_conv_rows3(const Geo& g, int dest_channels, float* final_dst, const floa
   static int enabled = getenv("DFHIP_STEM_ROWS") ? atoi(getenv("DFHIP_STEM_ROWS")) : 1;
   if (!enabled || g.mode != 0 || g.k != 3 || g.so != 1 || g.sd != 1 || g.u0 != -1) return -1;
   if (g.CS < 1 || g.CS > 4 || g.WS != 32 || g.WD != 32 || g.HS != g.HD) return -1;
-  // the kernel divides a row index < N * H by H with fast_div (magic = ceil(2^32 / H)): exact for every n < N * H
-  // only while n * (H - 1) < 2^32 when H is not a power of two
-  if ((g.HS & (g.HS - 1)) != 0 && (uint64_t)g.N * g.HS * g.HS >= ((uint64_t)1 << 32)) return -1;
-  const int rows = g.N * g.HS;
-  // two workgroups per CU, each wave walks rows / (8 CUs) rows: 15.3 us per launch at batch 256 against 17.4 with
-  // eight (one row per wave) -- fewer weight tiles staged, and the next row's loads run under the current row
-  dim3 grid((unsigned)std::min<int64_t>(df_ceil_div(rows, 4), (int64_t)num_cus() * 2),
-            (unsigned)df_ceil_div(dest_channels, 32));
-  const unsigned m_h = magic_u32((unsigned)g.HS);
-  float* part = (partials && rows_out && (int)grid.x <= cap_rows) ? partials : nullptr;
+  if ((int64_t)g.N * df_ceil_div(g.HS, 8) >= ((int64_t)1 << 31)) return -1;        // band index in an int
+  // a workgroup per band of rb rows of an image (the whole image when there are enough images to fill the chip);
+  // more bands than partial rows / twice the CUs: the workgroups walk them
+  static int rb_env = getenv("DFHIP_STEM_BAND") ? atoi(getenv("DFHIP_STEM_BAND")) : 0;
+  int rb = rb_env > 0 ? std::min(rb_env, 32) : 32;
+  if (rb_env <= 0) {
+    while (rb > 8 && (int64_t)g.N * df_ceil_div(g.HS, rb) < num_cus()) rb /= 2;
+  }
+  const int bands = df_ceil_div(g.HS, rb);
+  const int64_t items = (int64_t)g.N * bands;
+  const bool want_part = partials && rows_out && cap_rows > 0;
+  const int64_t cap = want_part ? std::min<int64_t>(cap_rows, (int64_t)num_cus() * 2) : (int64_t)num_cus() * 2;
+  dim3 grid((unsigned)std::min<int64_t>(items, cap), (unsigned)df_ceil_div(dest_channels, 32));
+  float* part = want_part ? partials : nullptr;
   if (rows_out) *rows_out = part ? (int)grid.x : 0;
 #define DF_STEM(CV)                                                                                   \
   case CV:                                                                                            \
-    DF_LAUNCH(k_conv_rows3<CV>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, final_dst, g.N, g.HS, \
-                       dest_channels, m_h, part);                                                     \
+    DF_LAUNCH(k_conv_rows3<CV>, grid, dim3(512), 0, stream(), g.src, g.wgt, bias, final_dst, g.N, g.HS, \
+                       dest_channels, rb, bands, part);                                               \
     break;
   switch (g.CS) { DF_STEM(1) DF_STEM(2) DF_STEM(3) DF_STEM(4) default: return -1; }
 #undef DF_STEM
   DF_LAUNCH_CHECK();
+#ifdef DFHIP_STEM_STAMPS
+  {
+    static int calls = 0;
+    if (++calls % 50 == 0) {
+      std::vector<unsigned long long> h((size_t)grid.x * 8 * 8);
+      (void)hipStreamSynchronize(stream());
+      (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stem_stamps), h.size() * sizeof(unsigned long long));
+      double seg[6] = {0}, cmax = 0;
+      unsigned long long r0 = ~0ull, r1 = 0;
+      const size_t nw = (size_t)grid.x * 8;
+      for (size_t b = 0; b < nw; b++) {
+        const unsigned long long* r = &h[b * 8];
+        for (int k = 1; k <= 5; k++) seg[k] += (double)(r[k] - r[k - 1]);
+        cmax = std::max(cmax, (double)(r[5] - r[0]));
+        r0 = std::min(r0, r[6]); r1 = std::max(r1, r[7]);
+      }
+      fprintf(stderr, "[stem-stamp] grid %u stats %d: span %.2f us; mean cycles per wave: tile + weights %.0f, operand setup %.0f, "
+              "rows %.0f, - %.0f, stats tail %.0f; slowest wave %.0f\n", grid.x, part != nullptr,
+              (double)(r1 - r0) / 100.0, seg[1] / nw, seg[2] / nw, seg[3] / nw, seg[4] / nw, seg[5] / nw, cmax);
+    }
+  }
+#endif
   return DFHIP_OK;
 }
 

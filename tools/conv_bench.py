@@ -49,6 +49,10 @@ def main():
                "wgrad": lambda: mod.conv2d_wgrad(x, y, dw, *geo),
                "dgrad_ow": lambda: mod.conv2d_dgrad(y, w, dx, *geo, mode="overwrite"),
                "dgrad_acc": lambda: mod.conv2d_dgrad(y, w, dx, *geo, mode="accumulate")}
+        if k == 3 and s == 1:
+            part_s = mod.Array(512 * O * 3)
+            if mod.conv2d_forward_stats(x, w, None, y, *geo, part_s, 512) > 0:
+                ops["fwd_stats"] = lambda: mod.conv2d_forward_stats(x, w, None, y, *geo, part_s, 512)
         if k == 3 and s == 1 and C == O and hasattr(mod, "conv2d_forward_bn_input"):
             # the same convolution with the BatchNorm of its input applied on load (partials from a producer run)
             part_in, part_out = mod.Array(512 * C * 3), mod.Array(512 * O * 3)
@@ -75,7 +79,7 @@ def main():
             mod.event_record(e1)
             us = mod.event_elapsed_ms(e0, e1) * 1e3 / args.iters
             print(f"{name:6s} {op:10s} {us:9.1f} {flops / us / 1e6:9.2f} {flops / 1e9:8.3f}")
-            if op in ("fwd_bn_in", "dgrad_pair"):
+            if op in ("fwd_bn_in", "dgrad_pair", "fwd_stats"):
                 continue
             if not (name == "stem" and op.startswith("dgrad")):
                 total[op] = total.get(op, 0.0) + us * COUNT[name]
