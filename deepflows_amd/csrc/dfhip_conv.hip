@@ -2080,6 +2080,235 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
 }
 
 // ---------------------------------------------------------------------------------------
+// weight gradient of the few-channel 3x3 / stride 1 / pad 1 stem on 32-wide images (K = C * 9 <= 32, O <= 32):
+// one 32 x 32 accumulator tile (output channel x (channel, tap)) per wave, the reduction index is the pixel.
+// A lane of the A operand is an OUTPUT CHANNEL: it loads four consecutive pixels of its own channel plane of dY
+// with one 16-byte load (the two half-waves take the two halves of an 8-pixel step), so dY never passes through
+// LDS and -- STEM -- the channel's constants of the BatchNorm / ReLU / MaxPool backward are six registers of the
+// lane; the image (12 KB with its zero padding, the tile of the forward kernel) is the only thing staged, and a
+// (channel, tap) lane of the B operand reads its pixel from it.  A workgroup walks whole images, a wave every
+// eighth step of an image with the loads of four steps in flight.  The generic kernel staged 256 pixels of dY per
+// group and barrier, sixteen MFMAs per wave between two global round trips: 27.6 us per launch.
+// ---------------------------------------------------------------------------------------
+template <bool STEM>
+__global__ __launch_bounds__(512) void k_wgrad_stem3(WGeo g) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int CH = kStemRows * kStemPitch;
+  constexpr int CMAX = 3, NQ = CMAX * kStemRows * 8, QR = (NQ + 511) / 512;
+  constexpr int DEPTH = 2;
+  constexpr int ZP = 68, YP = 20;                    // LDS pitches of a channel's 64 pixels / 16 pooled pixels (bank spread)
+  constexpr int WSLOT = 32 * ZP + 2 * 32 * YP;       // a wave's private transposition area (floats)
+  extern __shared__ __attribute__((aligned(16))) float smem_w3[];
+  float* Xl = smem_w3;                               // [CMAX][CH]
+  float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(smem_w3 + CMAX * CH);   // [8][16][64]: over the waves' areas
+  static_assert(8 * WSLOT >= 8 * 16 * 64, "the reduction fits the transposition areas");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Zs = smem_w3 + CMAX * CH + wave * WSLOT;
+  float* Ys = Zs + 32 * ZP;
+  float* Gs = Ys + 32 * YP;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int C = g.C, H = g.H, O = g.O, KK = C * 9;
+  const int nq = C * kStemRows * 8;
+  STEM_STAMP(6); STEM_STAMP(0);
+  const int o = min(l31, O - 1);                     // (a lane past the last channel repeats it: its rows are not stored)
+  float mean = 0.f, rsd = 1.f, gw = 1.f, gb = 0.f, k1 = 0.f, k2 = 0.f;
+  // STEM: the slices' sums of the statistics pass and the channel's constants are REQUESTED here and combined after
+  // the first tile is in place (one request per iteration was a round trip per slice, 32 slices; two batches in
+  // front of everything else still cost 7.5 us before the first load of the image left)
+  constexpr int SMAX = 32;
+  f32x4 prv = {0.f, 0.f, 0.f, 0.f};                  // 16 bytes of the [O][S][2] sums per thread, coalesced; transposed via LDS
+  const int npr4 = (O * g.st.S * 2) >> 2;            // (S is even or O * S * 2 a multiple of 4: see the launcher)
+  float c_mean = 0.f, c_var = 1.f, c_gamma = 1.f, c_beta = 0.f;
+  if constexpr (STEM) {
+    prv = *reinterpret_cast<const f32x4*>(g.st.partial + 4 * min(tid, npr4 - 1));
+    c_mean = g.st.mean[o];
+    c_var = g.st.var[o];
+    if (g.st.gamma) c_gamma = g.st.gamma[o];
+    if (g.st.beta) c_beta = g.st.beta[o];
+  }
+  // the (channel, tap) of this lane's column of the tile; a lane past K reads tap 0 (its columns are not stored)
+  const int ke = l31 < KK ? l31 : 0;
+  const int koff = (ke / 9) * CH + ((ke % 9) / 3 + half) * kStemPitch + (ke % 3) + 3;
+  if (tid < CMAX * kStemRows * 2) {                  // the columns either side of the image
+    const int t = tid >> 1;
+    Xl[(t / kStemRows) * CH + (t % kStemRows) * kStemPitch + ((tid & 1) ? 36 : 3)] = 0.0f;
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int rr = 0; rr < 16; rr++) acc[rr] = 0.0f;
+  STEM_STAMP(1);
+  // a step is a PAIR of image rows (one per half-wave): a lane takes the whole 128-byte row of its channel plane at
+  // once, and both rows of a pair share one row of the pooled planes.  (With 16 bytes per lane and step every line
+  // was touched eight times from four waves and came from L2 most of those times: 10.5 / 26.5 us.)
+  const int steps = H >> 1;                          // a wave takes steps wave, wave + 8, ...
+  const int nsw = (steps - wave + 7) >> 3;
+  for (int n = blockIdx.x; n < g.N; n += gridDim.x) {
+    // a step's dY rows (32 channels x 64 pixels) and pooled rows (32 x 16) are requested COALESCED -- a wave load covers
+    // whole lines: four channels x 256 bytes -- and turned into the lane-per-channel order through the wave's own LDS
+    // area when the step is consumed.  (A lane loading its own channel's line 16 bytes at a time made every line eight
+    // requests at the address unit: 12 000 line requests per CU and 11.5 us before the first MFMA.)
+    const float* zn = g.dy + (int64_t)n * O * H * 32 + (lane & 15) * 4;
+    const float* yn = nullptr;
+    const float* gn = nullptr;
+    if constexpr (STEM) {
+      yn = g.st.y + (int64_t)n * O * (H >> 1) * 16 + (lane & 3) * 4;
+      gn = g.st.g + (int64_t)n * O * (H >> 1) * 16 + (lane & 3) * 4;
+    }
+    f32x4 rz[DEPTH][8];
+    f32x4 ry[STEM ? DEPTH : 1][2], rg[STEM ? DEPTH : 1][2];
+    auto request = [&](int k, int slot) {
+      const int sidx = min(wave + 8 * k, steps - 1);
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        rz[slot][q] = *reinterpret_cast<const f32x4*>(zn + (int64_t)min(4 * q + (lane >> 4), O - 1) * H * 32 + sidx * 64);
+      if constexpr (STEM) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int64_t at = (int64_t)min(16 * q + (lane >> 2), O - 1) * (H >> 1) * 16 + sidx * 16;
+#ifdef DFHIP_STEM3_NOYG
+          ry[slot][q] = (f32x4){1.f, 1.f, 1.f, 1.f}; rg[slot][q] = (f32x4){(float)at, 1.f, 1.f, 1.f};
+#else
+          ry[slot][q] = *reinterpret_cast<const f32x4*>(yn + at);
+          rg[slot][q] = *reinterpret_cast<const f32x4*>(gn + at);
+#endif
+        }
+      }
+    };
+    // the image tile: requests, then the first steps' operands, then the commit
+    f32x4 tv[QR];
+    {
+      const float* xn = g.x + (int64_t)n * C * H * 32;
+#pragma unroll
+      for (int q0 = 0; q0 < QR; q0++) {
+        const int q = min(tid + 512 * q0, nq - 1);
+        const int pc = q & 7, t = q >> 3, lr = t % kStemRows, c = t / kStemRows;
+        const int row = min(max(lr - 1, 0), H - 1);
+        tv[q0] = *reinterpret_cast<const f32x4*>(xn + ((int64_t)c * H + row) * 32 + pc * 4);
+      }
+    }
+    // every wave is done with the previous image's tile -- and has ISSUED its tile requests: they sit in front of
+    // all the step requests at the address unit (a tile request queued behind seven other waves' steps arrived with
+    // the last of the data, and the barrier below held the first MFMA until then); likewise the first steps of all
+    // waves go in front of the second ones
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DEPTH; k++) {
+      request(k, k);
+      if (k + 1 < DEPTH) __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int q0 = 0; q0 < QR; q0++) {
+      const int q = tid + 512 * q0;
+      const int pc = q & 7, t = q >> 3, lr = t % kStemRows, c = t / kStemRows;
+      const bool in = lr >= 1 && lr <= H;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      if (q < nq) *reinterpret_cast<f32x4*>(&Xl[c * CH + lr * kStemPitch + 4 + pc * 4]) = in ? tv[q0] : zero;
+    }
+    if constexpr (STEM) {
+      if (n == (int)blockIdx.x && tid < npr4) {
+        // float 4 tid + e of [O][S][2] -> row (4 tid + e) / (2 S) at pitch 2 S + 2 (bank spread of the reads below)
+        float* pl = smem_w3 + CMAX * CH + 8 * WSLOT;       // [O][2 S + 2], its own area
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int f = 4 * tid + e, row = f / (2 * g.st.S);
+          pl[f + 2 * row] = prv[e];
+        }
+      }
+    }
+    __syncthreads();
+    if constexpr (STEM) {
+      if (n == (int)blockIdx.x) {
+        const float* pl = smem_w3 + CMAX * CH + 8 * WSLOT + o * (2 * g.st.S + 2);
+        float sdy = 0.0f, sdyx = 0.0f;
+#pragma unroll
+        for (int u = 0; u < SMAX; u++)
+          if (u < g.st.S) { sdy += pl[2 * u]; sdyx += pl[2 * u + 1]; }
+        if (blockIdx.x == 0 && tid < O) {
+          if (g.st.dgamma) g.st.dgamma[tid] = sdyx;
+          if (g.st.dbeta) g.st.dbeta[tid] = sdy;
+        }
+        const float m = (float)g.N * (float)H * 32.0f;
+        mean = c_mean;
+        rsd = 1.0f / sqrtf(c_var + g.st.eps);
+        gw = c_gamma;
+        gb = c_beta;
+        k1 = sdy / m;
+        k2 = sdyx / m;
+      }
+    }
+    STEM_STAMP(2);
+    for (int kb = 0; kb < nsw; kb += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; u++) {
+        const int k = kb + u;
+        if (k < nsw) {
+          const int sidx = wave + 8 * k;
+          const float* xr = Xl + koff + (2 * sidx) * kStemPitch;
+          // through the wave's area: channel (4 q + lane / 16) x 4 pixels in, this lane's channel row out
+          f32x4 zv[8], yv[STEM ? 4 : 1], gv[STEM ? 4 : 1];
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            *reinterpret_cast<f32x4*>(Zs + (4 * q + (lane >> 4)) * ZP + (lane & 15) * 4) = rz[u][q];
+          if constexpr (STEM) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+              *reinterpret_cast<f32x4*>(Ys + (16 * q + (lane >> 2)) * YP + (lane & 3) * 4) = ry[u][q];
+              *reinterpret_cast<f32x4*>(Gs + (16 * q + (lane >> 2)) * YP + (lane & 3) * 4) = rg[u][q];
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int q = 0; q < 8; q++) zv[q] = *reinterpret_cast<const f32x4*>(Zs + l31 * ZP + half * 32 + 4 * q);
+          if constexpr (STEM) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              yv[q] = *reinterpret_cast<const f32x4*>(Ys + l31 * YP + 4 * q);
+              gv[q] = *reinterpret_cast<const f32x4*>(Gs + l31 * YP + 4 * q);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int e = 0; e < 32; e++) {
+            float t = zv[e >> 2][e & 3];
+            if constexpr (STEM) {
+              const float z_ = t;
+              const float dy_ = stem_dy(z_, yv[e >> 3][(e >> 1) & 3], gv[e >> 3][(e >> 1) & 3], mean, rsd, gw, gb);
+              const float xh_ = (z_ - mean) * rsd;
+              t = (dy_ - k1 - xh_ * k2) * gw * rsd;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t, xr[e], acc, 0, 0, 0);
+          }
+        }
+        request(k + DEPTH, u);                     // (no load under a condition: past the end the last step again)
+      }
+    }
+  }
+  STEM_STAMP(3);
+  // the eight waves' tiles through LDS (over the transposition areas: every wave is done with its own); slab
+  // [blockIdx.x][O][K]
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 16; rr++) red[wave][rr][lane] = acc[rr];
+  __syncthreads();
+  float* out = g.dst + (int64_t)blockIdx.x * O * KK;
+#pragma unroll
+  for (int h2 = 0; h2 < 2; h2++) {
+    const int idx = tid + 512 * h2, rr = idx >> 6, ln = idx & 63;
+    float v = 0.0f;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; w8++) v += red[w8][rr][ln];
+    const int oo = (rr & 3) + 8 * (rr >> 2) + 4 * (ln >> 5), kk = ln & 31;
+    if (oo < O && kk < KK) out[(int64_t)oo * KK + kk] = v;
+  }
+  STEM_STAMP(4); STEM_STAMP(5); STEM_STAMP(7);
+}
+
+// ---------------------------------------------------------------------------------------
 // weight gradient, tap-major kernel (3x3 and 1x1 layers with >= 16 input channels).
 //
 // dW[o][c][i][j] = sum over (n, r, s) of dY[n][o][r][s] * X[n][c][r*stride+i-pad][s*stride+j-pad].
@@ -3672,8 +3901,63 @@ int launch_wgrad_v3(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
   return DFHIP_OK;
 }
 
+// the few-channel stem on 32-wide images (k_wgrad_stem3); -1 when the shape is not one it takes
+int run_wgrad_stem3(WGeo g, float* dw, bool stem) {
+  static int enabled = getenv("DFHIP_WGRAD_STEM3") ? atoi(getenv("DFHIP_WGRAD_STEM3")) : 1;
+  if (!enabled || g.k != 3 || g.stride != 1 || g.pad != 1 || g.W != 32 || g.ow != 32 || g.oh != g.H) return -1;
+  if (g.C < 1 || g.C > 3 || g.O < 1 || g.O > 32 || g.H > 32 || (g.H & 1)) return -1;
+  if (stem && (g.st.S < 1 || g.st.S > 32 || (g.O * g.st.S) % 2 != 0 || g.O * g.st.S * 2 > 4 * 512)) return -1;
+  const int64_t n = (int64_t)g.O * g.C * 9;
+  const int gx = (int)std::min<int64_t>(g.N, num_cus());
+  float* slabs = dw;
+  if (gx > 1) {
+    slabs = workspace((size_t)n * gx * sizeof(float));
+    if (!slabs) return DFHIP_OUT_OF_MEMORY;
+  }
+  g.dst = slabs;
+  const size_t lds = (size_t)(3 * kStemRows * kStemPitch + 8 * (32 * 68 + 2 * 32 * 20) + 32 * 66) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    DF_HIP(hipFuncSetAttribute((const void*)k_wgrad_stem3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DF_HIP(hipFuncSetAttribute((const void*)k_wgrad_stem3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  if (stem) DF_LAUNCH(k_wgrad_stem3<true>, dim3((unsigned)gx), dim3(512), lds, stream(), g);
+  else DF_LAUNCH(k_wgrad_stem3<false>, dim3((unsigned)gx), dim3(512), lds, stream(), g);
+  DF_LAUNCH_CHECK();
+#ifdef DFHIP_STEM_STAMPS
+  {
+    static int calls = 0;
+    if (++calls % 10 == 0) {
+      std::vector<unsigned long long> h((size_t)gx * 8 * 8);
+      (void)hipStreamSynchronize(stream());
+      (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stem_stamps), h.size() * sizeof(unsigned long long));
+      double seg[6] = {0};
+      unsigned long long r0 = ~0ull, r1 = 0;
+      const size_t nw = (size_t)gx * 8;
+      for (size_t b = 0; b < nw; b++) {
+        const unsigned long long* r = &h[b * 8];
+        for (int k = 1; k <= 4; k++) seg[k] += (double)(r[k] - r[k - 1]);
+        r0 = std::min(r0, r[6]); r1 = std::max(r1, r[7]);
+      }
+      fprintf(stderr, "[stem3-stamp] grid %d stem %d: span %.2f us; mean cycles per wave: constants %.0f, tile %.0f, steps %.0f, "
+              "reduce %.0f\n", gx, (int)stem, (double)(r1 - r0) / 100.0, seg[1] / nw, seg[2] / nw, seg[3] / nw, seg[4] / nw);
+    }
+  }
+#endif
+  if (gx > 1) {
+    DF_LAUNCH(k_flat_slab_sum, dim3((unsigned)df_ceil_div(n, 256)), dim3(1024), 0, stream(), slabs, dw, n, gx);
+    DF_LAUNCH_CHECK();
+  }
+  return DFHIP_OK;
+}
+
 // returns -1 when the shape is not eligible for the main weight-gradient kernel
 int run_wgrad_v3(WGeo g, float* dw, bool stem = false) {
+  {
+    const int st3 = run_wgrad_stem3(g, dw, stem);
+    if (st3 >= 0) return st3;
+  }
   const int k2 = g.k * g.k;
   const int KW = g.C * k2;
   if (g.ow & 1) return -1;
