@@ -59,7 +59,7 @@ constexpr int kBlk2 = 260;   // LDS pitch (floats) of a block of four operands x
 // KS: waves that share a tile and split every chunk's channel groups between them (1 or 2; their accumulators are
 // summed through LDS at the end): two waves per SIMD where the problem has only 1 024 tile x channel-tile units, and
 // each wave requests only its own groups' pixels.
-template <int C, int OWW, int TS, int OWG, int CG, int XA, int KS>
+template <int C, int OWW, int TS, int OWG, int CG, int XA, int KS, bool LSH>
 __global__ __launch_bounds__(64 * TS * OWG * KS) void k_conv3x3s2_pair(const float* __restrict__ x,
                                                                  const float* __restrict__ w,
                                                                  const float* __restrict__ wd,
@@ -162,7 +162,11 @@ __global__ __launch_bounds__(64 * TS * OWG * KS) void k_conv3x3s2_pair(const flo
       _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) {                                                  \
         const f32x2 t2_ = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)xo2[i_], p_ * (16 * HW), 0)); \
         raw[q_][i_ * 3 + 1] = t2_[0]; raw[q_][i_ * 3 + 2] = t2_[1];                                       \
-        raw[q_][i_ * 3] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)xo0[i_], p_ * (16 * HW), 0)); \
+        if constexpr (LSH) {                                  /* pixel 2s - 1 is the neighbouring lane's 2(s-1) + 1 */ \
+          raw[q_][i_ * 3] = 0.0f;                                                                            \
+        } else {                                                                                            \
+          raw[q_][i_ * 3] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)xo0[i_], p_ * (16 * HW), 0)); \
+        }                                                                                                   \
       }                                                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                                  \
     }                                                                                                     \
@@ -236,6 +240,15 @@ __global__ __launch_bounds__(64 * TS * OWG * KS) void k_conv3x3s2_pair(const flo
 #pragma unroll
           for (int q = 0; q < WBLK; q++)
             a4[(ch + 1) & 1][a][q] = Wl4[a * (NBLK * kBlk2 / 4) + ((ch + 1) * CBLK + q) * (kBlk2 / 4)];
+      }
+      if constexpr (LSH) {
+        // tap column 0 = the left neighbour's column 2 (one DPP move + one select per source row; the address unit
+        // was the busier side: six wave loads per channel group against twenty MFMAs)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const float sh = dpp_mov2<0x111>(raw[p][i * 3 + 2]);    // row_shr:1, zero into lane 0 of the 16
+          raw[p][i * 3] = s > 0 ? sh : 0.0f;
+        }
       }
 #pragma unroll
       for (int t = 0; t < 9; t++) {
@@ -329,17 +342,17 @@ __global__ __launch_bounds__(64 * TS * OWG * KS) void k_conv3x3s2_pair(const flo
   S2_STAMP(7);
 }
 
-template <int C, int OWW, int TS, int OWG, int CG, int XA, int KS = 1>
-int launch_s2(const float* x, const float* w, const float* wd, float* y, float* yd, float* partials, float* partials_d,
+template <int C, int OWW, int TS, int OWG, int CG, int XA, int KS = 1, bool LSH = false>
+int launch_s2_(const float* x, const float* w, const float* wd, float* y, float* yd, float* partials, float* partials_d,
               int lwo, int O, dim3 grid) {
   const size_t lds = (size_t)(OWG * OWW) * (C / 4 * 10 / 4) * kBlk2 * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA, KS>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA, KS, LSH>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536)));
     attr = true;
   }
-  DF_LAUNCH((k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA, KS>), grid, dim3(64 * TS * OWG * KS), lds, stream(), x, w, wd, y, yd, partials,
+  DF_LAUNCH((k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA, KS, LSH>), grid, dim3(64 * TS * OWG * KS), lds, stream(), x, w, wd, y, yd, partials,
             partials_d, lwo, O);
   DF_LAUNCH_CHECK();
 #ifdef DFHIP_S2_STAMPS
@@ -367,6 +380,14 @@ int launch_s2(const float* x, const float* w, const float* wd, float* y, float* 
   }
 #endif
   return DFHIP_OK;
+}
+
+template <int C, int OWW, int TS, int OWG, int CG, int XA, int KS = 1>
+int launch_s2(const float* x, const float* w, const float* wd, float* y, float* yd, float* partials, float* partials_d,
+              int lwo, int O, dim3 grid) {
+  static int lsh = getenv("DFHIP_S2_LSH") ? atoi(getenv("DFHIP_S2_LSH")) : 1;
+  if (lsh) return launch_s2_<C, OWW, TS, OWG, CG, XA, KS, true>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  return launch_s2_<C, OWW, TS, OWG, CG, XA, KS, false>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
 }
 
 }  // namespace
