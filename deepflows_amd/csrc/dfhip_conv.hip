@@ -1219,7 +1219,8 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__
 // GEO 0: 3x3 / stride 1 / pad 1, dY is 4 x 4 (nine sources).  GEO 1: 3x3 / stride 2 / pad 1, dY is 2 x 2: pixel (y, x)
 // keeps tap (1 + (y & 1), 1 + (x & 1)) of source (y >> 1, x >> 1) (four sources); PAIR (GEO 1): the block's 1x1 /
 // stride 2 shortcut adds sum_o dY2[o][y/2][x/2] W2[o][c] on the pixels with even (y, x) -- a fifth slice.
-template <int O, int GEO, bool PAIR>
+constexpr int kImg4Strip = 16 * 260;     // floats of a wave's transposition strip (16 images x (256 + 4))
+template <int O, int GEO, bool PAIR, bool TR>
 __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__ dy, const float* __restrict__ w,
                                                        const float* __restrict__ add, float* __restrict__ dx, int C,
                                                        const float* __restrict__ dy2, const float* __restrict__ w2) {
@@ -1235,9 +1236,73 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
   const int kk = lane >> 4, n = lane & 15;
   const int n0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
   const int ob = wave * OQ;
-  // dY operands of this wave's o range: the sources of image n0 + n, channel ob + 4 p + kk
+  // dY operands of this wave's o range: the sources of image n0 + n, channel ob + 4 p + kk.  A lane is an IMAGE, so
+  // read directly every lane of a request is a line of its own and the address unit takes them one per cycle (24-48
+  // requests x 64 lines per wave); instead the wave requests its (16 images x channels) block in the order it lies in
+  // memory -- a request = 1 KB = 8 lines -- and turns it through a wave-private LDS strip (`TR`).
   float sv[NK][NS], sv2[PAIR ? NK : 1][4];
-  {
+  if constexpr (TR) {
+    constexpr int WLF = (NSL * O * 16 > 3 * 16 * 64 * 4) ? NSL * O * 16 : 3 * 16 * 64 * 4;
+    float* strip = smem + WLF + wave * kImg4Strip;
+    if constexpr (GEO == 0) {
+      // chunks of 16 channels: per image 16 x 64 bytes in a row; strip row = an image (256 floats + 4: bank spread)
+      constexpr int NCH = OQ / 16;
+      static_assert(OQ % 16 == 0, "whole chunks");
+      f32x4 t[2][16];
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        t[0][i] = *reinterpret_cast<const f32x4*>(dy + ((int64_t)(n0 + i) * O + ob) * 16 + lane * 4);
+#pragma unroll
+      for (int ch = 0; ch < NCH; ch++) {
+        if (ch + 1 < NCH) {
+#pragma unroll
+          for (int i = 0; i < 16; i++)
+            t[(ch + 1) & 1][i] = *reinterpret_cast<const f32x4*>(dy + ((int64_t)(n0 + i) * O + ob + 16 * (ch + 1)) * 16 + lane * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) *reinterpret_cast<f32x4*>(strip + i * 260 + lane * 4) = t[ch & 1][i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int pp = 0; pp < 4; pp++)
+#pragma unroll
+          for (int u = 0; u < 3; u++) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(strip + n * 260 + (4 * pp + kk) * 16 + u * 4);
+            sv[4 * ch + pp][u * 3] = r[0]; sv[4 * ch + pp][u * 3 + 1] = r[1]; sv[4 * ch + pp][u * 3 + 2] = r[2];
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    } else {
+      // the 2 x 2 planes: per image OQ x 16 bytes in a row; 64 / OQ images per request; strip row = an image (OQ + 1 float4)
+      constexpr int IPL = 64 / OQ >= 1 ? 64 / OQ : 1, NL = 16 / IPL;
+      static_assert(OQ <= 64 && 64 % OQ == 0, "an image's row fits a request");
+      const int li = lane / OQ, lo = lane % OQ;
+      auto turn = [&](const float* src, float (&dst)[NK][4]) {
+        f32x4 t[NL];
+#pragma unroll
+        for (int i = 0; i < NL; i++)
+          t[i] = *reinterpret_cast<const f32x4*>(src + ((int64_t)(n0 + i * IPL + li) * O + ob + lo) * 4);
+#pragma unroll
+        for (int i = 0; i < NL; i++) *reinterpret_cast<f32x4*>(strip + ((i * IPL + li) * (OQ + 1) + lo) * 4) = t[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int p = 0; p < NK; p++) {
+          const f32x4 r = *reinterpret_cast<const f32x4*>(strip + (n * (OQ + 1) + 4 * p + kk) * 4);
+          dst[p][0] = r[0]; dst[p][1] = r[1]; dst[p][2] = r[2]; dst[p][3] = r[3];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      };
+      turn(dy, sv);
+      if constexpr (PAIR) turn(dy2, sv2);
+    }
+  } else {
     const float* sp = dy + ((int64_t)(n0 + n) * O + ob + kk) * SP;
 #pragma unroll
     for (int p = 0; p < NK; p++) {
@@ -1335,6 +1400,27 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
         *reinterpret_cast<f32x4*>(dx + obase + 16 * v + 4 * y) = r;
       }
   }
+}
+
+template <int O, int GEO, bool PAIR>
+int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* dx, int N, int C, const float* dy2,
+                      const float* w2) {
+  static int tr = getenv("DFHIP_IMG4_TR") ? atoi(getenv("DFHIP_IMG4_TR")) : 1;
+  dim3 grid((unsigned)(N / 16), (unsigned)(C / 16));
+  const size_t base = std::max((size_t)(PAIR ? 5 : 4) * O * 16, (size_t)3 * 16 * 64 * 4) * sizeof(float);
+  const size_t lds = base + (tr ? (size_t)4 * kImg4Strip * sizeof(float) : 0);
+  static bool attr = false;
+  if (!attr) {
+    DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)std::max(base + (size_t)4 * kImg4Strip * sizeof(float), (size_t)65536)));
+    DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)std::max(base, (size_t)65536)));
+    attr = true;
+  }
+  if (tr) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2);
+  else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, false>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -4745,24 +4831,11 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
     if (lean && img4 && mode == 0 && (geo == 0 || geo == 1) && H == 4 && W == 4 && N % 16 == 0 && C % 16 == 0 &&
         ((geo == 0 && (O == 64 || O == 128)) || (geo == 1 && (O == 128 || O == 256)))) {
       // 4 x 4 images: 16 images x 16 channels x 16 pixels per workgroup, no masked lanes (k_dgrad_ow_img4)
-      dim3 grid((unsigned)(N / 16), (unsigned)(C / 16));
-      const size_t lds = std::max((size_t)4 * O * 16, (size_t)3 * 16 * 64 * 4) * sizeof(float);
-#define DF_I4(OV, GV)                                                                                      \
-  do {                                                                                                     \
-    static bool attr = false;                                                                              \
-    if (!attr) {                                                                                           \
-      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<OV, GV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                 (int)std::max(lds, (size_t)65536)));                                      \
-      attr = true;                                                                                         \
-    }                                                                                                      \
-    DF_LAUNCH((k_dgrad_ow_img4<OV, GV, false>), grid, dim3(256), lds, stream(), dy, w, add, dx, C,         \
-              (const float*)nullptr, (const float*)nullptr);                                               \
-  } while (0)
-      if (geo == 0) { if (O == 64) DF_I4(64, 0); else DF_I4(128, 0); }
-      else { if (O == 128) DF_I4(128, 1); else DF_I4(256, 1); }
-#undef DF_I4
-      DF_LAUNCH_CHECK();
-      return DFHIP_OK;
+      const float* none = nullptr;
+      if (geo == 0) return O == 64 ? launch_dgrad_img4<64, 0, false>(dy, w, add, dx, N, C, none, none)
+                                   : launch_dgrad_img4<128, 0, false>(dy, w, add, dx, N, C, none, none);
+      return O == 128 ? launch_dgrad_img4<128, 1, false>(dy, w, add, dx, N, C, none, none)
+                      : launch_dgrad_img4<256, 1, false>(dy, w, add, dx, N, C, none, none);
     }
     if (lean_ok && (O == 128 || O == 256)) {
       // about two workgroups per CU (one at 256 channels: 140 KB of LDS); each walks tiles / grid.x tiles
@@ -4847,26 +4920,9 @@ int dfhip_conv2d_dgrad_pair(const float* dy, const float* w, const float* dy2, c
     double flops4 = 2.0 * N * H * W * (double)C * O + 2.0 * N * 4 * (double)C * O;
     double bytes4 = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * 4);
     ProfScope prof4("conv2d_dgrad_overwrite_igemm", flops4, bytes4);
-    dim3 grid((unsigned)(N / 16), (unsigned)(C / 16));
-    const size_t lds = std::max((size_t)5 * O * 16, (size_t)3 * 16 * 64 * 4) * sizeof(float);
-    if (O == 128) {
-      static bool attr = false;
-      if (!attr) {
-        DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)std::max(lds, (size_t)65536)));
-        attr = true;
-      }
-      DF_LAUNCH((k_dgrad_ow_img4<128, 1, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2);
-    } else {
-      static bool attr = false;
-      if (!attr) {
-        DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<256, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)std::max(lds, (size_t)65536)));
-        attr = true;
-      }
-      DF_LAUNCH((k_dgrad_ow_img4<256, 1, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2);
-    }
-    DF_LAUNCH_CHECK();
+    const int st4 = O == 128 ? launch_dgrad_img4<128, 1, true>(dy, w, add, dx, N, C, dy2, w2)
+                             : launch_dgrad_img4<256, 1, true>(dy, w, add, dx, N, C, dy2, w2);
+    if (st4 != DFHIP_OK) return st4;
     *done = 1;
     return DFHIP_OK;
   }
