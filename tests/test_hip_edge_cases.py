@@ -216,6 +216,55 @@ def test_few_channel_stem_kernel(hip_device, C, H, O, N, with_bias):
     assert_close(got, want, 1e-4, f"stem kernel C={C} H={H} O={O}")
 
 
+@pytest.mark.parametrize("C,H,O,N", [(3, 32, 32, 40), (2, 40, 16, 9), (3, 64, 8, 300), (1, 6, 5, 2), (3, 32, 20, 530)])
+def test_stem_kernel_partials_bands_and_walking_workgroups(hip_device, C, H, O, N):
+    """k_conv_rows3 with its BatchNorm partials: images higher than one band (H > 32: two bands with a shared halo row),
+    more bands than workgroups (a workgroup re-stages its tile and keeps its shifted sums across items), a band of
+    fewer rows than waves, ragged channel tiles; the partial rows combined with Chan's formula against the output's
+    mean / biased variance, with a channel mean far from zero (bias 3.0: the shifted sums must not cancel)."""
+    from conftest import assert_close
+    from oracle import ref_ops as R
+    mod = hip_device.mod
+    rng = np.random.default_rng(7 * C + H + N)
+    x = rng.standard_normal((N, C, H, 32)).astype(np.float32)
+    w = (rng.standard_normal((O, C, 3, 3)) * 0.3).astype(np.float32)
+    b = np.full(O, 3.0, np.float32)
+    yh, ph = mod.Array(N * O * H * 32), mod.Array(512 * O * 3)
+    rows = mod.conv2d_forward_stats(_arr(mod, x), _arr(mod, w), _arr(mod, b), yh, N, C, H, 32, O, 3, 1, 1, ph, 512)
+    y_ref = R.conv2d_forward(x, w, b.reshape(1, O, 1, 1), 1, 1)
+    assert_close(_back(mod, yh).reshape(y_ref.shape), y_ref, 1e-4, "stem forward")
+    assert 0 < rows <= 512
+    part = _back(mod, ph).reshape(512, O, 3)[:rows].astype(np.float64)
+    cnt, mu, m2 = np.zeros(O), np.zeros(O), np.zeros(O)
+    for r in range(rows):
+        nb, mb, qb = part[r, :, 0], part[r, :, 1], part[r, :, 2]
+        tot = cnt + nb
+        d = mb - mu
+        mu = mu + d * nb / np.maximum(tot, 1)
+        m2 = m2 + qb + d * d * cnt * nb / np.maximum(tot, 1)
+        cnt = tot
+    assert np.all(cnt == N * H * 32)
+    y64 = y_ref.astype(np.float64)
+    assert_close(mu, y64.mean(axis=(0, 2, 3)), 1e-5, "partials mean")
+    assert_close(m2 / cnt, y64.var(axis=(0, 2, 3)), 2e-5, "partials variance")
+
+
+@pytest.mark.parametrize("C,H,O,N", [(3, 32, 32, 16), (1, 8, 5, 3), (2, 2, 32, 300), (3, 30, 17, 7)])
+def test_stem_weight_gradient_kernel(hip_device, C, H, O, N):
+    """k_wgrad_stem3 stand-alone (dY given): fewer images than CUs, more images than workgroups (a workgroup walks
+    several), fewer row pairs than waves, ragged output channels and (channel, tap) columns."""
+    from conftest import assert_close
+    from oracle import ref_ops as R
+    mod = hip_device.mod
+    rng = np.random.default_rng(31 + C + H)
+    x = rng.standard_normal((N, C, H, 32)).astype(np.float32)
+    dy = rng.standard_normal((N, O, H, 32)).astype(np.float32)
+    dw = mod.Array(O * C * 9)
+    mod.conv2d_wgrad(_arr(mod, x), _arr(mod, dy), dw, N, C, H, 32, O, 3, 1, 1)
+    want = R.conv2d_wgrad(x, dy, 3, 1, 1)
+    assert_close(_back(mod, dw).reshape(want.shape), want, 1e-4, f"stem wgrad C={C} H={H} O={O} N={N}")
+
+
 @pytest.mark.parametrize("N,C,O,H,W,k,s,p", [
     (3, 32, 32, 4, 8, 3, 1, 1), (2, 64, 64, 8, 8, 3, 1, 1), (1, 96, 32, 2, 16, 3, 1, 1), (5, 32, 64, 16, 16, 3, 1, 1),
     (2, 32, 32, 32, 32, 3, 1, 1), (8, 128, 128, 4, 4, 3, 1, 1), (16, 64, 256, 2, 2, 3, 1, 1), (6, 32, 128, 4, 4, 3, 1, 1),
