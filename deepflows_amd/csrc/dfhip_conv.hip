@@ -1223,8 +1223,9 @@ constexpr int kImg4Strip = 16 * 260;     // floats of a wave's transposition str
 template <int O, int GEO, bool PAIR, bool TR>
 __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__ dy, const float* __restrict__ w,
                                                        const float* __restrict__ add, float* __restrict__ dx, int C,
-                                                       const float* __restrict__ dy2, const float* __restrict__ w2) {
-  static_assert(!PAIR || GEO == 1, "the shortcut rides on the stride-2 form");
+                                                       const float* __restrict__ dy2, const float* __restrict__ w2, int S) {
+  static_assert(!PAIR || GEO >= 1, "the shortcut rides on the stride-2 forms");
+  static_assert(GEO != 2 || TR, "the sub-image form reads its planes through the strip");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int OQ = O / 4, NK = OQ / 4;             // o per wave, MFMA k-steps per wave
@@ -1236,6 +1237,10 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
   const int kk = lane >> 4, n = lane & 15;
   const int n0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
   const int ob = wave * OQ;
+  // GEO 2: the image is S x S (S = 8), this workgroup's 4 x 4 block of it is (qy, qx); its sources are a 2 x 2 block of
+  // the (S/2) x (S/2) dY plane
+  const int Q = GEO == 2 ? (S >> 2) : 1;
+  const int qy = GEO == 2 ? (int)blockIdx.z / Q : 0, qx = GEO == 2 ? (int)blockIdx.z % Q : 0;
   // dY operands of this wave's o range: the sources of image n0 + n, channel ob + 4 p + kk.  A lane is an IMAGE, so
   // read directly every lane of a request is a line of its own and the address unit takes them one per cycle (24-48
   // requests x 64 lines per wave); instead the wave requests its (16 images x channels) block in the order it lies in
@@ -1275,6 +1280,43 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
+    } else if constexpr (GEO == 2) {
+      // 4 x 4 planes (S = 8) as in GEO 0: chunks of 16 channels, strip row = an image; this block's 2 x 2 sources are
+      // two 8-byte pieces of the lane's plane
+      constexpr int NCH = OQ / 16;
+      static_assert(OQ % 16 == 0, "whole chunks");
+      auto turn2 = [&](const float* src, float (&dst)[NK][4]) {
+        f32x4 t[2][16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          t[0][i] = *reinterpret_cast<const f32x4*>(src + ((int64_t)(n0 + i) * O + ob) * 16 + lane * 4);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+          if (ch + 1 < NCH) {
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+              t[(ch + 1) & 1][i] = *reinterpret_cast<const f32x4*>(src + ((int64_t)(n0 + i) * O + ob + 16 * (ch + 1)) * 16 + lane * 4);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; i++) *reinterpret_cast<f32x4*>(strip + i * 260 + lane * 4) = t[ch & 1][i];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int pp = 0; pp < 4; pp++)
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+              typedef float f32x2 __attribute__((ext_vector_type(2)));
+              const f32x2 r = *reinterpret_cast<const f32x2*>(strip + n * 260 + (4 * pp + kk) * 16 + (2 * qy + u) * 4 + 2 * qx);
+              dst[4 * ch + pp][u * 2] = r[0]; dst[4 * ch + pp][u * 2 + 1] = r[1];
+            }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+      };
+      turn2(dy, sv);
+      if constexpr (PAIR) turn2(dy2, sv2);
     } else {
       // the 2 x 2 planes: per image OQ x 16 bytes in a row; 64 / OQ images per request; strip row = an image (OQ + 1 float4)
       constexpr int IPL = 64 / OQ >= 1 ? 64 / OQ : 1, NL = 16 / IPL;
@@ -1390,35 +1432,43 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
 #pragma unroll
       for (int q = 0; q < 16; q++) acc[q] += ex[(ww * 16 + q) * 64 + lane];
     // register v of lane (kk, n) is channel c0 + 4 kk + v of image n0 + n; its sixteen pixels are adjacent
-    const int64_t obase = ((int64_t)(n0 + n) * C + c0 + 4 * kk) * 16;
+    // (GEO 2: rows of the block are S floats apart in an S x S plane)
+    const int rowp = GEO == 2 ? S : 4, plane = GEO == 2 ? S * S : 16;
+    const int64_t obase = ((int64_t)(n0 + n) * C + c0 + 4 * kk) * plane + (GEO == 2 ? 4 * qy * S + 4 * qx : 0);
 #pragma unroll
     for (int v = 0; v < 4; v++)
 #pragma unroll
       for (int y = 0; y < 4; y++) {
         f32x4 r = {acc[y * 4][v], acc[y * 4 + 1][v], acc[y * 4 + 2][v], acc[y * 4 + 3][v]};
-        if (add) r += *reinterpret_cast<const f32x4*>(add + obase + 16 * v + 4 * y);
-        *reinterpret_cast<f32x4*>(dx + obase + 16 * v + 4 * y) = r;
+        if (add) r += *reinterpret_cast<const f32x4*>(add + obase + (int64_t)plane * v + rowp * y);
+        *reinterpret_cast<f32x4*>(dx + obase + (int64_t)plane * v + rowp * y) = r;
       }
   }
 }
 
 template <int O, int GEO, bool PAIR>
 int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* dx, int N, int C, const float* dy2,
-                      const float* w2) {
-  static int tr = getenv("DFHIP_IMG4_TR") ? atoi(getenv("DFHIP_IMG4_TR")) : 1;
-  dim3 grid((unsigned)(N / 16), (unsigned)(C / 16));
+                      const float* w2, int S = 4) {
+  static int tr_env = getenv("DFHIP_IMG4_TR") ? atoi(getenv("DFHIP_IMG4_TR")) : 1;
+  const int tr = GEO == 2 ? 1 : tr_env;
+  dim3 grid((unsigned)(N / 16), (unsigned)(C / 16), (unsigned)(GEO == 2 ? (S / 4) * (S / 4) : 1));
   const size_t base = std::max((size_t)(PAIR ? 5 : 4) * O * 16, (size_t)3 * 16 * 64 * 4) * sizeof(float);
   const size_t lds = base + (tr ? (size_t)4 * kImg4Strip * sizeof(float) : 0);
   static bool attr = false;
   if (!attr) {
     DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)std::max(base + (size_t)4 * kImg4Strip * sizeof(float), (size_t)65536)));
-    DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)std::max(base, (size_t)65536)));
+    if constexpr (GEO != 2)
+      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)std::max(base, (size_t)65536)));
     attr = true;
   }
-  if (tr) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2);
-  else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, false>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2);
+  if constexpr (GEO == 2) {
+    DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S);
+  } else {
+    if (tr) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S);
+    else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, false>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S);
+  }
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -4923,6 +4973,18 @@ int dfhip_conv2d_dgrad_pair(const float* dy, const float* w, const float* dy2, c
     const int st4 = O == 128 ? launch_dgrad_img4<128, 1, true>(dy, w, add, dx, N, C, dy2, w2)
                              : launch_dgrad_img4<256, 1, true>(dy, w, add, dx, N, C, dy2, w2);
     if (st4 != DFHIP_OK) return st4;
+    *done = 1;
+    return DFHIP_OK;
+  }
+  static int img8 = getenv("DFHIP_DGRAD_IMG8") ? atoi(getenv("DFHIP_DGRAD_IMG8")) : 1;
+  if (lean && pair_on && img4 && img8 && mode == 0 && H == 8 && W == 8 && N % 16 == 0 && C % 16 == 0 && (O == 64 || O == 128)) {
+    // 8 x 8 images (layer3's first block): four 4 x 4 blocks per image, each the image-per-lane kernel of the case above
+    double flops8 = 2.0 * N * H * W * (double)C * O + 2.0 * N * 16 * (double)C * O;
+    double bytes8 = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * 16);
+    ProfScope prof8("conv2d_dgrad_overwrite_igemm", flops8, bytes8);
+    const int st8 = O == 64 ? launch_dgrad_img4<64, 2, true>(dy, w, add, dx, N, C, dy2, w2, 8)
+                            : launch_dgrad_img4<128, 2, true>(dy, w, add, dx, N, C, dy2, w2, 8);
+    if (st8 != DFHIP_OK) return st8;
     *done = 1;
     return DFHIP_OK;
   }

@@ -389,7 +389,7 @@ def test_wgrad_affine_outside_a_group_writes_the_operand_out(hip_device):
     assert_close(a, b, 1e-5, "wgrad_affine fall-back")
 
 
-@pytest.mark.parametrize("C,HW,O", [(32, 16, 64), (64, 8, 128), (32, 8, 32), (128, 4, 256), (48, 4, 128)])
+@pytest.mark.parametrize("C,HW,O", [(32, 16, 64), (64, 8, 128), (32, 8, 32), (128, 4, 256), (48, 4, 128), (48, 8, 64)])
 def test_shortcut_input_gradient_rides_on_the_stride2_kernel(hip_device, C, HW, O):
     """dfhip_conv2d_dgrad_pair: the reference-exact input gradients of a block's stride-2 3x3 convolution and of its
     1x1 / stride-2 shortcut (both read the block input) as one launch, against the two launches; and the same through
