@@ -48,6 +48,37 @@ __device__ __forceinline__ float block_sum(float v, float* sh /* >= 4 floats */)
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// Combination of convolution partials (count, mean, centred second moment per row) WITHOUT a chain of divisions: every
+// row is moved to one shift s (row 0's mean, a sample of the channel: the distances are of the size of its spread),
+//   sum (y - s) = n (mu - s),   sum (y - s)^2 = m2 + n (mu - s)^2,
+// the three sums are plain additions (butterflies inside a wave, the four waves through LDS in a fixed order: the same
+// value in every thread of every block of the channel), and mean = s + A1 / n, M2 = A2 - A1^2 / n.  Chan's pairwise
+// update in a shuffle tree was two IEEE divisions per level, nine levels: ~1 us on the critical path of every
+// BatchNorm forward kernel.
+struct RowSums { float n, a1, a2; };
+__device__ __forceinline__ void rows_add(RowSums& t, float nb, float mub, float m2b, float s) {
+  const float d = nb > 0.0f ? mub - s : 0.0f;
+  t.n += nb;
+  t.a1 = fmaf(nb, d, t.a1);
+  t.a2 += fmaf(nb * d, d, m2b);
+}
+// sw: 12 floats of LDS not in use by anyone else between the two barriers inside
+__device__ __forceinline__ void rows_finish(RowSums t, float s, float (*sw)[3], float& mean, float& var) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    t.n += __shfl_xor(t.n, o, 64); t.a1 += __shfl_xor(t.a1, o, 64); t.a2 += __shfl_xor(t.a2, o, 64);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sw[threadIdx.x >> 6][0] = t.n; sw[threadIdx.x >> 6][1] = t.a1; sw[threadIdx.x >> 6][2] = t.a2; }
+  __syncthreads();
+  const float n = (sw[0][0] + sw[1][0]) + (sw[2][0] + sw[3][0]);
+  const float a1 = (sw[0][1] + sw[1][1]) + (sw[2][1] + sw[3][1]);
+  const float a2 = (sw[0][2] + sw[1][2]) + (sw[2][2] + sw[3][2]);
+  const float mu_s = n > 0.0f ? a1 / n : 0.0f;
+  mean = s + mu_s;
+  var = n > 0.0f ? fmaxf(a2 - a1 * mu_s, 0.0f) / n : 0.0f;      // biased variance (batchnorm.py:41-42)
+}
+
 // ---------------------------------------------------------------------------------------
 // BatchNorm2d.  x is (N, C, HW) with HW contiguous.  Block (c, s) owns images
 // [s*ipb, (s+1)*ipb) of channel c.
@@ -287,16 +318,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
     float* __restrict__ running_var, int N, int C, int HW, int ipb, float eps, float momentum) {
   __shared__ float sw[4][3];
   const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
-  // Chan's update: (n, mu, m2) <- (n, mu, m2) (+) (nb, mub, m2b); rows per thread, then a shuffle
-  // tree inside the wave, then the four waves in order (the same sequence in every block)
-  auto chan = [](float& n, float& mu, float& m2, float nb, float mub, float m2b) {
-    if (nb > 0.0f) {
-      const float nn = n + nb, delta = mub - mu;
-      mu += delta * (nb / nn);
-      m2 += m2b + delta * delta * (n * nb / nn);
-      n = nn;
-    }
-  };
   // The thread's first partial row and its (up to two) 16-byte pieces of x / residual are REQUESTED before anything
   // is computed -- the row first, so that the combination below starts as soon as the rows are back (L2) while
   // the pieces of x are still on their way from HBM; the kernel is one round of memory latency long instead of two.
@@ -307,10 +328,12 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
   const float* rbase = residual ? residual + (int64_t)c * HW : nullptr;
   const int hw4 = HW >> 2;
   const bool fast = (HW & 3) == 0 && (n_hi - n_lo) * hw4 <= 2 * kThreads;
-  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f;
-  if (tid < rows) {
-    const float* p = partials + ((int64_t)tid * C + c) * 3;
+  float p0, p1, p2;
+  const float shift = partials[(int64_t)c * 3 + 1];          // row 0's mean
+  {
+    const float* p = partials + ((int64_t)min(tid, rows - 1) * C + c) * 3;      // (clamped: no load under a condition)
     p0 = p[0]; p1 = p[1]; p2 = p[2];
+    if (tid >= rows) { p0 = 0.0f; p2 = 0.0f; }
   }
   __builtin_amdgcn_sched_barrier(0);
   int64_t off[2] = {0, 0};
@@ -329,24 +352,14 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-  float n = 0.0f, mu = 0.0f, m2 = 0.0f;
-  chan(n, mu, m2, p0, p1, p2);
+  RowSums t = {0.0f, 0.0f, 0.0f};
+  rows_add(t, p0, p1, p2, shift);
   for (int r = tid + kThreads; r < rows; r += kThreads) {
     const float* p = partials + ((int64_t)r * C + c) * 3;
-    chan(n, mu, m2, p[0], p[1], p[2]);
+    rows_add(t, p[0], p[1], p[2], shift);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float nb = __shfl_down(n, o, 64), mub = __shfl_down(mu, o, 64), m2b = __shfl_down(m2, o, 64);
-    chan(n, mu, m2, nb, mub, m2b);
-  }
-  if ((tid & 63) == 0) { sw[tid >> 6][0] = n; sw[tid >> 6][1] = mu; sw[tid >> 6][2] = m2; }
-  __syncthreads();
-  n = sw[0][0]; mu = sw[0][1]; m2 = sw[0][2];
-#pragma unroll
-  for (int w4 = 1; w4 < 4; w4++) chan(n, mu, m2, sw[w4][0], sw[w4][1], sw[w4][2]);
-  const float mean = mu;
-  const float var = n > 0.0f ? m2 / n : 0.0f;   // biased variance (batchnorm.py:41-42)
+  float mean, var;
+  rows_finish(t, shift, sw, mean, var);
   if (s == 0 && tid == 0) {
     if (save_mean) save_mean[c] = mean;
     if (save_var) save_var[c] = var;
@@ -405,32 +418,14 @@ struct BnFwdSet {
 __device__ __forceinline__ void bn_partials_stats(const BnFwdSet& q, int c, int C, bool writer, float (*sw)[3],
                                                   float& mean, float& rsd, float& w, float& b) {
   const int tid = threadIdx.x;
-  auto chan = [](float& n, float& mu, float& m2, float nb, float mub, float m2b) {
-    if (nb > 0.0f) {
-      const float nn = n + nb, delta = mub - mu;
-      mu += delta * (nb / nn);
-      m2 += m2b + delta * delta * (n * nb / nn);
-      n = nn;
-    }
-  };
-  float n = 0.0f, mu = 0.0f, m2 = 0.0f;
+  const float shift = q.partials[(int64_t)c * 3 + 1];
+  RowSums t = {0.0f, 0.0f, 0.0f};
   for (int r = tid; r < q.rows; r += kThreads) {
     const float* p = q.partials + ((int64_t)r * C + c) * 3;
-    chan(n, mu, m2, p[0], p[1], p[2]);
+    rows_add(t, p[0], p[1], p[2], shift);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float nb = __shfl_down(n, o, 64), mub = __shfl_down(mu, o, 64), m2b = __shfl_down(m2, o, 64);
-    chan(n, mu, m2, nb, mub, m2b);
-  }
-  __syncthreads();                                  // sw may still be read from the previous set
-  if ((tid & 63) == 0) { sw[tid >> 6][0] = n; sw[tid >> 6][1] = mu; sw[tid >> 6][2] = m2; }
-  __syncthreads();
-  n = sw[0][0]; mu = sw[0][1]; m2 = sw[0][2];
-#pragma unroll
-  for (int w4 = 1; w4 < 4; w4++) chan(n, mu, m2, sw[w4][0], sw[w4][1], sw[w4][2]);
-  mean = mu;
-  const float var = n > 0.0f ? m2 / n : 0.0f;      // biased variance (batchnorm.py:41-42)
+  float var;
+  rows_finish(t, shift, sw, mean, var);
   if (writer) {
     if (q.save_mean) q.save_mean[c] = mean;
     if (q.save_var) q.save_var[c] = var;
@@ -447,14 +442,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials_pair(BnFwdSet A,
   __shared__ float sw[2][4][3];
   const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
   const bool writer = s == 0 && tid == 0;
-  auto chan = [](float& n, float& mu, float& m2, float nb, float mub, float m2b) {
-    if (nb > 0.0f) {
-      const float nn = n + nb, delta = mub - mu;
-      mu += delta * (nb / nn);
-      m2 += m2b + delta * delta * (n * nb / nn);
-      n = nn;
-    }
-  };
   // everything the block needs from memory is requested up front -- its first partial row of BOTH sets, then its
   // (up to two) 16-byte pieces of both tensors -- and the two sets are combined side by side with one barrier: the
   // kernel is one round of memory latency long (it was three: set A, set B, then the data)
@@ -473,6 +460,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials_pair(BnFwdSet A,
     if (tid < A.rows) { pa[0] = a0; pa[1] = a1; pa[2] = a2; }
     if (tid < B.rows) { pb[0] = b0; pb[1] = b1; pb[2] = b2; }
   }
+  const float shift_a = A.partials[(int64_t)c * 3 + 1], shift_b = B.partials[(int64_t)c * 3 + 1];   // row 0's means
   __builtin_amdgcn_sched_barrier(0);
   int64_t off[2] = {0, 0};
   bool have[2] = {false, false};
@@ -490,38 +478,45 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials_pair(BnFwdSet A,
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-  float na = 0.0f, mua = 0.0f, m2a = 0.0f, nb = 0.0f, mub = 0.0f, m2b = 0.0f;
-  chan(na, mua, m2a, pa[0], pa[1], pa[2]);
-  chan(nb, mub, m2b, pb[0], pb[1], pb[2]);
+  RowSums ta = {0.0f, 0.0f, 0.0f}, tb = {0.0f, 0.0f, 0.0f};
+  rows_add(ta, pa[0], pa[1], pa[2], shift_a);
+  rows_add(tb, pb[0], pb[1], pb[2], shift_b);
   for (int r = tid + kThreads; r < A.rows; r += kThreads) {
     const float* q = A.partials + ((int64_t)r * C + c) * 3;
-    chan(na, mua, m2a, q[0], q[1], q[2]);
+    rows_add(ta, q[0], q[1], q[2], shift_a);
   }
   for (int r = tid + kThreads; r < B.rows; r += kThreads) {
     const float* q = B.partials + ((int64_t)r * C + c) * 3;
-    chan(nb, mub, m2b, q[0], q[1], q[2]);
+    rows_add(tb, q[0], q[1], q[2], shift_b);
   }
+  // the two sets side by side: butterflies, one barrier pair, the four waves in a fixed order
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const float n1 = __shfl_down(na, o, 64), mu1 = __shfl_down(mua, o, 64), q1 = __shfl_down(m2a, o, 64);
-    const float n2 = __shfl_down(nb, o, 64), mu2 = __shfl_down(mub, o, 64), q2 = __shfl_down(m2b, o, 64);
-    chan(na, mua, m2a, n1, mu1, q1);
-    chan(nb, mub, m2b, n2, mu2, q2);
+    ta.n += __shfl_xor(ta.n, o, 64); ta.a1 += __shfl_xor(ta.a1, o, 64); ta.a2 += __shfl_xor(ta.a2, o, 64);
+    tb.n += __shfl_xor(tb.n, o, 64); tb.a1 += __shfl_xor(tb.a1, o, 64); tb.a2 += __shfl_xor(tb.a2, o, 64);
   }
   if ((tid & 63) == 0) {
-    sw[0][tid >> 6][0] = na; sw[0][tid >> 6][1] = mua; sw[0][tid >> 6][2] = m2a;
-    sw[1][tid >> 6][0] = nb; sw[1][tid >> 6][1] = mub; sw[1][tid >> 6][2] = m2b;
+    sw[0][tid >> 6][0] = ta.n; sw[0][tid >> 6][1] = ta.a1; sw[0][tid >> 6][2] = ta.a2;
+    sw[1][tid >> 6][0] = tb.n; sw[1][tid >> 6][1] = tb.a1; sw[1][tid >> 6][2] = tb.a2;
   }
   __syncthreads();
-  na = sw[0][0][0]; mua = sw[0][0][1]; m2a = sw[0][0][2];
-  nb = sw[1][0][0]; mub = sw[1][0][1]; m2b = sw[1][0][2];
-#pragma unroll
-  for (int w4 = 1; w4 < 4; w4++) {
-    chan(na, mua, m2a, sw[0][w4][0], sw[0][w4][1], sw[0][w4][2]);
-    chan(nb, mub, m2b, sw[1][w4][0], sw[1][w4][1], sw[1][w4][2]);
+  float ma, mb, vara, varb;
+  {
+    const float n = (sw[0][0][0] + sw[0][1][0]) + (sw[0][2][0] + sw[0][3][0]);
+    const float a1 = (sw[0][0][1] + sw[0][1][1]) + (sw[0][2][1] + sw[0][3][1]);
+    const float a2 = (sw[0][0][2] + sw[0][1][2]) + (sw[0][2][2] + sw[0][3][2]);
+    const float mu_s = n > 0.0f ? a1 / n : 0.0f;
+    ma = shift_a + mu_s;
+    vara = n > 0.0f ? fmaxf(a2 - a1 * mu_s, 0.0f) / n : 0.0f;      // biased (batchnorm.py:41-42)
   }
-  const float ma = mua, mb = mub;
-  const float vara = na > 0.0f ? m2a / na : 0.0f, varb = nb > 0.0f ? m2b / nb : 0.0f;   // biased (batchnorm.py:41-42)
+  {
+    const float n = (sw[1][0][0] + sw[1][1][0]) + (sw[1][2][0] + sw[1][3][0]);
+    const float a1 = (sw[1][0][1] + sw[1][1][1]) + (sw[1][2][1] + sw[1][3][1]);
+    const float a2 = (sw[1][0][2] + sw[1][1][2]) + (sw[1][2][2] + sw[1][3][2]);
+    const float mu_s = n > 0.0f ? a1 / n : 0.0f;
+    mb = shift_b + mu_s;
+    varb = n > 0.0f ? fmaxf(a2 - a1 * mu_s, 0.0f) / n : 0.0f;
+  }
   if (writer) {
     if (A.save_mean) A.save_mean[c] = ma;
     if (A.save_var) A.save_var[c] = vara;
@@ -619,32 +614,14 @@ __device__ __forceinline__ float max_nan(float m, float v) { return (m != m) ? m
 // sequence in every block (as k_bn_apply_partials); sw: 12 floats of LDS
 __device__ __forceinline__ void bn_combine_rows(const float* __restrict__ partials, int rows, int C, int c,
                                                 float (*sw)[3], float& mean, float& var) {
-  auto chan = [](float& n, float& mu, float& m2, float nb, float mub, float m2b) {
-    if (nb > 0.0f) {
-      const float nn = n + nb, delta = mub - mu;
-      mu += delta * (nb / nn);
-      m2 += m2b + delta * delta * (n * nb / nn);
-      n = nn;
-    }
-  };
   const int tid = threadIdx.x;
-  float n = 0.0f, mu = 0.0f, m2 = 0.0f;
+  const float shift = partials[(int64_t)c * 3 + 1];          // row 0's mean
+  RowSums t = {0.0f, 0.0f, 0.0f};
   for (int r = tid; r < rows; r += kThreads) {
     const float* p = partials + ((int64_t)r * C + c) * 3;
-    chan(n, mu, m2, p[0], p[1], p[2]);
+    rows_add(t, p[0], p[1], p[2], shift);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float nb = __shfl_down(n, o, 64), mub = __shfl_down(mu, o, 64), m2b = __shfl_down(m2, o, 64);
-    chan(n, mu, m2, nb, mub, m2b);
-  }
-  if ((tid & 63) == 0) { sw[tid >> 6][0] = n; sw[tid >> 6][1] = mu; sw[tid >> 6][2] = m2; }
-  __syncthreads();
-  n = sw[0][0]; mu = sw[0][1]; m2 = sw[0][2];
-#pragma unroll
-  for (int w4 = 1; w4 < 4; w4++) chan(n, mu, m2, sw[w4][0], sw[w4][1], sw[w4][2]);
-  mean = mu;
-  var = n > 0.0f ? m2 / n : 0.0f;   // biased variance (batchnorm.py:41-42)
+  rows_finish(t, shift, sw, mean, var);
 }
 
 // S > 0: partial = this library's [C][S][3] statistics pass;  S < 0: partial = convolution partials [-S rows][C][3]
