@@ -1440,8 +1440,7 @@ int fill_batch(TensorBatch& tb, int n, int first, float* const* p, const float* 
 }  // namespace
 
 // (scale, shift) of a training-mode BatchNorm from convolution partials, nothing normalised: the consumer is a
-// convolution that applies the pair on its operand loads (dfhip_conv2d_forward_bn_input).  One wave per channel;
-// weighted mean first, then the centred second moment about it: two plain reductions, the same value in every lane.
+// convolution that applies the pair on its operand loads (dfhip_conv2d_forward_bn_input).  One wave per channel.
 __global__ __launch_bounds__(256) void k_bn_finalize_partials(BnInput bn, int C) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
@@ -1456,19 +1455,21 @@ __global__ __launch_bounds__(256) void k_bn_finalize_partials(BnInput bn, int C)
     const float a0 = p[0], a1 = p[1], a2 = p[2];
     pn[k] = r < bn.rows ? a0 : 0.0f; pm[k] = a1; pq[k] = r < bn.rows ? a2 : 0.0f;
   }
-  float n = 0.0f, a = 0.0f;
+  // one butterfly over three shifted sums (rows_add above; the shift is row 0's mean) instead of the weighted mean
+  // first and the centred moment about it second
+  const float shift = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pm[0])));
+  RowSums t = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int k = 0; k < RP; k++) { n += pn[k]; a += pn[k] * pm[k]; }
+  for (int k = 0; k < RP; k++) rows_add(t, pn[k], pm[k], pq[k], shift);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { n += __shfl_xor(n, o, 64); a += __shfl_xor(a, o, 64); }
-  const float mu = n > 0.0f ? a / n : 0.0f;
-  float q = 0.0f;
-#pragma unroll
-  for (int k = 0; k < RP; k++) { const float d = pm[k] - mu; q += pq[k] + pn[k] * d * d; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  for (int o = 32; o > 0; o >>= 1) {
+    t.n += __shfl_xor(t.n, o, 64); t.a1 += __shfl_xor(t.a1, o, 64); t.a2 += __shfl_xor(t.a2, o, 64);
+  }
   if (lane != 0) return;
-  const float var = n > 0.0f ? q / n : 0.0f;           // biased variance (batchnorm.py:41-42)
+  const float n = t.n;
+  const float mu_s = n > 0.0f ? t.a1 / n : 0.0f;
+  const float mu = shift + mu_s;
+  const float var = n > 0.0f ? fmaxf(t.a2 - t.a1 * mu_s, 0.0f) / n : 0.0f;           // biased variance (batchnorm.py:41-42)
   const float rsd = 1.0f / sqrtf(var + bn.eps);
   const float sc = (bn.gamma ? bn.gamma[c] : 1.0f) * rsd;
   const float sh = (bn.beta ? bn.beta[c] : 0.0f) - mu * sc;
