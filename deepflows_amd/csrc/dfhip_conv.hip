@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_igemm_v4(Geo g) {
   const int half = lane >> 5, l31 = lane & 31;
   const int PT = g.PT, KSPLIT = 8 / g.PT;
   const int pt = wave % PT, ks = wave / PT;
-  int stamp_i = 0;
+  [[maybe_unused]] int stamp_i = 0;
 #ifdef DFHIP_STAMPS
 #define DF_STAMP()                                                                              \
   do {                                                                                          \
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
   __shared__ float Wl[NSL + (PAIR ? 1 : 0)][O][32]; // the weight slices of this channel tile: [slice][o][c]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int W = 1 << lw, HW = H << lw;
+  const int HW = H << lw;
   const int c0 = blockIdx.y * 32;
   const int tile = min(blockIdx.x * 4 + wave, tiles - 1);   // 32 consecutive pixels of one image (clamped: a
   const bool live = blockIdx.x * 4 + wave < tiles;          //  wave past the end still takes part in the barrier)
@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict_
   float* red = smem + NSLP * O * 32;                // [3][16][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int W = 1 << lw, HW = H << lw;
+  const int HW = H << lw;
   const int c0 = blockIdx.y * 32;
   const int slw = GEO == 0 ? lw : lw - 1;           // source plane: H x W, or H/2 x W/2
   const int SHW = GEO == 0 ? HW : HW >> 2;
@@ -1219,6 +1219,9 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__
 // GEO 0: 3x3 / stride 1 / pad 1, dY is 4 x 4 (nine sources).  GEO 1: 3x3 / stride 2 / pad 1, dY is 2 x 2: pixel (y, x)
 // keeps tap (1 + (y & 1), 1 + (x & 1)) of source (y >> 1, x >> 1) (four sources); PAIR (GEO 1): the block's 1x1 /
 // stride 2 shortcut adds sum_o dY2[o][y/2][x/2] W2[o][c] on the pixels with even (y, x) -- a fifth slice.
+// GEO 2: the GEO 1 pattern on one 4 x 4 block (blockIdx.z) of an 8 x 8 image whose dY is 4 x 4 (layer3's first
+// block: 256 workgroups where whole images would give 64).  TR: the dY planes are requested in memory order and turned
+// into the image-per-lane order through a wave-private LDS strip (see the operand section below).
 constexpr int kImg4Strip = 16 * 260;     // floats of a wave's transposition strip (16 images x (256 + 4))
 template <int O, int GEO, bool PAIR, bool TR>
 __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__ dy, const float* __restrict__ w,
@@ -1963,7 +1966,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  int stamp_i = 0;
+  [[maybe_unused]] int stamp_i = 0;
 #ifdef DFHIP_STAMPS
 #define WG_STAMP()                                                                              \
   do {                                                                                          \
@@ -2229,7 +2232,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_v3(WGeo g) {
 template <bool STEM>
 __global__ __launch_bounds__(512) void k_wgrad_stem3(WGeo g) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 [[maybe_unused]] __attribute__((ext_vector_type(2)));
   constexpr int CH = kStemRows * kStemPitch;
   constexpr int CMAX = 3, NQ = CMAX * kStemRows * 8, QR = (NQ + 511) / 512;
   constexpr int DEPTH = 2;
@@ -2490,7 +2493,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_tap(TGeo g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  int stamp_i = 0;
+  [[maybe_unused]] int stamp_i = 0;
 #ifdef DFHIP_STAMPS
 #define TG_STAMP()                                                                              \
   do {                                                                                          \
@@ -2883,7 +2886,7 @@ __device__ __forceinline__ void wgrad_rows_body(const RGeo& g, float* smem, cons
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  int stamp_i = 0;
+  [[maybe_unused]] int stamp_i = 0;
 #ifdef DFHIP_STAMPS
 #define RG_STAMP()                                                                              \
   do {                                                                                          \
