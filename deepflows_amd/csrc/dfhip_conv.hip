@@ -1743,6 +1743,139 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_fwd(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same layer with ALL FOUR output positions in one workgroup (16 images x 16 output channels; 16x16x4 MFMA:
+// D[16 channels][16 images] += A[16][4 source channels] . B[4][16]).  Every 36-byte weight record (o, c) is then read
+// whole, in memory order and once per workgroup (the one-position kernel reads 16 bytes of each from four workgroups:
+// the gather was 2.7 us of its 12.9), and the 2 x 2 input planes serve four positions.  The eight waves split the
+// source channels and stream their own slices -- eight channels at a time -- through wave-private LDS areas with the
+// next slice's requests in flight: no block barrier before the first MFMA.  Lane (kk, n) of the B operand is image n,
+// channel 4 p + kk; output position q takes input pixel s through tap (sy - qy + 1, sx - qx + 1): sixteen MFMAs per
+// k-step on nine weight operands.  Sums through LDS, 16-byte stores (the four positions of a channel are adjacent),
+// BatchNorm partials over the 16 images x 4 positions of a channel.
+// ---------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          float* __restrict__ stats, int O) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int CW = C / 8;                     // channels per wave
+  constexpr int NCHK = CW / 8;                  // slices of eight channels
+  constexpr int WP = 17;                        // pitch of a (channel, tap) row of 16 output channels
+  constexpr int WSL = 72 * WP + 16 * 9 * 4;     // floats of a wave's area: weights [72][17], planes [16 images][9 float4]
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 4, n = lane & 15;
+  const int n0 = blockIdx.x * 16, o0 = blockIdx.y * 16;
+  float* Wl = smem + wave * WSL;
+  float* Xs = Wl + 72 * WP;
+  const int cb = wave * CW;                     // this wave's first source channel
+  // requests of a slice: 16 records rows of 72 floats (eight channels x nine taps of one output channel) = 288 float4,
+  // 16 planes rows of 32 floats (eight channels x four pixels of one image) = 128 float4
+  f32x4 wq[5], xq[2];
+  auto request = [&](int ch) {
+    const int c0 = cb + 8 * ch;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int e = min(lane + 64 * i, 287), m = e / 18, j = e - 18 * m;
+      wq[i] = *reinterpret_cast<const f32x4*>(w + ((int64_t)(o0 + m) * C + c0) * 9 + 4 * j);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int e = lane + 64 * i, im = e >> 3, j = e & 7;
+      xq[i] = *reinterpret_cast<const f32x4*>(x + ((int64_t)(n0 + im) * C + c0 + j) * 4);
+    }
+  };
+  f32x4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  request(0);
+#pragma unroll
+  for (int ch = 0; ch < NCHK; ch++) {
+    // commit: weight float4 (m, j) holds (channel, tap) rows 4 j .. 4 j + 3 of output channel m
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int e = lane + 64 * i, m = min(e, 287) / 18, j = min(e, 287) - 18 * m;
+      if (e < 288) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) Wl[(4 * j + t) * WP + m] = wq[i][t];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int e = lane + 64 * i, im = e >> 3, j = e & 7;
+      *reinterpret_cast<f32x4*>(Xs + (im * 9 + j) * 4) = xq[i];
+    }
+    if (ch + 1 < NCHK) request(ch + 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float a[2][9];
+    f32x4 b[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+      for (int t = 0; t < 9; t++) a[p][t] = Wl[((4 * p + kk) * 9 + t) * WP + n];
+      b[p] = *reinterpret_cast<const f32x4*>(Xs + (n * 9 + 4 * p + kk) * 4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int sp = 0; sp < 4; sp++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int tap = ((sp >> 1) - (q >> 1) + 1) * 3 + ((sp & 1) - (q & 1) + 1);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][tap], b[p][sp], acc[q], 0, 0, 0);
+        }
+  }
+  // the eight waves' sums: waves 1..7 hand theirs over, wave 0 adds them in order
+  __syncthreads();
+  f32x4* ex = reinterpret_cast<f32x4*>(smem);
+  if (wave > 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) ex[((wave - 1) * 4 + q) * 64 + lane] = acc[q];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int ww = 0; ww < 7; ww++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] += ex[(ww * 4 + q) * 64 + lane];
+  // register v of lane (kk, n) is output channel o0 + 4 kk + v of image n0 + n; its four positions are adjacent
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const float bv = bias ? bias[o0 + 4 * kk + v] : 0.0f;
+    f32x4 r = {acc[0][v] + bv, acc[1][v] + bv, acc[2][v] + bv, acc[3][v] + bv};
+    acc[0][v] = r[0]; acc[1][v] = r[1]; acc[2][v] = r[2]; acc[3][v] = r[3];
+    *reinterpret_cast<f32x4*>(y + ((int64_t)(n0 + n) * O + o0 + 4 * kk + v) * 4) = r;
+  }
+  if (stats) {
+    // exact two-pass over the 64 values of a channel: the lane's four positions, then the 16 images of its DPP row
+    auto row16 = [](float t) {
+      t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xf, 0xf, true));   // row_ror:8
+      t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xf, 0xf, true));   // row_ror:4
+      t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x122, 0xf, 0xf, true));   // row_ror:2
+      t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x121, 0xf, 0xf, true));   // row_ror:1
+      return t;
+    };
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const float mean = row16((acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v])) * (1.0f / 64.0f);
+      float qs = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const float d = acc[q][v] - mean; qs = fmaf(d, d, qs); }
+      qs = row16(qs);
+      if (n == 0) {
+        float* o3 = stats + ((int64_t)blockIdx.x * O + o0 + 4 * kk + v) * 3;
+        o3[0] = 64.0f; o3[1] = mean; o3[2] = qs;
+      }
+    }
+  }
+}
+
 // out[i] = sum_s slabs[s][i] (+ bias[(i / plane) % CD])
 __global__ __launch_bounds__(256) void k_conv_slab_sum(const float* __restrict__ slabs,
                                                        const float* __restrict__ bias,
@@ -3794,6 +3927,18 @@ int run_conv_img2(const Geo& g, int O, float* y, const float* bias, float* parti
   if (!enabled || g.mode != 0 || g.k != 3 || g.so != 1 || g.sd != 1 || g.u0 != -1) return -1;
   if (g.HS != 2 || g.WS != 2 || g.HD != 2 || g.WD != 2 || (g.N % 32) != 0) return -1;
   if (!(g.CS == 128 || g.CS == 256)) return -1;
+  static int all4 = getenv("DFHIP_IMG2_ALL") ? atoi(getenv("DFHIP_IMG2_ALL")) : 1;
+  if (all4 && O % 16 == 0 && g.N % 16 == 0 && (!partials || g.N / 16 <= cap_rows)) {
+    // all four positions per workgroup (k_conv3x3_img2_all): 16 images x 16 channels
+    const int rows4 = g.N / 16;
+    if (rows_out) *rows_out = partials ? rows4 : 0;
+    dim3 grid4((unsigned)rows4, (unsigned)(O / 16));
+    const size_t lds4 = std::max((size_t)8 * (72 * 17 + 16 * 9 * 4), (size_t)7 * 4 * 64 * 4) * sizeof(float);
+    if (g.CS == 128) DF_LAUNCH(k_conv3x3_img2_all<128>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O);
+    else DF_LAUNCH(k_conv3x3_img2_all<256>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O);
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
   const int rows = g.N / 32 * 4;
   if (partials && rows > cap_rows) return -1;
   if (rows_out) *rows_out = partials ? rows : 0;
