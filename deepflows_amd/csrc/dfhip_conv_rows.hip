@@ -514,9 +514,191 @@ int launch_rowmma(const float* x, const float* w, const float* bias, float* y, f
   return DFHIP_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// 4 x 4 images (ResNet layer3, 128 -> 128 channels) with an IMAGE on the lane -- the forward twin of the
+// image-per-lane input-gradient kernels and of k_conv3x3_img2_all (dfhip_conv.hip).  v_mfma_f32_16x16x4_f32:
+// D[16 output channels][16 images] += A[16][4 source channels] . B[4][16]; an accumulator per output pixel, and a
+// (pixel, tap) pair whose source falls outside the image is simply NOT multiplied: 100 of the 144 pairs of a 4 x 4
+// image exist, so the layer is 0.84 instead of 1.21 GFLOP of MFMAs, and no lane shift, mask or select is needed to
+// build a tap operand (the register-operand kernel spends 8 DPP moves + 6 multiplies per 9 MFMAs on this width:
+// beside fp32 MFMAs that is matrix-pipe time).  A workgroup is 16 images x 16 output channels x one HALF of the image
+// (rows 2h, 2h + 1: 256 workgroups at batch 256); its eight waves split the source channels (16 each) and stream them
+// eight at a time through wave-private LDS areas: the weight records (16 output channels x 8 channels x 9 taps) and
+// the image planes (16 images x 8 channels x 64 bytes) both in memory order, then read back in MFMA lane order -- no
+// block barrier before the first MFMA.  `aff` (or nullptr): the BatchNorm of the input applied on its way out of the
+// strip (dfhip_conv2d_forward_bn_input: (scale, shift) per channel); the padding needs no care, it is never read.
+// Sums through LDS, 16-byte stores, BatchNorm partials over the 16 images x 8 pixels of a channel.
+// ---------------------------------------------------------------------------------------
+template <int HH>
+__device__ __forceinline__ void img4_fwd_mfmas(const float (&a)[9], const f32x4 (&xr)[4], f32x4 (&acc)[8]) {
+#pragma unroll
+  for (int yy = 0; yy < 2; yy++)
+#pragma unroll
+    for (int xx = 0; xx < 4; xx++)
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const int sy = 2 * HH + yy + i - 1, sx = xx + j - 1;
+          if (sy >= 0 && sy < 4 && sx >= 0 && sx < 4)
+            acc[yy * 4 + xx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i * 3 + j], xr[yy + i][sx], acc[yy * 4 + xx], 0, 0, 0);
+        }
+}
+
+template <int C>
+__global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          float* __restrict__ stats, int O,
+                                                          const float* __restrict__ aff) {
+  constexpr int CW = C / 8, NCHK = CW / 8, WP = 17, XP = 33;      // XP: float4 pitch of an image's strip row
+  constexpr int WSL = 72 * WP + 16 * XP * 4;                       // floats of a wave's area
+  extern __shared__ __attribute__((aligned(16))) float smem_i4[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 4, n = lane & 15;
+  const int n0 = blockIdx.x * 16, o0 = blockIdx.y * 16, h = blockIdx.z;
+  float* Wl = smem_i4 + wave * WSL;
+  float* Xs = Wl + 72 * WP;
+  const int cb = wave * CW;
+  f32x4 wq[5], xq[8];
+  auto request = [&](int ch) {
+    const int c0 = cb + 8 * ch;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int e = min(lane + 64 * i, 287), m = e / 18, j = e - 18 * m;
+      wq[i] = *reinterpret_cast<const f32x4*>(w + ((int64_t)(o0 + m) * C + c0) * 9 + 4 * j);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = lane + 64 * i, im = e >> 5, j = e & 31;      // float4 j of the image's 8 channels x 16 pixels
+      xq[i] = *reinterpret_cast<const f32x4*>(x + ((int64_t)(n0 + im) * C + c0) * 16 + 4 * j);
+    }
+  };
+  f32x4 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  request(0);
+#pragma unroll
+  for (int ch = 0; ch < NCHK; ch++) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int e = lane + 64 * i, m = min(e, 287) / 18, j = min(e, 287) - 18 * m;
+      if (e < 288) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) Wl[(4 * j + t) * WP + m] = wq[i][t];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = lane + 64 * i, im = e >> 5, j = e & 31;
+      *reinterpret_cast<f32x4*>(Xs + (im * XP + j) * 4) = xq[i];
+    }
+    const int c0 = cb + 8 * ch;
+    if (ch + 1 < NCHK) request(ch + 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float a[2][9];
+    f32x4 xr[2][4];                              // the four source rows 2h - 1 .. 2h + 2 (one of them outside: never used)
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+      for (int t = 0; t < 9; t++) a[p][t] = Wl[((4 * p + kk) * 9 + t) * WP + n];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = min(max(2 * h - 1 + r, 0), 3);
+        xr[p][r] = *reinterpret_cast<const f32x4*>(Xs + (n * XP + (4 * p + kk) * 4 + row) * 4);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (aff) {
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const f32x2 sc = *reinterpret_cast<const f32x2*>(aff + 2 * (c0 + 4 * p + kk));
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) xr[p][r][e] = fmaf(xr[p][r][e], sc[0], sc[1]);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      if (h == 0) img4_fwd_mfmas<0>(a[p], xr[p], acc);
+      else img4_fwd_mfmas<1>(a[p], xr[p], acc);
+    }
+  }
+  __syncthreads();
+  f32x4* ex = reinterpret_cast<f32x4*>(smem_i4);
+  if (wave > 0) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) ex[((wave - 1) * 8 + q) * 64 + lane] = acc[q];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int ww = 0; ww < 7; ww++)
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc[q] += ex[(ww * 8 + q) * 64 + lane];
+  // register v of lane (kk, n) is output channel o0 + 4 kk + v of image n0 + n; a row's four pixels are adjacent
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const float bv = bias ? bias[o0 + 4 * kk + v] : 0.0f;
+#pragma unroll
+    for (int yy = 0; yy < 2; yy++) {
+      f32x4 r = {acc[yy * 4][v] + bv, acc[yy * 4 + 1][v] + bv, acc[yy * 4 + 2][v] + bv, acc[yy * 4 + 3][v] + bv};
+      acc[yy * 4][v] = r[0]; acc[yy * 4 + 1][v] = r[1]; acc[yy * 4 + 2][v] = r[2]; acc[yy * 4 + 3][v] = r[3];
+      *reinterpret_cast<f32x4*>(y + ((int64_t)(n0 + n) * O + o0 + 4 * kk + v) * 16 + (2 * h + yy) * 4) = r;
+    }
+  }
+  if (stats) {
+    // exact two-pass over the 128 values of a channel: the lane's eight pixels, then the 16 images of its DPP row
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      float t = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; q++) t += acc[q][v];
+      const float mean = row_sum16(t) * (1.0f / 128.0f);
+      float qs = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; q++) { const float d = acc[q][v] - mean; qs = fmaf(d, d, qs); }
+      qs = row_sum16(qs);
+      if (n == 0) {
+        float* o3 = stats + ((int64_t)(blockIdx.x * 2 + h) * O + o0 + 4 * kk + v) * 3;
+        o3[0] = 128.0f; o3[1] = mean; o3[2] = qs;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 namespace dfhip {
+
+// 4 x 4 images with an image on the lane (k_conv3x3_img4_fwd); -1 when the shape is not one it takes
+static int run_conv_img4_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int O,
+                             float* partials, int cap_rows, int* rows_out, const BnInput* bn, bool dry_run) {
+  static int enabled = getenv("DFHIP_IMG4_FWD") ? atoi(getenv("DFHIP_IMG4_FWD")) : 1;
+  if (!enabled || C != 128 || N % 16 != 0 || O % 16 != 0) return -1;
+  const int rows = N / 16 * 2;
+  if (partials && rows > cap_rows) return -1;
+  if ((int64_t)rows * (O / 16) < num_cus() / 2) return -1;
+  if (bn && !bn->affine) return -1;
+  if (rows_out) *rows_out = partials ? rows : 0;
+  if (dry_run) return DFHIP_OK;
+  dim3 grid((unsigned)(N / 16), (unsigned)(O / 16), 2);
+  const size_t lds = std::max((size_t)8 * (72 * 17 + 16 * 33 * 4), (size_t)7 * 8 * 64 * 4) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_img4_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  DF_LAUNCH(k_conv3x3_img4_fwd<128>, grid, dim3(512), lds, stream(), x, w, bias, y, partials, O,
+            bn ? (const float*)bn->affine : (const float*)nullptr);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
 
 // returns -1 when the shape is not one this kernel takes
 int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int O,
@@ -525,6 +707,10 @@ int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y,
   static int enabled = getenv("DFHIP_ROWMMA") ? atoi(getenv("DFHIP_ROWMMA")) : 1;
   static int variant = getenv("DFHIP_ROWMMA_VARIANT") ? atoi(getenv("DFHIP_ROWMMA_VARIANT")) : 0;
   if (!enabled || k != 3 || stride != 1 || pad != 1) return -1;
+  if (W == 4 && H == 4 && C == 128) {
+    const int st4 = run_conv_img4_fwd(x, w, bias, y, N, C, O, partials, cap_rows, rows_out, bn, dry_run);
+    if (st4 >= 0) return st4;
+  }
   const int64_t HW = (int64_t)H * W;
   if (HW % 16 != 0) return -1;
   const int64_t tiles = (int64_t)N * HW / 16;
