@@ -637,7 +637,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
   }
   __syncthreads();
   if (wave != 0) return;
-#pragma unroll
+  // (one wave's tile at a time: fully unrolled the compiler requests all 56 vectors before the first addition and
+  // spills)
+#pragma unroll 1
   for (int ww = 0; ww < 7; ww++)
 #pragma unroll
     for (int q = 0; q < 8; q++) acc[q] += ex[(ww * 8 + q) * 64 + lane];
