@@ -390,6 +390,145 @@ int launch_s2(const float* x, const float* w, const float* wd, float* y, float* 
   return launch_s2_<C, OWW, TS, OWG, CG, XA, KS, false>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The pair on 4 x 4 images (ResNet layer4's first block, 128 -> 256 channels, outputs 2 x 2) with an IMAGE on the lane,
+// as k_conv3x3_img4_fwd (dfhip_conv_rows.hip): D[16 output channels][16 images], an accumulator per output pixel and
+// output, and a tap whose source lies outside the image is not multiplied -- 25 of the 36 (pixel, tap) pairs of the
+// stride-2 convolution exist, + the shortcut's four.  16 images x 16 output channels (of both convolutions) per
+// workgroup, eight waves x 16 source channels streamed eight at a time through wave-private LDS areas (weight
+// records and planes in memory order), two waves per SIMD: the register-operand kernel above runs this shape with one
+// wave per SIMD and its loop at 55 % of the pipe rate.
+// ---------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512) void k_conv3x3s2_img4_pair(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ wd, float* __restrict__ y,
+                                                             float* __restrict__ yd, float* __restrict__ partials,
+                                                             float* __restrict__ partials_d, int O) {
+  constexpr int CW = C / 8, NCHK = CW / 8, WP = 17, XP = 33;
+  constexpr int WSL = 72 * WP + 8 * WP + 16 * XP * 4;      // weights [72][17], shortcut weights [8][17], planes [16][33] float4
+  extern __shared__ __attribute__((aligned(16))) float smem_p4[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 4, n = lane & 15;
+  const int n0 = blockIdx.x * 16, o0 = blockIdx.y * 16;
+  float* Wl = smem_p4 + wave * WSL;
+  float* Dl = Wl + 72 * WP;
+  float* Xs = Dl + 8 * WP;
+  const int cb = wave * CW;
+  f32x4 wq[5], xq[8];
+  f32x2 dq;
+  auto request = [&](int ch) {
+    const int c0 = cb + 8 * ch;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int e = min(lane + 64 * i, 287), m = e / 18, j = e - 18 * m;
+      wq[i] = *reinterpret_cast<const f32x4*>(w + ((int64_t)(o0 + m) * C + c0) * 9 + 4 * j);
+    }
+    // shortcut weights: 16 output channels x 8 channels = 64 pairs of floats (lane: channel o = lane / 4, pair lane % 4)
+    dq = *reinterpret_cast<const f32x2*>(wd + (int64_t)(o0 + (lane >> 2)) * C + c0 + 2 * (lane & 3));
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = lane + 64 * i, im = e >> 5, j = e & 31;
+      xq[i] = *reinterpret_cast<const f32x4*>(x + ((int64_t)(n0 + im) * C + c0) * 16 + 4 * j);
+    }
+  };
+  f32x4 acc[4], accd[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; accd[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  request(0);
+#pragma unroll
+  for (int ch = 0; ch < NCHK; ch++) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const int e = lane + 64 * i, m = min(e, 287) / 18, j = min(e, 287) - 18 * m;
+      if (e < 288) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) Wl[(4 * j + t) * WP + m] = wq[i][t];
+      }
+    }
+    Dl[(2 * (lane & 3)) * WP + (lane >> 2)] = dq[0];
+    Dl[(2 * (lane & 3) + 1) * WP + (lane >> 2)] = dq[1];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int e = lane + 64 * i, im = e >> 5, j = e & 31;
+      *reinterpret_cast<f32x4*>(Xs + (im * XP + j) * 4) = xq[i];
+    }
+    if (ch + 1 < NCHK) request(ch + 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float a[2][9], ad[2];
+    f32x4 xr[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+      for (int t = 0; t < 9; t++) a[p][t] = Wl[((4 * p + kk) * 9 + t) * WP + n];
+      ad[p] = Dl[(4 * p + kk) * WP + n];
+#pragma unroll
+      for (int r = 0; r < 4; r++) xr[p][r] = *reinterpret_cast<const f32x4*>(Xs + (n * XP + (4 * p + kk) * 4 + r) * 4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int oy = 0; oy < 2; oy++)
+#pragma unroll
+        for (int ox = 0; ox < 2; ox++) {
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+              const int sy = 2 * oy + i - 1, sx = 2 * ox + j - 1;
+              if (sy >= 0 && sy < 4 && sx >= 0 && sx < 4)
+                acc[oy * 2 + ox] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][i * 3 + j], xr[p][sy][sx], acc[oy * 2 + ox], 0, 0, 0);
+            }
+          accd[oy * 2 + ox] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad[p], xr[p][2 * oy][2 * ox], accd[oy * 2 + ox], 0, 0, 0);
+        }
+  }
+  __syncthreads();
+  f32x4* ex = reinterpret_cast<f32x4*>(smem_p4);
+  if (wave > 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { ex[((wave - 1) * 8 + q) * 64 + lane] = acc[q]; ex[((wave - 1) * 8 + 4 + q) * 64 + lane] = accd[q]; }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll 1
+  for (int ww = 0; ww < 7; ww++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) { acc[q] += ex[(ww * 8 + q) * 64 + lane]; accd[q] += ex[(ww * 8 + 4 + q) * 64 + lane]; }
+  // register v of lane (kk, n) is output channel o0 + 4 kk + v of image n0 + n; its four output pixels are adjacent
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const int64_t at = ((int64_t)(n0 + n) * O + o0 + 4 * kk + v) * 4;
+    *reinterpret_cast<f32x4*>(y + at) = (f32x4){acc[0][v], acc[1][v], acc[2][v], acc[3][v]};
+    *reinterpret_cast<f32x4*>(yd + at) = (f32x4){accd[0][v], accd[1][v], accd[2][v], accd[3][v]};
+  }
+  if (partials) {
+    // exact two-pass over the 64 values of a channel (both outputs): the lane's four pixels, then the 16 images
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const float m1 = row_sum16b((acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v])) * (1.0f / 64.0f);
+      const float m2 = row_sum16b((accd[0][v] + accd[1][v]) + (accd[2][v] + accd[3][v])) * (1.0f / 64.0f);
+      float q1 = 0.0f, q2 = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float d1 = acc[q][v] - m1, d2 = accd[q][v] - m2;
+        q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2);
+      }
+      q1 = row_sum16b(q1); q2 = row_sum16b(q2);
+      if (n == 0) {
+        float* o1 = partials + ((int64_t)blockIdx.x * O + o0 + 4 * kk + v) * 3;
+        float* o2 = partials_d + ((int64_t)blockIdx.x * O + o0 + 4 * kk + v) * 3;
+        o1[0] = 64.0f; o1[1] = m1; o1[2] = q1;
+        o2[0] = 64.0f; o2[1] = m2; o2[2] = q2;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 namespace dfhip {
@@ -400,6 +539,23 @@ int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y
                        int O, float* partials, float* partials_d, int cap_rows, int* rows_out, bool dry_run) {
   static int enabled = getenv("DFHIP_S2_PAIR") ? atoi(getenv("DFHIP_S2_PAIR")) : 1;
   if (!enabled || H != W) return -1;
+  static int img4 = getenv("DFHIP_S2_IMG4") ? atoi(getenv("DFHIP_S2_IMG4")) : 1;
+  if (img4 && C == 128 && H == 4 && N % 16 == 0 && O % 16 == 0 && (!partials || N / 16 <= cap_rows) &&
+      (int64_t)(N / 16) * (O / 16) >= num_cus() / 2) {
+    // an image on the lane, taps outside the image not multiplied (k_conv3x3s2_img4_pair)
+    if (rows_out) *rows_out = partials ? N / 16 : 0;
+    if (dry_run) return DFHIP_OK;
+    dim3 grid4((unsigned)(N / 16), (unsigned)(O / 16));
+    const size_t lds4 = std::max((size_t)8 * (72 * 17 + 8 * 17 + 16 * 33 * 4), (size_t)7 * 8 * 64 * 4) * sizeof(float);
+    static bool attr4 = false;
+    if (!attr4) {
+      DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3s2_img4_pair<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+      attr4 = true;
+    }
+    DF_LAUNCH(k_conv3x3s2_img4_pair<128>, grid4, dim3(512), lds4, stream(), x, w, wd, y, yd, partials, partials_d, O);
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
   static int variant = getenv("DFHIP_S2_VARIANT") ? atoi(getenv("DFHIP_S2_VARIANT")) : 0;
   int otw, ts, owg, lwo;
   if (C == 32 && H == 16) { otw = 2; ts = 4; owg = 2; lwo = 3; }
