@@ -46,7 +46,7 @@ FAMILIES = {
     "conv2d_wgrad_grouped": ("k_wgrad_group",),
     "conv2d_wgrad_igemm": ("k_conv_wgrad_rows", "k_conv_wgrad_v3", "k_conv_wgrad_tap", "k_conv_wgrad<", "k_wgrad_tap_sum",
                            "k_flat_slab_sum", "k_wgrad_stem3"),
-    "conv2d_fwd_igemm": ("k_conv3x3_rowmma", "k_conv3x3s2_pair", "k_conv_igemm_v4<3, 0", "k_conv_igemm_v4<1, 0", "k_conv_igemm$", "k_conv_rows3", "k_conv1x1s2_fwd", "k_conv3x3_img2_fwd", "k_conv3x3_img2_all", "k_conv3x3_img4_fwd"),
+    "conv2d_fwd_igemm": ("k_conv3x3_rowmma", "k_conv3x3s2_pair", "k_conv3x3s2_img4_pair", "k_conv_igemm_v4<3, 0", "k_conv_igemm_v4<1, 0", "k_conv_igemm$", "k_conv_rows3", "k_conv1x1s2_fwd", "k_conv3x3_img2_fwd", "k_conv3x3_img2_all", "k_conv3x3_img4_fwd"),
     "conv2d_dgrad_igemm": ("k_conv_igemm_v4<3, 1", "k_conv_igemm_v4<1, 1"),
     "conv2d_dgrad_overwrite_igemm": ("k_conv_igemm_v4<3, 2", "k_conv_igemm_v4<1, 2", "k_dgrad_ow_s1", "k_dgrad_ow_img"),
     "bn2d_fwd": ("k_bn_apply_partials", "k_bn_finalize_partials", "k_bn_stats", "k_bn_apply"),
