@@ -249,6 +249,35 @@ def test_stem_kernel_partials_bands_and_walking_workgroups(hip_device, C, H, O, 
     assert_close(m2 / cnt, y64.var(axis=(0, 2, 3)), 2e-5, "partials variance")
 
 
+@pytest.mark.parametrize("N,C,HW,O,with_bias", [(256, 128, 4, 48, True), (128, 128, 4, 128, False), (64, 256, 2, 80, True),
+                                                (32, 128, 2, 256, True)])
+def test_image_per_lane_forward_kernels(hip_device, N, C, HW, O, with_bias):
+    """k_conv3x3_img4_fwd / k_conv3x3_img2_all (3x3 / stride 1 / pad 1 on 4 x 4 and 2 x 2 images, an image on the lane,
+    padding taps not multiplied): output against the oracle with a bias and ragged channel-tile counts, and the
+    BatchNorm partials (count, mean, centred second moment per workgroup and channel) against the output's statistics."""
+    from conftest import assert_close
+    from oracle import ref_ops as R
+    mod = hip_device.mod
+    rng = np.random.default_rng(N + C + O)
+    x = (rng.standard_normal((N, C, HW, HW)) + 0.5).astype(np.float32)
+    w = (rng.standard_normal((O, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+    b = rng.standard_normal(O).astype(np.float32) if with_bias else None
+    yh, ph = mod.Array(N * O * HW * HW), mod.Array(512 * O * 3)
+    rows = mod.conv2d_forward_stats(_arr(mod, x), _arr(mod, w), _arr(mod, b) if with_bias else None, yh,
+                                    N, C, HW, HW, O, 3, 1, 1, ph, 512)
+    y_ref = R.conv2d_forward(x, w, b.reshape(1, O, 1, 1) if with_bias else None, 1, 1)
+    assert_close(_back(mod, yh).reshape(y_ref.shape), y_ref, 1e-4, "image-per-lane forward")
+    assert rows > 0
+    part = _back(mod, ph).reshape(512, O, 3)[:rows].astype(np.float64)
+    cnt = part[:, :, 0].sum(axis=0)
+    mu = (part[:, :, 0] * part[:, :, 1]).sum(axis=0) / cnt
+    m2 = (part[:, :, 2] + part[:, :, 0] * (part[:, :, 1] - mu) ** 2).sum(axis=0)
+    assert np.all(cnt == N * HW * HW)
+    y64 = y_ref.astype(np.float64)
+    assert_close(mu, y64.mean(axis=(0, 2, 3)), 1e-5, "partials mean")
+    assert_close(m2 / cnt, y64.var(axis=(0, 2, 3)), 2e-5, "partials variance")
+
+
 @pytest.mark.parametrize("C,H,O,N", [(3, 32, 32, 16), (1, 8, 5, 3), (2, 2, 32, 300), (3, 30, 17, 7)])
 def test_stem_weight_gradient_kernel(hip_device, C, H, O, N):
     """k_wgrad_stem3 stand-alone (dY given): fewer images than CUs, more images than workgroups (a workgroup walks
