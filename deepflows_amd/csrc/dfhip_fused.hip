@@ -43,10 +43,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
   return (r0 + r1) + (r2 + r3);
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
-  return v;
+__device__ __forceinline__ float wave_max(float v) {      // (the same value in every lane)
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, true)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, true)));
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 // block-wide sum, result valid in every thread
 __device__ __forceinline__ float block_sum(float v, float* sh /* >= 4 floats */) {
@@ -73,10 +79,7 @@ __device__ __forceinline__ void rows_add(RowSums& t, float nb, float mub, float 
 }
 // sw: 12 floats of LDS not in use by anyone else between the two barriers inside
 __device__ __forceinline__ void rows_finish(RowSums t, float s, float (*sw)[3], float& mean, float& var) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    t.n += __shfl_xor(t.n, o, 64); t.a1 += __shfl_xor(t.a1, o, 64); t.a2 += __shfl_xor(t.a2, o, 64);
-  }
+  t.n = wave_sum(t.n); t.a1 = wave_sum(t.a1); t.a2 = wave_sum(t.a2);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) { sw[threadIdx.x >> 6][0] = t.n; sw[threadIdx.x >> 6][1] = t.a1; sw[threadIdx.x >> 6][2] = t.a2; }
   __syncthreads();
@@ -499,11 +502,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials_pair(BnFwdSet A,
     rows_add(tb, q[0], q[1], q[2], shift_b);
   }
   // the two sets side by side: butterflies, one barrier pair, the four waves in a fixed order
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    ta.n += __shfl_xor(ta.n, o, 64); ta.a1 += __shfl_xor(ta.a1, o, 64); ta.a2 += __shfl_xor(ta.a2, o, 64);
-    tb.n += __shfl_xor(tb.n, o, 64); tb.a1 += __shfl_xor(tb.a1, o, 64); tb.a2 += __shfl_xor(tb.a2, o, 64);
-  }
+  ta.n = wave_sum(ta.n); ta.a1 = wave_sum(ta.a1); ta.a2 = wave_sum(ta.a2);
+  tb.n = wave_sum(tb.n); tb.a1 = wave_sum(tb.a1); tb.a2 = wave_sum(tb.a2);
   if ((tid & 63) == 0) {
     sw[0][tid >> 6][0] = ta.n; sw[0][tid >> 6][1] = ta.a1; sw[0][tid >> 6][2] = ta.a2;
     sw[1][tid >> 6][0] = tb.n; sw[1][tid >> 6][1] = tb.a1; sw[1][tid >> 6][2] = tb.a2;
@@ -1022,11 +1022,9 @@ __global__ __launch_bounds__(kThreads) void k_ce_rows(const float* __restrict__ 
     float m = -INFINITY;
     for (int j = lane; j < cols; j += 64) m = fmaxf(m, x[j]);
     m = wave_max(m);
-    m = __shfl(m, 0, 64);
     float se = 0.0f;
     for (int j = lane; j < cols; j += 64) se += expf(x[j] - m);
     se = wave_sum(se);
-    se = __shfl(se, 0, 64);
     float lse = logf(se);
     float acc = 0.0f;
     for (int j = lane; j < cols; j += 64) acc += -((x[j] - m) - lse) * t[j];
@@ -1102,8 +1100,7 @@ __global__ __launch_bounds__(1024) void k_ce_small(const float* __restrict__ log
         if (j < cols) d[j] = gu[j] + (xv[j] == m ? -gsum : 0.0f);
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+  tot = wave_sum(tot);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = tot;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1129,18 +1126,18 @@ __global__ __launch_bounds__(kThreads) void k_ce_bwd(const float* __restrict__ l
     float* d = dlogits + (int64_t)r * cols;
     float m = -INFINITY;
     for (int j = lane; j < cols; j += 64) m = fmaxf(m, x[j]);
-    m = __shfl(wave_max(m), 0, 64);
+    m = wave_max(m);
     float se = 0.0f, st = 0.0f;
     for (int j = lane; j < cols; j += 64) {
       se += expf(x[j] - m);
       st += t[j];
     }
-    se = __shfl(wave_sum(se), 0, 64);
-    st = __shfl(wave_sum(st), 0, 64);
+    se = wave_sum(se);
+    st = wave_sum(st);
     // g_u[j] = gs * (softmax_j * sum(t) - t_j); the max() node routes -sum_j g_u to the ties
     float gsum = 0.0f;
     for (int j = lane; j < cols; j += 64) gsum += gs * t[j] * -1.0f + expf(x[j] - m) * ((gs * st) / se);
-    gsum = __shfl(wave_sum(gsum), 0, 64);
+    gsum = wave_sum(gsum);
     for (int j = lane; j < cols; j += 64) {
       float gu = gs * t[j] * -1.0f + expf(x[j] - m) * ((gs * st) / se);
       d[j] = gu + (x[j] == m ? -gsum : 0.0f);
@@ -1470,10 +1467,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_partials(BnInput bn, int C)
   RowSums t = {0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int k = 0; k < RP; k++) rows_add(t, pn[k], pm[k], pq[k], shift);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    t.n += __shfl_xor(t.n, o, 64); t.a1 += __shfl_xor(t.a1, o, 64); t.a2 += __shfl_xor(t.a2, o, 64);
-  }
+  t.n = wave_sum(t.n); t.a1 = wave_sum(t.a1); t.a2 = wave_sum(t.a2);
   if (lane != 0) return;
   const float n = t.n;
   const float mu_s = n > 0.0f ? t.a1 / n : 0.0f;
@@ -1498,8 +1492,7 @@ __device__ __forceinline__ void head_block_sum(float (&acc)[P], float (*sh)[P]) 
 #pragma unroll
   for (int j = 0; j < P; j++) {
     float v = acc[j];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = wave_sum(v);
     if (lane == 0) sh[wave][j] = v;
   }
   __syncthreads();
@@ -1661,8 +1654,7 @@ __global__ __launch_bounds__(1024) void k_pool_linear_bwd(const float* __restric
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int j = 0; j < P; j++) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+    acc[j] = wave_sum(acc[j]);
     if (lane == 0) sdy[wave * P + j] = acc[j];
   }
   __syncthreads();
