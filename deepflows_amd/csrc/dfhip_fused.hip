@@ -70,6 +70,13 @@ __device__ __forceinline__ float block_sum(float v, float* sh /* >= 4 floats */)
 // value in every thread of every block of the channel), and mean = s + A1 / n, M2 = A2 - A1^2 / n.  Chan's pairwise
 // update in a shuffle tree was two IEEE divisions per level, nine levels: ~1 us on the critical path of every
 // BatchNorm forward kernel.
+// a per-channel parameter (gamma / beta; nullptr = `dflt`) REQUESTED where this is called: at the top of a kernel, in
+// front of its barriers -- read where it is used (behind the statistics' barriers) it is a global round trip of its
+// own on the critical path of a 5 us kernel.  `any` = any valid array of C floats (the load is unconditional).
+__device__ __forceinline__ float chan_param(const float* p, const float* any, int c, float dflt) {
+  const float v = (p ? p : any)[c];
+  return p ? v : dflt;
+}
 struct RowSums { float n, a1, a2; };
 __device__ __forceinline__ void rows_add(RowSums& t, float nb, float mub, float m2b, float s) {
   const float d = nb > 0.0f ? mub - s : 0.0f;
@@ -282,6 +289,9 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(
     const float* __restrict__ partial, float* __restrict__ dx, float* __restrict__ dgamma,
     float* __restrict__ dbeta, int N, int C, int HW, int S, int ipb, float eps) {
   const int c = blockIdx.x, s = blockIdx.y;
+  // (the channel's constants are requested in front of the slices' sums, not behind their loop)
+  const float mean = save_mean[c], var_c = save_var[c];
+  const float w = chan_param(gamma, save_mean, c, 1.0f);
   float sdy = 0.0f, sdyx = 0.0f;
   for (int i = 0; i < S; i++) {
     sdy += partial[((int64_t)c * S + i) * 2];
@@ -292,9 +302,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(
     if (dbeta) dbeta[c] = sdy;
   }
   if (!dx) return;
-  const float mean = save_mean[c], sd = sqrtf(save_var[c] + eps);
+  const float sd = sqrtf(var_c + eps);
   const float rsd = 1.0f / sd;   // one division per thread: (x - mean) / sd becomes a multiply
-  const float w = gamma ? gamma[c] : 1.0f;
   const float m = (float)N * (float)HW;
   const float k1 = sdy / m, k2 = sdyx / m;
   const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
@@ -342,6 +351,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
   const bool fast = (HW & 3) == 0 && (n_hi - n_lo) * hw4 <= 2 * kThreads;
   float p0, p1, p2;
   const float shift = partials[(int64_t)c * 3 + 1];          // row 0's mean
+  const float w = chan_param(gamma, partials, c, 1.0f), b = chan_param(beta, partials, c, 0.0f);
   {
     const float* p = partials + ((int64_t)min(tid, rows - 1) * C + c) * 3;      // (clamped: no load under a condition)
     p0 = p[0]; p1 = p[1]; p2 = p[2];
@@ -380,7 +390,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials(
   }
   const float sd = sqrtf(var + eps);
   const float rsd = 1.0f / sd;   // one division per thread: (x - mean) / sd becomes a multiply
-  const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
   if (fast) {
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -473,6 +482,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials_pair(BnFwdSet A,
     if (tid < B.rows) { pb[0] = b0; pb[1] = b1; pb[2] = b2; }
   }
   const float shift_a = A.partials[(int64_t)c * 3 + 1], shift_b = B.partials[(int64_t)c * 3 + 1];   // row 0's means
+  const float wa = chan_param(A.gamma, A.partials, c, 1.0f), ba = chan_param(A.beta, A.partials, c, 0.0f);
+  const float wb = chan_param(B.gamma, B.partials, c, 1.0f), bb = chan_param(B.beta, B.partials, c, 0.0f);
   __builtin_amdgcn_sched_barrier(0);
   int64_t off[2] = {0, 0};
   bool have[2] = {false, false};
@@ -537,8 +548,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials_pair(BnFwdSet A,
     if (B.running_var) B.running_var[c] = B.running_var[c] * (1.0f - B.momentum) + varb * B.momentum;
   }
   const float ra = 1.0f / sqrtf(vara + A.eps), rb = 1.0f / sqrtf(varb + B.eps);
-  const float wa = A.gamma ? A.gamma[c] : 1.0f, ba = A.beta ? A.beta[c] : 0.0f;
-  const float wb = B.gamma ? B.gamma[c] : 1.0f, bb = B.beta ? B.beta[c] : 0.0f;
   if (fast) {
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -641,6 +650,7 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_pool_fwd(
     int C, int H, int W, int ipb, float eps, float momentum) {
   __shared__ float sw[4][3];
   const int c = blockIdx.x, s = blockIdx.y;
+  const float w = chan_param(gamma, partial, c, 1.0f), b = chan_param(beta, partial, c, 0.0f);   // (requested up front)
   float mean, var;
   if (S < 0) bn_combine_rows(partial, -S, C, c, sw, mean, var);
   else bn_combine(partial, c, S, mean, var);
@@ -652,7 +662,6 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_pool_fwd(
   }
   const float sd = sqrtf(var + eps);
   const float rsd = 1.0f / sd;
-  const float w = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
   const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
   const int oh = H >> 1, ow = W >> 1, ow4 = ow >> 2;
   const int items = (n_hi - n_lo) * oh * ow4;
@@ -844,6 +853,7 @@ __device__ __forceinline__ void bn_fused_bwd_body(int c, const float* __restrict
   const int hw4 = HW >> 2, nvec = N * hw4;
   const int64_t img_stride = (int64_t)C * HW;
   const float mean = save_mean[c], sd = sqrtf(save_var[c] + eps);
+  const float w = chan_param(gamma, save_mean, c, 1.0f);
   const float rsd = 1.0f / sd;   // one division per thread: (x - mean) / sd becomes a multiply
   const float* xb = x + (int64_t)c * HW;
   const float* gb = dy + (int64_t)c * HW;
@@ -877,7 +887,6 @@ __device__ __forceinline__ void bn_fused_bwd_body(int c, const float* __restrict
     if (dbeta) dbeta[c] = sdy;
   }
   if (!dx) return;
-  const float w = gamma ? gamma[c] : 1.0f;
   const float m = (float)N * (float)HW;
   const float k1 = sdy / m, k2 = sdyx / m;
   float* db = dx + (int64_t)c * HW;
@@ -1463,6 +1472,8 @@ __global__ __launch_bounds__(256) void k_bn_finalize_partials(BnInput bn, int C)
   }
   // one butterfly over three shifted sums (rows_add above; the shift is row 0's mean) instead of the weighted mean
   // first and the centred moment about it second
+  const float g_c = chan_param(bn.gamma, bn.part, c, 1.0f), b_c = chan_param(bn.beta, bn.part, c, 0.0f);   // (up front)
+  const float rm_c = chan_param(bn.running_mean, bn.part, c, 0.0f), rv_c = chan_param(bn.running_var, bn.part, c, 0.0f);
   const float shift = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pm[0])));
   RowSums t = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -1474,12 +1485,12 @@ __global__ __launch_bounds__(256) void k_bn_finalize_partials(BnInput bn, int C)
   const float mu = shift + mu_s;
   const float var = n > 0.0f ? fmaxf(t.a2 - t.a1 * mu_s, 0.0f) / n : 0.0f;           // biased variance (batchnorm.py:41-42)
   const float rsd = 1.0f / sqrtf(var + bn.eps);
-  const float sc = (bn.gamma ? bn.gamma[c] : 1.0f) * rsd;
-  const float sh = (bn.beta ? bn.beta[c] : 0.0f) - mu * sc;
+  const float sc = g_c * rsd;
+  const float sh = b_c - mu * sc;
   if (bn.save_mean) bn.save_mean[c] = mu;
   if (bn.save_var) bn.save_var[c] = var;
-  if (bn.running_mean) bn.running_mean[c] = bn.running_mean[c] * (1.0f - bn.momentum) + mu * bn.momentum;
-  if (bn.running_var) bn.running_var[c] = bn.running_var[c] * (1.0f - bn.momentum) + var * bn.momentum;
+  if (bn.running_mean) bn.running_mean[c] = rm_c * (1.0f - bn.momentum) + mu * bn.momentum;
+  if (bn.running_var) bn.running_var[c] = rv_c * (1.0f - bn.momentum) + var * bn.momentum;
   bn.affine[2 * c] = sc;
   bn.affine[2 * c + 1] = sh;
 }
