@@ -224,11 +224,21 @@ def main():
                          "pass (costs ~0.1 ms of split / event overhead per step: only pays for slow links)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: this process becomes the spawner of the N ranks (same command line, one child per
+        # GPU) and never touches HIP itself -- nothing of the package has been imported yet, and launch.py is
+        # standard library only (loaded by path so that not even the package's __init__ runs here)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_df_launch", os.path.join(ROOT, "deepflows_amd", "launch.py"))
+        launch = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(launch)
+        rc, _ = launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        sys.exit(rc)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != max(1, args.gpus):
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        sys.exit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     from deepflows_amd import backend_api, parallel, workloads
     from deepflows_amd.tensor import Graph
@@ -352,6 +362,7 @@ def main():
             roofline["algorithmic_bytes_per_launch"] = prof[dom]["bytes"] / prof[dom]["calls"]
             roofline["algorithmic_flops_per_launch"] = prof[dom]["flops"] / prof[dom]["calls"]
         exchanged = bucket.total if sync is not None else 0
+        rccl_ranks = mod.comm_count()[0] if comm.exchanges else None
         out = {
             "metric": wl["metric"],
             "value": value, "unit": "images/s", "n_gpus": comm.world, "steps": args.steps,
@@ -361,6 +372,8 @@ def main():
                        "global_batch": batch * comm.world, "parallelism": f"dp{comm.world}",
                        "conv_dgrad": args.dgrad, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,
                        "allreduce_elems": exchanged,
+                       # what the communicator itself reports (ncclCommCount), not the launcher's environment
+                       "rccl_ranks": rccl_ranks,
                        "collective_library": mod.comm_rccl_path() if sync is not None else None},
             "gpu_ms_per_step": gpu_ms / args.steps, "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
             "final_loss": final_loss,

@@ -943,6 +943,8 @@ static int (*p_ncclCommInitRank)(df_nccl_comm*, int, df_nccl_uid, int) = nullptr
 static int (*p_ncclAllReduce)(const void*, void*, size_t, int, int, df_nccl_comm, hipStream_t) = nullptr;
 static int (*p_ncclCommDestroy)(df_nccl_comm) = nullptr;
 static const char* (*p_ncclGetErrorString)(int) = nullptr;
+static int (*p_ncclCommCount)(df_nccl_comm, int*) = nullptr;
+static int (*p_ncclCommUserRank)(df_nccl_comm, int*) = nullptr;
 static df_nccl_comm g_comm = nullptr;
 static int g_world = 1;
 
@@ -966,6 +968,8 @@ static int load_rccl() {
   p_ncclAllReduce = (decltype(p_ncclAllReduce))dlsym(g_rccl, "ncclAllReduce");
   p_ncclCommDestroy = (decltype(p_ncclCommDestroy))dlsym(g_rccl, "ncclCommDestroy");
   p_ncclGetErrorString = (decltype(p_ncclGetErrorString))dlsym(g_rccl, "ncclGetErrorString");
+  p_ncclCommCount = (decltype(p_ncclCommCount))dlsym(g_rccl, "ncclCommCount");
+  p_ncclCommUserRank = (decltype(p_ncclCommUserRank))dlsym(g_rccl, "ncclCommUserRank");
   if (!p_ncclGetUniqueId || !p_ncclCommInitRank || !p_ncclAllReduce || !p_ncclCommDestroy) {
     set_error("librccl is missing a required symbol");
     return DFHIP_RUNTIME_ERROR;
@@ -1059,6 +1063,15 @@ int dfhip_comm_allreduce_max(float* value) {
   DF_NCCL(p_ncclAllReduce(d, d, 1, 7, 2, g_comm, g_stream));
   DF_HIP(hipMemcpyAsync(value, d, sizeof(float), hipMemcpyDeviceToHost, g_stream));
   DF_HIP(hipStreamSynchronize(g_stream));
+  return DFHIP_OK;
+}
+
+int dfhip_comm_count(int* ranks, int* rank) {
+  // what the communicator itself says (ncclCommCount / ncclCommUserRank), not what the launcher's environment said
+  DF_CHECK_ARG(g_comm && ranks && rank, "comm_count: no communicator / null output");
+  DF_CHECK_ARG(p_ncclCommCount && p_ncclCommUserRank, "librccl has no ncclCommCount / ncclCommUserRank");
+  DF_NCCL(p_ncclCommCount(g_comm, ranks));
+  DF_NCCL(p_ncclCommUserRank(g_comm, rank));
   return DFHIP_OK;
 }
 

@@ -514,6 +514,12 @@ class HipModule:
         _lib.check(self._lib.dfhip_comm_rccl_path(buf, 512))
         return buf.value.decode()
 
+    def comm_count(self):
+        """(ranks, rank) as the RCCL communicator reports them."""
+        n, r = c_int(0), c_int(0)
+        _lib.check(self._lib.dfhip_comm_count(byref(n), byref(r)))
+        return int(n.value), int(r.value)
+
     def comm_destroy(self):
         self._lib.dfhip_comm_destroy()
 

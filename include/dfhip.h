@@ -390,6 +390,8 @@ int dfhip_comm_wait(void);
 int dfhip_comm_allreduce_max(float* value);
 /* path of the shared object the RCCL symbols were resolved from ("" before dfhip_comm_unique_id / _init) */
 int dfhip_comm_rccl_path(char* out, int cap);
+/* size of the communicator and this process's rank in it, as RCCL reports them (ncclCommCount / ncclCommUserRank) */
+int dfhip_comm_count(int* ranks, int* rank);
 int dfhip_comm_destroy(void);
 
 /* Host helper (no device call): the float32 mask np.random.binomial(1, keep, n) would draw next from NumPy's legacy

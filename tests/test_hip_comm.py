@@ -153,5 +153,6 @@ def test_bench_exchange_path_runs_on_one_gpu():
     assert d["config"]["allreduce_elems"] == 2797610
     assert d["config"]["dispatch"] == "hipgraph" and d["n_gpus"] == 1
     assert d["config"]["collective_library"].startswith("/opt/rocm"), d["config"]["collective_library"]
+    assert d["config"]["rccl_ranks"] == 1                 # ncclCommCount of the communicator itself
     assert "rccl_allreduce" in d["kernels"]
     assert d["value"] > 0 and np.isfinite(d["final_loss"])

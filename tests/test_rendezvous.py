@@ -73,3 +73,44 @@ def test_the_package_does_not_import_torch():
             "graph_step, workloads, utils; assert 'torch' not in sys.modules, 'torch was imported'" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_a_rank_of_another_job_is_turned_away(tmp_path):
+    """a peer with a valid rank number but another job's token must not take a slot or get the id."""
+    import threading
+    sys.path.insert(0, ROOT)
+    from deepflows_amd import launch, rendezvous
+    port = launch.free_port_pair()
+    addr = ("127.0.0.1", port)
+    mine, other = rendezvous.job_token({"MASTER_PORT": "1", "DF_RUN_ID": "a"}), rendezvous.job_token({"MASTER_PORT": "1", "DF_RUN_ID": "b"})
+    assert mine != other and len(mine) == 16
+    got = {}
+
+    def serve():
+        got[0] = rendezvous.broadcast_from_rank0(b"x" * 128, 0, 2, timeout=30, address=addr, token=mine)
+    t = threading.Thread(target=serve)
+    t.start()
+    import pytest
+    with pytest.raises(PermissionError):
+        rendezvous.broadcast_from_rank0(b"", 1, 2, timeout=10, address=addr, token=other)
+    assert t.is_alive()                                  # the stranger consumed no slot: rank 0 is still waiting
+    assert rendezvous.broadcast_from_rank0(b"", 1, 2, timeout=10, address=addr, token=mine) == b"x" * 128
+    t.join(timeout=10)
+    assert got[0] == b"x" * 128
+
+
+def test_rank0_falls_back_to_every_interface_when_master_addr_is_not_local():
+    import threading
+    sys.path.insert(0, ROOT)
+    from deepflows_amd import launch, rendezvous
+    port = launch.free_port_pair()
+    tok = rendezvous.job_token({"DF_RUN_ID": "bind"})
+    got = {}
+
+    def serve():                                         # 192.0.2.1 (TEST-NET-1) is no address of this host
+        got[0] = rendezvous.broadcast_from_rank0(b"y" * 128, 0, 2, timeout=30, address=("192.0.2.1", port), token=tok)
+    t = threading.Thread(target=serve)
+    t.start()
+    assert rendezvous.broadcast_from_rank0(b"", 1, 2, timeout=20, address=("127.0.0.1", port), token=tok) == b"y" * 128
+    t.join(timeout=10)
+    assert got[0] == b"y" * 128
