@@ -91,6 +91,8 @@ _SIGS = {
     "dfhip_adam_hyper_table": [P, c_int, c_double, c_double, c_double, c_double, c_double, c_int, c_double],
     "dfhip_adam_step_dev": [c_int, PP, PP, PP, PP, I64P, P],
     "dfhip_sgd_step": [c_int, PP, PP, PP, I64P, c_double, c_double, c_double, c_int, c_double],
+    "dfhip_sgd_hyper": [P, c_double, c_double, c_double, c_int, c_double],
+    "dfhip_sgd_step_dev": [c_int, PP, PP, PP, I64P, P],
     "dfhip_pack": [c_int, PP, I64P, P],
     "dfhip_unpack": [c_int, PP, I64P, P],
     "dfhip_comm_unique_id": [c_char_p],

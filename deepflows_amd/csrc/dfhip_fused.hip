@@ -1394,7 +1394,20 @@ struct SgdHyper {
   int nesterov, use_momentum;
 };
 
-__global__ __launch_bounds__(kThreads) void k_sgd(TensorBatch tb, SgdHyper h) {
+__device__ __forceinline__ void sgd_block(const TensorBatch& tb, const SgdHyper& h);
+
+__global__ __launch_bounds__(kThreads) void k_sgd(TensorBatch tb, SgdHyper h) { sgd_block(tb, h); }
+
+// the same update with the scalars read from device memory (dfhip_sgd_hyper writes them): inside a captured training
+// step the launch is replayed unchanged while a learning-rate schedule keeps moving the scalars from the host
+__global__ __launch_bounds__(kThreads) void k_sgd_dev(TensorBatch tb, const float* __restrict__ hyper_dev) {
+  const SgdHyper h = *reinterpret_cast<const SgdHyper*>(hyper_dev);
+  sgd_block(tb, h);
+}
+
+__global__ void k_set_sgd_hyper(float* hyper_dev, SgdHyper h) { *reinterpret_cast<SgdHyper*>(hyper_dev) = h; }
+
+__device__ __forceinline__ void sgd_block(const TensorBatch& tb, const SgdHyper& h) {
   int t = find_tensor(tb, blockIdx.x);
   int64_t lo = (int64_t)(blockIdx.x - tb.blk_start[t]) * kChunk;
   int64_t hi = min(tb.size[t], lo + kChunk);
@@ -2275,6 +2288,50 @@ int dfhip_adam_step_dev(int n_tensors, float* const* params, const float* const*
   return DFHIP_OK;
 }
 
+static SgdHyper make_sgd_hyper(double lr, double momentum, double weight_decay, int nesterov, double grad_scale) {
+  SgdHyper h;
+  h.lr = (float)lr;
+  h.mu = (float)momentum;
+  h.wd = (float)weight_decay;
+  h.gscale = (float)grad_scale;
+  h.nesterov = nesterov;
+  h.use_momentum = momentum > 0.0;
+  return h;
+}
+
+int dfhip_sgd_hyper(float* hyper_dev, double lr, double momentum, double weight_decay, int nesterov,
+                    double grad_scale) {
+  DF_INIT();
+  DF_CHECK_ARG(hyper_dev, "sgd_hyper: null array");
+  if (capturing()) {
+    set_error("sgd_hyper: the scalars are written in front of a captured step, not inside it");
+    return DFHIP_INVALID_ARGUMENT;
+  }
+  const SgdHyper h = make_sgd_hyper(lr, momentum, weight_decay, nesterov, grad_scale);
+  DF_LAUNCH(k_set_sgd_hyper, dim3(1), dim3(1), 0, stream(), hyper_dev, h);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+int dfhip_sgd_step_dev(int n_tensors, float* const* params, const float* const* grads,
+                       float* const* momentum_buf, const int64_t* sizes, const float* hyper_dev) {
+  DF_INIT();
+  DF_CHECK_ARG(n_tensors >= 0 && hyper_dev, "sgd_step_dev: bad arguments");
+  if (n_tensors == 0) return DFHIP_OK;
+  DF_CHECK_ARG(params && grads && sizes, "sgd_step_dev: null table");
+  double total = 0;
+  for (int i = 0; i < n_tensors; i++) total += (double)sizes[i];
+  ProfScope prof("sgd_step", 0.0, (momentum_buf ? 20.0 : 12.0) * total);
+  for (int first = 0; first < n_tensors; first += kBatch) {
+    int n = std::min(kBatch, n_tensors - first);
+    TensorBatch tb;
+    int blocks = fill_batch(tb, n, first, params, grads, momentum_buf, nullptr, sizes);
+    DF_LAUNCH(k_sgd_dev, dim3(blocks), dim3(kThreads), 0, stream(), tb, hyper_dev);
+    DF_LAUNCH_CHECK();
+  }
+  return DFHIP_OK;
+}
+
 int dfhip_sgd_step(int n_tensors, float* const* params, const float* const* grads,
                    float* const* momentum_buf, const int64_t* sizes, double lr, double momentum,
                    double weight_decay, int nesterov, double grad_scale) {
@@ -2283,13 +2340,7 @@ int dfhip_sgd_step(int n_tensors, float* const* params, const float* const* grad
   if (n_tensors == 0) return DFHIP_OK;
   DF_CHECK_ARG(params && grads && sizes, "sgd_step: null table");
   DF_CHECK_ARG(momentum <= 0.0 || momentum_buf, "sgd_step: momentum needs buffers");
-  SgdHyper h;
-  h.lr = (float)lr;
-  h.mu = (float)momentum;
-  h.wd = (float)weight_decay;
-  h.gscale = (float)grad_scale;
-  h.nesterov = nesterov;
-  h.use_momentum = momentum > 0.0;
+  const SgdHyper h = make_sgd_hyper(lr, momentum, weight_decay, nesterov, grad_scale);
   double total = 0;
   for (int i = 0; i < n_tensors; i++) total += (double)sizes[i];
   ProfScope prof("sgd_step", 0.0, (h.use_momentum ? 20.0 : 12.0) * total);

@@ -476,6 +476,15 @@ class HipModule:
         _lib.check(self._lib.dfhip_sgd_step(n, _ptr_table(params), _ptr_table(grads), mb, sizes, lr,
                                             momentum, weight_decay, int(bool(nesterov)), grad_scale))
 
+    def sgd_hyper(self, hyper, lr, momentum, weight_decay, nesterov, grad_scale=1.0):
+        _lib.check(self._lib.dfhip_sgd_hyper(hyper.ptr, lr, momentum, weight_decay, int(bool(nesterov)), grad_scale))
+
+    def sgd_step_dev(self, params, grads, momentum_buf, hyper):
+        n = len(params)
+        sizes = (c_int64 * n)(*[p.size for p in params])
+        mb = _ptr_table(momentum_buf) if momentum_buf else None
+        _lib.check(self._lib.dfhip_sgd_step_dev(n, _ptr_table(params), _ptr_table(grads), mb, sizes, hyper.ptr))
+
     def pack(self, srcs, flat):
         n = len(srcs)
         sizes = (c_int64 * n)(*[s.size for s in srcs])

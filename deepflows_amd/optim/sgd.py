@@ -16,12 +16,32 @@ class SGD(Optimizer):
         self.lr, self.momentum, self.weight_decay, self.nesterov = lr, momentum, weight_decay, nesterov
         self.v = [backend_api.zeros(p.shape, device=p.device) for p in self.params]
 
-    # graph_step.CapturedTrainStep: SGD has no per-step host state (no bias correction), so its scalars are
-    # constants of the captured launch -- a changed learning rate needs a new capture
+    # graph_step.CapturedTrainStep sets device_hyper: the scalars of the update then live in a small device array
+    # that push_hyper() rewrites (a one-thread launch in front of the replay) whenever lr / momentum / weight decay /
+    # nesterov / grad_scale changed on the host -- a scheduler (optim/scheduler.py mutates optimizer.lr) or a loaded
+    # checkpoint takes effect on the next replay instead of being frozen into the captured launch
     device_hyper = False
+    _hyper = None
+    _hyper_key = None
+
+    def _scalars(self):
+        return (float(self.lr), float(self.momentum), float(self.weight_decay), bool(self.nesterov),
+                float(self.grad_scale))
 
     def push_hyper(self):
-        pass
+        mod = self._fused_mod()
+        if self._hyper is None:
+            self._hyper = mod.Array(16)
+        key = self._scalars()
+        if key == self._hyper_key:
+            return
+        if self._hyper_key is not None and (key[1] > 0.0) != (self._hyper_key[1] > 0.0):
+            raise RuntimeError("SGD: momentum was switched on or off after the step was captured (the captured launch "
+                               "has no momentum buffers / has them): capture the step again")
+        if getattr(mod, "capturing", False):
+            raise RuntimeError("SGD: the scalars must be written before the capture starts")
+        mod.sgd_hyper(self._hyper, *key)
+        self._hyper_key = key
 
     def note_replayed_apply(self):
         pass
@@ -34,6 +54,13 @@ class SGD(Optimizer):
             raise TypeError("SGD.step: a parameter has no gradient")   # as the reference would
         for i in live:
             self.params[i].data = self.params[i].data.compact()
+        if self.device_hyper:
+            if self._hyper_key is None or (self._hyper_key != self._scalars() and not getattr(mod, "capturing", False)):
+                self.push_hyper()
+            mod.sgd_step_dev([self.params[i].data._handle for i in live],
+                             [self.params[i].grad.compact()._handle for i in live],
+                             [self.v[i]._handle for i in live] if self.momentum > 0.0 else None, self._hyper)
+            return
         mod.sgd_step([self.params[i].data._handle for i in live],
                      [self.params[i].grad.compact()._handle for i in live],
                      [self.v[i]._handle for i in live] if self.momentum > 0.0 else None,

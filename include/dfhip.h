@@ -369,6 +369,14 @@ int dfhip_adam_step(int n_tensors, float* const* params, const float* const* gra
 int dfhip_sgd_step(int n_tensors, float* const* params, const float* const* grads,
                    float* const* momentum_buf, const int64_t* sizes, double lr, double momentum,
                    double weight_decay, int nesterov, double grad_scale);
+/* The same update with its scalars in a 16-float device array that dfhip_sgd_hyper writes (a one-thread launch on the
+ * library stream, refused inside a capture): a captured step replays dfhip_sgd_step_dev unchanged while a
+ * learning-rate scheduler (optim/scheduler.py:13-61 mutates optimizer.lr) keeps moving the scalars from the host.
+ * momentum_buf may be NULL only if the momentum written by dfhip_sgd_hyper is 0. */
+int dfhip_sgd_hyper(float* hyper_dev, double lr, double momentum, double weight_decay, int nesterov,
+                    double grad_scale);
+int dfhip_sgd_step_dev(int n_tensors, float* const* params, const float* const* grads,
+                       float* const* momentum_buf, const int64_t* sizes, const float* hyper_dev);
 
 /* Pack / unpack a list of tensors into one flat bucket (gradient all-reduce payload).   */
 int dfhip_pack(int n_tensors, const float* const* srcs, const int64_t* sizes, float* flat);

@@ -160,6 +160,48 @@ def test_captured_step_matches_eager_steps(hip_device):
         assert np.array_equal(a, b)
 
 
+def test_scheduler_over_a_captured_sgd_step_matches_eager(hip_device):
+    """SGD's scalars are read from a device array inside the captured step, so a scheduler that mutates
+    optimizer.lr between replays (optim/scheduler.py:13-61; the MLP script's StepLR) is NOT frozen into the graph:
+    captured + scheduler == eager + scheduler bit for bit, and differs from a run whose lr never moves."""
+    import numpy as np
+    from deepflows_amd import nn, optim, tensor, workloads
+    from deepflows_amd.graph_step import CapturedTrainStep
+    from deepflows_amd.optim.scheduler import StepLR
+    from deepflows_amd.tensor import Graph
+
+    def run(captured, schedule=True, momentum=0.9):
+        np.random.seed(11)
+        model = workloads.MLP((784, 256, 10), device=hip_device)
+        opt = optim.SGD(model.parameters(), lr=0.05, momentum=momentum, weight_decay=5e-4)
+        sched = StepLR(opt, step_size=2, gamma=0.5)
+        crit = nn.CrossEntropyLoss()
+        rng = np.random.default_rng(3)
+        x = tensor.Tensor(rng.random((128, 784), dtype=np.float32), device=hip_device)
+        y = tensor.Tensor(np.eye(10, dtype=np.float32)[rng.integers(0, 10, 128)], device=hip_device)
+        cs = CapturedTrainStep(model, crit, opt, x, y) if captured else None
+        lrs = []
+        for _ in range(6):
+            if captured:
+                cs.replay()
+            else:
+                workloads.train_step(model, crit, opt, x, y)
+                Graph.free_graph()
+            if schedule:
+                sched.step()
+            lrs.append(opt.lr)
+        return [p.numpy().copy() for p in opt.params], lrs
+
+    for momentum in (0.9, 0.0):
+        pe, lre = run(False, momentum=momentum)
+        pc, lrc = run(True, momentum=momentum)
+        assert lre == lrc and lre[-1] < 0.05 / 4 + 1e-12
+        for a, b in zip(pe, pc):
+            assert np.array_equal(a, b)
+        frozen, _ = run(True, schedule=False, momentum=momentum)
+        assert any(not np.array_equal(a, b) for a, b in zip(pc, frozen))
+
+
 def test_fused_stem_matches_the_three_operators(hip_device):
     """bn_relu_maxpool2_train(x) == max_pool2d(relu(batch_norm2d_train(x)), 2) forward and backward
     (the tie rules of the reference: every tied window maximum gets the gradient — whole windows

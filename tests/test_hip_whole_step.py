@@ -1,0 +1,112 @@
+"""GPU: the BENCHMARKED configurations, end to end, against the oracle (VERDICT r2 "Next" #2).
+
+The end-to-end goldens run at batch 2 / 4 / 8, where none of the kernels the headline number is made of dispatch
+(register-operand 3x3 needs N >= 128, the image-per-lane kernels N % 16 == 0, the grouped weight gradient a full
+queue).  Here ONE step of exactly `bench.py`'s job (`bench.build_job`: same seeds, same synthetic batch, same
+optimizer) runs on the hip device -- eagerly and through `CapturedTrainStep.replay()` -- and on the oracle (NumPy
+device + the primitive path = the reference's algorithm, test/ResNet_CIFAR10_cuda.py:20-100,177-202), and loss,
+logits, the stem's weight gradient, the per-tensor |grad| sums and the post-step |param| sums are compared under the
+measured fp32 budget of tests/error_budget.py (distance from a float64 evaluation of the same algorithm).  The test
+also asserts that the fused entry points the bench times were the ones taken (per-family launch counts)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import error_budget as eb
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def _collect(model, opt, loss, out, params_all):
+    res = {"loss": loss.numpy(), "logits": out.numpy(), "conv1_wgrad": params_all[0].grad.numpy(),
+           "grad_abs_sum": np.array([float(np.abs(p.grad.numpy().astype(np.float64)).sum()) for p in params_all])}
+    return res
+
+
+def _finish(res, params_all):
+    res["param_abs_sum_after"] = np.array([float(np.abs(p.data.numpy().astype(np.float64)).sum()) for p in params_all])
+    res["first_param_after"] = params_all[0].data.numpy()
+    return {k: np.asarray(v, dtype=np.float64) for k, v in res.items()}
+
+
+def bench_step(dev, workload, batch, captured=False, counts=None):
+    """One step of bench.py's job on `dev`.  Dropout (CNN) draws from the global NumPy generator, which build_job
+    seeds: the mask is the same on every device."""
+    import bench
+    from deepflows_amd import workloads
+    from deepflows_amd.tensor import Graph
+    model, opt, crit, xt, yt = bench.build_job(workload, dev, 0, batch)
+    params_all = list(opt.params)
+    mod = dev.mod
+    if captured:
+        from deepflows_amd.graph_step import CapturedTrainStep
+        rng_state = np.random.get_state()
+        cs = CapturedTrainStep(model, crit, opt, xt, yt)
+        np.random.set_state(rng_state)                  # the capture drew a mask nothing consumed: replay redraws it
+        loss = cs.replay()
+        for p, g in zip(opt.params, cs.grads):
+            p.grad = g
+        res = _collect(model, opt, loss, cs.outputs, params_all)
+        out = _finish(res, params_all)
+        cs.destroy()
+    else:
+        if counts is not None:
+            mod.prof_reset()
+            mod.prof_enable(True)
+        outputs = model(xt)
+        loss = crit(outputs, yt)
+        opt.zero_grad()
+        loss.backward()
+        res = _collect(model, opt, loss, outputs, params_all)
+        opt.step()
+        if counts is not None:
+            mod.synchronize()
+            mod.prof_enable(False)
+            counts.update({k: v["calls"] for k, v in mod.prof_read().items()})
+        out = _finish(res, params_all)
+    Graph.free_graph_all()
+    return out
+
+
+def _oracle(cls, workload, batch, accumulate=False):
+    import contextlib
+    from oracle.accumulate_mode import accumulate_im2col_gradient
+    ctx = accumulate_im2col_gradient() if accumulate else contextlib.nullcontext()
+    with ctx:
+        return eb.with_device(cls, lambda d: bench_step(d, workload, batch))
+
+
+CASES = {
+    # the headline: ResNet-18 bs 256, overwrite mode, all 62 tensors
+    "resnet18_bs256_overwrite": ("resnet18", 256, "overwrite",
+                                 {"conv2d_fwd_igemm": 17, "conv2d_wgrad_grouped": 1, "conv2d_dgrad_overwrite_igemm": 16,
+                                  "bn_relu_pool_fwd": 1, "bn_relu_pool_bwd": 1, "pool_linear_fwd": 1,
+                                  "pool_linear_bwd": 1, "softmax_ce_fwd": 1, "adam_step": 1}),
+    "cnn_bs256_overwrite": ("cnn", 256, "overwrite", {"adam_step": 1}),
+    "resnet18_bs128_accumulate": ("resnet18", 128, "accumulate", {"conv2d_wgrad_grouped": 1, "adam_step": 1}),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_benchmarked_step_matches_the_oracle(hip_device, case):
+    from oracle.numpy_device import NumpyDevice, NumpyDevice64
+    workload, batch, dgrad, want_counts = CASES[case]
+    hip_device.mod.conv_dgrad_mode = dgrad
+    counts = {}
+    eager = bench_step(hip_device, workload, batch, counts=counts)
+    replayed = bench_step(hip_device, workload, batch, captured=True)
+    print("\nlaunch counts per family:", dict(sorted(counts.items())))
+    for fam, n in want_counts.items():
+        assert counts.get(fam) == n, f"{case}: family {fam} ran {counts.get(fam)} times, the bench's composition has {n}"
+    # the replayed graph runs the same kernels in the same order as the eager step
+    for k in eager:
+        assert np.array_equal(eager[k], replayed[k]), f"{case}: replay differs from the eager step in {k}"
+    exact = _oracle(NumpyDevice64, workload, batch, accumulate=(dgrad == "accumulate"))
+    fp32 = _oracle(NumpyDevice, workload, batch, accumulate=(dgrad == "accumulate"))
+    eb.assert_within_budget(eager, exact, fp32, f"hip {case} (bench.py's job, one step)")
+    # the loss bench.py prints for this job is this number
+    assert abs(float(eager["loss"].reshape(-1)[0]) - float(fp32["loss"].reshape(-1)[0])) <= 1e-4 * abs(float(fp32["loss"].reshape(-1)[0]))

@@ -14,6 +14,15 @@ def test_conv2d_overwrite(cpu_oracle, name):
     pc.check_conv2d(cpu_oracle, name, "overwrite")
 
 
+@pytest.mark.parametrize("name", pc.CONV_CASES)
+def test_conv2d_accumulate_patch_matches_the_torch_goldens(cpu_oracle, name):
+    """oracle/accumulate_mode.py (the `+=` form of the im2col gradient, used as the whole-step oracle of the hip
+    device's accumulate mode) against the torch-generated `*_dx_accumulate` vectors."""
+    from oracle.accumulate_mode import accumulate_im2col_gradient
+    with accumulate_im2col_gradient():
+        pc.check_conv2d(cpu_oracle, name, "accumulate")
+
+
 def test_batchnorm2d(cpu_oracle):
     pc.check_batchnorm(cpu_oracle)
 
