@@ -124,9 +124,10 @@ def Device(device_name=None):
     if device_name in ("hip", "cuda"):
         dev = hip()
         if not dev.enabled():
+            from .. import hip_device
             raise RuntimeError(
-                "device 'hip' is not available: libdfhip.so is not built or no MI355X is visible "
-                "(there is no CPU fallback in deepflows_amd)")
+                "device 'hip' is not available: " + (hip_device.unavailable_reason or "libdfhip.so is not built or no "
+                "MI355X is visible") + " (there is no CPU fallback in deepflows_amd)")
         return dev
     raise KeyError(f"unknown device '{device_name}' (known: {sorted(all_devices())})")
 

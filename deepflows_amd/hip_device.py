@@ -606,14 +606,24 @@ def get_module():
     return _module
 
 
+unavailable_reason = ""      # why available() last said no (Device('hip') puts it into its error message)
+
+
 def available():
-    """True iff libdfhip.so is built AND a HIP device is visible. Never raises."""
+    """True iff libdfhip.so is built AND a HIP device is visible. Never raises; `unavailable_reason` says why not."""
+    global unavailable_reason
     if not _lib.library_present():
+        unavailable_reason = f"{_lib.LIB_PATH} is not built"
         return False
     try:
         lib = _lib.load()
         n = c_int()
-        lib.dfhip_device_count(byref(n))
-        return n.value > 0
-    except Exception:
+        rc = lib.dfhip_device_count(byref(n))
+        if n.value > 0:
+            unavailable_reason = ""
+            return True
+        unavailable_reason = "no HIP device is visible" + (f" ({lib.dfhip_last_error().decode('utf-8', 'replace')})" if rc else "")
+        return False
+    except Exception as e:        # e.g. a stale libdfhip.so that lacks a symbol the binding declares
+        unavailable_reason = f"{_lib.LIB_PATH} does not load: {type(e).__name__}: {e}"
         return False

@@ -361,12 +361,13 @@ class _Conv2dFused(_FusedNode):
         if node is self.w:
             if self._dw_ready is not None:
                 dw, placeholder = self._dw_ready
-                if grad is not placeholder:
-                    # the output of this convolution had another consumer whose contribution was added to the
-                    # placeholder: the stored dw does not contain it
-                    raise RuntimeError("stem backward: the convolution output feeds more than the pooling node; "
-                                       "set DF_STEM_FUSED_BWD=0")
-                return dw
+                self._dw_ready = None             # consumed: a second backward() over a retained graph starts afresh
+                if grad is placeholder:
+                    return dw
+                # cannot happen while the pooling node checks that it is the only consumer (the placeholder holds
+                # no values to fall back on): refuse rather than return a gradient without the other contribution
+                raise RuntimeError("stem backward: the convolution's output gradient is not the placeholder its "
+                                   "pooling node handed out (another consumer?); set DF_STEM_FUSED_BWD=0")
             out = _new(self.wd.shape, dev)
             dev.conv2d_wgrad(self.xd._handle, g._handle, out._handle, *self.geo)
             return out
@@ -766,7 +767,9 @@ class _BnReluPoolFused(_FusedNode):
             conv = self.x if isinstance(self.x, _Conv2dFused) else None
             if (conv is not None and _STEM_FUSED_BWD and hasattr(dev.mod, "stem_backward") and self.x.requires_grad
                     and not conv.x.requires_grad and conv.bias is None and conv.w.requires_grad
-                    and conv._dw_ready is None):
+                    and conv._dw_ready is None and len(conv.children) == 1 and conv.children[0] is self):
+                # (only when this node is the convolution output's ONLY consumer: another consumer's contribution
+                # would have to be added to a gradient tensor that is never formed)
                 # the convolution in front needs only its weight gradient: one statistics launch, then the weight
                 # gradient rebuilds d loss / d x from x while it stages it -- that tensor is never written.  The
                 # convolution's node receives a placeholder as its output gradient and hands the stored dw out.

@@ -37,12 +37,27 @@ def draw_decisions(bs, h, w, epoch, num_epochs, pad=4, rng=np.random):
     return dec
 
 
+class _Window:
+    """Non-owning window into a device array (duck type of a device handle: .ptr, .size)."""
+    __slots__ = ("ptr", "size", "_owner")
+
+    def __init__(self, owner, offset, size):
+        self.ptr, self.size, self._owner = owner.ptr + 4 * int(offset), int(size), owner
+
+
 class DeviceBatchPipeline:
-    def __init__(self, device, batch_shape, num_classes=10, eps=0.05, pad=4):
+    """`augment=False`: the scripts without augmentation (test/CNN_CIFAR10_cuda.py:128-136, test/MLP_MNIST_cuda.py)
+    -- the raw batch is copied from the staging slot into the step's input (no random draws, no clip); labels are
+    still turned into (smoothed) one-hot rows on the device.  `batch_shape` may then have any rank (MLP: (bs, 784))."""
+
+    def __init__(self, device, batch_shape, num_classes=10, eps=0.05, pad=4, augment=True):
         mod = device.mod
         if not hasattr(mod, "upload_async"):
             raise RuntimeError("DeviceBatchPipeline needs the hip device")
         self.mod, self.shape, self.K, self.eps, self.pad = mod, tuple(int(s) for s in batch_shape), int(num_classes), eps, pad
+        self.augment = bool(augment)
+        if self.augment and len(self.shape) != 4:
+            raise ValueError("augmentation needs (batch, channels, height, width) batches")
         n = int(np.prod(self.shape))
         bs = self.shape[0]
         # one staging array per slot: [raw batch | labels (int32) | decisions (int32 x 8)]
@@ -52,9 +67,12 @@ class DeviceBatchPipeline:
 
     def submit(self, inputs, labels, epoch=0, num_epochs=1, rng=np.random):
         """Start the upload of one raw batch (float32 NCHW) and its integer labels."""
-        bs, c, h, w = self.shape
+        bs = self.shape[0]
         assert tuple(inputs.shape) == self.shape
-        dec = draw_decisions(bs, h, w, epoch, num_epochs, self.pad, rng)
+        if self.augment:
+            dec = draw_decisions(bs, self.shape[2], self.shape[3], epoch, num_epochs, self.pad, rng)
+        else:
+            dec = np.zeros((bs, 8), dtype=np.int32)
         slot = self._next_submit & 1
         packed = np.empty(self._stage[slot].size, dtype=np.float32)
         packed[:self._off_lab] = np.asarray(inputs, dtype=np.float32).reshape(-1)
@@ -68,9 +86,13 @@ class DeviceBatchPipeline:
         """Augment the oldest submitted batch into x_tensor / y_tensor (device tensors of the step)."""
         assert self._next_deliver < self._next_submit, "deliver() without a submitted batch"
         slot = self._next_deliver & 1
-        bs, c, h, w = self.shape
+        bs = self.shape[0]
         st = self._stage[slot]
         self.mod.upload_wait(slot)
-        self.mod.augment_batch(st, x_tensor.data._handle, st, bs, c, h, w, self.pad, 0, self._off_dec)
+        if self.augment:
+            _, c, h, w = self.shape
+            self.mod.augment_batch(st, x_tensor.data._handle, st, bs, c, h, w, self.pad, 0, self._off_dec)
+        else:
+            self.mod.copy(_Window(st, 0, self._off_lab), _Window(x_tensor.data._handle, 0, self._off_lab))
         self.mod.onehot_smooth(st, y_tensor.data._handle, bs, self.K, self.eps, self._off_lab)
         self._next_deliver += 1

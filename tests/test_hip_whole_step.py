@@ -44,9 +44,7 @@ def bench_step(dev, workload, batch, captured=False, counts=None):
     mod = dev.mod
     if captured:
         from deepflows_amd.graph_step import CapturedTrainStep
-        rng_state = np.random.get_state()
-        cs = CapturedTrainStep(model, crit, opt, xt, yt)
-        np.random.set_state(rng_state)                  # the capture drew a mask nothing consumed: replay redraws it
+        cs = CapturedTrainStep(model, crit, opt, xt, yt)     # records only: the replay draws the Dropout mask
         loss = cs.replay()
         for p, g in zip(opt.params, cs.grads):
             p.grad = g
