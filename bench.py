@@ -45,6 +45,12 @@ WORKLOADS = {
     "cnn": {"batch": 256, "metric": "training-step images/sec, CNN-CIFAR10 bs=256",
             "text": "CNN-CIFAR10 (3 x Conv2d k5 + BN + pool, Dropout, test/CNN_CIFAR10_cuda.py:61-113) train step: "
                     "fwd + CE + bwd + Adam lr 5e-3 wd 5e-4, bs 256 per GPU, fp32"},
+    # the repository's other ResNet-18 (SURVEY §8d "a useful stress shape"): never the headline
+    "resnet18_wide": {"batch": 256, "metric": "training-step images/sec, ResNet-18 (test/ResNet.py, 64-512 channels) bs=256",
+                      "cpu_batch": 16,
+                      "text": "ResNet-18 of test/ResNet.py:24-154 (64/128/256/512 channels, 32x32 inputs, no stem pool, ReLU "
+                              "after the residual add; 852 GFLOP per step) train step: fwd + CE + bwd + SGD lr .01 momentum "
+                              ".9 wd 5e-4 (:237), bs 256 per GPU, fp32"},
     "mlp": {"batch": 128, "metric": "training-step samples/sec, MLP-MNIST 784-256-10 bs=128",
             "text": "MLP 784->256->10 (test/MLP_MNIST_cuda.py:37-59) train step: fwd + CE + bwd + SGD lr .05, "
                     "bs 128 per GPU, fp32"},
@@ -72,6 +78,9 @@ def build_job(workload, dev, rank, batch, register_blocks=True):
     if workload == "resnet18":
         model = workloads.ResNet18(10, device=dev, register_blocks=register_blocks)
         opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    elif workload == "resnet18_wide":
+        model = workloads.ResNet18Wide(10, device=dev, register_blocks=register_blocks)
+        opt = optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=0.0005)
     elif workload == "cnn":
         model = workloads.CIFAR10_CNN(10, device=dev)
         opt = optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4)
@@ -129,19 +138,27 @@ def _oracle_steps(workload, batch, threads, max_steps, seconds_budget):
 
 def cpu_baseline(workload, batch):
     """The oracle on this host: NumPy device + the front end's primitive path = the reference's algorithm (im2col by
-    k*k strided copies + np.matmul, unfused BN / CE / optimizer).  Bounded sample of the SAME workload: the full
-    batch, 1 warm-up + 1-2 timed steps on the physical cores of one socket, plus the 8-thread figure
-    SURVEY §6 quotes for comparison (on 1/8 of the batch for the conv workloads so that the run stays bounded)."""
+    k*k strided copies + np.matmul, unfused BN / CE / optimizer).  Bounded sample of the SAME workload at the GPU's
+    batch: 1 warm-up + 1-2 timed steps on the physical cores of one socket and again on 8 threads (the
+    thread count of SURVEY §6's in-container figures; the oracle's strided copies do not scale with cores, so fewer
+    threads can be faster).  `value` is the BETTER of the two configurations, `cores` the threads it used; both runs
+    are listed under `runs`."""
     cores, logical = host_cores()
-    dt, n = _oracle_steps(workload, batch, cores, 2 if workload != "mlp" else 50, 22.0 if workload != "mlp" else 3.0)
-    small = batch if workload == "mlp" else batch // 8
-    dt8, n8 = _oracle_steps(workload, small, 8, 3 if workload != "mlp" else 50, 8.0 if workload != "mlp" else 3.0)
-    return {"value": batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{WORKLOADS[workload]['text'].split(' train step')[0]} train step at batch {batch} (the GPU "
-                      f"batch), {n} timed step(s) after 1 warm-up, {dt:.2f} s/step, {cores} threads = physical cores "
-                      f"of one socket ({logical} logical CPUs), NumPy {np.__version__}",
-            "threads8": {"value": small / dt8, "unit": "images/s", "cores": 8,
-                         "sample": f"batch {small}, {n8} timed step(s), {dt8:.2f} s/step"}}
+    mlp = workload == "mlp"
+    gpu_batch = batch
+    batch = WORKLOADS[workload].get("cpu_batch", batch)      # (the 852-GFLOP stress shape: a smaller batch keeps it bounded)
+    runs = []
+    for threads in sorted({cores, min(8, logical)}, reverse=True):
+        dt, n = _oracle_steps(workload, batch, threads, 50 if mlp else 2, 3.0 if mlp else 14.0)
+        runs.append({"threads": threads, "value": batch / dt, "s_per_step": dt, "timed_steps": n})
+    best = max(runs, key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "images/s", "cores": best["threads"], "kind": "port",
+            "sample": f"{WORKLOADS[workload]['text'].split(' train step')[0]} train step at batch {batch} ("
+                      f"{'the GPU batch' if batch == gpu_batch else f'the GPU runs batch {gpu_batch}'}), "
+                      f"{best['timed_steps']} timed step(s) after 1 warm-up, {best['s_per_step']:.2f} s/step on "
+                      f"{best['threads']} threads (best of {[r['threads'] for r in runs]} threads; host: {cores} "
+                      f"physical cores per socket, {logical} logical CPUs), NumPy {np.__version__}",
+            "runs": runs}
 
 
 def csrc_fingerprint():
@@ -210,7 +227,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=list(WORKLOADS), default="resnet18",
-                    help="resnet18 = the BASELINE headline (default); cnn / mlp = BASELINE.json configs 2-3")
+                    help="resnet18 = the BASELINE headline (default); cnn / mlp = BASELINE.json configs 2-3; "
+                         "resnet18_wide = test/ResNet.py's 64-512 channel model (stress shape)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's own)")
     ap.add_argument("--dgrad", choices=["overwrite", "accumulate"], default="overwrite",
                     help="conv input-gradient mode: reference-exact (default) or mathematically correct")
     ap.add_argument("--registration", choices=["all", "f6"], default="all",
@@ -244,7 +263,7 @@ def main():
     from deepflows_amd.tensor import Graph
 
     wl = WORKLOADS[args.workload]
-    batch = wl["batch"]
+    batch = args.batch or wl["batch"]
     dev = backend_api.Device("hip")            # raises when the extension / GPU is missing
     mod = dev.mod
     mod.conv_dgrad_mode = args.dgrad
@@ -369,7 +388,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["text"],
-                       "global_batch": batch * comm.world, "parallelism": f"dp{comm.world}",
+                       "global_batch": batch * comm.world, "batch_per_gpu": batch, "parallelism": f"dp{comm.world}",
                        "conv_dgrad": args.dgrad, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,
                        "allreduce_elems": exchanged,
                        # what the communicator itself reports (ncclCommCount), not the launcher's environment

@@ -1133,7 +1133,8 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict_
 // ---------------------------------------------------------------------------------------
 template <int O>
 __global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       const float* __restrict__ add, float* __restrict__ dx, int C) {
+                                                       const float* __restrict__ add, float* __restrict__ dx, int C,
+                                                       int xo) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int OQ = O / 4, NK = OQ / 4;             // o per wave, MFMA k-steps per wave
@@ -1141,7 +1142,8 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__
   float* red = smem + 4 * O * 16;                   // [3 waves][16 values][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, n = lane & 15;
-  const int n0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
+  const DfTile wg = xcd_tile(xo);                   // XCD-aware order (dfhip_internal.h)
+  const int n0 = wg.x * 16, c0 = wg.y * 16;
   const int ob = wave * OQ;
   // dY operand of this wave's o range: pixel (0, 0) of image n0 + n, channel ob + 4 p + kk
   float sv[NK];
@@ -1226,7 +1228,8 @@ constexpr int kImg4Strip = 16 * 260;     // floats of a wave's transposition str
 template <int O, int GEO, bool PAIR, bool TR>
 __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__ dy, const float* __restrict__ w,
                                                        const float* __restrict__ add, float* __restrict__ dx, int C,
-                                                       const float* __restrict__ dy2, const float* __restrict__ w2, int S) {
+                                                       const float* __restrict__ dy2, const float* __restrict__ w2, int S,
+                                                       int xo) {
   static_assert(!PAIR || GEO >= 1, "the shortcut rides on the stride-2 forms");
   static_assert(GEO != 2 || TR, "the sub-image form reads its planes through the strip");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1238,7 +1241,8 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
   float* Wl = smem;                                 // [NSL slices][O][16 channels]; later the exchange area [3][16][64] f32x4
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, n = lane & 15;
-  const int n0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
+  const DfTile wg = xcd_tile(xo);                   // XCD-aware order (dfhip_internal.h)
+  const int n0 = wg.x * 16, c0 = wg.y * 16;
   const int ob = wave * OQ;
   // GEO 2: the image is S x S (S = 8), this workgroup's 4 x 4 block of it is (qy, qx); its sources are a 2 x 2 block of
   // the (S/2) x (S/2) dY plane
@@ -1457,6 +1461,9 @@ int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* 
   dim3 grid((unsigned)(N / 16), (unsigned)(C / 16), (unsigned)(GEO == 2 ? (S / 4) * (S / 4) : 1));
   const size_t base = std::max((size_t)(PAIR ? 5 : 4) * O * 16, (size_t)3 * 16 * 64 * 4) * sizeof(float);
   const size_t lds = base + (tr ? (size_t)4 * kImg4Strip * sizeof(float) : 0);
+  // blockIdx.y selects 16 input channels' weight columns (NSL slices x O), blockIdx.x 16 images of dY
+  const int dyp = GEO == 0 ? 16 : (GEO == 1 ? 4 : (S / 2) * (S / 2));
+  const int xo = xcd_arrangement(N / 16, C / 16, 4.0 * N * O * dyp * (PAIR ? 2 : 1), 4.0 * O * C * (PAIR ? 5 : 4));
   static bool attr = false;
   if (!attr) {
     DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1467,10 +1474,10 @@ int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* 
     attr = true;
   }
   if constexpr (GEO == 2) {
-    DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S);
+    DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
   } else {
-    if (tr) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S);
-    else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, false>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S);
+    if (tr) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
+    else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, false>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
   }
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -1757,7 +1764,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_fwd(const float* __restric
 template <int C>
 __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
-                                                          float* __restrict__ stats, int O) {
+                                                          float* __restrict__ stats, int O, int xo) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int CW = C / 8;                     // channels per wave
   constexpr int NCHK = CW / 8;                  // slices of eight channels
@@ -1766,7 +1773,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restric
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, n = lane & 15;
-  const int n0 = blockIdx.x * 16, o0 = blockIdx.y * 16;
+  const DfTile wg = xcd_tile(xo);               // (image tile, channel tile): XCD-aware order, dfhip_internal.h
+  const int n0 = wg.x * 16, o0 = wg.y * 16;
   float* Wl = smem + wave * WSL;
   float* Xs = Wl + 72 * WP;
   const int cb = wave * CW;                     // this wave's first source channel
@@ -1869,7 +1877,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restric
       for (int q = 0; q < 4; q++) { const float d = acc[q][v] - mean; qs = fmaf(d, d, qs); }
       qs = row16(qs);
       if (n == 0) {
-        float* o3 = stats + ((int64_t)blockIdx.x * O + o0 + 4 * kk + v) * 3;
+        float* o3 = stats + ((int64_t)wg.x * O + o0 + 4 * kk + v) * 3;
         o3[0] = 64.0f; o3[1] = mean; o3[2] = qs;
       }
     }
@@ -3934,8 +3942,10 @@ int run_conv_img2(const Geo& g, int O, float* y, const float* bias, float* parti
     if (rows_out) *rows_out = partials ? rows4 : 0;
     dim3 grid4((unsigned)rows4, (unsigned)(O / 16));
     const size_t lds4 = std::max((size_t)8 * (72 * 17 + 16 * 9 * 4), (size_t)7 * 4 * 64 * 4) * sizeof(float);
-    if (g.CS == 128) DF_LAUNCH(k_conv3x3_img2_all<128>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O);
-    else DF_LAUNCH(k_conv3x3_img2_all<256>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O);
+    // XCD arrangement: blockIdx.y selects 16 output channels' weights, blockIdx.x 16 images' planes
+    const int xo = xcd_arrangement(rows4, O / 16, 4.0 * g.N * g.CS * 4, 4.0 * O * g.CS * 9);
+    if (g.CS == 128) DF_LAUNCH(k_conv3x3_img2_all<128>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, xo);
+    else DF_LAUNCH(k_conv3x3_img2_all<256>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, xo);
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
   }
@@ -5010,6 +5020,8 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
       // 2 x 2 images: a plain product (k_dgrad_ow_img2)
       dim3 grid((unsigned)(N / 16), (unsigned)(C / 16));
       const size_t lds = ((size_t)4 * O * 16 + 3 * 16 * 64) * sizeof(float);
+      // blockIdx.y selects 16 input channels' weight columns (all O, four taps), blockIdx.x 16 images of dY
+      const int xo2 = xcd_arrangement(N / 16, C / 16, 4.0 * N * O * 4, 4.0 * O * C * 4);
 #define DF_I2(OV)                                                                                          \
   do {                                                                                                     \
     static bool attr = false;                                                                              \
@@ -5018,7 +5030,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
                                  (int)std::max(lds, (size_t)65536)));                                      \
       attr = true;                                                                                         \
     }                                                                                                      \
-    DF_LAUNCH(k_dgrad_ow_img2<OV>, grid, dim3(256), lds, stream(), dy, w, add, dx, C);                     \
+    DF_LAUNCH(k_dgrad_ow_img2<OV>, grid, dim3(256), lds, stream(), dy, w, add, dx, C, xo2);                \
   } while (0)
       if (O == 128) DF_I2(128); else if (O == 256) DF_I2(256); else DF_I2(512);
 #undef DF_I2

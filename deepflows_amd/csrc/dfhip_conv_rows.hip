@@ -550,13 +550,14 @@ template <int C>
 __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           float* __restrict__ stats, int O,
-                                                          const float* __restrict__ aff) {
+                                                          const float* __restrict__ aff, int xo) {
   constexpr int CW = C / 8, NCHK = CW / 8, WP = 17, XP = 33;      // XP: float4 pitch of an image's strip row
   constexpr int WSL = 72 * WP + 16 * XP * 4;                       // floats of a wave's area
   extern __shared__ __attribute__((aligned(16))) float smem_i4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, n = lane & 15;
-  const int n0 = blockIdx.x * 16, o0 = blockIdx.y * 16, h = blockIdx.z;
+  const DfTile wg = xcd_tile(xo);                // XCD-aware order (dfhip_internal.h)
+  const int n0 = wg.x * 16, o0 = wg.y * 16, h = blockIdx.z;
   float* Wl = smem_i4 + wave * WSL;
   float* Xs = Wl + 72 * WP;
   const int cb = wave * CW;
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
       for (int q = 0; q < 8; q++) { const float d = acc[q][v] - mean; qs = fmaf(d, d, qs); }
       qs = row_sum16(qs);
       if (n == 0) {
-        float* o3 = stats + ((int64_t)(blockIdx.x * 2 + h) * O + o0 + 4 * kk + v) * 3;
+        float* o3 = stats + ((int64_t)(wg.x * 2 + h) * O + o0 + 4 * kk + v) * 3;
         o3[0] = 128.0f; o3[1] = mean; o3[2] = qs;
       }
     }
@@ -696,8 +697,11 @@ static int run_conv_img4_fwd(const float* x, const float* w, const float* bias, 
     DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_img4_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
+  // blockIdx.y selects 16 output channels' weights, blockIdx.x 16 images' planes (both halves of an image tile are
+  // neighbours in z: they share the planes of the middle rows)
+  const int xo = xcd_arrangement(N / 16, O / 16, 4.0 * N * C * 16, 4.0 * O * C * 9);
   DF_LAUNCH(k_conv3x3_img4_fwd<128>, grid, dim3(512), lds, stream(), x, w, bias, y, partials, O,
-            bn ? (const float*)bn->affine : (const float*)nullptr);
+            bn ? (const float*)bn->affine : (const float*)nullptr, xo);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }

@@ -404,13 +404,14 @@ template <int C>
 __global__ __launch_bounds__(512) void k_conv3x3s2_img4_pair(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ wd, float* __restrict__ y,
                                                              float* __restrict__ yd, float* __restrict__ partials,
-                                                             float* __restrict__ partials_d, int O) {
+                                                             float* __restrict__ partials_d, int O, int xo) {
   constexpr int CW = C / 8, NCHK = CW / 8, WP = 17, XP = 33;
   constexpr int WSL = 72 * WP + 8 * WP + 16 * XP * 4;      // weights [72][17], shortcut weights [8][17], planes [16][33] float4
   extern __shared__ __attribute__((aligned(16))) float smem_p4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, n = lane & 15;
-  const int n0 = blockIdx.x * 16, o0 = blockIdx.y * 16;
+  const DfTile wg = xcd_tile(xo);                // XCD-aware order (dfhip_internal.h)
+  const int n0 = wg.x * 16, o0 = wg.y * 16;
   float* Wl = smem_p4 + wave * WSL;
   float* Dl = Wl + 72 * WP;
   float* Xs = Dl + 8 * WP;
@@ -520,8 +521,8 @@ __global__ __launch_bounds__(512) void k_conv3x3s2_img4_pair(const float* __rest
       }
       q1 = row_sum16b(q1); q2 = row_sum16b(q2);
       if (n == 0) {
-        float* o1 = partials + ((int64_t)blockIdx.x * O + o0 + 4 * kk + v) * 3;
-        float* o2 = partials_d + ((int64_t)blockIdx.x * O + o0 + 4 * kk + v) * 3;
+        float* o1 = partials + ((int64_t)wg.x * O + o0 + 4 * kk + v) * 3;
+        float* o2 = partials_d + ((int64_t)wg.x * O + o0 + 4 * kk + v) * 3;
         o1[0] = 64.0f; o1[1] = m1; o1[2] = q1;
         o2[0] = 64.0f; o2[1] = m2; o2[2] = q2;
       }
@@ -552,7 +553,8 @@ int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y
       DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3s2_img4_pair<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
       attr4 = true;
     }
-    DF_LAUNCH(k_conv3x3s2_img4_pair<128>, grid4, dim3(512), lds4, stream(), x, w, wd, y, yd, partials, partials_d, O);
+    const int xo = xcd_arrangement(N / 16, O / 16, 4.0 * N * C * 16, 4.0 * O * C * 10);
+    DF_LAUNCH(k_conv3x3s2_img4_pair<128>, grid4, dim3(512), lds4, stream(), x, w, wd, y, yd, partials, partials_d, O, xo);
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
   }

@@ -83,6 +83,34 @@ int run_conv_rowmma_dgrad(const float* dy, const float* w, const float* add, flo
 
 }  // namespace dfhip
 
+// ---- XCD-aware tile order ---------------------------------------------------------------------------------------
+// MI355X deals workgroups round-robin over its 8 XCDs in linear-id order (x fastest), and each XCD has an L2 of its
+// own: with the natural (blockIdx.x = image tile, blockIdx.y = channel tile) order every XCD sees EVERY channel tile,
+// i.e. each of the eight L2s pulls the whole weight tensor (MI355X_MICROARCH.md, Workgroup dispatch; measured on the
+// 2 x 2-image layers: 20 MB fetched for a 2.4 MB weight tensor).  xcd_tile() renumbers the tiles of a 2-D grid so
+// that the 8 XCDs form an xo x (8 / xo) arrangement: XCD (jo, ji) owns the channel tiles [jo * ny / xo, ...) and the
+// image tiles [ji * nx / (8 / xo), ...), and its L2 holds 1 / xo of the weights and xo / 8 of the images.  Placement
+// is a speed matter only (HIP promises none): any xo gives the same results.  xo = 0: the natural order.
+struct DfTile { int x, y; };
+#if defined(__HIPCC__)
+__device__ __forceinline__ DfTile xcd_tile(int xo) {
+  const int nx = (int)gridDim.x, ny = (int)gridDim.y;
+  if (xo <= 0) return {(int)blockIdx.x, (int)blockIdx.y};
+  const int lin = (int)blockIdx.y * nx + (int)blockIdx.x;      // (nx * ny % 8 == 0: every z plane starts on XCD 0's turn)
+  const int j = lin & 7, s = lin >> 3;
+  const int xi = 8 / xo, jo = j % xo, ji = j / xo;
+  const int wx = nx / xi, wy = ny / xo;
+  const int li = s % wx, lo = s / wx;
+  return {ji * wx + li, jo * wy + lo};
+}
+#endif
+namespace dfhip {
+// the arrangement for a grid of nx x ny tiles whose y operand (what blockIdx.y selects: weights) is y_bytes and whose x
+// operand (images) is x_bytes in all: the divisor xo of 8 with ny % xo == 0, nx % (8 / xo) == 0 that minimises the
+// bytes one XCD's L2 has to hold; 0 (natural order) when nothing divides or DFHIP_XCD_ORDER=0
+int xcd_arrangement(int nx, int ny, double x_bytes, double y_bytes);
+}
+
 // ---- point-wise pieces of the stem (BatchNorm -> ReLU -> MaxPool 2x2) shared by its kernels ----
 #if defined(__HIPCC__)
 __device__ __forceinline__ float bn_point(float v, float mean, float rsd, float w, float b) {

@@ -77,6 +77,22 @@ static int do_init(int device_id) {
 
 int ensure_init() { return g_init ? DFHIP_OK : do_init(-1); }
 
+int xcd_arrangement(int nx, int ny, double x_bytes, double y_bytes) {
+  static int enabled = getenv("DFHIP_XCD_ORDER") ? atoi(getenv("DFHIP_XCD_ORDER")) : 1;
+  if (!enabled || nx <= 0 || ny <= 0 || ((int64_t)nx * ny) % 8 != 0) return 0;
+  if (enabled == 2 || enabled == 4 || enabled == 8) {            // forced arrangement (A/B runs)
+    return (ny % enabled == 0 && nx % (8 / enabled) == 0) ? enabled : 0;
+  }
+  int best = 0;
+  double best_bytes = y_bytes + x_bytes / 8.0;                   // natural order: an XCD sees every y tile, 1/8 of x
+  for (int xo = 1; xo <= 8; xo *= 2) {
+    if (ny % xo != 0 || nx % (8 / xo) != 0) continue;
+    const double b = y_bytes / xo + x_bytes / (8 / xo);
+    if (b < best_bytes * 0.999) { best_bytes = b; best = xo; }
+  }
+  return best;
+}
+
 // ---------------------------------------------------------------------------------------
 // Caching pool.  Exact-size free lists (rounded to 256 B); a training loop requests the
 // same sizes every step, so after one warm-up step nothing reaches hipMalloc.  Frees are

@@ -74,6 +74,40 @@ def main():
     model.train()
     record("mbn", model, SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=0.0005), model.conv1)
 
+    # the repository's other ResNet-18 (test/ResNet.py:24-154: 64/128/256/512 channels, no stem pool, ReLU after the
+    # residual add), SGD lr .01 momentum .9 wd 5e-4 as in :237.  Its blocks sit in Python lists, so the optimizer
+    # sees 5 tensors; gradients are recorded for all 62.
+    ns = {"nn": rnn, "tensor": rt, "Tensor": RT, "__name__": "lifted"}
+    exec(lift_classes("ResNet.py", {"ResidualBlock", "ResNet", "ResNet18"}), ns)
+    np.random.seed(0)
+    model = ns["ResNet18"](10, img_size=(32, 32), device="cpu")
+    model.train()
+    opt = SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=0.0005)
+
+    def all_params(m):
+        out = [m.conv1.weight, m.bn1.weight, m.bn1.bias]
+        for stage in (m.layer1, m.layer2, m.layer3, m.layer4):
+            for blk in stage:
+                if blk.downsample is not None:          # created before the block's own layers (:88-91)
+                    out += [blk.downsample[0].weight, blk.downsample[1].weight, blk.downsample[1].bias]
+                out += [blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias]
+        return out + [m.fc.weight, m.fc.bias]
+    every = all_params(model)
+    g["wide_n_params"] = np.array([len(every), sum(int(np.prod(p.shape)) for p in every), len(list(model.parameters()))])
+    g["wide_init_abs_sum"] = np.array([float(np.abs(p.data.numpy()).sum()) for p in every])
+    out = model(RT(xb, device=dev))
+    loss = rnn.CrossEntropyLoss()(out, RT(yb, device=dev))
+    opt.zero_grad()
+    loss.backward()
+    g["wide_loss"], g["wide_logits"] = loss.numpy(), out.numpy()
+    g["wide_grad_abs_sum"] = np.array([float(np.abs(p.grad.numpy().astype(np.float64)).sum()) for p in every])
+    g["wide_conv1_wgrad"] = model.conv1.weight.grad.numpy()
+    g["wide_fc_wgrad"] = model.fc.weight.grad.numpy()
+    opt.step()
+    g["wide_param_abs_sum_after"] = np.array([float(np.abs(p.data.numpy().astype(np.float64)).sum()) for p in every])
+    g["wide_running_var_bn1"] = model.bn1.running_var.numpy()
+    rt.Graph.free_graph_all()
+
     np.savez_compressed(os.path.join(OUT, "g10_models.npz"), **g)
     print("wrote g10_models.npz:", {k: v.shape for k, v in g.items()})
 

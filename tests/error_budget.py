@@ -40,6 +40,29 @@ def resnet18_step(dev, mode="all", dgrad_mode=None):
     return {k: np.asarray(v, dtype=np.float64) for k, v in res.items()}
 
 
+def wide_resnet_step(dev):
+    """One SGD step of test/ResNet.py's ResNet-18 (64/128/256/512, ReLU after the add) at batch 2 on the g10 inputs."""
+    from deepflows_amd import nn, optim, workloads
+    from deepflows_amd.tensor import Graph, Tensor
+    g = load_golden("g10_models.npz")
+    np.random.seed(0)
+    model = workloads.ResNet18Wide(10, device=dev, register_blocks=False)
+    model.train()
+    every = workloads.all_block_parameters(model)
+    opt = optim.SGD(list(model.parameters()), lr=0.01, momentum=0.9, weight_decay=0.0005)
+    out = model(Tensor(g["x"], device=dev))
+    loss = nn.CrossEntropyLoss()(out, Tensor(g["y"], device=dev))
+    opt.zero_grad()
+    loss.backward()
+    res = {"loss": loss.numpy(), "logits": out.numpy(), "fc_wgrad": model.fc.weight.grad.numpy(),
+           "conv1_wgrad": model.conv1.weight.grad.numpy(),
+           "grad_abs_sum": np.array([float(np.abs(p.grad.numpy().astype(np.float64)).sum()) for p in every])}
+    opt.step()
+    res["param_abs_sum_after"] = np.array([float(np.abs(p.data.numpy().astype(np.float64)).sum()) for p in every])
+    Graph.free_graph_all()
+    return {k: np.asarray(v, dtype=np.float64) for k, v in res.items()}
+
+
 def cnn_steps(dev):
     """Two Adam steps of the CNN workload on the g8 golden inputs (Dropout masks from the seeded global generator)."""
     from deepflows_amd import nn, optim, workloads

@@ -364,6 +364,37 @@ def check_model_step(dev, tag, tol_grad=TOL):
     Graph.free_graph_all()
 
 
+def check_wide_resnet_step(dev, tol_grad=TOL):
+    """One SGD step of the repository's other ResNet-18 (test/ResNet.py:24-154: 64/128/256/512 channels, no stem
+    pool, ReLU after the residual add; blocks in Python lists, so the optimizer holds 5 of the 62 tensors) at batch 2
+    against the reference's own outputs (oracle/gen_models_golden.py, `wide_*`)."""
+    g = load_golden("g10_models.npz")
+    np.random.seed(0)
+    model = workloads.ResNet18Wide(10, device=dev, register_blocks=False)
+    model.train()
+    every = workloads.all_block_parameters(model)
+    n, numel, n_registered = (int(v) for v in g["wide_n_params"])
+    params = list(model.parameters())
+    assert len(every) == n and sum(int(np.prod(p.shape)) for p in every) == numel and len(params) == n_registered
+    init = np.array([float(np.abs(p.data.numpy()).sum()) for p in every])
+    assert_close(init, g["wide_init_abs_sum"], 1e-6, "wide: seeded init reproduces the reference's weights")
+    opt = optim.SGD(params, lr=0.01, momentum=0.9, weight_decay=0.0005)
+    out = model(Tensor(g["x"], device=dev))
+    loss = nn.CrossEntropyLoss()(out, Tensor(g["y"], device=dev))
+    opt.zero_grad(); loss.backward()
+    assert_close(out.numpy(), g["wide_logits"], TOL, "wide logits")
+    assert_close(loss.numpy(), g["wide_loss"], TOL, "wide loss")
+    gabs = np.array([float(np.abs(p.grad.numpy().astype(np.float64)).sum()) for p in every])
+    assert_close(gabs, g["wide_grad_abs_sum"], tol_grad, "wide |grad| checksums (all 62 tensors)")
+    assert_close(model.conv1.weight.grad.numpy(), g["wide_conv1_wgrad"], tol_grad, "wide first conv wgrad")
+    assert_close(model.fc.weight.grad.numpy(), g["wide_fc_wgrad"], tol_grad, "wide fc wgrad")
+    opt.step()
+    after = np.array([float(np.abs(p.data.numpy().astype(np.float64)).sum()) for p in every])
+    assert_close(after, g["wide_param_abs_sum_after"], 1e-4, "wide parameters after the step")
+    assert_close(model.bn1.running_var.numpy().reshape(-1), g["wide_running_var_bn1"].reshape(-1), TOL, "wide running var")
+    Graph.free_graph_all()
+
+
 # ---------------------------------------------------------------------------------------------
 # SURVEY §8(f) row 3: the remaining nn surface against outputs of the reference (g11_nn_surface.npz,
 # oracle/gen_f3_golden.py)

@@ -76,6 +76,21 @@ def test_vgg16_and_mobilenet_one_step(hip_device, tag):
     pc.check_model_step(hip_device, tag)
 
 
+def test_wide_resnet18_one_step(hip_device):
+    """test/ResNet.py's ResNet-18 (64/128/256/512, ReLU after the add) on the fused hip path: against the float64
+    yardstick under the measured budget (tests/error_budget.py), and against the reference's own outputs with the
+    gradient tolerance that budget gives (never a flat number above 1e-4)."""
+    import error_budget as eb
+    from conftest import rel_err
+    from oracle.numpy_device import NumpyDevice, NumpyDevice64
+    exact = eb.with_device(NumpyDevice64, eb.wide_resnet_step)
+    fp32 = eb.with_device(NumpyDevice, eb.wide_resnet_step)
+    got = eb.wide_resnet_step(hip_device)
+    eb.assert_within_budget(got, exact, fp32, "hip wide ResNet-18 step (batch 2)")
+    e32 = max(rel_err(fp32[k], exact[k]) for k in ("conv1_wgrad", "fc_wgrad", "grad_abs_sum"))
+    pc.check_wide_resnet_step(hip_device, tol_grad=max(1e-4, 4.0 * e32))
+
+
 @pytest.mark.parametrize("shape", [(8, 32, 16, 16, 32, 3, 1, 1), (6, 32, 16, 16, 64, 3, 2, 1), (4, 64, 8, 8, 64, 3, 1, 1),
                                    (16, 128, 4, 4, 128, 3, 1, 1), (32, 256, 2, 2, 256, 3, 1, 1), (64, 128, 2, 2, 80, 3, 1, 1), (5, 32, 16, 16, 64, 1, 2, 0),
                                    (8, 64, 8, 8, 128, 1, 2, 0),

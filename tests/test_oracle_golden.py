@@ -92,6 +92,10 @@ def test_ref_ops_match_goldens():
         assert_close(p_, g[f"adam_wd_step{t + 1}_0"], 1e-6, "adam")
 
 
+def test_wide_resnet18_one_step(cpu_oracle):
+    pc.check_wide_resnet_step(cpu_oracle)
+
+
 @pytest.mark.parametrize("tag", ["vgg", "mbn"])
 def test_vgg16_and_mobilenet_one_step(cpu_oracle, tag):
     """the VGG16 / MobileNetV1 models of test/VGG.py and test/MobileNet.py."""
