@@ -352,6 +352,13 @@ def main():
     mod.synchronize()
     mod.prof_enable(False)
     prof = mod.prof_read()
+    # the clock the chip holds under a dense fp32-MFMA load (0.2 s of back-to-back MFMAs on every SIMD): the matrix
+    # families are priced against the data-sheet peak (2.4 GHz); this says what that peak is worth on this device
+    try:
+        clock_mhz, probe_tflops = mod.clock_probe(200.0) if rank == 0 else (None, None)
+    except Exception as e:
+        print(f"[bench] clock probe failed: {e}", file=sys.stderr)
+        clock_mhz = probe_tflops = None
     comm.barrier()
 
     if rank == 0:
@@ -378,6 +385,8 @@ def main():
                                    else "paced by the host"))
             roofline["launches_per_step"] = d["calls_per_step"]
             roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom, d["calls_per_step"], args.workload, args.dgrad)
+            roofline["mfma_clock_mhz_under_load"] = clock_mhz
+            roofline["mfma_probe_tflops"] = probe_tflops
             roofline["algorithmic_bytes_per_launch"] = prof[dom]["bytes"] / prof[dom]["calls"]
             roofline["algorithmic_flops_per_launch"] = prof[dom]["flops"] / prof[dom]["calls"]
         exchanged = bucket.total if sync is not None else 0

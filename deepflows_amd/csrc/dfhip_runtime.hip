@@ -78,7 +78,12 @@ static int do_init(int device_id) {
 int ensure_init() { return g_init ? DFHIP_OK : do_init(-1); }
 
 int xcd_arrangement(int nx, int ny, double x_bytes, double y_bytes) {
-  static int enabled = getenv("DFHIP_XCD_ORDER") ? atoi(getenv("DFHIP_XCD_ORDER")) : 1;
+  // default OFF: measured on the ResNet-18 layers it takes (profiles/r03b_xcd_*): the L2 fills drop as sized (2 x 2
+  // forward 20.0 -> 9.0 MB, its input gradient 20.0 -> 11.6 MB, layer4's stride-2 gradient 13.8 -> 9.6 MB per launch)
+  // but no launch gets shorter (+0.1 ... +0.6 us: the weights come out of the Infinity Cache either way, and with the
+  // arrangement the 32 workgroups of an XCD ask for the same weight lines at the same moment).  DFHIP_XCD_ORDER=1
+  // chooses the arrangement by bytes, 2 / 4 / 8 force one.
+  static int enabled = getenv("DFHIP_XCD_ORDER") ? atoi(getenv("DFHIP_XCD_ORDER")) : 0;
   if (!enabled || nx <= 0 || ny <= 0 || ((int64_t)nx * ny) % 8 != 0) return 0;
   if (enabled == 2 || enabled == 4 || enabled == 8) {            // forced arrangement (A/B runs)
     return (ny % enabled == 0 && nx % (8 / enabled) == 0) ? enabled : 0;
@@ -332,6 +337,74 @@ int dfhip_sync(void) {
 void* dfhip_stream(void) {
   (void)flush_deferred();
   return (void*)g_stream;
+}
+
+// ---- clock probe: the shader clock the chip holds under a dense fp32-MFMA load -------------------------------------
+// One wave per SIMD on every CU issues independent 16x16x4 fp32 MFMAs (four accumulator chains, register operands,
+// data that is neither zero nor constant); lane 0 of each wave stamps the shader-cycle counter (s_memtime) and the
+// 100 MHz real-time counter around the loop: cycles / real time = the clock during the loop (MI355X_MICROARCH.md,
+// DVFS give-back item 6).  The matrix-pipe roofline of a kernel is 64 flop per cycle and SIMD at THIS clock; the
+// 157.3 TFLOP/s of the data sheet is the same figure at 2.4 GHz.
+__global__ __launch_bounds__(256) void k_clock_probe(unsigned long long* __restrict__ out, int iters, float seed) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  float a = seed + 0.001f * (float)lane, b = 1.0f - 0.002f * (float)lane;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    a = -a;                                       // keeps the sums bounded and the operands changing
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  float sink = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) sink += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (lane == 0) {
+    const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    out[2 * w] = c1 - c0;
+    out[2 * w + 1] = (r1 - r0) | ((unsigned long long)(sink == 12345.678f) << 63);     // (keeps the MFMAs alive)
+  }
+}
+
+int dfhip_clock_probe(double milliseconds, double* mhz, double* tflops) {
+  DF_INIT();
+  DF_CHECK_ARG(mhz && milliseconds > 0.0 && milliseconds <= 2000.0, "clock_probe: bad arguments");
+  const int waves = num_cus() * 4;
+  unsigned long long* d = nullptr;
+  DF_HIP(hipMalloc((void**)&d, (size_t)waves * 2 * sizeof(unsigned long long)));
+  std::vector<unsigned long long> h((size_t)waves * 2);
+  // launches of ~0.25 ms (4 MFMAs x 32 cycles per iteration at <= 2.4 GHz) back to back for the requested time; the
+  // stamps of the LAST launch are read
+  const int iters = 4700;
+  const int launches = std::max(1, (int)(milliseconds / 0.25));
+  for (int l = 0; l < launches; l++) {
+    hipLaunchKernelGGL(k_clock_probe, dim3((unsigned)num_cus()), dim3(256), 0, g_stream, d, iters, 0.37f + 0.01f * (float)l);
+  }
+  DF_LAUNCH_CHECK();
+  DF_HIP(hipMemcpyAsync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, g_stream));
+  DF_HIP(hipStreamSynchronize(g_stream));
+  (void)hipFree(d);
+  std::vector<double> clk;
+  for (int w = 0; w < waves; w++) {
+    const double cyc = (double)h[2 * (size_t)w], ticks = (double)(h[2 * (size_t)w + 1] & ~(1ull << 63));
+    if (ticks > 0) clk.push_back(cyc / ticks * 100.0);       // MHz: the real-time counter runs at 100 MHz
+  }
+  DF_CHECK_ARG(!clk.empty(), "clock_probe: no stamps came back");
+  std::sort(clk.begin(), clk.end());
+  *mhz = clk[clk.size() / 2];
+  if (tflops) {
+    // what the loop delivered: 4 MFMAs x 2048 flop per iteration and wave
+    double best = 0.0;
+    for (int w = 0; w < waves; w++) {
+      const double ticks = (double)(h[2 * (size_t)w + 1] & ~(1ull << 63));
+      if (ticks > best) best = ticks;
+    }
+    *tflops = best > 0 ? (double)waves * iters * 4.0 * 2048.0 / (best * 1e-8) / 1e12 : 0.0;
+  }
+  return DFHIP_OK;
 }
 
 int dfhip_device_name(char* out, int cap) {

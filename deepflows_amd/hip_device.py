@@ -562,6 +562,12 @@ class HipModule:
         _lib.check(self._lib.dfhip_event_elapsed_ms(e0, e1, byref(ms)))
         return ms.value
 
+    def clock_probe(self, milliseconds=100.0):
+        """(MHz the chip holds under a dense fp32-MFMA load, TFLOP/s that load delivered)."""
+        mhz, tf = c_double(0.0), c_double(0.0)
+        _lib.check(self._lib.dfhip_clock_probe(float(milliseconds), byref(mhz), byref(tf)))
+        return float(mhz.value), float(tf.value)
+
     def pool_stats(self):
         a, b, c = c_int64(), c_int64(), c_int64()
         self._lib.dfhip_pool_stats(byref(a), byref(b), byref(c))

@@ -332,6 +332,7 @@ class _Conv2dFused(_FusedNode):
     # (_BnReluPoolFused.grad_fn -> dfhip_stem_backward): grad_fn hands it out, the gradient it is called with is a
     # placeholder
     _dw_ready = None
+    _dw_from_stem = False        # (diagnostic: the last weight gradient handed out came from the stem's launch)
 
     def grad_fn(self, node, grad, accumulated=None):
         g = grad.compact()
@@ -363,6 +364,7 @@ class _Conv2dFused(_FusedNode):
                 dw, placeholder = self._dw_ready
                 self._dw_ready = None             # consumed: a second backward() over a retained graph starts afresh
                 if grad is placeholder:
+                    self._dw_from_stem = True
                     return dw
                 # cannot happen while the pooling node checks that it is the only consumer (the placeholder holds
                 # no values to fall back on): refuse rather than return a gradient without the other contribution

@@ -398,6 +398,11 @@ int dfhip_comm_wait(void);
 int dfhip_comm_allreduce_max(float* value);
 /* path of the shared object the RCCL symbols were resolved from ("" before dfhip_comm_unique_id / _init) */
 int dfhip_comm_rccl_path(char* out, int cap);
+/* Diagnostic: the shader clock (MHz, median over all SIMDs) the chip holds while every SIMD issues fp32 MFMAs back to
+ * back for `milliseconds`, and the TFLOP/s that loop delivered (tflops may be NULL).  bench.py prices the matrix-core
+ * families against the data-sheet peak and reports this figure beside it. */
+int dfhip_clock_probe(double milliseconds, double* mhz, double* tflops);
+
 /* size of the communicator and this process's rank in it, as RCCL reports them (ncclCommCount / ncclCommUserRank) */
 int dfhip_comm_count(int* ranks, int* rank);
 int dfhip_comm_destroy(void);

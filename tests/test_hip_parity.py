@@ -576,7 +576,7 @@ def test_stem_backward_without_the_full_resolution_gradient(hip_device, k, pad):
             loss = tensor.sum(y * Tensor(gy, device=dev))
             loss.backward()
             if fused:
-                assert z._dw_ready is not None, "the fused backward must take this shape"
+                assert z._dw_from_stem, "the fused backward must take this shape"
             results.append([y.numpy().copy(), conv.weight.grad.numpy().copy(), bn.weight.grad.numpy().copy(),
                             bn.bias.grad.numpy().copy()])
             Graph.free_graph_all()
