@@ -37,7 +37,14 @@ static hipStream_t g_stream = nullptr;
 static int g_num_cus = 256;
 static char g_devname[256] = "";
 
-hipStream_t stream() { return g_stream; }
+// A second stream for work that may run BESIDE what the library stream does next (weight gradients beside the rest of
+// the backward pass): dfhip_side_fork makes it wait for everything queued on the library stream so far, launches
+// issued while side_active() go to it, dfhip_side_join makes the library stream wait for it.  Inside a capture the two
+// become a fork and a join of the graph.
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_side_fork_ev = nullptr, g_side_join_ev = nullptr;
+static bool g_side_target = false, g_side_pending = false;
+hipStream_t stream() { return g_side_target ? g_side : g_stream; }
 bool initialised() { return g_init; }
 int num_cus() { return g_num_cus; }
 
@@ -348,23 +355,28 @@ void* dfhip_stream(void) {
 __global__ __launch_bounds__(256) void k_clock_probe(unsigned long long* __restrict__ out, int iters, float seed) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63;
-  float a = seed + 0.001f * (float)lane, b = 1.0f - 0.002f * (float)lane;
-  f32x4 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
-  for (int it = 0; it < iters; it++) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
-    a = -a;                                       // keeps the sums bounded and the operands changing
+  // two operand pairs of opposite sign, used alternately: the sums stay bounded and no vector instruction sits
+  // between the MFMAs (a VALU write to an MFMA operand costs wait states)
+  const float a0 = seed + 0.001f * (float)lane, a1 = -a0, b = 1.0f - 0.002f * (float)lane;
+  f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+  const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+  for (int it = 0; it < iters; it += 2) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, c3, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, c3, 0, 0, 0);
   }
-  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
-  float sink = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; i++) sink += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  const f32x4 cs = c0 + c1 + c2 + c3;
+  const float sink = cs[0] + cs[1] + cs[2] + cs[3];
   if (lane == 0) {
     const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    out[2 * w] = c1 - c0;
+    out[2 * w] = t1 - t0;
     out[2 * w + 1] = (r1 - r0) | ((unsigned long long)(sink == 12345.678f) << 63);     // (keeps the MFMAs alive)
   }
 }
@@ -378,7 +390,7 @@ int dfhip_clock_probe(double milliseconds, double* mhz, double* tflops) {
   std::vector<unsigned long long> h((size_t)waves * 2);
   // launches of ~0.25 ms (4 MFMAs x 32 cycles per iteration at <= 2.4 GHz) back to back for the requested time; the
   // stamps of the LAST launch are read
-  const int iters = 4700;
+  const int iters = 4700;                        // (even: the loop body is two iterations)
   const int launches = std::max(1, (int)(milliseconds / 0.25));
   for (int l = 0; l < launches; l++) {
     hipLaunchKernelGGL(k_clock_probe, dim3((unsigned)num_cus()), dim3(256), 0, g_stream, d, iters, 0.37f + 0.01f * (float)l);
@@ -860,6 +872,61 @@ static void release_capture_blocks(int capture_id) {
   }
 }
 
+static int side_fork() {
+  if (!g_side) {
+    DF_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+    DF_HIP(hipEventCreateWithFlags(&g_side_fork_ev, hipEventDisableTiming));
+    DF_HIP(hipEventCreateWithFlags(&g_side_join_ev, hipEventDisableTiming));
+  }
+  DF_HIP(hipEventRecord(g_side_fork_ev, g_stream));
+  DF_HIP(hipStreamWaitEvent(g_side, g_side_fork_ev, 0));
+  g_side_pending = true;
+  return DFHIP_OK;
+}
+static int side_join() {
+  g_side_target = false;
+  if (g_side_pending) {
+    DF_HIP(hipEventRecord(g_side_join_ev, g_side));
+    DF_HIP(hipStreamWaitEvent(g_stream, g_side_join_ev, 0));
+    g_side_pending = false;
+  }
+  return DFHIP_OK;
+}
+int dfhip_side_fork(void) { DF_INIT_KEEP(); return side_fork(); }
+int dfhip_side_target(int on) {
+  DF_INIT_KEEP();
+  DF_CHECK_ARG(!on || g_side_pending, "side_target: fork first");
+  g_side_target = on != 0;
+  return DFHIP_OK;
+}
+int dfhip_side_join(void) { DF_INIT_KEEP(); return side_join(); }
+
+// diagnostic: `wgs` workgroups of the clock-probe loop (iters x 4 MFMAs per wave) on the side stream, each holding
+// lds_bytes of LDS so that nothing else fits beside it on its CU -- what a long matrix-bound launch beside the main
+// stream costs the main stream
+int dfhip_side_probe(int wgs, int iters, int lds_bytes) {
+  DF_INIT_KEEP();
+  DF_CHECK_ARG(wgs > 0 && iters > 0 && lds_bytes >= 0 && lds_bytes <= 160 * 1024, "side_probe: bad arguments");
+  static unsigned long long* d = nullptr;
+  static int cap = 0;
+  if (cap < wgs) {
+    DF_CHECK_ARG(!g_capture_open, "side_probe: first call (allocation) inside a capture");
+    if (d) (void)hipFree(d);
+    DF_HIP(hipMalloc((void**)&d, (size_t)wgs * 8 * sizeof(unsigned long long)));
+    cap = wgs;
+  }
+  static bool attr = false;
+  if (!attr) {
+    DF_HIP(hipFuncSetAttribute((const void*)k_clock_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  int s = side_fork();
+  if (s != DFHIP_OK) return s;
+  hipLaunchKernelGGL(k_clock_probe, dim3((unsigned)wgs), dim3(256), (size_t)lds_bytes, g_side, d, iters, 0.41f);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
 int dfhip_graph_begin(void) {
   DF_INIT();
   DF_CHECK_ARG(!g_capture_open, "a capture is already open");
@@ -882,6 +949,7 @@ int dfhip_graph_end(void** graph_exec) {
   // the capture must be closed even when it has been invalidated (an illegal call inside it, e.g. a
   // blocking copy): otherwise every later launch on the stream fails
   const int f__ = flush_deferred();
+  (void)side_join();                               // a forked side stream must be back before the capture closes
   int id = g_capture_open;
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamEndCapture(g_stream, &graph);

@@ -38,12 +38,20 @@ class CapturedTrainStep:
         optimizer.device_hyper = True
         optimizer.push_hyper()                      # allocates the scalar array outside the capture
         mod.capture_feeds = []                      # host-drawn inputs of the step (Dropout masks), in forward order
+        if os.environ.get("DF_SIDE_PROBE"):         # (the diagnostic load allocates its stamp buffer on first use)
+            mod.side_probe(*[int(v) for v in os.environ["DF_SIDE_PROBE"].split(",")])
+            mod.side_join()
         mod.capture_begin()
         try:
             outputs = model(inputs)
             loss = criterion(outputs, targets)
             optimizer.zero_grad()
+            probe = os.environ.get("DF_SIDE_PROBE")      # diagnostic: "wgs,iters,lds_bytes" of MFMA load beside backward
+            if probe:
+                mod.side_probe(*[int(v) for v in probe.split(",")])
             loss.backward()
+            if probe:
+                mod.side_join()
             if sync is None:
                 optimizer.apply()
             Graph.free_graph()
