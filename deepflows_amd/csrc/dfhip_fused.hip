@@ -687,6 +687,49 @@ __global__ __launch_bounds__(kThreads) void k_bn_relu_pool_fwd(
   }
 }
 
+// The stem without its full-resolution tensor (dfhip_stem.hip): `sel` holds, per 2 x 2 window of the convolution
+// output, the extreme that survives bn + relu + max (the maximum for gamma >= 0, the minimum for gamma < 0: both maps
+// are monotone, so relu(bn(sel)) IS the pooled value, bit for bit); the statistics come from the convolution's
+// partials as in k_bn_relu_pool_fwd.  `sel` has CS >= C channel planes per image.  Block (c, s) owns images [s * ipb, (s + 1) * ipb) of channel c; P = pooled
+// pixels per plane (a multiple of 4).
+__global__ __launch_bounds__(kThreads) void k_sel_bn_relu_fwd(
+    const float* __restrict__ sel, int CS, const float* __restrict__ partial, int rows, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ save_mean, float* __restrict__ save_var,
+    float* __restrict__ running_mean, float* __restrict__ running_var, int N, int C, int P, int ipb, float eps,
+    float momentum) {
+  __shared__ float sw[4][3];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const float w = chan_param(gamma, partial, c, 1.0f), b = chan_param(beta, partial, c, 0.0f);   // (requested up front)
+  const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
+  const int p4 = P >> 2, items = (n_hi - n_lo) * p4;
+  // the first vector of every thread is requested before the rows are combined
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((int)threadIdx.x < items) {
+    const int img = n_lo + (int)threadIdx.x / p4, q = (int)threadIdx.x % p4;
+    v0 = *reinterpret_cast<const float4*>(sel + ((int64_t)img * CS + c) * P + 4 * q);
+  }
+  float mean, var;
+  bn_combine_rows(partial, rows, C, c, sw, mean, var);
+  if (s == 0 && threadIdx.x == 0) {
+    if (save_mean) save_mean[c] = mean;
+    if (save_var) save_var[c] = var;
+    if (running_mean) running_mean[c] = running_mean[c] * (1.0f - momentum) + mean * momentum;
+    if (running_var) running_var[c] = running_var[c] * (1.0f - momentum) + var * momentum;
+  }
+  const float rsd = 1.0f / sqrtf(var + eps);
+  for (int e = threadIdx.x; e < items; e += kThreads) {
+    const int img = n_lo + e / p4, q = e % p4;
+    const int64_t at = ((int64_t)img * C + c) * P + 4 * q;
+    const float4 v = e == (int)threadIdx.x ? v0 : *reinterpret_cast<const float4*>(sel + ((int64_t)img * CS + c) * P + 4 * q);
+    float4 r;
+    r.x = relu_point(bn_point(v.x, mean, rsd, w, b));
+    r.y = relu_point(bn_point(v.y, mean, rsd, w, b));
+    r.z = relu_point(bn_point(v.z, mean, rsd, w, b));
+    r.w = relu_point(bn_point(v.w, mean, rsd, w, b));
+    *reinterpret_cast<float4*>(y + at) = r;
+  }
+}
+
 // gradient that reaches the BatchNorm output at one input position
 
 template <bool APPLY>
@@ -1703,6 +1746,22 @@ int stem_bwd_stats(const float* z, const float* y, const float* g, const float* 
   DF_LAUNCH_CHECK();
   *partial = part;
   *S_out = S;
+  return DFHIP_OK;
+}
+
+int stem_pool_apply(const float* sel, int sel_planes, const float* partials, int rows, const float* gamma, const float* beta, float* y,
+                    float* save_mean, float* save_var, float* running_mean, float* running_var, int N, int C, int P,
+                    float eps, float momentum) {
+  if (rows < 1 || (P & 3)) {
+    set_error("stem_pool_apply: no partial rows / pooled plane not a multiple of 4");
+    return DFHIP_INVALID_ARGUMENT;
+  }
+  int S, ipb;
+  bn_split(N, C, S, ipb);
+  dim3 grid((unsigned)C, (unsigned)S);
+  DF_LAUNCH(k_sel_bn_relu_fwd, grid, dim3(kThreads), 0, stream(), sel, sel_planes, partials, rows, gamma, beta, y, save_mean, save_var,
+            running_mean, running_var, N, C, P, ipb, eps, momentum);
+  DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
 

@@ -147,6 +147,12 @@ int stem_bwd_stats(const float* z, const float* y, const float* g, const float* 
                    const float* mean, const float* var, int N, int C, int H, int W, float eps, const float** partial,
                    int* S);
 
+// dfhip_fused.hip: y = relu(bn(sel)) with the statistics from convolution partials -- the second launch of the stem
+// without its full-resolution tensor (dfhip_stem.hip)
+int stem_pool_apply(const float* sel, int sel_planes, const float* partials, int rows, const float* gamma, const float* beta, float* y,
+                    float* save_mean, float* save_var, float* running_mean, float* running_var, int N, int C, int P,
+                    float eps, float momentum);
+
 // every kernel launch of the library
 #define DF_LAUNCH(kern, grid, block, lds, strm, ...)                                                  \
   do {                                                                                                \

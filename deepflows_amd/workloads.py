@@ -170,13 +170,17 @@ class ResNet(nn.Module):
     def forward(self, x):
         if not isinstance(x, Tensor):
             x = Tensor(x)
-        x = self.conv1(x)
-        if not self._stem_pool:
-            x = self.relu(self.bn1(x))                                # test/ResNet.py:110-112: no pooling
-        elif nn.functional.bn_relu_maxpool2_fusable(x, self.bn1, self.pool1):
-            x = nn.functional.bn_relu_maxpool2_train(x, self.bn1)     # one node on the hip device
+        stem = nn.functional.stem_conv_bn_relu_pool_train(x, self.conv1, self.bn1, self.pool1) if self._stem_pool else None
+        if stem is not None:
+            x = stem                                                  # one node, the 33 MB convolution output never exists
+        elif not self._stem_pool:
+            x = self.relu(self.bn1(self.conv1(x)))                    # test/ResNet.py:110-112: no pooling
         else:
-            x = self.pool1(self.relu(self.bn1(x)))
+            x = self.conv1(x)
+            if nn.functional.bn_relu_maxpool2_fusable(x, self.bn1, self.pool1):
+                x = nn.functional.bn_relu_maxpool2_train(x, self.bn1)     # one node on the hip device
+            else:
+                x = self.pool1(self.relu(self.bn1(x)))
         for stage in (self.layer1, self.layer2, self.layer3):
             for blk in stage:
                 x = blk(x)

@@ -586,6 +586,57 @@ def test_stem_backward_without_the_full_resolution_gradient(hip_device, k, pad):
         assert_close(a, b, 2e-6, f"stem backward k={k}: " + nm)
 
 
+@pytest.mark.parametrize("N,C,H,O", [(32, 3, 32, 32), (5, 3, 32, 32), (7, 2, 16, 20), (3, 1, 8, 32), (300, 3, 32, 32)])
+def test_stem_without_its_convolution_output(hip_device, N, C, H, O):
+    """pool(relu(bn(conv(x)))) as the one node whose 33 MB convolution output never exists (dfhip_stem.hip: the
+    convolution keeps the window extreme that survives bn + relu + max -- the minimum where gamma < 0 --, the backward
+    kernels rebuild the convolution from x) against the separate operators with their own backward launches.  Integer
+    data and coarse weights: exact ties at the window maximum survive the convolution; gamma has negative and zero
+    channels."""
+    from deepflows_amd import nn, tensor
+    from deepflows_amd.tensor import Graph, Tensor
+    F = nn.functional
+    dev = hip_device
+    rng = np.random.default_rng(23)
+    x = rng.integers(-2, 3, size=(N, C, H, 32)).astype(np.float32)
+    gy = rng.standard_normal((N, O, H // 2, 16)).astype(np.float32)
+    gamma = (rng.integers(-4, 9, size=(1, O, 1, 1)) / 4).astype(np.float32)
+    gamma.reshape(-1)[:3] = (-1.0, 0.0, 0.75)
+    beta = (rng.integers(-4, 5, size=(1, O, 1, 1)) / 8).astype(np.float32)
+    pool = nn.MaxPool2d(kernel_size=2, stride=2)
+    results = []
+    for one_node in (True, False):
+        F._STEM_FUSED_BWD = False                    # the comparison path: every operator's own backward launch
+        try:
+            np.random.seed(2)
+            conv = nn.Conv2d(C, O, kernel_size=3, stride=1, padding=1, bias=False, device=dev)
+            wq = np.round(conv.weight.numpy() * 8) / 8
+            dev.mod.from_numpy(wq.astype(np.float32), conv.weight.data._handle)
+            bn = nn.BatchNorm2d(O, device=dev)
+            dev.mod.from_numpy(gamma, bn.weight.data._handle)
+            dev.mod.from_numpy(beta, bn.bias.data._handle)
+            bn.train()
+            xt = Tensor(x, device=dev)
+            if one_node:
+                y = F.stem_conv_bn_relu_pool_train(xt, conv, bn, pool)
+                assert y is not None, "the one-node stem must take this shape"
+            else:
+                y = F.bn_relu_maxpool2_train(conv(xt), bn)
+            loss = tensor.sum(y * Tensor(gy, device=dev))
+            loss.backward()
+            results.append([y.numpy().copy(), bn.running_mean.numpy().copy(), bn.running_var.numpy().copy(),
+                            conv.weight.grad.numpy().copy(), bn.weight.grad.numpy().copy(), bn.bias.grad.numpy().copy()])
+            Graph.free_graph_all()
+        finally:
+            F._STEM_FUSED_BWD = True
+    names = ("y", "running_mean", "running_var", "dw", "dgamma", "dbeta")
+    for a, b, nm in zip(results[0], results[1], names):
+        assert_close(a, b, 3e-6 if nm in ("y", "running_mean", "running_var") else 2e-5, f"stem without z ({N},{C},{H},{O}): " + nm)
+    # the pooled values are relu(bn(.)) of an element of the window: where the two paths' statistics agree to the bit
+    # the outputs must too -- at least the zero pattern (ReLU) is identical
+    assert np.array_equal(results[0][0] == 0.0, results[1][0] == 0.0)
+
+
 def test_classifier_head_as_one_node(hip_device):
     """fc(mean(mean(x, 2), 2)) + cross-entropy: the pooled-linear node and the loss gradient left behind by the loss
     kernel, against the separate nodes (mean_hw, Linear, cross-entropy with its own backward launch)."""
