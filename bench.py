@@ -171,28 +171,29 @@ def csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(family, calls_per_step, workload, dgrad):
-    """HBM bytes per launch of `family` from the newest committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    on this same command, FETCH_SIZE x2 per the gfx950 note) -- only if it was taken on THIS build of the kernels
-    and this workload; counters cannot be read from inside the process."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
+def pmc_file(workload, dgrad, explicit=None):
+    """The PMC summary (tools/pmc_summary.py --json) to quote: `explicit` if given, otherwise the newest committed
+    profiles/r*_pmc_traffic*.json that was taken on THIS build of the kernels, this workload and this mode.  Returns
+    (dict or None, why / where)."""
+    paths = [explicit] if explicit else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True)
+    if not paths:
         return None, "no PMC pass on file"
-    path = files[-1]
-    try:
-        pmc = json.load(open(path))
-    except Exception as e:
-        return None, f"{os.path.basename(path)} unreadable: {e}"
-    rel = os.path.relpath(path, ROOT)
-    if pmc.get("csrc_sha16") != csrc_fingerprint():
-        return None, f"{rel} was measured on kernel sources {pmc.get('csrc_sha16')} (git {pmc.get('git', '?')}), " \
-                     f"this build is {csrc_fingerprint()}: stale, not quoted"
-    if pmc.get("workload", "resnet18") != workload or pmc.get("dgrad", "overwrite") != dgrad:
-        return None, f"{rel} is a pass of another workload / mode"
-    fam = pmc.get("families", {}).get(family)
-    if not fam:
-        return None, f"{rel} has no entry for {family}"
-    return fam["hbm_bytes_per_step"] / calls_per_step, f"{rel} (git {pmc.get('git', '?')}, kernel sources {pmc['csrc_sha16']})"
+    why = []
+    for path in paths:
+        rel = os.path.relpath(path, ROOT)
+        try:
+            pmc = json.load(open(path))
+        except Exception as e:
+            why.append(f"{rel} unreadable: {e}")
+            continue
+        if pmc.get("workload", "resnet18") != workload or pmc.get("dgrad", "overwrite") != dgrad:
+            continue
+        if pmc.get("csrc_sha16") != csrc_fingerprint():
+            why.append(f"{rel} was measured on kernel sources {pmc.get('csrc_sha16')} (git {pmc.get('git', '?')}), this build "
+                       f"is {csrc_fingerprint()}: stale, not quoted")
+            continue
+        return pmc, f"{rel} (git {pmc.get('git', '?')}, kernel sources {pmc['csrc_sha16']})"
+    return None, "; ".join(why) if why else "no PMC pass of this workload / mode on file"
 
 
 def family_rooflines(prof, steps):
@@ -235,6 +236,9 @@ def main():
     ap.add_argument("--registration", choices=["all", "f6"], default="all",
                     help="all = every block registered (62 tensors); f6 = the reference script's 5 tensors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-traffic", default=None,
+                    help="PMC summary (tools/pmc_summary.py --json) to quote for traffic / executed flops instead of the "
+                         "newest matching file under profiles/")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
     ap.add_argument("--no-prof-gate", action="store_true",
                     help="per-family event pass with the queue running dry between launches (host-paced)")
@@ -352,6 +356,7 @@ def main():
     mod.synchronize()
     mod.prof_enable(False)
     prof = mod.prof_read()
+    kprof = mod.prof_read_kernels() if hasattr(mod, "prof_read_kernels") else {}
     # the clock the chip holds under a dense fp32-MFMA load (0.2 s of back-to-back MFMAs on every SIMD): the matrix
     # families are priced against the data-sheet peak (2.4 GHz); this says what that peak is worth on this device
     try:
@@ -384,7 +389,19 @@ def main():
                                   ("queued behind a gate and released per step (back to back)" if not args.no_prof_gate
                                    else "paced by the host"))
             roofline["launches_per_step"] = d["calls_per_step"]
-            roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom, d["calls_per_step"], args.workload, args.dgrad)
+            pmc, pmc_src = pmc_file(args.workload, args.dgrad, args.pmc_traffic)
+            pfam = (pmc or {}).get("families", {}).get(dom)
+            roofline["traffic_source"] = pmc_src if pfam or pmc is None else f"{pmc_src}: no entry for {dom}"
+            if pfam:
+                # counters of a separate rocprofv3 pass of this command on this build: HBM bytes per launch, the flops
+                # the matrix cores EXECUTED (padding taps that are skipped are algorithmic but not executed) against the
+                # peak over this run's own launch durations, and the matrix-pipe busy fraction inside the profiled pass
+                roofline["traffic"] = pfam["hbm_bytes_per_step"] / d["calls_per_step"]
+                if d["bound"] == "mfma" and pfam.get("executed_flops_per_step"):
+                    ex = pfam["executed_flops_per_step"] / d["calls_per_step"]
+                    roofline["executed_flops_per_launch"] = ex
+                    roofline["frac_executed"] = ex / (d["avg_us"] * 1e-6) / 1e12 / PEAK_MFMA_F32_TFLOPS
+                    roofline["mfma_busy"] = pfam.get("mfma_busy")
             roofline["mfma_clock_mhz_under_load"] = clock_mhz
             roofline["mfma_probe_tflops"] = probe_tflops
             roofline["algorithmic_bytes_per_launch"] = prof[dom]["bytes"] / prof[dom]["calls"]
@@ -408,6 +425,13 @@ def main():
             "roofline": roofline,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in
                         sorted(fams.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+            # per kernel instantiation (names as rocprofv3 prints them): launches per step, the kernel's own duration,
+            # the algorithmic work of the family calls it was the first launch of
+            "kernel_table": [{"kernel": name, "family": r["family"], "launches_per_step": round(r["launches"] / args.steps, 3),
+                              "avg_us": round(r["kernel_ms"] / r["launches"] * 1e3, 3),
+                              "alg_gflop_per_launch": round(r["flops"] / r["launches"] / 1e9, 4),
+                              "alg_mb_per_launch": round(r["bytes"] / r["launches"] / 1e6, 3)}
+                             for name, r in sorted(kprof.items(), key=lambda kv: -kv[1]["kernel_ms"]) if r["launches"]],
         }
         if comm.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, batch)

@@ -132,7 +132,7 @@ for _n in ("log", "exp", "tanh"):
     _SIGS["dfhip_ewise_" + _n] = [P, P, c_int64]
 
 # every symbol include/dfhip.h declares (tests check the .so exports all of them)
-ALL_SYMBOLS = sorted(list(_SIGS) + ["dfhip_last_error", "dfhip_stream", "dfhip_prof_read"])
+ALL_SYMBOLS = sorted(list(_SIGS) + ["dfhip_last_error", "dfhip_stream", "dfhip_prof_read", "dfhip_prof_read_kernels"])
 
 
 def library_present():
@@ -160,6 +160,9 @@ def load():
     lib.dfhip_prof_read.argtypes = [c_int, POINTER(c_char_p), POINTER(c_double), I64P,
                                     POINTER(c_double), POINTER(c_double), POINTER(c_double), I64P]
     lib.dfhip_prof_read.restype = c_int
+    lib.dfhip_prof_read_kernels.argtypes = [c_int, POINTER(c_char_p), POINTER(c_char_p), POINTER(c_double), I64P,
+                                            POINTER(c_double), POINTER(c_double)]
+    lib.dfhip_prof_read_kernels.restype = c_int
     _lib = lib
     return lib
 

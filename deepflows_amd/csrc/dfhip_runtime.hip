@@ -238,8 +238,20 @@ struct ProfSlot {
   // event pairs bound to the dispatches themselves: kernel-only time of the family's launches
   double kernel_ms = 0;
   int64_t kernel_launches = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> kpending;
+  struct KPending { hipEvent_t a, b; int rec; };
+  std::vector<KPending> kpending;
 };
+// per KERNEL (the instantiation's own name, from DF_LAUNCH): launches and the kernels' own durations, plus the
+// algorithmic flops / bytes of the scopes whose first launch it was
+struct KernelRec {
+  const char* pretty;          // __PRETTY_FUNCTION__ of df_kernel_name<&kernel>
+  std::string name;
+  int slot;                    // family
+  double ms = 0, flops = 0, bytes = 0;
+  int64_t launches = 0;
+};
+static std::vector<KernelRec> g_krec;
+static double g_scope_flops = 0, g_scope_bytes = 0;     // of the innermost scope, not yet handed to a kernel
 static int g_prof_scope = -1;           // slot of the innermost active ProfScope
 static bool g_prof_on = false;
 bool profiling() { return g_prof_on; }
@@ -269,21 +281,48 @@ static void prof_resolve(ProfSlot& s) {
   s.pending.clear();
   for (auto& pr : s.kpending) {
     float ms = 0;
-    if (hipEventSynchronize(pr.second) == hipSuccess &&
-        hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+    if (hipEventSynchronize(pr.b) == hipSuccess && hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
       s.kernel_ms += ms;
       s.kernel_launches++;
+      if (pr.rec >= 0) { g_krec[pr.rec].ms += ms; g_krec[pr.rec].launches++; }
     }
-    g_event_pool.push_back(pr.first);
-    g_event_pool.push_back(pr.second);
+    g_event_pool.push_back(pr.a);
+    g_event_pool.push_back(pr.b);
   }
   s.kpending.clear();
 }
-bool prof_kernel_events(hipEvent_t* start, hipEvent_t* stop) {
+static int kernel_record(const char* pretty, int slot) {
+  if (!pretty) return -1;
+  for (size_t i = 0; i < g_krec.size(); i++)
+    if (g_krec[i].slot == slot && (g_krec[i].pretty == pretty || strcmp(g_krec[i].pretty, pretty) == 0)) return (int)i;
+  KernelRec r;
+  r.pretty = pretty;
+  r.slot = slot;
+  // "const char *df_kernel_name() [K = &(anonymous namespace)::k_x<1, true>]" -> "k_x<1, true>"
+  std::string t = pretty;
+  size_t a = t.find("K = ");
+  if (a != std::string::npos) t = t.substr(a + 4);
+  if (!t.empty() && t[0] == '&') t = t.substr(1);
+  if (!t.empty() && t.back() == ']') t.pop_back();
+  for (const char* drop : {"(anonymous namespace)::", "dfhip::"}) {
+    size_t q;
+    while ((q = t.find(drop)) != std::string::npos) t.erase(q, strlen(drop));
+  }
+  r.name = t;
+  g_krec.push_back(r);
+  return (int)g_krec.size() - 1;
+}
+bool prof_kernel_events(const char* pretty, hipEvent_t* start, hipEvent_t* stop) {
   if (g_prof_scope < 0 || g_capture_open) return false;
   hipEvent_t a = get_event(), b = get_event();
   if (!a || !b) return false;
-  g_prof[g_prof_scope].kpending.emplace_back(a, b);
+  const int rec = kernel_record(pretty, g_prof_scope);
+  if (rec >= 0) {
+    g_krec[rec].flops += g_scope_flops;              // the scope's algorithmic work goes to its first launch
+    g_krec[rec].bytes += g_scope_bytes;
+    g_scope_flops = g_scope_bytes = 0;
+  }
+  g_prof[g_prof_scope].kpending.push_back({a, b, rec});
   *start = a;
   *stop = b;
   return true;
@@ -307,6 +346,8 @@ ProfScope::ProfScope(const char* family, double flops, double bytes) : slot(-1),
   on = true;
   prev = g_prof_scope;
   g_prof_scope = slot;
+  g_scope_flops = flops;
+  g_scope_bytes = bytes;
   (void)hipEventRecord(e0, g_stream);
 }
 ProfScope::~ProfScope() {
@@ -1069,7 +1110,28 @@ int dfhip_prof_reset(void) {
     s.ms = s.flops = s.bytes = s.kernel_ms = 0;
     s.calls = s.kernel_launches = 0;
   }
+  for (auto& k : g_krec) { k.ms = k.flops = k.bytes = 0; k.launches = 0; }
   return DFHIP_OK;
+}
+// per kernel instantiation: name, family, launches, summed duration of the kernels' own start / end stamps, and the
+// algorithmic flops / bytes of the family calls whose first launch it was
+int dfhip_prof_read_kernels(int cap, const char** names, const char** families, double* kernel_ms, int64_t* launches,
+                            double* flops, double* bytes) {
+  (void)flush_deferred();
+  for (auto& s : g_prof) prof_resolve(s);
+  int n = 0;
+  for (auto& k : g_krec) {
+    if (n >= cap) break;
+    if (k.launches == 0) continue;
+    names[n] = k.name.c_str();
+    families[n] = g_prof[k.slot].name;
+    kernel_ms[n] = k.ms;
+    launches[n] = k.launches;
+    flops[n] = k.flops;
+    bytes[n] = k.bytes;
+    n++;
+  }
+  return n;
 }
 int dfhip_prof_read(int cap, const char** names, double* total_ms, int64_t* calls,
                     double* flops, double* bytes, double* kernel_ms, int64_t* kernel_launches) {

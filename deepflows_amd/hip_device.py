@@ -632,6 +632,24 @@ class HipModule:
                 for i in range(n)}
 
 
+    def prof_read_kernels(self):
+        """Per kernel instantiation: {name: {family, launches, kernel_ms, flops, bytes}} (dfhip_prof_read_kernels)."""
+        cap = 256
+        names, fams = (c_char_p * cap)(), (c_char_p * cap)()
+        ms, launches = (c_double * cap)(), (c_int64 * cap)()
+        flops, nbytes = (c_double * cap)(), (c_double * cap)()
+        n = self._lib.dfhip_prof_read_kernels(cap, names, fams, ms, launches, flops, nbytes)
+        out = {}
+        for i in range(n):
+            key = names[i].decode()
+            ent = out.setdefault(key, {"family": fams[i].decode(), "launches": 0, "kernel_ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            ent["launches"] += launches[i]
+            ent["kernel_ms"] += ms[i]
+            ent["flops"] += flops[i]
+            ent["bytes"] += nbytes[i]
+        return out
+
+
 _module = None
 
 

@@ -468,6 +468,11 @@ int dfhip_prof_gate_open(void);
  * figure rocprofv3's kernel trace reports) */
 int dfhip_prof_read(int cap, const char** names, double* total_ms, int64_t* calls,
                     double* flops, double* bytes, double* kernel_ms, int64_t* kernel_launches);
+/* The same per KERNEL instantiation (name as the profiler prints it, e.g. "k_conv3x3_rowmma<4, 32, ...>"): launches,
+ * the kernels' own durations summed, and the algorithmic flops / bytes of the family calls whose first launch it was.
+ * Returns the number of rows written (<= cap); the name pointers stay valid until the library is unloaded. */
+int dfhip_prof_read_kernels(int cap, const char** names, const char** families, double* kernel_ms, int64_t* launches,
+                            double* flops, double* bytes);
 
 #ifdef __cplusplus
 }
