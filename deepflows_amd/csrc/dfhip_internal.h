@@ -30,7 +30,7 @@ struct ProfScope {
 // Inside an active ProfScope every launch also gets an event pair BOUND TO ITS DISPATCH (hipExtLaunchKernelGGL:
 // the pair reads the kernel's own start / end time stamps, what rocprofv3's kernel trace reports); false when no
 // scope is active.
-bool prof_kernel_events(const char* pretty_name, hipEvent_t* start, hipEvent_t* stop);
+bool prof_kernel_events(const void* host_function, hipEvent_t* start, hipEvent_t* stop);
 
 // scratch workspace (grown on demand, never shrunk); stream-ordered reuse
 float* workspace(size_t bytes);
@@ -153,15 +153,11 @@ int stem_pool_apply(const float* sel, int sel_planes, const float* partials, int
                     float* save_mean, float* save_var, float* running_mean, float* running_var, int N, int C, int P,
                     float eps, float momentum);
 
-// the instantiation's own name (clang: "... [K = &ns::kernel<1, true>]"), resolved at compile time per launch site
-template <auto K>
-const char* df_kernel_name() { return __PRETTY_FUNCTION__; }
-
 // every kernel launch of the library
 #define DF_LAUNCH(kern, grid, block, lds, strm, ...)                                                  \
   do {                                                                                                \
     hipEvent_t pa__, pb__;                                                                            \
-    if (dfhip::prof_kernel_events(df_kernel_name<kern>(), &pa__, &pb__))                              \
+    if (dfhip::prof_kernel_events((const void*)(kern), &pa__, &pb__))                                 \
       hipExtLaunchKernelGGL(kern, grid, block, lds, strm, pa__, pb__, 0, __VA_ARGS__);                \
     else                                                                                              \
       hipLaunchKernelGGL(kern, grid, block, lds, strm, __VA_ARGS__);                                  \

@@ -13,6 +13,8 @@
 #include <time.h>
 #include <string.h>
 
+#include <cxxabi.h>
+
 #include <algorithm>
 #include <mutex>
 #include <unordered_map>
@@ -244,8 +246,8 @@ struct ProfSlot {
 // per KERNEL (the instantiation's own name, from DF_LAUNCH): launches and the kernels' own durations, plus the
 // algorithmic flops / bytes of the scopes whose first launch it was
 struct KernelRec {
-  const char* pretty;          // __PRETTY_FUNCTION__ of df_kernel_name<&kernel>
-  std::string name;
+  const void* fn;              // the launch site's host function
+  std::string name;            // the instantiation's own name, demangled (hipKernelNameRefByPtr)
   int slot;                    // family
   double ms = 0, flops = 0, bytes = 0;
   int64_t launches = 0;
@@ -291,32 +293,41 @@ static void prof_resolve(ProfSlot& s) {
   }
   s.kpending.clear();
 }
-static int kernel_record(const char* pretty, int slot) {
-  if (!pretty) return -1;
+static int kernel_record(const void* fn, int slot) {
+  if (!fn) return -1;
   for (size_t i = 0; i < g_krec.size(); i++)
-    if (g_krec[i].slot == slot && (g_krec[i].pretty == pretty || strcmp(g_krec[i].pretty, pretty) == 0)) return (int)i;
+    if (g_krec[i].slot == slot && g_krec[i].fn == fn) return (int)i;
   KernelRec r;
-  r.pretty = pretty;
+  r.fn = fn;
   r.slot = slot;
-  // "const char *df_kernel_name() [K = &(anonymous namespace)::k_x<1, true>]" -> "k_x<1, true>"
-  std::string t = pretty;
-  size_t a = t.find("K = ");
-  if (a != std::string::npos) t = t.substr(a + 4);
-  if (!t.empty() && t[0] == '&') t = t.substr(1);
-  if (!t.empty() && t.back() == ']') t.pop_back();
+  // "void (anonymous namespace)::k_x<1, true>(float const*, int)" -> "k_x<1, true>" (as tools/pmc_summary.py shortens
+  // the profiler's names)
+  const char* mangled = hipKernelNameRefByPtr(fn, g_stream);
+  std::string t = mangled ? mangled : "?";
+  int status = 0;
+  char* dem = mangled ? abi::__cxa_demangle(mangled, nullptr, nullptr, &status) : nullptr;
+  if (dem && status == 0) t = dem;
+  free(dem);
   for (const char* drop : {"(anonymous namespace)::", "dfhip::"}) {
     size_t q;
     while ((q = t.find(drop)) != std::string::npos) t.erase(q, strlen(drop));
+  }
+  if (t.rfind("void ", 0) == 0) t = t.substr(5);
+  int depth = 0;
+  for (size_t i = 0; i < t.size(); i++) {
+    if (t[i] == '<') depth++;
+    else if (t[i] == '>') depth--;
+    else if (t[i] == '(' && depth == 0) { t = t.substr(0, i); break; }
   }
   r.name = t;
   g_krec.push_back(r);
   return (int)g_krec.size() - 1;
 }
-bool prof_kernel_events(const char* pretty, hipEvent_t* start, hipEvent_t* stop) {
+bool prof_kernel_events(const void* fn, hipEvent_t* start, hipEvent_t* stop) {
   if (g_prof_scope < 0 || g_capture_open) return false;
   hipEvent_t a = get_event(), b = get_event();
   if (!a || !b) return false;
-  const int rec = kernel_record(pretty, g_prof_scope);
+  const int rec = kernel_record(fn, g_prof_scope);
   if (rec >= 0) {
     g_krec[rec].flops += g_scope_flops;              // the scope's algorithmic work goes to its first launch
     g_krec[rec].bytes += g_scope_bytes;

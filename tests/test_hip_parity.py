@@ -426,6 +426,50 @@ def test_bn_applied_on_the_next_convolutions_loads(hip_device, C, HW, dgrad):
         assert_close(a, b, 3e-5, f"bn on conv loads C={C}: " + nm)
 
 
+def test_bn_on_conv_loads_with_a_large_channel_offset(hip_device):
+    """the operand path folds bn1 into fma(x, scale, shift) with shift = beta - mean * scale; when |mean| is
+    far above the channel's spread the two large terms cancel.  conv1's output gets a channel mean ~500 x its standard
+    deviation here (input offset 50, spread 0.1) and conv2(bn1(conv1(x))) is compared with the reference's expression
+    evaluated by the oracle in float64 -- allowed: max(1e-4, 2 x what the float32 oracle itself loses)."""
+    import error_budget as eb
+    from conftest import rel_err
+    from deepflows_amd import nn, tensor
+    from deepflows_amd.tensor import Graph, Tensor
+    from oracle.numpy_device import NumpyDevice, NumpyDevice64
+    F = nn.functional
+    rng = np.random.default_rng(19)
+    N, C, HW = 128, 32, 16
+    x = (50.0 + 0.1 * rng.standard_normal((N, C, HW, HW))).astype(np.float32)
+    gam = (1.0 + 0.3 * rng.standard_normal((1, C, 1, 1))).astype(np.float32)
+    bet = (0.5 * rng.standard_normal((1, C, 1, 1))).astype(np.float32)
+
+    def run(dev, fused):
+        np.random.seed(7)
+        conv1 = nn.Conv2d(C, C, kernel_size=3, stride=1, padding=1, bias=False, device=dev)
+        conv2 = nn.Conv2d(C, C, kernel_size=3, stride=1, padding=1, bias=False, device=dev)
+        bn1 = nn.BatchNorm2d(C, device=dev)
+        bn1.train()
+        dev.from_numpy(gam, bn1.weight.data._handle)
+        dev.from_numpy(bet, bn1.bias.data._handle)
+        z1 = conv1(Tensor(x, device=dev))
+        z2 = F.bn_conv2d_train(z1, bn1, conv2) if fused else conv2(bn1(z1))
+        assert z2 is not None
+        out = {"z1": z1.numpy().astype(np.float64), "z2": z2.numpy().astype(np.float64)}
+        Graph.free_graph_all()
+        return out
+    exact = eb.with_device(NumpyDevice64, lambda d: run(d, False))
+    fp32 = eb.with_device(NumpyDevice, lambda d: run(d, False))
+    got = run(hip_device, True)
+    # only the interior of z1 carries the big offset relative to its spread (the border rows see the zero padding);
+    # the ratio this case is about:
+    inner = exact["z1"][:, :, 2:-2, 2:-2]
+    ratio = np.abs(inner.mean(axis=(0, 2, 3))) / inner.std(axis=(0, 2, 3))
+    assert np.median(ratio) > 50, ratio
+    e32, e = rel_err(fp32["z2"], exact["z2"]), rel_err(got["z2"], exact["z2"])
+    print(f"\nbn on conv loads, |mean| / std of conv1's output {np.median(ratio):.0f} (median): hip {e:.3e}, fp32 oracle {e32:.3e}")
+    assert e <= max(1e-4, 2.0 * e32), (e, e32)
+
+
 def test_wgrad_affine_outside_a_group_writes_the_operand_out(hip_device):
     """dfhip_conv2d_wgrad_affine called stand-alone (no grouped sweep open): the operand x * scale + shift is
     materialised once and the ordinary kernels run; equal to the weight gradient of the explicit operand."""

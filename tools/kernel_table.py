@@ -44,10 +44,10 @@ def main():
         ex = c.get("executed_flops_per_launch")
         hbm = (c.get("fetch_bytes_per_launch", 0.0) + c.get("write_bytes_per_launch", 0.0)) if c else None
         if mf and alg_gf > 0:
-            fa = f"{alg_gf / us * 1e-3 / PEAK_TF:.3f}"
-            fe = f"{ex / 1e9 / us * 1e-3 / PEAK_TF:.3f}" if ex else "-"
+            fa = f"{alg_gf / us * 1e3 / PEAK_TF:.3f}"                       # GFLOP / us = 1e3 TFLOP/s
+            fe = f"{ex / 1e9 / us * 1e3 / PEAK_TF:.3f}" if ex else "-"
         else:
-            fa = f"{alg_mb / us * 1e-3 / (PEAK_GBS / 1e3):.3f} (HBM)" if alg_mb > 0 else "-"
+            fa = f"{alg_mb / us / (PEAK_GBS / 1e3):.3f} (HBM)" if alg_mb > 0 else "-"    # MB / us = TB/s
             fe = "-"
         busy = f"{c['mfma_busy']:.3f}" if c.get("mfma_busy") else "-"
         name = k if len(k) <= 64 else k[:61] + "..."

@@ -146,7 +146,12 @@ def _build_identity():
         git = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except Exception:
         git = ""
-    return git or os.environ.get("DF_GIT_HEAD", "?"), h.hexdigest()[:16]
+    if not git:                                   # the GPU box has no .git: tools/grun.sh leaves the hash in .git_head
+        try:
+            git = open(os.path.join(root, ".git_head")).read().strip()
+        except OSError:
+            git = os.environ.get("DF_GIT_HEAD", "?")
+    return git, h.hexdigest()[:16]
 
 
 def family_json(paths, steps, out_path, workload="resnet18", dgrad="overwrite"):

@@ -16,11 +16,11 @@ cd $ROOT
 N=$((3 + 2 + STEPS + STEPS))
 one() {   # one <suffix> <workload> <dgrad> [extra bench args]
   local sfx=$1 wl=$2 dg=$3; shift 3
-  local CMD="python3 bench.py --workload $wl --dgrad $dg --steps $STEPS --warmup 3 --no-cpu-baseline --no-prof-gate $*"
-  for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32"; do
-    set -- $pass; local name=$1; shift
-    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_${name}$sfx -o p -- $CMD > $OUT/pmc_${name}$sfx.log 2>&1
-  done
+  local extra="$*"
+  local CMD="python3 bench.py --workload $wl --dgrad $dg --steps $STEPS --warmup 3 --no-cpu-baseline --no-prof-gate"
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch$sfx -o p -- $CMD > $OUT/pmc_fetch$sfx.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write$sfx -o p -- $CMD > $OUT/pmc_write$sfx.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $OUT/pmc_sq$sfx -o p -- $CMD > $OUT/pmc_sq$sfx.log 2>&1
   python3 tools/pmc_summary.py --json $N $OUT/pmc_traffic$sfx.json --workload $wl --dgrad $dg \
       $(find $OUT/pmc_fetch$sfx $OUT/pmc_write$sfx $OUT/pmc_sq$sfx -name "*counter_collection.csv") > $OUT/pmc_summary$sfx.log 2>&1
   python3 tools/pmc_summary.py $(find $OUT/pmc_fetch$sfx $OUT/pmc_write$sfx $OUT/pmc_sq$sfx -name "*counter_collection.csv") > $OUT/pmc_per_kernel$sfx.txt 2>&1
@@ -29,10 +29,11 @@ one() {   # one <suffix> <workload> <dgrad> [extra bench args]
   f=$(find $OUT/stats$sfx -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && python3 tools/kernel_stats_txt.py $f > $OUT/rocprof_kernel_stats$sfx.txt
   rm -rf $OUT/stats$sfx
-  python3 bench.py --workload $wl --dgrad $dg --pmc-traffic $OUT/pmc_traffic$sfx.json "$@" > $OUT/bench$sfx.json 2> $OUT/bench$sfx.err
+  python3 bench.py --workload $wl --dgrad $dg --pmc-traffic $OUT/pmc_traffic$sfx.json $extra > $OUT/bench$sfx.json 2> $OUT/bench$sfx.err
   python3 tools/kernel_table.py $OUT/bench$sfx.json $OUT/pmc_traffic$sfx.json $OUT/rocprof_kernel_stats$sfx.txt > $OUT/kernel_table$sfx.md 2>> $OUT/bench$sfx.err
 }
 one "" resnet18 overwrite
+[ -n "${ONLY_HEADLINE:-}" ] && { ls -la $OUT | head; exit 0; }
 one _accumulate resnet18 accumulate --no-cpu-baseline
 one _cnn cnn overwrite
 python3 bench.py --workload mlp --steps 200 --warmup 20 > $OUT/bench_mlp.json 2> $OUT/bench_mlp.err
