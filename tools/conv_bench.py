@@ -14,6 +14,11 @@ LAYERS = [("stem", 3, 32, 32, 32, 3, 1, 1), ("l1", 32, 16, 16, 32, 3, 1, 1), ("l
           ("l2", 64, 8, 8, 64, 3, 1, 1), ("l2d", 32, 16, 16, 64, 1, 2, 0), ("l3a", 64, 8, 8, 128, 3, 2, 1),
           ("l3", 128, 4, 4, 128, 3, 1, 1), ("l3d", 64, 8, 8, 128, 1, 2, 0), ("l4a", 128, 4, 4, 256, 3, 2, 1),
           ("l4", 256, 2, 2, 256, 3, 1, 1), ("l4d", 128, 4, 4, 256, 1, 2, 0)]
+# test/ResNet.py's ResNet-18 (64 / 128 / 256 / 512 channels on 32 x 32 inputs, no stem pool): --wide
+WIDE = [("w_stem", 3, 32, 32, 64, 3, 1, 1), ("w_l1", 64, 32, 32, 64, 3, 1, 1), ("w_l2a", 64, 32, 32, 128, 3, 2, 1),
+        ("w_l2", 128, 16, 16, 128, 3, 1, 1), ("w_l2d", 64, 32, 32, 128, 1, 2, 0), ("w_l3a", 128, 16, 16, 256, 3, 2, 1),
+        ("w_l3", 256, 8, 8, 256, 3, 1, 1), ("w_l3d", 128, 16, 16, 256, 1, 2, 0), ("w_l4a", 256, 8, 8, 512, 3, 2, 1),
+        ("w_l4", 512, 4, 4, 512, 3, 1, 1), ("w_l4d", 256, 8, 8, 512, 1, 2, 0)]
 COUNT = {"stem": 1, "l1": 4, "l2a": 1, "l2": 3, "l2d": 1, "l3a": 1, "l3": 3, "l3d": 1, "l4a": 1, "l4": 3, "l4d": 1}
 
 
@@ -22,6 +27,7 @@ def main():
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--only", default="")
+    ap.add_argument("--wide", action="store_true", help="the layer shapes of test/ResNet.py's ResNet-18")
     ap.add_argument("--grouped", action="store_true")
     ap.add_argument("--reverse", action="store_true")
     ap.add_argument("--group-only", default="")
@@ -33,7 +39,10 @@ def main():
     rng = np.random.default_rng(0)
     total = {}
     print(f"{'layer':6s} {'op':10s} {'us':>9s} {'TFLOP/s':>9s} {'GFLOP':>8s}")
-    for name, C, H, W, O, k, s, p in LAYERS:
+    if args.wide:
+        COUNT.update({"w_stem": 1, "w_l1": 4, "w_l2a": 1, "w_l2": 3, "w_l2d": 1, "w_l3a": 1, "w_l3": 3, "w_l3d": 1, "w_l4a": 1,
+                      "w_l4": 3, "w_l4d": 1})
+    for name, C, H, W, O, k, s, p in (WIDE if args.wide else LAYERS):
         if args.only and name not in args.only.split(","):
             continue
         oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
