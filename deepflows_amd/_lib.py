@@ -46,6 +46,8 @@ _SIGS = {
     "dfhip_reduce_max": [P, P, c_int64, c_int64],
     "dfhip_gemm": [P, P, P, P, c_int64, c_int64, c_int64, c_int, c_int],
     "dfhip_linear_backward": [P, P, P, P, P, P, c_int64, c_int64, c_int64],
+    "dfhip_linear_relu_forward": [P, P, P, P, P, c_int64, c_int64, c_int64, POINTER(c_int)],
+    "dfhip_linear_relu_backward": [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, POINTER(c_int)],
     "dfhip_conv2d_forward": [P, P, P, P] + [c_int] * 8,
     "dfhip_conv2d_forward_stats": [P, P, P, P] + [c_int] * 8 + [P, c_int, POINTER(c_int)],
     "dfhip_bn2d_forward_partials": [P, P, c_int] + [P] * 8 + [c_int, c_int, c_int, c_float, c_float],

@@ -324,6 +324,20 @@ class HipModule:
         g = lambda h: h.ptr if h is not None else None
         _lib.check(self._lib.dfhip_linear_backward(g(x), g(w), dy.ptr, g(dx), g(dw), g(db), int(m), int(k), int(p)))
 
+    def linear_relu_forward(self, x, w, bias, z, r, m, k, p):
+        """relu(x.W + b) in one launch (z = the pre-activation, r = the output); False = too large, nothing launched."""
+        done = ctypes.c_int(0)
+        _lib.check(self._lib.dfhip_linear_relu_forward(x.ptr, w.ptr, bias.ptr if bias is not None else None, z.ptr, r.ptr,
+                                                       int(m), int(k), int(p), ctypes.byref(done)))
+        return bool(done.value)
+
+    def linear_relu_backward(self, x, w, z, r, dr, dx, dw, db, m, k, p):
+        g = lambda h: h.ptr if h is not None else None
+        done = ctypes.c_int(0)
+        _lib.check(self._lib.dfhip_linear_relu_backward(g(x), g(w), z.ptr, r.ptr, dr.ptr, g(dx), g(dw), g(db), int(m),
+                                                        int(k), int(p), ctypes.byref(done)))
+        return bool(done.value)
+
     def bn2d_forward_partials_pair(self, a, b, y, N, C, HW):
         """a, b = (x, partials, rows, gamma, beta, save_mean, save_var, running_mean, running_var, eps, momentum)."""
         g = lambda h: h.ptr if h is not None else None

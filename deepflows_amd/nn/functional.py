@@ -120,6 +120,66 @@ def relu(input: Tensor) -> Tensor:
     return tensor.maximum(input, 0)
 
 
+class _LinearReluFused(_FusedNode):
+    """relu(linear(x, W, b)) as ONE node: one forward launch (the pre-activation is kept), one backward launch (the
+    ReLU's gradient mask -- output == input, tensor.py:872-877 -- is applied on the operand loads of dx / dW / db).
+    For the launch-bound layers of the MLP workload (test/MLP_MNIST_cuda.py:44-56): three launches forward and four
+    backward otherwise."""
+
+    @classmethod
+    def build(cls, x, w, b):
+        dev = x.device
+        fn = getattr(dev.mod, "linear_relu_forward", None)
+        if fn is None or not _LINEAR_RELU or x.ndim != 2 or w.ndim != 2:
+            return None
+        m, k = (int(v) for v in x.shape)
+        p = int(w.shape[1])
+        xd, wd = x.data.compact(), w.data.compact()
+        z, r = _new((m, p), dev), _new((m, p), dev)
+        if not fn(xd._handle, wd._handle, b.data.compact()._handle if b is not None else None, z._handle, r._handle, m, k, p):
+            return None
+        node = cls.__new__(cls)
+        node.x, node.w, node.b = x, w, b
+        node._saved = (xd, wd, z)
+        node._grads = None
+        _FusedNode.__init__(node, r, [x, w, b])
+        return node
+
+    def grad_fn(self, node, grad):
+        if self._grads is None or self._grads[0] is not grad:
+            xd, wd, z = self._saved
+            dev = grad.device
+            m, k = xd.shape
+            p = wd.shape[1]
+            dx = _new((m, k), dev) if self.x.requires_grad else None
+            dw = _new((k, p), dev) if self.w.requires_grad else None
+            db = _new(self.b.shape, dev) if (self.b is not None and self.b.requires_grad) else None
+            h = lambda t: t._handle if t is not None else None
+            g = grad.compact()
+            if not dev.linear_relu_backward(xd._handle, wd._handle, z._handle, self.data._handle, g._handle, h(dx), h(dw),
+                                            h(db), m, k, p):
+                # (a layer the forward kernel took always has the backward kernel; kept for completeness)
+                masked = _new((m, p), dev)
+                dev.relu_backward(z._handle, self.data._handle, g._handle, masked._handle)
+                dev.linear_backward(xd._handle, wd._handle, masked._handle, h(dx), h(dw), h(db), m, k, p)
+            self._grads = (grad, dx, dw, db)
+        _, dx, dw, db = self._grads
+        return dx if node is self.x else (dw if node is self.w else db)
+
+
+_LINEAR_RELU = os.environ.get("DF_LINEAR_RELU", "1") != "0"
+
+
+def linear_relu(input: Tensor, weight: Tensor, bias=None):
+    """F.relu(F.linear(input, weight, bias)); one node on a fused device when the layer is small enough for the
+    one-launch kernels."""
+    if _fused(input) and is_grad_enable():
+        node = _LinearReluFused.build(input, weight, bias)
+        if node is not None:
+            return node
+    return relu(linear(input, weight, bias))
+
+
 class tanh(tensor.UnaryOperator):
     def forward(self, input):
         return backend_api.tanh(input.data)

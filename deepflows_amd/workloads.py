@@ -44,9 +44,11 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i in range(self.n_layers):
-            x = getattr(self, f"fc{i + 1}")(x)
+            fc = getattr(self, f"fc{i + 1}")
             if i + 1 < self.n_layers:
-                x = nn.functional.relu(x)
+                x = nn.functional.linear_relu(x, fc.weight, fc.bias)     # relu(fc(x)): one node on the hip device
+            else:
+                x = fc(x)
         return x
 
 

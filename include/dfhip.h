@@ -122,6 +122,16 @@ int dfhip_gemm(const float* a, const float* b, const float* bias, float* out,
  * be NULL.  One launch when the layer is small (a classifier head), the three contractions otherwise. */
 int dfhip_linear_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
                           int64_t m, int64_t k, int64_t p);
+/* F.relu(F.linear(x, W, b)) (nn/functional.py:8-16) as ONE launch for layers up to 1.5e8 flops: z (m,p) = x.W + b is kept
+ * for the backward pass, r = max(z, 0).  Backward of that pair: the upstream gradient dr counts only where r == z
+ * (tensor.py:872-877: the gradient passes where output == input, 0 included); the mask is applied on the operand loads
+ * of the three contractions (dx = (dr*mask).W^T, dw = x^T.(dr*mask), db = column sums), one launch.  *done = 0 (nothing
+ * launched) when the layer is too large for the one-launch kernels: the caller then runs gemm + relu / relu_backward +
+ * linear_backward. */
+int dfhip_linear_relu_forward(const float* x, const float* w, const float* bias, float* z, float* r, int64_t m,
+                              int64_t k, int64_t p, int* done);
+int dfhip_linear_relu_backward(const float* x, const float* w, const float* z, const float* r, const float* dr,
+                               float* dx, float* dw, float* db, int64_t m, int64_t k, int64_t p, int* done);
 
 /* Conv2d forward: nn/functional.py:316-344 (pad -> im2col -> GEMM) + conv.py:104-108
  * (bias (1,O,1,1), may be NULL).  x (N,C,H,W), w (O,C,k,k), y (N,O,oh,ow), all NCHW.  */

@@ -681,6 +681,34 @@ def test_stem_without_its_convolution_output(hip_device, N, C, H, O):
     assert np.array_equal(results[0][0] == 0.0, results[1][0] == 0.0)
 
 
+@pytest.mark.parametrize("m,k,p", [(128, 784, 256), (128, 256, 10), (37, 100, 20), (256, 2048, 10)])
+def test_linear_relu_as_one_node(hip_device, m, k, p):
+    """relu(linear(x, W, b)) as one forward and one backward launch (the ReLU mask on the operand loads) against the two
+    nodes; integer data, so pre-activations that are exactly 0 occur and must pass the gradient (tensor.py:872-877)."""
+    from deepflows_amd import nn, tensor
+    from deepflows_amd.tensor import Graph, Tensor
+    F = nn.functional
+    rng = np.random.default_rng(3)
+    x = rng.integers(-2, 3, size=(m, k)).astype(np.float32)
+    w = (rng.integers(-2, 3, size=(k, p)) / 4).astype(np.float32)
+    b = (rng.integers(-2, 3, size=(1, p)) / 2).astype(np.float32)
+    g = rng.standard_normal((m, p)).astype(np.float32)
+    results = []
+    for fused in (True, False):
+        xt, wt, bt = (Tensor(a, device=hip_device, requires_grad=True) for a in (x, w, b))
+        y = F.linear_relu(xt, wt, bt) if fused else F.relu(F.linear(xt, wt, bt))
+        if fused:
+            assert type(y).__name__ == "_LinearReluFused", "the one-node form must take this shape"
+        tensor.sum(y * Tensor(g, device=hip_device)).backward()
+        results.append([y.numpy().copy(), xt.grad.numpy().copy(), wt.grad.numpy().copy(), bt.grad.numpy().copy()])
+        Graph.free_graph_all()
+    z = x.astype(np.float64) @ w + b
+    assert (z == 0).sum() > 0, "the case must contain exact zeros"
+    for a, c, nm in zip(results[0], results[1], ("y", "dx", "dw", "db")):
+        assert_close(a, c, 2e-6, f"linear_relu {m}x{k}x{p}: " + nm)
+    assert np.array_equal(results[0][0], np.maximum(z, 0).astype(np.float32))          # exact in this integer case
+
+
 def test_classifier_head_as_one_node(hip_device):
     """fc(mean(mean(x, 2), 2)) + cross-entropy: the pooled-linear node and the loss gradient left behind by the loss
     kernel, against the separate nodes (mean_hw, Linear, cross-entropy with its own backward launch)."""
