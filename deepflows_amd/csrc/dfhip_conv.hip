@@ -3890,9 +3890,12 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, 
                               : launch_igemm_v4<KSV, 2>(g, grid, lds)))
   if (g.k == 1) st = DF_V4(1);
   else if (g.k == 3) st = DF_V4(3);
-  else      // 5x5 (the CNN workload's second convolution): the build with the run-time steps-per-wave count only
-    st = g.mode == 0 ? launch_igemm_v4n<5, 0, 0>(g, grid, lds)
-                     : (g.mode == 1 ? launch_igemm_v4n<5, 1, 0>(g, grid, lds) : launch_igemm_v4n<5, 2, 0>(g, grid, lds));
+  else {    // 5x5 (the CNN workload's second convolution)
+    static int k5_spec = getenv("DFHIP_IGEMM_K5_SPEC") ? atoi(getenv("DFHIP_IGEMM_K5_SPEC")) : 1;
+    if (k5_spec) st = DF_V4(5);
+    else st = g.mode == 0 ? launch_igemm_v4n<5, 0, 0>(g, grid, lds)
+                          : (g.mode == 1 ? launch_igemm_v4n<5, 1, 0>(g, grid, lds) : launch_igemm_v4n<5, 2, 0>(g, grid, lds));
+  }
 #undef DF_V4
   if (st != DFHIP_OK) return st;
   DF_LAUNCH_CHECK();
