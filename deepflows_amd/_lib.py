@@ -70,8 +70,8 @@ _SIGS = {
     "dfhip_bn_relu_maxpool2_backward": [P] * 10 + [c_int] * 4 + [c_float],
     "dfhip_bn_relu_maxpool2_forward_partials": [P, P, c_int] + [P] * 7 + [c_int] * 4 + [c_float, c_float],
     "dfhip_stem_backward": [P] * 11 + [c_int] * 8 + [c_float, POINTER(c_int)],
-    "dfhip_stem_forward_noz": [P] * 9 + [c_int] * 8 + [c_float, c_float, POINTER(c_int)],
-    "dfhip_stem_backward_noz": [P] * 11 + [c_int] * 8 + [c_float, POINTER(c_int)],
+    "dfhip_stem_forward_noz": [P] * 10 + [c_int] * 8 + [c_float, c_float, POINTER(c_int)],
+    "dfhip_stem_backward_noz": [P] * 13 + [c_int] * 8 + [c_float, POINTER(c_int)],
     "dfhip_upload_async": [P, P, c_int64, c_int],
     "dfhip_upload_wait": [c_int],
     "dfhip_augment_batch": [P, P, P, c_int, c_int, c_int, c_int, c_int],

@@ -69,8 +69,16 @@ static void st2_dump(const char* what, int gx) {
 static void st2_dump(const char*, int) {}
 #endif
 
-constexpr int kPitch = 40, kRows = 34;             // LDS tile of a channel: 34 rows of 40 floats, image column c at 4 + c
-constexpr int kCH = kRows * kPitch;
+// LDS tile of a channel: 32 + KS - 1 rows of 40 floats (KS / 2 zero rows above and below), image column c at 4 + c,
+// KS / 2 zero columns either side
+constexpr int kPitch = 40;
+template <int KS> struct TileGeo {
+  static constexpr int PAD = KS / 2, ROWS = 32 + KS - 1, CH = ROWS * kPitch;
+  // LDS index of (channel, tap) kk of an output pixel at row 0, column 0 of the image
+  static __device__ __host__ constexpr int koff(int kk) {
+    return (kk / (KS * KS)) * CH + ((kk % (KS * KS)) / KS) * kPitch + (kk % KS) + 4 - PAD;
+  }
+};
 
 template <int XM>
 __device__ __forceinline__ float swz(float v) {    // the value of lane (l ^ XM) of the same 32-lane group
@@ -95,56 +103,64 @@ __device__ __forceinline__ float stem_dy2(float bo, float pooled, float g) {
 }
 
 // the image tile: 16-byte pieces requested by every thread, committed with the zero rows above / below the image
-template <int C, int QR>
+template <int C, int KS, int QR>
 __device__ __forceinline__ void tile_request(const float* __restrict__ xn, int H, int tid, f32x4 (&v)[QR]) {
-  constexpr int NQ = C * kRows * 8;
+  typedef TileGeo<KS> G;
+  constexpr int NQ = C * G::ROWS * 8;
 #pragma unroll
   for (int q0 = 0; q0 < QR; q0++) {
     const int q = min(tid + 512 * q0, NQ - 1);
-    const int pc = q & 7, t = q >> 3, lr = t % kRows, c = t / kRows;
-    const int row = min(max(lr - 1, 0), H - 1);                        // (clamped: the commit zeroes what is outside)
+    const int pc = q & 7, t = q >> 3, lr = t % G::ROWS, c = t / G::ROWS;
+    const int row = min(max(lr - G::PAD, 0), H - 1);                   // (clamped: the commit zeroes what is outside)
     v[q0] = *reinterpret_cast<const f32x4*>(xn + ((int64_t)c * H + row) * 32 + pc * 4);
   }
 }
-template <int C, int QR>
+template <int C, int KS, int QR>
 __device__ __forceinline__ void tile_commit(float* __restrict__ Xl, int H, int tid, const f32x4 (&v)[QR]) {
-  constexpr int NQ = C * kRows * 8;
+  typedef TileGeo<KS> G;
+  constexpr int NQ = C * G::ROWS * 8;
 #pragma unroll
   for (int q0 = 0; q0 < QR; q0++) {
     const int q = tid + 512 * q0;
-    const int pc = q & 7, t = q >> 3, lr = t % kRows, c = t / kRows;
-    const bool in = lr >= 1 && lr <= H;
+    const int pc = q & 7, t = q >> 3, lr = t % G::ROWS, c = t / G::ROWS;
+    const bool in = lr >= G::PAD && lr < H + G::PAD;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    if (q < NQ) *reinterpret_cast<f32x4*>(&Xl[c * kCH + lr * kPitch + 4 + pc * 4]) = in ? v[q0] : z;
+    if (q < NQ) *reinterpret_cast<f32x4*>(&Xl[c * G::CH + lr * kPitch + 4 + pc * 4]) = in ? v[q0] : z;
   }
 }
-template <int C>
+template <int C, int KS>
 __device__ __forceinline__ void tile_side_columns(float* __restrict__ Xl, int tid) {
-  if (tid < C * kRows * 2) {                         // the columns either side of the image (never written again)
-    const int t = tid >> 1;
-    Xl[(t / kRows) * kCH + (t % kRows) * kPitch + ((tid & 1) ? 36 : 3)] = 0.0f;
+  typedef TileGeo<KS> G;
+  constexpr int SIDE = 2 * G::PAD;                   // zero columns per tile row (never written again)
+  for (int e = tid; e < C * G::ROWS * SIDE; e += 512) {
+    const int t = e / SIDE, sc = e % SIDE;
+    const int col = sc < G::PAD ? 4 - G::PAD + sc : 36 + (sc - G::PAD);
+    Xl[(t / G::ROWS) * G::CH + (t % G::ROWS) * kPitch + col] = 0.0f;
   }
 }
 
 // ---------------------------------------------------------------------------------------
 // forward: convolution on row pairs, BatchNorm partials of z, the selected extreme of every 2 x 2 window
 // ---------------------------------------------------------------------------------------
-template <int C>
+template <int C, int KS>
 __global__ __launch_bounds__(512) void k_stem_fwd_sel(const float* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ gamma, float* __restrict__ zsel,
-                                                      float* __restrict__ partials, int N, int H, int O) {
-  constexpr int KK = C * 9, NP = (KK + 1) / 2;
-  constexpr int NQ = C * kRows * 8, QR = (NQ + 511) / 512;
+                                                      const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                      float* __restrict__ zsel, float* __restrict__ partials, int N,
+                                                      int H, int O) {
+  typedef TileGeo<KS> G;
+  constexpr int KK = C * KS * KS, NP = (KK + 1) / 2;
+  constexpr bool AREG = NP <= 16;                   // the weight operands of a lane stay in registers (3x3); else LDS
+  constexpr int NQ = C * G::ROWS * 8, QR = (NQ + 511) / 512;
   constexpr int NWR = (32 * KK + 511) / 512;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  __shared__ float Wl[32 * KK];
-  __shared__ __attribute__((aligned(16))) float Xl[C * kCH];
-  __shared__ float sred[8][2][32], sshift[8][2][16], scount[8], Gl[32];
+  __shared__ float Wl[32 * KK + 32];
+  __shared__ __attribute__((aligned(16))) float Xl[C * G::CH];
+  __shared__ float sred[8][2][32], sshift[8][2][16], scount[8], Gl[32], Bl[32];
   ST2(6); ST2(0);
   int item = blockIdx.x;
   f32x4 tv[QR];
-  if (item < N) tile_request<C, QR>(x + (int64_t)item * C * H * 32, H, tid, tv);
+  if (item < N) tile_request<C, KS, QR>(x + (int64_t)item * C * H * 32, H, tid, tv);
   {
     float wv[NWR];
     const int nw = O * KK;
@@ -159,31 +175,34 @@ __global__ __launch_bounds__(512) void k_stem_fwd_sel(const float* __restrict__ 
       const int i = tid + 512 * i0;
       if (i < 32 * KK) Wl[i] = wv[i0];
     }
+    if (tid < 32) Wl[32 * KK + tid] = 0.0f;         // the weight a k slot past K reads (an odd K: the last MFMA's second slot)
     if (tid >= 480) {
       const int dl = tid - 480;
-      float t = 1.0f;
+      float t = 1.0f, bb = 0.0f;
       if (gamma) t = gamma[min(dl, O - 1)];
+      if (bias) bb = bias[min(dl, O - 1)];
       Gl[dl] = t < 0.0f ? -1.0f : 1.0f;             // which extreme of a window survives bn + relu + max
+      Bl[dl] = dl < O ? bb : 0.0f;
     }
-    tile_side_columns<C>(Xl, tid);
+    tile_side_columns<C, KS>(Xl, tid);
   }
-  if (item < N) tile_commit<C, QR>(Xl, H, tid, tv);
+  if (item < N) tile_commit<C, KS, QR>(Xl, H, tid, tv);
   __syncthreads();
   ST2(1);
-  float a[NP];
+  // weight operand of MFMA p: k index 2 p (lower half-wave) / 2 p + 1 (upper); a k past K is a zero weight
+  auto wsrc = [&](int p) { const int kk = 2 * p + half; return kk < KK ? l31 * KK + kk : 32 * KK + l31; };
+  float a[AREG ? NP : 1];
+  if constexpr (AREG) {
 #pragma unroll
-  for (int p = 0; p < NP; p++) {
-    const int kk = 2 * p + half;
-    a[p] = kk < KK ? Wl[l31 * KK + kk] : 0.0f;
+    for (int p = 0; p < NP; p++) a[p] = Wl[wsrc(p)];
   }
   // LDS index of (channel, tap) 2 p + half for output row 0: a compile-time constant per half-wave, selected where it is
-  // used (14 index registers would push the kernel over its 256: it spilled)
+  // used (index registers would push the kernel over its 256: it spilled)
   auto koff = [&](int p) {
     const int k0 = 2 * p < KK ? 2 * p : 0, k1 = 2 * p + 1 < KK ? 2 * p + 1 : 0;
-    const int o0 = (k0 / 9) * kCH + ((k0 % 9) / 3) * kPitch + (k0 % 3) + 3;
-    const int o1 = (k1 / 9) * kCH + ((k1 % 9) / 3) * kPitch + (k1 % 3) + 3;
-    return (half ? o1 : o0) + l31;
+    return (half ? G::koff(k1) : G::koff(k0)) + l31;
   };
+  constexpr int PCH = AREG ? NP : 4;                // MFMA pairs between two scheduling fences (register pressure, 5x5)
   // bit rr: the channel of accumulator register rr has a negative gamma (its windows keep their minimum)
   unsigned negmask = 0;
 #pragma unroll
@@ -198,21 +217,22 @@ __global__ __launch_bounds__(512) void k_stem_fwd_sel(const float* __restrict__ 
   while (item < N) {
     const int n = item;
     const int next = item + gridDim.x;
-    if (next < N) tile_request<C, QR>(x + (int64_t)next * C * H * 32, H, tid, tv);
+    if (next < N) tile_request<C, KS, QR>(x + (int64_t)next * C * H * 32, H, tid, tv);
     for (int pr = wave; pr < pairs; pr += 8) {
-      float b0[NP], b1[NP];
-#pragma unroll
-      for (int p = 0; p < NP; p++) {
-        b0[p] = Xl[koff(p) + (2 * pr) * kPitch];
-        b1[p] = Xl[koff(p) + (2 * pr + 1) * kPitch];
-      }
       f32x16 acc0, acc1;
 #pragma unroll
-      for (int rr = 0; rr < 16; rr++) { acc0[rr] = 0.0f; acc1[rr] = 0.0f; }
+      for (int rr = 0; rr < 16; rr++) {              // (the convolution's bias of the register's channel, or 0)
+        const float bb = Bl[(rr & 3) + 8 * (rr >> 2) + 4 * half];
+        acc0[rr] = bb; acc1[rr] = bb;
+      }
 #pragma unroll
       for (int p = 0; p < NP; p++) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], b0[p], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], b1[p], acc1, 0, 0, 0);
+        float ap;
+        if constexpr (AREG) ap = a[p]; else ap = Wl[wsrc(p)];
+        const float b0 = Xl[koff(p) + (2 * pr) * kPitch], b1 = Xl[koff(p) + (2 * pr + 1) * kPitch];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap, b1, acc1, 0, 0, 0);
+        if (p % PCH == PCH - 1) __builtin_amdgcn_sched_barrier(0);     // (keeps the operand reads of later pairs behind)
       }
       if (partials) {
         if (first) {
@@ -252,7 +272,7 @@ __global__ __launch_bounds__(512) void k_stem_fwd_sel(const float* __restrict__ 
     item = next;
     if (item < N) {
       __syncthreads();                               // every wave has read its rows of the tile
-      tile_commit<C, QR>(Xl, H, tid, tv);
+      tile_commit<C, KS, QR>(Xl, H, tid, tv);
       __syncthreads();
     }
   }
@@ -318,24 +338,28 @@ struct StemB {
   const float* beta;
   const float* mean;
   const float* var;
+  const float* bias;   // the convolution's bias (or nullptr)
   float* partial;      // [O][S][2]
-  float* slabs;        // WGRAD: [gridDim.x][O][K]
+  float* slabs;        // WGRAD: [gridDim.x][O][K + 1] (the last column: the bias gradient)
   float* dgamma;
   float* dbeta;
   int N, H, O, S;
   float eps;
 };
 
-template <int C, bool WGRAD>
+template <int C, int KS, bool WGRAD>
 __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
-  constexpr int KK = C * 9, NP = (KK + 1) / 2;
-  constexpr int NQ = C * kRows * 8, QR = (NQ + 511) / 512;
+  typedef TileGeo<KS> G;
+  constexpr int KK = C * KS * KS, NP = (KK + 1) / 2;
+  constexpr bool AREG = NP <= 16;                     // weight operands in registers (3x3) or read from LDS per MFMA
+  constexpr int KT = (KK + 31) / 32;                  // column tiles of the weight-gradient tile (32 (channel, tap) each)
+  constexpr int NQ = C * G::ROWS * 8, QR = (NQ + 511) / 512;
   constexpr int YP = 20;                              // LDS pitch of a channel's 16 pooled pixels (bank spread)
   constexpr int WSLOT = 2 * 32 * YP;                  // a wave's private transposition area: y and g
   extern __shared__ __attribute__((aligned(16))) float smem_sb[];
-  float* Xl = smem_sb;                                // [C][kCH]
-  float* Wl = Xl + C * kCH;                           // [32][KK]
-  float* area = Wl + 32 * KK + ((32 * KK) & 1);       // 8 wave areas; later the cross-wave reduction [8][16][64] / sums
+  float* Xl = smem_sb;                                // [C][G::CH]
+  float* Wl = Xl + C * G::CH;                         // [32][KK] + 32 zeros
+  float* area = Wl + 32 * KK + 32 + ((32 * KK) & 1);  // 8 wave areas; later the cross-wave reduction [8][16][64] / sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   float* Ys = area + wave * WSLOT;
@@ -379,11 +403,12 @@ __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
   };
   int item = blockIdx.x;
   f32x4 tv[QR];
-  if (item < g.N) tile_request<C, QR>(g.x + (int64_t)item * C * H * 32, H, tid, tv);
+  if (item < g.N) tile_request<C, KS, QR>(g.x + (int64_t)item * C * H * 32, H, tid, tv);
+  const float c_bias = g.bias ? g.bias[o] : 0.0f;
   {
     const int nw = O * KK;
-    for (int i = tid; i < 32 * KK; i += 512) Wl[i] = i < nw ? g.w[i] : 0.0f;
-    tile_side_columns<C>(Xl, tid);
+    for (int i = tid; i < 32 * KK + 32; i += 512) Wl[i] = i < nw ? g.w[i] : 0.0f;
+    tile_side_columns<C, KS>(Xl, tid);
   }
   float k1 = 0.0f, k2 = 0.0f;
   if constexpr (WGRAD) {
@@ -401,7 +426,7 @@ __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
     if ((tid & 15) == 0) { tot[2 * (tid >> 4)] = sdy; tot[2 * (tid >> 4) + 1] = sdyx; }
   }
   if (item < g.N) request_rows(item);
-  if (item < g.N) tile_commit<C, QR>(Xl, H, tid, tv);
+  if (item < g.N) tile_commit<C, KS, QR>(Xl, H, tid, tv);
   __syncthreads();
   ST2(1);
   const float rsd = 1.0f / sqrtf(c_var + g.eps);
@@ -418,43 +443,39 @@ __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
   }
   // operands of the transposed convolution: A = the pixel's (channel, tap) value, lane = pixel; B = the weights of
   // output channel l31 -- the forward kernel's registers with the roles swapped, the same k order
-  float a[NP];
-  int koff[NP];
+  auto wsrc = [&](int p) { const int kk = 2 * p + half; return kk < KK ? l31 * KK + kk : 32 * KK + l31; };
+  auto koff = [&](int p) {
+    const int k0 = 2 * p < KK ? 2 * p : 0, k1 = 2 * p + 1 < KK ? 2 * p + 1 : 0;
+    return (half ? G::koff(k1) : G::koff(k0)) + l31;
+  };
+  float a[AREG ? NP : 1];
+  if constexpr (AREG) {
 #pragma unroll
-  for (int p = 0; p < NP; p++) {
-    const int kk = 2 * p + half;
-    a[p] = kk < KK ? Wl[l31 * KK + kk] : 0.0f;
-    const int ke = kk < KK ? kk : 0;
-    koff[p] = (ke / 9) * kCH + ((ke % 9) / 3) * kPitch + (ke % 3) + 3 + l31;
+    for (int p = 0; p < NP; p++) a[p] = Wl[wsrc(p)];
   }
-  // WGRAD: the (channel, tap) column of this lane in the weight-gradient tile; a lane past K reads tap 0 (not stored)
-  const int kw = l31 < KK ? l31 : 0;
-  const int koffw = (kw / 9) * kCH + ((kw % 9) / 3) * kPitch + (kw % 3) + 3 + 4 * half;
-  f32x16 acc;
+  // WGRAD: the (channel, tap) columns of this lane in the weight-gradient tiles (column 32 t + l31 of tile t; a lane
+  // past K reads tap 0, its column is not stored)
+  int koffw[KT];
 #pragma unroll
-  for (int rr = 0; rr < 16; rr++) acc[rr] = 0.0f;
-  float s1 = 0.0f, s2 = 0.0f;
+  for (int t = 0; t < KT; t++) {
+    const int kw = 32 * t + l31 < KK ? 32 * t + l31 : 0;
+    koffw[t] = (kw / (KS * KS)) * G::CH + ((kw % (KS * KS)) / KS) * kPitch + (kw % KS) + 4 - G::PAD + 4 * half;
+  }
+  f32x16 acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; t++)
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) acc[t][rr] = 0.0f;
+  float s1 = 0.0f, s2 = 0.0f, sb = 0.0f;            // sb (WGRAD): the lane's sum of d loss / d z = the bias gradient
   ST2(2);
   const int nsw = (steps - wave + 7) >> 3;           // <= 2: the image has at most 16 row pairs
   while (item < g.N) {
     const int next = item + gridDim.x;
-    if (next < g.N) tile_request<C, QR>(g.x + (int64_t)next * C * H * 32, H, tid, tv);
+    if (next < g.N) tile_request<C, KS, QR>(g.x + (int64_t)next * C * H * 32, H, tid, tv);
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       if (k >= nsw) break;
       const int sidx = wave + 8 * k;
-      // the two rows' transposed convolutions while those are in flight
-      f32x16 zt[2];
-#pragma unroll
-      for (int h2 = 0; h2 < 2; h2++) {
-        float xb[NP];
-#pragma unroll
-        for (int p = 0; p < NP; p++) xb[p] = Xl[koff[p] + (2 * sidx + h2) * kPitch];
-#pragma unroll
-        for (int rr = 0; rr < 16; rr++) zt[h2][rr] = 0.0f;
-#pragma unroll
-        for (int p = 0; p < NP; p++) zt[h2] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[p], a[p], zt[h2], 0, 0, 0);
-      }
 #pragma unroll
       for (int q = 0; q < 2; q++) {
         *reinterpret_cast<f32x4*>(Ys + (16 * q + (lane >> 2)) * YP + (lane & 3) * 4) = ry[k][q];
@@ -474,18 +495,34 @@ __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      constexpr int PCHB = AREG ? NP : 8;
 #pragma unroll
       for (int h2 = 0; h2 < 2; h2++) {
-        const float* xr = Xl + koffw + (2 * sidx + h2) * kPitch;
+        // this row's transposed convolution (the accumulator starts from the lane's bias: the forward kernel's
+        // sequence), consumed before the next row's is formed
+        f32x16 zt;
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) zt[rr] = c_bias;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+          float ap;
+          if constexpr (AREG) ap = a[p]; else ap = Wl[wsrc(p)];
+          zt = __builtin_amdgcn_mfma_f32_32x32x2f32(Xl[koff(p) + (2 * sidx + h2) * kPitch], ap, zt, 0, 0, 0);
+          if (p % PCHB == PCHB - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        const int xrow = (2 * sidx + h2) * kPitch;
 #pragma unroll
         for (int rr = 0; rr < 16; rr++) {
-          const float z_ = zt[h2][rr];
+          const float z_ = zt[rr];
           const float xh_ = __fmul_rn(__fsub_rn(z_, c_mean), rsd);                  // bn_point's first two steps
           const float bo_ = __fadd_rn(__fmul_rn(xh_, gw), gb);
           const float dy_ = stem_dy2(bo_, yv[rr >> 2][(rr & 3) >> 1], gv[rr >> 2][(rr & 3) >> 1]);
           if constexpr (WGRAD) {
             const float t = (dy_ - k1 - xh_ * k2) * gw * rsd;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t, xr[(rr & 3) + 8 * (rr >> 2)], acc, 0, 0, 0);
+            sb += t;
+#pragma unroll
+            for (int ct = 0; ct < KT; ct++)
+              acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(t, Xl[koffw[ct] + xrow + (rr & 3) + 8 * (rr >> 2)], acc[ct], 0, 0, 0);
           } else {
             s1 += dy_;
             s2 += dy_ * xh_;
@@ -497,7 +534,7 @@ __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
     if (item < g.N) {
       request_rows(item);
       __syncthreads();
-      tile_commit<C, QR>(Xl, H, tid, tv);
+      tile_commit<C, KS, QR>(Xl, H, tid, tv);
       __syncthreads();
     }
   }
@@ -505,19 +542,35 @@ __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
   __syncthreads();                                   // every wave is done with its transposition area
   ST2(4);
   if constexpr (WGRAD) {
+    // the eight waves' tiles through LDS, a column tile at a time; slab [blockIdx.x][O][KK + 1], column KK = the bias
+    // gradient (the lanes' sums of d loss / d z: lane = channel, its two halves and the eight waves added in order)
     float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(area);       // [8][16][64]
+    float* out = g.slabs + (int64_t)blockIdx.x * O * (KK + 1);
 #pragma unroll
-    for (int rr = 0; rr < 16; rr++) red[wave][rr][lane] = acc[rr];
+    for (int ct = 0; ct < KT; ct++) {
+      if (ct > 0) __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) red[wave][rr][lane] = acc[ct][rr];
+      __syncthreads();
+#pragma unroll
+      for (int h2 = 0; h2 < 2; h2++) {
+        const int idx = tid + 512 * h2, rr = idx >> 6, ln = idx & 63;
+        float v = 0.0f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; w8++) v += red[w8][rr][ln];
+        const int oo = (rr & 3) + 8 * (rr >> 2) + 4 * (ln >> 5), kk = 32 * ct + (ln & 31);
+        if (oo < O && kk < KK) out[(int64_t)oo * (KK + 1) + kk] = v;
+      }
+    }
     __syncthreads();
-    float* out = g.slabs + (int64_t)blockIdx.x * O * KK;
+    float* sums = area;                              // [8 waves][64 lanes]
+    sums[wave * 64 + lane] = sb;
+    __syncthreads();
+    if (tid < O) {
+      float t = 0.0f;
 #pragma unroll
-    for (int h2 = 0; h2 < 2; h2++) {
-      const int idx = tid + 512 * h2, rr = idx >> 6, ln = idx & 63;
-      float v = 0.0f;
-#pragma unroll
-      for (int w8 = 0; w8 < 8; w8++) v += red[w8][rr][ln];
-      const int oo = (rr & 3) + 8 * (rr >> 2) + 4 * (ln >> 5), kk = ln & 31;
-      if (oo < O && kk < KK) out[(int64_t)oo * KK + kk] = v;
+      for (int w8 = 0; w8 < 8; w8++) t += sums[w8 * 64 + tid] + sums[w8 * 64 + 32 + tid];
+      out[(int64_t)tid * (KK + 1) + KK] = t;
     }
   } else {
     float* sums = area;                              // [8 waves][64 lanes][2]
@@ -537,8 +590,10 @@ __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
 
 // out[i] = sum over the slabs in a fixed order.  A block owns 32 consecutive elements; its 256 threads are 8 slab
 // groups x 32 elements, a thread takes the slabs sg, sg + 8, ... (eight loads in flight), the groups meet in LDS.
-__global__ __launch_bounds__(256) void k_stem_slab_sum(const float* __restrict__ slabs, float* __restrict__ out, int n,
-                                                       int splits) {
+// element i of a slab is (channel i / (KK + 1), column i % (KK + 1)): columns < KK go to dw[channel][column], column KK to
+// db[channel] (when there is a bias)
+__global__ __launch_bounds__(256) void k_stem_slab_sum(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                       float* __restrict__ db, int n, int splits, int KK) {
   __shared__ float part[8][32];
   const int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
   const int i = min(blockIdx.x * 32 + e, n - 1);
@@ -557,28 +612,34 @@ __global__ __launch_bounds__(256) void k_stem_slab_sum(const float* __restrict__
     float r = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; k++) r += part[k][e];
-    out[blockIdx.x * 32 + e] = r;
+    const int ch = i / (KK + 1), col = i - ch * (KK + 1);
+    if (col < KK) dw[ch * KK + col] = r;
+    else if (db) db[ch] = r;
   }
 }
 
-size_t stem_bwd_lds(int C) {
-  const int KK = C * 9;
-  return ((size_t)C * kCH + 32 * KK + ((32 * KK) & 1) + std::max(8 * 2 * 32 * 20 + 64, 8 * 16 * 64)) * sizeof(float);
+size_t stem_bwd_lds(int C, int k) {
+  const int KK = C * k * k;
+  return ((size_t)C * (32 + k - 1) * kPitch + 32 * KK + 32 + ((32 * KK) & 1) + std::max(8 * 2 * 32 * 20 + 64, 8 * 16 * 64)) *
+         sizeof(float);
 }
 
 bool stem_shape(int N, int C, int H, int W, int O, int k, int stride, int pad) {
   static int enabled = getenv("DFHIP_STEM_NOZ") ? atoi(getenv("DFHIP_STEM_NOZ")) : 1;
-  return enabled && N >= 1 && k == 3 && stride == 1 && pad == 1 && W == 32 && C >= 1 && C <= 3 && O >= 1 && O <= 32 &&
-         H >= 2 && H <= 32 && !(H & 1);
+  return enabled && N >= 1 && (k == 3 || k == 5) && stride == 1 && pad == k / 2 && W == 32 && C >= 1 && C <= 3 && O >= 1 &&
+         O <= 32 && H >= 2 && H <= 32 && !(H & 1);
 }
+
+// the instantiations: C = 1 .. 3 input channels, 3x3 or 5x5
+#define DF_STEM_CASES(X) X(1, 3) X(2, 3) X(3, 3) X(1, 5) X(2, 5) X(3, 5)
 
 }  // namespace
 
 extern "C" {
 
-int dfhip_stem_forward_noz(const float* x, const float* w, const float* gamma, const float* beta, float* y,
-                           float* save_mean, float* save_var, float* running_mean, float* running_var, int N, int C,
-                           int H, int W, int O, int k, int stride, int pad, float eps, float momentum, int* done) {
+int dfhip_stem_forward_noz(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                           float* y, float* save_mean, float* save_var, float* running_mean, float* running_var, int N,
+                           int C, int H, int W, int O, int k, int stride, int pad, float eps, float momentum, int* done) {
   DF_INIT();
   DF_CHECK_ARG(x && w && y && save_mean && save_var && done, "stem_forward_noz: null array");
   *done = 0;
@@ -589,18 +650,18 @@ int dfhip_stem_forward_noz(const float* x, const float* w, const float* gamma, c
   if (!zsel) return DFHIP_OUT_OF_MEMORY;
   float* partials = zsel + nsel;
   {
-    const double flops = 2.0 * N * H * 32.0 * C * 9 * O;
-    ProfScope prof("conv2d_fwd_igemm", flops, 4.0 * ((double)N * C * H * 32 + (double)O * C * 9 + (double)nsel));
-    switch (C) {
-      case 1: DF_LAUNCH(k_stem_fwd_sel<1>, dim3((unsigned)gx), dim3(512), 0, stream(), x, w, gamma, zsel, partials, N, H, O); break;
-      case 2: DF_LAUNCH(k_stem_fwd_sel<2>, dim3((unsigned)gx), dim3(512), 0, stream(), x, w, gamma, zsel, partials, N, H, O); break;
-      default: DF_LAUNCH(k_stem_fwd_sel<3>, dim3((unsigned)gx), dim3(512), 0, stream(), x, w, gamma, zsel, partials, N, H, O); break;
-    }
+    const double flops = 2.0 * N * H * 32.0 * C * k * k * O;
+    ProfScope prof("conv2d_fwd_igemm", flops, 4.0 * ((double)N * C * H * 32 + (double)O * C * k * k + (double)N * O * (H / 2) * 16));
+#define DF_CASE(CV, KV)                                                                                          \
+    if (C == CV && k == KV)                                                                                      \
+      DF_LAUNCH((k_stem_fwd_sel<CV, KV>), dim3((unsigned)gx), dim3(512), 0, stream(), x, w, bias, gamma, zsel, partials, N, H, O);
+    DF_STEM_CASES(DF_CASE)
+#undef DF_CASE
     DF_LAUNCH_CHECK();
     st2_dump("fwd_sel", gx);
   }
   {
-    ProfScope prof("bn_relu_pool_fwd", 0.0, 8.0 * (double)nsel);
+    ProfScope prof("bn_relu_pool_fwd", 0.0, 8.0 * (double)N * O * (H / 2) * 16);
     int s = stem_pool_apply(zsel, 32, partials, gx, gamma, beta, y, save_mean, save_var, running_mean, running_var, N, O,
                             (H / 2) * 16, eps, momentum);
     if (s != DFHIP_OK) return s;
@@ -609,56 +670,54 @@ int dfhip_stem_forward_noz(const float* x, const float* w, const float* gamma, c
   return DFHIP_OK;
 }
 
-int dfhip_stem_backward_noz(const float* x, const float* w, const float* y, const float* g, const float* gamma,
-                            const float* beta, const float* save_mean, const float* save_var, float* dw, float* dgamma,
-                            float* dbeta, int N, int C, int H, int W, int O, int k, int stride, int pad, float eps,
-                            int* done) {
+int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, const float* y, const float* g,
+                            const float* gamma, const float* beta, const float* save_mean, const float* save_var,
+                            float* dw, float* dbias, float* dgamma, float* dbeta, int N, int C, int H, int W, int O, int k,
+                            int stride, int pad, float eps, int* done) {
   DF_INIT();
   DF_CHECK_ARG(x && w && y && g && save_mean && save_var && dw && done, "stem_backward_noz: null array");
   *done = 0;
   if (!stem_shape(N, C, H, W, O, k, stride, pad)) return DFHIP_OK;
-  const int KK = C * 9;
+  const int KK = C * k * k;
   const int gx = (int)std::min<int64_t>(N, num_cus());
-  float* ws = workspace(((size_t)O * gx * 2 + (size_t)gx * O * KK) * sizeof(float));
+  float* ws = workspace(((size_t)O * gx * 2 + (size_t)gx * O * (KK + 1)) * sizeof(float));
   if (!ws) return DFHIP_OUT_OF_MEMORY;
   StemB b = {};
-  b.x = x; b.w = w; b.y = y; b.g = g; b.gamma = gamma; b.beta = beta; b.mean = save_mean; b.var = save_var;
+  b.x = x; b.w = w; b.y = y; b.g = g; b.gamma = gamma; b.beta = beta; b.mean = save_mean; b.var = save_var; b.bias = bias;
   b.partial = ws; b.slabs = ws + (size_t)O * gx * 2; b.dgamma = dgamma; b.dbeta = dbeta;
   b.N = N; b.H = H; b.O = O; b.S = gx; b.eps = eps;
-  const size_t lds = stem_bwd_lds(C);
+  const size_t lds = stem_bwd_lds(C, k);
   static bool attr = false;
   if (!attr) {
-    const int cap = (int)stem_bwd_lds(3);
-    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    const int cap = (int)stem_bwd_lds(3, 5);
+#define DF_CASE(CV, KV)                                                                                                   \
+    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<CV, KV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<CV, KV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DF_STEM_CASES(DF_CASE)
+#undef DF_CASE
     attr = true;
   }
   const double npix = (double)N * O * H * 32;
   {
     ProfScope prof("bn_relu_pool_bwd", 0.0, 4.0 * ((double)N * C * H * 32 + npix / 2));
-    switch (C) {
-      case 1: DF_LAUNCH((k_stem_bwd<1, false>), dim3((unsigned)gx), dim3(512), lds, stream(), b); break;
-      case 2: DF_LAUNCH((k_stem_bwd<2, false>), dim3((unsigned)gx), dim3(512), lds, stream(), b); break;
-      default: DF_LAUNCH((k_stem_bwd<3, false>), dim3((unsigned)gx), dim3(512), lds, stream(), b); break;
-    }
+#define DF_CASE(CV, KV) \
+    if (C == CV && k == KV) DF_LAUNCH((k_stem_bwd<CV, KV, false>), dim3((unsigned)gx), dim3(512), lds, stream(), b);
+    DF_STEM_CASES(DF_CASE)
+#undef DF_CASE
     DF_LAUNCH_CHECK();
     st2_dump("bwd_stats", gx);
   }
   {
-    ProfScope prof("conv2d_wgrad_igemm", 2.0 * N * H * 32.0 * C * 9 * O, 4.0 * ((double)N * C * H * 32 + (double)O * KK + npix / 2));
-    switch (C) {
-      case 1: DF_LAUNCH((k_stem_bwd<1, true>), dim3((unsigned)gx), dim3(512), lds, stream(), b); break;
-      case 2: DF_LAUNCH((k_stem_bwd<2, true>), dim3((unsigned)gx), dim3(512), lds, stream(), b); break;
-      default: DF_LAUNCH((k_stem_bwd<3, true>), dim3((unsigned)gx), dim3(512), lds, stream(), b); break;
-    }
+    ProfScope prof("conv2d_wgrad_igemm", 2.0 * N * H * 32.0 * KK * O, 4.0 * ((double)N * C * H * 32 + (double)O * KK + npix / 2));
+#define DF_CASE(CV, KV) \
+    if (C == CV && k == KV) DF_LAUNCH((k_stem_bwd<CV, KV, true>), dim3((unsigned)gx), dim3(512), lds, stream(), b);
+    DF_STEM_CASES(DF_CASE)
+#undef DF_CASE
     DF_LAUNCH_CHECK();
     st2_dump("bwd_wgrad", gx);
-    const int n = O * KK;
-    DF_LAUNCH(k_stem_slab_sum, dim3((unsigned)df_ceil_div(n, 32)), dim3(256), 0, stream(), (const float*)b.slabs, dw, n, gx);
+    const int n = O * (KK + 1);
+    DF_LAUNCH(k_stem_slab_sum, dim3((unsigned)df_ceil_div(n, 32)), dim3(256), 0, stream(), (const float*)b.slabs, dw, dbias, n,
+              gx, KK);
     DF_LAUNCH_CHECK();
   }
   *done = 1;

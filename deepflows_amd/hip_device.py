@@ -365,24 +365,25 @@ class HipModule:
                                                  pad, float(eps), ctypes.byref(done)))
         return bool(done.value)
 
-    def stem_forward_noz(self, x, w, gamma, beta, y, save_mean, save_var, running_mean, running_var, N, C, H, W, O, k,
-                         stride, pad, eps, momentum):
-        """pool(relu(bn(conv(x)))) of the CIFAR stem without the full-resolution convolution output; False = the shape
+    def stem_forward_noz(self, x, w, bias, gamma, beta, y, save_mean, save_var, running_mean, running_var, N, C, H, W, O,
+                         k, stride, pad, eps, momentum):
+        """pool(relu(bn(conv(x)))) of the CIFAR stems without the full-resolution convolution output; False = the shape
         has no such kernel (nothing was launched)."""
         gp = lambda h: h.ptr if h is not None else None
         done = ctypes.c_int(0)
-        _lib.check(self._lib.dfhip_stem_forward_noz(x.ptr, w.ptr, gp(gamma), gp(beta), y.ptr, save_mean.ptr, save_var.ptr,
-                                                    gp(running_mean), gp(running_var), N, C, H, W, O, k, stride, pad,
-                                                    float(eps), float(momentum), ctypes.byref(done)))
+        _lib.check(self._lib.dfhip_stem_forward_noz(x.ptr, w.ptr, gp(bias), gp(gamma), gp(beta), y.ptr, save_mean.ptr,
+                                                    save_var.ptr, gp(running_mean), gp(running_var), N, C, H, W, O, k,
+                                                    stride, pad, float(eps), float(momentum), ctypes.byref(done)))
         return bool(done.value)
 
-    def stem_backward_noz(self, x, w, y, g, gamma, beta, save_mean, save_var, dw, dgamma, dbeta, N, C, H, W, O, k,
-                          stride, pad, eps):
+    def stem_backward_noz(self, x, w, bias, y, g, gamma, beta, save_mean, save_var, dw, dbias, dgamma, dbeta, N, C, H, W,
+                          O, k, stride, pad, eps):
         gp = lambda h: h.ptr if h is not None else None
         done = ctypes.c_int(0)
-        _lib.check(self._lib.dfhip_stem_backward_noz(x.ptr, w.ptr, y.ptr, g.ptr, gp(gamma), gp(beta), save_mean.ptr,
-                                                     save_var.ptr, dw.ptr, gp(dgamma), gp(dbeta), N, C, H, W, O, k,
-                                                     stride, pad, float(eps), ctypes.byref(done)))
+        _lib.check(self._lib.dfhip_stem_backward_noz(x.ptr, w.ptr, gp(bias), y.ptr, g.ptr, gp(gamma), gp(beta),
+                                                     save_mean.ptr, save_var.ptr, dw.ptr, gp(dbias), gp(dgamma),
+                                                     gp(dbeta), N, C, H, W, O, k, stride, pad, float(eps),
+                                                     ctypes.byref(done)))
         return bool(done.value)
 
     def bn_relu_maxpool2_forward_partials(self, x, partials, rows, gamma, beta, y, save_mean, save_var, running_mean,

@@ -887,43 +887,50 @@ class _StemNoZFused(_FusedNode):
         k = getattr(pool, "kernel_size", None)
         st = getattr(pool, "stride", k)
         if (fn is None or not _STEM_NOZ or not _fused(x) or not bn.training or not is_grad_enable() or x.requires_grad
-                or len(x.shape) != 4 or conv.bias is not None or bn.weight is None or bn.bias is None
+                or len(x.shape) != 4 or bn.weight is None or bn.bias is None
                 or k != 2 or (st not in (None, 0, 2)) or getattr(pool, "padding", 0) not in (0, None)):
             return None
         N, C, H, W = (int(v) for v in x.shape)
         O, _, ks, _ = (int(v) for v in conv.weight.shape)
         geo = (N, C, H, W, O, ks, int(conv.stride), int(conv.padding))
         xd, wd = x.data.compact(), conv.weight.data.compact()
+        cb = conv.bias.data.compact() if conv.bias is not None else None     # (1, O, 1, 1): conv.py:104-108 adds it
         gd, bd = bn.weight.data.compact(), bn.bias.data.compact()
         out = _new((N, O, H // 2, W // 2), dev)
         mean, var = _new((1, O, 1, 1), dev), _new((1, O, 1, 1), dev)
         rm = bn.running_mean.data._handle if bn.running_mean is not None else None
         rv = bn.running_var.data._handle if bn.running_var is not None else None
-        if not fn(xd._handle, wd._handle, gd._handle, bd._handle, out._handle, mean._handle, var._handle, rm, rv, *geo,
-                  float(bn.eps), float(bn.momentum)):
+        if not fn(xd._handle, wd._handle, cb._handle if cb is not None else None, gd._handle, bd._handle, out._handle,
+                  mean._handle, var._handle, rm, rv, *geo, float(bn.eps), float(bn.momentum)):
             return None
         node = cls.__new__(cls)
-        node.w, node.weight, node.bias = conv.weight, bn.weight, bn.bias
+        node.w, node.cbias, node.weight, node.bias = conv.weight, conv.bias, bn.weight, bn.bias
         node.geo, node.eps = geo, float(bn.eps)
-        node._saved = (xd, wd, gd, bd, mean, var)
+        node._saved = (xd, wd, cb, gd, bd, mean, var)
         node.mean, node.var = mean, var
         node._grads = None
-        _FusedNode.__init__(node, out, [conv.weight, bn.weight, bn.bias])
+        _FusedNode.__init__(node, out, [conv.weight, conv.bias, bn.weight, bn.bias])
         return node
 
     def grad_fn(self, node, grad):
         if self._grads is None or self._grads[0] is not grad:
             dev = grad.device
-            xd, wd, gd, bd, mean, var = self._saved
+            xd, wd, cb, gd, bd, mean, var = self._saved
             O = self.geo[4]
             dw, dg, db = _new(wd.shape, dev), _new((1, O, 1, 1), dev), _new((1, O, 1, 1), dev)
-            if not dev.stem_backward_noz(xd._handle, wd._handle, self.data._handle, grad.compact()._handle, gd._handle,
-                                         bd._handle, mean._handle, var._handle, dw._handle, dg._handle, db._handle,
-                                         *self.geo, self.eps):
+            dcb = _new((1, O, 1, 1), dev) if cb is not None else None
+            h = lambda t: t._handle if t is not None else None
+            if not dev.stem_backward_noz(xd._handle, wd._handle, h(cb), self.data._handle, grad.compact()._handle,
+                                         gd._handle, bd._handle, mean._handle, var._handle, dw._handle, h(dcb),
+                                         dg._handle, db._handle, *self.geo, self.eps):
                 raise RuntimeError("stem backward: the shape the forward kernel took has no backward kernel")
-            self._grads = (grad, dw, dg, db)
-        _, dw, dg, db = self._grads
-        return dw if node is self.w else (dg if node is self.weight else db)
+            self._grads = (grad, dw, dcb, dg, db)
+        _, dw, dcb, dg, db = self._grads
+        if node is self.w:
+            return dw
+        if self.cbias is not None and node is self.cbias:
+            return dcb
+        return dg if node is self.weight else db
 
 
 _STEM_NOZ = os.environ.get("DF_STEM_NOZ", "1") != "0"

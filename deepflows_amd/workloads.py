@@ -74,6 +74,11 @@ class CIFAR10_CNN(nn.Module):
         for conv, bn, relu, pool in ((self.conv1, self.bn1, self.relu1, self.pool1),
                                      (self.conv2, self.bn2, self.relu2, self.pool2),
                                      (self.conv3, self.bn3, self.relu3, self.pool3)):
+            if conv is self.conv1:
+                stem = nn.functional.stem_conv_bn_relu_pool_train(x, conv, bn, pool)
+                if stem is not None:               # one node, the 33 MB output of the first convolution never exists
+                    x = stem
+                    continue
             x = conv(x)
             if nn.functional.bn_relu_maxpool2_fusable(x, bn, pool):
                 x = nn.functional.bn_relu_maxpool2_train(x, bn)     # pool(relu(bn(x))) as one node on the hip device

@@ -274,8 +274,8 @@ int dfhip_stem_backward(const float* x, const float* z, const float* y, const fl
                         const float* beta, const float* save_mean, const float* save_var, float* dw, float* dgamma,
                         float* dbeta, int N, int C, int H, int W, int O, int k, int stride, int pad, float eps,
                         int* done);
-/* The same stem for the shape of the CIFAR ResNet (3x3 / stride 1 / pad 1, 1-3 input channels, <= 32 output channels,
- * 32-wide images of even height <= 32, no bias) WITHOUT the full-resolution convolution output: forward writes only
+/* The same stem for the shapes of the CIFAR models (3x3 / pad 1 or 5x5 / pad 2, stride 1, 1-3 input channels, <= 32
+ * output channels, 32-wide images of even height <= 32; bias (O) and its gradient dbias optional) WITHOUT the full-resolution convolution output: forward writes only
  * y (N, O, H/2, 16) and the statistics -- BatchNorm and ReLU are monotone per channel, so the pooled value is
  * relu(bn(extreme of the window)) bit for bit and the convolution keeps only that extreme; backward rebuilds the
  * convolution output from x with the same MFMA sequence (the same bits) to apply the reference's tie rules
@@ -283,13 +283,13 @@ int dfhip_stem_backward(const float* x, const float* z, const float* y, const fl
  * dfhip_conv2d_forward_stats + dfhip_bn_relu_maxpool2_forward_partials / dfhip_stem_backward for that shape
  * (nn/functional.py:316-374 + nn/modules/batchnorm.py:30-55 in the reference).  *done = 0 (nothing launched) for any
  * other shape. */
-int dfhip_stem_forward_noz(const float* x, const float* w, const float* gamma, const float* beta, float* y,
-                           float* save_mean, float* save_var, float* running_mean, float* running_var, int N, int C,
-                           int H, int W, int O, int k, int stride, int pad, float eps, float momentum, int* done);
-int dfhip_stem_backward_noz(const float* x, const float* w, const float* y, const float* g, const float* gamma,
-                            const float* beta, const float* save_mean, const float* save_var, float* dw, float* dgamma,
-                            float* dbeta, int N, int C, int H, int W, int O, int k, int stride, int pad, float eps,
-                            int* done);
+int dfhip_stem_forward_noz(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                           float* y, float* save_mean, float* save_var, float* running_mean, float* running_var, int N,
+                           int C, int H, int W, int O, int k, int stride, int pad, float eps, float momentum, int* done);
+int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, const float* y, const float* g,
+                            const float* gamma, const float* beta, const float* save_mean, const float* save_var,
+                            float* dw, float* dbias, float* dgamma, float* dbeta, int N, int C, int H, int W, int O, int k,
+                            int stride, int pad, float eps, int* done);
 /* the same with the batch statistics from the partials the convolution that produced x left behind
  * (dfhip_conv2d_forward_stats: partials[rows][C][3]): no statistics pass over x */
 int dfhip_bn_relu_maxpool2_forward_partials(const float* x, const float* partials, int rows, const float* gamma,

@@ -630,8 +630,10 @@ def test_stem_backward_without_the_full_resolution_gradient(hip_device, k, pad):
         assert_close(a, b, 2e-6, f"stem backward k={k}: " + nm)
 
 
-@pytest.mark.parametrize("N,C,H,O", [(32, 3, 32, 32), (5, 3, 32, 32), (7, 2, 16, 20), (3, 1, 8, 32), (300, 3, 32, 32)])
-def test_stem_without_its_convolution_output(hip_device, N, C, H, O):
+@pytest.mark.parametrize("N,C,H,O,K,bias", [(32, 3, 32, 32, 3, False), (5, 3, 32, 32, 3, True), (7, 2, 16, 20, 3, False),
+                                              (3, 1, 8, 32, 3, False), (300, 3, 32, 32, 3, False), (32, 3, 32, 32, 5, True),
+                                              (6, 2, 16, 24, 5, False), (260, 3, 32, 32, 5, True)])
+def test_stem_without_its_convolution_output(hip_device, N, C, H, O, K, bias):
     """pool(relu(bn(conv(x)))) as the one node whose 33 MB convolution output never exists (dfhip_stem.hip: the
     convolution keeps the window extreme that survives bn + relu + max -- the minimum where gamma < 0 --, the backward
     kernels rebuild the convolution from x) against the separate operators with their own backward launches.  Integer
@@ -653,9 +655,11 @@ def test_stem_without_its_convolution_output(hip_device, N, C, H, O):
         F._STEM_FUSED_BWD = False                    # the comparison path: every operator's own backward launch
         try:
             np.random.seed(2)
-            conv = nn.Conv2d(C, O, kernel_size=3, stride=1, padding=1, bias=False, device=dev)
+            conv = nn.Conv2d(C, O, kernel_size=K, stride=1, padding=K // 2, bias=bias, device=dev)
             wq = np.round(conv.weight.numpy() * 8) / 8
             dev.mod.from_numpy(wq.astype(np.float32), conv.weight.data._handle)
+            if bias:
+                dev.mod.from_numpy((np.arange(O, dtype=np.float32).reshape(1, O, 1, 1) % 5 - 2) / 4, conv.bias.data._handle)
             bn = nn.BatchNorm2d(O, device=dev)
             dev.mod.from_numpy(gamma, bn.weight.data._handle)
             dev.mod.from_numpy(beta, bn.bias.data._handle)
@@ -669,13 +673,19 @@ def test_stem_without_its_convolution_output(hip_device, N, C, H, O):
             loss = tensor.sum(y * Tensor(gy, device=dev))
             loss.backward()
             results.append([y.numpy().copy(), bn.running_mean.numpy().copy(), bn.running_var.numpy().copy(),
-                            conv.weight.grad.numpy().copy(), bn.weight.grad.numpy().copy(), bn.bias.grad.numpy().copy()])
+                            conv.weight.grad.numpy().copy(), bn.weight.grad.numpy().copy(), bn.bias.grad.numpy().copy(),
+                            conv.bias.grad.numpy().copy() if bias else np.zeros(1, np.float32)])
             Graph.free_graph_all()
         finally:
             F._STEM_FUSED_BWD = True
     names = ("y", "running_mean", "running_var", "dw", "dgamma", "dbeta")
     for a, b, nm in zip(results[0], results[1], names):
-        assert_close(a, b, 3e-6 if nm in ("y", "running_mean", "running_var") else 2e-5, f"stem without z ({N},{C},{H},{O}): " + nm)
+        assert_close(a, b, 3e-6 if nm in ("y", "running_mean", "running_var") else 2e-5, f"stem without z ({N},{C},{H},{O},k{K}): " + nm)
+    if bias:
+        # the bias gradient is the sum of d loss / d z, which BatchNorm makes zero up to rounding: both paths return
+        # rounding noise far below the weight gradient's scale
+        scale = float(np.abs(results[1][3]).max())
+        assert float(np.abs(results[0][6]).max()) <= 1e-4 * scale and float(np.abs(results[1][6]).max()) <= 1e-4 * scale
     # the pooled values are relu(bn(.)) of an element of the window: where the two paths' statistics agree to the bit
     # the outputs must too -- at least the zero pattern (ReLU) is identical
     assert np.array_equal(results[0][0] == 0.0, results[1][0] == 0.0)
