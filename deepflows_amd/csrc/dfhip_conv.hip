@@ -4260,7 +4260,10 @@ int run_wgrad_v3(WGeo g, float* dw, bool stem = false) {
   if (g.ow & 1) return -1;
   if ((g.H * g.W) % 4 != 0 || (g.oh * g.ow) % 4 != 0) return -1;   // 16-byte aligned channel planes
   const int OT = g.O <= 32 ? 1 : 2;
-  const int KT = (g.k == 1 || KW <= 32) ? 1 : (g.O <= 32 ? 5 : 2);
+  // (column tiles per workgroup: with 64 output channels and a 5x5 kernel -- 800 columns -- five tiles per workgroup
+  // halve the dY operand reads per MFMA; DFHIP_WGRAD_KT5=0 restores two)
+  static int kt5 = getenv("DFHIP_WGRAD_KT5") ? atoi(getenv("DFHIP_WGRAD_KT5")) : 1;
+  const int KT = (g.k == 1 || KW <= 32) ? 1 : (g.O <= 32 ? 5 : ((kt5 && g.k == 5 && KW >= 320) ? 5 : 2));
   const int CH = std::min(g.C, (KT * 32 + k2 - 2) / k2 + 1);
   int gi = 1;
   size_t lds = 0;
@@ -4296,6 +4299,7 @@ int run_wgrad_v3(WGeo g, float* dw, bool stem = false) {
   }
   if (OT == 1 && KT == 5) return launch_wgrad_v3<1, 5, 4>(g, dw, lds, gx, ktg, otg);
   if (OT == 1) return launch_wgrad_v3<1, 1, 4>(g, dw, lds, gx, ktg, otg);
+  if (KT == 5) return launch_wgrad_v3<2, 5, 4>(g, dw, lds, gx, ktg, otg);
   if (KT == 2) return launch_wgrad_v3<2, 2, 4>(g, dw, lds, gx, ktg, otg);
   return launch_wgrad_v3<2, 1, 4>(g, dw, lds, gx, ktg, otg);
 }
