@@ -347,8 +347,16 @@ struct StemB {
   float eps;
 };
 
-template <int C, int KS, bool WGRAD>
+// MODE 0: statistics pass, 1: weight gradient from the statistics, 2: BOTH in one pass (3x3) -- the weight gradient is
+// linear in the two sums the statistics pass exists for:
+//     dW = gamma rsd (A - k1 S - k2 B),   A = sum dy (x) patch,  B = sum xhat (x) patch,  S = sum patch,
+//     k1 = sum dy / m,  k2 = sum dy xhat / m
+// so one kernel accumulates A and B (two MFMA streams on the same rebuilt z), S, sum dy and sum dy xhat per workgroup and
+// k_stem_combine forms dW, dgamma, dbeta and the bias gradient from the totals: one convolution rebuild instead of two,
+// one pass over y and g instead of two, one launch fewer.
+template <int C, int KS, int MODE>
 __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
+  constexpr bool WGRAD = MODE == 1, ONE = MODE == 2;
   typedef TileGeo<KS> G;
   constexpr int KK = C * KS * KS, NP = (KK + 1) / 2;
   constexpr bool AREG = NP <= 16;                     // weight operands in registers (3x3) or read from LDS per MFMA
@@ -461,12 +469,19 @@ __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
     const int kw = 32 * t + l31 < KK ? 32 * t + l31 : 0;
     koffw[t] = (kw / (KS * KS)) * G::CH + ((kw % (KS * KS)) / KS) * kPitch + (kw % KS) + 4 - G::PAD + 4 * half;
   }
-  f32x16 acc[KT];
+  f32x16 acc[KT], accB[ONE ? KT : 1];
 #pragma unroll
   for (int t = 0; t < KT; t++)
 #pragma unroll
     for (int rr = 0; rr < 16; rr++) acc[t][rr] = 0.0f;
+#pragma unroll
+  for (int t = 0; t < (ONE ? KT : 1); t++)
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) accB[t][rr] = 0.0f;
   float s1 = 0.0f, s2 = 0.0f, sb = 0.0f;            // sb (WGRAD): the lane's sum of d loss / d z = the bias gradient
+  float sx[ONE ? KT : 1], sxh = 0.0f;               // ONE: the lane's column sums of the patches; its sum of xhat
+#pragma unroll
+  for (int t = 0; t < (ONE ? KT : 1); t++) sx[t] = 0.0f;
   ST2(2);
   const int nsw = (steps - wave + 7) >> 3;           // <= 2: the image has at most 16 row pairs
   while (item < g.N) {
@@ -523,6 +538,17 @@ __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
 #pragma unroll
             for (int ct = 0; ct < KT; ct++)
               acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(t, Xl[koffw[ct] + xrow + (rr & 3) + 8 * (rr >> 2)], acc[ct], 0, 0, 0);
+          } else if constexpr (ONE) {
+            s1 += dy_;
+            s2 += dy_ * xh_;
+            sxh += xh_;
+#pragma unroll
+            for (int ct = 0; ct < KT; ct++) {
+              const float xv = Xl[koffw[ct] + xrow + (rr & 3) + 8 * (rr >> 2)];
+              acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy_, xv, acc[ct], 0, 0, 0);
+              accB[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(xh_, xv, accB[ct], 0, 0, 0);
+              sx[ct] += xv;
+            }
           } else {
             s1 += dy_;
             s2 += dy_ * xh_;
@@ -572,6 +598,53 @@ __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
       for (int w8 = 0; w8 < 8; w8++) t += sums[w8 * 64 + tid] + sums[w8 * 64 + 32 + tid];
       out[(int64_t)tid * (KK + 1) + KK] = t;
     }
+  } else if constexpr (ONE) {
+    // slab [blockIdx.x]: A [O][KK], B [O][KK], then per channel (sum dy, sum dy xhat, sum xhat), then S [KK]
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(area);
+    const int SL = 2 * O * KK + 3 * O + KK;
+    float* out = g.slabs + (int64_t)blockIdx.x * SL;
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+#pragma unroll
+      for (int ct = 0; ct < KT; ct++) {
+        if (which + ct > 0) __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) red[wave][rr][lane] = which ? accB[ct][rr] : acc[ct][rr];
+        __syncthreads();
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+          const int idx = tid + 512 * h2, rr = idx >> 6, ln = idx & 63;
+          float v = 0.0f;
+#pragma unroll
+          for (int w8 = 0; w8 < 8; w8++) v += red[w8][rr][ln];
+          const int oo = (rr & 3) + 8 * (rr >> 2) + 4 * (ln >> 5), kk = 32 * ct + (ln & 31);
+          if (oo < O && kk < KK) out[(int64_t)which * O * KK + (int64_t)oo * KK + kk] = v;
+        }
+      }
+    }
+    __syncthreads();
+    float* sums = area;                              // [8 waves][64 lanes][3 + KT]
+    constexpr int NS = 3 + KT;
+    sums[(wave * 64 + lane) * NS] = s1;
+    sums[(wave * 64 + lane) * NS + 1] = s2;
+    sums[(wave * 64 + lane) * NS + 2] = sxh;
+#pragma unroll
+    for (int ct = 0; ct < KT; ct++) sums[(wave * 64 + lane) * NS + 3 + ct] = sx[ct];
+    __syncthreads();
+    if (tid < 3 * O) {
+      const int ch = tid / 3, which = tid % 3;
+      float t = 0.0f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; w8++) t += sums[(w8 * 64 + ch) * NS + which] + sums[(w8 * 64 + 32 + ch) * NS + which];
+      out[2 * O * KK + tid] = t;
+    }
+    if (tid >= 128 && tid < 128 + KK) {
+      const int kk = tid - 128, ct = kk >> 5, ln = kk & 31;
+      float t = 0.0f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; w8++) t += sums[(w8 * 64 + ln) * NS + 3 + ct] + sums[(w8 * 64 + 32 + ln) * NS + 3 + ct];
+      out[2 * O * KK + 3 * O + kk] = t;
+    }
   } else {
     float* sums = area;                              // [8 waves][64 lanes][2]
     sums[(wave * 64 + lane) * 2] = s1;
@@ -615,6 +688,74 @@ __global__ __launch_bounds__(256) void k_stem_slab_sum(const float* __restrict__
     const int ch = i / (KK + 1), col = i - ch * (KK + 1);
     if (col < KK) dw[ch * KK + col] = r;
     else if (db) db[ch] = r;
+  }
+}
+
+// One-pass backward: totals over the workgroups' slabs (fixed order) and the weight gradient from them.  A block owns 32
+// consecutive elements (o, k) of dW; its 256 threads are 8 slab groups x 32 elements; every thread sums, over its
+// group's slabs, the five quantities its element needs: A[o][k], B[o][k], S[k], sum dy [o], sum dy xhat [o] (+ sum xhat).
+struct StemCombine {
+  const float* slabs;
+  const float* gamma;
+  const float* var;
+  float* dw;
+  float* dbias;
+  float* dgamma;
+  float* dbeta;
+  int O, KK, splits;
+  float m, eps;
+};
+__global__ __launch_bounds__(256) void k_stem_combine(StemCombine c) {
+  // eight elements of dW per block; a thread sums every 32nd slab of the six totals its element needs (A, B, the column sum
+  // and the three per-channel sums), all loads of a round in flight together; the 32 slab groups meet through the lanes and LDS.
+  __shared__ float part[4][6][8];
+  const int e = threadIdx.x & 7, sg = threadIdx.x >> 3;
+  const int n = c.O * c.KK, SL = 2 * n + 3 * c.O + c.KK;
+  const int i = min((int)blockIdx.x * 8 + e, n - 1);
+  const int o = i / c.KK, k = i - o * c.KK;
+  const int idx[6] = {i, n + i, 2 * n + 3 * c.O + k, 2 * n + 3 * o, 2 * n + 3 * o + 1, 2 * n + 3 * o + 2};
+  float t[6] = {0, 0, 0, 0, 0, 0};
+  for (int s0 = sg; s0 < c.splits; s0 += 256) {
+    float v[8][6];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const float* slab = c.slabs + (int64_t)min(s0 + 32 * u, c.splits - 1) * SL;
+#pragma unroll
+      for (int q = 0; q < 6; q++) v[u][q] = slab[idx[q]];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (s0 + 32 * u < c.splits) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) t[q] += v[u][q];
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < 6; q++) {
+    t[q] += __shfl_xor(t[q], 8);
+    t[q] += __shfl_xor(t[q], 16);
+    t[q] += __shfl_xor(t[q], 32);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 8) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) part[wave][q][e] = t[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && (int)blockIdx.x * 8 + e < n) {
+    float r[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) r[q] = (part[0][q][e] + part[1][q][e]) + (part[2][q][e] + part[3][q][e]);
+    const float A = r[0], B = r[1], S = r[2], s1 = r[3], s2 = r[4], sxh = r[5];
+    const float gw = c.gamma ? c.gamma[o] : 1.0f;
+    const float rsd = 1.0f / sqrtf(c.var[o] + c.eps);
+    const float k1 = s1 / c.m, k2 = s2 / c.m;
+    c.dw[i] = (A - k1 * S - k2 * B) * gw * rsd;
+    if (k == 0) {
+      if (c.dgamma) c.dgamma[o] = s2;
+      if (c.dbeta) c.dbeta[o] = s1;
+      if (c.dbias) c.dbias[o] = (s1 - k1 * c.m - k2 * sxh) * gw * rsd;      // sum of d loss / d z (zero up to rounding)
+    }
   }
 }
 
@@ -680,7 +821,10 @@ int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, c
   if (!stem_shape(N, C, H, W, O, k, stride, pad)) return DFHIP_OK;
   const int KK = C * k * k;
   const int gx = (int)std::min<int64_t>(N, num_cus());
-  float* ws = workspace(((size_t)O * gx * 2 + (size_t)gx * O * (KK + 1)) * sizeof(float));
+  static int onepass = getenv("DFHIP_STEM_ONEPASS") ? atoi(getenv("DFHIP_STEM_ONEPASS")) : 1;
+  const bool one = onepass && k == 3;   // (5x5: two accumulator sets of three tiles do not fit the registers)
+  const size_t SL = (size_t)2 * O * KK + 3 * O + KK;
+  float* ws = workspace(std::max((size_t)O * gx * 2 + (size_t)gx * O * (KK + 1), (size_t)gx * SL) * sizeof(float));
   if (!ws) return DFHIP_OUT_OF_MEMORY;
   StemB b = {};
   b.x = x; b.w = w; b.y = y; b.g = g; b.gamma = gamma; b.beta = beta; b.mean = save_mean; b.var = save_var; b.bias = bias;
@@ -691,17 +835,37 @@ int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, c
   if (!attr) {
     const int cap = (int)stem_bwd_lds(3, 5);
 #define DF_CASE(CV, KV)                                                                                                   \
-    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<CV, KV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
-    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<CV, KV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<CV, KV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<CV, KV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     DF_STEM_CASES(DF_CASE)
 #undef DF_CASE
+    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<1, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<2, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<3, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     attr = true;
   }
   const double npix = (double)N * O * H * 32;
+  if (one) {
+    // one pass: statistics and both halves of the weight gradient from one rebuild of the convolution
+    b.slabs = ws;
+    ProfScope prof("conv2d_wgrad_igemm", 2.0 * N * H * 32.0 * KK * O, 4.0 * ((double)N * C * H * 32 + (double)O * KK + npix / 2));
+    if (C == 1) DF_LAUNCH((k_stem_bwd<1, 3, 2>), dim3((unsigned)gx), dim3(512), lds, stream(), b);
+    else if (C == 2) DF_LAUNCH((k_stem_bwd<2, 3, 2>), dim3((unsigned)gx), dim3(512), lds, stream(), b);
+    else DF_LAUNCH((k_stem_bwd<3, 3, 2>), dim3((unsigned)gx), dim3(512), lds, stream(), b);
+    DF_LAUNCH_CHECK();
+    st2_dump("bwd_onepass", gx);
+    StemCombine c = {};
+    c.slabs = ws; c.gamma = gamma; c.var = save_var; c.dw = dw; c.dbias = dbias; c.dgamma = dgamma; c.dbeta = dbeta;
+    c.O = O; c.KK = KK; c.splits = gx; c.m = (float)N * (float)H * 32.0f; c.eps = eps;
+    DF_LAUNCH(k_stem_combine, dim3((unsigned)df_ceil_div(O * KK, 8)), dim3(256), 0, stream(), c);
+    DF_LAUNCH_CHECK();
+    *done = 1;
+    return DFHIP_OK;
+  }
   {
     ProfScope prof("bn_relu_pool_bwd", 0.0, 4.0 * ((double)N * C * H * 32 + npix / 2));
 #define DF_CASE(CV, KV) \
-    if (C == CV && k == KV) DF_LAUNCH((k_stem_bwd<CV, KV, false>), dim3((unsigned)gx), dim3(512), lds, stream(), b);
+    if (C == CV && k == KV) DF_LAUNCH((k_stem_bwd<CV, KV, 0>), dim3((unsigned)gx), dim3(512), lds, stream(), b);
     DF_STEM_CASES(DF_CASE)
 #undef DF_CASE
     DF_LAUNCH_CHECK();
@@ -710,7 +874,7 @@ int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, c
   {
     ProfScope prof("conv2d_wgrad_igemm", 2.0 * N * H * 32.0 * KK * O, 4.0 * ((double)N * C * H * 32 + (double)O * KK + npix / 2));
 #define DF_CASE(CV, KV) \
-    if (C == CV && k == KV) DF_LAUNCH((k_stem_bwd<CV, KV, true>), dim3((unsigned)gx), dim3(512), lds, stream(), b);
+    if (C == CV && k == KV) DF_LAUNCH((k_stem_bwd<CV, KV, 1>), dim3((unsigned)gx), dim3(512), lds, stream(), b);
     DF_STEM_CASES(DF_CASE)
 #undef DF_CASE
     DF_LAUNCH_CHECK();

@@ -82,7 +82,7 @@ CASES = {
     # the headline: ResNet-18 bs 256, overwrite mode, all 62 tensors
     "resnet18_bs256_overwrite": ("resnet18", 256, "overwrite",
                                  {"conv2d_fwd_igemm": 17, "conv2d_wgrad_grouped": 1, "conv2d_dgrad_overwrite_igemm": 16,
-                                  "bn_relu_pool_fwd": 1, "bn_relu_pool_bwd": 1, "pool_linear_fwd": 1,
+                                  "bn_relu_pool_fwd": 1, "pool_linear_fwd": 1,
                                   "pool_linear_bwd": 1, "softmax_ce_fwd": 1, "adam_step": 1}),
     "cnn_bs256_overwrite": ("cnn", 256, "overwrite", {"adam_step": 1}),
     "resnet18_bs128_accumulate": ("resnet18", 128, "accumulate", {"conv2d_wgrad_grouped": 1, "adam_step": 1}),

@@ -43,10 +43,10 @@ def main():
         assert mod.stem_backward(x, z, y, g, gam, bet, mean, var, dw, dg, db, *geo, 1e-5)
 
     def new_fwd():
-        assert mod.stem_forward_noz(x, w, gam, bet, y, mean, var, rm, rv, *geo, 1e-5, 0.1)
+        assert mod.stem_forward_noz(x, w, None, gam, bet, y, mean, var, rm, rv, *geo, 1e-5, 0.1)
 
     def new_bwd():
-        assert mod.stem_backward_noz(x, w, y, g, gam, bet, mean, var, dw, dg, db, *geo, 1e-5)
+        assert mod.stem_backward_noz(x, w, None, y, g, gam, bet, mean, var, dw, None, dg, db, *geo, 1e-5)
 
     for name, fn in (("old_fwd", old_fwd), ("old_bwd", old_bwd), ("new_fwd", new_fwd), ("new_bwd", new_bwd)):
         if args.only and name not in args.only.split(","):
