@@ -3385,7 +3385,41 @@ __device__ __forceinline__ void gl_read_row(const float* __restrict__ p, float (
   }
 }
 
-template <int KS, int PAD, int STRIDE, int W, int OW, int UR>
+// The operands of a unit: NP image pairs x (UR rows of dY, the NXR source rows under them).  Two such sets exist and the
+// unit loop is unrolled twice over them (MFMAs on one while the loads of the next unit land in the other): with ONE working
+// set and a register copy per unit the copy sat behind `s_waitcnt vmcnt(0)` -- every unit began by waiting for the load
+// issued nine MFMAs before its end -- and cost 64 moves of its own.
+template <int KS, int STRIDE, int UR>
+constexpr bool wg_row_used(int xr) {
+  for (int ur = 0; ur < UR; ur++)
+    for (int i = 0; i < KS; i++)
+      if (ur * STRIDE + i == xr) return true;
+  return false;
+}
+template <int KS, int STRIDE, int UR>
+constexpr int wg_used_rows() {
+  int n = 0;
+  for (int xr = 0; xr < (UR - 1) * STRIDE + KS; xr++) n += wg_row_used<KS, STRIDE, UR>(xr) ? 1 : 0;
+  return n;
+}
+template <int KS, int STRIDE, int UR>
+constexpr int wg_nth_used_row(int n) {
+  for (int xr = 0; xr < (UR - 1) * STRIDE + KS; xr++)
+    if (wg_row_used<KS, STRIDE, UR>(xr) && n-- == 0) return xr;
+  return 0;
+}
+template <int NP, int UR, int OW, int NXR, int W>
+struct WgOps {
+  float a[NP][UR][OW];
+  float b[NP][NXR][W];
+};
+struct WgUnit {
+  int rs;            // source row of (output row 0, tap row 0)
+  unsigned ybase;    // byte offsets of the unit's first pair / row in dY and (first pair) in x
+  unsigned xbase;
+};
+
+template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP>
 __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, const int bx, const int by,
                                                   const int bz) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -3396,12 +3430,19 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int H = d.H, oh = d.oh;
-  const int upr = oh / UR;                         // units per image pair
-  const int U = (d.N >> 1) * upr;
+  const int upr = oh / UR;                         // units per group of NP image pairs
+  const int rot = (upr & (upr - 1)) == 0 ? upr - 1 : 0;
+  const int rsh = upr == 2 ? 1 : 0;
+  const int U = (d.N / (2 * NP)) * upr;
   const int u_lo = bx * d.units, u_hi = min(U, u_lo + d.units);
-  const int64_t xplane = (int64_t)H * W, yplane = (int64_t)oh * OW;
-  const float* xl = d.x + ((int64_t)half * d.C + by * 32 + l31) * xplane;      // + pair * 2 * C * xplane
-  const float* yl = d.dy + ((int64_t)half * d.O + bz * 32 + l31) * yplane;
+  const int xplane = H * W, yplane = oh * OW;
+  // A lane is a channel plane: its offset is a loop constant (the buffer load's vector offset), everything that changes
+  // from piece to piece is the same for the whole wave (the scalar offset) -- no vector instruction per load
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy), 0, 0x7fffffff, 0x00020000);
+  const int xlane = ((half * d.C + by * 32 + l31) * xplane) * 4;
+  const int ylane = ((half * d.O + bz * 32 + l31) * yplane) * 4;
+  const unsigned xpair = (unsigned)(2 * d.C * xplane) * 4u, ypair = (unsigned)(2 * d.O * yplane) * 4u;
 
   f32x16 acc[T];
 #pragma unroll
@@ -3409,134 +3450,138 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
 #pragma unroll
     for (int rr = 0; rr < 16; rr++) acc[t][rr] = 0.0f;
 
-  auto row_used = [](int xr) {
-    for (int ur = 0; ur < UR; ur++)
-      for (int i = 0; i < KS; i++)
-        if (ur * STRIDE + i == xr) return true;
-    return false;
-  };
-  float a_n[UR][OW], b_n[NXR][W];
-  int rs_n = 0;
 #ifdef DFHIP_STAMPS
   unsigned long long dbg_issue = 0, dbg_mfma = 0;
+  const unsigned long long dbg_t0 = __builtin_readcyclecounter();
+  unsigned long long dbg_first = 0, dbg_last = 0;
 #endif
-  // The operand rows of a unit are NV-float vectors ("pieces"): UR * OW/VA of dY, then W/VB per used source
-  // row.  A piece is one wave load that touches 64 different cache lines (a lane per channel plane), which
-  // the address unit takes ~64 cycles to accept: issued in one burst the sixteen of them hold the wave --
-  // and with it its MFMA stream -- for ~1 800 cycles per unit.  They are therefore spread over the MFMAs
-  // of the current unit, one piece every few MFMAs.
+  // The operand rows of a unit are 8- or 16-byte vectors ("pieces"), in the order the MFMAs want them: per pair UR * OW/VA of
+  // dY, then W/VB per used source row.  A piece is one wave load that touches up to 64 different cache lines (a lane per
+  // channel plane), which the address unit takes ~64-110 cycles to accept: they are spread evenly over the MFMAs of the unit
+  // before.  Every load is unconditional (a row outside the image is read from the nearest row inside and never multiplied;
+  // the last unit of a wave is loaded twice): the wait counts are then exact -- an MFMA waits for its own operand, not for
+  // the youngest load.
   constexpr int VA = OW % 4 == 0 ? 4 : 2, VB = W % 4 == 0 ? 4 : 2;
-  constexpr int PA = UR * (OW / VA), PBR = W / VB;            // pieces of dY; pieces per source row
-  constexpr int NPIECE = PA + NXR * PBR;
-  const float* yp_n = yl;
-  const float* xp_n = xl;
-  auto piece = [&](int k) {                                  // k is a compile-time constant at every call
-    if (k < PA) {
-      const int ur = k / (OW / VA), q = k % (OW / VA);
+  constexpr int PA = UR * (OW / VA), PBR = W / VB;
+  constexpr int NUSED = wg_used_rows<KS, STRIDE, UR>();
+  constexpr int PPP = PA + NUSED * PBR;                     // pieces per pair
+  constexpr int NPIECE = NP * PPP;
+  typedef WgOps<NP, UR, OW, NXR, W> Ops;
+  auto piece = [&](Ops& o, const WgUnit& un, int k) {      // k is a compile-time constant at every call
+    const int p = k / PPP, kk = k % PPP;
+    if (kk < PA) {
+      const int ur = kk / (OW / VA), q = kk % (OW / VA);
+      const unsigned so = un.ybase + (unsigned)p * ypair + (unsigned)(ur * OW * 4);
       if constexpr (VA == 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(yp_n + ur * OW + 4 * q);
-        a_n[ur][4 * q] = t.x; a_n[ur][4 * q + 1] = t.y; a_n[ur][4 * q + 2] = t.z; a_n[ur][4 * q + 3] = t.w;
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yres, ylane + 16 * q, so, 0));
+        o.a[p][ur][4 * q] = t.x; o.a[p][ur][4 * q + 1] = t.y; o.a[p][ur][4 * q + 2] = t.z; o.a[p][ur][4 * q + 3] = t.w;
       } else {
-        const f32x2 t = *reinterpret_cast<const f32x2*>(yp_n + ur * OW + 2 * q);
-        a_n[ur][2 * q] = t.x; a_n[ur][2 * q + 1] = t.y;
+        const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yres, ylane + 8 * q, so, 0));
+        o.a[p][ur][2 * q] = t.x; o.a[p][ur][2 * q + 1] = t.y;
       }
     } else {
-      const int xr = (k - PA) / PBR, q = (k - PA) % PBR;
-      if (row_used(xr) && (unsigned)(rs_n + xr) < (unsigned)H) {
-        const float* src = xp_n + (int64_t)(rs_n + xr) * W;
-        if constexpr (VB == 4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * q);
-          b_n[xr][4 * q] = t.x; b_n[xr][4 * q + 1] = t.y; b_n[xr][4 * q + 2] = t.z; b_n[xr][4 * q + 3] = t.w;
-        } else {
-          const f32x2 t = *reinterpret_cast<const f32x2*>(src + 2 * q);
-          b_n[xr][2 * q] = t.x; b_n[xr][2 * q + 1] = t.y;
-        }
+      // the kk-th used source row
+      const int xr = wg_nth_used_row<KS, STRIDE, UR>((kk - PA) / PBR);
+      const int q = (kk - PA) % PBR;
+      const int row = min(max(un.rs + xr, 0), H - 1);
+      const unsigned so = un.xbase + (unsigned)p * xpair + (unsigned)(row * W * 4);
+      if constexpr (VB == 4) {
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, xlane + 16 * q, so, 0));
+        o.b[p][xr][4 * q] = t.x; o.b[p][xr][4 * q + 1] = t.y; o.b[p][xr][4 * q + 2] = t.z; o.b[p][xr][4 * q + 3] = t.w;
+      } else {
+        const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xres, xlane + 8 * q, so, 0));
+        o.b[p][xr][2 * q] = t.x; o.b[p][xr][2 * q + 1] = t.y;
       }
     }
   };
-  auto next_unit = [&](int uu) {                             // row / pointers of the unit whose pieces follow
-    const int pr = (int)fast_div((unsigned)uu, d.m_br);
-    const int r = (uu - pr * upr) * UR;
-    rs_n = r * STRIDE - PAD;                                 // source row of (output row 0, tap row 0)
-    yp_n = yl + (int64_t)pr * 2 * d.O * yplane + (int64_t)r * OW;
-    xp_n = xl + (int64_t)pr * 2 * d.C * xplane;
+  auto unit_of = [&](int uu) {                               // rows / offsets of unit uu
+    const int pg = (int)fast_div((unsigned)uu, d.m_br);
+    // a wave takes every fourth unit: without the rotation by the group index it would meet the same rows of every image --
+    // the waves with the image's first and last rows (a tap row less) idled 8 % (16 x 16 planes) to 16 % (8 x 8) of the
+    // workgroup at the cross-wave sum
+    int ri = uu - pg * upr + ((pg >> rsh) & rot);
+    ri -= ri >= upr ? upr : 0;
+    const int r = ri * UR;
+    WgUnit un;
+    un.rs = r * STRIDE - PAD;
+    un.ybase = (unsigned)pg * (unsigned)NP * ypair + (unsigned)(r * OW * 4);
+    un.xbase = (unsigned)pg * (unsigned)NP * xpair;
+    return un;
   };
-  if (u_lo + wave < u_hi) {
-    next_unit(u_lo + wave);
-#pragma unroll
-    for (int k = 0; k < NPIECE; k++) piece(k);
-  }
-  constexpr int NIT = UR * KS * OW;                          // (ur, i, s) iterations of a unit, <= KS MFMAs each
-  constexpr int STEP = NIT / NPIECE > 0 ? NIT / NPIECE : 1;
-  // affine source operand: a lane is a channel plane, so (scale, shift) are two registers of the lane; rows outside
-  // the image are never read by an MFMA (rowok), columns outside it do not exist in the code
+  // affine source operand: a lane is a channel plane, so (scale, shift) are two registers of the lane; applied to a row in
+  // place when the MFMAs first reach it (rows outside the image are never multiplied, columns outside it do not exist in
+  // the code)
   const bool affine = d.aff != nullptr;
   float aff_sc = 1.0f, aff_sh = 0.0f;
   if (affine) { aff_sc = d.aff[2 * (by * 32 + l31)]; aff_sh = d.aff[2 * (by * 32 + l31) + 1]; }
-  for (int u = u_lo + wave; u < u_hi; u += NW) {
-    float a[UR][OW], b[NXR][W];
-#pragma unroll
-    for (int ur = 0; ur < UR; ur++)
-#pragma unroll
-      for (int s = 0; s < OW; s++) a[ur][s] = a_n[ur][s];
-    if (affine) {
-#pragma unroll
-      for (int xr = 0; xr < NXR; xr++)
-#pragma unroll
-        for (int c = 0; c < W; c++) b[xr][c] = fmaf(b_n[xr][c], aff_sc, aff_sh);
-    } else {
-#pragma unroll
-      for (int xr = 0; xr < NXR; xr++)
-#pragma unroll
-        for (int c = 0; c < W; c++) b[xr][c] = b_n[xr][c];
-    }
-    const int rs = rs_n;
-    const bool more = u + NW < u_hi;
-    if (more) next_unit(u + NW);
-    // small planes (W <= 4): the lanes' rows share cache lines, a burst is cheap and schedules better
-    constexpr bool SPREAD = W >= 8;
-    if (!SPREAD && more) {
-#pragma unroll
-      for (int k = 0; k < NPIECE; k++) piece(k);
-    }
+  constexpr int NIT = NP * UR * KS * OW;                     // (pair, ur, i, s) iterations of a unit, <= KS MFMAs each
+  // MFMAs of the unit in `c` (rows from cu.rs), the pieces of unit `nu` into `n` on the way
+  auto compute = [&](Ops& c, const WgUnit& cu, Ops& n, const WgUnit& nu) {
 #ifdef DFHIP_STAMPS
     const unsigned long long tq1 = __builtin_readcyclecounter();
+    if (!dbg_first) dbg_first = tq1;
 #endif
 #pragma unroll
-    for (int ur = 0; ur < UR; ur++) {
+    for (int p = 0; p < NP; p++) {
 #pragma unroll
-      for (int i = 0; i < KS; i++) {
-        const bool rowok = (unsigned)(rs + ur * STRIDE + i) < (unsigned)H;
+      for (int ur = 0; ur < UR; ur++) {
 #pragma unroll
-        for (int s = 0; s < OW; s++) {
-          const int it = (ur * KS + i) * OW + s;
-          if (SPREAD && it % STEP == 0 && it / STEP < NPIECE) {
-            if (more) piece(it / STEP);                      // one operand piece of the next unit
-            __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < KS; i++) {
+          // (a scalar branch per tap row even where the unit is the whole plane and the answer is known at compile time: as one
+          // basic block the unit of a 2 x 2 plane took 50 600 cycles per workgroup against 44 700 -- same box, -DDFHIP_STAMPS)
+          const bool rowok = (unsigned)(cu.rs + ur * STRIDE + i) < (unsigned)H;
+          if (affine && (ur == 0 || i + STRIDE >= KS)) {     // first use of source row ur * STRIDE + i
+#pragma unroll
+            for (int cc = 0; cc < W; cc++) c.b[p][ur * STRIDE + i][cc] = fmaf(c.b[p][ur * STRIDE + i][cc], aff_sc, aff_sh);
           }
-          if (rowok) {
 #pragma unroll
-            for (int j = 0; j < KS; j++) {
-              const int col = s * STRIDE + j - PAD;
-              if (col >= 0 && col < W)
-                acc[i * KS + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                    a[ur][s], b[ur * STRIDE + i][col >= 0 && col < W ? col : 0], acc[i * KS + j], 0, 0, 0);
+          for (int s = 0; s < OW; s++) {
+            const int it = ((p * UR + ur) * KS + i) * OW + s;
+            // pieces k with floor(k * NIT / NPIECE) == it
+#pragma unroll
+            for (int k = (it * NPIECE + NIT - 1) / NIT; k < ((it + 1) * NPIECE + NIT - 1) / NIT; k++) piece(n, nu, k);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rowok) {
+#pragma unroll
+              for (int j = 0; j < KS; j++) {
+                const int col = s * STRIDE + j - PAD;
+                if (col >= 0 && col < W)
+                  acc[i * KS + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                      c.a[p][ur][s], c.b[p][ur * STRIDE + i][col >= 0 && col < W ? col : 0], acc[i * KS + j], 0, 0, 0);
+              }
             }
           }
         }
       }
     }
-    if (SPREAD && more) {                                    // pieces that did not get a slot (NPIECE > NIT)
-#pragma unroll
-      for (int k = (NIT + STEP - 1) / STEP; k < NPIECE; k++) piece(k);
-    }
 #ifdef DFHIP_STAMPS
     const unsigned long long tq2 = __builtin_readcyclecounter();
     dbg_mfma += tq2 - tq1;
+    dbg_last = tq2;
 #endif
+  };
+  {
+    Ops s0, s1;
+    int u = u_lo + wave;
+    if (u < u_hi) {
+      WgUnit u0 = unit_of(u), u1;
+#pragma unroll
+      for (int k = 0; k < NPIECE; k++) piece(s0, u0, k);
+      while (true) {
+        u1 = unit_of(min(u + NW, u_hi - 1));
+        compute(s0, u0, s1, u1);
+        u += NW;
+        if (u >= u_hi) break;
+        u0 = unit_of(min(u + NW, u_hi - 1));
+        compute(s1, u1, s0, u0);
+        u += NW;
+        if (u >= u_hi) break;
+      }
+    }
   }
 #ifdef DFHIP_STAMPS
-  if (d.dbg && tid == 0) { d.dbg[2 * blockIdx.x] = dbg_issue; d.dbg[2 * blockIdx.x + 1] = dbg_mfma; }
+  // (prologue: entry .. first MFMA section; between: first .. last section minus the sections themselves)
+  if (d.dbg && tid == 0) { d.dbg[2 * blockIdx.x] = ((dbg_first - dbg_t0) << 32) | ((dbg_last - dbg_first) & 0xffffffffull); d.dbg[2 * blockIdx.x + 1] = dbg_mfma; }
 #endif
   // cross-wave sum through LDS, RR taps per round (as the staged body of a grouped launch)
   f32x4* red = reinterpret_cast<f32x4*>(smem);
@@ -3566,10 +3611,12 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
   }
 }
 
+// (id, kernel, pad, stride, W, OW, output rows per unit, image pairs per unit of the direct body: units of few MFMAs are
+// bound by the latency of their loads and by the hand-over between units, so small planes take several pairs)
 #define DF_ROWS_KINDS(X) \
-  X(0, 3, 1, 1, 16, 16, 1) X(1, 3, 1, 1, 8, 8, 2) X(2, 3, 1, 1, 4, 4, 4) X(3, 3, 1, 1, 2, 2, 2)      \
-  X(4, 3, 1, 2, 16, 8, 1) X(5, 3, 1, 2, 8, 4, 2) X(6, 3, 1, 2, 4, 2, 2)                              \
-  X(7, 1, 0, 2, 16, 8, 1) X(8, 1, 0, 2, 8, 4, 1) X(9, 1, 0, 2, 4, 2, 1)
+  X(0, 3, 1, 1, 16, 16, 1, 1) X(1, 3, 1, 1, 8, 8, 2, 1) X(2, 3, 1, 1, 4, 4, 4, 1) X(3, 3, 1, 1, 2, 2, 2, 4)      \
+  X(4, 3, 1, 2, 16, 8, 1, 1) X(5, 3, 1, 2, 8, 4, 2, 1) X(6, 3, 1, 2, 4, 2, 2, 2)                              \
+  X(7, 1, 0, 2, 16, 8, 1, 4) X(8, 1, 0, 2, 8, 4, 1, 8) X(9, 1, 0, 2, 4, 2, 1, 8)
 
 // (one wave per SIMD, like the stand-alone kernel: the row-unit body needs ~470 registers, and built
 // for two resident workgroups -- 256 registers -- it spills 120-210 of them)
@@ -3595,9 +3642,9 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
   g.stamps = nullptr;
   g.single = d.single;
   switch (d.kind) {
-#define DF_CASE(ID, KSV, PADV, SV, WV, OWV, URV)                                                   \
+#define DF_CASE(ID, KSV, PADV, SV, WV, OWV, URV, NPV)                                              \
   case ID:                                                                                         \
-    if (d.direct) wgrad_rows_direct<KSV, PADV, SV, WV, OWV, URV>(d, smem, bx, by, bz);            \
+    if (d.direct) wgrad_rows_direct<KSV, PADV, SV, WV, OWV, URV, NPV>(d, smem, bx, by, bz);       \
     else wgrad_rows_body<KSV, PADV, SV, WV, OWV, URV, true>(g, smem, bx, by, bz, d.ps, d.CT, d.OT); \
     break;
     DF_ROWS_KINDS(DF_CASE)
@@ -4398,6 +4445,7 @@ struct GQueued {
   int T;
   size_t lds;
   double flops, bytes;
+  double work;                   // estimated cycles of one of its workgroups (set by group_flush)
   int W, ow, k, stride, pad;     // the rest of the call's arguments (a small group is re-planned as stand-alone launches)
 };
 std::vector<GQueued> g_queue;
@@ -4420,15 +4468,40 @@ std::vector<hipEvent_t> g_side_events;            // recycled join events
 hipStream_t g_group_stream = nullptr;             // stream the group kernels go to (nullptr: the library stream)
 float* g_group_slabs = nullptr;                   // slab area supplied by the side flush (nullptr: scratch slot 0)
 
+// Workgroup length of a grouped layer (operands from global memory).  The body runs one workgroup per CU (470 registers), so
+// the launch ends when the CU with the longest queue does: a layer is cut so that a workgroup is about `target` cycles of
+// its executed MFMAs (64 issue cycles each, four waves) -- long enough that the ~12 000 cycles around the MFMA stream (first
+// operands, cross-wave sum, slab stores) stay small, short enough that the longest workgroup is a fraction of the launch
+// (with the 256 / (tiles * 16) rule the 64-channel layers ran 400 000-cycle workgroups: the whole launch).
+static double replan_direct(GQueued& e, int target) {
+  GDesc& d = e.d;
+  int UR = 1, NP = 1;
+  switch (d.kind) {
+#define DF_UR(ID, KSV, PADV, SV, WV, OWV, URV, NPV) case ID: UR = URV; NP = NPV; break;
+    DF_ROWS_KINDS(DF_UR)
+#undef DF_UR
+    default: break;
+  }
+  // cycles of a wave per unit, measured with the in-kernel counters (-DDFHIP_STAMPS, DFHIP_CONV_STAMP=1; batch 256): the
+  // MFMA issue slots of the unit plus what its operand loads and hand-over cost -- units of few MFMAs (1x1 kernels, 2 x 2
+  // planes) are bound by the latency of their loads, not by their MFMA count
+  static const double kUnitCycles[10] = {9260, 8720, 7640, 5560, 4780, 4680, 4490, 9400, 7200, 2840};
+  const int upr = d.oh / UR, U = (d.N / (2 * NP)) * upr;
+  const double unit_cycles = d.kind >= 0 && d.kind < 10 ? kUnitCycles[d.kind] : 5000.0;
+  if (target > 0) {
+    const double per_wave = std::max(1.0, (target - 14000.0) / unit_cycles);
+    const int want = 4 * (int)std::max(1.0, std::floor(per_wave + 0.5));
+    const int ps = std::max(1, (int)std::floor((double)U / want + 0.5));
+    d.units = std::max(4, ((int)df_ceil_div(U, ps) + 3) & ~3);
+    d.ps = (int)df_ceil_div(U, d.units);
+  }
+  return d.units / 4 * unit_cycles + 14000.0;
+}
+
 int group_flush() {
   if (g_queue.empty()) return DFHIP_OK;
   std::vector<GQueued> q;
   q.swap(g_queue);                                  // (re-entrancy: scratch() may ask for a flush)
-  size_t total = 0, lds = 0;
-  for (auto& e : q) {
-    total += (size_t)e.d.ps * e.d.OT * e.d.CT * e.T * 1024 * sizeof(float);
-    lds = std::max(lds, e.lds);
-  }
   // A grouped layer is cut into 16x fewer, longer workgroups than a stand-alone launch (the other layers of the
   // sweep fill the chip).  A sweep that queued too little for that (the CNN workload: one eligible layer) would
   // leave most CUs idle: its layers are re-planned and launched stand-alone instead.  (A quarter of the chip: the
@@ -4453,6 +4526,13 @@ int group_flush() {
       return st < 0 ? DFHIP_RUNTIME_ERROR : st;
     }
   }
+  static int target = getenv("DFHIP_WGRAD_GROUP_CYCLES") ? atoi(getenv("DFHIP_WGRAD_GROUP_CYCLES")) : 0;
+  size_t total = 0, lds = 0;
+  for (auto& e : q) {
+    e.work = e.d.direct ? replan_direct(e, target) : (double)e.d.N * e.d.oh * e.d.oh * e.T / e.d.ps * 16.0;
+    total += (size_t)e.d.ps * e.d.OT * e.d.CT * e.T * 1024 * sizeof(float);
+    lds = std::max(lds, e.lds);
+  }
   hipStream_t gst = g_group_stream ? g_group_stream : stream();
   float* base = nullptr;
   if (g_group_stream) {
@@ -4464,10 +4544,7 @@ int group_flush() {
   }
   if (!base) return DFHIP_OUT_OF_MEMORY;
   // longest workgroups first (they are dispatched in grid order): the launch ends on short ones
-  std::stable_sort(q.begin(), q.end(), [](const GQueued& a, const GQueued& b) {
-    auto work = [](const GQueued& e) { return (double)e.d.N * e.d.oh * e.d.oh * e.T / e.d.ps; };
-    return work(a) > work(b);
-  });
+  std::stable_sort(q.begin(), q.end(), [](const GQueued& a, const GQueued& b) { return a.work > b.work; });
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     DF_HIP(hipFuncSetAttribute((const void*)k_wgrad_group, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -4525,6 +4602,21 @@ int group_flush() {
       for (auto v : h) { mx = std::max(mx, v); sum += (double)v; }
       for (int i = 0; i < wgs; i++) { si += (double)hd[2 * i]; sm += (double)hd[2 * i + 1]; }
       fprintf(stderr, "[stampg]   wave 0 of a workgroup: load issue %.0f, MFMA sections %.0f cycles (mean)\n", si / wgs, sm / wgs);
+      for (int i = 0, b0 = 0; i < n; i++) {                   // per layer: where the workgroups' cycles go
+        const GDesc& dd = wg.d[i];
+        double tc = 0, tm = 0;
+        unsigned long long lmx = 0;
+        double tp = 0, tspan = 0;
+        for (int b = b0; b < dd.wg_end; b++) {
+          tc += (double)h[b]; tm += (double)hd[2 * b + 1]; lmx = std::max(lmx, h[b]);
+          tp += (double)(hd[2 * b] >> 32); tspan += (double)(hd[2 * b] & 0xffffffffull);
+        }
+        const int cnt = dd.wg_end - b0;
+        fprintf(stderr, "[stampg]   layer %2d kind %d direct %d C %3d O %3d H %2d: %4d workgroups (ps %d), cycles mean %.0f max %llu, "
+                "MFMA sections %.0f, prologue %.0f, first..last section %.0f, after %.0f; share of all cycles %.3f\n", i, dd.kind, dd.direct,
+                dd.C, dd.O, dd.H, cnt, dd.ps, tc / cnt, lmx, tm / cnt, tp / cnt, tspan / cnt, (tc - tp - tspan) / cnt, tc / sum);
+        b0 = dd.wg_end;
+      }
       fprintf(stderr, "[stampg] %d workgroups, launch %.1f us; cycles per workgroup: mean %.0f max %llu -> >= %.2f GHz if the longest one spans the launch\n",
               wgs, ms * 1e3, sum / wgs, mx, (double)mx / (ms * 1e3) * 1e-3);
       (void)hipEventDestroy(se0); (void)hipEventDestroy(se1);
@@ -4646,9 +4738,9 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
   g.m_di = magic_u32((unsigned)B4);
   const int ps = std::max(1, std::min(g.ngroups, ps0));
   if (grouped) {
-    int kind = -1;
-#define DF_KIND(ID, KSV, PADV, SV, WV, OWV, URV) \
-  if (k == KSV && stride == SV && W == WV && UR == URV) kind = ID;
+    int kind = -1, NPk = 1;
+#define DF_KIND(ID, KSV, PADV, SV, WV, OWV, URV, NPV) \
+  if (k == KSV && stride == SV && W == WV && UR == URV) { kind = ID; NPk = NPV; }
     DF_ROWS_KINDS(DF_KIND)
 #undef DF_KIND
     if (kind < 0) return -1;
@@ -4662,11 +4754,12 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
     d.single = g.single; d.kind = kind; d.ps = ps; d.CT = CT; d.OT = OT;
     e.dw = dw; e.T = k * k; e.lds = best_lds;
     static int direct_on = getenv("DFHIP_WGRAD_DIRECT") ? atoi(getenv("DFHIP_WGRAD_DIRECT")) : 1;
-    if (aff && !(direct_on && C % 32 == 0 && O % 32 == 0)) return -1;
+    const bool direct = direct_on && C % 32 == 0 && O % 32 == 0 && (N / 2) % NPk == 0;
+    if (aff && !direct) return -1;
     d.aff = aff;
-    if (direct_on && C % 32 == 0 && O % 32 == 0) {
+    if (direct) {
       // operands straight from global memory: a block takes a contiguous run of units (a multiple of 4)
-      const int upr = oh / UR, U = (N / 2) * upr;
+      const int upr = oh / UR, U = (N / (2 * NPk)) * upr;
       int upb = (int)df_ceil_div(U, ps0);
       upb = std::max(4, (upb + 3) & ~3);
       d.direct = 1;
@@ -4683,7 +4776,7 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
     if (side_every > 0 && (int)g_queue.size() >= side_every && !profiling()) return side_flush();
     return DFHIP_OK;
   }
-#define DF_ROWS(ID, KSV, PADV, SV, WV, OWV, URV) \
+#define DF_ROWS(ID, KSV, PADV, SV, WV, OWV, URV, NPV) \
   if (k == KSV && stride == SV && W == WV && UR == URV)  \
     return launch_wgrad_rows<KSV, PADV, SV, WV, OWV, URV>(g, dw, best_lds, ps, CT, OT);
   DF_ROWS_KINDS(DF_ROWS)
