@@ -3344,6 +3344,8 @@ struct GDesc {
   int single, kind, ps, CT, OT;
   int wg_end;                // workgroups of layers 0..this one (exclusive end of this layer's range)
   int direct;                // operands straight from global memory (units = units per block, m_br = magic(oh / UR))
+  const float* dy2;          // direct, 3x3 / stride 2 only, or nullptr: dY of the block's 1x1 shortcut, whose weight
+  float* slabs2;             //   gradient this layer's workgroups compute too (group_flush pairs the two queue entries)
   const float* aff;          // direct only, or nullptr: C x (scale, shift), the source operand is x * scale + shift
                              // (the BatchNorm a convolution applied to its input on load: dfhip_conv2d_forward_bn_input)
   unsigned long long* dbg;   // diagnostic builds: per-workgroup cycles (load issue, MFMA section) of wave 0
@@ -3408,9 +3410,10 @@ constexpr int wg_nth_used_row(int n) {
     if (wg_row_used<KS, STRIDE, UR>(xr) && n-- == 0) return xr;
   return 0;
 }
-template <int NP, int UR, int OW, int NXR, int W>
+template <int NP, int UR, int OW, int NXR, int W, bool PAIR>
 struct WgOps {
   float a[NP][UR][OW];
+  float a2[PAIR ? NP : 1][PAIR ? UR : 1][PAIR ? OW : 1];    // PAIR: dY of the block's 1x1 shortcut (see wgrad_rows_direct)
   float b[NP][NXR][W];
 };
 struct WgUnit {
@@ -3419,9 +3422,14 @@ struct WgUnit {
   unsigned xbase;
 };
 
-template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP>
+// PAIR (3x3 / stride 2 only): the weight gradient of the block's 1x1 / stride-2 shortcut rides along.  The shortcut reads the
+// pixels of the centre tap, so its gradient is one more accumulator fed by the same source operand and the shortcut's own dY
+// (d.dy2, same shape as dY): the 1x1 layers stop being launches of their own kind -- units of 2-8 MFMAs per image pair, bound
+// by their loads (5.5 % of the grouped launch's cycles for 0.7 % of its MFMAs).
+template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP, bool PAIR>
 __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, const int bx, const int by,
                                                   const int bz) {
+  static_assert(!PAIR || (KS == 3 && STRIDE == 2 && PAD == 1), "the shortcut rides on the 3x3 / stride-2 body");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   constexpr int T = KS * KS, NW = kRowsWaves;
@@ -3440,15 +3448,19 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
   // from piece to piece is the same for the whole wave (the scalar offset) -- no vector instruction per load
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t y2res =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PAIR ? d.dy2 : d.dy), 0, 0x7fffffff, 0x00020000);
   const int xlane = ((half * d.C + by * 32 + l31) * xplane) * 4;
   const int ylane = ((half * d.O + bz * 32 + l31) * yplane) * 4;
   const unsigned xpair = (unsigned)(2 * d.C * xplane) * 4u, ypair = (unsigned)(2 * d.O * yplane) * 4u;
 
-  f32x16 acc[T];
+  f32x16 acc[T], acc2;
 #pragma unroll
   for (int t = 0; t < T; t++)
 #pragma unroll
     for (int rr = 0; rr < 16; rr++) acc[t][rr] = 0.0f;
+#pragma unroll
+  for (int rr = 0; rr < 16; rr++) acc2[rr] = 0.0f;
 
 #ifdef DFHIP_STAMPS
   unsigned long long dbg_issue = 0, dbg_mfma = 0;
@@ -3464,9 +3476,10 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
   constexpr int VA = OW % 4 == 0 ? 4 : 2, VB = W % 4 == 0 ? 4 : 2;
   constexpr int PA = UR * (OW / VA), PBR = W / VB;
   constexpr int NUSED = wg_used_rows<KS, STRIDE, UR>();
-  constexpr int PPP = PA + NUSED * PBR;                     // pieces per pair
+  constexpr int PA2 = PAIR ? 2 * PA : PA;                   // (PAIR: the shortcut's dY rows follow the convolution's)
+  constexpr int PPP = PA2 + NUSED * PBR;                    // pieces per pair
   constexpr int NPIECE = NP * PPP;
-  typedef WgOps<NP, UR, OW, NXR, W> Ops;
+  typedef WgOps<NP, UR, OW, NXR, W, PAIR> Ops;
   auto piece = [&](Ops& o, const WgUnit& un, int k) {      // k is a compile-time constant at every call
     const int p = k / PPP, kk = k % PPP;
     if (kk < PA) {
@@ -3479,10 +3492,20 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
         const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yres, ylane + 8 * q, so, 0));
         o.a[p][ur][2 * q] = t.x; o.a[p][ur][2 * q + 1] = t.y;
       }
+    } else if (PAIR && kk < PA2) {
+      const int k2 = kk - PA, ur = k2 / (OW / VA), q = k2 % (OW / VA);
+      const unsigned so = un.ybase + (unsigned)p * ypair + (unsigned)(ur * OW * 4);
+      if constexpr (VA == 4) {
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(y2res, ylane + 16 * q, so, 0));
+        o.a2[p][ur][4 * q] = t.x; o.a2[p][ur][4 * q + 1] = t.y; o.a2[p][ur][4 * q + 2] = t.z; o.a2[p][ur][4 * q + 3] = t.w;
+      } else {
+        const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(y2res, ylane + 8 * q, so, 0));
+        o.a2[p][ur][2 * q] = t.x; o.a2[p][ur][2 * q + 1] = t.y;
+      }
     } else {
       // the kk-th used source row
-      const int xr = wg_nth_used_row<KS, STRIDE, UR>((kk - PA) / PBR);
-      const int q = (kk - PA) % PBR;
+      const int xr = wg_nth_used_row<KS, STRIDE, UR>((kk - PA2) / PBR);
+      const int q = (kk - PA2) % PBR;
       const int row = min(max(un.rs + xr, 0), H - 1);
       const unsigned so = un.xbase + (unsigned)p * xpair + (unsigned)(row * W * 4);
       if constexpr (VB == 4) {
@@ -3549,6 +3572,10 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
                   acc[i * KS + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                       c.a[p][ur][s], c.b[p][ur * STRIDE + i][col >= 0 && col < W ? col : 0], acc[i * KS + j], 0, 0, 0);
               }
+              if constexpr (PAIR) {                          // the centre tap's pixel (row 2 (r + ur), column 2 s: always inside)
+                if (i == 1)
+                  acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a2[p][ur][s], c.b[p][ur * STRIDE + 1][2 * s], acc2, 0, 0, 0);
+              }
             }
           }
         }
@@ -3609,6 +3636,31 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
       *reinterpret_cast<f32x4*>(slab + (int64_t)t * 1024 + (q * 64 + lane) * 4) = v;
     }
   }
+  if constexpr (PAIR) {                                      // the shortcut's tile: one more round
+    float* slab2 = d.slabs2 + (((int64_t)bx * d.OT + bz) * d.CT + by) * 1024;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      red[(wave * 4 + q) * 64 + lane] = (f32x4){acc2[4 * q], acc2[4 * q + 1], acc2[4 * q + 2], acc2[4 * q + 3]};
+    __syncthreads();
+    f32x4 v = red[(0 * 4 + wave) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < NW; w++) {
+      const f32x4 uu = red[(w * 4 + wave) * 64 + lane];
+      v.x += uu.x; v.y += uu.y; v.z += uu.z; v.w += uu.w;
+    }
+    *reinterpret_cast<f32x4*>(slab2 + (wave * 64 + lane) * 4) = v;
+  }
+}
+
+template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP>
+__device__ __forceinline__ void wgrad_direct_any(const GDesc& d, float* smem, const int bx, const int by, const int bz) {
+  if constexpr (KS == 3 && STRIDE == 2) {
+    if (d.dy2) wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, true>(d, smem, bx, by, bz);
+    else wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, false>(d, smem, bx, by, bz);
+  } else {
+    wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, false>(d, smem, bx, by, bz);
+  }
 }
 
 // (id, kernel, pad, stride, W, OW, output rows per unit, image pairs per unit of the direct body: units of few MFMAs are
@@ -3625,6 +3677,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
   const int b = blockIdx.x;
 #ifdef DFHIP_STAMPS
   const unsigned long long t_begin = __builtin_readcyclecounter();
+  const unsigned long long r_begin = wall_clock64();          // (constant 100 MHz: the clock the cycles ran at, CU occupancy)
 #endif
   int li = 0;
   while (li + 1 < a.n && b >= a.d[li].wg_end) li++;
@@ -3644,7 +3697,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
   switch (d.kind) {
 #define DF_CASE(ID, KSV, PADV, SV, WV, OWV, URV, NPV)                                              \
   case ID:                                                                                         \
-    if (d.direct) wgrad_rows_direct<KSV, PADV, SV, WV, OWV, URV, NPV>(d, smem, bx, by, bz);       \
+    if (d.direct) wgrad_direct_any<KSV, PADV, SV, WV, OWV, URV, NPV>(d, smem, bx, by, bz);        \
     else wgrad_rows_body<KSV, PADV, SV, WV, OWV, URV, true>(g, smem, bx, by, bz, d.ps, d.CT, d.OT); \
     break;
     DF_ROWS_KINDS(DF_CASE)
@@ -3652,7 +3705,11 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
     default: break;
   }
 #ifdef DFHIP_STAMPS
-  if (a.ticks && threadIdx.x == 0) a.ticks[b] = __builtin_readcyclecounter() - t_begin;
+  if (a.ticks && threadIdx.x == 0) {
+    a.ticks[b] = __builtin_readcyclecounter() - t_begin;
+    a.ticks[3 * (size_t)gridDim.x + b] = r_begin;
+    a.ticks[4 * (size_t)gridDim.x + b] = wall_clock64();
+  }
 #endif
 }
 
@@ -4446,6 +4503,7 @@ struct GQueued {
   size_t lds;
   double flops, bytes;
   double work;                   // estimated cycles of one of its workgroups (set by group_flush)
+  int rides_on;                  // -1, or the queue index of the 3x3 / stride-2 layer whose workgroups compute this 1x1 shortcut too
   int W, ow, k, stride, pad;     // the rest of the call's arguments (a small group is re-planned as stand-alone launches)
 };
 std::vector<GQueued> g_queue;
@@ -4527,9 +4585,36 @@ int group_flush() {
     }
   }
   static int target = getenv("DFHIP_WGRAD_GROUP_CYCLES") ? atoi(getenv("DFHIP_WGRAD_GROUP_CYCLES")) : 0;
-  size_t total = 0, lds = 0;
   for (auto& e : q) {
     e.work = e.d.direct ? replan_direct(e, target) : (double)e.d.N * e.d.oh * e.d.oh * e.T / e.d.ps * 16.0;
+    e.rides_on = -1;
+    e.d.dy2 = nullptr; e.d.slabs2 = nullptr;
+  }
+  // longest workgroups first (they are dispatched in grid order): the launch ends on short ones
+  std::stable_sort(q.begin(), q.end(), [](const GQueued& a, const GQueued& b) { return a.work > b.work; });
+  // a block's 1x1 / stride-2 shortcut reads the same tensor as its 3x3 / stride-2 convolution: the shortcut's weight gradient
+  // rides on that layer's workgroups (wgrad_rows_direct<PAIR>) -- it keeps its slabs (one per workgroup of the host layer) and
+  // its entry in the slab sum, and has no workgroups of its own
+  static int pair_on = getenv("DFHIP_WGRAD_PAIR") ? atoi(getenv("DFHIP_WGRAD_PAIR")) : 1;
+  if (pair_on && q.size() <= (size_t)kMaxGroup) {
+    for (size_t b = 0; b < q.size(); b++) {
+      GQueued& sc = q[b];
+      if (!(sc.d.direct && sc.k == 1 && sc.stride == 2 && !sc.d.aff)) continue;
+      for (size_t a = 0; a < q.size(); a++) {
+        GQueued& cv = q[a];
+        if (cv.d.direct && cv.k == 3 && cv.stride == 2 && cv.pad == 1 && !cv.d.aff && !cv.d.dy2 && cv.d.x == sc.d.x &&
+            cv.d.N == sc.d.N && cv.d.C == sc.d.C && cv.d.H == sc.d.H && cv.W == sc.W && cv.d.O == sc.d.O &&
+            cv.d.oh == sc.d.oh && cv.ow == sc.ow) {
+          sc.rides_on = (int)a;
+          sc.d.ps = cv.d.ps;
+          cv.d.dy2 = sc.d.dy;
+          break;
+        }
+      }
+    }
+  }
+  size_t total = 0, lds = 0;
+  for (auto& e : q) {
     total += (size_t)e.d.ps * e.d.OT * e.d.CT * e.T * 1024 * sizeof(float);
     lds = std::max(lds, e.lds);
   }
@@ -4543,8 +4628,6 @@ int group_flush() {
     base = workspace_slot(0, total);
   }
   if (!base) return DFHIP_OUT_OF_MEMORY;
-  // longest workgroups first (they are dispatched in grid order): the launch ends on short ones
-  std::stable_sort(q.begin(), q.end(), [](const GQueued& a, const GQueued& b) { return a.work > b.work; });
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     DF_HIP(hipFuncSetAttribute((const void*)k_wgrad_group, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -4555,16 +4638,25 @@ int group_flush() {
     const int n = (int)std::min<size_t>(kMaxGroup, q.size() - i0);
     WGroup wg = {};
     SGroup sg = {};
-    wg.n = sg.n = n;
-    int wgs = 0, vbs = 0;
+    sg.n = n;
+    int wgs = 0, vbs = 0, nl = 0;
     double flops = 0, bytes = 0, sbytes = 0;
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n; i++) {                             // slab areas first: a host layer needs its rider's
       GQueued& e = q[i0 + i];
       e.d.slabs = base;
       base += (size_t)e.d.ps * e.d.OT * e.d.CT * e.T * 1024;
-      wgs += e.d.ps * e.d.CT * e.d.OT;
-      e.d.wg_end = wgs;
-      wg.d[i] = e.d;
+    }
+    for (int i = 0; i < n; i++) {
+      GQueued& e = q[i0 + i];
+      if (e.rides_on >= 0) q[e.rides_on].d.slabs2 = e.d.slabs;
+    }
+    for (int i = 0; i < n; i++) {
+      GQueued& e = q[i0 + i];
+      if (e.rides_on < 0) {
+        wgs += e.d.ps * e.d.CT * e.d.OT;
+        e.d.wg_end = wgs;
+        wg.d[nl++] = e.d;
+      }
       sg.s[i] = make_slab_sum(e.d.slabs, e.dw, e.d.ps, e.d.OT, e.d.CT, e.T, e.d.O, e.d.C);
       // tap-major items: (tile, q, lane) positions, 256 / SL of them per block
       sg.s[i].SL = 1;
@@ -4575,13 +4667,14 @@ int group_flush() {
       flops += e.flops; bytes += e.bytes;
       sbytes += (double)(e.d.ps + 1) * e.d.OT * e.d.CT * e.T * 4096.0;
     }
+    wg.n = nl;
     static int stamp_mode = -1;
     if (stamp_mode < 0) stamp_mode = getenv("DFHIP_CONV_STAMP") ? atoi(getenv("DFHIP_CONV_STAMP")) : 0;
     hipEvent_t se0 = nullptr, se1 = nullptr;
     if (stamp_mode) {
-      wg.ticks = (unsigned long long*)workspace2((size_t)wgs * 8 * 3);
-      (void)hipMemsetAsync(wg.ticks, 0, (size_t)wgs * 8 * 3, gst);
-      for (int i = 0; i < n; i++) wg.d[i].dbg = wg.ticks + wgs;
+      wg.ticks = (unsigned long long*)workspace2((size_t)wgs * 8 * 5);
+      (void)hipMemsetAsync(wg.ticks, 0, (size_t)wgs * 8 * 5, gst);
+      for (int i = 0; i < nl; i++) wg.d[i].dbg = wg.ticks + wgs;
       (void)hipEventCreate(&se0); (void)hipEventCreate(&se1);
       (void)hipEventRecord(se0, gst);
     }
@@ -4600,9 +4693,37 @@ int group_flush() {
       (void)hipMemcpy(hd.data(), wg.ticks + wgs, (size_t)wgs * 16, hipMemcpyDeviceToHost);
       unsigned long long mx = 0; double sum = 0, si = 0, sm = 0;
       for (auto v : h) { mx = std::max(mx, v); sum += (double)v; }
+      {
+        std::vector<unsigned long long> rt(2 * (size_t)wgs);
+        (void)hipMemcpy(rt.data(), wg.ticks + 3 * (size_t)wgs, (size_t)wgs * 16, hipMemcpyDeviceToHost);
+        unsigned long long r0 = ~0ull, r1 = 0;
+        double res = 0, ghz_lo = 1e9, ghz_hi = 0;
+        for (int b = 0; b < wgs; b++) {
+          r0 = std::min(r0, rt[b]); r1 = std::max(r1, rt[wgs + b]);
+          const double dt = (double)(rt[wgs + b] - rt[b]) * 10.0;          // ns
+          res += dt;
+          if (dt > 0) { const double g = (double)h[b] / dt; ghz_lo = std::min(ghz_lo, g); ghz_hi = std::max(ghz_hi, g); }
+        }
+        const double span = (double)(r1 - r0) * 10.0;
+        fprintf(stderr, "[stampg]   first start .. last end %.1f us; workgroups resident %.1f CU-us = %.3f of %d CUs x span; clock of a "
+                "workgroup %.2f-%.2f GHz (mean %.2f)\n", span * 1e-3, res * 1e-3, res / (span * num_cus()), num_cus(), ghz_lo, ghz_hi,
+                sum / res);
+        // how many workgroups are resident over time (20 slices of the span)
+        fprintf(stderr, "[stampg]   resident workgroups per twentieth of the span:");
+        for (int sl = 0; sl < 20; sl++) {
+          const double t0 = (double)r0 + (double)(r1 - r0) * sl / 20.0, t1 = (double)r0 + (double)(r1 - r0) * (sl + 1) / 20.0;
+          double occ = 0;
+          for (int b = 0; b < wgs; b++) {
+            const double a0 = std::max(t0, (double)rt[b]), a1 = std::min(t1, (double)rt[wgs + b]);
+            if (a1 > a0) occ += (a1 - a0) / (t1 - t0);
+          }
+          fprintf(stderr, " %.0f", occ);
+        }
+        fprintf(stderr, "\n");
+      }
       for (int i = 0; i < wgs; i++) { si += (double)hd[2 * i]; sm += (double)hd[2 * i + 1]; }
       fprintf(stderr, "[stampg]   wave 0 of a workgroup: load issue %.0f, MFMA sections %.0f cycles (mean)\n", si / wgs, sm / wgs);
-      for (int i = 0, b0 = 0; i < n; i++) {                   // per layer: where the workgroups' cycles go
+      for (int i = 0, b0 = 0; i < nl; i++) {                  // per layer: where the workgroups' cycles go
         const GDesc& dd = wg.d[i];
         double tc = 0, tm = 0;
         unsigned long long lmx = 0;
