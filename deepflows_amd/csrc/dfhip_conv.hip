@@ -1761,7 +1761,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_fwd(const float* __restric
 // k-step on nine weight operands.  Sums through LDS, 16-byte stores (the four positions of a channel are adjacent),
 // BatchNorm partials over the 16 images x 4 positions of a channel.
 // ---------------------------------------------------------------------------------------
-template <int C>
+// DG (accumulate-mode input gradient of the same layer): x is dY (C = the convolution's output channels), w the convolution's
+// own [C][O][3][3] tensor -- a slice's records are then rows of 16 x 9 consecutive floats per contraction channel, stored with
+// the tap flipped (the gradient's tap of (source s, position q) is 8 - the forward's) -- and `bias` is the gradient the
+// tensor already holds, [N][O][2][2], added in the epilogue.
+template <int C, bool DG = false>
 __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           float* __restrict__ stats, int O, int xo) {
@@ -1785,8 +1789,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restric
     const int c0 = cb + 8 * ch;
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-      const int e = min(lane + 64 * i, 287), m = e / 18, j = e - 18 * m;
-      wq[i] = *reinterpret_cast<const f32x4*>(w + ((int64_t)(o0 + m) * C + c0) * 9 + 4 * j);
+      if constexpr (DG) {
+        const int e = min(lane + 64 * i, 287), oj = e / 36, j = e - 36 * oj;
+        wq[i] = *reinterpret_cast<const f32x4*>(w + ((int64_t)(c0 + oj) * O + o0) * 9 + 4 * j);
+      } else {
+        const int e = min(lane + 64 * i, 287), m = e / 18, j = e - 18 * m;
+        wq[i] = *reinterpret_cast<const f32x4*>(w + ((int64_t)(o0 + m) * C + c0) * 9 + 4 * j);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -1805,8 +1814,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restric
     for (int i = 0; i < 5; i++) {
       const int e = lane + 64 * i, m = min(e, 287) / 18, j = min(e, 287) - 18 * m;
       if (e < 288) {
+        if constexpr (DG) {
+          const int oj = min(e, 287) / 36, jj = min(e, 287) - 36 * oj;
 #pragma unroll
-        for (int t = 0; t < 4; t++) Wl[(4 * j + t) * WP + m] = wq[i][t];
+          for (int t = 0; t < 4; t++) {
+            const int f = 4 * jj + t, mo = f / 9, tap = f - 9 * mo;
+            Wl[(oj * 9 + 8 - tap) * WP + mo] = wq[i][t];
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; t++) Wl[(4 * j + t) * WP + m] = wq[i][t];
+        }
       }
     }
 #pragma unroll
@@ -1855,10 +1873,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restric
   // register v of lane (kk, n) is output channel o0 + 4 kk + v of image n0 + n; its four positions are adjacent
 #pragma unroll
   for (int v = 0; v < 4; v++) {
-    const float bv = bias ? bias[o0 + 4 * kk + v] : 0.0f;
-    f32x4 r = {acc[0][v] + bv, acc[1][v] + bv, acc[2][v] + bv, acc[3][v] + bv};
-    acc[0][v] = r[0]; acc[1][v] = r[1]; acc[2][v] = r[2]; acc[3][v] = r[3];
-    *reinterpret_cast<f32x4*>(y + ((int64_t)(n0 + n) * O + o0 + 4 * kk + v) * 4) = r;
+    if constexpr (DG) {
+      f32x4 r = {acc[0][v], acc[1][v], acc[2][v], acc[3][v]};
+      if (bias) r += *reinterpret_cast<const f32x4*>(bias + ((int64_t)(n0 + n) * O + o0 + 4 * kk + v) * 4);
+      *reinterpret_cast<f32x4*>(y + ((int64_t)(n0 + n) * O + o0 + 4 * kk + v) * 4) = r;
+    } else {
+      const float bv = bias ? bias[o0 + 4 * kk + v] : 0.0f;
+      f32x4 r = {acc[0][v] + bv, acc[1][v] + bv, acc[2][v] + bv, acc[3][v] + bv};
+      acc[0][v] = r[0]; acc[1][v] = r[1]; acc[2][v] = r[2]; acc[3][v] = r[3];
+      *reinterpret_cast<f32x4*>(y + ((int64_t)(n0 + n) * O + o0 + 4 * kk + v) * 4) = r;
+    }
   }
   if (stats) {
     // exact two-pass over the 64 values of a channel: the lane's four positions, then the 16 images of its DPP row
@@ -5303,6 +5327,18 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
     }
   }
   if (mode == 1) {
+    // 2 x 2 images: the forward's all-positions kernel with the roles of the channel counts swapped (k_conv3x3_img2_all<DG>)
+    static int img2dg = getenv("DFHIP_DGRAD_IMG2_ACC") ? atoi(getenv("DFHIP_DGRAD_IMG2_ACC")) : 1;
+    if (img2dg && k == 3 && stride == 1 && pad == 1 && H == 2 && W == 2 && N % 16 == 0 && C % 16 == 0 &&
+        (O == 128 || O == 256)) {
+      dim3 grid4((unsigned)(N / 16), (unsigned)(C / 16));
+      const size_t lds4 = std::max((size_t)8 * (72 * 17 + 16 * 9 * 4), (size_t)7 * 4 * 64 * 4) * sizeof(float);
+      const int xo = xcd_arrangement(N / 16, C / 16, 4.0 * N * O * 4, 4.0 * O * C * 9);
+      if (O == 128) DF_LAUNCH((k_conv3x3_img2_all<128, true>), grid4, dim3(512), lds4, stream(), dy, w, add, dx, (float*)nullptr, C, xo);
+      else DF_LAUNCH((k_conv3x3_img2_all<256, true>), grid4, dim3(512), lds4, stream(), dy, w, add, dx, (float*)nullptr, C, xo);
+      DF_LAUNCH_CHECK();
+      return DFHIP_OK;
+    }
     int st = run_conv_rowmma_dgrad(dy, w, add, dx, N, C, H, W, O, k, stride, pad);
     if (st >= 0) return st;
   }

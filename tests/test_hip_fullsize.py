@@ -244,12 +244,14 @@ def test_register_operand_forward_with_partials(hip_device, name, bias):
     assert_close(m2 / cnt, y64.var(axis=(0, 2, 3)), 1e-5, "partials variance")
 
 
-@pytest.mark.parametrize("name", ["l1", "l2", "l3"])
+@pytest.mark.parametrize("name", ["l1", "l2", "l3", "l4", "l4_128_to_256", "l4_256_to_128"])
 def test_register_operand_accumulate_dgrad_with_held_gradient(hip_device, name):
     """The mathematically correct input gradient of the 3x3 / stride 1 layers on the register-operand kernel (weights
-    transposed and flipped while they are staged), with and without the gradient the tensor already holds."""
+    transposed and flipped while they are staged; 2 x 2 images: the forward's all-positions kernel with the channel counts
+    swapped, also where they differ), with and without the gradient the tensor already holds."""
     mod = hip_device.mod
-    C, H, W, O, k, s, p = LAYERS[name]
+    C, H, W, O, k, s, p = {"l4_128_to_256": (128, 2, 2, 256, 3, 1, 1), "l4_256_to_128": (256, 2, 2, 128, 3, 1, 1)}.get(
+        name) or LAYERS[name]
     rng = np.random.default_rng(17)
     dy = rng.standard_normal((N, O, H, W)).astype(np.float32)
     w = (rng.standard_normal((O, C, k, k)) / np.sqrt(O * k * k)).astype(np.float32)
