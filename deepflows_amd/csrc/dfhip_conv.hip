@@ -5341,6 +5341,10 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
     }
     int st = run_conv_rowmma_dgrad(dy, w, add, dx, N, C, H, W, O, k, stride, pad);
     if (st >= 0) return st;
+    if (k == 3 && stride == 2 && pad == 1) {                 // one product per (pixel, tap) pair that exists
+      st = run_dgrad_s2_acc(dy, w, nullptr, nullptr, add, dx, N, C, H, W, O);
+      if (st >= 0) return st;
+    }
   }
   if (add) {
     g.addsrc = add;
@@ -5381,6 +5385,17 @@ int dfhip_conv2d_dgrad_pair(const float* dy, const float* w, const float* dy2, c
   static int pair_on = getenv("DFHIP_DGRAD_PAIR") ? atoi(getenv("DFHIP_DGRAD_PAIR")) : 1;
   int lw = 0;
   while ((1 << lw) < W) lw++;
+  if (pair_on && mode == 1) {
+    // accumulate mode: the stride-2 kernel that multiplies only the (pixel, tap) pairs that exist, shortcut included
+    double flopsa = 2.0 * N * oh * ow * (double)C * 10 * O;
+    double bytesa = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * oh * ow);
+    if (run_dgrad_s2_acc(dy, w, dy2, w2, add, dx, N, C, H, W, O, true) < 0) return DFHIP_OK;    // (shape test only)
+    ProfScope profa("conv2d_dgrad_igemm", flopsa, bytesa);
+    const int sta = run_dgrad_s2_acc(dy, w, dy2, w2, add, dx, N, C, H, W, O);
+    if (sta != DFHIP_OK) return sta < 0 ? DFHIP_RUNTIME_ERROR : sta;
+    *done = 1;
+    return DFHIP_OK;
+  }
   static int img4 = getenv("DFHIP_DGRAD_IMG4") ? atoi(getenv("DFHIP_DGRAD_IMG4")) : 1;
   if (lean && pair_on && img4 && mode == 0 && H == 4 && W == 4 && N % 16 == 0 && C % 16 == 0 && (O == 128 || O == 256)) {
     // 4 x 4 images (layer4's first block): the image-per-lane kernel with the shortcut as a fifth slice

@@ -530,9 +530,195 @@ __global__ __launch_bounds__(512) void k_conv3x3s2_img4_pair(const float* __rest
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Accumulate-mode input gradient of a 3x3 / stride 2 / pad 1 convolution (the mathematically complete sum, tensor.py:708 with
+// `+=` instead of the reference's `=`; DESIGN.md "Overwrite and accumulate"), optionally with the gradient of the block's 1x1 /
+// stride 2 shortcut in the same launch.  Input pixel (y, x) = (2u + ey, 2v + ex) receives from output pixel (u + du, v + dv)
+// through tap (ky, kx) only where y + 1 - ky is even: class (ey, ex) has (1 + ey)(1 + ex) taps -- ey = 0: ky = 1, du = 0;
+// ey = 1: (ky, du) = (0, 1) and (2, 0) -- i.e. 9 products per 4 pixels, where the implicit GEMM over the zero-stuffed dY
+// multiplies 36.  A tile is 32 pixels of ONE class (consecutive positions of the flattened (n, u, v) space: the lanes read a
+// dense run of dY), a workgroup stages only its class's weight slices, and the classes' workgroups are sized by their tap
+// counts.  32x32x2 MFMA as in k_dgrad_ow_s1: D[32 channels][32 pixels] += W[32][2 o] . dY[2 o][32].
+// SPLIT (O >= 128): the four waves of a workgroup share a tile and split o; their partial tiles meet in LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+struct S2Acc {
+  const float* dy; const float* w; const float* dy2; const float* w2; const float* add; float* dx;
+  int C, H, lw;              // dx is (N, C, H, H), H = 1 << lw
+  int tiles;                 // tiles of 32 pixels per class
+  int cls_end[4];            // blockIdx.x ranges of the classes, in the order 3 (four taps), 1, 2, 0
+};
+
+template <int O, bool SPLIT, bool PAIR, int EY, int EX>
+__device__ __forceinline__ void dgrad_s2_acc_class(const S2Acc& a, float* smem, const int slot, const int nslots) {
+  constexpr int NT = (1 + EY) * (1 + EX);                 // taps of the class
+  constexpr bool SC = PAIR && EY == 0 && EX == 0;         // the shortcut lands on the even-even pixels
+  constexpr int NSL = NT + (SC ? 1 : 0);
+  constexpr int OQ = SPLIT ? O / 4 : O, NP = OQ / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int C = a.C, H = a.H, W = a.H, low = a.lw - 1, oh = H >> 1, ow = W >> 1;
+  const int ohw = oh * ow;
+  const int c0 = blockIdx.y * 32;
+  float* Wl = smem;                                       // [NSL][O][32]
+  float* red = smem + NSL * O * 32;                       // SPLIT: [3][16][64]
+  // weight slices of this class: tap t = ty * (1 + EX) + tx; ty -> ky = EY ? 2 * ty : 1, du = EY ? 1 - ty : 0
+  {
+    // (twelve (o, c) pairs of a thread in flight: <= 48 loads, under the 63 the wait counter can tell apart)
+    constexpr int PAIRS = O * 32 / 256, PB = PAIRS < 12 ? PAIRS : (PAIRS % 12 == 0 ? 12 : 8);
+    static_assert(PAIRS % PB == 0, "weight staging rounds");
+    for (int i0 = 0; i0 < PAIRS; i0 += PB) {
+      float wv[PB][NSL];
+#pragma unroll
+      for (int i = 0; i < PB; i++) {
+        const int e = tid + 256 * (i0 + i), o = e >> 5, c = e & 31;
+        const float* q = a.w + ((int64_t)o * C + c0 + c) * 9;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const int ty = t / (1 + EX), tx = t % (1 + EX);
+          const int ky = EY ? 2 * ty : 1, kx = EX ? 2 * tx : 1;
+          wv[i][t] = q[ky * 3 + kx];
+        }
+        if constexpr (SC) wv[i][NT] = a.w2[(int64_t)o * C + c0 + c];
+      }
+#pragma unroll
+      for (int i = 0; i < PB; i++) {
+        const int e = tid + 256 * (i0 + i), o = e >> 5, c = e & 31;
+#pragma unroll
+        for (int t = 0; t < NSL; t++) Wl[(t * O + o) * 32 + c] = wv[i][t];
+      }
+    }
+  }
+  __syncthreads();
+  const int ob = SPLIT ? wave * OQ : 0;
+  const int first = SPLIT ? slot : slot * 4 + wave, step = SPLIT ? nslots : nslots * 4;
+  for (int tile = first; tile < a.tiles; tile += step) {
+    const int p = tile * 32 + l31;
+    const int n = p / ohw, rem = p - n * ohw, u = rem >> low, v = rem & (ow - 1);
+    // every operand of the tile is requested up front (unconditional loads at a clamped position, zeroed afterwards)
+    float sv[NSL][NP];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const int ty = t / (1 + EX), tx = t % (1 + EX);
+      const int du = EY ? 1 - ty : 0, dv = EX ? 1 - tx : 0;
+      const int su = min(u + du, oh - 1), sx = min(v + dv, ow - 1);
+      const float* sp = a.dy + ((int64_t)n * O + ob + half) * ohw + su * ow + sx;
+#pragma unroll
+      for (int kp = 0; kp < NP; kp++) sv[t][kp] = sp[(int64_t)(2 * kp) * ohw];
+    }
+    if constexpr (SC) {
+      const float* sp = a.dy2 + ((int64_t)n * O + ob + half) * ohw + u * ow + v;
+#pragma unroll
+      for (int kp = 0; kp < NP; kp++) sv[NT][kp] = sp[(int64_t)(2 * kp) * ohw];
+    }
+    const int y = 2 * u + EY, x = 2 * v + EX;
+    const int64_t obase = (((int64_t)n * C + c0) * H + y) * W + x;
+    const int64_t HW = (int64_t)H * W;
+    float held[16];
+    const bool stores = !SPLIT || wave == 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+      held[r] = (a.add && stores) ? a.add[obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW] : 0.0f;
+    f32x16s acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NSL; t++) {
+      bool inside = true;
+      if (t < NT) {
+        const int ty = t / (1 + EX), tx = t % (1 + EX);
+        const int du = EY ? 1 - ty : 0, dv = EX ? 1 - tx : 0;
+        inside = u + du < oh && v + dv < ow;
+      }
+      const float* wq = Wl + (t * O + ob + half) * 32 + l31;
+#pragma unroll
+      for (int kp = 0; kp < NP; kp++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[2 * kp * 32], inside ? sv[t][kp] : 0.0f, acc, 0, 0, 0);
+    }
+    if constexpr (SPLIT) {
+      if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int ww = 0; ww < 3; ww++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[r] += red[(ww * 16 + r) * 64 + lane];
+      }
+    }
+    if (stores) {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        a.dx[obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW] = acc[r] + held[r];
+    }
+    if constexpr (SPLIT) __syncthreads();               // the exchange area is free again
+  }
+}
+
+template <int O, bool SPLIT, bool PAIR>
+__global__ __launch_bounds__(256) void k_dgrad_s2_acc(S2Acc a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  if (b < a.cls_end[0]) dgrad_s2_acc_class<O, SPLIT, PAIR, 1, 1>(a, smem, b, a.cls_end[0]);
+  else if (b < a.cls_end[1]) dgrad_s2_acc_class<O, SPLIT, PAIR, 0, 1>(a, smem, b - a.cls_end[0], a.cls_end[1] - a.cls_end[0]);
+  else if (b < a.cls_end[2]) dgrad_s2_acc_class<O, SPLIT, PAIR, 1, 0>(a, smem, b - a.cls_end[1], a.cls_end[2] - a.cls_end[1]);
+  else dgrad_s2_acc_class<O, SPLIT, PAIR, 0, 0>(a, smem, b - a.cls_end[2], a.cls_end[3] - a.cls_end[2]);
+}
+
+template <int O, bool SPLIT, bool PAIR>
+int launch_dgrad_s2_acc(const S2Acc& a, int gx, int C) {
+  const size_t lds = ((size_t)4 * O * 32 + (SPLIT ? 3 * 16 * 64 : 0)) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_s2_acc<O, SPLIT, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)std::max(lds, (size_t)65536)));
+    attr = true;
+  }
+  DF_LAUNCH((k_dgrad_s2_acc<O, SPLIT, PAIR>), dim3((unsigned)gx, (unsigned)(C / 32)), dim3(256), lds, stream(), a);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
 }  // namespace
 
 namespace dfhip {
+
+// dx (N, C, H, H) = [add +] the complete (accumulate-mode) input gradient of conv3x3/s2/p1 from dy (N, O, H/2, H/2)
+// [+ that of the block's conv1x1/s2/p0 shortcut from dy2, w2]; -1 when the shape is not one this kernel takes
+int run_dgrad_s2_acc(const float* dy, const float* w, const float* dy2, const float* w2, const float* add, float* dx, int N,
+                     int C, int H, int W, int O, bool dry_run) {
+  static int enabled = getenv("DFHIP_DGRAD_S2_ACC") ? atoi(getenv("DFHIP_DGRAD_S2_ACC")) : 1;
+  if (!enabled || H != W || H < 4 || (H & (H - 1)) || C % 32 != 0 || !(O == 64 || O == 128 || O == 256)) return -1;
+  const int64_t cp = (int64_t)N * (H / 2) * (W / 2);       // pixels per class
+  if (cp % 128 != 0) return -1;
+  if (dry_run) return DFHIP_OK;
+  int lw = 0;
+  while ((1 << lw) < W) lw++;
+  S2Acc a = {};
+  a.dy = dy; a.w = w; a.dy2 = dy2; a.w2 = w2; a.add = add; a.dx = dx;
+  a.C = C; a.H = H; a.lw = lw; a.tiles = (int)(cp / 32);
+  const bool split = O >= 128, pair = dy2 != nullptr;
+  // workgroups per class, in the order (1,1), (0,1), (1,0), (0,0).  Unsplit: four tiles per workgroup whatever the class (the
+  // long ones are dispatched first).  SPLIT: a workgroup walks tiles; the classes share about one workgroup per CU and channel
+  // tile in proportion to their taps
+  const int weight[4] = {4, 2, 2, pair ? 2 : 1};
+  int cnt[4];
+  if (!split) {
+    for (int q = 0; q < 4; q++) cnt[q] = a.tiles / 4;
+  } else {
+    const int budget = std::max(9, num_cus() / (C / 32));
+    const int wsum = weight[0] + weight[1] + weight[2] + weight[3];
+    for (int q = 0; q < 4; q++) cnt[q] = std::max(1, std::min(a.tiles, budget * weight[q] / wsum));
+  }
+  int gx = 0;
+  for (int q = 0; q < 4; q++) { gx += cnt[q]; a.cls_end[q] = gx; }
+  if (O == 64) return pair ? launch_dgrad_s2_acc<64, false, true>(a, gx, C) : launch_dgrad_s2_acc<64, false, false>(a, gx, C);
+  if (O == 128) return pair ? launch_dgrad_s2_acc<128, true, true>(a, gx, C) : launch_dgrad_s2_acc<128, true, false>(a, gx, C);
+  return pair ? launch_dgrad_s2_acc<256, true, true>(a, gx, C) : launch_dgrad_s2_acc<256, true, false>(a, gx, C);
+}
 
 // x (N, C, H, H) -> y = conv3x3/s2/p1(x, w) and yd = conv1x1/s2/p0(x, wd), both (N, O, H/2, H/2); -1 when the shape is
 // not one this kernel takes (dry_run: only the shape test)

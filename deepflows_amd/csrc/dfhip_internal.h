@@ -81,6 +81,11 @@ int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y
 int run_conv_rowmma_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int C, int H, int W,
                           int O, int k, int stride, int pad);
 
+// dfhip_conv_s2.hip: accumulate-mode input gradient of 3x3 / stride 2 / pad 1 (+ the block's 1x1 / stride 2 shortcut when dy2,
+// w2 are given), one product per (pixel, tap) pair that exists; -1 when the shape is not eligible
+int run_dgrad_s2_acc(const float* dy, const float* w, const float* dy2, const float* w2, const float* add, float* dx, int N,
+                     int C, int H, int W, int O, bool dry_run = false);
+
 }  // namespace dfhip
 
 // ---- XCD-aware tile order ---------------------------------------------------------------------------------------

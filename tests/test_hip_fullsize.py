@@ -264,6 +264,34 @@ def test_register_operand_accumulate_dgrad_with_held_gradient(hip_device, name):
     assert_close(_back(mod, dxh, want.shape), want + held, 1e-4, name + " accumulate dgrad + held gradient")
 
 
+@pytest.mark.parametrize("name", ["l2a", "l3a", "l4a"])
+def test_accumulate_dgrad_of_the_stride2_layers_with_shortcut_and_held_gradient(hip_device, name):
+    """The complete input gradient of a block's 3x3 / stride-2 convolution at batch 256 -- alone, with the gradient the tensor
+    already holds, and together with the block's 1x1 / stride-2 shortcut (k_dgrad_s2_acc: only the (pixel, tap) pairs that
+    exist are multiplied) -- against the oracle's sums."""
+    mod = hip_device.mod
+    C, H, W, O, k, s, p = LAYERS[name]
+    rng = np.random.default_rng(19)
+    oh, ow = H // 2, W // 2
+    dy = rng.standard_normal((N, O, oh, ow)).astype(np.float32)
+    dy2 = rng.standard_normal((N, O, oh, ow)).astype(np.float32)
+    w = (rng.standard_normal((O, C, 3, 3)) / np.sqrt(O * 9)).astype(np.float32)
+    w2 = (rng.standard_normal((O, C, 1, 1)) / np.sqrt(O)).astype(np.float32)
+    held = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    shape = (N, C, H, W)
+    want3 = R.conv2d_dgrad(dy, w, shape, 2, 1, "accumulate")
+    want1 = R.conv2d_dgrad(dy2, w2, shape, 2, 0, "accumulate")
+    dyh, dy2h, wh, w2h, heldh, dxh = _arr(mod, dy), _arr(mod, dy2), _arr(mod, w), _arr(mod, w2), _arr(mod, held), mod.Array(held.size)
+    mod.conv2d_dgrad(dyh, wh, dxh, N, C, H, W, O, 3, 2, 1, mode="accumulate")
+    assert_close(_back(mod, dxh, shape), want3, 1e-4, name + " accumulate dgrad")
+    mod.conv2d_dgrad_add(dyh, wh, heldh, dxh, N, C, H, W, O, 3, 2, 1, mode="accumulate")
+    assert_close(_back(mod, dxh, shape), want3 + held, 1e-4, name + " accumulate dgrad + held gradient")
+    assert mod.conv2d_dgrad_pair(dyh, wh, dy2h, w2h, heldh, dxh, N, C, H, W, O, mode="accumulate")
+    assert_close(_back(mod, dxh, shape), want3 + want1 + held, 1e-4, name + " accumulate dgrad + shortcut + held gradient")
+    assert mod.conv2d_dgrad_pair(dyh, wh, dy2h, w2h, None, dxh, N, C, H, W, O, mode="accumulate")
+    assert_close(_back(mod, dxh, shape), want3 + want1, 1e-4, name + " accumulate dgrad + shortcut")
+
+
 def test_xcd_aware_tile_order_gives_the_same_results():
     """The XCD arrangement of the image-per-lane kernels (dfhip_internal.h xcd_tile; off by default, a speed switch
     only) renumbers workgroups: the layer3 / layer4 full-size checks must pass unchanged with it on (the switch is
