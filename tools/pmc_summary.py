@@ -123,6 +123,15 @@ FAMILIES = {
 
 def _family_of(kernel):
     k = short(kernel)
+    # kernels that serve the accumulate-mode input gradient through a template flag (`DG`) belong to that family
+    if k.startswith("k_dgrad_s2_acc"):
+        return "conv2d_dgrad_igemm"
+    if k.startswith("k_conv3x3_img2_all<") and k.endswith(", true>"):
+        return "conv2d_dgrad_igemm"
+    if k.startswith("k_conv3x3_rowmma<"):
+        args = [a.strip() for a in k[len("k_conv3x3_rowmma<"):-1].split(",")]
+        if len(args) > 8 and args[8] == "true":
+            return "conv2d_dgrad_igemm"
     for fam, prefixes in FAMILIES.items():
         if any((k == pr[:-1]) if pr.endswith("$") else k.startswith(pr) for pr in prefixes):
             return fam

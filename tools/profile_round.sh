@@ -32,13 +32,18 @@ one() {   # one <suffix> <workload> <dgrad> [extra bench args]
   python3 bench.py --workload $wl --dgrad $dg --pmc-traffic $OUT/pmc_traffic$sfx.json $extra > $OUT/bench$sfx.json 2> $OUT/bench$sfx.err
   python3 tools/kernel_table.py $OUT/bench$sfx.json $OUT/pmc_traffic$sfx.json $OUT/rocprof_kernel_stats$sfx.txt > $OUT/kernel_table$sfx.md 2>> $OUT/bench$sfx.err
 }
-one "" resnet18 overwrite
-[ -n "${ONLY_HEADLINE:-}" ] && { ls -la $OUT | head; exit 0; }
-one _accumulate resnet18 accumulate --no-cpu-baseline
-one _cnn cnn overwrite
+# CONFIGS="headline accumulate cnn rest" (default: all) picks the configurations; ONLY_HEADLINE=1 is CONFIGS=headline
+CFG=${CONFIGS:-"headline accumulate cnn rest"}
+[ -n "${ONLY_HEADLINE:-}" ] && CFG=headline
+has() { case " $CFG " in *" $1 "*) return 0;; esac; return 1; }
+has headline && one "" resnet18 overwrite
+has accumulate && one _accumulate resnet18 accumulate --no-cpu-baseline
+has cnn && one _cnn cnn overwrite
+if has rest; then
 python3 bench.py --workload mlp --steps 200 --warmup 20 > $OUT/bench_mlp.json 2> $OUT/bench_mlp.err
 python3 bench.py --workload resnet18_wide --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_wide.json 2> $OUT/bench_wide.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_wide -o s -- python3 bench.py --workload resnet18_wide --steps 5 --warmup 2 --no-cpu-baseline --no-prof-gate > $OUT/stats_wide.log 2>&1
 f=$(find $OUT/stats_wide -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python3 tools/kernel_stats_txt.py $f > $OUT/rocprof_kernel_stats_wide.txt; rm -rf $OUT/stats_wide
-python3 tools/roofline_table.py $OUT/bench.json > $OUT/roofline_table.md 2>/dev/null
+fi
+has headline && python3 tools/roofline_table.py $OUT/bench.json > $OUT/roofline_table.md 2>/dev/null
 ls -la $OUT | head -60
