@@ -4584,7 +4584,7 @@ int group_flush() {
   if (g_queue.empty()) return DFHIP_OK;
   std::vector<GQueued> q;
   q.swap(g_queue);                                  // (re-entrancy: scratch() may ask for a flush)
-  // A grouped layer is cut into 16x fewer, longer workgroups than a stand-alone launch (the other layers of the
+  // A grouped layer is cut into 8x fewer, longer workgroups than a stand-alone launch (the other layers of the
   // sweep fill the chip).  A sweep that queued too little for that (the CNN workload: one eligible layer) would
   // leave most CUs idle: its layers are re-planned and launched stand-alone instead.  (A quarter of the chip: the
   // two half sweeps of the overlapped data-parallel step -- layer4 + classifier, then the rest, ~200 workgroups
@@ -4825,7 +4825,8 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
   const int CT = (int)df_ceil_div(C, 32), OT = (int)df_ceil_div(O, 32);
   // pixel slabs per (channel tile, output tile): a stand-alone launch needs one workgroup per CU;
   // a grouped launch has the other layers to fill the chip with and takes longer workgroups
-  static int gdiv = getenv("DFHIP_WGRAD_GROUP_DIV") ? atoi(getenv("DFHIP_WGRAD_GROUP_DIV")) : 16;
+  // (8: re-measured with the round-3 body -- 4 / 6 / 8 / 10 / 12 / 16 / 24: 131 / 138 / 127 / 140 / 135 / 138 / 240 us for the R18 sweep)
+  static int gdiv = getenv("DFHIP_WGRAD_GROUP_DIV") ? atoi(getenv("DFHIP_WGRAD_GROUP_DIV")) : 8;
   const int ps0 = std::max(1, num_cus() / (CT * OT) / (grouped ? std::max(1, gdiv) : 1));
   static int gpb1 = getenv("DFHIP_WGRAD_GPB") ? atoi(getenv("DFHIP_WGRAD_GPB")) : 2;   // groups per block aimed at
   static int gpbg = getenv("DFHIP_WGRAD_GROUP_GPB") ? atoi(getenv("DFHIP_WGRAD_GROUP_GPB")) : 2;
