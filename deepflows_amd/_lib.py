@@ -93,6 +93,7 @@ _SIGS = {
                         c_double, c_int, c_double],
     "dfhip_adam_hyper": [P, c_double, c_double, c_double, c_double, c_double, c_int, c_double],
     "dfhip_adam_hyper_table": [P, c_int, c_double, c_double, c_double, c_double, c_double, c_int, c_double],
+    "dfhip_adam_hyper_index": [P, POINTER(c_int), POINTER(c_int)],
     "dfhip_adam_step_dev": [c_int, PP, PP, PP, PP, I64P, P],
     "dfhip_sgd_step": [c_int, PP, PP, PP, I64P, c_double, c_double, c_double, c_int, c_double],
     "dfhip_sgd_hyper": [P, c_double, c_double, c_double, c_int, c_double],

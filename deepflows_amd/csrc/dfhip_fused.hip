@@ -2326,6 +2326,21 @@ int dfhip_adam_hyper_table(float* hyper_dev, int cap, double lr, double beta1, d
   return DFHIP_OK;
 }
 
+int dfhip_adam_hyper_index(const float* hyper_dev, int* index, int* cap) {
+  DF_INIT();
+  DF_CHECK_ARG(hyper_dev && index && cap, "adam_hyper_index: null argument");
+  if (capturing()) {
+    set_error("adam_hyper_index: a device-to-host copy cannot be part of a captured step");
+    return DFHIP_INVALID_ARGUMENT;
+  }
+  int ctl[4] = {0, 0, 0, 0};
+  DF_HIP(hipStreamSynchronize(stream()));
+  DF_HIP(hipMemcpy(ctl, hyper_dev, sizeof(ctl), hipMemcpyDeviceToHost));
+  *index = ctl[0];
+  *cap = ctl[2];
+  return DFHIP_OK;
+}
+
 int dfhip_adam_step_dev(int n_tensors, float* const* params, const float* const* grads,
                         float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
                         const float* hyper_dev) {

@@ -498,6 +498,12 @@ class HipModule:
         _lib.check(self._lib.dfhip_adam_hyper_table(hyper.ptr, int(cap), lr, beta1, beta2, eps, weight_decay,
                                                     int(first_step), grad_scale))
 
+    def adam_hyper_index(self, hyper):
+        """(entries of the table the device has consumed, length of the table); drains the stream."""
+        idx, cap = c_int(0), c_int(0)
+        _lib.check(self._lib.dfhip_adam_hyper_index(hyper.ptr, byref(idx), byref(cap)))
+        return idx.value, cap.value
+
     def adam_step_dev(self, params, grads, exp_avg, exp_avg_sq, hyper):
         n = len(params)
         sizes = (c_int64 * n)(*[p.size for p in params])

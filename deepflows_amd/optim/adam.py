@@ -44,6 +44,14 @@ class Adam(Optimizer):
             return
         if getattr(mod, "capturing", False):
             raise RuntimeError("Adam: the scalar table must be written before the capture starts")
+        if self._table_key is not None:
+            # the table is about to be replaced: what the device consumed must be what this object counted (a replayed
+            # step that was not noted, or noted without running, has trained with another step's bias corrections)
+            index, _ = mod.adam_hyper_index(self._hyper)
+            if index != self._table_used:
+                raise RuntimeError(f"Adam: the device has taken {index} steps from its scalar table, the host counted "
+                                   f"{self._table_used}: a captured step was replayed without note_replayed_apply() "
+                                   "(or the other way round)")
         mod.adam_hyper_table(self._hyper, self._HYPER_STEPS, self.lr, self.beta1, self.beta2, self.eps,
                              self.weight_decay, self.t, self.grad_scale)
         self._table_key, self._table_used = (scalars, self.t), 0

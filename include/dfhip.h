@@ -155,10 +155,11 @@ int dfhip_conv2d_forward_s2_pair(const float* x, const float* w, const float* wd
 
 /* dx = dgrad(3x3 / stride 2 / pad 1; dy, w) + dgrad(1x1 / stride 2 / pad 0; dy2, w2) (+ add, may be NULL): the two
  * gradients the input of a residual block receives when its shortcut is a convolution (test/ResNet_CIFAR10_cuda.py:
- * 58-63: conv1 and downsample[0] both read x; tensor.py:444 sums them), each with the reference's last-writer-wins
- * rule (functional.py:285-294), as one launch.  dy, dy2 (N, O, H/2, W/2); w (O, C, 3, 3); w2 (O, C, 1, 1); dx
- * (N, C, H, W).  mode as dfhip_conv2d_dgrad; *done = 0 (nothing launched) when the shape / mode has no such kernel:
- * the caller then runs dfhip_conv2d_dgrad followed by dfhip_conv2d_dgrad_add. */
+ * 58-63: conv1 and downsample[0] both read x; tensor.py:444 sums them) as one launch.  mode as dfhip_conv2d_dgrad:
+ * 0 = each with the reference's last-writer-wins rule (functional.py:285-294), 1 = the complete sums (a pixel of
+ * parity class (ey, ex) receives through (1 + ey)(1 + ex) taps; only those products are formed).  dy, dy2 (N, O, H/2,
+ * W/2); w (O, C, 3, 3); w2 (O, C, 1, 1); dx (N, C, H, W).  *done = 0 (nothing launched) when the shape has no such
+ * kernel: the caller then runs dfhip_conv2d_dgrad followed by dfhip_conv2d_dgrad_add. */
 int dfhip_conv2d_dgrad_pair(const float* dy, const float* w, const float* dy2, const float* w2, const float* add,
                             float* dx, int N, int C, int H, int W, int O, int mode, int* done);
 
@@ -378,6 +379,12 @@ int dfhip_adam_hyper(float* hyper_dev, double lr, double beta1, double beta2, do
                      double weight_decay, int step, double grad_scale);
 int dfhip_adam_hyper_table(float* hyper_dev, int cap, double lr, double beta1, double beta2, double eps,
                            double weight_decay, int first_step, double grad_scale);
+/* Where the device is in a table written by dfhip_adam_hyper_table: *index = entries consumed so far (every
+ * dfhip_adam_step_dev moves it on, on the device), *cap = its length.  Drains the stream (not inside a capture).  The
+ * host mirror of optim/adam.py:34 (`self.t`) checks it against its own count before it rewrites a table: a replayed
+ * step the host did not count -- or counted without running -- would otherwise train on with another step's bias
+ * corrections (entries past the end are clamped to the last one). */
+int dfhip_adam_hyper_index(const float* hyper_dev, int* index, int* cap);
 int dfhip_adam_step_dev(int n_tensors, float* const* params, const float* const* grads,
                         float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
                         const float* hyper_dev);

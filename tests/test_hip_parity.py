@@ -336,6 +336,36 @@ def test_failed_capture_leaves_the_device_usable(hip_device):
     assert all(np.isfinite(v) for v in losses)
 
 
+def test_adam_notices_a_step_count_the_device_does_not_share(hip_device):
+    """The captured Adam update reads its bias corrections from a table the device walks by itself.  When the host's count
+    of consumed entries and the device's differ (a replay that was not noted, or noted without running), the next rewrite
+    of the table must refuse instead of training on with another step's corrections."""
+    from deepflows_amd import nn, optim, tensor, workloads
+    from deepflows_amd.graph_step import CapturedTrainStep
+    from deepflows_amd.tensor import Graph
+    np.random.seed(5)
+    model = workloads.MLP((16, 8, 4), device=hip_device)
+    opt = optim.Adam(model.parameters(), lr=1e-3)
+    crit = nn.CrossEntropyLoss()
+    rng = np.random.default_rng(6)
+    x = tensor.Tensor(rng.standard_normal((8, 16)).astype(np.float32), device=hip_device)
+    y = tensor.Tensor(np.eye(4, dtype=np.float32)[rng.integers(0, 4, 8)], device=hip_device)
+    step = CapturedTrainStep(model, crit, opt, x, y)
+    for _ in range(3):
+        step.replay()
+    index, cap = hip_device.mod.adam_hyper_index(opt._hyper)
+    assert index == opt._table_used and cap == opt._HYPER_STEPS
+    opt.lr = 5e-4                      # a scheduler moved the rate: the table is rewritten in front of the next replay
+    step.replay()
+    assert hip_device.mod.adam_hyper_index(opt._hyper)[0] == 1
+    opt.note_replayed_apply()          # the host counts a step the device never ran
+    opt.lr = 2.5e-4
+    with pytest.raises(RuntimeError, match="host counted"):
+        step.replay()
+    step.destroy()
+    Graph.free_graph_all()
+
+
 def test_paired_batchnorm_matches_two_layers(hip_device):
     """bn_a(conv_a(x)) + bn_b(conv_b(x)) as the paired node (one launch each way) against the two separate
     BatchNorm nodes + residual add: outputs, input / parameter gradients and running statistics."""
