@@ -212,6 +212,37 @@ def test_grouped_wgrad_small_batches(hip_device):
             assert_close(_back(mod, dwh, shape), R.conv2d_wgrad(x, dy, k, s, p), 1e-4, f"{name} n={n} grouped")
 
 
+@pytest.mark.parametrize("n", [256, 48, 40, 24, 6])
+def test_grouped_wgrad_with_shortcuts_that_share_their_blocks_input(hip_device, n):
+    """In a residual block with a convolution shortcut both the 3x3 / stride-2 convolution and the 1x1 / stride-2 shortcut
+    read the block input: queued in one group with the SAME x array, the shortcut's weight gradient rides on the
+    convolution's workgroups (a tenth accumulator, wgrad_rows_direct<PAIR>).  Every layer kind of the grouped body in one
+    group, against the oracle, at the benchmarked batch and at batches where the units of several image pairs do / do
+    not divide the batch (48: all kinds direct; 40, 24: the 8-pair kinds fall back to the staged body; 6: all staged)."""
+    mod = hip_device.mod
+    if not mod.wgrad_grouping:
+        pytest.skip("DF_WGRAD_GROUP=0")
+    rng = np.random.default_rng(29)
+    assert mod.wgrad_group_begin()
+    held = []
+    shared = {}
+    for name in ("l1", "l2", "l3", "l4", "l2a", "l2d", "l3a", "l3d", "l4a", "l4d"):
+        C, H, W, O, k, s, p = LAYERS[name]
+        oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        key = (C, H, W) if s == 2 else name
+        if key not in shared:
+            x = rng.standard_normal((n, C, H, W)).astype(np.float32)
+            shared[key] = (x, _arr(mod, x))
+        x, xh = shared[key]
+        dy = rng.standard_normal((n, O, oh, ow)).astype(np.float32)
+        dyh, dwh = _arr(mod, dy), mod.Array(O * C * k * k)
+        mod.conv2d_wgrad(xh, dyh, dwh, n, C, H, W, O, k, s, p)
+        held.append((name, x, dy, k, s, p, xh, dyh, dwh, (O, C, k, k)))
+    mod.wgrad_group_end()
+    for name, x, dy, k, s, p, xh, dyh, dwh, shape in held:
+        assert_close(_back(mod, dwh, shape), R.conv2d_wgrad(x, dy, k, s, p), 1e-4, f"{name} n={n} grouped, shared input")
+
+
 @pytest.mark.parametrize("name,bias", [("l1", False), ("l2", True), ("l3", False), ("l1", True)])
 def test_register_operand_forward_with_partials(hip_device, name, bias):
     """3x3 / stride 1 forward on the register-operand kernel (dfhip_conv_rows.hip) at batch 256: the output
