@@ -653,10 +653,12 @@ inline uint32_t mt_temper(uint32_t y) {
 namespace {
 __attribute__((target("avx2"))) inline void mt_regenerate_avx2(uint32_t* mt) { DF_MT_BODY }
 }
+extern "C++" {            // (the generators are templates over the element type of the mask)
 #define DF_MASK_ATTR
 #define DF_MASK_NAME bernoulli_mask_base
 #define DF_MT_REGEN mt_regenerate
-DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64_t n, float* out) {
+template <typename OUT>
+DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64_t n, OUT* out) {
   // tempered outputs are produced a block at a time into `buf`; `have` of them are not consumed yet
   uint32_t buf[kMtN];
   int p = *pos, have = 0, at = 0;
@@ -676,7 +678,7 @@ DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64
     if (has_carry) {                                // a double straddling two blocks
       const uint32_t a = carry_a >> 5, b = buf[at] >> 6;
       const double u = (a * 67108864.0 + b) / 9007199254740992.0;
-      out[done++] = low ? (u > thr ? 1.0f : 0.0f) : (u > thr ? 0.0f : 1.0f);
+      out[done++] = low ? (u > thr ? (OUT)1 : (OUT)0) : (u > thr ? (OUT)0 : (OUT)1);
       at++; have--;
       has_carry = false;
       continue;
@@ -684,16 +686,16 @@ DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64
     int64_t pairs = have / 2;
     if (pairs > n - done) pairs = n - done;
     const uint32_t* q = buf + at;
-    float* o = out + done;
+    OUT* o = out + done;
     if (low) {
       for (int64_t i = 0; i < pairs; i++) {
         const double u = ((q[2 * i] >> 5) * 67108864.0 + (q[2 * i + 1] >> 6)) / 9007199254740992.0;
-        o[i] = u > thr ? 1.0f : 0.0f;
+        o[i] = u > thr ? (OUT)1 : (OUT)0;
       }
     } else {
       for (int64_t i = 0; i < pairs; i++) {
         const double u = ((q[2 * i] >> 5) * 67108864.0 + (q[2 * i + 1] >> 6)) / 9007199254740992.0;
-        o[i] = u > thr ? 0.0f : 1.0f;
+        o[i] = u > thr ? (OUT)0 : (OUT)1;
       }
     }
     done += pairs;
@@ -717,7 +719,8 @@ DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64
 #define DF_MASK_ATTR __attribute__((target("avx2")))
 #define DF_MASK_NAME bernoulli_mask_avx2
 #define DF_MT_REGEN mt_regenerate_avx2
-DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64_t n, float* out) {
+template <typename OUT>
+DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64_t n, OUT* out) {
   // tempered outputs are produced a block at a time into `buf`; `have` of them are not consumed yet
   uint32_t buf[kMtN];
   int p = *pos, have = 0, at = 0;
@@ -737,7 +740,7 @@ DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64
     if (has_carry) {                                // a double straddling two blocks
       const uint32_t a = carry_a >> 5, b = buf[at] >> 6;
       const double u = (a * 67108864.0 + b) / 9007199254740992.0;
-      out[done++] = low ? (u > thr ? 1.0f : 0.0f) : (u > thr ? 0.0f : 1.0f);
+      out[done++] = low ? (u > thr ? (OUT)1 : (OUT)0) : (u > thr ? (OUT)0 : (OUT)1);
       at++; have--;
       has_carry = false;
       continue;
@@ -745,16 +748,16 @@ DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64
     int64_t pairs = have / 2;
     if (pairs > n - done) pairs = n - done;
     const uint32_t* q = buf + at;
-    float* o = out + done;
+    OUT* o = out + done;
     if (low) {
       for (int64_t i = 0; i < pairs; i++) {
         const double u = ((q[2 * i] >> 5) * 67108864.0 + (q[2 * i + 1] >> 6)) / 9007199254740992.0;
-        o[i] = u > thr ? 1.0f : 0.0f;
+        o[i] = u > thr ? (OUT)1 : (OUT)0;
       }
     } else {
       for (int64_t i = 0; i < pairs; i++) {
         const double u = ((q[2 * i] >> 5) * 67108864.0 + (q[2 * i + 1] >> 6)) / 9007199254740992.0;
-        o[i] = u > thr ? 0.0f : 1.0f;
+        o[i] = u > thr ? (OUT)0 : (OUT)1;
       }
     }
     done += pairs;
@@ -776,13 +779,25 @@ DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64
 #undef DF_MASK_NAME
 #undef DF_MT_REGEN
 
+}  // extern "C++"
+
 int dfhip_host_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n, float* out) {
   if (!key || !pos || !out || n < 0 || *pos < 0 || *pos > kMtN) {
     set_error("host_bernoulli_mask: bad arguments");
     return DFHIP_INVALID_ARGUMENT;
   }
   static const bool avx2 = __builtin_cpu_supports("avx2");
-  return avx2 ? bernoulli_mask_avx2(key, pos, keep, n, out) : bernoulli_mask_base(key, pos, keep, n, out);
+  return avx2 ? bernoulli_mask_avx2<float>(key, pos, keep, n, out) : bernoulli_mask_base<float>(key, pos, keep, n, out);
+}
+
+// a mask of 0 / 1 BYTES read from pinned host memory -> floats in device memory (four elements per thread)
+__global__ __launch_bounds__(256) void k_mask_bytes_from_host(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const uchar4 b = reinterpret_cast<const uchar4*>(src)[i];
+    reinterpret_cast<float4*>(dst)[i] = make_float4((float)b.x, (float)b.y, (float)b.z, (float)b.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = (float)src[(n4 << 2) + threadIdx.x];
 }
 
 // the same mask generated straight into a pinned staging slot and sent to `dst` on the library stream: no
@@ -811,9 +826,28 @@ int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n,
     DF_HIP(hipHostMalloc(&sl.p, want, hipHostMallocDefault));
     sl.bytes = want;
   }
+  static int by_kernel = getenv("DFHIP_UPLOAD_KERNEL") ? atoi(getenv("DFHIP_UPLOAD_KERNEL")) : 1;
+  // the mask crosses PCIe as bytes (a quarter of the floats: 2 MB per step of the CNN workload were 40 us in front of every
+  // replay) and becomes floats in the kernel that fetches it
+  static int as_bytes = getenv("DFHIP_MASK_BYTES") ? atoi(getenv("DFHIP_MASK_BYTES")) : 1;
+  if (by_kernel && as_bytes && (((uintptr_t)dst) & 15) == 0) {
+    if (*pos < 0 || *pos > kMtN) {
+      set_error("upload_bernoulli_mask: bad generator position");
+      return DFHIP_INVALID_ARGUMENT;
+    }
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    const int stb = avx2 ? bernoulli_mask_avx2<uint8_t>(key, pos, keep, n, (uint8_t*)sl.p)
+                         : bernoulli_mask_base<uint8_t>(key, pos, keep, n, (uint8_t*)sl.p);
+    if (stb != DFHIP_OK) return stb;
+    const int blocks = (int)std::min<int64_t>(1024, (n / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_mask_bytes_from_host, dim3(blocks), dim3(256), 0, g_stream, (const uint8_t*)sl.p, dst, n);
+    DF_LAUNCH_CHECK();
+    DF_HIP(hipEventRecord(sl.done, g_stream));
+    sl.busy = true;
+    return DFHIP_OK;
+  }
   int st = dfhip_host_bernoulli_mask(key, pos, keep, n, (float*)sl.p);
   if (st != DFHIP_OK) return st;
-  static int by_kernel = getenv("DFHIP_UPLOAD_KERNEL") ? atoi(getenv("DFHIP_UPLOAD_KERNEL")) : 1;
   if (by_kernel && (((uintptr_t)dst) & 15) == 0) {
     const int blocks = (int)std::min<int64_t>(1024, (n / 4 + 255) / 256 + 1);
     hipLaunchKernelGGL(k_copy_from_host, dim3(blocks), dim3(256), 0, g_stream, (const float*)sl.p, dst, n);
