@@ -1494,15 +1494,17 @@ int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* 
 template <int C>
 __global__ __launch_bounds__(256) void k_conv1x1s2_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                       float* __restrict__ stats, int H, int lw, int O) {
+                                                       float* __restrict__ stats, int H, int lw, int O, int DT) {
+  // DT: tiles of 32 output channels a workgroup computes from the pixel operand it loaded ONCE (the stride-2 gather
+  // uses half of every sector it fetches; with one channel tile per workgroup the 64-channel 32 x 32 layer of the wide
+  // ResNet fetched its input four times: 30 us for 1.07 GFLOP)
   constexpr int NP = C / 2, WT = 33, TS = 36;
-  __shared__ __attribute__((aligned(16))) float smem[(C * WT > 4 * 32 * TS + 4 * 96) ? C * WT : 4 * 32 * TS + 4 * 96];
-  float* Wl = smem;                                 // [c][WT] (transposed weight tile), later the epilogue's tiles
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wl = smem;                                 // [DT][c][WT] (transposed weight tiles)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int W = 1 << lw, HW = H << lw;
   const int olw = lw - 1, OW = W >> 1, OHW = HW >> 2;
-  const int d0 = blockIdx.y * 32;
   const int tile = blockIdx.x * 4 + wave;
   const int p = tile * 32 + l31;                    // flat output pixel (n, r, s)
   const int n = p / OHW, rem = p - n * OHW;
@@ -1513,79 +1515,84 @@ __global__ __launch_bounds__(256) void k_conv1x1s2_fwd(const float* __restrict__
 #pragma unroll
     for (int kp = 0; kp < NP; kp++) b[kp] = xb[(int64_t)(2 * kp) * HW];
   }
+  const int dbase = blockIdx.y * DT * 32;
   {
     constexpr int RUN4 = C / 4;                     // float4s per output channel
-    const int dmax = min(32, O - d0);
-    for (int f = tid; f < 32 * RUN4; f += 256) {
+    const int dmax = min(32 * DT, O - dbase);
+    for (int f = tid; f < 32 * DT * RUN4; f += 256) {
       const int row = f / RUN4, e4 = f - row * RUN4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < dmax) v = *reinterpret_cast<const float4*>(w + (int64_t)(d0 + row) * C + 4 * e4);
-      float* q = Wl + (4 * e4) * WT + row;
+      if (row < dmax) v = *reinterpret_cast<const float4*>(w + (int64_t)(dbase + row) * C + 4 * e4);
+      float* q = Wl + (row >> 5) * (C * WT) + (4 * e4) * WT + (row & 31);
       q[0] = v.x; q[WT] = v.y; q[2 * WT] = v.z; q[3 * WT] = v.w;
     }
   }
   __syncthreads();
-  f32x16 acc;
+  float* Tt = smem + DT * (C * WT) + wave * (32 * TS);   // [4][32 channels][TS]
+  float* sb = smem + DT * (C * WT) + 4 * (32 * TS);      // [4][32][3]
+  for (int dt = 0; dt < DT; dt++) {
+    const int d0 = dbase + dt * 32;
+    if (d0 >= O) break;
+    f32x16 acc;
 #pragma unroll
-  for (int rr = 0; rr < 16; rr++) acc[rr] = 0.0f;
-  {
-    const float* aq = Wl + half * WT + l31;
+    for (int rr = 0; rr < 16; rr++) acc[rr] = 0.0f;
+    {
+      const float* aq = Wl + dt * (C * WT) + half * WT + l31;
 #pragma unroll
-    for (int kp = 0; kp < NP; kp++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[(2 * kp) * WT], b[kp], acc, 0, 0, 0);
-  }
-  if (bias) {
-#pragma unroll
-    for (int rr = 0; rr < 16; rr++) acc[rr] += bias[min(d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half, O - 1)];
-  }
-  __syncthreads();                                  // the weight tile is dead
-  float* Tt = smem + wave * (32 * TS);              // [4][32 channels][TS]
-  float* sb = smem + 4 * (32 * TS);                 // [4][32][3]
-#pragma unroll
-  for (int rr = 0; rr < 16; rr++) Tt[((rr & 3) + 8 * (rr >> 2) + 4 * half) * TS + l31] = acc[rr];
-  // (each wave reads back only its own tile: no barrier needed before the stores)
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int f = lane + 64 * u, o = f >> 3, q4 = f & 7;
-    if (d0 + o < O) {
-      const int pp = tile * 32 + 4 * q4;            // four consecutive output pixels (same image: OHW % 4 == 0)
-      const int nn = pp / OHW, rr0 = pp - nn * OHW;
-      const float4 v = *reinterpret_cast<const float4*>(Tt + o * TS + 4 * q4);
-      *reinterpret_cast<float4*>(y + ((int64_t)nn * O + d0 + o) * OHW + rr0) = v;
+      for (int kp = 0; kp < NP; kp++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[(2 * kp) * WT], b[kp], acc, 0, 0, 0);
     }
-  }
-  if (stats) {
-    const float* row = Tt + l31 * TS + 16 * half;
-    float vals[16];
+    if (bias) {
 #pragma unroll
-    for (int q4 = 0; q4 < 4; q4++) {
-      const float4 t4 = *reinterpret_cast<const float4*>(row + 4 * q4);
-      vals[4 * q4] = t4.x; vals[4 * q4 + 1] = t4.y; vals[4 * q4 + 2] = t4.z; vals[4 * q4 + 3] = t4.w;
+      for (int rr = 0; rr < 16; rr++) acc[rr] += bias[min(d0 + (rr & 3) + 8 * (rr >> 2) + 4 * half, O - 1)];
     }
-    float t = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 16; i++) t += vals[i];
-    t += __shfl_xor(t, 32);
-    const float mean_t = t * (1.0f / 32.0f);
-    float q = 0.0f;
+    for (int rr = 0; rr < 16; rr++) Tt[((rr & 3) + 8 * (rr >> 2) + 4 * half) * TS + l31] = acc[rr];
+    // (each wave reads back only its own tile: no barrier needed before the stores)
 #pragma unroll
-    for (int i = 0; i < 16; i++) { const float dlt = vals[i] - mean_t; q += dlt * dlt; }
-    q += __shfl_xor(q, 32);
-    if (half == 0) {
-      float* o3 = sb + (wave * 32 + l31) * 3;
-      o3[0] = 32.0f; o3[1] = mean_t; o3[2] = q;
-    }
-    __syncthreads();
-    if (tid < 32 && d0 + tid < O) {
-      float cn = 0.0f, mu = 0.0f, m2 = 0.0f;
-      for (int tt = 0; tt < 4; tt++) {
-        const float* o3 = sb + (tt * 32 + tid) * 3;
-        const float nb = o3[0], nn = cn + nb, delta = o3[1] - mu;
-        mu += delta * (nb / nn);
-        m2 += o3[2] + delta * delta * (cn * nb / nn);
-        cn = nn;
+    for (int u = 0; u < 4; u++) {
+      const int f = lane + 64 * u, o = f >> 3, q4 = f & 7;
+      if (d0 + o < O) {
+        const int pp = tile * 32 + 4 * q4;            // four consecutive output pixels (same image: OHW % 4 == 0)
+        const int nn = pp / OHW, rr0 = pp - nn * OHW;
+        const float4 v = *reinterpret_cast<const float4*>(Tt + o * TS + 4 * q4);
+        *reinterpret_cast<float4*>(y + ((int64_t)nn * O + d0 + o) * OHW + rr0) = v;
       }
-      float* o3 = stats + ((int64_t)blockIdx.x * O + d0 + tid) * 3;
-      o3[0] = cn; o3[1] = mu; o3[2] = m2;
+    }
+    if (stats) {
+      const float* row = Tt + l31 * TS + 16 * half;
+      float vals[16];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; q4++) {
+        const float4 t4 = *reinterpret_cast<const float4*>(row + 4 * q4);
+        vals[4 * q4] = t4.x; vals[4 * q4 + 1] = t4.y; vals[4 * q4 + 2] = t4.z; vals[4 * q4 + 3] = t4.w;
+      }
+      float t = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; i++) t += vals[i];
+      t += __shfl_xor(t, 32);
+      const float mean_t = t * (1.0f / 32.0f);
+      float q = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; i++) { const float dlt = vals[i] - mean_t; q += dlt * dlt; }
+      q += __shfl_xor(q, 32);
+      if (half == 0) {
+        float* o3 = sb + (wave * 32 + l31) * 3;
+        o3[0] = 32.0f; o3[1] = mean_t; o3[2] = q;
+      }
+      __syncthreads();
+      if (tid < 32 && d0 + tid < O) {
+        float cn = 0.0f, mu = 0.0f, m2 = 0.0f;
+        for (int tt = 0; tt < 4; tt++) {
+          const float* o3 = sb + (tt * 32 + tid) * 3;
+          const float nb = o3[0], nn = cn + nb, delta = o3[1] - mu;
+          mu += delta * (nb / nn);
+          m2 += o3[2] + delta * delta * (cn * nb / nn);
+          cn = nn;
+        }
+        float* o3 = stats + ((int64_t)blockIdx.x * O + d0 + tid) * 3;
+        o3[0] = cn; o3[1] = mu; o3[2] = m2;
+      }
+      __syncthreads();                                // sb and the tiles are rewritten by the next channel tile
     }
   }
 }
@@ -4101,11 +4108,11 @@ int run_conv_img2(const Geo& g, int O, float* y, const float* bias, float* parti
   return DFHIP_OK;
 }
 
-// shortcut convolution (1x1 / stride 2 / pad 0, 32-128 source channels); -1 when not eligible
+// shortcut convolution (1x1 / stride 2 / pad 0, 32-256 source channels); -1 when not eligible
 int run_conv1x1s2(const Geo& g, int O, float* y, const float* bias, float* partials, int cap_rows, int* rows_out) {
   static int enabled = getenv("DFHIP_SHORTCUT_LEAN") ? atoi(getenv("DFHIP_SHORTCUT_LEAN")) : 1;
   if (!enabled || g.mode != 0 || g.k != 1 || g.so != 2 || g.sd != 1 || g.u0 != 0) return -1;
-  if (!(g.CS == 32 || g.CS == 64 || g.CS == 128)) return -1;
+  if (!(g.CS == 32 || g.CS == 64 || g.CS == 128 || g.CS == 256)) return -1;
   if ((g.HS & 1) || (g.WS & 1) || g.HD * 2 != g.HS || g.WD * 2 != g.WS) return -1;
   int lw = 0;
   while ((1 << lw) < g.WS) lw++;
@@ -4116,10 +4123,21 @@ int run_conv1x1s2(const Geo& g, int O, float* y, const float* bias, float* parti
   if (partials && rows > cap_rows) return -1;
   if ((int64_t)rows * df_ceil_div(O, 32) < num_cus() / 2) return -1;   // too few workgroups: the k-split kernel wins
   if (rows_out) *rows_out = partials ? rows : 0;
-  dim3 grid((unsigned)rows, (unsigned)df_ceil_div(O, 32));
-  if (g.CS == 32) DF_LAUNCH(k_conv1x1s2_fwd<32>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O);
-  else if (g.CS == 64) DF_LAUNCH(k_conv1x1s2_fwd<64>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O);
-  else DF_LAUNCH(k_conv1x1s2_fwd<128>, grid, dim3(256), 0, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O);
+  // channel tiles per workgroup: as many as still leave two workgroups per CU (and 64 KB of LDS per workgroup)
+  const int OT = (int)df_ceil_div(O, 32);
+  static int dtmax = getenv("DFHIP_SHORTCUT_DT") ? atoi(getenv("DFHIP_SHORTCUT_DT")) : 8;
+  int DT = 1;
+  auto lds_of = [&](int dt) { return ((size_t)dt * g.CS * 33 + 4 * 32 * 36 + 4 * 96) * sizeof(float); };
+  // (more tiles per workgroup with 87-155 KB of LDS and one workgroup per CU were measured: 128 channels 23.6 -> 26.2 us)
+  while (DT * 2 <= std::min(OT, dtmax) && (int64_t)rows * df_ceil_div(OT, DT * 2) >= 2 * (int64_t)num_cus() &&
+         lds_of(DT * 2) <= 64 * 1024)
+    DT *= 2;
+  const size_t lds = lds_of(DT);
+  dim3 grid((unsigned)rows, (unsigned)df_ceil_div(OT, DT));
+  if (g.CS == 32) DF_LAUNCH(k_conv1x1s2_fwd<32>, grid, dim3(256), lds, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O, DT);
+  else if (g.CS == 64) DF_LAUNCH(k_conv1x1s2_fwd<64>, grid, dim3(256), lds, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O, DT);
+  else if (g.CS == 128) DF_LAUNCH(k_conv1x1s2_fwd<128>, grid, dim3(256), lds, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O, DT);
+  else DF_LAUNCH(k_conv1x1s2_fwd<256>, grid, dim3(256), lds, stream(), g.src, g.wgt, bias, y, partials, g.HS, lw, O, DT);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
