@@ -275,6 +275,40 @@ def test_register_operand_forward_with_partials(hip_device, name, bias):
     assert_close(m2 / cnt, y64.var(axis=(0, 2, 3)), 1e-5, "partials variance")
 
 
+@pytest.mark.parametrize("C,H,O,n,bias", [(64, 32, 128, 64, False), (128, 16, 256, 128, True), (256, 8, 512, 256, False),
+                                           (32, 16, 64, 256, True), (64, 8, 96, 256, False)])
+def test_shortcut_convolution_with_partials_and_several_channel_tiles(hip_device, C, H, O, n, bias):
+    """1x1 / stride 2 forward (k_conv1x1s2_fwd: a workgroup computes several 32-channel tiles from one load of its pixel
+    operand; the wide ResNet-18's shapes, the 256-channel form, a channel count that is not a multiple of 32): the output
+    against the oracle and the BatchNorm partials of every channel tile combined with Chan's formula."""
+    mod = hip_device.mod
+    rng = np.random.default_rng(43)
+    oh = H // 2
+    x = (rng.standard_normal((n, C, H, H)) + 0.25).astype(np.float32)
+    w = (rng.standard_normal((O, C, 1, 1)) / np.sqrt(C)).astype(np.float32)
+    b = rng.standard_normal(O).astype(np.float32) if bias else None
+    cap = 2048
+    yh, ph = mod.Array(n * O * oh * oh), mod.Array(cap * O * 3)
+    rows = mod.conv2d_forward_stats(_arr(mod, x), _arr(mod, w), _arr(mod, b) if bias else None, yh,
+                                    n, C, H, H, O, 1, 2, 0, ph, cap)
+    y_ref = R.conv2d_forward(x, w, b, 2, 0)
+    assert_close(_back(mod, yh, y_ref.shape), y_ref, 1e-4, "shortcut forward")
+    assert rows > 0
+    part = _back(mod, ph, (cap, O, 3))[:rows].astype(np.float64)
+    cnt, mu, m2 = np.zeros(O), np.zeros(O), np.zeros(O)
+    for r in range(rows):
+        nb, mb, qb = part[r, :, 0], part[r, :, 1], part[r, :, 2]
+        tot = cnt + nb
+        d = mb - mu
+        mu = mu + d * nb / np.maximum(tot, 1)
+        m2 = m2 + qb + d * d * cnt * nb / np.maximum(tot, 1)
+        cnt = tot
+    assert np.all(cnt == n * oh * oh)
+    y64 = y_ref.astype(np.float64)
+    assert_close(mu, y64.mean(axis=(0, 2, 3)), 1e-5, "partials mean")
+    assert_close(m2 / cnt, y64.var(axis=(0, 2, 3)), 1e-5, "partials variance")
+
+
 @pytest.mark.parametrize("name", ["l1", "l2", "l3", "l4", "l4_128_to_256", "l4_256_to_128"])
 def test_register_operand_accumulate_dgrad_with_held_gradient(hip_device, name):
     """The mathematically correct input gradient of the 3x3 / stride 1 layers on the register-operand kernel (weights
