@@ -3699,7 +3699,8 @@ __device__ __forceinline__ void wgrad_direct_any(const GDesc& d, float* smem, co
 #define DF_ROWS_KINDS(X) \
   X(0, 3, 1, 1, 16, 16, 1, 1) X(1, 3, 1, 1, 8, 8, 2, 1) X(2, 3, 1, 1, 4, 4, 4, 1) X(3, 3, 1, 1, 2, 2, 2, 4)      \
   X(4, 3, 1, 2, 16, 8, 1, 1) X(5, 3, 1, 2, 8, 4, 2, 1) X(6, 3, 1, 2, 4, 2, 2, 2)                              \
-  X(7, 1, 0, 2, 16, 8, 1, 4) X(8, 1, 0, 2, 8, 4, 1, 8) X(9, 1, 0, 2, 4, 2, 1, 8)
+  X(7, 1, 0, 2, 16, 8, 1, 4) X(8, 1, 0, 2, 8, 4, 1, 8) X(9, 1, 0, 2, 4, 2, 1, 8)                              \
+  X(10, 3, 1, 1, 32, 32, 1, 1) X(11, 3, 1, 2, 32, 16, 1, 1) X(12, 1, 0, 2, 32, 16, 1, 2)
 
 // (one wave per SIMD, like the stand-alone kernel: the row-unit body needs ~470 registers, and built
 // for two resident workgroups -- 256 registers -- it spills 120-210 of them)
@@ -4585,9 +4586,9 @@ static double replan_direct(GQueued& e, int target) {
   // cycles of a wave per unit, measured with the in-kernel counters (-DDFHIP_STAMPS, DFHIP_CONV_STAMP=1; batch 256): the
   // MFMA issue slots of the unit plus what its operand loads and hand-over cost -- units of few MFMAs (1x1 kernels, 2 x 2
   // planes) are bound by the latency of their loads, not by their MFMA count
-  static const double kUnitCycles[10] = {9260, 8720, 7640, 5560, 4780, 4680, 4490, 9400, 7200, 2840};
+  static const double kUnitCycles[13] = {9260, 8720, 7640, 5560, 4780, 4680, 4490, 9400, 7200, 2840, 19000, 9800, 9400};
   const int upr = d.oh / UR, U = (d.N / (2 * NP)) * upr;
-  const double unit_cycles = d.kind >= 0 && d.kind < 10 ? kUnitCycles[d.kind] : 5000.0;
+  const double unit_cycles = d.kind >= 0 && d.kind < 13 ? kUnitCycles[d.kind] : 5000.0;
   if (target > 0) {
     const double per_wave = std::max(1.0, (target - 14000.0) / unit_cycles);
     const int want = 4 * (int)std::max(1.0, std::floor(per_wave + 0.5));
@@ -4620,6 +4621,8 @@ int group_flush() {
                                          e.k, e.stride, e.pad);
         else
           st = run_wgrad_rows(e.d.x, e.d.dy, e.dw, e.d.N, e.d.C, e.d.H, e.W, e.d.O, e.d.oh, e.ow, e.k, e.stride, e.pad);
+        if (st < 0)                                 // (a shape the stand-alone row kernel does not take: the general path)
+          st = dfhip_conv2d_wgrad(e.d.x, e.d.dy, e.dw, e.d.N, e.d.C, e.d.H, e.W, e.d.O, e.k, e.stride, e.pad);
         if (st != DFHIP_OK) break;
       }
       g_group_on = was;
@@ -4836,7 +4839,8 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
   if (C < 16 || (N & 1)) return -1;
   const bool k3 = k == 3 && pad == 1, k1 = k == 1 && pad == 0 && stride == 2;
   if (!k3 && !k1) return -1;
-  if (!(W == 16 || W == 8 || W == 4 || (W == 2 && stride == 1))) return -1;
+  if (!(W == 32 || W == 16 || W == 8 || W == 4 || (W == 2 && stride == 1))) return -1;
+  if (W == 32 && !g_group_on) return -1;     // (32-wide planes: the grouped body only -- stand-alone it spills 50-70 registers)
   if (ow != (W + 2 * pad - k) / stride + 1 || (stride == 2 && ow * 2 != W) || stride > 2) return -1;
   if ((H * W) % 4 != 0 || (oh * ow) % 4 != 0) return -1;
   const bool grouped = g_group_on;
@@ -4850,7 +4854,7 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
   static int gpbg = getenv("DFHIP_WGRAD_GROUP_GPB") ? atoi(getenv("DFHIP_WGRAD_GROUP_GPB")) : 2;
   const int gpb = grouped ? gpbg : gpb1;
   // output rows per unit (must match the instantiations)
-  const int UR = k == 1 ? 1 : (stride == 1 ? (W == 16 ? 1 : (W == 8 ? 2 : (W == 4 ? 4 : 2))) : (W == 16 ? 1 : 2));
+  const int UR = k == 1 ? 1 : (stride == 1 ? (W >= 16 ? 1 : (W == 8 ? 2 : (W == 4 ? 4 : 2))) : (W >= 16 ? 1 : 2));
   const double per_block = (double)(N / 2) * (oh / UR) / ps0;
   const double target = std::max((double)kRowsWaves, per_block / std::max(1, gpb));
   static int gcap = getenv("DFHIP_WGRAD_GROUP_LDS") ? atoi(getenv("DFHIP_WGRAD_GROUP_LDS")) : 160;
@@ -4890,7 +4894,12 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
       }
     }
   }
-  if (best > 1e29) return -1;
+  // (no staging plan -- 32-wide planes exceed the vectors a thread keeps in flight -- is fine for a layer the grouped launch
+  // takes with its operands straight from global memory)
+  const bool staged_plan = best < 1e29;
+  static int direct_allowed = getenv("DFHIP_WGRAD_DIRECT") ? atoi(getenv("DFHIP_WGRAD_DIRECT")) : 1;
+  if (!staged_plan && !(grouped && direct_allowed && C % 32 == 0 && O % 32 == 0)) return -1;
+  if (!staged_plan) { g.BI = 2; g.BR = UR; g.gr = oh / UR; g.RLr = std::min(H, (UR - 1) * stride + k); g.units = 4; }
   g.x = x; g.dy = dy;
   g.N = N; g.C = C; g.H = H; g.O = O; g.oh = oh;
   g.ngroups = (N / g.BI) * g.gr;
@@ -4919,6 +4928,7 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
     e.dw = dw; e.T = k * k; e.lds = best_lds;
     static int direct_on = getenv("DFHIP_WGRAD_DIRECT") ? atoi(getenv("DFHIP_WGRAD_DIRECT")) : 1;
     const bool direct = direct_on && C % 32 == 0 && O % 32 == 0 && (N / 2) % NPk == 0;
+    if (!direct && !staged_plan) return -1;
     if (aff && !direct) return -1;
     d.aff = aff;
     if (direct) {

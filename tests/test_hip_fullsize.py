@@ -275,6 +275,36 @@ def test_register_operand_forward_with_partials(hip_device, name, bias):
     assert_close(m2 / cnt, y64.var(axis=(0, 2, 3)), 1e-5, "partials variance")
 
 
+@pytest.mark.parametrize("n", [64, 32, 6])
+def test_grouped_wgrad_of_32_wide_planes(hip_device, n):
+    """The 64-channel 32 x 32 layers of the wide ResNet-18 (test/ResNet.py) and of VGG16 in a weight-gradient group: 3x3 /
+    stride 1, the block's 3x3 / stride 2 with its 1x1 / stride-2 shortcut on the same input, beside 16-wide layers --
+    32-wide planes exist in the grouped body with operands from global memory only (batch 6: too few workgroups for a
+    group, every layer takes the stand-alone paths)."""
+    mod = hip_device.mod
+    if not mod.wgrad_grouping:
+        pytest.skip("DF_WGRAD_GROUP=0")
+    rng = np.random.default_rng(31)
+    shapes = [(64, 32, 32, 64, 3, 1, 1), (64, 32, 32, 128, 3, 2, 1), (64, 32, 32, 128, 1, 2, 0), (128, 16, 16, 128, 3, 1, 1),
+              (32, 32, 32, 64, 3, 1, 1)]
+    assert mod.wgrad_group_begin()
+    held, shared = [], {}
+    for C, H, W, O, k, s, p in shapes:
+        oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        key = (C, H, W, s == 2)
+        if key not in shared:
+            x = rng.standard_normal((n, C, H, W)).astype(np.float32)
+            shared[key] = (x, _arr(mod, x))
+        x, xh = shared[key]
+        dy = rng.standard_normal((n, O, oh, ow)).astype(np.float32)
+        dyh, dwh = _arr(mod, dy), mod.Array(O * C * k * k)
+        mod.conv2d_wgrad(xh, dyh, dwh, n, C, H, W, O, k, s, p)
+        held.append((x, dy, k, s, p, xh, dyh, dwh, (O, C, k, k)))
+    mod.wgrad_group_end()
+    for x, dy, k, s, p, xh, dyh, dwh, shape in held:
+        assert_close(_back(mod, dwh, shape), R.conv2d_wgrad(x, dy, k, s, p), 1e-4, f"{shape} n={n} grouped, 32-wide planes")
+
+
 @pytest.mark.parametrize("C,H,O,n,bias", [(64, 32, 128, 64, False), (128, 16, 256, 128, True), (256, 8, 512, 256, False),
                                            (32, 16, 64, 256, True), (64, 8, 96, 256, False)])
 def test_shortcut_convolution_with_partials_and_several_channel_tiles(hip_device, C, H, O, n, bias):
