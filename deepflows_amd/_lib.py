@@ -23,6 +23,18 @@ P = c_void_p
 I64P = POINTER(c_int64)
 PP = POINTER(c_void_p)
 
+
+class BnBwdIn(ctypes.Structure):
+    """dfhip_bn_bwd_in (include/dfhip.h): a BatchNorm2d backward pass applied on the consumer's operand loads."""
+    _fields_ = [("z", P), ("rows", P), ("nrows", c_int), ("K", c_int), ("kidx", c_int), ("mean", P), ("var", P),
+                ("gamma", P), ("eps", c_float), ("inv_m", c_float), ("dgamma", P), ("dbeta", P), ("table", P)]
+
+
+class BnStatsOut(ctypes.Structure):
+    """dfhip_bn_stats_out: the partial rows a producer leaves behind for the BatchNorm layers its output feeds."""
+    _fields_ = [("n", c_int), ("z", P * 2), ("mean", P * 2), ("rows", P), ("cap_rows", c_int), ("nrows", c_int)]
+
+
 _SIGS = {
     "dfhip_init": [c_int],
     "dfhip_host_bernoulli_mask": [P, POINTER(c_int), c_double, c_int64, P],
@@ -60,6 +72,12 @@ _SIGS = {
     "dfhip_conv2d_dgrad": [P, P, P] + [c_int] * 9,
     "dfhip_conv2d_dgrad_add": [P, P, P, P] + [c_int] * 9,
     "dfhip_conv2d_dgrad_pair": [P, P, P, P, P, P] + [c_int] * 6 + [POINTER(c_int)],
+    "dfhip_conv2d_bn_bwd_supported": [c_int] * 9 + [POINTER(c_int), POINTER(c_int), POINTER(c_int)],
+    "dfhip_conv2d_dgrad_bn": [P, P, P, P] + [c_int] * 8 + [POINTER(BnBwdIn), POINTER(BnStatsOut)],
+    "dfhip_conv2d_dgrad_pair_bn": [P, P, P, P, P, P] + [c_int] * 5 + [POINTER(BnBwdIn), POINTER(BnBwdIn), POINTER(BnStatsOut)],
+    "dfhip_conv2d_wgrad_bn": [P, P, P, P, P, P] + [c_int] * 8 + [POINTER(c_int)],
+    "dfhip_bn_bwd_table": [POINTER(BnBwdIn), c_int],
+    "dfhip_bn2d_backward_apply_table": [P, P, P, P, c_int, c_int, c_int],
     "dfhip_conv2d_forward_s2_pair": [P, P, P, P, P] + [c_int] * 5 + [P, P, c_int, POINTER(c_int), POINTER(c_int)],
     "dfhip_bn2d_forward_train": [P] * 8 + [c_int, c_int, c_int, c_float, c_float],
     "dfhip_bn2d_forward_eval": [P] * 6 + [c_int, c_int, c_int, c_float],

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "dfhip_internal.h"
+#include "dfhip_bnbwd.h"
 
 using namespace dfhip;
 
@@ -869,619 +870,6 @@ __global__ __launch_bounds__(512) void k_conv_rows3(const float* __restrict__ x,
   STEM_STAMP(5); STEM_STAMP(7);
 }
 
-// ---------------------------------------------------------------------------------------
-// "overwrite" input gradient of a 3x3 / stride 1 / pad 1 convolution, as what it is: the reference's
-// k*k strided assignments (functional.py:285-294, last writer wins) leave, for input pixel (y, x),
-// only the tap (ti, tj) = (y >= 1 ? 2 : 1, x >= 1 ? 2 : 1) and with it the source pixel
-// (max(y-1, 0), max(x-1, 0)):
-//     dX[n][c][y][x] = sum_o dY[n][o][max(y-1,0)][max(x-1,0)] * W[o][c][ti][tj]
-// -- a 1x1 convolution of a shifted, edge-clamped dY with one of four weight slices (interior,
-// top row, left column, corner), 1/9 of the products of the true gradient.  With so little
-// arithmetic the staged kernel above is all fixed cost (12 us for 2.5 us of MFMAs); here a wave owns
-// a 32-pixel x 32-channel tile outright: the dY operand of its pixels is read ONCE from global
-// memory into registers (O/2 coalesced loads), each of the <= 4 weight slices present in the tile
-// is applied with the lanes of the other slices masked, and the tile leaves as sixteen 128-byte
-// stores per half-wave (plus the gradient the tensor already holds, tensor.py:444).  No LDS, no
-// barrier.  Used while O <= 64 (dY operand in registers) and a tile is 32 pixels of one image.
-// ---------------------------------------------------------------------------------------
-// GEO 0: 3x3 / stride 1 / pad 1 (above).  GEO 1: 3x3 / stride 2 / pad 1 -- the surviving tap of pixel
-// (y, x) is (1 + (y & 1), 1 + (x & 1)) and its source (y >> 1, x >> 1): a nearest-neighbour
-// up-sampling of dY followed by one of four 1x1 convolutions by pixel parity.  GEO 2: 1x1 / stride 2 /
-// pad 0 -- even (y, x) receive sum_o dY[o][y/2][x/2] W[o][c], the others stay zero.
-template <int GEO>
-struct OwGeo {
-  static constexpr int NSL = GEO == 2 ? 1 : 4;      // weight slices
-  __device__ static void pixel(int y, int x, int& u, int& v, int& cls) {
-    if (GEO == 0) { u = max(y - 1, 0); v = max(x - 1, 0); cls = (y >= 1 ? 2 : 0) + (x >= 1 ? 1 : 0); }
-    else if (GEO == 1) { u = y >> 1; v = x >> 1; cls = ((y & 1) << 1) + (x & 1); }
-    else { u = y >> 1; v = x >> 1; cls = ((y | x) & 1) ? -1 : 0; }
-  }
-  // lane -> pixel of tile t.  Default: 32 consecutive pixels of the flattened (n, y, x) space.  Stride 2
-  // with pg: the four tiles 4b..4b+3 are the four parity classes of one block of 128 flat pixels (128/W
-  // flat rows), so a tile holds ONE class -- a quarter of the MFMAs of a mixed tile -- and its lanes read
-  // a dense run of dY; the classes' stride-2 stores complete each other's cache lines.
-  __device__ static void decode(int t, int l31, int lw, int H, int pg, int& n, int& y, int& x) {
-    if (GEO == 1 && pg) {
-      const int b = t >> 2, py = (t >> 1) & 1, px = t & 1;
-      const int ry = l31 >> (lw - 1), rx = l31 & ((1 << (lw - 1)) - 1);
-      const int R = b * (128 >> lw) + 2 * ry + py;          // flat row (n * H + y); H is even
-      n = R / H; y = R - n * H; x = 2 * rx + px;
-    } else {
-      const int HW = H << lw, p = t * 32 + l31;
-      n = p / HW;
-      const int rem = p - n * HW;
-      y = rem >> lw; x = rem & ((1 << lw) - 1);
-    }
-  }
-  // the NSL weights of one (o, c) pair, from the (O, C, k, k) tensor
-  __device__ static void slices(const float* __restrict__ w, int64_t oc, float (&out)[4]) {
-    if (GEO == 2) { out[0] = w[oc]; out[1] = out[2] = out[3] = 0.0f; }
-    else { const float* q = w + oc * 9; out[0] = q[4]; out[1] = q[5]; out[2] = q[7]; out[3] = q[8]; }
-  }
-};
-
-// PAIR (GEO 1 only): the block's 1x1 / stride 2 shortcut convolution reads the same input tensor, and its input
-// gradient lands on the pixels with even (y, x) -- parity class 0 of this kernel, same source pixel (y >> 1, x >> 1):
-// dy2 / w2 (O, C, 1, 1) are a FIFTH slice with an operand of its own, and the two gradients of the tensor leave as one
-// sum (tensor.py:444) instead of a second launch that re-reads and re-writes the even pixels.
-template <int O, int GEO, bool PAIR = false>
-__global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ dy, const float* __restrict__ w,
-                                                     const float* __restrict__ add, float* __restrict__ dx,
-                                                     int C, int H, int lw, int tiles, int pg,
-                                                     const float* __restrict__ dy2 = nullptr,
-                                                     const float* __restrict__ w2 = nullptr) {
-  static_assert(!PAIR || GEO == 1, "the shortcut rides on the stride-2 3x3 kernel");
-  constexpr int NP = O / 2, NSL = OwGeo<GEO>::NSL;
-  __shared__ float Wl[NSL + (PAIR ? 1 : 0)][O][32]; // the weight slices of this channel tile: [slice][o][c]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  const int HW = H << lw;
-  const int c0 = blockIdx.y * 32;
-  const int tile = min(blockIdx.x * 4 + wave, tiles - 1);   // 32 consecutive pixels of one image (clamped: a
-  const bool live = blockIdx.x * 4 + wave < tiles;          //  wave past the end still takes part in the barrier)
-  int n, y, x;
-  OwGeo<GEO>::decode(tile, l31, lw, H, pg, n, y, x);
-  const int rem = (y << lw) + x;
-  int u, v, cls;                                    // source pixel, slice q <-> tap (1 + (q >> 1), 1 + (q & 1))
-  OwGeo<GEO>::pixel(y, x, u, v, cls);
-  const int slw = GEO == 0 ? lw : lw - 1;           // source plane: H x W, or H/2 x W/2
-  const int SHW = GEO == 0 ? HW : HW >> 2;
-  // everything this wave needs from global memory is requested up front: its dY operand ...
-  float sv[NP];
-  {
-    const float* sp = dy + ((int64_t)n * O + half) * SHW + (u << slw) + v;
-#pragma unroll
-    for (int kp = 0; kp < NP; kp++) sv[kp] = sp[(int64_t)(2 * kp) * SHW];
-  }
-  float sv2[PAIR ? NP : 1];
-  if constexpr (PAIR) {
-    const float* sp = dy2 + ((int64_t)n * O + half) * SHW + (u << slw) + v;
-#pragma unroll
-    for (int kp = 0; kp < NP; kp++) sv2[kp] = sp[(int64_t)(2 * kp) * SHW];
-  }
-  // ... the gradient the tensor already holds (added in the epilogue; requested now, not after the MFMAs) ...
-  const int64_t obase = ((int64_t)n * C + c0) * HW + rem;
-  float held[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++)
-    held[r] = add ? add[obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW] : 0.0f;
-  // ... and its share of the weight slices (thread -> (o, c) pairs, the four taps 4, 5, 7, 8 of each)
-  constexpr int PAIRS = O * 32 / 256;
-  float wv[PAIRS][4], wv2[PAIRS];
-#pragma unroll
-  for (int i = 0; i < PAIRS; i++) {
-    const int e = threadIdx.x + 256 * i, o = e >> 5, c = e & 31;
-    OwGeo<GEO>::slices(w, (int64_t)o * C + c0 + c, wv[i]);
-    wv2[i] = PAIR ? w2[(int64_t)o * C + c0 + c] : 0.0f;
-  }
-#pragma unroll
-  for (int i = 0; i < PAIRS; i++) {
-    const int e = threadIdx.x + 256 * i, o = e >> 5, c = e & 31;
-#pragma unroll
-    for (int q = 0; q < NSL; q++) Wl[q][o][c] = wv[i][q];
-    if constexpr (PAIR) Wl[NSL][o][c] = wv2[i];
-  }
-  __syncthreads();
-  if (!live) return;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-#pragma unroll
-  for (int q = 0; q < NSL; q++) {
-    const bool mine = cls == q;
-    if (__ballot(mine) == 0ull) continue;
-    float a[NP];
-#pragma unroll
-    for (int kp = 0; kp < NP; kp++) a[kp] = Wl[q][2 * kp + half][l31];
-#pragma unroll
-    for (int kp = 0; kp < NP; kp++)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], mine ? sv[kp] : 0.0f, acc, 0, 0, 0);
-  }
-  if constexpr (PAIR) {
-    const bool mine = cls == 0;
-    if (__ballot(mine) != 0ull) {
-      float a[NP];
-#pragma unroll
-      for (int kp = 0; kp < NP; kp++) a[kp] = Wl[NSL][2 * kp + half][l31];
-#pragma unroll
-      for (int kp = 0; kp < NP; kp++)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], mine ? sv2[kp] : 0.0f, acc, 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 16; r++)
-    dx[obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW] = acc[r] + held[r];
-}
-
-// The same for 128 / 256 output channels: ONE tile per workgroup, its four waves split the reduction
-// over o four ways (each keeps O/8 dY values per lane) and their partial tiles are summed through LDS
-// in wave order.  The weight slices (4 x O x 32 floats) sit in dynamic LDS.
-template <int O, int GEO, bool PAIR = false>
-__global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict__ dy, const float* __restrict__ w,
-                                                        const float* __restrict__ add, float* __restrict__ dx,
-                                                        int C, int H, int lw, int tiles, int pg,
-                                                        const float* __restrict__ dy2 = nullptr,
-                                                        const float* __restrict__ w2 = nullptr) {
-  static_assert(!PAIR || GEO == 1, "the shortcut rides on the stride-2 3x3 kernel");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int OQ = O / 4, NP = OQ / 2, NSL = OwGeo<GEO>::NSL, NSLP = NSL + (PAIR ? 1 : 0);
-  float* Wl = smem;                                 // [NSLP][O][32]
-  float* red = smem + NSLP * O * 32;                // [3][16][64]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  const int HW = H << lw;
-  const int c0 = blockIdx.y * 32;
-  const int slw = GEO == 0 ? lw : lw - 1;           // source plane: H x W, or H/2 x W/2
-  const int SHW = GEO == 0 ? HW : HW >> 2;
-  const int ob = wave * OQ;                         // this wave's slice of the reduction
-  // the weight slices of this channel tile, once per workgroup (it walks several pixel tiles)
-  constexpr int PAIRS = O * 32 / 256;
-  for (int i0 = 0; i0 < PAIRS; i0 += 16) {          // sixteen (o, c) pairs in flight per thread
-    float wv[16][4], wv2[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int e = threadIdx.x + 256 * (i0 + i), o = e >> 5, c = e & 31;
-      OwGeo<GEO>::slices(w, (int64_t)o * C + c0 + c, wv[i]);
-      wv2[i] = PAIR ? w2[(int64_t)o * C + c0 + c] : 0.0f;
-    }
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int e = threadIdx.x + 256 * (i0 + i), o = e >> 5, c = e & 31;
-#pragma unroll
-      for (int q = 0; q < NSL; q++) Wl[(q * O + o) * 32 + c] = wv[i][q];
-      if constexpr (PAIR) Wl[(NSL * O + o) * 32 + c] = wv2[i];
-    }
-  }
-  __syncthreads();
-  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    int n, y, x;
-    OwGeo<GEO>::decode(tile, l31, lw, H, pg, n, y, x);
-    const int rem = (y << lw) + x;
-    int u, v, cls;
-    OwGeo<GEO>::pixel(y, x, u, v, cls);
-    float sv[NP];
-    {
-      const float* sp = dy + ((int64_t)n * O + ob + half) * SHW + (u << slw) + v;
-#pragma unroll
-      for (int kp = 0; kp < NP; kp++) sv[kp] = sp[(int64_t)(2 * kp) * SHW];
-    }
-    float sv2[PAIR ? NP : 1];
-    if constexpr (PAIR) {
-      const float* sp = dy2 + ((int64_t)n * O + ob + half) * SHW + (u << slw) + v;
-#pragma unroll
-      for (int kp = 0; kp < NP; kp++) sv2[kp] = sp[(int64_t)(2 * kp) * SHW];
-    }
-    const int64_t obase = ((int64_t)n * C + c0) * HW + rem;
-    float held[16];                                 // (wave 0 stores the tile: it requests the held gradient now)
-#pragma unroll
-    for (int r = 0; r < 16; r++)
-      held[r] = (add && wave == 0) ? add[obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW] : 0.0f;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-#pragma unroll
-    for (int q = 0; q < NSL; q++) {
-      const bool mine = cls == q;
-      if (__ballot(mine) == 0ull) continue;
-      const float* wq = Wl + (q * O + ob + half) * 32 + l31;
-      float a[NP];
-#pragma unroll
-      for (int kp = 0; kp < NP; kp++) a[kp] = wq[2 * kp * 32];
-#pragma unroll
-      for (int kp = 0; kp < NP; kp++)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], mine ? sv[kp] : 0.0f, acc, 0, 0, 0);
-    }
-    if constexpr (PAIR) {
-      const bool mine = cls == 0;
-      if (__ballot(mine) != 0ull) {
-        const float* wq = Wl + (NSL * O + ob + half) * 32 + l31;
-        float a[NP];
-#pragma unroll
-        for (int kp = 0; kp < NP; kp++) a[kp] = wq[2 * kp * 32];
-#pragma unroll
-        for (int kp = 0; kp < NP; kp++)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], mine ? sv2[kp] : 0.0f, acc, 0, 0, 0);
-      }
-    }
-    if (wave > 0) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-      for (int ww = 0; ww < 3; ww++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] += red[(ww * 16 + r) * 64 + lane];
-#pragma unroll
-      for (int r = 0; r < 16; r++)
-        dx[obase + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * half) * HW] = acc[r] + held[r];
-    }
-    __syncthreads();                                // red is reused by the next tile
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// The overwrite-mode input gradient of a 3x3 / stride 1 / pad 1 convolution on 2 x 2 IMAGES (ResNet layer4): all
-// four input pixels keep a tap whose source is output pixel (0, 0) -- (y, x) -> (max(y - 1, 0), max(x - 1, 0)) --
-// so dX[n][c][q] = sum_o dY[n][o][0][0] W[o][c][{4, 5, 7, 8}[q]]: a plain product of a 256 x O matrix with an
-// O x 4C one whose result IS the NCHW tensor.  The general kernel above gives a tile 8 images x 4 pixels and runs
-// four passes with three quarters of the lanes masked (12 us per launch for 0.13 GFLOP); here a workgroup owns 16
-// images x 16 channels x the four pixels: v_mfma_f32_16x16x4_f32 with an image on the lane, one accumulator per
-// pixel, the four waves split o and are summed through LDS, and a lane leaves with 16-byte stores (its four
-// pixels of a channel are adjacent in memory).
-// ---------------------------------------------------------------------------------------
-template <int O>
-__global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       const float* __restrict__ add, float* __restrict__ dx, int C,
-                                                       int xo) {
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int OQ = O / 4, NK = OQ / 4;             // o per wave, MFMA k-steps per wave
-  float* Wl = smem;                                 // [4 slices][O][16 channels]
-  float* red = smem + 4 * O * 16;                   // [3 waves][16 values][64 lanes]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kk = lane >> 4, n = lane & 15;
-  const DfTile wg = xcd_tile(xo);                   // XCD-aware order (dfhip_internal.h)
-  const int n0 = wg.x * 16, c0 = wg.y * 16;
-  const int ob = wave * OQ;
-  // dY operand of this wave's o range: pixel (0, 0) of image n0 + n, channel ob + 4 p + kk
-  float sv[NK];
-  {
-    const float* sp = dy + ((int64_t)(n0 + n) * O + ob + kk) * 4;
-#pragma unroll
-    for (int p = 0; p < NK; p++) sv[p] = sp[(int64_t)p * 16];
-  }
-  // the gradient the tensor already holds: wave 0 stores the tile and requests its pieces now
-  f32x4 held[4];
-  const int64_t obase = ((int64_t)(n0 + n) * C + c0 + 4 * kk) * 4;
-#pragma unroll
-  for (int v = 0; v < 4; v++) {
-    held[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (add && wave == 0) held[v] = *reinterpret_cast<const f32x4*>(add + obase + 4 * v);
-  }
-  // weight slices: (o, c) pairs, taps 4, 5, 7, 8 of each; 16 pairs per thread in two rounds of eight
-  constexpr int PAIRS = O * 16 / 256;
-#pragma unroll
-  for (int i0 = 0; i0 < PAIRS; i0 += 8) {
-    float wv[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int e = tid + 256 * (i0 + i), o = e >> 4, c = e & 15;
-      const float* q = w + ((int64_t)o * C + c0 + c) * 9;
-      wv[i][0] = q[4]; wv[i][1] = q[5]; wv[i][2] = q[7]; wv[i][3] = q[8];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int e = tid + 256 * (i0 + i), o = e >> 4, c = e & 15;
-#pragma unroll
-      for (int q = 0; q < 4; q++) Wl[(q * O + o) * 16 + c] = wv[i][q];
-    }
-  }
-  __syncthreads();
-  f32x4 acc[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int p = 0; p < NK; p++) {
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[(q * O + ob + 4 * p + kk) * 16 + n], sv[p], acc[q], 0, 0, 0);
-  }
-  if (wave > 0) {
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-      for (int v = 0; v < 4; v++) red[((wave - 1) * 16 + q * 4 + v) * 64 + lane] = acc[q][v];
-  }
-  __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int ww = 0; ww < 3; ww++)
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) acc[q][v] += red[(ww * 16 + q * 4 + v) * 64 + lane];
-    // register v of lane (kk, n) is channel c0 + 4 kk + v of image n0 + n; its four pixels are adjacent
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-      f32x4 r = {acc[0][v], acc[1][v], acc[2][v], acc[3][v]};
-      r += held[v];
-      *reinterpret_cast<f32x4*>(dx + obase + 4 * v) = r;
-    }
-  }
-}
-
-// The same idea on 4 x 4 IMAGES (ResNet layer3): input pixel (y, x) keeps the tap whose source is output pixel
-// (max(y - 1, 0), max(x - 1, 0)) -- one of nine -- with one of four weight slices.  The general kernel's 32-pixel tile
-// (two images) holds all four slices and runs four passes with most lanes masked; here a workgroup owns 16 images x
-// 16 channels x the sixteen pixels: an image on the lane, one accumulator per pixel (16 MFMAs per k-step, none of
-// them masked), the nine source pixels of a k-step are nine loads, the four waves split o and are summed through
-// LDS, and a lane leaves with 16-byte stores (the pixels of a channel are adjacent in memory).
-// GEO 0: 3x3 / stride 1 / pad 1, dY is 4 x 4 (nine sources).  GEO 1: 3x3 / stride 2 / pad 1, dY is 2 x 2: pixel (y, x)
-// keeps tap (1 + (y & 1), 1 + (x & 1)) of source (y >> 1, x >> 1) (four sources); PAIR (GEO 1): the block's 1x1 /
-// stride 2 shortcut adds sum_o dY2[o][y/2][x/2] W2[o][c] on the pixels with even (y, x) -- a fifth slice.
-// GEO 2: the GEO 1 pattern on one 4 x 4 block (blockIdx.z) of an 8 x 8 image whose dY is 4 x 4 (layer3's first
-// block: 256 workgroups where whole images would give 64).  TR: the dY planes are requested in memory order and turned
-// into the image-per-lane order through a wave-private LDS strip (see the operand section below).
-constexpr int kImg4Strip = 16 * 260;     // floats of a wave's transposition strip (16 images x (256 + 4))
-template <int O, int GEO, bool PAIR, bool TR>
-__global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       const float* __restrict__ add, float* __restrict__ dx, int C,
-                                                       const float* __restrict__ dy2, const float* __restrict__ w2, int S,
-                                                       int xo) {
-  static_assert(!PAIR || GEO >= 1, "the shortcut rides on the stride-2 forms");
-  static_assert(GEO != 2 || TR, "the sub-image form reads its planes through the strip");
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int OQ = O / 4, NK = OQ / 4;             // o per wave, MFMA k-steps per wave
-  constexpr int SW = GEO == 0 ? 3 : 2, NS = SW * SW;  // sources per image: SW x SW of a (GEO 0: 4, GEO 1: 2)-wide plane
-  constexpr int PW = GEO == 0 ? 4 : 2, SP = PW * PW;  // dY plane
-  constexpr int NSL = PAIR ? 5 : 4;
-  float* Wl = smem;                                 // [NSL slices][O][16 channels]; later the exchange area [3][16][64] f32x4
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kk = lane >> 4, n = lane & 15;
-  const DfTile wg = xcd_tile(xo);                   // XCD-aware order (dfhip_internal.h)
-  const int n0 = wg.x * 16, c0 = wg.y * 16;
-  const int ob = wave * OQ;
-  // GEO 2: the image is S x S (S = 8), this workgroup's 4 x 4 block of it is (qy, qx); its sources are a 2 x 2 block of
-  // the (S/2) x (S/2) dY plane
-  const int Q = GEO == 2 ? (S >> 2) : 1;
-  const int qy = GEO == 2 ? (int)blockIdx.z / Q : 0, qx = GEO == 2 ? (int)blockIdx.z % Q : 0;
-  // dY operands of this wave's o range: the sources of image n0 + n, channel ob + 4 p + kk.  A lane is an IMAGE, so
-  // read directly every lane of a request is a line of its own and the address unit takes them one per cycle (24-48
-  // requests x 64 lines per wave); instead the wave requests its (16 images x channels) block in the order it lies in
-  // memory -- a request = 1 KB = 8 lines -- and turns it through a wave-private LDS strip (`TR`).
-  float sv[NK][NS], sv2[PAIR ? NK : 1][4];
-  if constexpr (TR) {
-    constexpr int WLF = (NSL * O * 16 > 3 * 16 * 64 * 4) ? NSL * O * 16 : 3 * 16 * 64 * 4;
-    float* strip = smem + WLF + wave * kImg4Strip;
-    if constexpr (GEO == 0) {
-      // chunks of 16 channels: per image 16 x 64 bytes in a row; strip row = an image (256 floats + 4: bank spread)
-      constexpr int NCH = OQ / 16;
-      static_assert(OQ % 16 == 0, "whole chunks");
-      f32x4 t[2][16];
-#pragma unroll
-      for (int i = 0; i < 16; i++)
-        t[0][i] = *reinterpret_cast<const f32x4*>(dy + ((int64_t)(n0 + i) * O + ob) * 16 + lane * 4);
-#pragma unroll
-      for (int ch = 0; ch < NCH; ch++) {
-        if (ch + 1 < NCH) {
-#pragma unroll
-          for (int i = 0; i < 16; i++)
-            t[(ch + 1) & 1][i] = *reinterpret_cast<const f32x4*>(dy + ((int64_t)(n0 + i) * O + ob + 16 * (ch + 1)) * 16 + lane * 4);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) *reinterpret_cast<f32x4*>(strip + i * 260 + lane * 4) = t[ch & 1][i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int pp = 0; pp < 4; pp++)
-#pragma unroll
-          for (int u = 0; u < 3; u++) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(strip + n * 260 + (4 * pp + kk) * 16 + u * 4);
-            sv[4 * ch + pp][u * 3] = r[0]; sv[4 * ch + pp][u * 3 + 1] = r[1]; sv[4 * ch + pp][u * 3 + 2] = r[2];
-          }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-    } else if constexpr (GEO == 2) {
-      // 4 x 4 planes (S = 8) as in GEO 0: chunks of 16 channels, strip row = an image; this block's 2 x 2 sources are
-      // two 8-byte pieces of the lane's plane
-      constexpr int NCH = OQ / 16;
-      static_assert(OQ % 16 == 0, "whole chunks");
-      auto turn2 = [&](const float* src, float (&dst)[NK][4]) {
-        f32x4 t[2][16];
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-          t[0][i] = *reinterpret_cast<const f32x4*>(src + ((int64_t)(n0 + i) * O + ob) * 16 + lane * 4);
-#pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {
-          if (ch + 1 < NCH) {
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-              t[(ch + 1) & 1][i] = *reinterpret_cast<const f32x4*>(src + ((int64_t)(n0 + i) * O + ob + 16 * (ch + 1)) * 16 + lane * 4);
-          }
-#pragma unroll
-          for (int i = 0; i < 16; i++) *reinterpret_cast<f32x4*>(strip + i * 260 + lane * 4) = t[ch & 1][i];
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-          for (int pp = 0; pp < 4; pp++)
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-              typedef float f32x2 __attribute__((ext_vector_type(2)));
-              const f32x2 r = *reinterpret_cast<const f32x2*>(strip + n * 260 + (4 * pp + kk) * 16 + (2 * qy + u) * 4 + 2 * qx);
-              dst[4 * ch + pp][u * 2] = r[0]; dst[4 * ch + pp][u * 2 + 1] = r[1];
-            }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-      };
-      turn2(dy, sv);
-      if constexpr (PAIR) turn2(dy2, sv2);
-    } else {
-      // the 2 x 2 planes: per image OQ x 16 bytes in a row; 64 / OQ images per request; strip row = an image (OQ + 1 float4)
-      constexpr int IPL = 64 / OQ >= 1 ? 64 / OQ : 1, NL = 16 / IPL;
-      static_assert(OQ <= 64 && 64 % OQ == 0, "an image's row fits a request");
-      const int li = lane / OQ, lo = lane % OQ;
-      auto turn = [&](const float* src, float (&dst)[NK][4]) {
-        f32x4 t[NL];
-#pragma unroll
-        for (int i = 0; i < NL; i++)
-          t[i] = *reinterpret_cast<const f32x4*>(src + ((int64_t)(n0 + i * IPL + li) * O + ob + lo) * 4);
-#pragma unroll
-        for (int i = 0; i < NL; i++) *reinterpret_cast<f32x4*>(strip + ((i * IPL + li) * (OQ + 1) + lo) * 4) = t[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int p = 0; p < NK; p++) {
-          const f32x4 r = *reinterpret_cast<const f32x4*>(strip + (n * (OQ + 1) + 4 * p + kk) * 4);
-          dst[p][0] = r[0]; dst[p][1] = r[1]; dst[p][2] = r[2]; dst[p][3] = r[3];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      };
-      turn(dy, sv);
-      if constexpr (PAIR) turn(dy2, sv2);
-    }
-  } else {
-    const float* sp = dy + ((int64_t)(n0 + n) * O + ob + kk) * SP;
-#pragma unroll
-    for (int p = 0; p < NK; p++) {
-      if constexpr (GEO == 1) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(sp + (int64_t)p * 4 * SP);       // the 2 x 2 plane
-        sv[p][0] = t[0]; sv[p][1] = t[1]; sv[p][2] = t[2]; sv[p][3] = t[3];
-      } else {
-#pragma unroll
-        for (int u = 0; u < SW; u++)
-#pragma unroll
-          for (int v = 0; v < SW; v++) sv[p][u * SW + v] = sp[(int64_t)p * 4 * SP + u * PW + v];
-      }
-    }
-    if constexpr (PAIR) {
-      const float* sp2 = dy2 + ((int64_t)(n0 + n) * O + ob + kk) * SP;
-#pragma unroll
-      for (int p = 0; p < NK; p++) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(sp2 + (int64_t)p * 4 * SP);     // the 2 x 2 plane
-        sv2[p][0] = t[0]; sv2[p][1] = t[1]; sv2[p][2] = t[2]; sv2[p][3] = t[3];
-      }
-    }
-  }
-  // weight slices: (o, c) pairs, taps 4, 5, 7, 8 of each (+ the shortcut's weight)
-  constexpr int PAIRS = O * 16 / 256, PB = PAIRS < 8 ? PAIRS : 8;
-  static_assert(PAIRS % PB == 0, "weight staging rounds");
-#pragma unroll
-  for (int i0 = 0; i0 < PAIRS; i0 += PB) {
-    float wv[PB][4], wv2[PB];
-#pragma unroll
-    for (int i = 0; i < PB; i++) {
-      const int e = tid + 256 * (i0 + i), o = e >> 4, c = e & 15;
-      const float* q = w + ((int64_t)o * C + c0 + c) * 9;
-      wv[i][0] = q[4]; wv[i][1] = q[5]; wv[i][2] = q[7]; wv[i][3] = q[8];
-      wv2[i] = PAIR ? w2[(int64_t)o * C + c0 + c] : 0.0f;
-    }
-#pragma unroll
-    for (int i = 0; i < PB; i++) {
-      const int e = tid + 256 * (i0 + i), o = e >> 4, c = e & 15;
-#pragma unroll
-      for (int q = 0; q < 4; q++) Wl[(q * O + o) * 16 + c] = wv[i][q];
-      if constexpr (PAIR) Wl[(4 * O + o) * 16 + c] = wv2[i];
-    }
-  }
-  __syncthreads();
-  f32x4 acc[16];
-#pragma unroll
-  for (int q = 0; q < 16; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int p = 0; p < NK; p++) {
-    float a[NSL];
-#pragma unroll
-    for (int q = 0; q < NSL; q++) a[q] = Wl[(q * O + ob + 4 * p + kk) * 16 + n];
-#pragma unroll
-    for (int y = 0; y < 4; y++)
-#pragma unroll
-      for (int x = 0; x < 4; x++) {
-        int u, v, cls;
-        if (GEO == 0) { u = y >= 1 ? y - 1 : 0; v = x >= 1 ? x - 1 : 0; cls = (y >= 1 ? 2 : 0) + (x >= 1 ? 1 : 0); }
-        else { u = y >> 1; v = x >> 1; cls = ((y & 1) << 1) + (x & 1); }
-        acc[y * 4 + x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cls], sv[p][u * SW + v], acc[y * 4 + x], 0, 0, 0);
-      }
-  }
-  if constexpr (PAIR) {
-    // the shortcut's gradient: pixel (2u, 2v) <- dY2[u][v]
-#pragma unroll
-    for (int p = 0; p < NK; p++) {
-      const float a5 = Wl[(4 * O + ob + 4 * p + kk) * 16 + n];
-#pragma unroll
-      for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int v = 0; v < 2; v++)
-          acc[(2 * u) * 4 + 2 * v] = __builtin_amdgcn_mfma_f32_16x16x4f32(a5, sv2[p][u * 2 + v], acc[(2 * u) * 4 + 2 * v], 0, 0, 0);
-    }
-  }
-  __syncthreads();                                  // the weight image is dead: it becomes the exchange area
-  f32x4* ex = reinterpret_cast<f32x4*>(smem);
-  if (wave > 0) {
-#pragma unroll
-    for (int q = 0; q < 16; q++) ex[((wave - 1) * 16 + q) * 64 + lane] = acc[q];
-  }
-  __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int ww = 0; ww < 3; ww++)
-#pragma unroll
-      for (int q = 0; q < 16; q++) acc[q] += ex[(ww * 16 + q) * 64 + lane];
-    // register v of lane (kk, n) is channel c0 + 4 kk + v of image n0 + n; its sixteen pixels are adjacent
-    // (GEO 2: rows of the block are S floats apart in an S x S plane)
-    const int rowp = GEO == 2 ? S : 4, plane = GEO == 2 ? S * S : 16;
-    const int64_t obase = ((int64_t)(n0 + n) * C + c0 + 4 * kk) * plane + (GEO == 2 ? 4 * qy * S + 4 * qx : 0);
-#pragma unroll
-    for (int v = 0; v < 4; v++)
-#pragma unroll
-      for (int y = 0; y < 4; y++) {
-        f32x4 r = {acc[y * 4][v], acc[y * 4 + 1][v], acc[y * 4 + 2][v], acc[y * 4 + 3][v]};
-        if (add) r += *reinterpret_cast<const f32x4*>(add + obase + (int64_t)plane * v + rowp * y);
-        *reinterpret_cast<f32x4*>(dx + obase + (int64_t)plane * v + rowp * y) = r;
-      }
-  }
-}
-
-template <int O, int GEO, bool PAIR>
-int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* dx, int N, int C, const float* dy2,
-                      const float* w2, int S = 4) {
-  static int tr_env = getenv("DFHIP_IMG4_TR") ? atoi(getenv("DFHIP_IMG4_TR")) : 1;
-  const int tr = GEO == 2 ? 1 : tr_env;
-  dim3 grid((unsigned)(N / 16), (unsigned)(C / 16), (unsigned)(GEO == 2 ? (S / 4) * (S / 4) : 1));
-  const size_t base = std::max((size_t)(PAIR ? 5 : 4) * O * 16, (size_t)3 * 16 * 64 * 4) * sizeof(float);
-  const size_t lds = base + (tr ? (size_t)4 * kImg4Strip * sizeof(float) : 0);
-  // blockIdx.y selects 16 input channels' weight columns (NSL slices x O), blockIdx.x 16 images of dY
-  const int dyp = GEO == 0 ? 16 : (GEO == 1 ? 4 : (S / 2) * (S / 2));
-  const int xo = xcd_arrangement(N / 16, C / 16, 4.0 * N * O * dyp * (PAIR ? 2 : 1), 4.0 * O * C * (PAIR ? 5 : 4));
-  static bool attr = false;
-  if (!attr) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)std::max(base + (size_t)4 * kImg4Strip * sizeof(float), (size_t)65536)));
-    if constexpr (GEO != 2)
-      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)std::max(base, (size_t)65536)));
-    attr = true;
-  }
-  if constexpr (GEO == 2) {
-    DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
-  } else {
-    if (tr) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
-    else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, false>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
-  }
-  DF_LAUNCH_CHECK();
-  return DFHIP_OK;
-}
 
 // ---------------------------------------------------------------------------------------
 // forward, 1x1 / stride 2 / pad 0 (the ResNet shortcut convolutions): K = C is 16-64 MFMAs per
@@ -3364,7 +2752,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_conv_wgrad_rows(RGeo g) {
 // cut into fewer, longer workgroups than a stand-alone launch would need to fill the chip, which
 // also divides the slab traffic.  k_wgrad_group_sum then sums every layer's slabs in one launch.
 // ---------------------------------------------------------------------------------------
-constexpr int kMaxGroup = 24;
+constexpr int kMaxGroup = 21;        // (the launch's argument block stays below 4 KB)
 struct GDesc {
   const float* x;
   const float* dy;
@@ -3379,7 +2767,16 @@ struct GDesc {
   float* slabs2;             //   gradient this layer's workgroups compute too (group_flush pairs the two queue entries)
   const float* aff;          // direct only, or nullptr: C x (scale, shift), the source operand is x * scale + shift
                              // (the BatchNorm a convolution applied to its input on load: dfhip_conv2d_forward_bn_input)
+  // direct only, or nullptr: dy is the gradient of a BatchNorm OUTPUT whose backward pass has not been applied
+  // (dfhip_bnbwd.h): the operand is A dy + B (z - mean) + Cc with z = bnz and (A, B, mean, Cc) = bntab[o]; bnz2 / bntab2: the
+  // same for dy2
+  const float* bnz;
+  const float4* bntab;
+  const float* bnz2;
+  const float4* bntab2;
+#ifdef DFHIP_STAMPS
   unsigned long long* dbg;   // diagnostic builds: per-workgroup cycles (load issue, MFMA section) of wave 0
+#endif
 };
 struct WGroup {
   int n;
@@ -3441,11 +2838,13 @@ constexpr int wg_nth_used_row(int n) {
     if (wg_row_used<KS, STRIDE, UR>(xr) && n-- == 0) return xr;
   return 0;
 }
-template <int NP, int UR, int OW, int NXR, int W, bool PAIR>
+template <int NP, int UR, int OW, int NXR, int W, bool PAIR, bool BN>
 struct WgOps {
   float a[NP][UR][OW];
   float a2[PAIR ? NP : 1][PAIR ? UR : 1][PAIR ? OW : 1];    // PAIR: dY of the block's 1x1 shortcut (see wgrad_rows_direct)
   float b[NP][NXR][W];
+  float az[BN ? NP : 1][BN ? UR : 1][BN ? OW : 1];          // BN: the BatchNorm input under dY (and under the shortcut's dY)
+  float az2[(BN && PAIR) ? NP : 1][(BN && PAIR) ? UR : 1][(BN && PAIR) ? OW : 1];
 };
 struct WgUnit {
   int rs;            // source row of (output row 0, tap row 0)
@@ -3457,7 +2856,10 @@ struct WgUnit {
 // pixels of the centre tap, so its gradient is one more accumulator fed by the same source operand and the shortcut's own dY
 // (d.dy2, same shape as dY): the 1x1 layers stop being launches of their own kind -- units of 2-8 MFMAs per image pair, bound
 // by their loads (5.5 % of the grouped launch's cycles for 0.7 % of its MFMAs).
-template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP, bool PAIR>
+// BN: dY (and the shortcut's dY) are gradients of BatchNorm outputs whose backward pass is applied here, on the operand: a lane
+// is an output channel, so the channel's (A, B, mean, Cc) are four registers; the BatchNorm input z arrives through pieces of
+// its own (same offsets as dY) and a row of dY becomes A dy + B (z - mean) + Cc when the MFMAs first reach it.
+template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP, bool PAIR, bool BN>
 __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, const int bx, const int by,
                                                   const int bz) {
   static_assert(!PAIR || (KS == 3 && STRIDE == 2 && PAD == 1), "the shortcut rides on the 3x3 / stride-2 body");
@@ -3481,6 +2883,18 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t y2res =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PAIR ? d.dy2 : d.dy), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t zres =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((BN && d.bnz) ? d.bnz : d.dy), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t z2res =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((BN && PAIR && d.bnz2) ? d.bnz2 : (PAIR ? d.dy2 : d.dy)), 0, 0x7fffffff,
+                                        0x00020000);
+  // (a descriptor without a table -- one of the two gradients of a PAIR is a plain one -- is the identity; its z pieces
+  // re-read dY)
+  float4 bt = make_float4(1.0f, 0.0f, 0.0f, 0.0f), bt2 = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+  if constexpr (BN) {
+    if (d.bntab) bt = d.bntab[bz * 32 + l31];
+    if constexpr (PAIR) { if (d.bntab2) bt2 = d.bntab2[bz * 32 + l31]; }
+  }
   const int xlane = ((half * d.C + by * 32 + l31) * xplane) * 4;
   const int ylane = ((half * d.O + bz * 32 + l31) * yplane) * 4;
   const unsigned xpair = (unsigned)(2 * d.C * xplane) * 4u, ypair = (unsigned)(2 * d.O * yplane) * 4u;
@@ -3508,9 +2922,10 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
   constexpr int PA = UR * (OW / VA), PBR = W / VB;
   constexpr int NUSED = wg_used_rows<KS, STRIDE, UR>();
   constexpr int PA2 = PAIR ? 2 * PA : PA;                   // (PAIR: the shortcut's dY rows follow the convolution's)
-  constexpr int PPP = PA2 + NUSED * PBR;                    // pieces per pair
+  constexpr int PAZ = BN ? PA2 : 0;                         // (BN: then the BatchNorm inputs under both)
+  constexpr int PPP = PA2 + PAZ + NUSED * PBR;              // pieces per pair
   constexpr int NPIECE = NP * PPP;
-  typedef WgOps<NP, UR, OW, NXR, W, PAIR> Ops;
+  typedef WgOps<NP, UR, OW, NXR, W, PAIR, BN> Ops;
   auto piece = [&](Ops& o, const WgUnit& un, int k) {      // k is a compile-time constant at every call
     const int p = k / PPP, kk = k % PPP;
     if (kk < PA) {
@@ -3533,10 +2948,30 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
         const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(y2res, ylane + 8 * q, so, 0));
         o.a2[p][ur][2 * q] = t.x; o.a2[p][ur][2 * q + 1] = t.y;
       }
+    } else if (BN && kk < PA2 + PA) {
+      const int k2 = kk - PA2, ur = k2 / (OW / VA), q = k2 % (OW / VA);
+      const unsigned so = un.ybase + (unsigned)p * ypair + (unsigned)(ur * OW * 4);
+      if constexpr (VA == 4) {
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zres, ylane + 16 * q, so, 0));
+        o.az[p][ur][4 * q] = t.x; o.az[p][ur][4 * q + 1] = t.y; o.az[p][ur][4 * q + 2] = t.z; o.az[p][ur][4 * q + 3] = t.w;
+      } else {
+        const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(zres, ylane + 8 * q, so, 0));
+        o.az[p][ur][2 * q] = t.x; o.az[p][ur][2 * q + 1] = t.y;
+      }
+    } else if (BN && PAIR && kk < PA2 + PAZ) {
+      const int k2 = kk - PA2 - PA, ur = k2 / (OW / VA), q = k2 % (OW / VA);
+      const unsigned so = un.ybase + (unsigned)p * ypair + (unsigned)(ur * OW * 4);
+      if constexpr (VA == 4) {
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z2res, ylane + 16 * q, so, 0));
+        o.az2[p][ur][4 * q] = t.x; o.az2[p][ur][4 * q + 1] = t.y; o.az2[p][ur][4 * q + 2] = t.z; o.az2[p][ur][4 * q + 3] = t.w;
+      } else {
+        const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(z2res, ylane + 8 * q, so, 0));
+        o.az2[p][ur][2 * q] = t.x; o.az2[p][ur][2 * q + 1] = t.y;
+      }
     } else {
       // the kk-th used source row
-      const int xr = wg_nth_used_row<KS, STRIDE, UR>((kk - PA2) / PBR);
-      const int q = (kk - PA2) % PBR;
+      const int xr = wg_nth_used_row<KS, STRIDE, UR>((kk - PA2 - PAZ) / PBR);
+      const int q = (kk - PA2 - PAZ) % PBR;
       const int row = min(max(un.rs + xr, 0), H - 1);
       const unsigned so = un.xbase + (unsigned)p * xpair + (unsigned)(row * W * 4);
       if constexpr (VB == 4) {
@@ -3584,6 +3019,16 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
           // (a scalar branch per tap row even where the unit is the whole plane and the answer is known at compile time: as one
           // basic block the unit of a 2 x 2 plane took 50 600 cycles per workgroup against 44 700 -- same box, -DDFHIP_STAMPS)
           const bool rowok = (unsigned)(cu.rs + ur * STRIDE + i) < (unsigned)H;
+          if constexpr (BN) {
+            if (i == 0) {                                    // first use of output row ur of pair p
+#pragma unroll
+              for (int s = 0; s < OW; s++) c.a[p][ur][s] = bn_bwd_point(c.a[p][ur][s], c.az[p][ur][s], bt);
+              if constexpr (PAIR) {
+#pragma unroll
+                for (int s = 0; s < OW; s++) c.a2[p][ur][s] = bn_bwd_point(c.a2[p][ur][s], c.az2[p][ur][s], bt2);
+              }
+            }
+          }
           if (affine && (ur == 0 || i + STRIDE >= KS)) {     // first use of source row ur * STRIDE + i
 #pragma unroll
             for (int cc = 0; cc < W; cc++) c.b[p][ur * STRIDE + i][cc] = fmaf(c.b[p][ur * STRIDE + i][cc], aff_sc, aff_sh);
@@ -3686,12 +3131,18 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
 
 template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP>
 __device__ __forceinline__ void wgrad_direct_any(const GDesc& d, float* smem, const int bx, const int by, const int bz) {
+  const bool bn = d.bnz != nullptr || d.bnz2 != nullptr;
   if constexpr (KS == 3 && STRIDE == 2) {
-    if (d.dy2) wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, true>(d, smem, bx, by, bz);
-    else wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, false>(d, smem, bx, by, bz);
-  } else {
-    wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, false>(d, smem, bx, by, bz);
+    if (d.dy2) {
+      if (bn) wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, true, true>(d, smem, bx, by, bz);
+      else wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, true, false>(d, smem, bx, by, bz);
+      return;
+    }
   }
+  if constexpr (W <= 16) {       // (the BatchNorm operand exists for the planes of the CIFAR models' residual stages)
+    if (bn) { wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, false, true>(d, smem, bx, by, bz); return; }
+  }
+  wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, false, false>(d, smem, bx, by, bz);
 }
 
 // (id, kernel, pad, stride, W, OW, output rows per unit, image pairs per unit of the direct body: units of few MFMAs are
@@ -4552,7 +4003,9 @@ struct GQueued {
 std::vector<GQueued> g_queue;
 bool g_group_on = false;
 int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
-                   int k, int stride, int pad, const float* aff = nullptr);
+                   int k, int stride, int pad, const float* aff = nullptr, const float* bnz = nullptr,
+                   const float* bntab = nullptr);
+int bn_bwd_materialise(const float* dy, const float* z, const float* tab, float* dz, int N, int O, int HW);
 int wgrad_affine_materialised(const float* x, const float* aff, const float* dy, float* dw, int N, int C, int H, int W,
                               int O, int oh, int ow, int k, int stride, int pad);
 
@@ -4616,13 +4069,23 @@ int group_flush() {
       g_group_on = false;
       int st = DFHIP_OK;
       for (auto& e : q) {
+        const float* edy = e.d.dy;
+        float* tmp = nullptr;
+        if (e.d.bnz) {                              // the pending BatchNorm backward written out once
+          st = dfhip_malloc((int64_t)e.d.N * e.d.O * e.d.oh * e.ow, &tmp);
+          if (st != DFHIP_OK) break;
+          st = bn_bwd_materialise(e.d.dy, e.d.bnz, reinterpret_cast<const float*>(e.d.bntab), tmp, e.d.N, e.d.O, e.d.oh * e.ow);
+          if (st != DFHIP_OK) { (void)dfhip_free(tmp); break; }
+          edy = tmp;
+        }
         if (e.d.aff)
-          st = wgrad_affine_materialised(e.d.x, e.d.aff, e.d.dy, e.dw, e.d.N, e.d.C, e.d.H, e.W, e.d.O, e.d.oh, e.ow,
+          st = wgrad_affine_materialised(e.d.x, e.d.aff, edy, e.dw, e.d.N, e.d.C, e.d.H, e.W, e.d.O, e.d.oh, e.ow,
                                          e.k, e.stride, e.pad);
         else
-          st = run_wgrad_rows(e.d.x, e.d.dy, e.dw, e.d.N, e.d.C, e.d.H, e.W, e.d.O, e.d.oh, e.ow, e.k, e.stride, e.pad);
+          st = run_wgrad_rows(e.d.x, edy, e.dw, e.d.N, e.d.C, e.d.H, e.W, e.d.O, e.d.oh, e.ow, e.k, e.stride, e.pad);
         if (st < 0)                                 // (a shape the stand-alone row kernel does not take: the general path)
-          st = dfhip_conv2d_wgrad(e.d.x, e.d.dy, e.dw, e.d.N, e.d.C, e.d.H, e.W, e.d.O, e.k, e.stride, e.pad);
+          st = dfhip_conv2d_wgrad(e.d.x, edy, e.dw, e.d.N, e.d.C, e.d.H, e.W, e.d.O, e.k, e.stride, e.pad);
+        if (tmp) (void)dfhip_free(tmp);             // stream-ordered pool: later work on the stream may reuse it
         if (st != DFHIP_OK) break;
       }
       g_group_on = was;
@@ -4634,6 +4097,7 @@ int group_flush() {
     e.work = e.d.direct ? replan_direct(e, target) : (double)e.d.N * e.d.oh * e.d.oh * e.T / e.d.ps * 16.0;
     e.rides_on = -1;
     e.d.dy2 = nullptr; e.d.slabs2 = nullptr;
+    e.d.bnz2 = nullptr; e.d.bntab2 = nullptr;
   }
   // longest workgroups first (they are dispatched in grid order): the launch ends on short ones
   std::stable_sort(q.begin(), q.end(), [](const GQueued& a, const GQueued& b) { return a.work > b.work; });
@@ -4653,6 +4117,7 @@ int group_flush() {
           sc.rides_on = (int)a;
           sc.d.ps = cv.d.ps;
           cv.d.dy2 = sc.d.dy;
+          cv.d.bnz2 = sc.d.bnz; cv.d.bntab2 = sc.d.bntab;
           break;
         }
       }
@@ -4719,7 +4184,9 @@ int group_flush() {
     if (stamp_mode) {
       wg.ticks = (unsigned long long*)workspace2((size_t)wgs * 8 * 5);
       (void)hipMemsetAsync(wg.ticks, 0, (size_t)wgs * 8 * 5, gst);
+#ifdef DFHIP_STAMPS
       for (int i = 0; i < nl; i++) wg.d[i].dbg = wg.ticks + wgs;
+#endif
       (void)hipEventCreate(&se0); (void)hipEventCreate(&se1);
       (void)hipEventRecord(se0, gst);
     }
@@ -4832,10 +4299,11 @@ int side_join() {
 
 // returns -1 when the shape is not one the row-unit kernel is built for
 int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
-                   int k, int stride, int pad, const float* aff) {
+                   int k, int stride, int pad, const float* aff, const float* bnz, const float* bntab) {
   static int enabled = getenv("DFHIP_WGRAD_ROWS") ? atoi(getenv("DFHIP_WGRAD_ROWS")) : 1;
   if (!enabled) return -1;
   if (aff && !g_group_on) return -1;        // the affine operand exists in the grouped direct body only
+  if (bnz && (!g_group_on || W > 16)) return -1;   // so does the BatchNorm-backward operand (planes up to 16 wide)
   if (C < 16 || (N & 1)) return -1;
   const bool k3 = k == 3 && pad == 1, k1 = k == 1 && pad == 0 && stride == 2;
   if (!k3 && !k1) return -1;
@@ -4929,8 +4397,9 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
     static int direct_on = getenv("DFHIP_WGRAD_DIRECT") ? atoi(getenv("DFHIP_WGRAD_DIRECT")) : 1;
     const bool direct = direct_on && C % 32 == 0 && O % 32 == 0 && (N / 2) % NPk == 0;
     if (!direct && !staged_plan) return -1;
-    if (aff && !direct) return -1;
+    if ((aff || bnz) && !direct) return -1;
     d.aff = aff;
+    d.bnz = bnz; d.bntab = reinterpret_cast<const float4*>(bntab);
     if (direct) {
       // operands straight from global memory: a block takes a contiguous run of units (a multiple of 4)
       const int upr = oh / UR, U = (N / (2 * NPk)) * upr;
@@ -4968,6 +4437,44 @@ __global__ __launch_bounds__(256) void k_affine_nchw(const float* __restrict__ x
   float4 v = reinterpret_cast<const float4*>(x)[i];
   v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
   reinterpret_cast<float4*>(y)[i] = v;
+}
+
+// dz[n][o][:] = A dy + B (z - mean) + Cc with (A, B, mean, Cc) = tab[o]: a pending BatchNorm backward (dfhip_bnbwd.h) written
+// out, for the consumers that have no operand path for it (16-byte pieces; HW % 4 == 0)
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_table(const float* __restrict__ dy, const float* __restrict__ z,
+                                                           const float4* __restrict__ tab, float* __restrict__ dz, int O,
+                                                           int hw4, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 t = tab[(int)((i / hw4) % O)];
+  const float4 g = reinterpret_cast<const float4*>(dy)[i], v = reinterpret_cast<const float4*>(z)[i];
+  float4 r;
+  r.x = bn_bwd_point(g.x, v.x, t); r.y = bn_bwd_point(g.y, v.y, t);
+  r.z = bn_bwd_point(g.z, v.z, t); r.w = bn_bwd_point(g.w, v.w, t);
+  reinterpret_cast<float4*>(dz)[i] = r;
+}
+
+int bn_bwd_materialise(const float* dy, const float* z, const float* tab, float* dz, int N, int O, int HW) {
+  if (HW % 4 != 0) {
+    set_error("bn2d_backward_apply_table: H * W must be a multiple of 4");
+    return DFHIP_INVALID_ARGUMENT;
+  }
+  const int64_t n = (int64_t)N * O * HW;
+  ProfScope prof("bn2d_bwd", 0.0, 12.0 * (double)n);
+  DF_LAUNCH(k_bn_bwd_apply_table, dim3((unsigned)df_ceil_div(n / 4, 256)), dim3(256), 0, stream(), dy, z,
+            reinterpret_cast<const float4*>(tab), dz, O, HW / 4, n / 4);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+// the table (and dgamma / dbeta) of a pending BatchNorm backward from the rows its producer left behind, as a launch of
+// its own: for a convolution that needs no input gradient (the input-gradient kernels build the table themselves)
+__global__ __launch_bounds__(256) void k_bn_bwd_table(const BnBwdIn b, int O) {
+  __shared__ float4 tab[256];
+  __shared__ __attribute__((aligned(16))) float part[kBnPartFloats];
+  BnTableBuilder<256> tb;
+  tb.issue(b, O);
+  tb.finish(b, O, tab, part, true);
 }
 
 // fall-back of dfhip_conv2d_wgrad_affine: the operand is written out once and the weight gradient runs NOW on the
@@ -5257,7 +4764,8 @@ int dfhip_conv2d_forward_s2_pair(const float* x, const float* w, const float* wd
 }
 
 static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, float* dx, int N, int C, int H,
-                             int W, int O, int k, int stride, int pad, int mode) {
+                             int W, int O, int k, int stride, int pad, int mode, const BnBwdIn* bi = nullptr,
+                             BnStatsOut* so = nullptr) {
   int oh, ow;
   int s = check_conv_args("conv2d_dgrad", N, C, H, W, O, k, stride, pad, oh, ow);
   if (s != DFHIP_OK) return s;
@@ -5275,85 +4783,17 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
   g.CD = C; g.HD = H; g.WD = W;
   g.k = k; g.so = 1; g.sd = stride; g.u0 = pad - (k - 1);
   g.mode = mode == 0 ? 2 : 1; g.wC = C; g.pad = pad; g.stride = stride; g.oh = oh; g.ow = ow;
-  {
-    // overwrite mode, 3x3 / stride 1 / pad 1, few output channels: the shifted 1x1 kernel
-    static int lean = getenv("DFHIP_DGRAD_LEAN") ? atoi(getenv("DFHIP_DGRAD_LEAN")) : 1;
-    int lw = 0;
-    while ((1 << lw) < W) lw++;
-    // (a tile is 32 consecutive pixels of the flattened (n, y, x) space; every lane decodes its own pixel)
-    const int geo = (k == 3 && stride == 1 && pad == 1) ? 0 : (k == 3 && stride == 2 && pad == 1) ? 1
-                    : (k == 1 && stride == 2 && pad == 0) ? 2 : -1;
-    const bool lean_ok = lean && mode == 0 && geo >= 0 && C % 32 == 0 && (1 << lw) == W && H >= 2 && W >= 2 &&
-                         ((int64_t)N * H * W) % 32 == 0 && (geo == 0 || (H % 2 == 0 && oh * 2 == H && ow * 2 == W));
-    const int tiles = lean_ok ? (int)((int64_t)N * H * W / 32) : 0;
-    // stride 2: parity-grouped tiles when whole 128-pixel blocks tile the tensor
-    const int pg = (geo == 1 && ((int64_t)N * H * W) % 128 == 0 && W <= 64) ? 1 : 0;
-    static int img2 = getenv("DFHIP_DGRAD_IMG2") ? atoi(getenv("DFHIP_DGRAD_IMG2")) : 1;
-    if (lean && img2 && mode == 0 && geo == 0 && H == 2 && W == 2 && N % 16 == 0 && C % 16 == 0 &&
-        (O == 128 || O == 256 || O == 512)) {
-      // 2 x 2 images: a plain product (k_dgrad_ow_img2)
-      dim3 grid((unsigned)(N / 16), (unsigned)(C / 16));
-      const size_t lds = ((size_t)4 * O * 16 + 3 * 16 * 64) * sizeof(float);
-      // blockIdx.y selects 16 input channels' weight columns (all O, four taps), blockIdx.x 16 images of dY
-      const int xo2 = xcd_arrangement(N / 16, C / 16, 4.0 * N * O * 4, 4.0 * O * C * 4);
-#define DF_I2(OV)                                                                                          \
-  do {                                                                                                     \
-    static bool attr = false;                                                                              \
-    if (!attr) {                                                                                           \
-      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img2<OV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                 (int)std::max(lds, (size_t)65536)));                                      \
-      attr = true;                                                                                         \
-    }                                                                                                      \
-    DF_LAUNCH(k_dgrad_ow_img2<OV>, grid, dim3(256), lds, stream(), dy, w, add, dx, C, xo2);                \
-  } while (0)
-      if (O == 128) DF_I2(128); else if (O == 256) DF_I2(256); else DF_I2(512);
-#undef DF_I2
-      DF_LAUNCH_CHECK();
-      return DFHIP_OK;
+  if (mode == 0) {
+    // overwrite mode: the kernels without phases of dfhip_dgrad_ow.hip (one surviving tap per input pixel)
+    const int st = run_dgrad_ow(dy, w, add, dx, N, C, H, W, O, k, stride, pad, bi, so);
+    if (st != -1) {
+      if (st == -2) { set_error("conv2d_dgrad: no kernel with the BatchNorm descriptors for this shape (query dfhip_conv2d_bn_bwd_supported first)"); return DFHIP_INVALID_ARGUMENT; }
+      return st;
     }
-    static int img4 = getenv("DFHIP_DGRAD_IMG4") ? atoi(getenv("DFHIP_DGRAD_IMG4")) : 1;
-    if (lean && img4 && mode == 0 && (geo == 0 || geo == 1) && H == 4 && W == 4 && N % 16 == 0 && C % 16 == 0 &&
-        ((geo == 0 && (O == 64 || O == 128)) || (geo == 1 && (O == 128 || O == 256)))) {
-      // 4 x 4 images: 16 images x 16 channels x 16 pixels per workgroup, no masked lanes (k_dgrad_ow_img4)
-      const float* none = nullptr;
-      if (geo == 0) return O == 64 ? launch_dgrad_img4<64, 0, false>(dy, w, add, dx, N, C, none, none)
-                                   : launch_dgrad_img4<128, 0, false>(dy, w, add, dx, N, C, none, none);
-      return O == 128 ? launch_dgrad_img4<128, 1, false>(dy, w, add, dx, N, C, none, none)
-                      : launch_dgrad_img4<256, 1, false>(dy, w, add, dx, N, C, none, none);
-    }
-    if (lean_ok && (O == 128 || O == 256)) {
-      // about two workgroups per CU (one at 256 channels: 140 KB of LDS); each walks tiles / grid.x tiles
-      // (1x1: the slice is small, one tile per workgroup)
-      const int want = geo == 2 ? tiles : std::max(1, num_cus() * (O == 128 ? 2 : 1) / (C / 32));
-      dim3 grid((unsigned)std::min(tiles, want), (unsigned)(C / 32));
-      const size_t lds = ((size_t)(geo == 2 ? 1 : 4) * O * 32 + 3 * 16 * 64) * sizeof(float);
-#define DF_KS(OV, GV)                                                                                         \
-  do {                                                                                                        \
-    static bool attr = false;                                                                                 \
-    if (!attr) {                                                                                              \
-      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_s1_ks<OV, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                 (int)std::max(lds, (size_t)65536)));                                         \
-      attr = true;                                                                                            \
-    }                                                                                                         \
-    DF_LAUNCH((k_dgrad_ow_s1_ks<OV, GV>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, H, lw, tiles, pg, \
-              (const float*)nullptr, (const float*)nullptr);                                                    \
-  } while (0)
-      if (O == 128) { if (geo == 0) DF_KS(128, 0); else if (geo == 1) DF_KS(128, 1); else DF_KS(128, 2); }
-      else { if (geo == 0) DF_KS(256, 0); else if (geo == 1) DF_KS(256, 1); else DF_KS(256, 2); }
-#undef DF_KS
-      DF_LAUNCH_CHECK();
-      return DFHIP_OK;
-    }
-    if (lean_ok && (O == 32 || O == 64)) {
-      dim3 grid((unsigned)df_ceil_div(tiles, 4), (unsigned)(C / 32));
-#define DF_A(OV, GV) DF_LAUNCH((k_dgrad_ow_s1<OV, GV>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg, \
-                               (const float*)nullptr, (const float*)nullptr)
-      if (O == 32) { if (geo == 0) DF_A(32, 0); else if (geo == 1) DF_A(32, 1); else DF_A(32, 2); }
-      else { if (geo == 0) DF_A(64, 0); else if (geo == 1) DF_A(64, 1); else DF_A(64, 2); }
-#undef DF_A
-      DF_LAUNCH_CHECK();
-      return DFHIP_OK;
-    }
+  }
+  if (bi || so) {
+    set_error("conv2d_dgrad: no kernel with the BatchNorm descriptors for this shape (query dfhip_conv2d_bn_bwd_supported first)");
+    return DFHIP_INVALID_ARGUMENT;
   }
   if (mode == 1) {
     // 2 x 2 images: the forward's all-positions kernel with the roles of the channel counts swapped (k_conv3x3_img2_all<DG>)
@@ -5396,6 +4836,26 @@ int dfhip_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C,
   return conv2d_dgrad_impl(dy, w, nullptr, dx, N, C, H, W, O, k, stride, pad, mode);
 }
 
+// the overwrite-mode pair launch (dfhip_dgrad_ow.hip) inside its profiling bracket; *done = 0: no kernel for the shape
+static int dgrad_pair_overwrite(const float* dy, const float* w, const float* dy2, const float* w2, const float* add,
+                                float* dx, int N, int C, int H, int W, int O, const BnBwdIn* bi, const BnBwdIn* bi2,
+                                BnStatsOut* so, int* done) {
+  const int oh = H / 2, ow = W / 2;
+  const int t = run_dgrad_ow_pair(dy, w, dy2, w2, add, dx, N, C, H, W, O, bi, bi2, so, true);
+  if (t < 0) {
+    if (bi || bi2 || so) { set_error("conv2d_dgrad_pair: no kernel with the BatchNorm descriptors for this shape"); return DFHIP_INVALID_ARGUMENT; }
+    return DFHIP_OK;
+  }
+  const double flops = 2.0 * N * H * W * (double)C * O + 2.0 * N * oh * ow * (double)C * O;
+  const double bytes = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * oh * ow);
+  ProfScope prof("conv2d_dgrad_overwrite_igemm", flops, bytes);
+  const int st = run_dgrad_ow_pair(dy, w, dy2, w2, add, dx, N, C, H, W, O, bi, bi2, so);
+  if (st < 0) { set_error("conv2d_dgrad_pair: the shape test and the kernel's own disagree"); return DFHIP_RUNTIME_ERROR; }
+  if (st != DFHIP_OK) return st;
+  *done = 1;
+  return DFHIP_OK;
+}
+
 // dx = dgrad(3x3 / stride 2 / pad 1; dy, w) + dgrad(1x1 / stride 2 / pad 0; dy2, w2) (+ add): the two consumers of a
 // residual block's input whose shortcut is a convolution (test/ResNet_CIFAR10_cuda.py:58-63: conv1 and downsample[0]
 // both read x), reference-exact ("overwrite") mode, as ONE launch -- the shortcut's gradient lands on the even pixels,
@@ -5425,61 +4885,119 @@ int dfhip_conv2d_dgrad_pair(const float* dy, const float* w, const float* dy2, c
     *done = 1;
     return DFHIP_OK;
   }
-  static int img4 = getenv("DFHIP_DGRAD_IMG4") ? atoi(getenv("DFHIP_DGRAD_IMG4")) : 1;
-  if (lean && pair_on && img4 && mode == 0 && H == 4 && W == 4 && N % 16 == 0 && C % 16 == 0 && (O == 128 || O == 256)) {
-    // 4 x 4 images (layer4's first block): the image-per-lane kernel with the shortcut as a fifth slice
-    double flops4 = 2.0 * N * H * W * (double)C * O + 2.0 * N * 4 * (double)C * O;
-    double bytes4 = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * 4);
-    ProfScope prof4("conv2d_dgrad_overwrite_igemm", flops4, bytes4);
-    const int st4 = O == 128 ? launch_dgrad_img4<128, 1, true>(dy, w, add, dx, N, C, dy2, w2)
-                             : launch_dgrad_img4<256, 1, true>(dy, w, add, dx, N, C, dy2, w2);
-    if (st4 != DFHIP_OK) return st4;
-    *done = 1;
-    return DFHIP_OK;
-  }
-  static int img8 = getenv("DFHIP_DGRAD_IMG8") ? atoi(getenv("DFHIP_DGRAD_IMG8")) : 1;
-  if (lean && pair_on && img4 && img8 && mode == 0 && H == 8 && W == 8 && N % 16 == 0 && C % 16 == 0 && (O == 64 || O == 128)) {
-    // 8 x 8 images (layer3's first block): four 4 x 4 blocks per image, each the image-per-lane kernel of the case above
-    double flops8 = 2.0 * N * H * W * (double)C * O + 2.0 * N * 16 * (double)C * O;
-    double bytes8 = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * 16);
-    ProfScope prof8("conv2d_dgrad_overwrite_igemm", flops8, bytes8);
-    const int st8 = O == 64 ? launch_dgrad_img4<64, 2, true>(dy, w, add, dx, N, C, dy2, w2, 8)
-                            : launch_dgrad_img4<128, 2, true>(dy, w, add, dx, N, C, dy2, w2, 8);
-    if (st8 != DFHIP_OK) return st8;
-    *done = 1;
-    return DFHIP_OK;
-  }
-  const bool ok = lean && pair_on && mode == 0 && C % 32 == 0 && (1 << lw) == W && H >= 2 && W >= 2 &&
-                  ((int64_t)N * H * W) % 32 == 0 && H % 2 == 0 && oh * 2 == H && ow * 2 == W &&
-                  (O == 32 || O == 64 || O == 128);          // (256: five slices do not fit the LDS)
-  if (!ok) return DFHIP_OK;
-  const int tiles = (int)((int64_t)N * H * W / 32);
-  const int pg = (((int64_t)N * H * W) % 128 == 0 && W <= 64) ? 1 : 0;
-  double flops = 2.0 * N * H * W * (double)C * O + 2.0 * N * oh * ow * (double)C * O;
-  double bytes = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * oh * ow);
-  ProfScope prof("conv2d_dgrad_overwrite_igemm", flops, bytes);
-  if (O == 128) {
-    // (five slices = 92 KB of LDS: ONE workgroup per CU, which walks twice the tiles of the unpaired launch)
-    const int want = std::max(1, num_cus() / (C / 32));
-    dim3 grid((unsigned)std::min(tiles, want), (unsigned)(C / 32));
-    const size_t lds = ((size_t)5 * O * 32 + 3 * 16 * 64) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_s1_ks<128, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)std::max(lds, (size_t)65536)));
-      attr = true;
-    }
-    DF_LAUNCH((k_dgrad_ow_s1_ks<128, 1, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, H, lw, tiles, pg, dy2, w2);
-  } else {
-    dim3 grid((unsigned)df_ceil_div(tiles, 4), (unsigned)(C / 32));
-    if (O == 32)
-      DF_LAUNCH((k_dgrad_ow_s1<32, 1, true>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg, dy2, w2);
-    else
-      DF_LAUNCH((k_dgrad_ow_s1<64, 1, true>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg, dy2, w2);
-  }
-  DF_LAUNCH_CHECK();
+  if (mode != 0) return DFHIP_OK;
+  return dgrad_pair_overwrite(dy, w, dy2, w2, add, dx, N, C, H, W, O, nullptr, nullptr, nullptr, done);
+}
+
+// ---- the BatchNorm-backward forms (dfhip_bnbwd.h) ----
+static int check_bn_in(const char* fn, const BnBwdIn* b) {
+  if (!b) return DFHIP_OK;
+  DF_CHECK_ARG(b->z && b->rows && b->mean && b->var, "%s: dfhip_bn_bwd_in with a null array", fn);
+  DF_CHECK_ARG(b->nrows >= 1 && b->nrows <= kBnRowsMax && b->K >= 2 && b->K <= 3 && b->kidx >= 1 && b->kidx < b->K,
+               "%s: dfhip_bn_bwd_in rows %d (1..%d), K %d, kidx %d", fn, b->nrows, kBnRowsMax, b->K, b->kidx);
+  return DFHIP_OK;
+}
+static int check_bn_out(const char* fn, const BnStatsOut* o) {
+  if (!o) return DFHIP_OK;
+  DF_CHECK_ARG((o->n == 1 || o->n == 2) && o->rows && o->cap_rows >= 1, "%s: dfhip_bn_stats_out n %d, cap_rows %d",
+               fn, o->n, o->cap_rows);
+  for (int j = 0; j < o->n; j++) DF_CHECK_ARG(o->z[j] && o->mean[j], "%s: dfhip_bn_stats_out with a null array", fn);
+  return DFHIP_OK;
+}
+
+int dfhip_conv2d_bn_bwd_supported(int N, int C, int H, int W, int O, int k, int stride, int pad, int pair,
+                                  int* dgrad_ok, int* wgrad_ok, int* stats_rows) {
+  DF_CHECK_ARG(dgrad_ok && wgrad_ok && stats_rows, "conv2d_bn_bwd_supported: null result");
+  *dgrad_ok = *wgrad_ok = *stats_rows = 0;
+  int oh, ow;
+  if (check_conv_args("conv2d_bn_bwd_supported", N, C, H, W, O, k, stride, pad, oh, ow) != DFHIP_OK) return DFHIP_OK;
+  static int enabled = getenv("DFHIP_BN_BWD_FUSED") ? atoi(getenv("DFHIP_BN_BWD_FUSED")) : 1;
+  if (!enabled) return DFHIP_OK;
+  BnBwdIn bi = {};
+  BnStatsOut so = {};
+  so.n = 1;
+  const int st = pair ? run_dgrad_ow_pair(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, C, H, W, O, &bi, &bi, &so, true)
+                      : run_dgrad_ow(nullptr, nullptr, nullptr, nullptr, N, C, H, W, O, k, stride, pad, &bi, &so, true);
+  // (the table of a pending backward is built from rows of O * K <= 768 floats; the rows are one per workgroup)
+  *dgrad_ok = st == DFHIP_OK && O * 3 <= 768 && so.nrows <= kBnRowsMax;
+  *stats_rows = *dgrad_ok ? so.nrows : 0;
+  // the grouped direct body of the weight gradient: whole 32-channel tiles, planes of 2 .. 16 pixels a side (DF_ROWS_KINDS)
+  const bool k3 = k == 3 && pad == 1, k1 = k == 1 && pad == 0 && stride == 2;
+  static int direct_on = getenv("DFHIP_WGRAD_DIRECT") ? atoi(getenv("DFHIP_WGRAD_DIRECT")) : 1;
+  *wgrad_ok = direct_on && (k3 || k1) && C % 32 == 0 && O % 32 == 0 && N % 16 == 0 && H == W &&
+              (W == 16 || W == 8 || W == 4 || (W == 2 && stride == 1)) && (stride == 1 || stride == 2) &&
+              (stride == 1 || ow * 2 == W) && (H * W) % 4 == 0 && (oh * ow) % 4 == 0;
+  return DFHIP_OK;
+}
+
+int dfhip_conv2d_dgrad_bn(const float* dy, const float* w, const float* add, float* dx, int N, int C, int H, int W,
+                          int O, int k, int stride, int pad, const dfhip_bn_bwd_in* in, dfhip_bn_stats_out* out) {
+  DF_INIT_KEEP();
+  DF_TOUCH(dy); DF_TOUCH(w); DF_TOUCH(add); DF_TOUCH(dx);
+  int s = check_bn_in("conv2d_dgrad_bn", in);
+  if (s != DFHIP_OK) return s;
+  s = check_bn_out("conv2d_dgrad_bn", out);
+  if (s != DFHIP_OK) return s;
+  return conv2d_dgrad_impl(dy, w, add, dx, N, C, H, W, O, k, stride, pad, 0, in, out);
+}
+
+int dfhip_conv2d_dgrad_pair_bn(const float* dy, const float* w, const float* dy2, const float* w2, const float* add,
+                               float* dx, int N, int C, int H, int W, int O, const dfhip_bn_bwd_in* in,
+                               const dfhip_bn_bwd_in* in2, dfhip_bn_stats_out* out) {
+  DF_INIT_KEEP();
+  DF_TOUCH(dy); DF_TOUCH(w); DF_TOUCH(dy2); DF_TOUCH(w2); DF_TOUCH(add); DF_TOUCH(dx);
+  DF_CHECK_ARG(dy && w && dy2 && w2 && dx, "conv2d_dgrad_pair_bn: null array");
+  int oh, ow;
+  int s = check_conv_args("conv2d_dgrad_pair_bn", N, C, H, W, O, 3, 2, 1, oh, ow);
+  if (s != DFHIP_OK) return s;
+  s = check_bn_in("conv2d_dgrad_pair_bn", in);
+  if (s != DFHIP_OK) return s;
+  s = check_bn_in("conv2d_dgrad_pair_bn", in2);
+  if (s != DFHIP_OK) return s;
+  s = check_bn_out("conv2d_dgrad_pair_bn", out);
+  if (s != DFHIP_OK) return s;
+  int done = 0;
+  s = dgrad_pair_overwrite(dy, w, dy2, w2, add, dx, N, C, H, W, O, in, in2, out, &done);
+  if (s != DFHIP_OK) return s;
+  if (!done) { set_error("conv2d_dgrad_pair_bn: no kernel for this shape (query dfhip_conv2d_bn_bwd_supported first)"); return DFHIP_INVALID_ARGUMENT; }
+  return DFHIP_OK;
+}
+
+int dfhip_conv2d_wgrad_bn(const float* x, const float* affine, const float* dy, const float* z, const float* table,
+                          float* dw, int N, int C, int H, int W, int O, int k, int stride, int pad, int* done) {
+  DF_INIT_KEEP();
+  DF_TOUCH(x); DF_TOUCH(dy); DF_TOUCH(dw);
+  DF_CHECK_ARG(x && dy && z && table && dw && done, "conv2d_wgrad_bn: null array");
+  *done = 0;
+  int oh, ow;
+  int s = check_conv_args("conv2d_wgrad_bn", N, C, H, W, O, k, stride, pad, oh, ow);
+  if (s != DFHIP_OK) return s;
+  if (!g_group_on) return DFHIP_OK;
+  const int st = run_wgrad_rows(x, dy, dw, N, C, H, W, O, oh, ow, k, stride, pad, affine, z, table);
+  if (st < 0) return DFHIP_OK;
+  if (st != DFHIP_OK) return st;
   *done = 1;
   return DFHIP_OK;
+}
+
+int dfhip_bn_bwd_table(const dfhip_bn_bwd_in* in, int O) {
+  DF_INIT_KEEP();
+  DF_CHECK_ARG(in && in->table && O > 0, "bn_bwd_table: null descriptor / table");
+  int s = check_bn_in("bn_bwd_table", in);
+  if (s != DFHIP_OK) return s;
+  ProfScope prof("bn2d_bwd", 0.0, 4.0 * O * (2.0 * in->nrows + 8.0));
+  DF_CHECK_ARG(O % 4 == 0 && O <= 256, "bn_bwd_table: O must be a multiple of 4, at most 256");
+  DF_LAUNCH(k_bn_bwd_table, dim3(1), dim3(256), 0, stream(), *in, O);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+int dfhip_bn2d_backward_apply_table(const float* dy, const float* z, const float* table, float* dz, int N, int O,
+                                    int HW) {
+  DF_INIT_KEEP();
+  DF_TOUCH(dy); DF_TOUCH(dz);
+  DF_CHECK_ARG(dy && z && table && dz && N > 0 && O > 0 && HW > 0, "bn2d_backward_apply_table: null array / empty shape");
+  return bn_bwd_materialise(dy, z, table, dz, N, O, HW);
 }
 
 // dx = conv2d_dgrad(dy, w) + add: the gradient accumulation of a tensor with two consumers

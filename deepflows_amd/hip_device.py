@@ -303,6 +303,84 @@ class HipModule:
         m = {"overwrite": 0, "accumulate": 1}[mode]
         _lib.check(self._lib.dfhip_conv2d_dgrad_add(dy.ptr, w.ptr, add.ptr, dx.ptr, N, C, H, W, O, k, stride, pad, m))
 
+    # ---- BatchNorm2d backward without a launch of its own (include/dfhip.h: dfhip_bn_bwd_in / dfhip_bn_stats_out) ----
+    _bn_supported = None
+
+    def conv2d_bn_bwd_supported(self, N, C, H, W, O, k, stride, pad, pair=False):
+        """(dgrad_ok, wgrad_ok, stats_rows): the convolution's input / weight gradient have kernels that apply a pending
+        BatchNorm backward on their operand loads (overwrite mode); the rows that input gradient leaves behind for the
+        BatchNorm layers its output feeds.  Cached per shape."""
+        if self._bn_supported is None:
+            self._bn_supported = {}
+        key = (N, C, H, W, O, k, stride, pad, bool(pair))
+        hit = self._bn_supported.get(key)
+        if hit is None:
+            a, b, r = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+            _lib.check(self._lib.dfhip_conv2d_bn_bwd_supported(N, C, H, W, O, k, stride, pad, 1 if pair else 0,
+                                                               ctypes.byref(a), ctypes.byref(b), ctypes.byref(r)))
+            hit = self._bn_supported[key] = (bool(a.value), bool(b.value), int(r.value))
+        return hit
+
+    @staticmethod
+    def _bn_in(p):
+        """ctypes descriptor of a pending BatchNorm backward `p` (attributes z, rows, nrows, K, kidx, mean, var, gamma,
+        eps, m, dgamma, dbeta, table: HipArray handles / numbers); None -> NULL."""
+        if p is None:
+            return None
+        g = lambda h: h.ptr if h is not None else None
+        return _lib.BnBwdIn(p.z.ptr, p.rows.ptr, int(p.nrows), int(p.K), int(p.kidx), p.mean.ptr, p.var.ptr, g(p.gamma),
+                            float(p.eps), 1.0 / float(p.m), g(p.dgamma), g(p.dbeta), g(p.table))
+
+    @staticmethod
+    def _bn_out(targets, rows, cap_rows):
+        if not targets:
+            return None
+        so = _lib.BnStatsOut()
+        so.n = len(targets)
+        for j, (z, mean) in enumerate(targets):
+            so.z[j] = z.ptr
+            so.mean[j] = mean.ptr
+        so.rows = rows.ptr
+        so.cap_rows = int(cap_rows)
+        so.nrows = 0
+        return so
+
+    def conv2d_dgrad_bn(self, dy, w, add, dx, N, C, H, W, O, k, stride, pad, pending=None, targets=None, rows=None,
+                        cap_rows=0):
+        """overwrite-mode dx = dgrad(dy', w) (+ add) where dy' is the pending BatchNorm backward of dy (`pending`) or dy
+        itself, leaving the partial rows of the BatchNorm layers `targets` = [(z, mean), ...] in `rows`; returns the
+        number of rows written."""
+        bi, so = self._bn_in(pending), self._bn_out(targets, rows, cap_rows)
+        _lib.check(self._lib.dfhip_conv2d_dgrad_bn(dy.ptr, w.ptr, add.ptr if add is not None else None, dx.ptr, N, C, H, W,
+                                                   O, k, stride, pad, ctypes.byref(bi) if bi is not None else None,
+                                                   ctypes.byref(so) if so is not None else None))
+        return int(so.nrows) if so is not None else 0
+
+    def conv2d_dgrad_pair_bn(self, dy, w, dy2, w2, add, dx, N, C, H, W, O, pending=None, pending2=None, targets=None,
+                             rows=None, cap_rows=0):
+        bi, bi2, so = self._bn_in(pending), self._bn_in(pending2), self._bn_out(targets, rows, cap_rows)
+        ref = lambda s: ctypes.byref(s) if s is not None else None
+        _lib.check(self._lib.dfhip_conv2d_dgrad_pair_bn(dy.ptr, w.ptr, dy2.ptr, w2.ptr, add.ptr if add is not None else None,
+                                                        dx.ptr, N, C, H, W, O, ref(bi), ref(bi2), ref(so)))
+        return int(so.nrows) if so is not None else 0
+
+    def conv2d_wgrad_bn(self, x, affine, dy, z, table, dw, N, C, H, W, O, k, stride, pad):
+        """the (grouped) weight gradient with dy' = pending BatchNorm backward of dy formed on the operand loads; False =
+        nothing was queued (not inside a group, or no such kernel for the shape)."""
+        done = ctypes.c_int(0)
+        _lib.check(self._lib.dfhip_conv2d_wgrad_bn(x.ptr, affine.ptr if affine is not None else None, dy.ptr, z.ptr,
+                                                   table.ptr, dw.ptr, N, C, H, W, O, k, stride, pad, ctypes.byref(done)))
+        if done.value and self._wgrad_hold is not None:
+            self._wgrad_hold.append((x, affine, dy, z, table, dw))
+        return bool(done.value)
+
+    def bn_bwd_table(self, pending, O):
+        bi = self._bn_in(pending)
+        _lib.check(self._lib.dfhip_bn_bwd_table(ctypes.byref(bi), int(O)))
+
+    def bn2d_backward_apply_table(self, dy, z, table, dz, N, O, HW):
+        _lib.check(self._lib.dfhip_bn2d_backward_apply_table(dy.ptr, z.ptr, table.ptr, dz.ptr, N, O, HW))
+
     def bn2d_forward_train(self, x, gamma, beta, y, save_mean, save_var, running_mean, running_var,
                            N, C, HW, eps, momentum):
         g = lambda h: h.ptr if h is not None else None

@@ -32,6 +32,95 @@ def _new(shape, device):
 _BN_PARTIAL_ROWS = 512
 _CONV_BN_STATS = os.environ.get("DF_CONV_BN_STATS", "1") != "0"
 
+# ---- BatchNorm2d backward without a launch of its own (include/dfhip.h: dfhip_bn_bwd_in / dfhip_bn_stats_out) -----------
+# The autograd chain of nn/modules/batchnorm.py:30-55 needs sum(dy) and sum(dy * (z - mean)) over the whole batch before
+# it can form dz.  On a fused device the kernel that PRODUCES dy (the input gradient of the next convolution) leaves those
+# sums behind as partial rows (tag `bn_rows` on the gradient it returns), the BatchNorm node then hands its parent -- the
+# convolution whose output z is -- the SAME dy tagged with a _PendingBN (tag `bn_pending`), and that convolution's input- and
+# weight-gradient kernels form dz on their operand loads.  Anything that cannot take a pending gradient writes it out first
+# (_pending_materialise); DF_BN_BWD_FUSED=0 switches the whole mechanism off.
+_BN_BWD_FUSED = os.environ.get("DF_BN_BWD_FUSED", "1") != "0"
+
+
+class _PendingBN:
+    """dz = A dy + B (z - mean) + Cc per channel, not yet applied; handles as the C ABI wants them."""
+    __slots__ = ("z", "rows", "nrows", "K", "kidx", "mean", "var", "gamma", "eps", "m", "dgamma", "dbeta", "table",
+                 "table_ready", "geo", "keep")
+
+    def __init__(self, z, rows, nrows, K, kidx, mean, var, gamma, eps, geo, dgamma, dbeta, table, keep):
+        self.z, self.rows, self.nrows, self.K, self.kidx = z, rows, nrows, K, kidx
+        self.mean, self.var, self.gamma, self.eps = mean, var, gamma, eps
+        self.geo = geo                      # (N, O, HW) of dy
+        self.m = geo[0] * geo[2]
+        self.dgamma, self.dbeta, self.table = dgamma, dbeta, table
+        self.table_ready = False            # the table / dgamma / dbeta have been written (by an input-gradient launch)
+        self.keep = keep                    # the BackendTensors behind the handles
+
+
+class _BnRows:
+    """what a producer left behind for the BatchNorm node `owner`: rows (nrows x C x K), sums 0 and 1 + j are layer j's"""
+    __slots__ = ("owner", "rows", "nrows", "K")
+
+    def __init__(self, owner, rows, nrows, K):
+        self.owner, self.rows, self.nrows, self.K = owner, rows, nrows, K
+
+
+def _alias(t):
+    """the same storage as another BackendTensor object (tags do not travel)"""
+    t = t.compact()
+    return BackendTensor.make(t.shape, device=t.device, handle=t._handle)
+
+
+def _pending_table(pend, dev):
+    if not pend.table_ready:
+        dev.bn_bwd_table(pend, pend.geo[1])
+        pend.table_ready = True
+
+
+def _pending_materialise(pend, dy):
+    """the pending BatchNorm backward written out: a plain gradient tensor (and dgamma / dbeta filled)"""
+    dev = dy.device
+    _pending_table(pend, dev)
+    dz = _new(dy.shape, dev)
+    N, O, HW = pend.geo
+    dev.bn2d_backward_apply_table(dy.compact()._handle, pend.z, pend.table, dz._handle, N, O, HW)
+    return dz
+
+
+def _plain(grad):
+    """`grad` as a gradient tensor without tags (a pending BatchNorm backward is written out)"""
+    pend = getattr(grad, "bn_pending", None)
+    return grad if pend is None else _pending_materialise(pend, grad)
+
+
+def _accepts_pending(znode):
+    """the convolution node `znode` takes its output gradient as a pending BatchNorm backward"""
+    if not _BN_BWD_FUSED or not isinstance(znode, (_Conv2dFused, _BnConv2dFused)) or len(znode.children) != 1:
+        return False
+    mod = znode.device.mod
+    if not hasattr(mod, "conv2d_dgrad_bn") or getattr(mod, "conv_dgrad_mode", "") != "overwrite":
+        return False
+    return znode._pending_ok()
+
+
+def _stats_targets(xnode, me, sib=None):
+    """[(z handle, mean handle), ...] of the BatchNorm layers whose output gradient the producer `me` is about to COMPLETE
+    (every other consumer of `xnode` was created after `me`, so the reverse sweep has been there; `sib`: a node whose
+    contribution `me` delivers in the same launch), or None."""
+    if not _BN_BWD_FUSED or not isinstance(xnode, (_BatchNorm2dFused, _BatchNorm2dPairFused)):
+        return None
+    for ch in xnode.children:
+        if ch is me or ch is sib:
+            continue
+        if ch.unique_id < me.unique_id:
+            return None
+    return xnode._deferred_targets()
+
+
+def _tag_rows(out, xnode, rows, nrows, K):
+    out.bn_rows = _BnRows(xnode, rows, nrows, K)
+
+
 
 class _FusedNode(Tensor):
     """Autograd node produced by one fused kernel; parents are the differentiable inputs."""
@@ -378,6 +467,7 @@ class _Conv2dFused(_FusedNode):
             node.bn_partials = (part, rows) if (part is not None and rows > 0) else None
             _FusedNode.__init__(node, out, [x, wt, None])
             nodes.append(node)
+        nodes[0]._sibling_host = nodes[1]     # (the shortcut's node: its input gradient rides on conv1's launch)
         return nodes[1], nodes[0]
 
     # the engine may hand over the gradient the input already holds (tensor.py backward): the sum
@@ -394,28 +484,79 @@ class _Conv2dFused(_FusedNode):
     _dw_ready = None
     _dw_from_stem = False        # (diagnostic: the last weight gradient handed out came from the stem's launch)
 
+    def _pending_ok(self):
+        """this node's input- and weight-gradient kernels can take a pending BatchNorm backward as their dY"""
+        mod = self.device.mod
+        if self.bias is not None:
+            return False
+        host = getattr(self, "_sibling_host", None)
+        if host is not None:
+            # a block's 1x1 shortcut: its input gradient rides on conv1's pair launch
+            dg = mod.conv2d_bn_bwd_supported(*host.geo, pair=True)[0] if self.x.requires_grad else True
+        elif self.shortcut_sibling is not None:
+            dg = mod.conv2d_bn_bwd_supported(*self.geo, pair=True)[0] if self.x.requires_grad else True
+        else:
+            dg = mod.conv2d_bn_bwd_supported(*self.geo)[0] if self.x.requires_grad else True
+        wg = mod.conv2d_bn_bwd_supported(*self.geo)[1] if self.w.requires_grad else True
+        return dg and wg
+
     def grad_fn(self, node, grad, accumulated=None):
+        pend = getattr(grad, "bn_pending", None)
         g = grad.compact()
         dev = g.device
+        h = lambda t: t._handle if t is not None else None
         if node is self.x:
             if self._dx_delivered:
                 return None                       # conv1's launch already carried this node's input gradient
             sib = self.shortcut_sibling
+            N, C, H, W, O = self.geo[:5]
+            add = accumulated.compact() if accumulated is not None else None
             if (sib is not None and sib.x is self.x and sib.grad is not None and not sib._dx_delivered
                     and hasattr(dev.mod, "conv2d_dgrad_pair") and self.geo[5:] == (3, 2, 1) and sib.geo[5:] == (1, 2, 0)
                     and sib.geo[:5] == self.geo[:5]):
                 sg = sib.grad.data if isinstance(sib.grad, Tensor) else sib.grad
+                spend = getattr(sg, "bn_pending", None)
                 out = _new(self.xd.shape, dev)
-                N, C, H, W, O = self.geo[:5]
-                if dev.conv2d_dgrad_pair(g._handle, self.wd._handle, sg.compact()._handle, sib.wd._handle,
-                                         accumulated.compact()._handle if accumulated is not None else None,
+                targets = _stats_targets(self.x, self, sib)
+                ok, _, cap = dev.mod.conv2d_bn_bwd_supported(*self.geo, pair=True)
+                if (pend is not None or spend is not None or targets) and ok:
+                    rows = _new((cap, C, 1 + len(targets)), dev) if targets else None
+                    nrows = dev.conv2d_dgrad_pair_bn(g._handle, self.wd._handle, sg.compact()._handle, sib.wd._handle, h(add),
+                                                     out._handle, N, C, H, W, O, pend, spend, targets, h(rows), cap)
+                    if pend is not None:
+                        pend.table_ready = True
+                    if spend is not None:
+                        spend.table_ready = True
+                    if targets:
+                        _tag_rows(out, self.x, rows, nrows, 1 + len(targets))
+                    sib._dx_delivered = True
+                    return out
+                if pend is not None:
+                    g = _pending_materialise(pend, g)
+                    self._plain_grad = (grad, g)
+                if spend is not None:
+                    sg = _pending_materialise(spend, sg)
+                    sib.grad = sg                 # (the shortcut's weight gradient then reads the plain tensor)
+                if dev.conv2d_dgrad_pair(g._handle, self.wd._handle, sg.compact()._handle, sib.wd._handle, h(add),
                                          out._handle, N, C, H, W, O):
                     sib._dx_delivered = True
                     return out
             out = _new(self.xd.shape, dev)
-            if accumulated is not None:
-                dev.conv2d_dgrad_add(g._handle, self.wd._handle, accumulated.compact()._handle, out._handle,
-                                     *self.geo)
+            targets = _stats_targets(self.x, self)
+            ok, _, cap = dev.mod.conv2d_bn_bwd_supported(*self.geo)
+            if (pend is not None or targets) and ok:
+                rows = _new((cap, C, 1 + len(targets)), dev) if targets else None
+                nrows = dev.conv2d_dgrad_bn(g._handle, self.wd._handle, h(add), out._handle, *self.geo, pend, targets,
+                                            h(rows), cap)
+                if pend is not None:
+                    pend.table_ready = True
+                if targets:
+                    _tag_rows(out, self.x, rows, nrows, 1 + len(targets))
+                return out
+            if pend is not None:
+                g = self._plain_of(grad, pend)
+            if add is not None:
+                dev.conv2d_dgrad_add(g._handle, self.wd._handle, add._handle, out._handle, *self.geo)
             else:
                 dev.conv2d_dgrad(g._handle, self.wd._handle, out._handle, *self.geo)
             return out
@@ -431,11 +572,26 @@ class _Conv2dFused(_FusedNode):
                 raise RuntimeError("stem backward: the convolution's output gradient is not the placeholder its "
                                    "pooling node handed out (another consumer?); set DF_STEM_FUSED_BWD=0")
             out = _new(self.wd.shape, dev)
+            if pend is not None:
+                _pending_table(pend, dev)         # (written by the input-gradient launch where there was one)
+                if dev.conv2d_wgrad_bn(self.xd._handle, None, g._handle, pend.z, pend.table, out._handle, *self.geo):
+                    return out
+                g = self._plain_of(grad, pend)
             dev.conv2d_wgrad(self.xd._handle, g._handle, out._handle, *self.geo)
             return out
+        if pend is not None:
+            g = self._plain_of(grad, pend)
         out = _new(self.bias.shape, dev)
         dev.reduce_to_shape(g._handle, out._handle, g.shape, self.bias.shape)
         return out
+
+    _plain_grad = None
+
+    def _plain_of(self, grad, pend):
+        """the pending gradient written out, once per gradient tensor"""
+        if self._plain_grad is None or self._plain_grad[0] is not grad:
+            self._plain_grad = (grad, _pending_materialise(pend, grad))
+        return self._plain_grad[1]
 
 
 def conv2d(x: Tensor, kernel: Tensor, padding: int = 0, stride: int = 1, bias=None):
@@ -603,16 +759,34 @@ class _BatchNorm2dFused(_FusedNode):
         self._grads = None
         super().__init__(out, [x, weight, bias, residual])
 
+    _defer = None
+
+    def _deferred_targets(self):
+        """[(z, mean)] when this layer's backward pass can ride on its neighbours' kernels (decided once), else None"""
+        if self._defer is None:
+            self._defer = bool(self.weight is not None and self.x.requires_grad and _accepts_pending(self.x))
+        return [(self.xd._handle, self.mean._handle)] if self._defer else None
+
     def grad_fn(self, node, grad):
         if self._grads is None or self._grads[0] is not grad:
             dev = grad.device
             N, C, HW = self.geo
             need_dx = self.x.requires_grad
-            dx = _new(self.xd.shape, dev) if need_dx else None
             dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
             h = lambda t: t._handle if t is not None else None
-            dev.bn2d_backward(grad.compact()._handle, self.xd._handle, h(self.wd), self.mean._handle,
-                              self.var._handle, h(dx), dg._handle, db._handle, N, C, HW, self.eps)
+            left = getattr(grad, "bn_rows", None)
+            if left is not None and left.owner is self and self._defer:
+                # the producer of `grad` left this layer's sums behind: the convolution in front forms dx on its loads
+                table = _new((C, 4), dev)
+                pend = _PendingBN(self.xd._handle, left.rows._handle, left.nrows, left.K, 1, self.mean._handle,
+                                  self.var._handle, h(self.wd), self.eps, (N, C, HW), dg._handle, db._handle,
+                                  table._handle, (self.xd, left.rows, self.mean, self.var, self.wd, dg, db, table, grad))
+                dx = _alias(grad)
+                dx.bn_pending = pend
+            else:
+                dx = _new(self.xd.shape, dev) if need_dx else None
+                dev.bn2d_backward(grad.compact()._handle, self.xd._handle, h(self.wd), self.mean._handle,
+                                  self.var._handle, h(dx), dg._handle, db._handle, N, C, HW, self.eps)
             self._grads = (grad, dx, dg, db)
         _, dx, dg, db = self._grads
         if node is self.x:
@@ -653,18 +827,40 @@ class _BatchNorm2dPairFused(_FusedNode):
         self._grads = None
         super().__init__(out, [xa, bn_a.weight, bn_a.bias, xb, bn_b.weight, bn_b.bias])
 
+    _defer = None
+
+    def _deferred_targets(self):
+        """[(z_a, mean_a), (z_b, mean_b)] when both layers' backward passes can ride on their neighbours' kernels"""
+        if self._defer is None:
+            self._defer = bool(all(bn.weight is not None for bn in self.bns) and all(x.requires_grad for x in self.xs)
+                               and all(_accepts_pending(x) for x in self.xs))
+        if not self._defer:
+            return None
+        return [(xd._handle, mean._handle) for xd, (mean, _) in zip(self.xd, self.stats)]
+
     def grad_fn(self, node, grad):
         if self._grads is None or self._grads[0] is not grad:
             dev = grad.device
             N, C, HW = self.geo
             h = lambda t: t._handle if t is not None else None
             res, sets = [], []
-            for x, xd, wd, bn, (mean, var) in zip(self.xs, self.xd, self.wd, self.bns, self.stats):
-                dx = _new(xd.shape, dev) if x.requires_grad else None
-                dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
-                res.append((dx, dg, db))
-                sets.append((xd._handle, h(wd), mean._handle, var._handle, h(dx), dg._handle, db._handle, bn.eps))
-            dev.bn2d_backward_pair(grad.compact()._handle, sets[0], sets[1], N, C, HW)
+            left = getattr(grad, "bn_rows", None)
+            if left is not None and left.owner is self and self._defer and left.K == 3:
+                for i, (xd, wd, bn, (mean, var)) in enumerate(zip(self.xd, self.wd, self.bns, self.stats)):
+                    dg, db, table = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev), _new((C, 4), dev)
+                    pend = _PendingBN(xd._handle, left.rows._handle, left.nrows, left.K, 1 + i, mean._handle, var._handle,
+                                      h(wd), float(bn.eps), (N, C, HW), dg._handle, db._handle, table._handle,
+                                      (xd, left.rows, mean, var, wd, dg, db, table, grad))
+                    dx = _alias(grad)
+                    dx.bn_pending = pend
+                    res.append((dx, dg, db))
+            else:
+                for x, xd, wd, bn, (mean, var) in zip(self.xs, self.xd, self.wd, self.bns, self.stats):
+                    dx = _new(xd.shape, dev) if x.requires_grad else None
+                    dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+                    res.append((dx, dg, db))
+                    sets.append((xd._handle, h(wd), mean._handle, var._handle, h(dx), dg._handle, db._handle, bn.eps))
+                dev.bn2d_backward_pair(grad.compact()._handle, sets[0], sets[1], N, C, HW)
             self._grads = (grad, res)
         _, res = self._grads
         for i in range(2):
@@ -724,28 +920,82 @@ class _BnConv2dFused(_FusedNode):
         _FusedNode.__init__(node, out, [x, bn.weight, bn.bias, w, cbias])
         return node
 
+    def _pending_ok(self):
+        """the convolution's input- and weight-gradient kernels can take a pending BatchNorm backward as their dY"""
+        mod = self.device.mod
+        if self.cbias is not None:
+            return False
+        dg, wg, _ = mod.conv2d_bn_bwd_supported(*self.geo)
+        return dg and (wg or not self.w.requires_grad)
+
+    _defer_in = None
+
+    def _defer_bn(self):
+        """this node's own BatchNorm (in front of the convolution) hands ITS backward pass to the node that made x"""
+        if self._defer_in is None:
+            self._defer_in = bool(self.x.requires_grad and self.gamma is not None and _accepts_pending(self.x)
+                                  and self.device.mod.conv2d_bn_bwd_supported(*self.geo)[0])
+        return self._defer_in
+
     def grad_fn(self, node, grad):
         if self._grads is None or self._grads[0] is not grad:
+            pend = getattr(grad, "bn_pending", None)
             g = grad.compact()
             dev = g.device
             N, C, H, W, O, k, stride, pad = self.geo
             h = lambda t: t._handle if t is not None else None
             dw = dcb = dx = dg = db = None
-            if self.w.requires_grad:
-                dw = _new(self.wd.shape, dev)
-                dev.conv2d_wgrad_affine(self.xd._handle, self.affine._handle, g._handle, dw._handle, *self.geo)
-            if self.cbias is not None and self.cbias.requires_grad:
-                dcb = _new(self.cbias.shape, dev)
-                dev.reduce_to_shape(g._handle, dcb._handle, g.shape, self.cbias.shape)
             bn_needs = (self.x.requires_grad or (self.gamma is not None and self.gamma.requires_grad)
                         or (self.beta is not None and self.beta.requires_grad))
+            gp = None                                          # the output gradient written out, where that is needed
+            da = None
             if bn_needs:
                 da = _new(self.xd.shape, dev)                  # gradient of the (never materialised) normalised tensor
-                dev.conv2d_dgrad(g._handle, self.wd._handle, da._handle, *self.geo)
-                dx = _new(self.xd.shape, dev) if self.x.requires_grad else None
-                dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
-                dev.bn2d_backward(da._handle, self.xd._handle, h(self.gd), self.mean._handle, self.var._handle,
-                                  h(dx), dg._handle, db._handle, N, C, H * W, self.eps)
+                defer = _BN_BWD_FUSED and self._defer_bn()
+                if pend is not None or defer:
+                    # (the input gradient first: its launch writes the table the weight gradient reads)
+                    targets = [(self.xd._handle, self.mean._handle)] if defer else None
+                    cap = dev.mod.conv2d_bn_bwd_supported(*self.geo)[2]
+                    rows = _new((cap, C, 2), dev) if defer else None
+                    nrows = dev.conv2d_dgrad_bn(g._handle, self.wd._handle, None, da._handle, *self.geo, pend, targets,
+                                                h(rows), cap)
+                    if pend is not None:
+                        pend.table_ready = True
+                    dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+                    if defer:
+                        table = _new((C, 4), dev)
+                        mine = _PendingBN(self.xd._handle, rows._handle, nrows, 2, 1, self.mean._handle, self.var._handle,
+                                          h(self.gd), self.eps, (N, C, H * W), dg._handle, db._handle, table._handle,
+                                          (self.xd, rows, self.mean, self.var, self.gd, dg, db, table, da))
+                        dx = _alias(da)
+                        dx.bn_pending = mine
+                    else:
+                        dx = _new(self.xd.shape, dev) if self.x.requires_grad else None
+                        dev.bn2d_backward(da._handle, self.xd._handle, h(self.gd), self.mean._handle, self.var._handle,
+                                          h(dx), dg._handle, db._handle, N, C, H * W, self.eps)
+                else:
+                    dev.conv2d_dgrad(g._handle, self.wd._handle, da._handle, *self.geo)
+                    dx = _new(self.xd.shape, dev) if self.x.requires_grad else None
+                    dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+                    dev.bn2d_backward(da._handle, self.xd._handle, h(self.gd), self.mean._handle, self.var._handle,
+                                      h(dx), dg._handle, db._handle, N, C, H * W, self.eps)
+            if self.w.requires_grad:
+                dw = _new(self.wd.shape, dev)
+                queued = False
+                if pend is not None:
+                    _pending_table(pend, dev)
+                    queued = dev.conv2d_wgrad_bn(self.xd._handle, self.affine._handle, g._handle, pend.z, pend.table,
+                                                 dw._handle, *self.geo)
+                    if not queued:
+                        gp = _pending_materialise(pend, g)
+                if not queued:
+                    dev.conv2d_wgrad_affine(self.xd._handle, self.affine._handle, (gp if gp is not None else g)._handle, dw._handle, *self.geo)
+            if self.cbias is not None and self.cbias.requires_grad:
+                if pend is not None and gp is None:
+                    gp = _pending_materialise(pend, g)
+                gb = gp if gp is not None else g
+                dcb = _new(self.cbias.shape, dev)
+                dev.reduce_to_shape(gb._handle, dcb._handle, gb.shape, self.cbias.shape)
             self._grads = (grad, dx, dg, db, dw, dcb)
         _, dx, dg, db, dw, dcb = self._grads
         if node is self.x:

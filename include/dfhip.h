@@ -213,6 +213,68 @@ int dfhip_conv2d_forward_stats(const float* x, const float* w, const float* bias
 int dfhip_conv2d_dgrad(const float* dy, const float* w, float* dx,
                        int N, int C, int H, int W, int O, int k, int stride, int pad, int mode);
 
+/* ---- BatchNorm2d backward without a launch of its own --------------------------------------------------------
+ * Autograd of nn/modules/batchnorm.py:30-55 (training mode, biased variance): for y = gamma (z - mean) r + beta,
+ * r = 1 / sqrt(var + eps), m = N*H*W elements per channel,
+ *     dz = A dy + B (z - mean) + Cc,  A = gamma r,  B = -A r k2,  Cc = -A k1,
+ *     k1 = sum(dy) / m,  k2 = r sum(dy (z - mean)) / m,   dgamma = r sum(dy (z - mean)),  dbeta = sum(dy).
+ * The two sums need all of dy.  Instead of a statistics pass and an apply pass behind a launch boundary,
+ *   - the kernel that PRODUCES dy (the input gradient of the next convolution) leaves per-channel partial rows
+ *     (sum dy, sum dy (z - mean)) behind (dfhip_bn_stats_out), one row per workgroup, at most DFHIP_BN_ROWS_MAX;
+ *   - the kernels that CONSUME dz (input gradient and weight gradient of the convolution whose output z is) add the
+ *     rows up and form dz on their operand loads (dfhip_bn_bwd_in); dz itself is never written.
+ * All arrays are device arrays; the structs are read by the host side of the call only. */
+#define DFHIP_BN_ROWS_MAX 512
+typedef struct dfhip_bn_bwd_in {
+  const float* z;        /* the BatchNorm layer's input, same shape as dy                                         */
+  const float* rows;     /* nrows x O x K partial sums left behind by the producer of dy                          */
+  int nrows, K, kidx;    /* (row[0], row[kidx]) = (sum dy, sum dy (z - mean)) over the row's share of the tensor  */
+  const float* mean;     /* O: batch mean / biased variance saved by the forward pass                             */
+  const float* var;
+  const float* gamma;    /* O, or NULL (1)                                                                        */
+  float eps;
+  float inv_m;           /* 1 / (N * H * W of dy)                                                                 */
+  float* dgamma;         /* O each, may be NULL: written by the call that adds up the rows (dfhip_conv2d_dgrad_bn, */
+  float* dbeta;          /* dfhip_conv2d_dgrad_pair_bn, dfhip_bn_bwd_table)                                       */
+  float* table;          /* O x 4: (A, B, mean, Cc) per channel, written by the same call, read by               */
+                         /* dfhip_conv2d_wgrad_bn and dfhip_bn2d_backward_apply_table                              */
+} dfhip_bn_bwd_in;
+typedef struct dfhip_bn_stats_out {
+  int n;                 /* 1 or 2 BatchNorm layers whose OUTPUT gradient the produced tensor is (2: bn2(z2) + bn_d(z_d), */
+  const float* z[2];     /* the tail of a residual block whose shortcut is convolution + BatchNorm); their inputs ...     */
+  const float* mean[2];  /* ... and batch means                                                                           */
+  float* rows;           /* cap_rows x C x (1 + n): (sum dx, sum dx (z0 - mean0)[, sum dx (z1 - mean1)])                  */
+  int cap_rows;          /* >= the rows the call writes (*stats_rows of dfhip_conv2d_bn_bwd_supported)                    */
+  int nrows;             /* out: rows written                                                                             */
+} dfhip_bn_stats_out;
+/* *dgrad_ok / *wgrad_ok = 1 when dfhip_conv2d_dgrad_bn (pair = 0; dfhip_conv2d_dgrad_pair_bn: pair = 1) / a grouped
+ * dfhip_conv2d_wgrad_bn has a kernel with the BatchNorm descriptors for this convolution (overwrite mode only);
+ * *stats_rows = the rows that input-gradient call writes into a dfhip_bn_stats_out. */
+int dfhip_conv2d_bn_bwd_supported(int N, int C, int H, int W, int O, int k, int stride, int pad, int pair,
+                                  int* dgrad_ok, int* wgrad_ok, int* stats_rows);
+/* dfhip_conv2d_dgrad / dfhip_conv2d_dgrad_add (add may be NULL) in mode 0 (tensor.py:708 + functional.py:285-294) with
+ * `in` (may be NULL): dy is the gradient of a BatchNorm OUTPUT, its backward is applied on the operand loads; and
+ * `out` (may be NULL): dx is the output gradient of out->n BatchNorm layers, their rows are left behind.
+ * DFHIP_INVALID_ARGUMENT when the shape has no such kernel (dfhip_conv2d_bn_bwd_supported says so beforehand). */
+int dfhip_conv2d_dgrad_bn(const float* dy, const float* w, const float* add, float* dx, int N, int C, int H, int W,
+                          int O, int k, int stride, int pad, const dfhip_bn_bwd_in* in, dfhip_bn_stats_out* out);
+/* dfhip_conv2d_dgrad_pair in mode 0 with the descriptors of dy (in), of the shortcut's dy2 (in2) and of dx (out);
+ * each may be NULL. */
+int dfhip_conv2d_dgrad_pair_bn(const float* dy, const float* w, const float* dy2, const float* w2, const float* add,
+                               float* dx, int N, int C, int H, int W, int O, const dfhip_bn_bwd_in* in,
+                               const dfhip_bn_bwd_in* in2, dfhip_bn_stats_out* out);
+/* dfhip_conv2d_wgrad (affine == NULL) / dfhip_conv2d_wgrad_affine whose dy is the gradient of a BatchNorm output:
+ * z and table (O x 4) as in dfhip_bn_bwd_in, the table already written.  Only inside a group (dfhip_wgrad_group_begin);
+ * *done = 0 (nothing queued) otherwise or when the grouped kernel does not take the shape: the caller then writes dz
+ * out (dfhip_bn2d_backward_apply_table) and calls dfhip_conv2d_wgrad. */
+int dfhip_conv2d_wgrad_bn(const float* x, const float* affine, const float* dy, const float* z, const float* table,
+                          float* dw, int N, int C, int H, int W, int O, int k, int stride, int pad, int* done);
+/* the table, dgamma and dbeta of `in` as a launch of its own (for a convolution that needs no input gradient) */
+int dfhip_bn_bwd_table(const dfhip_bn_bwd_in* in, int O);
+/* dz (N, O, HW) = A dy + B (z - mean) + Cc from the table: the pending backward written out */
+int dfhip_bn2d_backward_apply_table(const float* dy, const float* z, const float* table, float* dz, int N, int O,
+                                    int HW);
+
 /* BatchNorm2d training forward from the partials of dfhip_conv2d_forward_stats (x is that
  * convolution's output): statistics by Chan's combination of the partial rows, then
  * y = (x - mean) / sqrt(var + eps) * gamma + beta (+ residual, the shortcut of a residual block:

@@ -1,0 +1,250 @@
+"""BatchNorm2d backward without a launch of its own (include/dfhip.h: dfhip_bn_bwd_in / dfhip_bn_stats_out), against
+the oracle (oracle/ref_ops.py: the autograd chain of nn/modules/batchnorm.py:30-55 and the reference's last-writer-wins
+input gradient, nn/functional.py:285-294) at the benchmarked sizes:
+
+  * the input-gradient kernels with a pending BatchNorm backward on their dY operand and / or the partial rows of the
+    BatchNorm layers their output feeds (one and two layers), stand-alone and for a block with a convolution shortcut;
+  * the rows themselves: complete sums, identical in every repetition (the in-launch combination is order-fixed);
+  * the grouped weight gradient with the pending operand;
+  * a whole ResNet-18 step with the mechanism on and off.
+"""
+import types
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, rel_err
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+N = 256
+EPS = 1e-5
+
+
+def _arr(mod, a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    h = mod.Array(a.size)
+    mod.from_numpy(a, h)
+    return h
+
+
+def _back(mod, h, shape):
+    return mod.to_numpy(h, (h.size,), (1,), 0).reshape(shape)
+
+
+def _bn_layer(rng, shape, offset=0.3):
+    """a BatchNorm layer's saved state for an input z of `shape`: (z, gamma, mean, var)"""
+    c = shape[1]
+    z = (rng.standard_normal(shape) * 1.3 + offset).astype(np.float32)
+    gamma = (rng.standard_normal((1, c, 1, 1)) * 0.5 + 1.0).astype(np.float32)
+    mean = z.mean(axis=(0, 2, 3), keepdims=True, dtype=np.float64).astype(np.float32)
+    var = z.var(axis=(0, 2, 3), keepdims=True, dtype=np.float64).astype(np.float32)
+    return z, gamma, mean, var
+
+
+def _rows_of(dy, z, mean):
+    """the complete sums a producer's rows add up to: (sum dy, sum dy (z - mean)) per channel, float64"""
+    d = dy.astype(np.float64)
+    return d.sum(axis=(0, 2, 3)), (d * (z.astype(np.float64) - mean.astype(np.float64))).sum(axis=(0, 2, 3))
+
+
+def _pending(mod, dy, z, gamma, mean, var, rows_h=None, nrows=0, K=2, kidx=1):
+    """a dfhip_bn_bwd_in for the gradient dy of a BatchNorm output; rows from the host when no producer left them"""
+    n, c, h, w = dy.shape
+    if rows_h is None:
+        s1, s2 = _rows_of(dy, z, mean)
+        # 301 rows whose sum is the total (the consumer adds rows up; not a multiple of its row groups)
+        rs = np.random.default_rng(c)
+        wts = rs.random((301, 1)) + 0.1
+        wts /= wts.sum()
+        rows = np.zeros((301, c, 2), np.float64)
+        rows[:, :, 0], rows[:, :, 1] = wts * s1[None, :], wts[::-1] * s2[None, :]
+        rows_h, nrows, K, kidx = _arr(mod, rows.astype(np.float32)), 301, 2, 1
+    p = types.SimpleNamespace()
+    p.z, p.rows, p.nrows, p.K, p.kidx = _arr(mod, z), rows_h, nrows, K, kidx
+    p.mean, p.var, p.gamma, p.eps, p.m = _arr(mod, mean), _arr(mod, var), _arr(mod, gamma), EPS, n * h * w
+    p.dgamma, p.dbeta, p.table = mod.Array(c), mod.Array(c), mod.Array(4 * c)
+    return p
+
+
+# (C, H, W, O, k, stride, pad) of the ResNet-18 layers the s1 kernels take
+S1_LAYERS = {"l1": (32, 16, 16, 32, 3, 1, 1), "l2": (64, 8, 8, 64, 3, 1, 1)}
+
+
+@pytest.mark.parametrize("name", list(S1_LAYERS))
+@pytest.mark.parametrize("with_in", [False, True])
+@pytest.mark.parametrize("n_targets", [0, 1, 2])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_dgrad_with_pending_batchnorm_and_rows(hip_device, name, with_in, n_targets, with_add):
+    if not with_in and n_targets == 0:
+        pytest.skip("the plain kernel: test_hip_fullsize.py")
+    mod = hip_device.mod
+    C, H, W, O, k, s, p = S1_LAYERS[name]
+    geo = (N, C, H, W, O, k, s, p)
+    assert mod.conv2d_bn_bwd_supported(*geo)[0]
+    rng = np.random.default_rng(11 + 7 * n_targets + with_in)
+    oh, ow = H // s, W // s
+    dy = (rng.standard_normal((N, O, oh, ow)) * 0.1).astype(np.float32)
+    w = (rng.standard_normal((O, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+    add = rng.standard_normal((N, C, H, W)).astype(np.float32) * 0.05 if with_add else None
+    z, gamma, mean, var = _bn_layer(rng, dy.shape)
+    pend = _pending(mod, dy, z, gamma, mean, var) if with_in else None
+    if with_in:
+        dz, dg_ref, db_ref = R.batchnorm2d_backward(dy, z, gamma, mean, var)
+    else:
+        dz = dy
+    want = R.conv2d_dgrad(dz.astype(np.float32), w, (N, C, H, W), s, p, "overwrite")
+    if with_add:
+        want = want + add
+    targets, tz = [], []
+    for j in range(n_targets):
+        zt, _, mt, _ = _bn_layer(rng, (N, C, H, W), offset=5.0 * (j + 1))     # (an offset many times the spread)
+        tz.append((zt, mt))
+        targets.append((_arr(mod, zt), _arr(mod, mt)))
+    cap = mod.conv2d_bn_bwd_supported(*geo)[2]
+    rows = mod.Array(cap * C * (1 + n_targets)) if n_targets else None
+    dx = mod.Array(N * C * H * W)
+    first = None
+    for rep in range(6):
+        nrows = mod.conv2d_dgrad_bn(_arr(mod, dy), _arr(mod, w), _arr(mod, add) if with_add else None, dx, *geo, pend,
+                                    targets or None, rows, cap)
+        got = _back(mod, dx, (N, C, H, W))
+        assert_close(got, want, 1e-4, f"{name} dx")
+        if n_targets:
+            assert 1 <= nrows <= cap
+            r = _back(mod, rows, (cap, C, 1 + n_targets))[:nrows]
+            if first is None:
+                first = r.copy()
+            assert np.array_equal(r, first), "rows differ between repetitions"
+            tot = r.astype(np.float64).sum(axis=0)
+            for j, (zt, mt) in enumerate(tz):
+                s1, s2 = _rows_of(got, zt, mt)
+                assert np.abs(tot[:, 0] - s1).max() <= 1e-5 * np.abs(got.astype(np.float64)).sum(axis=(0, 2, 3)).max(), "sum dx"
+                scale = np.abs(got.astype(np.float64) * (zt - mt)).sum(axis=(0, 2, 3)).max()
+                assert np.abs(tot[:, 1 + j] - s2).max() <= 1e-5 * scale, "sum dx (z - mean)"
+    if with_in:
+        assert_close(_back(mod, pend.dgamma, (1, O, 1, 1)), dg_ref, 1e-4, "dgamma")
+        assert_close(_back(mod, pend.dbeta, (1, O, 1, 1)), db_ref, 1e-4, "dbeta")
+
+
+@pytest.mark.parametrize("which", ["both", "conv_only", "shortcut_only", "rows_only"])
+def test_pair_dgrad_with_pending_batchnorms(hip_device, which):
+    """layer2's first block: conv1 (3x3 / stride 2) and the 1x1 / stride-2 shortcut read the block input; their output
+    gradients are pending BatchNorm backwards of different layers (bn1 on z1, bn_d on z_d)."""
+    mod = hip_device.mod
+    C, H, W, O = 32, 16, 16, 64
+    geo = (N, C, H, W, O)
+    assert mod.conv2d_bn_bwd_supported(N, C, H, W, O, 3, 2, 1, pair=True)[0]
+    rng = np.random.default_rng(5)
+    dy = (rng.standard_normal((N, O, 8, 8)) * 0.1).astype(np.float32)
+    dy2 = (rng.standard_normal((N, O, 8, 8)) * 0.1).astype(np.float32)
+    w = (rng.standard_normal((O, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    w2 = (rng.standard_normal((O, C, 1, 1)) / np.sqrt(C)).astype(np.float32)
+    z1, g1, m1, v1 = _bn_layer(rng, dy.shape)
+    zd, gd, md, vd = _bn_layer(rng, dy.shape, offset=-2.0)
+    p1 = _pending(mod, dy, z1, g1, m1, v1) if which in ("both", "conv_only") else None
+    p2 = _pending(mod, dy2, zd, gd, md, vd) if which in ("both", "shortcut_only") else None
+    dz1 = R.batchnorm2d_backward(dy, z1, g1, m1, v1)[0] if p1 is not None else dy
+    dzd = R.batchnorm2d_backward(dy2, zd, gd, md, vd)[0] if p2 is not None else dy2
+    want = (R.conv2d_dgrad(dz1.astype(np.float32), w, (N, C, H, W), 2, 1, "overwrite")
+            + R.conv2d_dgrad(dzd.astype(np.float32), w2, (N, C, H, W), 2, 0, "overwrite"))
+    zt, _, mt, _ = _bn_layer(rng, (N, C, H, W), offset=3.0)
+    targets = [(_arr(mod, zt), _arr(mod, mt))]
+    cap = mod.conv2d_bn_bwd_supported(N, C, H, W, O, 3, 2, 1, pair=True)[2]
+    rows = mod.Array(cap * C * 2)
+    dx = mod.Array(N * C * H * W)
+    nrows = mod.conv2d_dgrad_pair_bn(_arr(mod, dy), _arr(mod, w), _arr(mod, dy2), _arr(mod, w2), None, dx, *geo, p1, p2,
+                                     targets, rows, cap)
+    got = _back(mod, dx, (N, C, H, W))
+    assert_close(got, want, 1e-4, "pair dx")
+    tot = _back(mod, rows, (cap, C, 2))[:nrows].astype(np.float64).sum(axis=0)
+    s1, s2 = _rows_of(got, zt, mt)
+    scale = np.abs(got.astype(np.float64) * (zt - mt)).sum(axis=(0, 2, 3)).max()
+    assert np.abs(tot[:, 1] - s2).max() <= 1e-5 * scale
+    assert np.abs(tot[:, 0] - s1).max() <= 1e-5 * np.abs(got.astype(np.float64)).sum(axis=(0, 2, 3)).max()
+
+
+@pytest.mark.parametrize("name", ["l1", "l2", "l3", "l4", "l2a", "l2d"])
+def test_grouped_weight_gradient_with_pending_batchnorm(hip_device, name):
+    from test_hip_fullsize import LAYERS
+    mod = hip_device.mod
+    C, H, W, O, k, s, p = LAYERS[name]
+    geo = (N, C, H, W, O, k, s, p)
+    assert mod.conv2d_bn_bwd_supported(*geo)[1]
+    oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    dy = (rng.standard_normal((N, O, oh, ow)) * 0.1).astype(np.float32)
+    z, gamma, mean, var = _bn_layer(rng, dy.shape, offset=4.0)
+    pend = _pending(mod, dy, z, gamma, mean, var)
+    mod.bn_bwd_table(pend, O)
+    dz, dg_ref, db_ref = R.batchnorm2d_backward(dy, z, gamma, mean, var)
+    assert_close(_back(mod, pend.dgamma, (1, O, 1, 1)), dg_ref, 1e-4, "dgamma (table launch)")
+    assert_close(_back(mod, pend.dbeta, (1, O, 1, 1)), db_ref, 1e-4, "dbeta (table launch)")
+    # the pending gradient written out
+    dzh = mod.Array(dy.size)
+    mod.bn2d_backward_apply_table(_arr(mod, dy), pend.z, pend.table, dzh, N, O, oh * ow)
+    assert_close(_back(mod, dzh, dy.shape), dz, 1e-4, "apply_table")
+    want = R.conv2d_wgrad(x, dz.astype(np.float32), k, s, p)
+    # filler layers so that the group is large enough to run grouped (a small group is re-planned stand-alone)
+    fill = []
+    assert mod.wgrad_group_begin()
+    dwh = mod.Array(O * C * k * k)
+    xh, dyh = _arr(mod, x), _arr(mod, dy)
+    queued = mod.conv2d_wgrad_bn(xh, None, dyh, pend.z, pend.table, dwh, *geo)
+    assert queued
+    fx, fdy = _arr(mod, rng.standard_normal((N, 32, 16, 16))), _arr(mod, rng.standard_normal((N, 32, 16, 16)))
+    for _ in range(3):
+        fill.append(mod.Array(32 * 32 * 9))
+        mod.conv2d_wgrad(fx, fdy, fill[-1], N, 32, 16, 16, 32, 3, 1, 1)
+    mod.wgrad_group_end()
+    assert_close(_back(mod, dwh, (O, C, k, k)), want, 1e-4, name + " dw (grouped, pending operand)")
+    # and alone in its group: the stand-alone fall-back writes the gradient out
+    assert mod.wgrad_group_begin()
+    dwh2 = mod.Array(O * C * k * k)
+    assert mod.conv2d_wgrad_bn(xh, None, dyh, pend.z, pend.table, dwh2, *geo)
+    mod.wgrad_group_end()
+    assert_close(_back(mod, dwh2, (O, C, k, k)), want, 1e-4, name + " dw (small group)")
+
+
+def _resnet_step(dev, fused, seed=0):
+    import deepflows_amd.nn.functional as F
+    from deepflows_amd import nn, optim, workloads
+    from deepflows_amd.tensor import Graph, Tensor
+    old = F._BN_BWD_FUSED
+    F._BN_BWD_FUSED = fused
+    try:
+        rng = np.random.default_rng(7)
+        x = np.clip(rng.standard_normal((N, 3, 32, 32)).astype(np.float32), -1, 1)
+        y = workloads.smooth_one_hot(rng.integers(0, 10, N), 10, 0.05)
+        np.random.seed(seed)
+        model = workloads.ResNet18(10, device=dev, register_blocks=True)
+        model.train()
+        opt = optim.SGD(model.parameters(), lr=0.05)
+        loss, out = workloads.train_step(model, nn.CrossEntropyLoss(), opt, Tensor(x, device=dev), Tensor(y, device=dev))
+        grads = [p.grad.numpy().copy() for p in model.parameters()]
+        res = (loss.numpy().copy(), out.numpy().copy(), grads)
+        Graph.free_graph_all()
+        return res
+    finally:
+        F._BN_BWD_FUSED = old
+
+
+def test_resnet18_step_with_and_without_the_pending_backward(hip_device):
+    """every parameter gradient of a batch-256 ResNet-18 step with the BatchNorm backward riding on its neighbours'
+    kernels against the same step with stand-alone BatchNorm backward launches"""
+    la, oa, ga = _resnet_step(hip_device, True)
+    lb, ob, gb = _resnet_step(hip_device, False)
+    assert np.array_equal(la, lb) and np.array_equal(oa, ob)          # (the forward pass is the same code)
+    # (a gradient that is zero analytically -- dbeta of a BatchNorm whose output gradient went through a BatchNorm backward
+    # and a convolution -- is rounding noise in both runs: differences are measured against the largest gradient entry of
+    # the whole step as well as against the tensor's own)
+    top = max(float(np.abs(b).max()) for b in gb)
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(ga, gb)):
+        d = float(np.abs(a.astype(np.float64) - b).max())
+        e = d / max(float(np.abs(b).max()), 1e-2 * top)
+        worst = max(worst, e)
+        assert e <= 1e-4, f"parameter {i} (shape {a.shape}): gradients differ by {e:.3e}"
+    print(f"pending vs stand-alone BatchNorm backward: worst relative difference of a parameter gradient {worst:.2e}")
