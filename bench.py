@@ -71,12 +71,16 @@ def make_batch(workload, rank, batch):
     return x, y.astype(np.float32)
 
 
-def build_job(workload, dev, rank, batch, register_blocks=True):
+def build_job(workload, dev, rank, batch, register_blocks=True, model_kind="plain"):
+    """model_kind (resnet18 only): "plain" = workloads.ResNet18Plain, whose forward() is the text of the reference's script
+    (test/ResNet_CIFAR10_cuda.py:31-47, 84-99: module calls, `out + identity`, two tensor.mean) -- the fusions happen
+    inside the modules (nn/lazy.py); "fused" = workloads.ResNet18, the forward() rewritten around the fused entry points."""
     from deepflows_amd import nn, optim, workloads
     from deepflows_amd.tensor import Tensor
     np.random.seed(0)                      # identical replicas on every rank
     if workload == "resnet18":
-        model = workloads.ResNet18(10, device=dev, register_blocks=register_blocks)
+        cls = workloads.ResNet18Plain if model_kind == "plain" else workloads.ResNet18
+        model = cls(10, device=dev, register_blocks=register_blocks)
         opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
     elif workload == "resnet18_wide":
         model = workloads.ResNet18Wide(10, device=dev, register_blocks=register_blocks)
@@ -235,6 +239,9 @@ def main():
                     help="conv input-gradient mode: reference-exact (default) or mathematically correct")
     ap.add_argument("--registration", choices=["all", "f6"], default="all",
                     help="all = every block registered (62 tensors); f6 = the reference script's 5 tensors")
+    ap.add_argument("--model", choices=["plain", "fused"], default="plain",
+                    help="resnet18: plain = the model written as the reference's script writes it (default: what an unmodified "
+                         "user model gets); fused = the forward() rewritten around the fused entry points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pmc-traffic", default=None,
                     help="PMC summary (tools/pmc_summary.py --json) to quote for traffic / executed flops instead of the "
@@ -272,7 +279,8 @@ def main():
     mod = dev.mod
     mod.conv_dgrad_mode = args.dgrad
     comm = parallel.init_communicator(dev)
-    model, opt, crit, xt, yt = build_job(args.workload, dev, rank, batch, register_blocks=(args.registration == "all"))
+    model, opt, crit, xt, yt = build_job(args.workload, dev, rank, batch, register_blocks=(args.registration == "all"),
+                                         model_kind=args.model)
     bucket = parallel.GradientBucket(opt.params, comm)
     opt.grad_scale = 1.0 / comm.world
     # DF_FORCE_SYNC=1 (with DF_FORCE_COMM=1): exercise the exchange path of a multi-GPU run on one GPU
@@ -337,6 +345,31 @@ def main():
     wall = comm.max_float(wall)
     gpu_ms = mod.event_elapsed_ms(e0, e1)
     final_loss = float(loss.numpy()[0])
+
+    # the OTHER way of writing the model (see build_job), same job, same K replays: reported beside the headline
+    other_kind = "fused" if args.model == "plain" else "plain"
+    other_value = None
+    if args.workload == "resnet18" and comm.world == 1 and sync is None and captured is not None:
+        try:
+            from deepflows_amd.graph_step import CapturedTrainStep
+            m2, o2, c2, x2, y2 = build_job(args.workload, dev, rank, batch, register_blocks=(args.registration == "all"),
+                                           model_kind=other_kind)
+            for _ in range(2):
+                workloads.train_step(m2, c2, o2, x2, y2)
+                Graph.free_graph()
+            cap2 = CapturedTrainStep(m2, c2, o2, x2, y2)
+            for _ in range(2):
+                cap2.replay()
+            mod.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                cap2.replay()
+            mod.synchronize()
+            other_value = batch * args.steps / (time.perf_counter() - t2)
+            cap2.destroy()
+            del m2, o2, cap2
+        except Exception as e:
+            print(f"[bench] the {other_kind} model was not timed ({type(e).__name__}: {e})", file=sys.stderr)
 
     # second pass over the same K steps with per-family HIP events (roofline); events cannot be
     # recorded inside a graph replay, so this pass issues the same step eagerly
@@ -422,6 +455,8 @@ def main():
                        "collective_library": mod.comm_rccl_path() if sync is not None else None},
             "gpu_ms_per_step": gpu_ms / args.steps, "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
             "final_loss": final_loss,
+            "model": args.model if args.workload == "resnet18" else None,
+            f"{other_kind}_images_per_s": other_value,
             "roofline": roofline,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in
                         sorted(fams.items(), key=lambda kv: -kv[1]["ms_per_step"])},

@@ -11,13 +11,13 @@
 // launch boundary (5-7 us each way for 0.1-25 MB at batch 256: ramp + two dependent round trips).  Here
 //   * the kernel that PRODUCES dy (the input-gradient kernel of the next layer) leaves per-channel partial rows
 //     (sum dy, sum dy (z - mu)) behind from its epilogue, one row per workgroup -- one extra read stream of z at the
-//     positions it stores; no atomics, no hand-off inside the launch (an in-launch combination of the rows by the last
-//     workgroup to arrive was built first: its write-through stores, counter round trip and re-read cost every workgroup
-//     3-5 us at its END, 5-15 us per launch, more than the stand-alone BatchNorm kernel it replaces);
+//     positions it stores; no atomics, nothing a workgroup waits for at its END (an in-launch combination of the rows by
+//     the last workgroup to arrive was built first: its write-through stores, counter round trip and re-read cost every
+//     workgroup 3-5 us, 5-15 us per launch, more than the stand-alone BatchNorm kernel it replaces);
 //   * the kernels that CONSUME dz (the input gradient and the weight gradient of the convolution whose output z is): every
-//     workgroup of the input-gradient launch adds up the rows (all its threads, 16-byte loads, a fixed order: bn_table_build)
-//     while its operands are in flight and forms dz on its operand loads; its first workgroup writes dgamma / dbeta and the
-//     per-channel table the weight gradient reads.
+//     workgroup of the input-gradient launch adds the rows up at its START while its operands are in flight
+//     (BnTableBuilder) and forms dz on its operand loads; its first workgroup writes dgamma / dbeta and the per-channel
+//     table the weight gradient reads.
 // HBM bytes are the same as with the stand-alone kernel (z is read once by the producer and once by each consumer,
 // dz is never written); what disappears is the launch.
 #pragma once
@@ -47,9 +47,8 @@ int run_dgrad_ow_pair(const float* dy, const float* w, const float* dy2, const f
 namespace dfhip {
 
 // (A, B, mean, Cc) of a channel from its complete sums s1 = sum dy, s2 = sum dy (z - mean); sdyx = dgamma
-__device__ __forceinline__ float4 bn_bwd_coeffs(const BnBwdIn& b, int o, float s1, float s2, float& sdyx) {
-  const float mean = b.mean[o], var = b.var[o];
-  const float w = b.gamma ? b.gamma[o] : 1.0f;
+__device__ __forceinline__ float4 bn_bwd_coeffs(const BnBwdIn& b, float mean, float var, float w, float s1, float s2,
+                                                float& sdyx) {
   const float rsd = 1.0f / sqrtf(var + b.eps);
   sdyx = s2 * rsd;
   const float k1 = s1 * b.inv_m, k2 = sdyx * b.inv_m;
@@ -63,19 +62,36 @@ __device__ __forceinline__ float bn_bwd_point(float dy, float z, const float4 t)
 
 // The per-channel table of a pending BatchNorm backward, built by ALL threads of a workgroup (NT of them) from the rows
 // its producer left behind.  The rows are [nrows][O][K] floats, a row is O*K/4 <= NT 16-byte pieces; thread (g, c) adds
-// the pieces c of rows g, g + NG, ... -- issue() requests the first 16 of them, the caller then requests its operands,
-// finish() adds them up (further rows, if any, in rounds of 16) --, the NG partial sums of a column are added through LDS
-// in the order of g, and thread o turns (sum dy, sum dy (z - mean)) into (A, B, mean, Cc).  A fixed order of additions:
-// the same bits in every workgroup and every run.  tab: O float4 in LDS; part: kBnPartFloats floats of LDS scratch.
-// `first`: this workgroup also leaves the table and the layer's parameter gradients behind.  finish() contains workgroup
-// barriers (every thread calls it) and ends with its threads' LDS stores: the caller's next barrier publishes tab.
+// the pieces c of rows g, g + NG, ... -- issue() requests the first 16 of them (and the channel constants), the caller
+// then requests its operands, finish() adds them up (further rows, if any, in rounds of 16) --, the NG partial sums of a
+// column are added through LDS in the order of g, and thread o turns (sum dy, sum dy (z - mean)) into (A, B, mean, Cc).
+// A fixed order of additions: the same bits in every workgroup and every run.  tab: O float4 in LDS; part:
+// kBnPartFloats floats of LDS scratch.  `first`: this workgroup also leaves the table and the layer's parameter
+// gradients behind.  finish() contains workgroup barriers (every thread calls it) and ends with its threads' LDS
+// stores: the caller's next barrier publishes tab.
+// What this costs a 7.5-8.5 us input-gradient launch of the 16 x 16 / 8 x 8 stages (tools/bn_bwd_bench.py, same box):
+// +1.0-1.3 us for the second operand stream and the transform, +1.7-1.9 us for the table (every workgroup pulls the 64 KB
+// of rows through its L2, two LDS rounds).  Built and measured instead, both dropped: (a) the rows combined inside the
+// PRODUCING launch by the last workgroup of a group to arrive (write-through stores, arrival counter, re-read): every
+// workgroup waits 3-5 us at its end, +5-15 us per launch; (b) 16 group sums published by the first workgroups of the
+// CONSUMING launch as 8-byte {value, tag} granules that every workgroup polls behind its operand loads (correct over 150
+// repetitions from cleared tags, a self-computing fall-back instead of a progress assumption): the publish is a
+// write-through store behind an L2 read, visible after 2.5-3 us -- +2.3-2.7 us, no better than everybody reading all rows.
 constexpr int kBnPartFloats = 1024 + 768;
 template <int NT>
 struct BnTableBuilder {
+  static constexpr int OPT = (256 + NT - 1) / NT;      // channels per thread
   float4 v[16];
+  float cm[OPT], cv[OPT], cw[OPT];                     // the thread's channels: mean, var, gamma
   int w4, NG, g, c;
   __device__ __forceinline__ void issue(const BnBwdIn& b, int O) {
     if (!b.rows) return;
+    // (the channel constants with the first requests, not behind the caller's operands)
+#pragma unroll
+    for (int i = 0; i < OPT; i++) {
+      const int o = min((int)threadIdx.x + i * NT, O - 1);
+      cm[i] = b.mean[o]; cv[i] = b.var[o]; cw[i] = b.gamma ? b.gamma[o] : 1.0f;
+    }
     w4 = (O * b.K) >> 2;
     NG = NT / w4;
     g = (int)threadIdx.x / w4;
@@ -115,15 +131,19 @@ struct BnTableBuilder {
       tot[col] = t;
     }
     __syncthreads();
-    for (int o = tid; o < O; o += NT) {
-      float sdyx;
-      const float s1 = tot[o * b.K];
-      const float4 t = bn_bwd_coeffs(b, o, s1, tot[o * b.K + b.kidx], sdyx);
-      tab[o] = t;
-      if (first) {
-        if (b.table) reinterpret_cast<float4*>(b.table)[o] = t;
-        if (b.dgamma) b.dgamma[o] = sdyx;
-        if (b.dbeta) b.dbeta[o] = s1;
+#pragma unroll
+    for (int i = 0; i < OPT; i++) {
+      const int o = tid + i * NT;
+      if (o < O) {
+        float sdyx;
+        const float s1 = tot[o * b.K];
+        const float4 t = bn_bwd_coeffs(b, cm[i], cv[i], cw[i], s1, tot[o * b.K + b.kidx], sdyx);
+        tab[o] = t;
+        if (first) {
+          if (b.table) reinterpret_cast<float4*>(b.table)[o] = t;
+          if (b.dgamma) b.dgamma[o] = sdyx;
+          if (b.dbeta) b.dbeta[o] = s1;
+        }
       }
     }
   }

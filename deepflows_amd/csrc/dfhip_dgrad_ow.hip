@@ -89,14 +89,15 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
                                                      const float* __restrict__ dy2, const float* __restrict__ w2,
                                                      const OwBn bn) {
   static_assert(!PAIR || GEO == 1, "the shortcut rides on the stride-2 3x3 kernel");
-  static_assert(NST == 0 || BNI, "the statistics epilogue exists in the BatchNorm builds");
   constexpr int NP = O / 2, NSL = OwGeo<GEO>::NSL;
   constexpr int KS = 1 + NST;
+  constexpr bool BN = BNI || NST > 0;               // a BatchNorm build: more loads than a wave keeps in flight, see below
   __shared__ float Wl[NSL + (PAIR ? 1 : 0)][O][32]; // the weight slices of this channel tile: [slice][o][c]
   __shared__ float4 tab[BNI ? (PAIR ? 2 : 1) : 1][BNI ? O : 1];
   __shared__ float wsum[NST ? 4 : 1][NST ? 32 : 1][KS];
   __shared__ float mtl[NST ? NST : 1][32];
   __shared__ __attribute__((aligned(16))) float tpart[BNI ? kBnPartFloats : 4];
+  const int lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int HW = H << lw;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
       }
     }
   };
-  if constexpr (!BNI) {
+  if constexpr (!BN) {
     // everything this wave needs from global memory is requested up front: its dY operand, the gradient the tensor already
     // holds (added in the epilogue; requested now, not after the MFMAs), its share of the weight slices
     load_operands();
@@ -174,17 +175,21 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
         mtl[j][ch] = bn.mt[j][c0 + ch];
       }
     }
-    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
-    BnTableBuilder<256> tb;
-    tb.issue(bn.in, O);
-    __builtin_amdgcn_sched_barrier(0);
-    load_operands();
-    __builtin_amdgcn_sched_barrier(0);
-    tb.finish(bn.in, O, tab[0], tpart, first);
-    if constexpr (PAIR) {
-      __syncthreads();                                 // (the scratch of the first table is free)
-      tb.issue(bn.in2, O);
-      tb.finish(bn.in2, O, tab[1], tpart, first);
+    if constexpr (BNI) {
+      const bool first = lin == 0;
+      BnTableBuilder<256> tb;
+      tb.issue(bn.in, O);
+      __builtin_amdgcn_sched_barrier(0);
+      load_operands();
+      __builtin_amdgcn_sched_barrier(0);
+      tb.finish(bn.in, O, tab[0], tpart, first);
+      if constexpr (PAIR) {
+        __syncthreads();                               // (the scratch of the first table is free)
+        tb.issue(bn.in2, O);
+        tb.finish(bn.in2, O, tab[1], tpart, first);
+      }
+    } else {
+      load_operands();
     }
   }
 #pragma unroll
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
   }
   __syncthreads();
   if constexpr (NST == 0) { if (!live) return; }
-  if constexpr (BNI) {
+  if constexpr (BN) {
     __builtin_amdgcn_sched_barrier(0);
     load_epilogue();
     __builtin_amdgcn_sched_barrier(0);
@@ -771,20 +776,17 @@ int launch_ow_s1(const float* dy, const float* w, const float* add, float* dx, i
   } else {
     int st = make_ow_bn(bn, bi, bi2, so, (int)grid.x, (int)grid.y, C);
     if (st != DFHIP_OK) return st;
-    // (a launch with statistics but without a pending BatchNorm in front takes the BNI build with the identity table:
-    // its z operand is dy itself)
-    if (!bi) { bn.in = BnBwdIn{}; bn.in.z = dy; }
-    if (PAIR && !bi2) { bn.in2 = BnBwdIn{}; bn.in2.z = dy2; }
     const int nst = so ? so->n : 0;
-    if (nst == 0)
-      DF_LAUNCH((k_dgrad_ow_s1<O, GEO, PAIR, true, 0>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg,
-                dy2, w2, bn);
-    else if (nst == 1)
-      DF_LAUNCH((k_dgrad_ow_s1<O, GEO, PAIR, true, 1>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg,
-                dy2, w2, bn);
-    else
-      DF_LAUNCH((k_dgrad_ow_s1<O, GEO, PAIR, true, 2>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg,
-                dy2, w2, bn);
+    const bool bni = bi || bi2;
+    // (of a PAIR only one gradient may be pending: the other one's descriptor is the identity, its z operand re-reads dY)
+    if (bni && !bi) { bn.in = BnBwdIn{}; bn.in.z = dy; }
+    if (bni && PAIR && !bi2) { bn.in2 = BnBwdIn{}; bn.in2.z = dy2; }
+#define DF_OW(BNIV, NSTV)                                                                                             \
+  DF_LAUNCH((k_dgrad_ow_s1<O, GEO, PAIR, BNIV, NSTV>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg, \
+            dy2, w2, bn)
+    if (bni) { if (nst == 0) DF_OW(true, 0); else if (nst == 1) DF_OW(true, 1); else DF_OW(true, 2); }
+    else { if (nst == 1) DF_OW(false, 1); else DF_OW(false, 2); }
+#undef DF_OW
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
   }

@@ -17,7 +17,7 @@ import numpy as np
 from .. import backend_api, tensor
 from ..autograd import is_grad_enable
 from ..backend_selection import BackendTensor
-from ..tensor import Tensor
+from ..tensor import Tensor, realize
 
 
 def _fused(t):
@@ -40,15 +40,19 @@ _CONV_BN_STATS = os.environ.get("DF_CONV_BN_STATS", "1") != "0"
 # weight-gradient kernels form dz on their operand loads.  Anything that cannot take a pending gradient writes it out first
 # (_pending_materialise); DF_BN_BWD_FUSED=0 switches the whole mechanism off.
 _BN_BWD_FUSED = os.environ.get("DF_BN_BWD_FUSED", "1") != "0"
+# the same for the two convolutions that read a block's input when its shortcut is a convolution (one launch forms both input
+# gradients): measured, that launch with two pending operands takes longer than the two stand-alone BatchNorm launches it
+# replaces (layer2's first block: 9.2 -> 24 us against 5.2 + 6.5 us) -- off unless asked for
+_BN_BWD_PAIR = os.environ.get("DF_BN_BWD_PAIR", "0") != "0"
 
 
 class _PendingBN:
     """dz = A dy + B (z - mean) + Cc per channel, not yet applied; handles as the C ABI wants them."""
-    __slots__ = ("z", "rows", "nrows", "K", "kidx", "mean", "var", "gamma", "eps", "m", "dgamma", "dbeta", "table",
-                 "table_ready", "geo", "keep")
+    __slots__ = ("z", "rows", "nrows", "cap_rows", "K", "kidx", "mean", "var", "gamma", "eps", "m", "dgamma", "dbeta",
+                 "table", "table_ready", "geo", "keep")
 
-    def __init__(self, z, rows, nrows, K, kidx, mean, var, gamma, eps, geo, dgamma, dbeta, table, keep):
-        self.z, self.rows, self.nrows, self.K, self.kidx = z, rows, nrows, K, kidx
+    def __init__(self, z, rows, nrows, cap_rows, K, kidx, mean, var, gamma, eps, geo, dgamma, dbeta, table, keep):
+        self.z, self.rows, self.nrows, self.cap_rows, self.K, self.kidx = z, rows, nrows, cap_rows, K, kidx
         self.mean, self.var, self.gamma, self.eps = mean, var, gamma, eps
         self.geo = geo                      # (N, O, HW) of dy
         self.m = geo[0] * geo[2]
@@ -58,11 +62,12 @@ class _PendingBN:
 
 
 class _BnRows:
-    """what a producer left behind for the BatchNorm node `owner`: rows (nrows x C x K), sums 0 and 1 + j are layer j's"""
-    __slots__ = ("owner", "rows", "nrows", "K")
+    """what a producer left behind for the BatchNorm node `owner`: rows (nrows of a buffer with room for cap_rows, x C x K),
+    sums 0 and 1 + j are layer j's"""
+    __slots__ = ("owner", "rows", "nrows", "cap_rows", "K")
 
-    def __init__(self, owner, rows, nrows, K):
-        self.owner, self.rows, self.nrows, self.K = owner, rows, nrows, K
+    def __init__(self, owner, rows, nrows, cap_rows, K):
+        self.owner, self.rows, self.nrows, self.cap_rows, self.K = owner, rows, nrows, cap_rows, K
 
 
 def _alias(t):
@@ -117,8 +122,12 @@ def _stats_targets(xnode, me, sib=None):
     return xnode._deferred_targets()
 
 
-def _tag_rows(out, xnode, rows, nrows, K):
-    out.bn_rows = _BnRows(xnode, rows, nrows, K)
+def _new_rows(cap, C, K, dev):
+    return _new((cap, C, K), dev)
+
+
+def _tag_rows(out, xnode, rows, nrows, cap, K):
+    out.bn_rows = _BnRows(xnode, rows, nrows, cap, K)
 
 
 
@@ -182,6 +191,7 @@ class _LinearFused(_FusedNode):
 
 
 def linear(input: Tensor, weight: Tensor, bias=None):
+    input = realize(input)
     if _fused(input) and input.ndim == 2 and weight.ndim == 2:
         return _LinearFused(input, weight, bias)
     affine = input @ weight
@@ -204,6 +214,7 @@ class _ReLUFused(_FusedNode):
 
 
 def relu(input: Tensor) -> Tensor:
+    input = realize(input)
     if _fused(input):
         return _ReLUFused(input)
     return tensor.maximum(input, 0)
@@ -262,6 +273,7 @@ _LINEAR_RELU = os.environ.get("DF_LINEAR_RELU", "1") != "0"
 def linear_relu(input: Tensor, weight: Tensor, bias=None):
     """F.relu(F.linear(input, weight, bias)); one node on a fused device when the layer is small enough for the
     one-launch kernels."""
+    input = realize(input)
     if _fused(input) and is_grad_enable():
         node = _LinearReluFused.build(input, weight, bias)
         if node is not None:
@@ -342,6 +354,7 @@ class _CrossEntropyFused(_FusedNode):
 
 
 def cross_entropy(input: Tensor, target: Tensor, reduction: str = 'mean', dim: int = 1):
+    input = realize(input)
     if (_fused(input) and reduction == 'mean' and dim == 1 and input.ndim == 2
             and not target.requires_grad):
         return _CrossEntropyFused(input, target)
@@ -434,6 +447,7 @@ class _Conv2dFused(_FusedNode):
         biases that read the same tensor -- a residual block and its shortcut (test/ResNet_CIFAR10_cuda.py:31-47) -- from
         ONE launch (the shortcut rides as a tenth tap of the 3x3 loop); two ordinary nodes come back, each with its own
         grad_fn.  None when that form does not apply: the caller then calls the two modules."""
+        x = realize(x)
         dev = x.device
         fn = getattr(dev.mod, "conv2d_forward_s2_pair", None)
         if (fn is None or not _S2_PAIR or len(x.shape) != 4 or conv1.bias is not None or conv_d.bias is not None
@@ -490,6 +504,8 @@ class _Conv2dFused(_FusedNode):
         if self.bias is not None:
             return False
         host = getattr(self, "_sibling_host", None)
+        if (host is not None or self.shortcut_sibling is not None) and not _BN_BWD_PAIR:
+            return False
         if host is not None:
             # a block's 1x1 shortcut: its input gradient rides on conv1's pair launch
             dg = mod.conv2d_bn_bwd_supported(*host.geo, pair=True)[0] if self.x.requires_grad else True
@@ -520,7 +536,7 @@ class _Conv2dFused(_FusedNode):
                 targets = _stats_targets(self.x, self, sib)
                 ok, _, cap = dev.mod.conv2d_bn_bwd_supported(*self.geo, pair=True)
                 if (pend is not None or spend is not None or targets) and ok:
-                    rows = _new((cap, C, 1 + len(targets)), dev) if targets else None
+                    rows = _new_rows(cap, C, 1 + len(targets), dev) if targets else None
                     nrows = dev.conv2d_dgrad_pair_bn(g._handle, self.wd._handle, sg.compact()._handle, sib.wd._handle, h(add),
                                                      out._handle, N, C, H, W, O, pend, spend, targets, h(rows), cap)
                     if pend is not None:
@@ -528,7 +544,7 @@ class _Conv2dFused(_FusedNode):
                     if spend is not None:
                         spend.table_ready = True
                     if targets:
-                        _tag_rows(out, self.x, rows, nrows, 1 + len(targets))
+                        _tag_rows(out, self.x, rows, nrows, cap, 1 + len(targets))
                     sib._dx_delivered = True
                     return out
                 if pend is not None:
@@ -545,13 +561,13 @@ class _Conv2dFused(_FusedNode):
             targets = _stats_targets(self.x, self)
             ok, _, cap = dev.mod.conv2d_bn_bwd_supported(*self.geo)
             if (pend is not None or targets) and ok:
-                rows = _new((cap, C, 1 + len(targets)), dev) if targets else None
+                rows = _new_rows(cap, C, 1 + len(targets), dev) if targets else None
                 nrows = dev.conv2d_dgrad_bn(g._handle, self.wd._handle, h(add), out._handle, *self.geo, pend, targets,
                                             h(rows), cap)
                 if pend is not None:
                     pend.table_ready = True
                 if targets:
-                    _tag_rows(out, self.x, rows, nrows, 1 + len(targets))
+                    _tag_rows(out, self.x, rows, nrows, cap, 1 + len(targets))
                 return out
             if pend is not None:
                 g = self._plain_of(grad, pend)
@@ -598,6 +614,7 @@ def conv2d(x: Tensor, kernel: Tensor, padding: int = 0, stride: int = 1, bias=No
     """x (N,C,H,W), kernel (O,C,k,k) -> (N,O,oh,ow).  `bias` (1,O,1,1) is an extension used by
     nn.Conv2d so the fused kernel adds it in its epilogue; the reference adds it in
     Conv2d.forward (conv.py:104-108)."""
+    x = realize(x)
     if _fused(x):
         return _Conv2dFused(x, kernel, bias, padding, stride)
     N = x.shape[0]
@@ -671,6 +688,7 @@ class _PoolLinearFused(_FusedNode):
 
 def mean_hw_linear(x: Tensor, fc) -> Tensor:
     """fc(mean_hw(x)) for an nn.Linear `fc`; one node on a fused device when the layer is classifier-sized."""
+    x = realize(x)
     mod = x.device.mod
     if (_fused(x) and len(x.shape) == 4 and hasattr(mod, "pool_linear_forward") and int(fc.weight.shape[1]) <= 16
             and int(fc.weight.shape[0]) == int(x.shape[1]) and os.environ.get("DF_HEAD_FUSED", "1") != "0"):
@@ -681,6 +699,7 @@ def mean_hw_linear(x: Tensor, fc) -> Tensor:
 def mean_hw(x: Tensor) -> Tensor:
     """mean over H then over W with the reference's `mean(axis)` semantics (two calls of
     tensor.mean(x, axis=2)); one kernel each way on a fused device."""
+    x = realize(x)
     if _fused(x) and len(x.shape) == 4 and hasattr(x.device.mod, "reduce_axis"):
         return _MeanHWFused(x)
     return tensor.mean(tensor.mean(x, axis=2), axis=2)
@@ -704,6 +723,7 @@ class _MaxPool2dFused(_FusedNode):
 
 
 def max_pool2d(x: Tensor, kernel_size: int, stride: int, padding=0):
+    x = realize(x)
     if _fused(x) and padding == 0 and stride == kernel_size:
         return _MaxPool2dFused(x, kernel_size)
     N, C = x.shape[0], x.shape[1]
@@ -715,6 +735,7 @@ def max_pool2d(x: Tensor, kernel_size: int, stride: int, padding=0):
 
 
 def avg_pool2d(x: Tensor, kernel_size: int, stride: int, padding=0):
+    x = realize(x)
     N, C = x.shape[0], x.shape[1]
     col = _im2col2d(_pad2d(x, padding), kernel_size, stride)
     oh, ow = col.shape[-2:]
@@ -778,7 +799,7 @@ class _BatchNorm2dFused(_FusedNode):
             if left is not None and left.owner is self and self._defer:
                 # the producer of `grad` left this layer's sums behind: the convolution in front forms dx on its loads
                 table = _new((C, 4), dev)
-                pend = _PendingBN(self.xd._handle, left.rows._handle, left.nrows, left.K, 1, self.mean._handle,
+                pend = _PendingBN(self.xd._handle, left.rows._handle, left.nrows, left.cap_rows, left.K, 1, self.mean._handle,
                                   self.var._handle, h(self.wd), self.eps, (N, C, HW), dg._handle, db._handle,
                                   table._handle, (self.xd, left.rows, self.mean, self.var, self.wd, dg, db, table, grad))
                 dx = _alias(grad)
@@ -797,6 +818,7 @@ class _BatchNorm2dFused(_FusedNode):
 
 
 def batch_norm2d_train(x, weight, bias, running_mean, running_var, eps, momentum, residual=None):
+    x, residual = realize(x), realize(residual)
     return _BatchNorm2dFused(x, weight, bias, running_mean, running_var, eps, momentum, residual)
 
 
@@ -848,7 +870,7 @@ class _BatchNorm2dPairFused(_FusedNode):
             if left is not None and left.owner is self and self._defer and left.K == 3:
                 for i, (xd, wd, bn, (mean, var)) in enumerate(zip(self.xd, self.wd, self.bns, self.stats)):
                     dg, db, table = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev), _new((C, 4), dev)
-                    pend = _PendingBN(xd._handle, left.rows._handle, left.nrows, left.K, 1 + i, mean._handle, var._handle,
+                    pend = _PendingBN(xd._handle, left.rows._handle, left.nrows, left.cap_rows, left.K, 1 + i, mean._handle, var._handle,
                                       h(wd), float(bn.eps), (N, C, HW), dg._handle, db._handle, table._handle,
                                       (xd, left.rows, mean, var, wd, dg, db, table, grad))
                     dx = _alias(grad)
@@ -956,7 +978,7 @@ class _BnConv2dFused(_FusedNode):
                     # (the input gradient first: its launch writes the table the weight gradient reads)
                     targets = [(self.xd._handle, self.mean._handle)] if defer else None
                     cap = dev.mod.conv2d_bn_bwd_supported(*self.geo)[2]
-                    rows = _new((cap, C, 2), dev) if defer else None
+                    rows = _new_rows(cap, C, 2, dev) if defer else None
                     nrows = dev.conv2d_dgrad_bn(g._handle, self.wd._handle, None, da._handle, *self.geo, pend, targets,
                                                 h(rows), cap)
                     if pend is not None:
@@ -964,7 +986,7 @@ class _BnConv2dFused(_FusedNode):
                     dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
                     if defer:
                         table = _new((C, 4), dev)
-                        mine = _PendingBN(self.xd._handle, rows._handle, nrows, 2, 1, self.mean._handle, self.var._handle,
+                        mine = _PendingBN(self.xd._handle, rows._handle, nrows, cap, 2, 1, self.mean._handle, self.var._handle,
                                           h(self.gd), self.eps, (N, C, H * W), dg._handle, db._handle, table._handle,
                                           (self.xd, rows, self.mean, self.var, self.gd, dg, db, table, da))
                         dx = _alias(da)
@@ -1018,6 +1040,7 @@ def bn_conv2d_train(x, bn, conv):
     applied on the convolution's operand loads (one node, no normalised tensor).  Returns None when that form does
     not apply (not a fused device, evaluation mode, x carries no convolution partials, or the shape has no such
     kernel): the caller then writes conv(bn(x))."""
+    x = realize(x)
     mod = x.device.mod
     if not (_BN_INPUT and _CONV_BN_STATS and _fused(x) and hasattr(mod, "conv2d_forward_bn_input") and bn.training
             and is_grad_enable() and bn.weight is not None and bn.bias is not None):
@@ -1028,6 +1051,7 @@ def bn_conv2d_train(x, bn, conv):
 def batch_norm2d_pair_fusable(xa, bn_a, xb, bn_b):
     """True when bn_a(xa) + bn_b(xb) can run as the paired node: fused device, both layers in training
     mode with affine parameters, equal shapes, both inputs carry convolution partials."""
+    xa, xb = realize(xa), realize(xb)
     mod = xa.device.mod
     return (_fused(xa) and hasattr(mod, "bn2d_forward_partials_pair") and bn_a.training and bn_b.training
             and is_grad_enable() and tuple(xa.shape) == tuple(xb.shape) and len(xa.shape) == 4
@@ -1036,6 +1060,7 @@ def batch_norm2d_pair_fusable(xa, bn_a, xb, bn_b):
 
 
 def batch_norm2d_pair_train(xa, bn_a, xb, bn_b):
+    xa, xb = realize(xa), realize(xb)
     return _BatchNorm2dPairFused(xa, bn_a, xb, bn_b)
 
 
@@ -1110,6 +1135,7 @@ _STEM_FUSED_BWD = os.environ.get("DF_STEM_FUSED_BWD", "1") != "0"
 def bn_relu_maxpool2_fusable(x, bn, pool):
     """True when pool(relu(bn(x))) can run as the fused stem node: fused device, training mode,
     2x2 / stride-2 / unpadded pooling, even height, width a multiple of 8."""
+    x = realize(x)
     if not (_fused(x) and bn.training and hasattr(x.device.mod, "bn_relu_maxpool2_forward")):
         return False
     k = getattr(pool, "kernel_size", None)
@@ -1120,6 +1146,7 @@ def bn_relu_maxpool2_fusable(x, bn, pool):
 
 
 def bn_relu_maxpool2_train(x, bn):
+    x = realize(x)
     return _BnReluPoolFused(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum)
 
 
@@ -1189,6 +1216,7 @@ _STEM_NOZ = os.environ.get("DF_STEM_NOZ", "1") != "0"
 def stem_conv_bn_relu_pool_train(x, conv, bn, pool):
     """pool(relu(bn(conv(x)))) as one node without the convolution's output tensor, or None when that form does not
     apply (the caller then writes the three calls)."""
+    x = realize(x)
     return _StemNoZFused.build(x, conv, bn, pool)
 
 
@@ -1204,4 +1232,5 @@ class _BatchNorm2dEvalFused(_FusedNode):
 
 
 def batch_norm2d_eval(x, weight, bias, running_mean, running_var, eps):
+    x = realize(x)
     return _BatchNorm2dEvalFused(x, weight, bias, running_mean, running_var, eps)

@@ -1,0 +1,210 @@
+"""Deferred module calls: how a model written as the reference writes it reaches the fused kernels.
+
+The reference's scripts call one module after the other (test/ResNet_CIFAR10_cuda.py:31-47, 84-99):
+
+    out = self.conv1(x); out = self.bn1(out); out = self.conv2(out); out = self.bn2(out)      # a residual block
+    for layer in self.downsample: identity = layer(identity)
+    out = out + identity
+    x = self.conv1(x); x = self.bn1(x); x = self.relu(x); x = self.pool1(x)                   # the stem
+    x = tensor.mean(x, axis=2); x = tensor.mean(x, axis=2); x = self.fc(x)                    # the head
+
+The hip device has kernels for the SEQUENCES (the stem without its full-resolution tensor; BatchNorm applied on the next
+convolution's operand loads; a block's 3x3 / stride-2 convolution and its 1x1 shortcut from one launch; the block's two
+BatchNorms and its sum in one pass; the two means and the Linear in one launch).  `deepflows_amd/workloads.py` used to reach
+them through a forward() rewritten around private entry points.  Here the modules themselves do it: on a fused device, in
+training mode, with gradients enabled, Conv2d / BatchNorm2d / ReLU return a `tensor.LazyTensor` that only RECORDS the call
+when its input is a recorded call it can extend, and the call that completes a sequence (MaxPool2d, `+`, Linear) -- or
+anything else that touches the object -- launches.  What is launched for a sequence is exactly what the hand-written forward
+launched; what is launched when a deferred result is touched on its own is the ordinary node of that module.
+
+Recorded forms (x0 a real tensor):
+    conv(x0)                                   "conv"
+    bn(conv(..))                               "bn"        (training mode only)
+    conv(bn(conv(..)))                         "conv" over "bn"
+    relu(bn(conv(x0)))                         "relu"
+    mean(x0, axis=2), mean(mean(x0, 2), 2)     "mean2", "meanhw"
+Completing calls: MaxPool2d(relu(bn(conv(x0)))), bn(conv(bn(conv(x0)))) + identity, Linear(meanhw(x0)).
+DF_LAZY_MODULES=0 switches the mechanism off (every module call launches its own node, as before)."""
+import os
+
+from .. import tensor
+from ..autograd import is_grad_enable
+from ..tensor import LazyTensor, Tensor, realize
+from . import functional as F
+
+ENABLED = os.environ.get("DF_LAZY_MODULES", "1") != "0"
+
+
+def _state(x):
+    """(op, input, module, extra) of a deferred result that has not been forced, else None"""
+    if type(x) is not LazyTensor:
+        return None
+    st = object.__getattribute__(x, "_lz")
+    return None if st[4] is not None else st
+
+
+def _is(x, op):
+    st = _state(x)
+    return st is not None and st[0] == op
+
+
+def _can_defer(x):
+    """deferral applies to tensors of a fused device while gradients are recorded"""
+    if not ENABLED or not is_grad_enable():
+        return False
+    if _state(x) is not None:
+        return True
+    x = realize(x)
+    return isinstance(x, Tensor) and F._fused(x)
+
+
+# ---- what the modules call ---------------------------------------------------------------------------------------------
+def conv2d(module, x):
+    """Conv2d.forward"""
+    if _can_defer(x) and (_state(x) is None or _is(x, "bn")):
+        return LazyTensor("conv", x, module)
+    return F.conv2d(realize(x), module.weight, module.padding, module.stride, bias=module.bias)
+
+
+def batch_norm2d(module, x):
+    """BatchNorm2d.forward without a residual: deferred behind a deferred convolution in training mode; None = not
+    deferred (the module runs its own forward on realize(x))"""
+    if module.training and _is(x, "conv") and ENABLED and is_grad_enable():
+        return LazyTensor("bn", x, module)
+    return None
+
+
+def _input(x):
+    return _state(x)[1]
+
+
+def _conv_of_real(x):
+    """x is a recorded convolution of a tensor that exists"""
+    return _is(x, "conv") and _state(_input(x)) is None
+
+
+def relu(x):
+    """ReLU.forward on a deferred bn(conv(x0)); None = not that form"""
+    if _is(x, "bn") and _conv_of_real(_input(x)):
+        return LazyTensor("relu", x)
+    return None
+
+
+def max_pool2d(module, x):
+    """MaxPool2d.forward: pool(relu(bn(conv(x0)))) is the stem; None = not that form"""
+    if not _is(x, "relu"):
+        return None
+    bn_l = _state(x)[1]
+    conv_l = _state(bn_l)[1]
+    conv, bn = _state(conv_l)[2], _state(bn_l)[2]
+    x0 = realize(_state(conv_l)[1])
+    out = F.stem_conv_bn_relu_pool_train(x0, conv, bn, module)
+    if out is not None:                                    # one node, the convolution's output never exists
+        return out
+    z = realize(conv_l)
+    if F.bn_relu_maxpool2_fusable(z, bn, module):
+        return F.bn_relu_maxpool2_train(z, bn)             # pool(relu(bn(z))) as one node
+    return None                                            # (the caller pools realize(x))
+
+
+def linear(module, x):
+    """Linear.forward on mean(mean(x0, 2), 2): the classifier head as one node; None = not that form"""
+    if not _is(x, "meanhw"):
+        return None
+    return F.mean_hw_linear(realize(_state(x)[1]), module)
+
+
+# ---- hooks of tensor.py ------------------------------------------------------------------------------------------------
+def _mean(x, axis, keepdims):
+    if not ENABLED or axis != 2 or keepdims or not is_grad_enable():
+        return None
+    if _is(x, "mean2"):
+        return LazyTensor("meanhw", _state(x)[1])
+    if _state(x) is None and isinstance(x, Tensor) and type(x) is not LazyTensor and F._fused(x) and len(x.shape) == 4 \
+            and hasattr(x.device.mod, "reduce_axis"):
+        return LazyTensor("mean2", x)
+    return None
+
+
+def _force(lz):
+    """the node a deferred result stands for, launched on its own"""
+    op, x, module, _, _ = object.__getattribute__(lz, "_lz")
+    if op == "conv":
+        if _is(x, "bn"):
+            # conv(bn(z)): BatchNorm applied on the convolution's operand loads where the device has that form
+            bn_l = _state(x)
+            z = realize(bn_l[1])
+            out = F.bn_conv2d_train(z, bn_l[2], module)
+            if out is not None:
+                return out
+        xr = realize(x)
+        return F.conv2d(xr, module.weight, module.padding, module.stride, bias=module.bias)
+    if op == "bn":
+        return module.forward(realize(x))
+    if op == "relu":
+        return F.relu(realize(x))
+    if op == "mean2":
+        return _plain_mean(realize(x))
+    if op == "meanhw":
+        return F.mean_hw(realize(x))
+    raise RuntimeError(f"deferred call of unknown kind {op!r}")
+
+
+def _plain_mean(x):
+    node = object.__new__(tensor.mean)                     # (past mean.__new__: this call is not deferred again)
+    node.__init__(x, axis=2)
+    return node
+
+
+def _add(a, b):
+    """`a + b` with a deferred: bn2(conv2(..)) + identity is the tail of a residual block"""
+    out = _block_tail(a, b)
+    if out is not None:
+        return out
+    return tensor.add(realize(a), realize(b))
+
+
+def _block_tail(out_l, identity):
+    """test/ResNet_CIFAR10_cuda.py:31-47 from `out = self.bn2(out)` on: the launches of the hand-fused block
+    (workloads.ResidualBlock.forward)"""
+    if not _is(out_l, "bn") or not _is(_state(out_l)[1], "conv"):
+        return None
+    bn2 = _state(out_l)[2]
+    conv2_l = _state(out_l)[1]
+    # the shortcut: bn_d(conv_d(x0)) not launched yet, or a tensor
+    short = None
+    if _is(identity, "bn") and _conv_of_real(_input(identity)):
+        short = (_state(_input(identity))[2], _state(identity)[2], _input(identity))      # (conv_d, bn_d, conv_d's record)
+    # conv1 of the block, when conv2 reads bn1(conv1(x0)) and nothing of it has been launched
+    conv1_l = None
+    c2_in = _state(conv2_l)[1]
+    if _is(c2_in, "bn") and _conv_of_real(_input(c2_in)):
+        conv1_l = _input(c2_in)
+    zd = None
+    if short is not None:
+        conv_d, bn_d, convd_l = short
+        xd0 = _state(convd_l)[1]
+        if conv1_l is not None and _state(conv1_l)[1] is xd0:
+            # conv1 and the shortcut convolution read the same tensor: one launch for both where the device has it
+            conv1 = _state(conv1_l)[2]
+            both = F._Conv2dFused.pair_s2(xd0, conv1, conv_d) if F._fused(xd0) else None
+            if both is not None:
+                z1, zd = both
+                object.__getattribute__(conv1_l, "_lz")[4] = z1
+                object.__getattribute__(convd_l, "_lz")[4] = zd
+        if zd is None:
+            zd = realize(convd_l)
+        if conv1_l is not None:
+            z1 = realize(conv1_l)
+            if hasattr(z1, "shortcut_sibling") and hasattr(zd, "shortcut_sibling") and getattr(z1, "x", None) is getattr(zd, "x", 0):
+                z1.shortcut_sibling = zd               # both read x: one launch forms both input gradients
+                zd._sibling_host = z1
+    z2 = realize(conv2_l)                              # conv2(bn1(z1)): bn1 on the operand loads where that form applies
+    if short is not None:
+        if F.batch_norm2d_pair_fusable(z2, bn2, zd, bn_d):
+            return F.batch_norm2d_pair_train(z2, bn2, zd, bn_d)        # bn2(z2) + bn_d(zd): one launch each way
+        identity = bn_d.forward(zd)
+    return bn2.forward(z2, residual=realize(identity))
+
+
+tensor._lazy_hooks.update({"force": _force, "add": _add, "mean": _mean})

@@ -1,6 +1,7 @@
 """Activation modules — mirror of DeepFlows/nn/modules/activation.py (the functional ones
 that work in the reference: ReLU, Tanh, LeakyReLU, Softmax, LogSoftmax)."""
 from .. import functional as F
+from .. import lazy
 from .module import Module
 
 __all__ = ['ReLU', 'Tanh', 'LeakyReLU', 'Softmax', 'LogSoftmax']
@@ -8,7 +9,8 @@ __all__ = ['ReLU', 'Tanh', 'LeakyReLU', 'Softmax', 'LogSoftmax']
 
 class ReLU(Module):
     def forward(self, input):
-        return F.relu(input)
+        deferred = lazy.relu(input)                    # (relu(bn(conv(x))) in front of a pooling layer: the stem, nn/lazy.py)
+        return deferred if deferred is not None else F.relu(lazy.realize(input))
 
 
 class Tanh(Module):

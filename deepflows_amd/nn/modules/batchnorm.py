@@ -7,6 +7,7 @@ from ... import backend_api, tensor
 from ...autograd import is_grad_enable
 from ...tensor import Tensor
 from .. import functional as F
+from .. import lazy
 from ..parameter import Parameter
 from .module import Module
 
@@ -27,6 +28,11 @@ class BatchNorm2d(Module):
     def forward(self, x: Tensor, residual: Tensor = None) -> Tensor:
         """`residual` (extension): returns bn(x) + residual; on a fused device in training mode the
         add happens inside the normalisation kernel."""
+        if residual is None:
+            deferred = lazy.batch_norm2d(self, x)      # (behind a recorded convolution the call is recorded too: nn/lazy.py)
+            if deferred is not None:
+                return deferred
+        x, residual = lazy.realize(x), lazy.realize(residual)
         if residual is not None:
             if self.training and bool(getattr(x.device.mod, "fused", False)):
                 return F.batch_norm2d_train(x, self.weight, self.bias, self.running_mean,

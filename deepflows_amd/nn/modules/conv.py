@@ -4,6 +4,7 @@ import math
 
 from ... import backend_api, tensor
 from .. import functional as F
+from .. import lazy
 from .. import init
 from ..parameter import Parameter
 from .module import Module
@@ -29,7 +30,8 @@ class Conv2d(Module):
                 init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x):
-        return F.conv2d(x, self.weight, self.padding, self.stride, bias=self.bias)
+        # (on a fused device the call may be recorded instead of launched: nn/lazy.py)
+        return lazy.conv2d(self, x)
 
     def extra_repr(self):
         return (f"in_channels={self.in_channels}, out_channels={self.out_channels}, "

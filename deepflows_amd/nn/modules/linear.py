@@ -5,6 +5,7 @@ import math
 from ... import backend_api
 from ...tensor import Tensor, empty
 from .. import functional as F
+from .. import lazy
 from .. import init
 from ..parameter import Parameter
 from .module import Module
@@ -31,7 +32,10 @@ class Linear(Module):
             init.uniform_(self.bias, -bound, bound)
 
     def forward(self, input: Tensor) -> Tensor:
-        return F.linear(input, self.weight, self.bias)
+        out = lazy.linear(self, input)                 # (fc(mean(mean(x, 2), 2)): the classifier head as one node, nn/lazy.py)
+        if out is not None:
+            return out
+        return F.linear(lazy.realize(input), self.weight, self.bias)
 
     def extra_repr(self) -> str:
         return f'in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}'

@@ -1,6 +1,7 @@
 """Pooling modules — mirror of DeepFlows/nn/modules/pool.py (MaxPool2d default stride=0,
 pool.py:44)."""
 from .. import functional as F
+from .. import lazy
 from .module import Module
 
 
@@ -10,7 +11,10 @@ class MaxPool2d(Module):
         self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
 
     def forward(self, x):
-        return F.max_pool2d(x, self.kernel_size, self.stride, self.padding)
+        out = lazy.max_pool2d(self, x)                 # (pool(relu(bn(conv(x)))): the stem as one node, nn/lazy.py)
+        if out is not None:
+            return out
+        return F.max_pool2d(lazy.realize(x), self.kernel_size, self.stride, self.padding)
 
     def extra_repr(self):
         return f"kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}"
@@ -22,7 +26,7 @@ class AvgPool2d(Module):
         self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
 
     def forward(self, x):
-        return F.avg_pool2d(x, self.kernel_size, self.stride, self.padding)
+        return F.avg_pool2d(lazy.realize(x), self.kernel_size, self.stride, self.padding)
 
     def extra_repr(self):
         return f"kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}"

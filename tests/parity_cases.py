@@ -298,10 +298,11 @@ def check_cnn(dev):
     Graph.free_graph_all()
 
 
-def check_resnet18(dev, mode):
+def check_resnet18(dev, mode, plain=False):
+    """plain: the model class whose forward() is the reference script's text (workloads.ResNet18Plain)"""
     g = load_golden("g8_end_to_end.npz")
     np.random.seed(0)
-    model = workloads.ResNet18(10, device=dev, register_blocks=(mode == "all"))
+    model = (workloads.ResNet18Plain if plain else workloads.ResNet18)(10, device=dev, register_blocks=(mode == "all"))
     model.train()
     params_all = workloads.all_block_parameters(model)
     opt_params = list(model.parameters())

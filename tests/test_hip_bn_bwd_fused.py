@@ -49,20 +49,23 @@ def _rows_of(dy, z, mean):
     return d.sum(axis=(0, 2, 3)), (d * (z.astype(np.float64) - mean.astype(np.float64))).sum(axis=(0, 2, 3))
 
 
-def _pending(mod, dy, z, gamma, mean, var, rows_h=None, nrows=0, K=2, kidx=1):
+def _pending(mod, dy, z, gamma, mean, var, rows_h=None, nrows=0, cap=0, K=2, kidx=1):
     """a dfhip_bn_bwd_in for the gradient dy of a BatchNorm output; rows from the host when no producer left them"""
     n, c, h, w = dy.shape
+    rows_host = None
     if rows_h is None:
         s1, s2 = _rows_of(dy, z, mean)
         # 301 rows whose sum is the total (the consumer adds rows up; not a multiple of its row groups)
         rs = np.random.default_rng(c)
         wts = rs.random((301, 1)) + 0.1
         wts /= wts.sum()
-        rows = np.zeros((301, c, 2), np.float64)
-        rows[:, :, 0], rows[:, :, 1] = wts * s1[None, :], wts[::-1] * s2[None, :]
-        rows_h, nrows, K, kidx = _arr(mod, rows.astype(np.float32)), 301, 2, 1
+        rows = np.zeros((320, c, 2), np.float64)
+        rows[:301, :, 0], rows[:301, :, 1] = wts * s1[None, :], wts[::-1] * s2[None, :]
+        rows_host = rows.astype(np.float32)
+        rows_h, nrows, cap, K, kidx = _arr(mod, rows_host), 301, 320, 2, 1
     p = types.SimpleNamespace()
-    p.z, p.rows, p.nrows, p.K, p.kidx = _arr(mod, z), rows_h, nrows, K, kidx
+    p.rows_host = rows_host
+    p.z, p.rows, p.nrows, p.cap_rows, p.K, p.kidx = _arr(mod, z), rows_h, nrows, cap, K, kidx
     p.mean, p.var, p.gamma, p.eps, p.m = _arr(mod, mean), _arr(mod, var), _arr(mod, gamma), EPS, n * h * w
     p.dgamma, p.dbeta, p.table = mod.Array(c), mod.Array(c), mod.Array(4 * c)
     return p
@@ -126,6 +129,36 @@ def test_dgrad_with_pending_batchnorm_and_rows(hip_device, name, with_in, n_targ
     if with_in:
         assert_close(_back(mod, pend.dgamma, (1, O, 1, 1)), dg_ref, 1e-4, "dgamma")
         assert_close(_back(mod, pend.dbeta, (1, O, 1, 1)), db_ref, 1e-4, "dbeta")
+
+
+def test_table_of_a_pending_backward_is_the_same_in_every_launch(hip_device):
+    """the addition of the producer's rows by every workgroup of the consuming launch (fixed order): 60 launches with other
+    kernels' traffic in between give the same bits -- dx, table, dgamma, dbeta -- and so does the table launch of its own"""
+    mod = hip_device.mod
+    C, H, W, O, k, s, p = S1_LAYERS["l1"]
+    geo = (N, C, H, W, O, k, s, p)
+    rng = np.random.default_rng(2)
+    dy = (rng.standard_normal((N, O, H, W)) * 0.1).astype(np.float32)
+    w = (rng.standard_normal((O, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+    z, gamma, mean, var = _bn_layer(rng, dy.shape)
+    pend = _pending(mod, dy, z, gamma, mean, var)
+    dyh, wh, dx = _arr(mod, dy), _arr(mod, w), mod.Array(N * C * H * W)
+    junk = mod.Array(64 << 20)
+    first = None
+    for rep in range(60):
+        if rep % 3 == 1:
+            mod.fill(junk, float(rep))                      # (another kernel's traffic in front of the launch)
+        mod.conv2d_dgrad_bn(dyh, wh, None, dx, *geo, pend, None, None, 0)
+        got = (_back(mod, dx, (N, C, H, W)).copy(), _back(mod, pend.table, (O, 4)).copy(),
+               _back(mod, pend.dgamma, (O,)).copy(), _back(mod, pend.dbeta, (O,)).copy())
+        if first is None:
+            first = got
+            dz = R.batchnorm2d_backward(dy, z, gamma, mean, var)[0]
+            assert_close(got[0], R.conv2d_dgrad(dz.astype(np.float32), w, (N, C, H, W), s, p, "overwrite"), 1e-4, "dx")
+        for a, b in zip(got, first):
+            assert np.array_equal(a, b), f"repetition {rep} differs"
+    mod.bn_bwd_table(pend, O)
+    assert np.array_equal(_back(mod, pend.table, (O, 4)), first[1])
 
 
 @pytest.mark.parametrize("which", ["both", "conv_only", "shortcut_only", "rows_only"])

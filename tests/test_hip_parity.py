@@ -69,6 +69,13 @@ def test_resnet18_one_adam_step(hip_device, mode):
     pc.check_resnet18(hip_device, mode)
 
 
+@pytest.mark.parametrize("mode", ["f6", "all"])
+def test_resnet18_written_as_the_reference_writes_it(hip_device, mode):
+    """the unmodified model text (plain module calls, `out + identity`, two tensor.mean) on the hip device: the modules record
+    their calls and launch the fused kernels (nn/lazy.py); same golden as the hand-fused class"""
+    pc.check_resnet18(hip_device, mode, plain=True)
+
+
 @pytest.mark.parametrize("tag", ["vgg", "mbn"])
 def test_vgg16_and_mobilenet_one_step(hip_device, tag):
     """VGG16 (test/VGG.py) and MobileNetV1 (test/MobileNet.py) on the fused hip path

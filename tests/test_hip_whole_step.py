@@ -33,13 +33,14 @@ def _finish(res, params_all):
     return {k: np.asarray(v, dtype=np.float64) for k, v in res.items()}
 
 
-def bench_step(dev, workload, batch, captured=False, counts=None):
+def bench_step(dev, workload, batch, captured=False, counts=None, model_kind="plain"):
     """One step of bench.py's job on `dev`.  Dropout (CNN) draws from the global NumPy generator, which build_job
-    seeds: the mask is the same on every device."""
+    seeds: the mask is the same on every device.  model_kind: bench.py's default ("plain": the ResNet-18 written as the
+    reference's script writes it) or "fused" (the forward() rewritten around the fused entry points)."""
     import bench
     from deepflows_amd import workloads
     from deepflows_amd.tensor import Graph
-    model, opt, crit, xt, yt = bench.build_job(workload, dev, 0, batch)
+    model, opt, crit, xt, yt = bench.build_job(workload, dev, 0, batch, model_kind=model_kind)
     params_all = list(opt.params)
     mod = dev.mod
     if captured:
@@ -82,7 +83,9 @@ CASES = {
     # the headline: ResNet-18 bs 256, overwrite mode, all 62 tensors
     "resnet18_bs256_overwrite": ("resnet18", 256, "overwrite",
                                  {"conv2d_fwd_igemm": 17, "conv2d_wgrad_grouped": 1, "conv2d_dgrad_overwrite_igemm": 16,
-                                  "bn_relu_pool_fwd": 1, "pool_linear_fwd": 1,
+                                  # (of the 19 BatchNorm layers behind the stem, the 8 of the 16 x 16 / 8 x 8 stages that do
+                                  # not sit in a block with a convolution shortcut and whose gradient comes from such a kernel have no launch of their own)
+                                  "bn2d_bwd": 11, "bn_relu_pool_fwd": 1, "pool_linear_fwd": 1,
                                   "pool_linear_bwd": 1, "softmax_ce_fwd": 1, "adam_step": 1}),
     "cnn_bs256_overwrite": ("cnn", 256, "overwrite", {"adam_step": 1}),
     "resnet18_bs128_accumulate": ("resnet18", 128, "accumulate", {"conv2d_wgrad_grouped": 1, "adam_step": 1}),
@@ -108,3 +111,17 @@ def test_benchmarked_step_matches_the_oracle(hip_device, case):
     eb.assert_within_budget(eager, exact, fp32, f"hip {case} (bench.py's job, one step)")
     # the loss bench.py prints for this job is this number
     assert abs(float(eager["loss"].reshape(-1)[0]) - float(fp32["loss"].reshape(-1)[0])) <= 1e-4 * abs(float(fp32["loss"].reshape(-1)[0]))
+
+
+def test_model_written_as_the_reference_writes_it_launches_the_fused_kernels(hip_device):
+    """bench.py's default model (workloads.ResNet18Plain: forward() = the text of test/ResNet_CIFAR10_cuda.py:31-47, 84-99)
+    against the class whose forward() was rewritten around the fused entry points: the same launches per family, the same
+    bits in every compared quantity."""
+    hip_device.mod.conv_dgrad_mode = "overwrite"
+    ca, cb = {}, {}
+    plain = bench_step(hip_device, "resnet18", 256, counts=ca, model_kind="plain")
+    fused = bench_step(hip_device, "resnet18", 256, counts=cb, model_kind="fused")
+    print("\nlaunch counts per family (plain):", dict(sorted(ca.items())))
+    assert ca == cb, f"different launches: plain {sorted(ca.items())} vs hand-fused {sorted(cb.items())}"
+    for k in plain:
+        assert np.array_equal(plain[k], fused[k]), f"the plain model differs from the hand-fused one in {k}"

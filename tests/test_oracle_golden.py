@@ -61,6 +61,12 @@ def test_resnet18_one_adam_step(cpu_oracle, mode):
     pc.check_resnet18(cpu_oracle, mode)
 
 
+@pytest.mark.parametrize("mode", ["f6", "all"])
+def test_resnet18_written_as_the_reference_writes_it(cpu_oracle, mode):
+    """workloads.ResNet18Plain -- forward() = the text of test/ResNet_CIFAR10_cuda.py:31-47, 84-99 -- against the same golden"""
+    pc.check_resnet18(cpu_oracle, mode, plain=True)
+
+
 def test_ref_ops_match_goldens():
     """oracle/ref_ops.py (the full-size checker) reproduces the conv / BN / pool / CE fixtures."""
     import numpy as np

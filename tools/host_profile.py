@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Host-side profile of one training step (cProfile over K steps, GPU queue drained first): where
 the Python / ctypes time of the hot path goes."""
 import cProfile
@@ -12,7 +11,7 @@ from deepflows_amd import backend_api, workloads  # noqa: E402
 from deepflows_amd.tensor import Graph  # noqa: E402
 
 dev = backend_api.Device("hip")
-model, opt, crit, xt, yt = bench.build_job(dev, 0, bench.BATCH, register_blocks=True)
+model, opt, crit, xt, yt = bench.build_job("resnet18", dev, 0, 256, register_blocks=True)
 
 
 def step():
