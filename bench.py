@@ -346,6 +346,29 @@ def main():
     gpu_ms = mod.event_elapsed_ms(e0, e1)
     final_loss = float(loss.numpy()[0])
 
+    # the exchange step by itself (data parallel, or DF_FORCE_COMM=1 DF_FORCE_SYNC=1 on one GPU): K x (all-reduce of the bucket
+    # the backward kernels wrote + optimizer) against K x optimizer, stream events around each loop
+    exchange_us = optimizer_us = None
+    if sync is not None:
+        def timed_loop(fn):
+            a, b = mod.event(), mod.event()
+            mod.synchronize()
+            mod.event_record(a)
+            for _ in range(args.steps):
+                fn()
+            mod.event_record(b)
+            mod.synchronize()
+            return mod.event_elapsed_ms(a, b) * 1e3 / args.steps
+        if captured is not None:
+            opt.device_hyper = False
+        def exch():
+            sync()
+            opt.step()
+        exchange_us = timed_loop(exch)
+        optimizer_us = timed_loop(opt.step)
+        if captured is not None:
+            opt.device_hyper = True
+
     # the OTHER way of writing the model (see build_job), same job, same K replays: reported beside the headline
     other_kind = "fused" if args.model == "plain" else "plain"
     other_value = None
@@ -450,6 +473,12 @@ def main():
                        "global_batch": batch * comm.world, "batch_per_gpu": batch, "parallelism": f"dp{comm.world}",
                        "conv_dgrad": args.dgrad, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,
                        "allreduce_elems": exchanged,
+                       # the exchange step: inside the captured graph or enqueued behind it; gradients the last sync() had to
+                       # copy into the bucket (0: every backward kernel wrote its gradient in place); its time by itself
+                       "exchange_captured": getattr(captured, "exchange_captured", None) if sync is not None else None,
+                       "exchange_fallback_reason": getattr(captured, "exchange_fallback_reason", None) if sync is not None else None,
+                       "grads_copied_into_bucket": bucket.packed_last if sync is not None else None,
+                       "exchange_us": exchange_us, "optimizer_us": optimizer_us,
                        # what the communicator itself reports (ncclCommCount), not the launcher's environment
                        "rccl_ranks": rccl_ranks,
                        "collective_library": mod.comm_rccl_path() if sync is not None else None},

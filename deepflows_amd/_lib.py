@@ -123,6 +123,7 @@ _SIGS = {
     "dfhip_allreduce_sum": [P, c_int64],
     "dfhip_allreduce_sum_async": [P, c_int64],
     "dfhip_comm_wait": [],
+    "dfhip_comm_check": [],
     "dfhip_comm_allreduce_max": [POINTER(c_float)],
     "dfhip_comm_rccl_path": [c_char_p, c_int],
     "dfhip_comm_count": [POINTER(c_int), POINTER(c_int)],

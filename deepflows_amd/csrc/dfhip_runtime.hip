@@ -16,7 +16,9 @@
 #include <cxxabi.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -1209,6 +1211,7 @@ static int (*p_ncclCommDestroy)(df_nccl_comm) = nullptr;
 static const char* (*p_ncclGetErrorString)(int) = nullptr;
 static int (*p_ncclCommCount)(df_nccl_comm, int*) = nullptr;
 static int (*p_ncclCommUserRank)(df_nccl_comm, int*) = nullptr;
+static int (*p_ncclCommGetAsyncError)(df_nccl_comm, int*) = nullptr;
 static df_nccl_comm g_comm = nullptr;
 static int g_world = 1;
 
@@ -1234,6 +1237,7 @@ static int load_rccl() {
   p_ncclGetErrorString = (decltype(p_ncclGetErrorString))dlsym(g_rccl, "ncclGetErrorString");
   p_ncclCommCount = (decltype(p_ncclCommCount))dlsym(g_rccl, "ncclCommCount");
   p_ncclCommUserRank = (decltype(p_ncclCommUserRank))dlsym(g_rccl, "ncclCommUserRank");
+  p_ncclCommGetAsyncError = (decltype(p_ncclCommGetAsyncError))dlsym(g_rccl, "ncclCommGetAsyncError");
   if (!p_ncclGetUniqueId || !p_ncclCommInitRank || !p_ncclAllReduce || !p_ncclCommDestroy) {
     set_error("librccl is missing a required symbol");
     return DFHIP_RUNTIME_ERROR;
@@ -1269,6 +1273,52 @@ int dfhip_comm_init(int rank, int world, const char* id128) {
   DF_NCCL(p_ncclCommInitRank(&g_comm, world, id, rank));
   g_world = world;
   return DFHIP_OK;
+}
+
+// A peer that died or a link that failed does not fail the collective call that was enqueued before: it shows up as the
+// communicator's ASYNCHRONOUS error (ncclCommGetAsyncError) while the local stream simply never finishes.  Every host-side
+// wait of the exchange path polls it, so that a broken job ends with an error (the launcher then reaps the other ranks by
+// PID) instead of hanging in hipStreamSynchronize.  ncclSuccess = 0, ncclInProgress = 7.
+static int comm_async_check(const char* where) {
+  if (!g_comm || !p_ncclCommGetAsyncError) return DFHIP_OK;
+  int st = 0;
+  const int r = p_ncclCommGetAsyncError(g_comm, &st);
+  if (r != 0 || (st != 0 && st != 7)) {
+    const int bad = r != 0 ? r : st;
+    set_error("RCCL reports an asynchronous error (%s) at %s: the job cannot continue", p_ncclGetErrorString ? p_ncclGetErrorString(bad) : "?",
+              where);
+    return DFHIP_RUNTIME_ERROR;
+  }
+  return DFHIP_OK;
+}
+
+// hipStreamSynchronize with the communicator polled meanwhile; DFHIP_COMM_TIMEOUT_S (default 1800) bounds the wait
+static int comm_sync_stream(hipStream_t s, const char* where) {
+  static double limit = getenv("DFHIP_COMM_TIMEOUT_S") ? atof(getenv("DFHIP_COMM_TIMEOUT_S")) : 1800.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spins = 0;; spins++) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return comm_async_check(where);
+    if (q != hipErrorNotReady) {
+      set_error("%s: the stream failed: %s", where, hipGetErrorString(q));
+      return DFHIP_RUNTIME_ERROR;
+    }
+    if ((spins & 255) == 255) {
+      const int st = comm_async_check(where);
+      if (st != DFHIP_OK) return st;
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (waited > limit) {
+        set_error("%s: no completion after %.0f s (DFHIP_COMM_TIMEOUT_S): a rank of the job is gone or stuck", where, waited);
+        return DFHIP_RUNTIME_ERROR;
+      }
+      if (waited > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
+}
+
+int dfhip_comm_check(void) {
+  DF_INIT_KEEP();
+  return comm_async_check("dfhip_comm_check");
 }
 
 int dfhip_allreduce_sum(float* buf, int64_t n) {
@@ -1312,7 +1362,7 @@ int dfhip_comm_wait(void) {
     DF_HIP(hipStreamWaitEvent(g_stream, g_comm_done, 0));
     g_comm_pending = false;
   }
-  return DFHIP_OK;
+  return comm_async_check("dfhip_comm_wait");
 }
 
 // max over ranks of one host float (step time of the slowest rank) / barrier: a one-element all-reduce on the
@@ -1326,8 +1376,7 @@ int dfhip_comm_allreduce_max(float* value) {
   // ncclFloat32 = 7, ncclMax = 2
   DF_NCCL(p_ncclAllReduce(d, d, 1, 7, 2, g_comm, g_stream));
   DF_HIP(hipMemcpyAsync(value, d, sizeof(float), hipMemcpyDeviceToHost, g_stream));
-  DF_HIP(hipStreamSynchronize(g_stream));
-  return DFHIP_OK;
+  return comm_sync_stream(g_stream, "dfhip_comm_allreduce_max (barrier)");
 }
 
 int dfhip_comm_count(int* ranks, int* rank) {

@@ -13,6 +13,7 @@ The reference has nothing comparable (it launches 8 575 device calls per step fr
 SURVEY F8); this is the MI355X-native replacement for that dispatch loop.
 """
 import os
+import sys
 
 import numpy as np
 
@@ -24,11 +25,11 @@ class CapturedTrainStep:
     `inputs` / `targets` are device tensors whose buffers the graph reads on every replay (refill
     them in place to feed new batches); `loss` is the device tensor a replay overwrites.
 
-    With a gradient exchange (`sync`, data parallel) the graph ends after backward: the all-reduce
-    (RCCL) and the optimizer kernel are enqueued eagerly behind it on the same stream — three
-    launches instead of ~170 — so no collective is ever part of a captured graph."""
+    With a gradient exchange (`sync`, data parallel) the all-reduce (RCCL) and the optimizer kernel are part of the
+    captured graph where the collective can be captured (`exchange_captured`), else the graph ends after backward and they
+    are enqueued eagerly behind every replay on the same stream."""
 
-    def __init__(self, model, criterion, optimizer, inputs, targets, sync=None):
+    def __init__(self, model, criterion, optimizer, inputs, targets, sync=None, capture_exchange=None):
         mod = inputs.device.mod
         if not (getattr(mod, "fused", False) and hasattr(mod, "capture_begin")):
             raise RuntimeError("CapturedTrainStep needs the hip device")
@@ -37,10 +38,31 @@ class CapturedTrainStep:
         self.mod, self.optimizer, self.sync = mod, optimizer, sync
         optimizer.device_hyper = True
         optimizer.push_hyper()                      # allocates the scalar array outside the capture
-        mod.capture_feeds = []                      # host-drawn inputs of the step (Dropout masks), in forward order
         if os.environ.get("DF_SIDE_PROBE"):         # (the diagnostic load allocates its stamp buffer on first use)
             mod.side_probe(*[int(v) for v in os.environ["DF_SIDE_PROBE"].split(",")])
             mod.side_join()
+        # Round 4: the exchange step is captured too where the collective library lets a stream capture record it (RCCL
+        # does for ncclAllReduce): a data-parallel step is then ONE graph launch -- backward, all-reduce of the bucket the
+        # backward kernels wrote, optimizer -- with nothing issued eagerly behind it.  If the capture refuses (an older
+        # librccl, a collective that needs host interaction), the step is captured again without it and the exchange is
+        # enqueued behind every replay as in rounds 1-3; `exchange_captured` / `exchange_fallback_reason` say which.
+        if capture_exchange is None:
+            capture_exchange = os.environ.get("DF_CAPTURE_EXCHANGE", "1") != "0"
+        self.exchange_captured, self.exchange_fallback_reason = False, None
+        if sync is not None and capture_exchange:
+            try:
+                self._capture(model, criterion, optimizer, inputs, targets, with_exchange=True)
+                self.exchange_captured = True
+                return
+            except Exception as e:                  # (the failed capture has been closed and destroyed)
+                self.exchange_fallback_reason = f"{type(e).__name__}: {e}"
+                print(f"[graph_step] the gradient exchange could not be captured ({self.exchange_fallback_reason}); "
+                      "it is enqueued behind every replay instead", file=sys.stderr)
+        self._capture(model, criterion, optimizer, inputs, targets, with_exchange=False)
+
+    def _capture(self, model, criterion, optimizer, inputs, targets, with_exchange):
+        mod, sync = self.mod, self.sync
+        mod.capture_feeds = []                      # host-drawn inputs of the step (Dropout masks), in forward order
         mod.capture_begin()
         try:
             outputs = model(inputs)
@@ -52,7 +74,9 @@ class CapturedTrainStep:
             loss.backward()
             if probe:
                 mod.side_join()
-            if sync is None:
+            if sync is not None and with_exchange:
+                sync()
+            if sync is None or with_exchange:
                 optimizer.apply()
             Graph.free_graph()
         except BaseException:
@@ -61,6 +85,7 @@ class CapturedTrainStep:
                 mod.capture_end().destroy()
             except Exception:
                 pass
+            Graph.free_graph()
             raise
         self.feeds, mod.capture_feeds = mod.capture_feeds, None
         self.loss, self.outputs = loss, outputs
@@ -80,7 +105,7 @@ class CapturedTrainStep:
                 if up is None or mask._handle.size < 8192 or not up(mask._handle, keep):
                     self.mod.from_numpy(np.ascontiguousarray(bernoulli_mask(keep, mask.shape)), mask._handle)
         self.graph.replay()
-        if self.sync is not None:
+        if self.sync is not None and not self.exchange_captured:
             for p, g in zip(opt.params, self.grads):
                 p.grad = g
             self.sync()

@@ -632,6 +632,10 @@ class HipModule:
     def comm_wait(self):
         _lib.check(self._lib.dfhip_comm_wait())
 
+    def comm_check(self):
+        """raises when RCCL reports an asynchronous error on the communicator (a rank died, a link failed)"""
+        _lib.check(self._lib.dfhip_comm_check())
+
     def comm_allreduce_max(self, value):
         v = c_float(float(value))
         _lib.check(self._lib.dfhip_comm_allreduce_max(byref(v)))

@@ -28,6 +28,16 @@ def _new(shape, device):
     return BackendTensor.make(tuple(int(s) for s in shape), device=device)
 
 
+def _grad_out(param, shape, device):
+    """The array a kernel writes `param`'s gradient into: the parameter's slice of the data-parallel gradient bucket
+    (`grad_slot`, parallel.GradientBucket) when it has one and this is the first contribution of the sweep -- the all-reduce
+    then runs on what the backward kernels wrote, no pack launch --, a new array otherwise."""
+    slot = getattr(param, "grad_slot", None)
+    if slot is not None and param.grad is None and tuple(slot.shape) == tuple(int(s) for s in shape):
+        return slot
+    return _new(shape, device)
+
+
 # rows of the BatchNorm partials buffer a fused convolution may fill (one per workgroup)
 _BN_PARTIAL_ROWS = 512
 _CONV_BN_STATS = os.environ.get("DF_CONV_BN_STATS", "1") != "0"
@@ -170,8 +180,8 @@ class _LinearFused(_FusedNode):
             # dx, dw and db of the layer as one call (one launch for a classifier-sized layer)
             if self._grads is None or self._grads[0] is not grad:
                 dx = _new((m, k), dev) if self.x.requires_grad else None
-                dw = _new((k, p), dev) if self.w.requires_grad else None
-                db = _new(self.b.shape, dev) if (self.b is not None and self.b.requires_grad) else None
+                dw = _grad_out(self.w, (k, p), dev) if self.w.requires_grad else None
+                db = _grad_out(self.b, self.b.shape, dev) if (self.b is not None and self.b.requires_grad) else None
                 h = lambda t: t._handle if t is not None else None
                 dev.linear_backward(xd._handle, wd._handle, g._handle, h(dx), h(dw), h(db), m, k, p)
                 self._grads = (grad, dx, dw, db)
@@ -182,10 +192,10 @@ class _LinearFused(_FusedNode):
             dev.gemm(g._handle, wd._handle, None, out._handle, m, p, k, False, True)   # dY . W^T
             return out
         if node is self.w:
-            out = _new((k, p), dev)
+            out = _grad_out(self.w, (k, p), dev)
             dev.gemm(xd._handle, g._handle, None, out._handle, k, m, p, True, False)   # X^T . dY
             return out
-        out = _new(self.b.shape, dev)
+        out = _grad_out(self.b, self.b.shape, dev)
         dev.reduce_to_shape(g._handle, out._handle, g.shape, self.b.shape)
         return out
 
@@ -252,8 +262,8 @@ class _LinearReluFused(_FusedNode):
             m, k = xd.shape
             p = wd.shape[1]
             dx = _new((m, k), dev) if self.x.requires_grad else None
-            dw = _new((k, p), dev) if self.w.requires_grad else None
-            db = _new(self.b.shape, dev) if (self.b is not None and self.b.requires_grad) else None
+            dw = _grad_out(self.w, (k, p), dev) if self.w.requires_grad else None
+            db = _grad_out(self.b, self.b.shape, dev) if (self.b is not None and self.b.requires_grad) else None
             h = lambda t: t._handle if t is not None else None
             g = grad.compact()
             if not dev.linear_relu_backward(xd._handle, wd._handle, z._handle, self.data._handle, g._handle, h(dx), h(dw),
@@ -587,7 +597,7 @@ class _Conv2dFused(_FusedNode):
                 # no values to fall back on): refuse rather than return a gradient without the other contribution
                 raise RuntimeError("stem backward: the convolution's output gradient is not the placeholder its "
                                    "pooling node handed out (another consumer?); set DF_STEM_FUSED_BWD=0")
-            out = _new(self.wd.shape, dev)
+            out = _grad_out(self.w, self.wd.shape, dev)
             if pend is not None:
                 _pending_table(pend, dev)         # (written by the input-gradient launch where there was one)
                 if dev.conv2d_wgrad_bn(self.xd._handle, None, g._handle, pend.z, pend.table, out._handle, *self.geo):
@@ -597,7 +607,7 @@ class _Conv2dFused(_FusedNode):
             return out
         if pend is not None:
             g = self._plain_of(grad, pend)
-        out = _new(self.bias.shape, dev)
+        out = _grad_out(self.bias, self.bias.shape, dev)
         dev.reduce_to_shape(g._handle, out._handle, g.shape, self.bias.shape)
         return out
 
@@ -676,8 +686,8 @@ class _PoolLinearFused(_FusedNode):
             N, C, HW, P = self.geo
             dev = grad.device
             dx = _new(self.x.shape, dev) if self.x.requires_grad else None
-            dw = _new(self.wd.shape, dev) if self.w.requires_grad else None
-            db = _new(self.b.shape, dev) if (self.b is not None and self.b.requires_grad) else None
+            dw = _grad_out(self.w, self.wd.shape, dev) if self.w.requires_grad else None
+            db = _grad_out(self.b, self.b.shape, dev) if (self.b is not None and self.b.requires_grad) else None
             h = lambda t: t._handle if t is not None else None
             dev.pool_linear_backward(grad.compact()._handle, self.pooled._handle, self.wd._handle, h(dx), h(dw), h(db),
                                      N, C, HW, P, 1.0 / float(HW))
@@ -793,7 +803,7 @@ class _BatchNorm2dFused(_FusedNode):
             dev = grad.device
             N, C, HW = self.geo
             need_dx = self.x.requires_grad
-            dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+            dg, db = _grad_out(self.weight, (1, C, 1, 1), dev), _grad_out(self.bias, (1, C, 1, 1), dev)
             h = lambda t: t._handle if t is not None else None
             left = getattr(grad, "bn_rows", None)
             if left is not None and left.owner is self and self._defer:
@@ -869,7 +879,7 @@ class _BatchNorm2dPairFused(_FusedNode):
             left = getattr(grad, "bn_rows", None)
             if left is not None and left.owner is self and self._defer and left.K == 3:
                 for i, (xd, wd, bn, (mean, var)) in enumerate(zip(self.xd, self.wd, self.bns, self.stats)):
-                    dg, db, table = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev), _new((C, 4), dev)
+                    dg, db, table = _grad_out(bn.weight, (1, C, 1, 1), dev), _grad_out(bn.bias, (1, C, 1, 1), dev), _new((C, 4), dev)
                     pend = _PendingBN(xd._handle, left.rows._handle, left.nrows, left.cap_rows, left.K, 1 + i, mean._handle, var._handle,
                                       h(wd), float(bn.eps), (N, C, HW), dg._handle, db._handle, table._handle,
                                       (xd, left.rows, mean, var, wd, dg, db, table, grad))
@@ -879,7 +889,7 @@ class _BatchNorm2dPairFused(_FusedNode):
             else:
                 for x, xd, wd, bn, (mean, var) in zip(self.xs, self.xd, self.wd, self.bns, self.stats):
                     dx = _new(xd.shape, dev) if x.requires_grad else None
-                    dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+                    dg, db = _grad_out(bn.weight, (1, C, 1, 1), dev), _grad_out(bn.bias, (1, C, 1, 1), dev)
                     res.append((dx, dg, db))
                     sets.append((xd._handle, h(wd), mean._handle, var._handle, h(dx), dg._handle, db._handle, bn.eps))
                 dev.bn2d_backward_pair(grad.compact()._handle, sets[0], sets[1], N, C, HW)
@@ -983,7 +993,7 @@ class _BnConv2dFused(_FusedNode):
                                                 h(rows), cap)
                     if pend is not None:
                         pend.table_ready = True
-                    dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+                    dg, db = _grad_out(self.gamma, (1, C, 1, 1), dev), _grad_out(self.beta, (1, C, 1, 1), dev)
                     if defer:
                         table = _new((C, 4), dev)
                         mine = _PendingBN(self.xd._handle, rows._handle, nrows, cap, 2, 1, self.mean._handle, self.var._handle,
@@ -998,11 +1008,11 @@ class _BnConv2dFused(_FusedNode):
                 else:
                     dev.conv2d_dgrad(g._handle, self.wd._handle, da._handle, *self.geo)
                     dx = _new(self.xd.shape, dev) if self.x.requires_grad else None
-                    dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+                    dg, db = _grad_out(self.gamma, (1, C, 1, 1), dev), _grad_out(self.beta, (1, C, 1, 1), dev)
                     dev.bn2d_backward(da._handle, self.xd._handle, h(self.gd), self.mean._handle, self.var._handle,
                                       h(dx), dg._handle, db._handle, N, C, H * W, self.eps)
             if self.w.requires_grad:
-                dw = _new(self.wd.shape, dev)
+                dw = _grad_out(self.w, self.wd.shape, dev)
                 queued = False
                 if pend is not None:
                     _pending_table(pend, dev)
@@ -1016,7 +1026,7 @@ class _BnConv2dFused(_FusedNode):
                 if pend is not None and gp is None:
                     gp = _pending_materialise(pend, g)
                 gb = gp if gp is not None else g
-                dcb = _new(self.cbias.shape, dev)
+                dcb = _grad_out(self.cbias, self.cbias.shape, dev)
                 dev.reduce_to_shape(gb._handle, dcb._handle, gb.shape, self.cbias.shape)
             self._grads = (grad, dx, dg, db, dw, dcb)
         _, dx, dg, db, dw, dcb = self._grads
@@ -1099,7 +1109,7 @@ class _BnReluPoolFused(_FusedNode):
         if self._grads is None or self._grads[0] is not grad:
             dev = grad.device
             N, C, H, W = self.geo
-            dg, db = _new((1, C, 1, 1), dev), _new((1, C, 1, 1), dev)
+            dg, db = _grad_out(self.weight, (1, C, 1, 1), dev), _grad_out(self.bias, (1, C, 1, 1), dev)
             h = lambda t: t._handle if t is not None else None
             conv = self.x if isinstance(self.x, _Conv2dFused) else None
             if (conv is not None and _STEM_FUSED_BWD and hasattr(dev.mod, "stem_backward") and self.x.requires_grad
@@ -1110,7 +1120,7 @@ class _BnReluPoolFused(_FusedNode):
                 # the convolution in front needs only its weight gradient: one statistics launch, then the weight
                 # gradient rebuilds d loss / d x from x while it stages it -- that tensor is never written.  The
                 # convolution's node receives a placeholder as its output gradient and hands the stored dw out.
-                dw = _new(conv.wd.shape, dev)
+                dw = _grad_out(conv.w, conv.wd.shape, dev)
                 if dev.stem_backward(conv.xd._handle, self.xd._handle, self.data._handle, grad.compact()._handle,
                                      h(self.wd), h(self.bd), self.mean._handle, self.var._handle, dw._handle,
                                      dg._handle, db._handle, *conv.geo, self.eps):
@@ -1194,8 +1204,8 @@ class _StemNoZFused(_FusedNode):
             dev = grad.device
             xd, wd, cb, gd, bd, mean, var = self._saved
             O = self.geo[4]
-            dw, dg, db = _new(wd.shape, dev), _new((1, O, 1, 1), dev), _new((1, O, 1, 1), dev)
-            dcb = _new((1, O, 1, 1), dev) if cb is not None else None
+            dw, dg, db = _grad_out(self.w, wd.shape, dev), _grad_out(self.weight, (1, O, 1, 1), dev), _grad_out(self.bias, (1, O, 1, 1), dev)
+            dcb = _grad_out(self.cbias, (1, O, 1, 1), dev) if cb is not None else None
             h = lambda t: t._handle if t is not None else None
             if not dev.stem_backward_noz(xd._handle, wd._handle, h(cb), self.data._handle, grad.compact()._handle,
                                          gd._handle, bd._handle, mean._handle, var._handle, dw._handle, h(dcb),

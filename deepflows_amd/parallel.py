@@ -12,6 +12,11 @@ is the new functionality BASELINE's north star asks for (§8e).  Design for MI35
     no host synchronisation anywhere in the step;
   * the optimizer reads the gradients straight out of the bucket (views, no unpack) and applies
     the 1/world average inside its fused kernel (`grad_scale`);
+  * round 4: the backward kernels WRITE the gradients straight into the bucket -- every registered parameter carries
+    its slice of the bucket as `grad_slot`, and the fused nodes take it as the output array of the kernel that forms
+    the parameter's gradient (nn/functional.py: _grad_out) -- so the exchange step is the all-reduce alone: no pack
+    launch, no second copy of the 11 MB.  A parameter whose gradient did not end up in its slot (it received two
+    contributions, or came from a node that allocates its own output) is copied in as before;
   * BatchNorm statistics and dropout masks stay rank-local (no SyncBN), the loss is the mean
     over the local batch.
 world == 1 degenerates to "no bucket, no collective" so the single-GPU path is bit-identical
@@ -22,6 +27,19 @@ import os
 import numpy as np
 
 from .backend_selection import BackendTensor
+
+
+# gradients are formed in the bucket itself (DF_GRAD_IN_BUCKET=0: packed by a launch of their own, as in rounds 1-3)
+IN_PLACE = os.environ.get("DF_GRAD_IN_BUCKET", "1") != "0"
+
+
+def _same_array(a, b):
+    """two compact BackendTensors over the same device memory"""
+    ha, hb = a._handle, b._handle
+    if isinstance(ha, np.ndarray) or isinstance(hb, np.ndarray):
+        return isinstance(ha, np.ndarray) and isinstance(hb, np.ndarray) and ha.shape == hb.shape and \
+            ha.__array_interface__["data"][0] == hb.__array_interface__["data"][0]
+    return getattr(ha, "ptr", None) is not None and ha.ptr == hb.ptr and ha.size == hb.size
 
 
 class _ArrayView:
@@ -121,10 +139,26 @@ class GradientBucket:
         self.sizes = [int(p.size) for p in self.params]
         self.total = sum(self.sizes)
         self.flat = None
+        self.slots = []
         if (comm.world > 1 or comm.exchanges) and self.params:
             dev = self.params[0].device
             self.flat = BackendTensor.make((self.total,), device=dev)
             self.flat.fill(0.0)
+            if IN_PLACE:
+                off = 0
+                for p, n in zip(self.params, self.sizes):
+                    slot = self._view(off, p)
+                    self.slots.append(slot)
+                    p.grad_slot = slot            # (the kernels that form p's gradient write it here)
+                    off += n
+        self.packed_last = None                   # how many gradients the last sync() had to copy into the bucket
+
+    def release(self):
+        """the parameters stop pointing at this bucket (another bucket over the same parameters takes over)"""
+        for p in self.params:
+            if getattr(p, "grad_slot", None) is not None:
+                p.grad_slot = None
+        self.slots = []
 
     def _view(self, offset, p):
         h = self.flat._handle
@@ -142,19 +176,30 @@ class GradientBucket:
         if self.flat is None:
             return
         dev = self.params[0].device
-        grads = []
-        for p in self.params:
+        grads, outside = [], 0
+        for i, p in enumerate(self.params):
             if p.grad is None:
                 raise RuntimeError("GradientBucket.sync: a parameter has no gradient")
-            grads.append(p.grad.compact())
-        pack = getattr(dev.mod, "pack", None)
-        if pack is not None:
-            pack([g._handle for g in grads], self.flat._handle)
+            g = p.grad.compact()
+            grads.append(g)
+            if not (self.slots and _same_array(g, self.slots[i])):
+                outside += 1
+        self.packed_last = outside
+        if outside == 0:
+            pass                                  # every gradient was written in place: nothing to pack
+        elif outside < len(grads) and hasattr(dev.mod, "copy") and not isinstance(self.flat._handle, np.ndarray):
+            for i, g in enumerate(grads):
+                if not _same_array(g, self.slots[i]):
+                    dev.mod.copy(g._handle, self.slots[i]._handle)
         else:
-            off = 0
-            for g, n in zip(grads, self.sizes):
-                self.flat._handle[off:off + n] = g._handle
-                off += n
+            pack = getattr(dev.mod, "pack", None)
+            if pack is not None:
+                pack([g._handle for g in grads], self.flat._handle)
+            else:
+                off = 0
+                for g, n in zip(grads, self.sizes):
+                    self.flat._handle[off:off + n] = g._handle
+                    off += n
         if overlap and isinstance(self.comm, RcclCommunicator):
             self.comm.allreduce_sum(self.flat, overlap=True)
         else:

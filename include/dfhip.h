@@ -486,6 +486,12 @@ int dfhip_allreduce_sum(float* buf, int64_t n);               /* The same all-re
  * dfhip_comm_wait makes the library stream wait for all of them (call it before the optimizer). */
 int dfhip_allreduce_sum_async(float* buf, int64_t n);
 int dfhip_comm_wait(void);
+/* Poll the communicator's asynchronous error state (ncclCommGetAsyncError): a peer that died or a link that failed does
+ * not fail the collective that was already enqueued, the local stream just never finishes.  DFHIP_RUNTIME_ERROR (with
+ * the RCCL error text in dfhip_last_error) when the communicator is broken -- the caller ends its process with a failure
+ * status and the launcher reaps the other ranks.  dfhip_comm_wait and dfhip_comm_allreduce_max (the barrier, which waits
+ * for its stream with this poll and a DFHIP_COMM_TIMEOUT_S bound instead of a bare hipStreamSynchronize) call it too. */
+int dfhip_comm_check(void);
 
 /* in place, library stream */
 /* max over the ranks of one host float (one-element ncclAllReduce(max) + stream synchronisation): the barrier and

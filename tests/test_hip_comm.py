@@ -2,7 +2,8 @@
 size a 1-GPU box allows): librccl is dlopen'ed, ncclCommInitRank / ncclAllReduce run on the
 library stream, the bucket views feed the fused Adam, and the result equals the no-communicator
 step bit for bit (sum over one rank, grad_scale = 1).  Also the captured step with a gradient
-exchange (graph up to backward, then pack + all-reduce + Adam eagerly)."""
+exchange (round 4: all-reduce and Adam inside the graph, the gradients formed in the bucket by the backward kernels; the
+rounds 1-3 form -- graph up to backward, then the exchange eagerly -- as the fall-back)."""
 import os
 
 import numpy as np
@@ -84,12 +85,52 @@ def test_captured_step_with_gradient_exchange(rccl_comm):
     m2, o2, b2 = twin()
     workloads.train_step(m2, crit, o2, xs, ys, sync=b2.sync)
     Graph.free_graph()
+    assert b2.packed_last == 0, "the backward kernels did not write every gradient into the bucket"
     cs = CapturedTrainStep(m2, crit, o2, xs, ys, sync=b2.sync)
+    # RCCL lets a stream capture record ncclAllReduce: the step is ONE graph (backward, all-reduce, Adam)
+    assert cs.exchange_captured, cs.exchange_fallback_reason
     cs.replay()
     cs.replay()
+    dev.mod.comm_check()                            # (ncclCommGetAsyncError: the communicator is healthy)
     assert o1.t == o2.t == 4
     for a, b in zip(o1.params, o2.params):
         assert np.array_equal(a.data.numpy(), b.data.numpy())
+    # and the same with the exchange enqueued behind the graph (what an uncapturable collective falls back to)
+    m3, o3, b3 = twin()
+    workloads.train_step(m3, crit, o3, xs, ys, sync=b3.sync)
+    Graph.free_graph()
+    cs3 = CapturedTrainStep(m3, crit, o3, xs, ys, sync=b3.sync, capture_exchange=False)
+    assert not cs3.exchange_captured
+    cs3.replay()
+    cs3.replay()
+    for a, b in zip(o1.params, o3.params):
+        assert np.array_equal(a.data.numpy(), b.data.numpy())
+
+
+def test_gradients_are_formed_in_the_bucket(rccl_comm):
+    """every parameter gradient of a ResNet-18 / CNN step is written by its backward kernel into the parameter's slice of
+    the flat bucket (no pack launch); a parameter that collects two contributions is copied in"""
+    from deepflows_amd import nn, optim, parallel, workloads
+    from deepflows_amd.tensor import Graph, Tensor
+    dev, comm = rccl_comm
+    rng = np.random.default_rng(4)
+    for make, shape in ((lambda: workloads.ResNet18Plain(device=dev, register_blocks=True), (32, 3, 32, 32)),
+                        (lambda: workloads.CIFAR10_CNN(10, device=dev), (16, 3, 32, 32)),
+                        (lambda: workloads.MLP((784, 256, 10), device=dev), (16, 784))):
+        np.random.seed(2)
+        m = make()
+        o = optim.Adam(workloads.all_block_parameters(m) if hasattr(m, "layer1") else m.parameters(), lr=1e-3)
+        b = parallel.GradientBucket(o.params, comm)
+        xs = Tensor(rng.standard_normal(shape).astype(np.float32), device=dev)
+        ys = Tensor(np.eye(10, dtype=np.float32)[rng.integers(0, 10, shape[0])], device=dev)
+        dev.mod.prof_reset()
+        dev.mod.prof_enable(True)
+        workloads.train_step(m, nn.CrossEntropyLoss(), o, xs, ys, sync=b.sync)
+        dev.mod.synchronize()
+        dev.mod.prof_enable(False)
+        Graph.free_graph()
+        assert b.packed_last == 0, f"{type(m).__name__}: {b.packed_last} gradients were copied into the bucket"
+        assert not dev.mod.prof_read().get("bucket_pack", {}).get("calls"), "a pack launch ran"
 
 
 def test_overlapped_step_matches_eager_exchange(rccl_comm):
@@ -156,3 +197,8 @@ def test_bench_exchange_path_runs_on_one_gpu():
     assert d["config"]["rccl_ranks"] == 1                 # ncclCommCount of the communicator itself
     assert "rccl_allreduce" in d["kernels"]
     assert d["value"] > 0 and np.isfinite(d["final_loss"])
+    # round 4: the exchange is part of the captured graph, the gradients are formed in the bucket, its time is reported
+    assert d["config"]["exchange_captured"] is True, d["config"]["exchange_fallback_reason"]
+    assert d["config"]["grads_copied_into_bucket"] == 0
+    assert d["config"]["exchange_us"] > 0 and d["config"]["optimizer_us"] > 0
+    print("exchange step at world 1: %.1f us (optimizer alone %.1f us)" % (d["config"]["exchange_us"], d["config"]["optimizer_us"]))
