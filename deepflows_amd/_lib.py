@@ -92,6 +92,7 @@ _SIGS = {
     "dfhip_stem_backward_noz": [P] * 13 + [c_int] * 8 + [c_float, POINTER(c_int)],
     "dfhip_upload_async": [P, P, c_int64, c_int],
     "dfhip_upload_wait": [c_int],
+    "dfhip_upload_release": [c_int],
     "dfhip_augment_batch": [P, P, P, c_int, c_int, c_int, c_int, c_int],
     "dfhip_onehot_smooth": [P, P, c_int, c_int, c_double],
     "dfhip_maxpool2d_forward": [P, P, c_int, c_int, c_int, c_int],

@@ -892,6 +892,7 @@ struct UploadSlot {
   hipEvent_t done = nullptr;     // H2D of this slot finished
   hipEvent_t consumed = nullptr; // the library stream has passed the kernels that read the destination
   bool in_flight = false;
+  bool released = false;         // `consumed` was recorded behind the readers of the previous upload (dfhip_upload_release)
 };
 static UploadSlot g_up[2];
 static hipStream_t g_copy_stream = nullptr;
@@ -916,8 +917,12 @@ int dfhip_upload_async(const void* host, float* dst, int64_t bytes, int slot) {
     u.bytes = (size_t)bytes;
   }
   memcpy(u.pinned, host, (size_t)bytes);
-  // the destination may still be read by kernels the library stream has queued for the previous use
-  DF_HIP(hipEventRecord(u.consumed, g_stream));
+  // The destination may still be read by kernels the library stream has queued for its previous use.  Where the caller
+  // marked the end of those readers (dfhip_upload_release) the copy waits for exactly that point -- and runs beside
+  // whatever was queued after it: the training step of the batch before --; otherwise it waits for everything queued so far
+  // (round 3's behaviour: the copy of batch k + 1 then started only when step k had finished, ~0.1 ms per step exposed).
+  if (!u.released) DF_HIP(hipEventRecord(u.consumed, g_stream));
+  u.released = false;
   DF_HIP(hipStreamWaitEvent(g_copy_stream, u.consumed, 0));
   DF_HIP(hipMemcpyAsync(dst, u.pinned, (size_t)bytes, hipMemcpyHostToDevice, g_copy_stream));
   DF_HIP(hipEventRecord(u.done, g_copy_stream));
@@ -930,6 +935,16 @@ int dfhip_upload_wait(int slot) {
   DF_CHECK_ARG(slot == 0 || slot == 1, "upload_wait: slot must be 0 or 1");
   UploadSlot& u = g_up[slot];
   if (u.in_flight) DF_HIP(hipStreamWaitEvent(g_stream, u.done, 0));
+  return DFHIP_OK;
+}
+
+int dfhip_upload_release(int slot) {
+  DF_INIT_KEEP();
+  DF_CHECK_ARG(slot == 0 || slot == 1, "upload_release: slot must be 0 or 1");
+  UploadSlot& u = g_up[slot];
+  if (!u.done) return DFHIP_OK;                     // (nothing was ever uploaded through this slot)
+  DF_HIP(hipEventRecord(u.consumed, g_stream));
+  u.released = true;
   return DFHIP_OK;
 }
 
@@ -984,6 +999,12 @@ int dfhip_side_fork(void) { DF_INIT_KEEP(); return side_fork(); }
 int dfhip_side_target(int on) {
   DF_INIT_KEEP();
   DF_CHECK_ARG(!on || g_side_pending, "side_target: fork first");
+  // Launches retargeted this way share the library stream's scratch areas and pool ordering: only kernels that use neither
+  // may run there.  That is true of the diagnostic load (dfhip_side_probe) and of nothing a front end would call, so the
+  // switch is refused unless the diagnostic asked for it (DF_SIDE_PROBE / DFHIP_SIDE_TARGET=1).
+  static int allowed = (getenv("DF_SIDE_PROBE") || (getenv("DFHIP_SIDE_TARGET") && atoi(getenv("DFHIP_SIDE_TARGET")))) ? 1 : 0;
+  DF_CHECK_ARG(!on || allowed, "side_target: diagnostic only (the side stream shares the library stream's scratch areas); "
+               "set DFHIP_SIDE_TARGET=1 to use it anyway");
   g_side_target = on != 0;
   return DFHIP_OK;
 }

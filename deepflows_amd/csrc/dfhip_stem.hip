@@ -820,7 +820,8 @@ int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, c
   *done = 0;
   if (!stem_shape(N, C, H, W, O, k, stride, pad)) return DFHIP_OK;
   const int KK = C * k * k;
-  const int gx = (int)std::min<int64_t>(N, num_cus());
+  // (k_stem_bwd<.., 1> adds up at most 16 lanes x 16 slices: the slices of the first pass are capped at 256 whatever the device)
+  const int gx = (int)std::min<int64_t>(N, std::min(num_cus(), 256));
   static int onepass = getenv("DFHIP_STEM_ONEPASS") ? atoi(getenv("DFHIP_STEM_ONEPASS")) : 1;
   const bool one = onepass && k == 3;   // (5x5: two accumulator sets of three tiles do not fit the registers)
   const size_t SL = (size_t)2 * O * KK + 3 * O + KK;

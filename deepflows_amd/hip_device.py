@@ -142,20 +142,23 @@ class HipModule:
                                                strides=tuple(4 * s for s in strides))
         return np.array(view, dtype=np.float32, copy=True)
 
-    def compact(self, src, dst, shape, strides, offset):
+    # (parameter names as the reference's device modules spell them -- backend_tensor.py:66-170, pinned by
+    # tests/golden/protocol_signatures.json -- so that a keyword call is a drop-in too)
+    def compact(self, src_handle, dst_handle, shape, strides, offset):
         nd, sh = _dims(shape)
         _, st = _dims(strides)
-        _lib.check(self._lib.dfhip_compact(src.ptr, dst.ptr, dst.size, nd, sh, st, int(offset)))
+        _lib.check(self._lib.dfhip_compact(src_handle.ptr, dst_handle.ptr, dst_handle.size, nd, sh, st, int(offset)))
 
-    def ewise_setitem(self, src, dst, shape, strides, offset):
+    def ewise_setitem(self, other_handle, view_handle, shape, strides, offset):
         nd, sh = _dims(shape)
         _, st = _dims(strides)
-        _lib.check(self._lib.dfhip_ewise_setitem(src.ptr, dst.ptr, src.size, nd, sh, st, int(offset)))
+        _lib.check(self._lib.dfhip_ewise_setitem(other_handle.ptr, view_handle.ptr, other_handle.size, nd, sh, st,
+                                                 int(offset)))
 
-    def scalar_setitem(self, size, value, dst, shape, strides, offset):
+    def scalar_setitem(self, size, scalar, view_handle, shape, strides, offset):
         nd, sh = _dims(shape)
         _, st = _dims(strides)
-        _lib.check(self._lib.dfhip_scalar_setitem(int(size), float(value), dst.ptr, nd, sh, st, int(offset)))
+        _lib.check(self._lib.dfhip_scalar_setitem(int(size), float(scalar), view_handle.ptr, nd, sh, st, int(offset)))
 
     # ---- elementwise ----------------------------------------------------------------------
     def _binary(self, fn, a, b, out):
@@ -199,11 +202,11 @@ class HipModule:
             raise ValueError("matmul: array sizes do not match (m, n, p)")
         _lib.check(self._lib.dfhip_matmul(a.ptr, b.ptr, out.ptr, m, n, p))
 
-    def reduce_sum(self, a, out, reduce_size):
-        _lib.check(self._lib.dfhip_reduce_sum(a.ptr, out.ptr, a.size // int(reduce_size), int(reduce_size)))
+    def reduce_sum(self, view_handle, out_handle, last_dim):
+        _lib.check(self._lib.dfhip_reduce_sum(view_handle.ptr, out_handle.ptr, view_handle.size // int(last_dim), int(last_dim)))
 
-    def reduce_max(self, a, out, reduce_size):
-        _lib.check(self._lib.dfhip_reduce_max(a.ptr, out.ptr, a.size // int(reduce_size), int(reduce_size)))
+    def reduce_max(self, view_handle, out_handle, last_dim):
+        _lib.check(self._lib.dfhip_reduce_max(view_handle.ptr, out_handle.ptr, view_handle.size // int(last_dim), int(last_dim)))
 
     # ---- fused hot path ---------------------------------------------------------------------
     def gemm(self, a, b, bias, out, m, n, p, ta=False, tb=False):
@@ -495,6 +498,10 @@ class HipModule:
 
     def upload_wait(self, slot):
         _lib.check(self._lib.dfhip_upload_wait(int(slot)))
+
+    def upload_release(self, slot):
+        """the kernels that read slot's last upload are enqueued: the next upload through it may start behind them"""
+        _lib.check(self._lib.dfhip_upload_release(int(slot)))
 
     def augment_batch(self, src, out, decisions, N, C, H, W, pad, src_offset_floats=0, dec_offset_floats=0):
         _lib.check(self._lib.dfhip_augment_batch(src.ptr + 4 * int(src_offset_floats), out.ptr,

@@ -17,6 +17,7 @@ exits non-zero makes the job fail with that code; the surviving ranks (which wou
 import json
 import os
 import socket
+import signal
 import subprocess
 import sys
 import threading
@@ -62,6 +63,10 @@ def _is_json_object(line):
         return False
 
 
+class _Terminated(Exception):
+    """SIGTERM reached the spawner"""
+
+
 def spawn_ranks(world, command, timeout=None, grace=20.0, out=None, err=None, env=None):
     """Run `command` (argv list) as `world` ranks.  Returns (exit code, last JSON-object line of rank 0 or None).
     The JSON line is written to `out` last; exit code = 0 only if every rank exited 0."""
@@ -89,44 +94,82 @@ def spawn_ranks(world, command, timeout=None, grace=20.0, out=None, err=None, en
                 err.write(f"[rank {rank}] {line}")
                 err.flush()
 
-    for r in range(world):
-        p = subprocess.Popen(command, env=rank_environment(r, world, port, base=env), stdout=subprocess.PIPE,
-                             stderr=None, text=True, bufsize=1)
-        procs.append(p)
-        t = threading.Thread(target=pump_rank0 if r == 0 else pump_other,
-                             args=(p.stdout,) if r == 0 else (r, p.stdout), daemon=True)
-        t.start()
-        threads.append(t)
-
-    deadline = None if timeout is None else time.monotonic() + timeout
-    failed_at = None
-    code = 0
-    while True:
-        states = [p.poll() for p in procs]
-        bad = [(r, s) for r, s in enumerate(states) if s not in (None, 0)]
-        if bad and failed_at is None:
-            failed_at = time.monotonic()
-            code = bad[0][1] if bad[0][1] > 0 else 128 - bad[0][1]      # a signal -n reads as 128 + n
-            err.write("[launch] rank %d exited with %d; the other ranks get %.0f s\n" % (bad[0][0], bad[0][1], grace))
-            err.flush()
-        if all(s is not None for s in states):
-            break
-        now = time.monotonic()
-        if (failed_at is not None and now - failed_at > grace) or (deadline is not None and now > deadline):
-            if failed_at is None:
-                code = 124
-                err.write("[launch] timeout: terminating the ranks\n")
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()
-            t_end = time.monotonic() + 5.0
-            for p in procs:
+    def reap():
+        """terminate, then kill, every rank that is still alive (by PID; a child is a fresh process: nothing is re-exec'ed)"""
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            try:
+                p.terminate()
+            except OSError:
+                pass
+        t_end = time.monotonic() + 5.0
+        for p in alive:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
                 try:
-                    p.wait(timeout=max(0.1, t_end - time.monotonic()))
-                except subprocess.TimeoutExpired:
                     p.kill()
-            break
-        time.sleep(0.05)
+                except OSError:
+                    pass
+        for p in alive:
+            try:
+                p.wait(timeout=5.0)
+            except subprocess.TimeoutExpired:
+                pass
+
+    # SIGTERM to the spawner (a job timeout) must not leave ranks behind that wait in a collective forever and hold their
+    # GPUs: it is turned into an exception that unwinds through the `finally` below
+    def on_term(signum, frame):
+        raise _Terminated(signum)
+
+    old_term = None
+    if threading.current_thread() is threading.main_thread():
+        try:
+            old_term = signal.signal(signal.SIGTERM, on_term)
+        except (ValueError, OSError):
+            old_term = None
+    code = 0
+    try:
+        for r in range(world):
+            p = subprocess.Popen(command, env=rank_environment(r, world, port, base=env), stdout=subprocess.PIPE,
+                                 stderr=None, text=True, bufsize=1)
+            procs.append(p)
+            t = threading.Thread(target=pump_rank0 if r == 0 else pump_other,
+                                 args=(p.stdout,) if r == 0 else (r, p.stdout), daemon=True)
+            t.start()
+            threads.append(t)
+
+        deadline = None if timeout is None else time.monotonic() + timeout
+        failed_at = None
+        while True:
+            states = [p.poll() for p in procs]
+            bad = [(r, s) for r, s in enumerate(states) if s not in (None, 0)]
+            if bad and failed_at is None:
+                failed_at = time.monotonic()
+                code = bad[0][1] if bad[0][1] > 0 else 128 - bad[0][1]      # a signal -n reads as 128 + n
+                err.write("[launch] rank %d exited with %d; the other ranks get %.0f s\n" % (bad[0][0], bad[0][1], grace))
+                err.flush()
+            if all(s is not None for s in states):
+                break
+            now = time.monotonic()
+            if (failed_at is not None and now - failed_at > grace) or (deadline is not None and now > deadline):
+                if failed_at is None:
+                    code = 124
+                    err.write("[launch] timeout: terminating the ranks\n")
+                reap()
+                break
+            time.sleep(0.05)
+    except _Terminated as e:
+        code = 128 + int(e.args[0])
+        err.write("[launch] signal %d: terminating the ranks\n" % int(e.args[0]))
+    finally:
+        # (a failed Popen of a later rank, KeyboardInterrupt, SIGTERM, any exception: no rank outlives the spawner)
+        reap()
+        if old_term is not None:
+            try:
+                signal.signal(signal.SIGTERM, old_term)
+            except (ValueError, OSError):
+                pass
     for p in procs:
         p.wait()
     for t in threads:

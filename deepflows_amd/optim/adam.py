@@ -3,8 +3,15 @@ gradient, `t` starts at 1 and advances once per step(), parameters without a gra
 skipped.  On a fused device: one multi-tensor in-place kernel (17 launches per parameter in
 the reference) with the same operation order; scalars are rounded to fp32 where the
 reference's NumPy device rounds them."""
+import os
+
+import os
+
 from .. import backend_api
 from .optimizer import Optimizer
+
+
+_CHECK_TABLE = os.environ.get("DF_ADAM_CHECK_TABLE", "0") != "0"
 
 
 class Adam(Optimizer):
@@ -44,9 +51,12 @@ class Adam(Optimizer):
             return
         if getattr(mod, "capturing", False):
             raise RuntimeError("Adam: the scalar table must be written before the capture starts")
-        if self._table_key is not None:
+        if self._table_key is not None and (self._table_used >= self._HYPER_STEPS or _CHECK_TABLE):
             # the table is about to be replaced: what the device consumed must be what this object counted (a replayed
-            # step that was not noted, or noted without running, has trained with another step's bias corrections)
+            # step that was not noted, or noted without running, has trained with another step's bias corrections).
+            # The read-back drains the device, so it runs when the table is exhausted (once per 1 024 steps) -- a schedule
+            # that moves the learning rate every batch rewrites the table in front of every replay and must not wait
+            # for the GPU each time -- or on every rewrite with DF_ADAM_CHECK_TABLE=1.
             index, _ = mod.adam_hyper_index(self._hyper)
             if index != self._table_used:
                 raise RuntimeError(f"Adam: the device has taken {index} steps from its scalar table, the host counted "

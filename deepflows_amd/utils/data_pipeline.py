@@ -95,4 +95,6 @@ class DeviceBatchPipeline:
         else:
             self.mod.copy(_Window(st, 0, self._off_lab), _Window(x_tensor.data._handle, 0, self._off_lab))
         self.mod.onehot_smooth(st, y_tensor.data._handle, bs, self.K, self.eps, self._off_lab)
+        if hasattr(self.mod, "upload_release"):
+            self.mod.upload_release(slot)       # (the staging slot is free for the batch after next from HERE on the stream)
         self._next_deliver += 1

@@ -374,6 +374,10 @@ int dfhip_bn_relu_maxpool2_backward(const float* x, const float* y, const float*
  * dfhip_onehot_smooth: :180-184, onehot * (1 - eps) + eps / K from int32 labels. */
 int dfhip_upload_async(const void* host, float* dst, int64_t bytes, int slot);
 int dfhip_upload_wait(int slot);
+/* dfhip_upload_release: every kernel that reads the destination of slot's last upload has been enqueued -- the next
+ * dfhip_upload_async through this slot waits for THIS point of the library stream, not for what is enqueued later
+ * (the training step of that batch runs beside the next copy). */
+int dfhip_upload_release(int slot);
 int dfhip_augment_batch(const float* in, float* out, const int* decisions, int N, int C, int H, int W, int pad);
 int dfhip_onehot_smooth(const int* labels, float* out, int N, int K, double eps);
 

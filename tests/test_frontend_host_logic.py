@@ -268,3 +268,34 @@ def test_backward_brackets_the_sweep_with_the_wgrad_group(cpu_oracle):
     finally:
         del mod.wgrad_group_begin, mod.wgrad_group_end
         Graph.free_graph_all()
+
+
+def test_device_modules_follow_the_references_protocol():
+    """The 26 methods of the reference's device module (names, parameter names, parameter order) as the REFERENCE defines
+    them -- tests/golden/protocol_signatures.json, written by oracle/gen_protocol_signatures.py from
+    DeepFlows/backend/backend_tensor.py:64-172 (inspect.signature of NumpyBackend) and the m.def names of
+    ndarray_backend_cuda.cu:515-717 -- against the hip device module and the oracle's NumPy device."""
+    import inspect
+    import json
+    import os
+    from conftest import GOLDEN
+    from deepflows_amd.hip_device import HipModule
+    from oracle.numpy_device import NumpyDevice
+    ref = json.load(open(os.path.join(GOLDEN, "protocol_signatures.json")))
+    assert len(ref["numpy_backend"]) == 26
+    for cls in (HipModule, NumpyDevice):
+        for name, params in ref["numpy_backend"].items():
+            fn = getattr(cls, name, None)
+            assert fn is not None, f"{cls.__name__} lacks protocol method {name}"
+            sig = inspect.signature(fn)
+            mine = [p for p in sig.parameters if p != "self"]
+            if cls is HipModule:
+                assert mine[:len(params)] == params, f"{cls.__name__}.{name}{tuple(mine)}: the reference has {tuple(params)}"
+            else:
+                assert len(mine) >= len(params), f"{cls.__name__}.{name} takes fewer arguments than the reference's"
+            extra = list(sig.parameters.values())[1 + len(params):]
+            assert all(p.default is not inspect.Parameter.empty for p in extra), f"{cls.__name__}.{name}: extra required arguments"
+    # every function the reference's CUDA extension exports exists on the hip module under the same name
+    for name in ref["cuda_module"]["functions"]:
+        assert hasattr(HipModule, name), f"HipModule lacks {name} (exported by the reference's CUDA module)"
+    assert ref["cuda_module"]["classes"] == ["Array"] and hasattr(HipModule, "Array")

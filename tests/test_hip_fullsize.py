@@ -14,7 +14,8 @@ LAYERS = {"stem": (3, 32, 32, 32, 3, 1, 1), "l1": (32, 16, 16, 32, 3, 1, 1), "l2
           "l2": (64, 8, 8, 64, 3, 1, 1), "l2d": (32, 16, 16, 64, 1, 2, 0), "l3a": (64, 8, 8, 128, 3, 2, 1),
           "l3": (128, 4, 4, 128, 3, 1, 1), "l3d": (64, 8, 8, 128, 1, 2, 0), "l4a": (128, 4, 4, 256, 3, 2, 1),
           "l4": (256, 2, 2, 256, 3, 1, 1), "l4d": (128, 4, 4, 256, 1, 2, 0),
-          "cnn2": (32, 16, 16, 64, 5, 1, 2)}
+          # CNN-CIFAR10 (test/CNN_CIFAR10_cuda.py:61-108): conv1 5x5 3->32 on 32x32, conv2 5x5 32->64 on 16x16, conv3 3x3 64->128 on 8x8
+          "cnn1": (3, 32, 32, 32, 5, 1, 2), "cnn2": (32, 16, 16, 64, 5, 1, 2), "cnn3": (64, 8, 8, 128, 3, 1, 1)}
 
 
 def _arr(mod, a):
@@ -31,7 +32,7 @@ def _back(mod, h, shape):
 def test_conv_layer_full_size(hip_device, name):
     mod = hip_device.mod
     C, H, W, O, k, s, p = LAYERS[name]
-    n = 64 if name == "cnn2" else N
+    n = N                                   # (every layer of both benchmarked models at the benchmarked batch)
     oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     rng = np.random.default_rng(hash(name) % 1000)
     x = rng.standard_normal((n, C, H, W)).astype(np.float32)
@@ -159,7 +160,7 @@ def test_grouped_wgrad_all_layers(hip_device):
     rng = np.random.default_rng(11)
     jobs = []
     for name, (C, H, W, O, k, s, p) in LAYERS.items():
-        n = 64 if name == "cnn2" else N
+        n = N                                   # (every layer of both benchmarked models at the benchmarked batch)
         oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         x = rng.standard_normal((n, C, H, W)).astype(np.float32)
         dy = rng.standard_normal((n, O, oh, ow)).astype(np.float32)

@@ -367,8 +367,14 @@ def test_adam_notices_a_step_count_the_device_does_not_share(hip_device):
     assert hip_device.mod.adam_hyper_index(opt._hyper)[0] == 1
     opt.note_replayed_apply()          # the host counts a step the device never ran
     opt.lr = 2.5e-4
-    with pytest.raises(RuntimeError, match="host counted"):
-        step.replay()
+    # (the read-back drains the device: it runs when the table is exhausted, or on every rewrite when asked for)
+    from deepflows_amd.optim import adam as adam_module
+    adam_module._CHECK_TABLE = True
+    try:
+        with pytest.raises(RuntimeError, match="host counted"):
+            step.replay()
+    finally:
+        adam_module._CHECK_TABLE = False
     step.destroy()
     Graph.free_graph_all()
 

@@ -90,3 +90,39 @@ def test_bench_gpus_2_fails_inside_the_ranks_not_at_argument_parsing():
     assert "needs `python -m torch.distributed.run" not in r.stderr
     assert "[launch] rank" in r.stderr                    # the spawner reported a rank's exit ...
     assert "HIP" in r.stderr or "hip" in r.stderr         # ... whose own error is the missing device
+
+
+def test_a_terminated_spawner_leaves_no_rank_behind(tmp_path):
+    """SIGTERM to the spawner (a job timeout): the ranks it started -- which would otherwise wait in a collective forever and
+    hold their GPUs -- are terminated by PID before it exits (spawn_ranks never cleaned up on an abnormal exit)."""
+    import signal
+    import time
+    worker = tmp_path / "sleeper.py"
+    worker.write_text("import os, time\n"
+                      "open(os.path.join(%r, 'pid.' + os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                      "time.sleep(600)\n" % str(tmp_path))
+    spawner = tmp_path / "spawner.py"
+    spawner.write_text("import sys\nsys.path.insert(0, %r)\nfrom deepflows_amd import launch\n"
+                       "rc, _ = launch.spawn_ranks(2, [sys.executable, %r])\nsys.exit(rc)\n" % (ROOT, str(worker)))
+    p = subprocess.Popen([sys.executable, str(spawner)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        t_end = time.monotonic() + 30
+        while not all((tmp_path / f"pid.{r}").exists() and (tmp_path / f"pid.{r}").read_text() for r in range(2)):
+            assert time.monotonic() < t_end, "the ranks never started"
+            time.sleep(0.05)
+        pids = [int((tmp_path / f"pid.{r}").read_text()) for r in range(2)]
+        p.send_signal(signal.SIGTERM)
+        rc = p.wait(timeout=30)
+        assert rc == 128 + signal.SIGTERM, (rc, p.stderr.read().decode()[-500:])
+        t_end = time.monotonic() + 10
+        for pid in pids:
+            while True:
+                try:
+                    os.kill(pid, 0)
+                except ProcessLookupError:
+                    break
+                assert time.monotonic() < t_end, f"rank process {pid} outlived its spawner"
+                time.sleep(0.05)
+    finally:
+        if p.poll() is None:
+            p.kill()

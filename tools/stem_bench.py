@@ -1,8 +1,10 @@
-#!/usr/bin/env python3
 """Back-to-back timing of the stem pool(relu(bn(conv(x)))) at batch 256: the one-node form without the convolution's
 output tensor (dfhip_stem.hip) against the two-node form (convolution with partials + fused bn/relu/pool; backward =
 dfhip_stem_backward).  HIP events on the library stream around `iters` calls; run under rocprofv3 --kernel-trace for
-the per-kernel split."""
+the per-kernel split:
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof -- python3 tools/stem_bench.py
+(the interpreter itself after `--`, never this file through an `env` hop: the profiler's preloaded library has initialised the
+GPU by then, and an exec behind that takes the machine down on this pool)."""
 import argparse
 import os
 import sys
