@@ -986,166 +986,6 @@ __global__ __launch_bounds__(256) void k_conv1x1s2_fwd(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------
-// forward, 3x3 / stride 1 / pad 1 on 2 x 2 images (ResNet layer4): every output pixel p sees all four
-// input pixels q, each through the tap (qy - py + 1, qx - px + 1), so the layer is, per output
-// position, a dense contraction over K = 4 C -- and 5 of the 9 taps of a 3x3 window only ever meet
-// padding.  The staged kernel multiplies those zeros (56 % of its MFMAs) and streams all nine taps
-// through LDS in eight chunks.  Here a workgroup owns (32 images, one output position, 32 output
-// channels): the four taps it needs go to LDS once (4 x C x 32 floats), a lane is an IMAGE and reads
-// x[n][c][0..3] -- all four input pixels -- as one 16-byte load per channel, the eight waves split
-// the channels and are summed through LDS.  Epilogue: stores (a lane's outputs are 16 bytes apart in
-// memory; the other positions' workgroups fill the gaps) and the BatchNorm partials.
-// ---------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(512) void k_conv3x3_img2_fwd(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, float* __restrict__ y,
-                                                          float* __restrict__ stats, int O) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int CK = C / 8, NP = CK / 2, WT = 33, TS = 36;
-  float* Wl = smem;                                 // [q][c][WT]
-  const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  const int pos = blockIdx.x & 3, py = pos >> 1, px = pos & 1;
-  const int n = (blockIdx.x >> 2) * 32 + l31;       // this lane's image
-  const int d0 = blockIdx.y * 32;
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  // the four taps this output position needs, for all channels: W[d0+o][c][tap(q)] -> Wl[(q*C + c)*WT + o]
-  // (sixteen (o, c) pairs = 32 loads in flight per thread; the pixel operand is requested after them,
-  // its latency runs under the LDS writes and the barrier)
-  // The taps of q = 0..3 are t0, t0 + 1, t0 + 3, t0 + 4 with t0 = 3 (1 - py) + (1 - px): two adjacent
-  // pairs, requested as two 8-byte loads (the address unit's cost of a gather is per cache line touched,
-  // and a wave's 64 records of 36 bytes touch 36 of them per request whatever its width).
-  {
-    const int t0 = (1 - py) * 3 + (1 - px);
-    const int dmax = min(32, O - d0);
-    constexpr int PAIRS = 32 * C / 512, NB = PAIRS < 16 ? PAIRS : 16;
-    for (int i0 = 0; i0 < PAIRS; i0 += NB) {
-      float wv[NB][4];
-#pragma unroll
-      for (int i = 0; i < NB; i++) {
-        const int e = tid + 512 * (i0 + i), o = e / C, c = e - o * C;
-        const float* src = w + ((int64_t)(d0 + min(o, dmax - 1)) * C + c) * 9 + t0;
-        const float m = o < dmax ? 1.0f : 0.0f;     // (the address is clamped: load first, mask after)
-        wv[i][0] = src[0] * m; wv[i][1] = src[1] * m; wv[i][2] = src[3] * m; wv[i][3] = src[4] * m;
-      }
-#pragma unroll
-      for (int i = 0; i < NB; i++) {
-        const int e = tid + 512 * (i0 + i), o = e / C, c = e - o * C;
-#pragma unroll
-        for (int q = 0; q < 4; q++) Wl[(q * C + c) * WT + o] = wv[i][q];
-      }
-    }
-  }
-  // The pixel operand of this wave's channels: lane (image, half) needs the whole 2 x 2 plane of channel
-  // 2 kp + half as one float4.  Read that way a request is 64 pieces of 16 bytes 4 KB apart and the
-  // address unit takes them one lane per cycle (4.1 us of the launch); instead the wave reads its slice
-  // in runs -- four lanes cover the 64 contiguous bytes of one image's four channels, 16 images per
-  // request -- and turns it through a wave-private LDS strip (XS floats per image: conflict-free 16-byte
-  // reads) four channels at a time.
-  f32x4 xv[NP];
-  {
-    constexpr int NCH = CK / 4, XS = 20;
-    float* Xt = smem + 4 * C * WT + ks * (32 * XS);
-    f32x4 xg[NCH][2];
-    const float* xb = x + ((int64_t)((blockIdx.x >> 2) * 32 + (lane >> 2)) * C + ks * CK + (lane & 3)) * 4;
-#pragma unroll
-    for (int j = 0; j < NCH; j++)
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-        xg[j][i] = *reinterpret_cast<const f32x4*>(xb + (int64_t)16 * i * C * 4 + j * 16);
-    float* wr = Xt + (lane >> 2) * XS + (lane & 3) * 4;
-    const float* rd = Xt + l31 * XS + half * 4;
-#pragma unroll
-    for (int j = 0; j < NCH; j++) {
-      *reinterpret_cast<f32x4*>(wr) = xg[j][0];
-      *reinterpret_cast<f32x4*>(wr + 16 * XS) = xg[j][1];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      xv[2 * j] = *reinterpret_cast<const f32x4*>(rd);
-      xv[2 * j + 1] = *reinterpret_cast<const f32x4*>(rd + 8);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-  }
-  __syncthreads();
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-  {
-    // the weight operand of all 4 NP MFMAs is read up front: with two waves per SIMD a read per MFMA
-    // leaves its LDS latency exposed on every other one (the phase ran at 40 % of the pipe rate)
-    const float* aq = Wl + (ks * CK + half) * WT + l31;
-    float av[NP][4];
-#pragma unroll
-    for (int kp = 0; kp < NP; kp++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) av[kp][q] = aq[(q * C + 2 * kp) * WT];
-    __builtin_amdgcn_sched_barrier(0);              // (the scheduler would sink the reads back to their uses)
-#pragma unroll
-    for (int kp = 0; kp < NP; kp++) {
-      const float bq[4] = {xv[kp].x, xv[kp].y, xv[kp].z, xv[kp].w};
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp][q], bq[q], acc, 0, 0, 0);
-    }
-  }
-  __syncthreads();                                  // the weights are dead: their LDS becomes the epilogue's
-  float* red = smem;                                // [7][16][64]
-  if (ks > 0) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) red[((ks - 1) * 16 + r) * 64 + lane] = acc[r];
-  }
-  __syncthreads();
-  if (ks == 0) {
-#pragma unroll
-    for (int s2 = 0; s2 < 7; s2++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] += red[(s2 * 16 + r) * 64 + lane];
-    if (bias) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] += bias[min(d0 + (r & 3) + 8 * (r >> 2) + 4 * half, O - 1)];
-    }
-    float* yo = y + ((int64_t)n * O + d0) * 4 + pos;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int o = (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (d0 + o < O) yo[o * 4] = acc[r];
-    }
-  }
-  if (stats) {
-    __syncthreads();                                // red is dead
-    float* Tt = smem;                               // [32 channels][TS]: the tile, images along the row
-    if (ks == 0) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) Tt[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + l31] = acc[r];
-      // (same wave reads it back: lane (channel = l31, half) walks 16 of the 32 images)
-      const float* row = Tt + l31 * TS + 16 * half;
-      float vals[16];
-#pragma unroll
-      for (int q4 = 0; q4 < 4; q4++) {
-        const float4 t4 = *reinterpret_cast<const float4*>(row + 4 * q4);
-        vals[4 * q4] = t4.x; vals[4 * q4 + 1] = t4.y; vals[4 * q4 + 2] = t4.z; vals[4 * q4 + 3] = t4.w;
-      }
-      float t = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 16; i++) t += vals[i];
-      t += __shfl_xor(t, 32);
-      const float mean_t = t * (1.0f / 32.0f);
-      float q = 0.0f;
-#pragma unroll
-      for (int i = 0; i < 16; i++) { const float dlt = vals[i] - mean_t; q += dlt * dlt; }
-      q += __shfl_xor(q, 32);
-      if (half == 0 && d0 + l31 < O) {
-        float* o3 = stats + ((int64_t)blockIdx.x * O + d0 + l31) * 3;
-        o3[0] = 32.0f; o3[1] = mean_t; o3[2] = q;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------
 // The same layer with ALL FOUR output positions in one workgroup (16 images x 16 output channels; 16x16x4 MFMA:
 // D[16 channels][16 images] += A[16][4 source channels] . B[4][16]).  Every 36-byte weight record (o, c) is then read
 // whole, in memory order and once per workgroup (the one-position kernel reads 16 bytes of each from four workgroups:
@@ -3525,37 +3365,17 @@ int run_conv_img2(const Geo& g, int O, float* y, const float* bias, float* parti
   if (!enabled || g.mode != 0 || g.k != 3 || g.so != 1 || g.sd != 1 || g.u0 != -1) return -1;
   if (g.HS != 2 || g.WS != 2 || g.HD != 2 || g.WD != 2 || (g.N % 32) != 0) return -1;
   if (!(g.CS == 128 || g.CS == 256)) return -1;
-  static int all4 = getenv("DFHIP_IMG2_ALL") ? atoi(getenv("DFHIP_IMG2_ALL")) : 1;
-  if (all4 && O % 16 == 0 && g.N % 16 == 0 && (!partials || g.N / 16 <= cap_rows)) {
-    // all four positions per workgroup (k_conv3x3_img2_all): 16 images x 16 channels
-    const int rows4 = g.N / 16;
-    if (rows_out) *rows_out = partials ? rows4 : 0;
-    dim3 grid4((unsigned)rows4, (unsigned)(O / 16));
-    const size_t lds4 = std::max((size_t)8 * (72 * 17 + 16 * 9 * 4), (size_t)7 * 4 * 64 * 4) * sizeof(float);
-    // XCD arrangement: blockIdx.y selects 16 output channels' weights, blockIdx.x 16 images' planes
-    const int xo = xcd_arrangement(rows4, O / 16, 4.0 * g.N * g.CS * 4, 4.0 * O * g.CS * 9);
-    if (g.CS == 128) DF_LAUNCH(k_conv3x3_img2_all<128>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, xo);
-    else DF_LAUNCH(k_conv3x3_img2_all<256>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, xo);
-    DF_LAUNCH_CHECK();
-    return DFHIP_OK;
-  }
-  const int rows = g.N / 32 * 4;
-  if (partials && rows > cap_rows) return -1;
-  if (rows_out) *rows_out = partials ? rows : 0;
-  dim3 grid((unsigned)rows, (unsigned)df_ceil_div(O, 32));
-  const size_t lds = std::max((size_t)4 * g.CS * 33 + 8 * 32 * 20, (size_t)7 * 16 * 64) * sizeof(float);   // weights + the waves' x strips
-#define DF_I2(CV)                                                                                                 \
-  do {                                                                                                            \
-    static bool attr = false;                                                                                     \
-    if (!attr) {                                                                                                  \
-      DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_img2_fwd<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                 (int)std::max(lds, (size_t)65536)));                                             \
-      attr = true;                                                                                                \
-    }                                                                                                             \
-    DF_LAUNCH(k_conv3x3_img2_fwd<CV>, grid, dim3(512), lds, stream(), g.src, g.wgt, bias, y, partials, O); \
-  } while (0)
-  if (g.CS == 128) DF_I2(128); else DF_I2(256);
-#undef DF_I2
+  // all four positions per workgroup (k_conv3x3_img2_all): 16 images x 16 channels; other channel counts / more rows than
+  // the partials buffer holds take the staged kernel (the one-position-per-workgroup kernel of round 2 is gone: superseded)
+  if (O % 16 != 0 || g.N % 16 != 0 || (partials && g.N / 16 > cap_rows)) return -1;
+  const int rows4 = g.N / 16;
+  if (rows_out) *rows_out = partials ? rows4 : 0;
+  dim3 grid4((unsigned)rows4, (unsigned)(O / 16));
+  const size_t lds4 = std::max((size_t)8 * (72 * 17 + 16 * 9 * 4), (size_t)7 * 4 * 64 * 4) * sizeof(float);
+  // XCD arrangement: blockIdx.y selects 16 output channels' weights, blockIdx.x 16 images' planes
+  const int xo = xcd_arrangement(rows4, O / 16, 4.0 * g.N * g.CS * 4, 4.0 * O * g.CS * 9);
+  if (g.CS == 128) DF_LAUNCH(k_conv3x3_img2_all<128>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, xo);
+  else DF_LAUNCH(k_conv3x3_img2_all<256>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, xo);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -4870,10 +4690,7 @@ int dfhip_conv2d_dgrad_pair(const float* dy, const float* w, const float* dy2, c
   int oh, ow;
   int s = check_conv_args("conv2d_dgrad_pair", N, C, H, W, O, 3, 2, 1, oh, ow);
   if (s != DFHIP_OK) return s;
-  static int lean = getenv("DFHIP_DGRAD_LEAN") ? atoi(getenv("DFHIP_DGRAD_LEAN")) : 1;
   static int pair_on = getenv("DFHIP_DGRAD_PAIR") ? atoi(getenv("DFHIP_DGRAD_PAIR")) : 1;
-  int lw = 0;
-  while ((1 << lw) < W) lw++;
   if (pair_on && mode == 1) {
     // accumulate mode: the stride-2 kernel that multiplies only the (pixel, tap) pairs that exist, shortcut included
     double flopsa = 2.0 * N * oh * ow * (double)C * 10 * O;
