@@ -48,16 +48,22 @@ def _run_matrix(tmp_path, mode, switches):
     failed = [(tag, err) for tag, rc, err, _ in done if rc != 0]
     assert not failed, f"children failed: {failed}"
     base = np.load(done[0][3])
-    worst = {}
+    worst, bad = {}, []
     for (name, _), (tag, _, _, out) in zip(jobs[1:], done[1:]):
         got = np.load(out)
         for k in base.files:
             e = rel_err(got[k], base[k])
-            worst[name] = max(worst.get(name, 0.0), e)
-            assert e <= 1e-4, f"{name}: {k} differs from the default path by {e:.3e}"
+            worst[name] = max(worst.get(name, (0.0, ""))[0], e), (k if e >= worst.get(name, (0.0, ""))[0] else worst[name][1])
+            # the first layer's weight gradient sits behind ReLU / pooling ties: two CORRECT fp32 evaluations that differ
+            # in summation order are up to 1e-3 apart there (tests/test_hip_whole_step.py: the fp32 oracle itself is
+            # 8.4e-4 from the float64 evaluation for the CNN's conv1) -- 5e-3 for that quantity, 1e-4 for the rest
+            lim = 5e-3 if k.endswith("_first_wgrad") else 1e-4
+            if e > lim:
+                bad.append((name, k, e))
     print(f"\n{mode}: largest relative difference from the default path per switch")
-    for name, e in sorted(worst.items(), key=lambda kv: -kv[1]):
-        print(f"  {name:28s} {e:.2e}")
+    for name, (e, k) in sorted(worst.items(), key=lambda kv: -kv[1][0]):
+        print(f"  {name:28s} {e:.2e}  ({k})")
+    assert not bad, f"switches that change the results: {bad}"
 
 
 def test_every_switch_computes_what_the_default_path_computes(tmp_path):
