@@ -12,6 +12,8 @@ Every function keeps the reference's name and argument meaning.  Each has two bo
     (functional.py:285-294) unless the device is switched to conv_dgrad_mode="accumulate".
 """
 import os
+import weakref
+
 import numpy as np
 
 from .. import backend_api, tensor
@@ -74,10 +76,16 @@ class _PendingBN:
 class _BnRows:
     """what a producer left behind for the BatchNorm node `owner`: rows (nrows of a buffer with room for cap_rows, x C x K),
     sums 0 and 1 + j are layer j's"""
-    __slots__ = ("owner", "rows", "nrows", "cap_rows", "K")
+    __slots__ = ("_owner", "rows", "nrows", "cap_rows", "K")
 
     def __init__(self, owner, rows, nrows, cap_rows, K):
-        self.owner, self.rows, self.nrows, self.cap_rows, self.K = owner, rows, nrows, cap_rows, K
+        # (a weak reference: the owner's cached gradients hold the tensor that carries this tag -- a strong one would be a
+        # reference cycle, and the arrays of a step would wait for the cycle collector instead of going back to the pool)
+        self._owner, self.rows, self.nrows, self.cap_rows, self.K = weakref.ref(owner), rows, nrows, cap_rows, K
+
+    @property
+    def owner(self):
+        return self._owner()
 
 
 def _alias(t):
@@ -491,7 +499,7 @@ class _Conv2dFused(_FusedNode):
             node.bn_partials = (part, rows) if (part is not None and rows > 0) else None
             _FusedNode.__init__(node, out, [x, wt, None])
             nodes.append(node)
-        nodes[0]._sibling_host = nodes[1]     # (the shortcut's node: its input gradient rides on conv1's launch)
+        nodes[0]._sibling_host = weakref.ref(nodes[1])     # (the shortcut's node: its input gradient rides on conv1's launch)
         return nodes[1], nodes[0]
 
     # the engine may hand over the gradient the input already holds (tensor.py backward): the sum
@@ -513,7 +521,7 @@ class _Conv2dFused(_FusedNode):
         mod = self.device.mod
         if self.bias is not None:
             return False
-        host = getattr(self, "_sibling_host", None)
+        host = self._sibling_host() if getattr(self, "_sibling_host", None) is not None else None
         if (host is not None or self.shortcut_sibling is not None) and not _BN_BWD_PAIR:
             return False
         if host is not None:

@@ -26,6 +26,7 @@ Recorded forms (x0 a real tensor):
 Completing calls: MaxPool2d(relu(bn(conv(x0)))), bn(conv(bn(conv(x0)))) + identity, Linear(meanhw(x0)).
 DF_LAZY_MODULES=0 switches the mechanism off (every module call launches its own node, as before)."""
 import os
+import weakref
 
 from .. import tensor
 from ..autograd import is_grad_enable
@@ -198,7 +199,7 @@ def _block_tail(out_l, identity):
             z1 = realize(conv1_l)
             if hasattr(z1, "shortcut_sibling") and hasattr(zd, "shortcut_sibling") and getattr(z1, "x", None) is getattr(zd, "x", 0):
                 z1.shortcut_sibling = zd               # both read x: one launch forms both input gradients
-                zd._sibling_host = z1
+                zd._sibling_host = weakref.ref(z1)
     z2 = realize(conv2_l)                              # conv2(bn1(z1)): bn1 on the operand loads where that form applies
     if short is not None:
         if F.batch_norm2d_pair_fusable(z2, bn2, zd, bn_d):

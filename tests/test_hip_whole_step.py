@@ -125,3 +125,31 @@ def test_model_written_as_the_reference_writes_it_launches_the_fused_kernels(hip
     assert ca == cb, f"different launches: plain {sorted(ca.items())} vs hand-fused {sorted(cb.items())}"
     for k in plain:
         assert np.array_equal(plain[k], fused[k]), f"the plain model differs from the hand-fused one in {k}"
+
+
+@pytest.mark.parametrize("model_kind", ["plain", "fused"])
+def test_eager_steps_return_every_array_to_the_pool_without_the_cycle_collector(hip_device, model_kind):
+    """The arrays of a step go back to the library's pool when their Python owners die -- by reference counting: with the
+    cycle collector switched off, steady-state eager steps must not reach hipMalloc (a reference cycle among the nodes or
+    the gradient tags of a step would keep its arrays until some later collection: the pool then grows by a step's worth of
+    memory per step -- tools/soak.py caught exactly that in round 4)."""
+    import gc
+    import bench
+    from deepflows_amd import workloads
+    from deepflows_amd.tensor import Graph
+    mod = hip_device.mod
+    model, opt, crit, xt, yt = bench.build_job("resnet18", hip_device, 0, 64, model_kind=model_kind)
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(4):
+            workloads.train_step(model, crit, opt, xt, yt)
+            Graph.free_graph()
+        s0 = mod.pool_stats()
+        for _ in range(6):
+            workloads.train_step(model, crit, opt, xt, yt)
+            Graph.free_graph()
+        s1 = mod.pool_stats()
+    finally:
+        gc.enable()
+    assert s1["hipmalloc_calls"] == s0["hipmalloc_calls"], (s0, s1)
