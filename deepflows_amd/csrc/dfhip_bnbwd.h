@@ -77,7 +77,9 @@ __device__ __forceinline__ float bn_bwd_point(float dy, float z, const float4 t)
 // CONSUMING launch as 8-byte {value, tag} granules that every workgroup polls behind its operand loads (correct over 150
 // repetitions from cleared tags, a self-computing fall-back instead of a progress assumption): the publish is a
 // write-through store behind an L2 read, visible after 2.5-3 us -- +2.3-2.7 us, no better than everybody reading all rows.
-constexpr int kBnPartFloats = 1024 + 768;
+// LDS scratch of a builder of NT threads: a 16-byte partial per thread, then the complete sums of the (up to 768) columns
+constexpr int bn_part_floats(int NT) { return 4 * NT + 768; }
+constexpr int kBnPartFloats = bn_part_floats(256);
 template <int NT>
 struct BnTableBuilder {
   static constexpr int OPT = (256 + NT - 1) / NT;      // channels per thread
@@ -107,7 +109,7 @@ struct BnTableBuilder {
       for (int o = tid; o < O; o += NT) tab[o] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
       return;
     }
-    float* tot = part + 1024;                          // the complete sums of the (up to 768) columns
+    float* tot = part + 4 * NT;                        // the complete sums of the (up to 768) columns
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int gg = min(g, NG - 1);
     const float4* src = reinterpret_cast<const float4*>(b.rows) + c;

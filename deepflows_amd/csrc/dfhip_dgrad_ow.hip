@@ -82,8 +82,12 @@ struct OwGeo {
 // BNI: dy (and dy2) are gradients of BatchNorm OUTPUTS whose backward pass has not been applied; the operand is formed
 // on load from (dy, z) and the per-channel table built from the producer's rows (dfhip_bnbwd.h).  NST: dx is the output
 // gradient of NST BatchNorm layers; the tile's per-channel sums of dx and dx (z_t - mean_t) leave as partial rows.
-template <int O, int GEO, bool PAIR, bool BNI, int NST>
-__global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ dy, const float* __restrict__ w,
+// NW: waves (32-pixel tiles) per workgroup.  4 everywhere but for the 32-channel BatchNorm builds (NW = 8): a workgroup leaves
+// ONE row of sums, and every workgroup of the consuming launch reads all rows -- with 512 workgroups of 4 waves on the
+// 16 x 16 x 32-channel layers that was 512 x 64 KB = 32 MB of row reads per launch (PMC: 40 MB fetched for 19.6 MB algorithmic),
+// with 256 workgroups of 8 waves it is 256 x 32 KB.
+template <int O, int GEO, bool PAIR, bool BNI, int NST, int NW>
+__global__ __launch_bounds__(64 * NW) void k_dgrad_ow_s1(const float* __restrict__ dy, const float* __restrict__ w,
                                                      const float* __restrict__ add, float* __restrict__ dx,
                                                      int C, int H, int lw, int tiles, int pg,
                                                      const float* __restrict__ dy2, const float* __restrict__ w2,
@@ -91,19 +95,20 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
   static_assert(!PAIR || GEO == 1, "the shortcut rides on the stride-2 3x3 kernel");
   constexpr int NP = O / 2, NSL = OwGeo<GEO>::NSL;
   constexpr int KS = 1 + NST;
+  constexpr int NT = 64 * NW;                       // threads: NW waves, a 32-pixel tile each
   constexpr bool BN = BNI || NST > 0;               // a BatchNorm build: more loads than a wave keeps in flight, see below
   __shared__ float Wl[NSL + (PAIR ? 1 : 0)][O][32]; // the weight slices of this channel tile: [slice][o][c]
   __shared__ float4 tab[BNI ? (PAIR ? 2 : 1) : 1][BNI ? O : 1];
-  __shared__ float wsum[NST ? 4 : 1][NST ? 32 : 1][KS];
+  __shared__ float wsum[NST ? NW : 1][NST ? 32 : 1][KS];
   __shared__ float mtl[NST ? NST : 1][32];
-  __shared__ __attribute__((aligned(16))) float tpart[BNI ? kBnPartFloats : 4];
+  __shared__ __attribute__((aligned(16))) float tpart[BNI ? bn_part_floats(64 * NW) : 4];
   const int lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int HW = H << lw;
   const int c0 = blockIdx.y * 32;
-  const int tile = min(blockIdx.x * 4 + wave, tiles - 1);   // 32 consecutive pixels of one image (clamped: a
-  const bool live = blockIdx.x * 4 + wave < tiles;          //  wave past the end still takes part in the barriers)
+  const int tile = min((int)blockIdx.x * NW + wave, tiles - 1);   // 32 consecutive pixels of one image (clamped: a
+  const bool live = (int)blockIdx.x * NW + wave < tiles;          //  wave past the end still takes part in the barriers)
   int n, y, x;
   OwGeo<GEO>::decode(tile, l31, lw, H, pg, n, y, x);
   const int rem = (y << lw) + x;
@@ -113,12 +118,13 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
   const int SHW = GEO == 0 ? HW : HW >> 2;
   const int64_t soff = ((int64_t)n * O + half) * SHW + (u << slw) + v;
   const int64_t obase = ((int64_t)n * C + c0) * HW + rem;
-  constexpr int PAIRS = O * 32 / 256;
+  constexpr int PAIRS = O * 32 / NT;
+  static_assert(O * 32 % NT == 0, "whole rounds of weight staging");
   float wv[PAIRS][4], wv2[PAIRS];
   auto load_weights = [&]() {       // the thread's share of the weight slices: (o, c) pairs, the four taps 4, 5, 7, 8 of each
 #pragma unroll
     for (int i = 0; i < PAIRS; i++) {
-      const int e = threadIdx.x + 256 * i, o = e >> 5, c = e & 31;
+      const int e = threadIdx.x + NT * i, o = e >> 5, c = e & 31;
       OwGeo<GEO>::slices(w, (int64_t)o * C + c0 + c, wv[i]);
       wv2[i] = PAIR ? w2[(int64_t)o * C + c0 + c] : 0.0f;
     }
@@ -170,14 +176,14 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
     // needs is requested behind the barrier and lands under the MFMAs.
     load_weights();
     if constexpr (NST > 0) {
-      if ((int)threadIdx.x >= 192 && (int)threadIdx.x < 192 + 32 * NST) {
-        const int j = (threadIdx.x - 192) >> 5, ch = threadIdx.x & 31;
+      if ((int)threadIdx.x >= NT - 64 && (int)threadIdx.x < NT - 64 + 32 * NST) {
+        const int j = (threadIdx.x - (NT - 64)) >> 5, ch = threadIdx.x & 31;
         mtl[j][ch] = bn.mt[j][c0 + ch];
       }
     }
     if constexpr (BNI) {
       const bool first = lin == 0;
-      BnTableBuilder<256> tb;
+      BnTableBuilder<NT> tb;
       tb.issue(bn.in, O);
       __builtin_amdgcn_sched_barrier(0);
       load_operands();
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
   }
 #pragma unroll
   for (int i = 0; i < PAIRS; i++) {
-    const int e = threadIdx.x + 256 * i, o = e >> 5, c = e & 31;
+    const int e = threadIdx.x + NT * i, o = e >> 5, c = e & 31;
 #pragma unroll
     for (int q = 0; q < NSL; q++) Wl[q][o][c] = wv[i][q];
     if constexpr (PAIR) Wl[NSL][o][c] = wv2[i];
@@ -267,8 +273,9 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1(const float* __restrict__ d
     __syncthreads();
     if ((int)threadIdx.x < 32 * KS) {
       const int ch = threadIdx.x / KS, k = threadIdx.x % KS;
-      bn.rows[((int64_t)blockIdx.x * C + c0) * KS + threadIdx.x] =
-          (wsum[0][ch][k] + wsum[1][ch][k]) + (wsum[2][ch][k] + wsum[3][ch][k]);
+      float t = (wsum[0][ch][k] + wsum[1][ch][k]) + (wsum[2][ch][k] + wsum[3][ch][k]);
+      if constexpr (NW == 8) t += (wsum[4][ch][k] + wsum[5][ch][k]) + (wsum[6][ch][k] + wsum[7][ch][k]);
+      bn.rows[((int64_t)blockIdx.x * C + c0) * KS + threadIdx.x] = t;
     }
   }
 }
@@ -760,13 +767,14 @@ int make_ow_bn(OwBn& b, const BnBwdIn* bi, const BnBwdIn* bi2, BnStatsOut* so, i
 
 template <int O, int GEO, bool PAIR>
 int launch_ow_s1(const float* dy, const float* w, const float* add, float* dx, int C, int H, int lw, int tiles, int pg,
-                 const float* dy2, const float* w2, const BnBwdIn* bi, const BnBwdIn* bi2, BnStatsOut* so) {
-  dim3 grid((unsigned)df_ceil_div(tiles, 4), (unsigned)(C / 32));
+                 const float* dy2, const float* w2, const BnBwdIn* bi, const BnBwdIn* bi2, BnStatsOut* so, bool dry_run = false) {
   OwBn bn;
   const bool any = bi || bi2 || so;
   if (!any) {
+    if (dry_run) return DFHIP_OK;
+    dim3 grid((unsigned)df_ceil_div(tiles, 4), (unsigned)(C / 32));
     bn = OwBn{};
-    DF_LAUNCH((k_dgrad_ow_s1<O, GEO, PAIR, false, 0>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg,
+    DF_LAUNCH((k_dgrad_ow_s1<O, GEO, PAIR, false, 0, 4>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg,
               dy2, w2, bn);
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
@@ -774,6 +782,13 @@ int launch_ow_s1(const float* dy, const float* w, const float* add, float* dx, i
   if constexpr (GEO == 2) {
     return -2;
   } else {
+    // eight waves per workgroup for the 32-channel layers (half the rows, half the readers of the rows: see the kernel)
+    static int nw8 = getenv("DFHIP_DGRAD_BN_NW8") ? atoi(getenv("DFHIP_DGRAD_BN_NW8")) : 1;
+    constexpr bool CAN8 = O == 32 && !PAIR;
+    const int nw = (CAN8 && nw8) ? 8 : 4;
+    dim3 grid((unsigned)df_ceil_div(tiles, nw), (unsigned)(C / 32));
+    if (so) so->nrows = (int)grid.x;
+    if (dry_run) return DFHIP_OK;
     int st = make_ow_bn(bn, bi, bi2, so, (int)grid.x, (int)grid.y, C);
     if (st != DFHIP_OK) return st;
     const int nst = so ? so->n : 0;
@@ -781,11 +796,17 @@ int launch_ow_s1(const float* dy, const float* w, const float* add, float* dx, i
     // (of a PAIR only one gradient may be pending: the other one's descriptor is the identity, its z operand re-reads dY)
     if (bni && !bi) { bn.in = BnBwdIn{}; bn.in.z = dy; }
     if (bni && PAIR && !bi2) { bn.in2 = BnBwdIn{}; bn.in2.z = dy2; }
-#define DF_OW(BNIV, NSTV)                                                                                             \
-  DF_LAUNCH((k_dgrad_ow_s1<O, GEO, PAIR, BNIV, NSTV>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg, \
-            dy2, w2, bn)
-    if (bni) { if (nst == 0) DF_OW(true, 0); else if (nst == 1) DF_OW(true, 1); else DF_OW(true, 2); }
-    else { if (nst == 1) DF_OW(false, 1); else DF_OW(false, 2); }
+#define DF_OW(BNIV, NSTV, NWV)                                                                                          \
+  DF_LAUNCH((k_dgrad_ow_s1<O, GEO, PAIR, BNIV, NSTV, NWV>), grid, dim3(64 * NWV), 0, stream(), dy, w, add, dx, C, H, lw, \
+            tiles, pg, dy2, w2, bn)
+#define DF_OW_NW(BNIV, NSTV)                                    \
+  do {                                                          \
+    if constexpr (CAN8) { if (nw == 8) { DF_OW(BNIV, NSTV, 8); break; } } \
+    DF_OW(BNIV, NSTV, 4);                                       \
+  } while (0)
+    if (bni) { if (nst == 0) DF_OW_NW(true, 0); else if (nst == 1) DF_OW_NW(true, 1); else DF_OW_NW(true, 2); }
+    else { if (nst == 1) DF_OW_NW(false, 1); else DF_OW_NW(false, 2); }
+#undef DF_OW_NW
 #undef DF_OW
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
@@ -875,10 +896,8 @@ int run_dgrad_ow(const float* dy, const float* w, const float* add, float* dx, i
   }
   if (lean_ok && (O == 32 || O == 64)) {
     if (bnform && geo == 2) return -2;
-    if (so) so->nrows = (int)df_ceil_div(tiles, 4);
-    if (dry_run) return DFHIP_OK;
     const float* none = nullptr;
-#define DF_A(OV, GV) return launch_ow_s1<OV, GV, false>(dy, w, add, dx, C, H, lw, tiles, pg, none, none, bi, nullptr, so)
+#define DF_A(OV, GV) return launch_ow_s1<OV, GV, false>(dy, w, add, dx, C, H, lw, tiles, pg, none, none, bi, nullptr, so, dry_run)
     if (O == 32) { if (geo == 0) DF_A(32, 0); else if (geo == 1) DF_A(32, 1); else DF_A(32, 2); }
     else { if (geo == 0) DF_A(64, 0); else if (geo == 1) DF_A(64, 1); else DF_A(64, 2); }
 #undef DF_A
@@ -917,9 +936,8 @@ int run_dgrad_ow_pair(const float* dy, const float* w, const float* dy2, const f
   if (!ok) return -1;
   if (O == 128 && bnform) return -2;
   const int tiles = (int)((int64_t)N * H * W / 32);
-  if (so) so->nrows = (int)df_ceil_div(tiles, 4);
-  if (dry_run) return DFHIP_OK;
   const int pg = (((int64_t)N * H * W) % 128 == 0 && W <= 64) ? 1 : 0;
+  if (O == 128 && dry_run) return DFHIP_OK;
   if (O == 128) {
     // (five slices = 92 KB of LDS: ONE workgroup per CU, which walks twice the tiles of the unpaired launch)
     const int want = std::max(1, num_cus() / (C / 32));
@@ -935,8 +953,8 @@ int run_dgrad_ow_pair(const float* dy, const float* w, const float* dy2, const f
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
   }
-  if (O == 32) return launch_ow_s1<32, 1, true>(dy, w, add, dx, C, H, lw, tiles, pg, dy2, w2, bi, bi2, so);
-  return launch_ow_s1<64, 1, true>(dy, w, add, dx, C, H, lw, tiles, pg, dy2, w2, bi, bi2, so);
+  if (O == 32) return launch_ow_s1<32, 1, true>(dy, w, add, dx, C, H, lw, tiles, pg, dy2, w2, bi, bi2, so, dry_run);
+  return launch_ow_s1<64, 1, true>(dy, w, add, dx, C, H, lw, tiles, pg, dy2, w2, bi, bi2, so, dry_run);
 }
 
 }  // namespace dfhip

@@ -133,7 +133,7 @@ def test_dgrad_with_pending_batchnorm_and_rows(hip_device, name, with_in, n_targ
 
 def test_table_of_a_pending_backward_is_the_same_in_every_launch(hip_device):
     """the addition of the producer's rows by every workgroup of the consuming launch (fixed order): 60 launches with other
-    kernels' traffic in between give the same bits -- dx, table, dgamma, dbeta -- and so does the table launch of its own"""
+    kernels' traffic in between give the same bits -- dx, table, dgamma, dbeta"""
     mod = hip_device.mod
     C, H, W, O, k, s, p = S1_LAYERS["l1"]
     geo = (N, C, H, W, O, k, s, p)
@@ -157,8 +157,10 @@ def test_table_of_a_pending_backward_is_the_same_in_every_launch(hip_device):
             assert_close(got[0], R.conv2d_dgrad(dz.astype(np.float32), w, (N, C, H, W), s, p, "overwrite"), 1e-4, "dx")
         for a, b in zip(got, first):
             assert np.array_equal(a, b), f"repetition {rep} differs"
+    # the table launch of its own (a convolution that needs no input gradient) adds the rows up in groups of its own size:
+    # the same table up to the rounding of the sums
     mod.bn_bwd_table(pend, O)
-    assert np.array_equal(_back(mod, pend.table, (O, 4)), first[1])
+    assert_close(_back(mod, pend.table, (O, 4)), first[1], 1e-5, "table launch")
 
 
 @pytest.mark.parametrize("which", ["both", "conv_only", "shortcut_only", "rows_only"])
