@@ -1029,8 +1029,21 @@ int dfhip_side_probe(int wgs, int iters, int lds_bytes) {
     DF_HIP(hipFuncSetAttribute((const void*)k_clock_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  int s = side_fork();
-  if (s != DFHIP_OK) return s;
+  // DFHIP_SIDE_FREE=1 (diagnostic): the load is enqueued on the second stream WITHOUT a fork event -- it runs beside whatever
+  // the library stream does, ordered only against earlier loads (tools/probes/side_free.py: what a persistent kernel on
+  // a second queue costs the captured step, without the fork / join edges of a graph)
+  static int free_run = getenv("DFHIP_SIDE_FREE") ? atoi(getenv("DFHIP_SIDE_FREE")) : 0;
+  if (free_run) {
+    if (!g_side) {
+      DF_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+      DF_HIP(hipEventCreateWithFlags(&g_side_fork_ev, hipEventDisableTiming));
+      DF_HIP(hipEventCreateWithFlags(&g_side_join_ev, hipEventDisableTiming));
+    }
+    g_side_pending = true;                          // (dfhip_side_join then waits for it)
+  } else {
+    int s = side_fork();
+    if (s != DFHIP_OK) return s;
+  }
   hipLaunchKernelGGL(k_clock_probe, dim3((unsigned)wgs), dim3(256), (size_t)lds_bytes, g_side, d, iters, 0.41f);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
