@@ -332,6 +332,9 @@ def main():
                          "synthetic CIFAR-shaped images through DataLoader -> DeviceBatchPipeline -> captured step (+ ragged tail); "
                          "prints its own JSON line (images/s of the whole epoch, next to the resident-batch rate of the same job)")
     ap.add_argument("--epoch-images", type=int, default=50000)
+    ap.add_argument("--no-other-model", action="store_true",
+                    help="do not time the other model class beside the headline (profiler passes: every launch of the run is then "
+                         "one of the 3 warm-up + 2 + K replayed + K eager steps the counters are divided by)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pmc-traffic", default=None,
                     help="PMC summary (tools/pmc_summary.py --json) to quote for traffic / executed flops instead of the "
@@ -441,33 +444,43 @@ def main():
     gpu_ms = mod.event_elapsed_ms(e0, e1)
     final_loss = float(loss.numpy()[0])
 
-    # the exchange step by itself (data parallel, or DF_FORCE_COMM=1 DF_FORCE_SYNC=1 on one GPU): K x (all-reduce of the bucket
-    # the backward kernels wrote + optimizer) against K x optimizer, stream events around each loop
-    exchange_us = optimizer_us = None
-    if sync is not None:
-        def timed_loop(fn):
-            a, b = mod.event(), mod.event()
-            mod.synchronize()
-            mod.event_record(a)
-            for _ in range(args.steps):
-                fn()
-            mod.event_record(b)
-            mod.synchronize()
-            return mod.event_elapsed_ms(a, b) * 1e3 / args.steps
-        if captured is not None:
-            opt.device_hyper = False
-        def exch():
-            sync()
-            opt.step()
-        exchange_us = timed_loop(exch)
-        optimizer_us = timed_loop(opt.step)
-        if captured is not None:
-            opt.device_hyper = True
+    # what the exchange costs inside the step (data parallel, or DF_FORCE_COMM=1 DF_FORCE_SYNC=1 on one GPU): the same job
+    # captured once more WITHOUT an exchange (a twin model, gradients in arrays of their own) and replayed K times, against K
+    # more replays of the step with it -- same process, same box, back to back
+    exchange_us = None
+    if sync is not None and captured is not None and comm.world == 1:
+        try:
+            from deepflows_amd.graph_step import CapturedTrainStep
+
+            def replays(cs):
+                for _ in range(2):
+                    cs.replay()
+                mod.synchronize()
+                t = time.perf_counter()
+                for _ in range(args.steps):
+                    cs.replay()
+                mod.synchronize()
+                return (time.perf_counter() - t) * 1e6 / args.steps
+            with_us = replays(captured)
+            m2, o2, c2, x2, y2 = build_job(args.workload, dev, rank, batch, register_blocks=(args.registration == "all"),
+                                           model_kind=args.model)
+            for p2 in o2.params:
+                p2.grad_slot = None
+            for _ in range(2):
+                workloads.train_step(m2, c2, o2, x2, y2)
+                Graph.free_graph()
+            cap2 = CapturedTrainStep(m2, c2, o2, x2, y2)
+            without_us = replays(cap2)
+            exchange_us = with_us - without_us
+            cap2.destroy()
+            del m2, o2, cap2
+        except Exception as e:
+            print(f"[bench] the step without the exchange was not timed ({type(e).__name__}: {e})", file=sys.stderr)
 
     # the OTHER way of writing the model (see build_job), same job, same K replays: reported beside the headline
     other_kind = "fused" if args.model == "plain" else "plain"
     other_value = None
-    if args.workload == "resnet18" and comm.world == 1 and sync is None and captured is not None:
+    if args.workload == "resnet18" and comm.world == 1 and sync is None and captured is not None and not args.no_other_model:
         try:
             from deepflows_amd.graph_step import CapturedTrainStep
             m2, o2, c2, x2, y2 = build_job(args.workload, dev, rank, batch, register_blocks=(args.registration == "all"),
@@ -569,11 +582,12 @@ def main():
                        "conv_dgrad": args.dgrad, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,
                        "allreduce_elems": exchanged,
                        # the exchange step: inside the captured graph or enqueued behind it; gradients the last sync() had to
-                       # copy into the bucket (0: every backward kernel wrote its gradient in place); its time by itself
+                       # copy into the bucket (0: every backward kernel wrote its gradient in place)
                        "exchange_captured": getattr(captured, "exchange_captured", None) if sync is not None else None,
                        "exchange_fallback_reason": getattr(captured, "exchange_fallback_reason", None) if sync is not None else None,
                        "grads_copied_into_bucket": bucket.packed_last if sync is not None else None,
-                       "exchange_us": exchange_us, "optimizer_us": optimizer_us,
+                       # (world 1 only: replayed step with the exchange minus replayed step without, microseconds)
+                       "exchange_us_in_graph": exchange_us,
                        # what the communicator itself reports (ncclCommCount), not the launcher's environment
                        "rccl_ranks": rccl_ranks,
                        "collective_library": mod.comm_rccl_path() if sync is not None else None},

@@ -231,7 +231,14 @@ class _ReLUFused(_FusedNode):
         return out
 
 
+_lazy_relu = None           # nn/lazy.py: relu of a recorded call (relu(fc(x)), relu(bn(conv(x)))) extends or completes the record
+
+
 def relu(input: Tensor) -> Tensor:
+    if _lazy_relu is not None:
+        out = _lazy_relu(input)
+        if out is not None:
+            return out
     input = realize(input)
     if _fused(input):
         return _ReLUFused(input)

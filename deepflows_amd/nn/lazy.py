@@ -23,7 +23,8 @@ Recorded forms (x0 a real tensor):
     conv(bn(conv(..)))                         "conv" over "bn"
     relu(bn(conv(x0)))                         "relu"
     mean(x0, axis=2), mean(mean(x0, 2), 2)     "mean2", "meanhw"
-Completing calls: MaxPool2d(relu(bn(conv(x0)))), bn(conv(bn(conv(x0)))) + identity, Linear(meanhw(x0)).
+    fc(x0), x0 two-dimensional                 "linear"
+Completing calls: MaxPool2d(relu(bn(conv(x0)))), bn(conv(bn(conv(x0)))) + identity, Linear(meanhw(x0)), F.relu(fc(x0)).
 DF_LAZY_MODULES=0 switches the mechanism off (every module call launches its own node, as before)."""
 import os
 import weakref
@@ -85,9 +86,14 @@ def _conv_of_real(x):
 
 
 def relu(x):
-    """ReLU.forward on a deferred bn(conv(x0)); None = not that form"""
+    """F.relu / ReLU.forward on a recorded call: relu(bn(conv(x0))) stays recorded (a pooling layer may complete the stem);
+    relu(fc(x0)) is one node (test/MLP_MNIST_cuda.py:51-52 `F.relu(self.fc1(x))`); None = not such a form"""
     if _is(x, "bn") and _conv_of_real(_input(x)):
         return LazyTensor("relu", x)
+    if _is(x, "linear"):
+        st = _state(x)
+        # (the recorded fc(x) itself stays recorded: whoever still holds it and touches it later launches the plain Linear)
+        return F.linear_relu(realize(st[1]), st[2].weight, st[2].bias)
     return None
 
 
@@ -109,10 +115,15 @@ def max_pool2d(module, x):
 
 
 def linear(module, x):
-    """Linear.forward on mean(mean(x0, 2), 2): the classifier head as one node; None = not that form"""
-    if not _is(x, "meanhw"):
-        return None
-    return F.mean_hw_linear(realize(_state(x)[1]), module)
+    """Linear.forward: on mean(mean(x0, 2), 2) the classifier head as one node; on a 2-D tensor of a fused device the call is
+    recorded (an F.relu may follow: one node for both); None = the module launches F.linear"""
+    if _is(x, "meanhw"):
+        return F.mean_hw_linear(realize(_state(x)[1]), module)
+    if ENABLED and is_grad_enable() and _state(x) is None:
+        xr = realize(x)
+        if isinstance(xr, Tensor) and F._fused(xr) and len(xr.shape) == 2 and hasattr(xr.device.mod, "linear_relu_forward"):
+            return LazyTensor("linear", xr, module)
+    return None
 
 
 # ---- hooks of tensor.py ------------------------------------------------------------------------------------------------
@@ -142,6 +153,8 @@ def _force(lz):
         return F.conv2d(xr, module.weight, module.padding, module.stride, bias=module.bias)
     if op == "bn":
         return module.forward(realize(x))
+    if op == "linear":
+        return F.linear(realize(x), module.weight, module.bias)
     if op == "relu":
         return F.relu(realize(x))
     if op == "mean2":
@@ -209,3 +222,4 @@ def _block_tail(out_l, identity):
 
 
 tensor._lazy_hooks.update({"force": _force, "add": _add, "mean": _mean})
+F._lazy_relu = relu

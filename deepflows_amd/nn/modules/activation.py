@@ -9,8 +9,7 @@ __all__ = ['ReLU', 'Tanh', 'LeakyReLU', 'Softmax', 'LogSoftmax']
 
 class ReLU(Module):
     def forward(self, input):
-        deferred = lazy.relu(input)                    # (relu(bn(conv(x))) in front of a pooling layer: the stem, nn/lazy.py)
-        return deferred if deferred is not None else F.relu(lazy.realize(input))
+        return F.relu(input)                           # (on a recorded call F.relu extends / completes the record: nn/lazy.py)
 
 
 class Tanh(Module):

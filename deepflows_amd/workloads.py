@@ -43,12 +43,12 @@ class MLP(nn.Module):
             setattr(self, f"fc{i + 1}", nn.Linear(sizes[i], sizes[i + 1], device=device))
 
     def forward(self, x):
+        # test/MLP_MNIST_cuda.py:51-54: `x = F.relu(self.fc1(x)) ... x = self.fc3(x)` -- on the hip device relu(fc(x)) becomes one
+        # node inside the modules (nn/lazy.py)
         for i in range(self.n_layers):
-            fc = getattr(self, f"fc{i + 1}")
+            x = getattr(self, f"fc{i + 1}")(x)
             if i + 1 < self.n_layers:
-                x = nn.functional.linear_relu(x, fc.weight, fc.bias)     # relu(fc(x)): one node on the hip device
-            else:
-                x = fc(x)
+                x = nn.functional.relu(x)
         return x
 
 
@@ -71,22 +71,27 @@ class CIFAR10_CNN(nn.Module):
         self.fc = nn.Linear(128 * 4 * 4, num_classes, device=device)
 
     def forward(self, x):
-        for conv, bn, relu, pool in ((self.conv1, self.bn1, self.relu1, self.pool1),
-                                     (self.conv2, self.bn2, self.relu2, self.pool2),
-                                     (self.conv3, self.bn3, self.relu3, self.pool3)):
-            if conv is self.conv1:
-                stem = nn.functional.stem_conv_bn_relu_pool_train(x, conv, bn, pool)
-                if stem is not None:               # one node, the 33 MB output of the first convolution never exists
-                    x = stem
-                    continue
-            x = realize(conv(x))
-            if nn.functional.bn_relu_maxpool2_fusable(x, bn, pool):
-                x = nn.functional.bn_relu_maxpool2_train(x, bn)     # pool(relu(bn(x))) as one node on the hip device
-            else:
-                x = pool(relu(bn(x)))
+        # the script's text (test/CNN_CIFAR10_cuda.py:86-108); on the hip device the modules record their calls and launch
+        # pool(relu(bn(conv(x)))) as the stem node / the fused BatchNorm-ReLU-pool node (nn/lazy.py)
+        x = self.conv1(x)
+        x = self.bn1(x)
+        x = self.relu1(x)
+        x = self.pool1(x)
+
+        x = self.conv2(x)
+        x = self.bn2(x)
+        x = self.relu2(x)
+        x = self.pool2(x)
+
+        x = self.conv3(x)
+        x = self.bn3(x)
+        x = self.relu3(x)
+        x = self.pool3(x)
+
         x = x.reshape(x.shape[0], -1)
         x = self.drop(x)
-        return self.fc(x)
+        x = self.fc(x)
+        return x
 
 
 class ResidualBlock(nn.Module):

@@ -200,5 +200,5 @@ def test_bench_exchange_path_runs_on_one_gpu():
     # round 4: the exchange is part of the captured graph, the gradients are formed in the bucket, its time is reported
     assert d["config"]["exchange_captured"] is True, d["config"]["exchange_fallback_reason"]
     assert d["config"]["grads_copied_into_bucket"] == 0
-    assert d["config"]["exchange_us"] > 0 and d["config"]["optimizer_us"] > 0
-    print("exchange step at world 1: %.1f us (optimizer alone %.1f us)" % (d["config"]["exchange_us"], d["config"]["optimizer_us"]))
+    assert d["config"]["exchange_us_in_graph"] is not None and d["config"]["exchange_us_in_graph"] < 25.0
+    print("exchange at world 1 inside the captured step: %+.1f us per step" % d["config"]["exchange_us_in_graph"])

@@ -17,7 +17,7 @@ N=$((3 + 2 + STEPS + STEPS))
 one() {   # one <suffix> <workload> <dgrad> [extra bench args]
   local sfx=$1 wl=$2 dg=$3; shift 3
   local extra="$*"
-  local CMD="python3 bench.py --workload $wl --dgrad $dg --steps $STEPS --warmup 3 --no-cpu-baseline --no-prof-gate"
+  local CMD="python3 bench.py --workload $wl --dgrad $dg --steps $STEPS --warmup 3 --no-cpu-baseline --no-prof-gate --no-other-model"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch$sfx -o p -- $CMD > $OUT/pmc_fetch$sfx.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write$sfx -o p -- $CMD > $OUT/pmc_write$sfx.log 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $OUT/pmc_sq$sfx -o p -- $CMD > $OUT/pmc_sq$sfx.log 2>&1
@@ -42,7 +42,7 @@ has cnn && one _cnn cnn overwrite
 if has rest; then
 python3 bench.py --workload mlp --steps 200 --warmup 20 > $OUT/bench_mlp.json 2> $OUT/bench_mlp.err
 python3 bench.py --workload resnet18_wide --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_wide.json 2> $OUT/bench_wide.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_wide -o s -- python3 bench.py --workload resnet18_wide --steps 5 --warmup 2 --no-cpu-baseline --no-prof-gate > $OUT/stats_wide.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_wide -o s -- python3 bench.py --workload resnet18_wide --steps 5 --warmup 2 --no-cpu-baseline --no-prof-gate --no-other-model > $OUT/stats_wide.log 2>&1
 f=$(find $OUT/stats_wide -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python3 tools/kernel_stats_txt.py $f > $OUT/rocprof_kernel_stats_wide.txt; rm -rf $OUT/stats_wide
 fi
 has headline && python3 tools/roofline_table.py $OUT/bench.json > $OUT/roofline_table.md 2>/dev/null

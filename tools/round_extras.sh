@@ -2,7 +2,7 @@
 # The round's measurements that are not part of tools/profile_round.sh (run on the GPU box through gpurun, after it):
 #   soak.json            5 000 replays of the captured headline step, clock probe before / after (tools/soak.py)
 #   exchange_world1.json bench.py with the exchange path forced on one GPU (RCCL communicator of one rank): exchange_captured,
-#                        grads_copied_into_bucket, exchange_us, optimizer_us
+#                        grads_copied_into_bucket, exchange_us_in_graph
 #   epoch.json           bench.py --epoch: 50 000 images through DataLoader + device input pipeline + captured step
 #   bn_bwd_bench.txt     the input-gradient kernels with / without the BatchNorm-backward forms (tools/bn_bwd_bench.py)
 #   usage: tools/round_extras.sh <tag>
@@ -21,5 +21,5 @@ cut -c1-250 $OUT/bench.json 2>/dev/null
 cut -c1-700 $OUT/soak.json
 python3 -c "
 import json,sys
-d=json.loads(open('$OUT/exchange_world1.json').read().strip().split(chr(10))[-1]); print('exchange world 1:', d['ms_per_step'], {k: d['config'][k] for k in ('exchange_captured','grads_copied_into_bucket','exchange_us','optimizer_us','rccl_ranks')})"
+d=json.loads(open('$OUT/exchange_world1.json').read().strip().split(chr(10))[-1]); print('exchange world 1:', d['ms_per_step'], {k: d['config'][k] for k in ('exchange_captured','grads_copied_into_bucket','exchange_us_in_graph','rccl_ranks')})"
 cut -c1-420 $OUT/epoch.json
