@@ -5,8 +5,6 @@ the reference) with the same operation order; scalars are rounded to fp32 where 
 reference's NumPy device rounds them."""
 import os
 
-import os
-
 from .. import backend_api
 from .optimizer import Optimizer
 

@@ -26,7 +26,7 @@ OVERWRITE = [
     ("DFHIP_XCD_ORDER", "1"), ("DFHIP_BN_BWD_FUSED", "0"), ("DF_BN_BWD_FUSED", "0"), ("DF_BN_BWD_PAIR", "1"),
     ("DF_LAZY_MODULES", "0"), ("DF_LINEAR_RELU", "0"), ("DFHIP_MASK_BYTES", "0"), ("DF_S2_PAIR", "0"),
     ("DF_CONV_BN_STATS", "0"), ("DF_HEAD_FUSED", "0"), ("DF_WGRAD_GROUP", "0"), ("DF_BN_INPUT", "0"),
-    ("DF_STEM_FUSED_BWD", "0"),
+    ("DF_STEM_FUSED_BWD", "0"), ("DFHIP_DGRAD_BN_NW8", "0"), ("DF_GRAD_IN_BUCKET", "0"),
 ]
 ACCUMULATE = [("DFHIP_DGRAD_IMG2_ACC", "0"), ("DFHIP_DGRAD_S2_ACC", "0"), ("DFHIP_WGRAD_DIRECT", "0")]
 
