@@ -7,6 +7,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "dfhip_bnbwd.h"
 
@@ -491,14 +492,18 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__
 // GEO 2: the GEO 1 pattern on one 4 x 4 block (blockIdx.z) of an 8 x 8 image whose dY is 4 x 4 (layer3's first
 // block: 256 workgroups where whole images would give 64).  TR: the dY planes are requested in memory order and turned
 // into the image-per-lane order through a wave-private LDS strip (see the operand section below).
+// HS 2 (GEO 0 / 1): blockIdx.z selects image rows 2 z, 2 z + 1 -- eight accumulators per lane, twice the workgroups (the
+// 128-channel layers gave 128 workgroups of four waves: half the CUs had nothing, the other half one wave per SIMD);
+// a pixel's products are added in the same order either way.
 constexpr int kImg4Strip = 16 * 260;     // floats of a wave's transposition strip (16 images x (256 + 4))
-template <int O, int GEO, bool PAIR, bool TR>
+template <int O, int GEO, bool PAIR, bool TR, int HS = 1>
 __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__ dy, const float* __restrict__ w,
                                                        const float* __restrict__ add, float* __restrict__ dx, int C,
                                                        const float* __restrict__ dy2, const float* __restrict__ w2, int S,
                                                        int xo) {
   static_assert(!PAIR || GEO >= 1, "the shortcut rides on the stride-2 forms");
   static_assert(GEO != 2 || TR, "the sub-image form reads its planes through the strip");
+  static_assert(HS == 1 || (HS == 2 && GEO != 2), "row halves: whole 4 x 4 images only");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int OQ = O / 4, NK = OQ / 4;             // o per wave, MFMA k-steps per wave
@@ -663,56 +668,66 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
     }
   }
   __syncthreads();
-  f32x4 acc[16];
+  constexpr int NY = HS == 2 ? 2 : 4, NQ = NY * 4;  // image rows / pixels of this workgroup
+  const int hz = HS == 2 ? (int)blockIdx.z : 0;
+  f32x4 acc[NQ];
 #pragma unroll
-  for (int q = 0; q < 16; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int p = 0; p < NK; p++) {
-    float a[NSL];
-#pragma unroll
-    for (int q = 0; q < NSL; q++) a[q] = Wl[(q * O + ob + 4 * p + kk) * 16 + n];
-#pragma unroll
-    for (int y = 0; y < 4; y++)
-#pragma unroll
-      for (int x = 0; x < 4; x++) {
-        int u, v, cls;
-        if (GEO == 0) { u = y >= 1 ? y - 1 : 0; v = x >= 1 ? x - 1 : 0; cls = (y >= 1 ? 2 : 0) + (x >= 1 ? 1 : 0); }
-        else { u = y >> 1; v = x >> 1; cls = ((y & 1) << 1) + (x & 1); }
-        acc[y * 4 + x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cls], sv[p][u * SW + v], acc[y * 4 + x], 0, 0, 0);
-      }
-  }
-  if constexpr (PAIR) {
-    // the shortcut's gradient: pixel (2u, 2v) <- dY2[u][v]
+  for (int q = 0; q < NQ; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto products = [&](auto y0c) {
+    constexpr int Y0 = decltype(y0c)::value;        // first image row of the workgroup
 #pragma unroll
     for (int p = 0; p < NK; p++) {
-      const float a5 = Wl[(4 * O + ob + 4 * p + kk) * 16 + n];
+      float a[NSL];
 #pragma unroll
-      for (int u = 0; u < 2; u++)
+      for (int q = 0; q < NSL; q++) a[q] = Wl[(q * O + ob + 4 * p + kk) * 16 + n];
 #pragma unroll
-        for (int v = 0; v < 2; v++)
-          acc[(2 * u) * 4 + 2 * v] = __builtin_amdgcn_mfma_f32_16x16x4f32(a5, sv2[p][u * 2 + v], acc[(2 * u) * 4 + 2 * v], 0, 0, 0);
+      for (int yy = 0; yy < NY; yy++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+          const int y = Y0 + yy;
+          int u, v, cls;
+          if (GEO == 0) { u = y >= 1 ? y - 1 : 0; v = x >= 1 ? x - 1 : 0; cls = (y >= 1 ? 2 : 0) + (x >= 1 ? 1 : 0); }
+          else { u = y >> 1; v = x >> 1; cls = ((y & 1) << 1) + (x & 1); }
+          acc[yy * 4 + x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cls], sv[p][u * SW + v], acc[yy * 4 + x], 0, 0, 0);
+        }
     }
-  }
+    if constexpr (PAIR) {
+      // the shortcut's gradient: pixel (2u, 2v) <- dY2[u][v]
+#pragma unroll
+      for (int p = 0; p < NK; p++) {
+        const float a5 = Wl[(4 * O + ob + 4 * p + kk) * 16 + n];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+          for (int v = 0; v < 2; v++)
+            if (2 * u >= Y0 && 2 * u < Y0 + NY)
+              acc[(2 * u - Y0) * 4 + 2 * v] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(a5, sv2[p][u * 2 + v], acc[(2 * u - Y0) * 4 + 2 * v], 0, 0, 0);
+      }
+    }
+  };
+  if (HS == 2 && hz == 1) products(std::integral_constant<int, 2>{});
+  else products(std::integral_constant<int, 0>{});
   __syncthreads();                                  // the weight image is dead: it becomes the exchange area
   f32x4* ex = reinterpret_cast<f32x4*>(smem);
   if (wave > 0) {
 #pragma unroll
-    for (int q = 0; q < 16; q++) ex[((wave - 1) * 16 + q) * 64 + lane] = acc[q];
+    for (int q = 0; q < NQ; q++) ex[((wave - 1) * NQ + q) * 64 + lane] = acc[q];
   }
   __syncthreads();
   if (wave == 0) {
 #pragma unroll
     for (int ww = 0; ww < 3; ww++)
 #pragma unroll
-      for (int q = 0; q < 16; q++) acc[q] += ex[(ww * 16 + q) * 64 + lane];
+      for (int q = 0; q < NQ; q++) acc[q] += ex[(ww * NQ + q) * 64 + lane];
     // register v of lane (kk, n) is channel c0 + 4 kk + v of image n0 + n; its sixteen pixels are adjacent
     // (GEO 2: rows of the block are S floats apart in an S x S plane)
     const int rowp = GEO == 2 ? S : 4, plane = GEO == 2 ? S * S : 16;
-    const int64_t obase = ((int64_t)(n0 + n) * C + c0 + 4 * kk) * plane + (GEO == 2 ? 4 * qy * S + 4 * qx : 0);
+    const int64_t obase = ((int64_t)(n0 + n) * C + c0 + 4 * kk) * plane + (GEO == 2 ? 4 * qy * S + 4 * qx : 0) + 8 * hz;
 #pragma unroll
     for (int v = 0; v < 4; v++)
 #pragma unroll
-      for (int y = 0; y < 4; y++) {
+      for (int y = 0; y < NY; y++) {
         f32x4 r = {acc[y * 4][v], acc[y * 4 + 1][v], acc[y * 4 + 2][v], acc[y * 4 + 3][v]};
         if (add) r += *reinterpret_cast<const f32x4*>(add + obase + (int64_t)plane * v + rowp * y);
         *reinterpret_cast<f32x4*>(dx + obase + (int64_t)plane * v + rowp * y) = r;
@@ -724,8 +739,11 @@ template <int O, int GEO, bool PAIR>
 int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* dx, int N, int C, const float* dy2,
                       const float* w2, int S = 4) {
   static int tr_env = getenv("DFHIP_IMG4_TR") ? atoi(getenv("DFHIP_IMG4_TR")) : 1;
+  static int halves_env = getenv("DFHIP_IMG4_HALVES") ? atoi(getenv("DFHIP_IMG4_HALVES")) : 1;
   const int tr = GEO == 2 ? 1 : tr_env;
-  dim3 grid((unsigned)(N / 16), (unsigned)(C / 16), (unsigned)(GEO == 2 ? (S / 4) * (S / 4) : 1));
+  // whole images give (N / 16) x (C / 16) workgroups: where that leaves CUs without one, a workgroup takes two image rows
+  const bool halves = GEO != 2 && tr && halves_env && (N / 16) * (C / 16) < num_cus();
+  dim3 grid((unsigned)(N / 16), (unsigned)(C / 16), (unsigned)(GEO == 2 ? (S / 4) * (S / 4) : (halves ? 2 : 1)));
   const size_t base = std::max((size_t)(PAIR ? 5 : 4) * O * 16, (size_t)3 * 16 * 64 * 4) * sizeof(float);
   const size_t lds = base + (tr ? (size_t)4 * kImg4Strip * sizeof(float) : 0);
   // blockIdx.y selects 16 input channels' weight columns (NSL slices x O), blockIdx.x 16 images of dY
@@ -735,15 +753,19 @@ int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* 
   if (!attr) {
     DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)std::max(base + (size_t)4 * kImg4Strip * sizeof(float), (size_t)65536)));
-    if constexpr (GEO != 2)
+    if constexpr (GEO != 2) {
       DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)std::max(base, (size_t)65536)));
+      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)std::max(base + (size_t)4 * kImg4Strip * sizeof(float), (size_t)65536)));
+    }
     attr = true;
   }
   if constexpr (GEO == 2) {
     DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
   } else {
-    if (tr) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
+    if (halves) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true, 2>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
+    else if (tr) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
     else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, false>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
   }
   DF_LAUNCH_CHECK();
