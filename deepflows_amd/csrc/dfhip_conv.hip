@@ -4946,9 +4946,17 @@ int dfhip_conv2d_forward_bn_input(const float* x, const float* partials_in, int 
   int rows = 0;
   if (run_conv_rowmma(x, w, bias, y, N, C, H, W, O, k, stride, pad, want ? partials : nullptr, cap_rows, &rows, &bn, true) < 0)
     return DFHIP_OK;
-  int st = bn_finalize_partials(bn, C);
-  if (st < 0) return DFHIP_OK;
-  if (st != DFHIP_OK) return st;
+  // the (scale, shift) table: built by every workgroup of the convolution from the producer's rows (the register-operand
+  // kernels: the rows are requested in front of the weights; the image-per-lane kernel of the 4 x 4 layers: every wave
+  // for its own sixteen channels), or by a launch of its own (DFHIP_BN_INPUT_COMBINE=0)
+  static int combine_env = getenv("DFHIP_BN_INPUT_COMBINE") ? atoi(getenv("DFHIP_BN_INPUT_COMBINE")) : 1;
+  bn.combine = combine_env && rows_in >= 1 ? 1 : 0;
+  int st = DFHIP_OK;
+  if (!bn.combine) {
+    st = bn_finalize_partials(bn, C);
+    if (st < 0) return DFHIP_OK;
+    if (st != DFHIP_OK) return st;
+  }
   ProfScope prof("conv2d_fwd_igemm", flops, bytes);
   st = run_conv_rowmma(x, w, bias, y, N, C, H, W, O, k, stride, pad, want ? partials : nullptr, cap_rows, &rows, &bn);
   if (st < 0) {

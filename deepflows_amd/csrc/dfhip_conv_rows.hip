@@ -94,6 +94,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   extern __shared__ __attribute__((aligned(16))) float Wl[];   // [OW][C/4*9/4 blocks][64 lanes][4] at pitch kBlk
   __shared__ float sred[8][16][2];
   __shared__ __attribute__((aligned(8))) float bn_tab[BNI ? C : 1][2];
+  __shared__ float bn_acc[BNI ? 512 / C : 1][BNI ? C : 1][3];
   constexpr int W = 1 << LW;
   constexpr int NG = C / 4;                    // channel groups (one MFMA k-step each)
   constexpr int NCH = NG / CG;                 // weight chunks
@@ -111,9 +112,31 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   RS_STAMP(0);
   // ---- BNI: the (scale, shift) pair of this thread's channel is requested first (dfhip_bn2d_finalize_partials wrote
   // the table from the producer's partials) ----
+  // bn.combine: there was no such launch -- every workgroup adds the producer's rows up for itself (thread = a channel
+  // x a sixteenth / an eighth of the rows, 12-byte loads requested here, in front of the weights; the shifted sums of
+  // k_bn_finalize_partials, combined through LDS in a fixed order), workgroup (0, 0) leaves the table, the batch
+  // statistics and the running statistics behind for the backward pass.
   f32x2 bn_pair = {1.0f, 0.0f};
+  constexpr int BNG = 512 / C, BRP = 16;            // row groups; rows per thread and pass
+  f32x3u bn_row[BNI ? BRP : 1];
+  float bn_shift = 0.0f, bn_g = 1.0f, bn_b = 0.0f, bn_rm = 0.0f, bn_rv = 0.0f;
+  const int bn_c = tid % C, bn_gr = tid / C;
   if constexpr (BNI) {
-    if (tid < C) bn_pair = *reinterpret_cast<const f32x2*>(bn.affine + 2 * tid);
+    if (bn.combine) {
+      const float* pc = bn.part + bn_c * 3;
+#pragma unroll
+      for (int k2 = 0; k2 < BRP; k2++)
+        bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(bn_gr + BNG * k2, bn.rows - 1) * (C * 3));
+      bn_shift = pc[1];                               // row 0's mean
+      if (tid < C) {
+        if (bn.gamma) bn_g = bn.gamma[tid];
+        if (bn.beta) bn_b = bn.beta[tid];
+        if (bn.running_mean) bn_rm = bn.running_mean[tid];
+        if (bn.running_var) bn_rv = bn.running_var[tid];
+      }
+    } else {
+      if (tid < C) bn_pair = *reinterpret_cast<const f32x2*>(bn.affine + 2 * tid);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -241,8 +264,32 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   for (int c0 = 0; c0 < XA && c0 < NCH; c0++) RM_XLOAD(c0);
   RS_STAMP(1);
   if constexpr (BNI) {
-    if (tid < C) { bn_tab[tid][0] = bn_pair[0]; bn_tab[tid][1] = bn_pair[1]; }
-    // (the table becomes visible with the barrier behind the first weight commit)
+    if (bn.combine) {
+      float tn = 0.0f, t1 = 0.0f, t2 = 0.0f;
+      auto add_rows = [&](int r0) {
+#pragma unroll
+        for (int k2 = 0; k2 < BRP; k2++) {
+          const bool in = r0 + bn_gr + BNG * k2 < bn.rows;
+          const float nb = in ? bn_row[k2][0] : 0.0f, d = nb > 0.0f ? bn_row[k2][1] - bn_shift : 0.0f;
+          tn += nb;
+          t1 = fmaf(nb, d, t1);
+          t2 += fmaf(nb * d, d, in ? bn_row[k2][2] : 0.0f);
+        }
+      };
+      add_rows(0);
+      for (int r0 = BNG * BRP; r0 < bn.rows; r0 += BNG * BRP) {     // (more rows than one pass holds: uniform, rare)
+        const float* pc = bn.part + bn_c * 3;
+#pragma unroll
+        for (int k2 = 0; k2 < BRP; k2++)
+          bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(r0 + bn_gr + BNG * k2, bn.rows - 1) * (C * 3));
+        add_rows(r0);
+      }
+      bn_acc[bn_gr][bn_c][0] = tn; bn_acc[bn_gr][bn_c][1] = t1; bn_acc[bn_gr][bn_c][2] = t2;
+      // (summed per channel behind the barrier of the first weight commit; a second barrier publishes the table)
+    } else {
+      if (tid < C) { bn_tab[tid][0] = bn_pair[0]; bn_tab[tid][1] = bn_pair[1]; }
+      // (the table becomes visible with the barrier behind the first weight commit)
+    }
   }
   RM_WCOMMIT(0);
   RS_STAMP(2);
@@ -262,6 +309,31 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   f32x4 a4[2][CBLK];                                       // weight operands of two chunks: CG groups x 9 taps each
 #pragma unroll
   for (int q = 0; q < CBLK; q++) a4[0][q] = Wl4[q * (kBlk / 4)];
+  if constexpr (BNI) {
+    if (bn.combine) {
+      if (tid < C) {
+        float n = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+        for (int g2 = 0; g2 < BNG; g2++) { n += bn_acc[g2][tid][0]; a1 += bn_acc[g2][tid][1]; a2 += bn_acc[g2][tid][2]; }
+        const float mu_s = n > 0.0f ? a1 / n : 0.0f;
+        const float mu = bn_shift + mu_s;
+        const float var = n > 0.0f ? fmaxf(a2 - a1 * mu_s, 0.0f) / n : 0.0f;          // biased variance (batchnorm.py:41-42)
+        const float rsd = 1.0f / sqrtf(var + bn.eps);
+        bn_pair[0] = bn_g * rsd;
+        bn_pair[1] = bn_b - mu * bn_pair[0];
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+          if (bn.save_mean) bn.save_mean[tid] = mu;
+          if (bn.save_var) bn.save_var[tid] = var;
+          if (bn.running_mean) bn.running_mean[tid] = bn_rm * (1.0f - bn.momentum) + mu * bn.momentum;
+          if (bn.running_var) bn.running_var[tid] = bn_rv * (1.0f - bn.momentum) + var * bn.momentum;
+          bn.affine[2 * tid] = bn_pair[0];
+          bn.affine[2 * tid + 1] = bn_pair[1];
+        }
+      }
+      if (tid < C) { bn_tab[tid][0] = bn_pair[0]; bn_tab[tid][1] = bn_pair[1]; }
+      __syncthreads();
+    }
+  }
   float bsh[2][NT][3][3];
   auto make_shifts = [&](float (&b)[NT][3][3], const float (&rw)[NL]) {
 #pragma unroll
@@ -546,12 +618,13 @@ __device__ __forceinline__ void img4_fwd_mfmas(const float (&a)[9], const f32x4 
         }
 }
 
-template <int C>
+template <int C, bool COMB>
 __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           float* __restrict__ stats, int O,
-                                                          const float* __restrict__ aff, int xo) {
+                                                          const float* __restrict__ aff, int xo, BnInput bn) {
   constexpr int CW = C / 8, NCHK = CW / 8, WP = 17, XP = 33;      // XP: float4 pitch of an image's strip row
+  static_assert(CW == 16, "a wave's channels are one DPP row of the combine below");
   constexpr int WSL = 72 * WP + 16 * XP * 4;                       // floats of a wave's area
   extern __shared__ __attribute__((aligned(16))) float smem_i4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -578,7 +651,69 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
   f32x4 acc[8];
 #pragma unroll
   for (int q = 0; q < 8; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // aff && bn.combine: no launch has turned the producer's rows into the (scale, shift) table -- a wave needs the
+  // pairs of its own sixteen channels only: lane (g, c) adds up rows g, g + 4, ... of channel cb + c (requested in
+  // front of the first chunk), the four groups meet through two lane exchanges, and the operand lanes fetch their
+  // channel's pair from lane c with a bpermute; no barrier, nothing through LDS.  Workgroup (0, 0, 0) leaves the
+  // table and the statistics behind for the backward pass.
+  constexpr int BRP = 8;
+  f32x3u bn_row[COMB ? BRP : 1];
+  float bn_shift = 0.0f, bn_g = 1.0f, bn_b = 0.0f, bn_rm = 0.0f, bn_rv = 0.0f;
+  constexpr bool combine = COMB;                  // (the launcher picks the build: aff && bn.combine)
+  if constexpr (combine) {
+    const float* pc = bn.part + (cb + n) * 3;
+#pragma unroll
+    for (int k2 = 0; k2 < BRP; k2++)
+      bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(kk + 4 * k2, bn.rows - 1) * (C * 3));
+    bn_shift = pc[1];
+    if (bn.gamma) bn_g = bn.gamma[cb + n];
+    if (bn.beta) bn_b = bn.beta[cb + n];
+    if (bn.running_mean) bn_rm = bn.running_mean[cb + n];
+    if (bn.running_var) bn_rv = bn.running_var[cb + n];
+    __builtin_amdgcn_sched_barrier(0);
+  }
   request(0);
+  f32x2 bn_pair = {1.0f, 0.0f};
+  if constexpr (combine) {
+    float tn = 0.0f, t1 = 0.0f, t2 = 0.0f;
+    auto add_rows = [&](int r0) {
+#pragma unroll
+      for (int k2 = 0; k2 < BRP; k2++) {
+        const bool in = r0 + kk + 4 * k2 < bn.rows;
+        const float nb = in ? bn_row[k2][0] : 0.0f, d = nb > 0.0f ? bn_row[k2][1] - bn_shift : 0.0f;
+        tn += nb;
+        t1 = fmaf(nb, d, t1);
+        t2 += fmaf(nb * d, d, in ? bn_row[k2][2] : 0.0f);
+      }
+    };
+    add_rows(0);
+    for (int r0 = 4 * BRP; r0 < bn.rows; r0 += 4 * BRP) {
+      const float* pc = bn.part + (cb + n) * 3;
+#pragma unroll
+      for (int k2 = 0; k2 < BRP; k2++)
+        bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(r0 + kk + 4 * k2, bn.rows - 1) * (C * 3));
+      add_rows(r0);
+    }
+    // groups 0 + 1 and 2 + 3, then the two sums: the same order in every lane
+    auto xlane = [&](float v, int m) { return __shfl_xor(v, m, 64); };
+    tn += xlane(tn, 16); t1 += xlane(t1, 16); t2 += xlane(t2, 16);
+    tn += xlane(tn, 32); t1 += xlane(t1, 32); t2 += xlane(t2, 32);
+    const float mu_s = tn > 0.0f ? t1 / tn : 0.0f;
+    const float mu = bn_shift + mu_s;
+    const float var = tn > 0.0f ? fmaxf(t2 - t1 * mu_s, 0.0f) / tn : 0.0f;            // biased variance (batchnorm.py:41-42)
+    const float rsd = 1.0f / sqrtf(var + bn.eps);
+    bn_pair[0] = bn_g * rsd;
+    bn_pair[1] = bn_b - mu * bn_pair[0];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && kk == 0) {
+      const int c = cb + n;
+      if (bn.save_mean) bn.save_mean[c] = mu;
+      if (bn.save_var) bn.save_var[c] = var;
+      if (bn.running_mean) bn.running_mean[c] = bn_rm * (1.0f - bn.momentum) + mu * bn.momentum;
+      if (bn.running_var) bn.running_var[c] = bn_rv * (1.0f - bn.momentum) + var * bn.momentum;
+      bn.affine[2 * c] = bn_pair[0];
+      bn.affine[2 * c + 1] = bn_pair[1];
+    }
+  }
 #pragma unroll
   for (int ch = 0; ch < NCHK; ch++) {
 #pragma unroll
@@ -617,7 +752,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
     if (aff) {
 #pragma unroll
       for (int p = 0; p < 2; p++) {
-        const f32x2 sc = *reinterpret_cast<const f32x2*>(aff + 2 * (c0 + 4 * p + kk));
+        f32x2 sc;
+        if constexpr (combine) {       // (every lane of the wave holds the pair of channel cb + (lane & 15))
+          sc[0] = __shfl(bn_pair[0], 8 * ch + 4 * p + kk, 64);
+          sc[1] = __shfl(bn_pair[1], 8 * ch + 4 * p + kk, 64);
+        } else {
+          sc = *reinterpret_cast<const f32x2*>(aff + 2 * (c0 + 4 * p + kk));
+        }
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
@@ -694,14 +835,19 @@ static int run_conv_img4_fwd(const float* x, const float* w, const float* bias, 
   const size_t lds = std::max((size_t)8 * (72 * 17 + 16 * 33 * 4), (size_t)7 * 8 * 64 * 4) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_img4_fwd<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_img4_fwd<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_img4_fwd<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
   // blockIdx.y selects 16 output channels' weights, blockIdx.x 16 images' planes (both halves of an image tile are
   // neighbours in z: they share the planes of the middle rows)
   const int xo = xcd_arrangement(N / 16, O / 16, 4.0 * N * C * 16, 4.0 * O * C * 9);
-  DF_LAUNCH(k_conv3x3_img4_fwd<128>, grid, dim3(512), lds, stream(), x, w, bias, y, partials, O,
-            bn ? (const float*)bn->affine : (const float*)nullptr, xo);
+  if (bn && bn->combine)
+    DF_LAUNCH((k_conv3x3_img4_fwd<128, true>), grid, dim3(512), lds, stream(), x, w, bias, y, partials, O,
+              (const float*)bn->affine, xo, *bn);
+  else
+    DF_LAUNCH((k_conv3x3_img4_fwd<128, false>), grid, dim3(512), lds, stream(), x, w, bias, y, partials, O,
+              bn ? (const float*)bn->affine : (const float*)nullptr, xo, BnInput{});
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }

@@ -62,6 +62,7 @@ struct BnInput {
   float* running_mean;         // C or nullptr: updated in place (batchnorm.py:44-52)
   float* running_var;
   float* affine;               // C x (scale, shift): y = x * scale + shift, for the weight gradient
+  int combine;                 // 1: no bn_finalize_partials launch has run -- the consuming kernel adds the rows up itself
 };
 
 // dfhip_fused.hip: bn.part -> bn.affine (+ save_mean / save_var / running statistics); -1 when there is nothing to combine
