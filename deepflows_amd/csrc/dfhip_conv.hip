@@ -30,6 +30,7 @@
 
 #include "dfhip_internal.h"
 #include "dfhip_bnbwd.h"
+#include "dfhip_stem_combine.h"
 
 using namespace dfhip;
 
@@ -2627,6 +2628,8 @@ struct SGroup {
   int n;
   int vb_end[kMaxGroup];
   SlabSum s[kMaxGroup];
+  int stem_blocks;              // the first workgroups of the launch: the stem's one-pass backward, last step (dfhip_stem_combine.h)
+  StemCombine stem;
 };
 
 // Row-unit weight gradient with the operands straight from global memory (grouped launches, channel
@@ -3106,7 +3109,13 @@ __device__ __forceinline__ void wgrad_group_sum_body(const SlabSum& d, const int
 
 __global__ __launch_bounds__(256) void k_wgrad_group_sum(SGroup a) {
   __shared__ float4 part[256 * 9];
-  const int b = blockIdx.x;
+  // (the stem's workgroups are a chain of dependent round trips over its 256 slabs: dispatched first, they run beside the
+  // streaming ones instead of behind them)
+  if ((int)blockIdx.x < a.stem_blocks) {             // (uniform per workgroup)
+    stem_combine_body(a.stem, (int)blockIdx.x);
+    return;
+  }
+  const int b = (int)blockIdx.x - a.stem_blocks;
   int li = 0;
   while (li + 1 < a.n && b >= a.vb_end[li]) li++;
   const SlabSum& d = a.s[li];
@@ -3822,6 +3831,7 @@ struct GQueued {
 };
 std::vector<GQueued> g_queue;
 bool g_group_on = false;
+struct StemPending { bool active = false; StemCombine c; int blocks = 0; } g_stem_pending;
 int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
                    int k, int stride, int pad, const float* aff = nullptr, const float* bnz = nullptr,
                    const float* bntab = nullptr);
@@ -4075,8 +4085,15 @@ int group_flush() {
       (void)hipEventDestroy(se0); (void)hipEventDestroy(se1);
     }
     {
+      // the stem's one-pass backward left its last step for this launch (on the library stream only: its totals were written there)
+      if (g_stem_pending.active && !g_group_stream && i0 + kMaxGroup >= q.size()) {
+        sg.stem = g_stem_pending.c;
+        sg.stem_blocks = g_stem_pending.blocks;
+        g_stem_pending.active = false;
+        sbytes += 4.0 * (double)sg.stem.splits * (2.0 * sg.stem.O * sg.stem.KK + 3.0 * sg.stem.O + sg.stem.KK);
+      }
       ProfScope prof("wgrad_slab_sum", 0.0, sbytes);
-      DF_LAUNCH(k_wgrad_group_sum, dim3((unsigned)vbs), dim3(256), 0, gst, sg);
+      DF_LAUNCH(k_wgrad_group_sum, dim3((unsigned)(vbs + sg.stem_blocks)), dim3(256), 0, gst, sg);
       DF_LAUNCH_CHECK();
     }
   }
@@ -4464,6 +4481,11 @@ int flush_deferred() {
     int st = group_flush();
     if (st != DFHIP_OK) return st;
   }
+  if (g_stem_pending.active) {                      // no grouped slab sum took it along
+    g_stem_pending.active = false;
+    int st = stem_combine_launch(g_stem_pending.c, g_stem_pending.blocks);
+    if (st != DFHIP_OK) return st;
+  }
   if (!g_side_pending.empty()) {
     int st = side_join();
     if (st != DFHIP_OK) return st;
@@ -4475,6 +4497,10 @@ int flush_deferred() {
 }
 bool deferred_touches(const void* p) {
   if (!p) return false;
+  if (g_stem_pending.active) {
+    const StemCombine& c = g_stem_pending.c;
+    if (p == c.dw || p == c.dgamma || p == c.dbeta || p == c.dbias || p == c.slabs) return true;
+  }
   for (const auto& sp : g_side_pending)              // a gradient in flight on the side stream: join first
     for (const auto& r : sp.dws)
       if ((const float*)p >= r.first && (const float*)p < r.second) return true;
@@ -4486,6 +4512,15 @@ bool deferred_touches(const void* p) {
   return q >= lo && q < lo + (int64_t)g_def.a.O * g_def.a.C * g_def.a.T;
 }
 int deferred_scratch_slot() { return g_def.active ? g_def.slot : -1; }
+bool group_collecting() { return g_group_on && !g_queue.empty() && !g_group_stream && g_side_pending.empty(); }
+bool stem_combine_pending() { return g_stem_pending.active; }
+bool stem_combine_defer(const StemCombine& c, int blocks) {
+  if (!group_collecting() || g_stem_pending.active) return false;
+  g_stem_pending.c = c;
+  g_stem_pending.blocks = blocks;
+  g_stem_pending.active = true;
+  return true;
+}
 }  // namespace dfhip
 
 extern "C" {

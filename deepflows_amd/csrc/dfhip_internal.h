@@ -48,6 +48,9 @@ float* workspace_small(size_t bytes);
 int flush_deferred();
 bool deferred_touches(const void* p);
 int deferred_scratch_slot();          // scratch slot holding the pending slabs, -1 if none
+bool group_collecting();              // between dfhip_wgrad_group_begin / _end with weight gradients queued on the library stream
+bool stem_combine_pending();          // the stem's one-pass backward left its last step to the group's slab sum (its totals
+                                      // live in the second scratch area until then; dfhip_stem_combine.h)
 
 // A training-mode BatchNorm2d standing between two convolutions, applied by the SECOND one on its operand loads
 // (dfhip_conv2d_forward_bn_input): the partials the first convolution left behind and where the by-products go.

@@ -209,6 +209,7 @@ static float* scratch(int i, size_t bytes) {
   // A scratch area is simply a pool block that is returned to the pool as soon as a
   // bigger one is needed; stream order makes the hand-over safe.
   if (deferred_scratch_slot() == i) (void)flush_deferred();   // its slabs live in this slot
+  if (i == 1 && stem_combine_pending()) (void)flush_deferred();   // the stem's totals live in this one
   bytes = (bytes + 255) & ~(size_t)255;
   ScratchSlot& s = g_ws[i];
   bool wrong_owner = false;

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "dfhip_internal.h"
+#include "dfhip_stem_combine.h"
 
 using namespace dfhip;
 
@@ -691,73 +692,9 @@ __global__ __launch_bounds__(256) void k_stem_slab_sum(const float* __restrict__
   }
 }
 
-// One-pass backward: totals over the workgroups' slabs (fixed order) and the weight gradient from them.  A block owns 32
-// consecutive elements (o, k) of dW; its 256 threads are 8 slab groups x 32 elements; every thread sums, over its
-// group's slabs, the five quantities its element needs: A[o][k], B[o][k], S[k], sum dy [o], sum dy xhat [o] (+ sum xhat).
-struct StemCombine {
-  const float* slabs;
-  const float* gamma;
-  const float* var;
-  float* dw;
-  float* dbias;
-  float* dgamma;
-  float* dbeta;
-  int O, KK, splits;
-  float m, eps;
-};
-__global__ __launch_bounds__(256) void k_stem_combine(StemCombine c) {
-  // eight elements of dW per block; a thread sums every 32nd slab of the six totals its element needs (A, B, the column sum
-  // and the three per-channel sums), all loads of a round in flight together; the 32 slab groups meet through the lanes and LDS.
-  __shared__ float part[4][6][8];
-  const int e = threadIdx.x & 7, sg = threadIdx.x >> 3;
-  const int n = c.O * c.KK, SL = 2 * n + 3 * c.O + c.KK;
-  const int i = min((int)blockIdx.x * 8 + e, n - 1);
-  const int o = i / c.KK, k = i - o * c.KK;
-  const int idx[6] = {i, n + i, 2 * n + 3 * c.O + k, 2 * n + 3 * o, 2 * n + 3 * o + 1, 2 * n + 3 * o + 2};
-  float t[6] = {0, 0, 0, 0, 0, 0};
-  for (int s0 = sg; s0 < c.splits; s0 += 256) {
-    float v[8][6];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const float* slab = c.slabs + (int64_t)min(s0 + 32 * u, c.splits - 1) * SL;
-#pragma unroll
-      for (int q = 0; q < 6; q++) v[u][q] = slab[idx[q]];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (s0 + 32 * u < c.splits) {
-#pragma unroll
-        for (int q = 0; q < 6; q++) t[q] += v[u][q];
-      }
-  }
-#pragma unroll
-  for (int q = 0; q < 6; q++) {
-    t[q] += __shfl_xor(t[q], 8);
-    t[q] += __shfl_xor(t[q], 16);
-    t[q] += __shfl_xor(t[q], 32);
-  }
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) < 8) {
-#pragma unroll
-    for (int q = 0; q < 6; q++) part[wave][q][e] = t[q];
-  }
-  __syncthreads();
-  if (threadIdx.x < 8 && (int)blockIdx.x * 8 + e < n) {
-    float r[6];
-#pragma unroll
-    for (int q = 0; q < 6; q++) r[q] = (part[0][q][e] + part[1][q][e]) + (part[2][q][e] + part[3][q][e]);
-    const float A = r[0], B = r[1], S = r[2], s1 = r[3], s2 = r[4], sxh = r[5];
-    const float gw = c.gamma ? c.gamma[o] : 1.0f;
-    const float rsd = 1.0f / sqrtf(c.var[o] + c.eps);
-    const float k1 = s1 / c.m, k2 = s2 / c.m;
-    c.dw[i] = (A - k1 * S - k2 * B) * gw * rsd;
-    if (k == 0) {
-      if (c.dgamma) c.dgamma[o] = s2;
-      if (c.dbeta) c.dbeta[o] = s1;
-      if (c.dbias) c.dbias[o] = (s1 - k1 * c.m - k2 * sxh) * gw * rsd;      // sum of d loss / d z (zero up to rounding)
-    }
-  }
-}
+// One-pass backward: the totals over the workgroups' slabs and dW, dgamma, dbeta, dbias from them (dfhip_stem_combine.h;
+// inside a weight-gradient group the same body runs as extra workgroups of the group's slab-sum launch)
+__global__ __launch_bounds__(256) void k_stem_combine(StemCombine c) { stem_combine_body(c, (int)blockIdx.x); }
 
 size_t stem_bwd_lds(int C, int k) {
   const int KK = C * k * k;
@@ -811,21 +748,40 @@ int dfhip_stem_forward_noz(const float* x, const float* w, const float* bias, co
   return DFHIP_OK;
 }
 
+}  // extern "C"
+namespace dfhip {
+int stem_combine_launch(const StemCombine& c, int blocks) {
+  DF_LAUNCH(k_stem_combine, dim3((unsigned)blocks), dim3(256), 0, stream(), c);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+}  // namespace dfhip
+extern "C" {
+
 int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, const float* y, const float* g,
                             const float* gamma, const float* beta, const float* save_mean, const float* save_var,
                             float* dw, float* dbias, float* dgamma, float* dbeta, int N, int C, int H, int W, int O, int k,
                             int stride, int pad, float eps, int* done) {
-  DF_INIT();
+  DF_INIT_KEEP();
   DF_CHECK_ARG(x && w && y && g && save_mean && save_var && dw && done, "stem_backward_noz: null array");
   *done = 0;
+  static int onepass = getenv("DFHIP_STEM_ONEPASS") ? atoi(getenv("DFHIP_STEM_ONEPASS")) : 1;
+  static int ride_env = getenv("DFHIP_STEM_COMBINE_RIDES") ? atoi(getenv("DFHIP_STEM_COMBINE_RIDES")) : 1;
+  // queued weight gradients stay queued when the one-pass form runs inside their group: the group's slab-sum launch then
+  // does this call's last step (the slabs of totals live in the second scratch area, the group's own in the first)
+  const bool ride = ride_env && onepass && k == 3 && group_collecting() && stem_shape(N, C, H, W, O, k, stride, pad);
+  if (!ride) {
+    int f__ = flush_deferred();
+    if (f__ != DFHIP_OK) return f__;
+  }
   if (!stem_shape(N, C, H, W, O, k, stride, pad)) return DFHIP_OK;
   const int KK = C * k * k;
   // (k_stem_bwd<.., 1> adds up at most 16 lanes x 16 slices: the slices of the first pass are capped at 256 whatever the device)
   const int gx = (int)std::min<int64_t>(N, std::min(num_cus(), 256));
-  static int onepass = getenv("DFHIP_STEM_ONEPASS") ? atoi(getenv("DFHIP_STEM_ONEPASS")) : 1;
   const bool one = onepass && k == 3;   // (5x5: two accumulator sets of three tiles do not fit the registers)
   const size_t SL = (size_t)2 * O * KK + 3 * O + KK;
-  float* ws = workspace(std::max((size_t)O * gx * 2 + (size_t)gx * O * (KK + 1), (size_t)gx * SL) * sizeof(float));
+  const size_t ws_bytes = std::max((size_t)O * gx * 2 + (size_t)gx * O * (KK + 1), (size_t)gx * SL) * sizeof(float);
+  float* ws = ride ? workspace2(ws_bytes) : workspace(ws_bytes);
   if (!ws) return DFHIP_OUT_OF_MEMORY;
   StemB b = {};
   b.x = x; b.w = w; b.y = y; b.g = g; b.gamma = gamma; b.beta = beta; b.mean = save_mean; b.var = save_var; b.bias = bias;
@@ -858,8 +814,12 @@ int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, c
     StemCombine c = {};
     c.slabs = ws; c.gamma = gamma; c.var = save_var; c.dw = dw; c.dbias = dbias; c.dgamma = dgamma; c.dbeta = dbeta;
     c.O = O; c.KK = KK; c.splits = gx; c.m = (float)N * (float)H * 32.0f; c.eps = eps;
-    DF_LAUNCH(k_stem_combine, dim3((unsigned)df_ceil_div(O * KK, 8)), dim3(256), 0, stream(), c);
-    DF_LAUNCH_CHECK();
+    const int cblocks = (int)df_ceil_div(O * KK, 8);
+    // (a weight-gradient group is collecting: its slab-sum launch, which follows this call, takes the combine along)
+    if (!(ride && stem_combine_defer(c, cblocks))) {
+      int st = stem_combine_launch(c, cblocks);
+      if (st != DFHIP_OK) return st;
+    }
     *done = 1;
     return DFHIP_OK;
   }
