@@ -1001,11 +1001,19 @@ __global__ __launch_bounds__(256) void k_conv1x1s2_fwd(const float* __restrict__
 // own [C][O][3][3] tensor -- a slice's records are then rows of 16 x 9 consecutive floats per contraction channel, stored with
 // the tap flipped (the gradient's tap of (source s, position q) is 8 - the forward's) -- and `bias` is the gradient the
 // tensor already holds, [N][O][2][2], added in the epilogue.
-template <int C, bool DG = false>
+// BNC (forward only): x is the RAW output of the previous convolution and the operand is its training-mode BatchNorm
+// (dfhip_conv2d_forward_bn_input; no activation in between).  No launch turns the producer's partial rows into a (scale, shift)
+// table: a wave needs the pairs of its own CW channels only -- lane (g, c) adds up rows g, g + 64 / CW, ... of channel cb + c
+// (requested in front of the first slice), the groups meet through lane exchanges, the operand lanes fetch their channel's
+// pair from lane c.  Workgroup (0, 0) leaves the table and the statistics behind for the backward pass.  (The padding needs
+// no care: a tap outside the image is never multiplied.)
+template <int C, bool DG = false, bool BNC = false>
 __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
-                                                          float* __restrict__ stats, int O, int xo) {
+                                                          float* __restrict__ stats, int O, int xo, BnInput bn) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+  static_assert(!(DG && BNC), "the BatchNorm operand is a forward form");
   constexpr int CW = C / 8;                     // channels per wave
   constexpr int NCHK = CW / 8;                  // slices of eight channels
   constexpr int WP = 17;                        // pitch of a (channel, tap) row of 16 output channels
@@ -1042,7 +1050,63 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restric
   f32x4 acc[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int BG = 64 / CW, BRP = 8;          // row groups of the wave (2 at 32 channels, 4 at 16); rows per lane and pass
+  static_assert(!BNC || CW == 16 || CW == 32, "a wave's channels are a half or a quarter of its lanes");
+  f32x3u bn_row[BNC ? BRP : 1];
+  float bn_shift = 0.0f, bn_g = 1.0f, bn_b = 0.0f, bn_rm = 0.0f, bn_rv = 0.0f;
+  const int bc = lane % CW, bg = lane / CW;
+  if constexpr (BNC) {
+    const float* pc = bn.part + (cb + bc) * 3;
+#pragma unroll
+    for (int k2 = 0; k2 < BRP; k2++)
+      bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(bg + BG * k2, bn.rows - 1) * (C * 3));
+    bn_shift = pc[1];
+    if (bn.gamma) bn_g = bn.gamma[cb + bc];
+    if (bn.beta) bn_b = bn.beta[cb + bc];
+    if (bn.running_mean) bn_rm = bn.running_mean[cb + bc];
+    if (bn.running_var) bn_rv = bn.running_var[cb + bc];
+    __builtin_amdgcn_sched_barrier(0);
+  }
   request(0);
+  float bn_sc = 1.0f, bn_sh = 0.0f;
+  if constexpr (BNC) {
+    float tn = 0.0f, t1 = 0.0f, t2 = 0.0f;
+    auto add_rows = [&](int r0) {
+#pragma unroll
+      for (int k2 = 0; k2 < BRP; k2++) {
+        const bool in = r0 + bg + BG * k2 < bn.rows;
+        const float nb = in ? bn_row[k2][0] : 0.0f, d = nb > 0.0f ? bn_row[k2][1] - bn_shift : 0.0f;
+        tn += nb;
+        t1 = fmaf(nb, d, t1);
+        t2 += fmaf(nb * d, d, in ? bn_row[k2][2] : 0.0f);
+      }
+    };
+    add_rows(0);
+    for (int r0 = BG * BRP; r0 < bn.rows; r0 += BG * BRP) {
+      const float* pc = bn.part + (cb + bc) * 3;
+#pragma unroll
+      for (int k2 = 0; k2 < BRP; k2++)
+        bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(r0 + bg + BG * k2, bn.rows - 1) * (C * 3));
+      add_rows(r0);
+    }
+    if constexpr (BG == 4) { tn += __shfl_xor(tn, 16, 64); t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64); }
+    tn += __shfl_xor(tn, 32, 64); t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+    const float mu_s = tn > 0.0f ? t1 / tn : 0.0f;
+    const float mu = bn_shift + mu_s;
+    const float var = tn > 0.0f ? fmaxf(t2 - t1 * mu_s, 0.0f) / tn : 0.0f;            // biased variance (batchnorm.py:41-42)
+    const float rsd = 1.0f / sqrtf(var + bn.eps);
+    bn_sc = bn_g * rsd;
+    bn_sh = bn_b - mu * bn_sc;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && bg == 0) {
+      const int c = cb + bc;
+      if (bn.save_mean) bn.save_mean[c] = mu;
+      if (bn.save_var) bn.save_var[c] = var;
+      if (bn.running_mean) bn.running_mean[c] = bn_rm * (1.0f - bn.momentum) + mu * bn.momentum;
+      if (bn.running_var) bn.running_var[c] = bn_rv * (1.0f - bn.momentum) + var * bn.momentum;
+      bn.affine[2 * c] = bn_sc;
+      bn.affine[2 * c + 1] = bn_sh;
+    }
+  }
 #pragma unroll
   for (int ch = 0; ch < NCHK; ch++) {
     // commit: weight float4 (m, j) holds (channel, tap) rows 4 j .. 4 j + 3 of output channel m
@@ -1083,6 +1147,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restric
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (BNC) {
+#pragma unroll
+      for (int p = 0; p < 2; p++) {      // (lane c of the wave holds the pair of channel cb + c)
+        const float sc = __shfl(bn_sc, 8 * ch + 4 * p + kk, 64), sh = __shfl(bn_sh, 8 * ch + 4 * p + kk, 64);
+#pragma unroll
+        for (int e = 0; e < 4; e++) b[p][e] = fmaf(b[p][e], sc, sh);
+      }
+    }
 #pragma unroll
     for (int p = 0; p < 2; p++)
 #pragma unroll
@@ -3383,8 +3455,29 @@ int run_conv_img2(const Geo& g, int O, float* y, const float* bias, float* parti
   const size_t lds4 = std::max((size_t)8 * (72 * 17 + 16 * 9 * 4), (size_t)7 * 4 * 64 * 4) * sizeof(float);
   // XCD arrangement: blockIdx.y selects 16 output channels' weights, blockIdx.x 16 images' planes
   const int xo = xcd_arrangement(rows4, O / 16, 4.0 * g.N * g.CS * 4, 4.0 * O * g.CS * 9);
-  if (g.CS == 128) DF_LAUNCH(k_conv3x3_img2_all<128>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, xo);
-  else DF_LAUNCH(k_conv3x3_img2_all<256>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, xo);
+  if (g.CS == 128) DF_LAUNCH(k_conv3x3_img2_all<128>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, xo, BnInput{});
+  else DF_LAUNCH(k_conv3x3_img2_all<256>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, xo, BnInput{});
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+// the same layer with the training-mode BatchNorm of its input applied on the operand loads, the table built by every wave
+// for its own channels (k_conv3x3_img2_all<.., BNC>); -1 when the shape is not one it takes
+int run_conv_img2_bn(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int O, int k,
+                     int stride, int pad, float* partials, int cap_rows, int* rows_out, const BnInput& bn, bool dry_run) {
+  static int enabled = getenv("DFHIP_IMG2_LEAN") ? atoi(getenv("DFHIP_IMG2_LEAN")) : 1;
+  static int bn_on = getenv("DFHIP_IMG2_BN_INPUT") ? atoi(getenv("DFHIP_IMG2_BN_INPUT")) : 1;
+  if (!enabled || !bn_on || k != 3 || stride != 1 || pad != 1 || H != 2 || W != 2 || (N % 32) != 0) return -1;
+  if (!(C == 128 || C == 256) || O % 16 != 0 || !bn.part || bn.rows < 1 || !bn.affine) return -1;
+  const int rows4 = N / 16;
+  if (partials && rows4 > cap_rows) return -1;
+  if (rows_out) *rows_out = partials ? rows4 : 0;
+  if (dry_run) return DFHIP_OK;
+  dim3 grid4((unsigned)rows4, (unsigned)(O / 16));
+  const size_t lds4 = std::max((size_t)8 * (72 * 17 + 16 * 9 * 4), (size_t)7 * 4 * 64 * 4) * sizeof(float);
+  const int xo = xcd_arrangement(rows4, O / 16, 4.0 * N * C * 4, 4.0 * O * C * 9);
+  if (C == 128) DF_LAUNCH((k_conv3x3_img2_all<128, false, true>), grid4, dim3(512), lds4, stream(), x, w, bias, y, partials, O, xo, bn);
+  else DF_LAUNCH((k_conv3x3_img2_all<256, false, true>), grid4, dim3(512), lds4, stream(), x, w, bias, y, partials, O, xo, bn);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -4658,8 +4751,8 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
       dim3 grid4((unsigned)(N / 16), (unsigned)(C / 16));
       const size_t lds4 = std::max((size_t)8 * (72 * 17 + 16 * 9 * 4), (size_t)7 * 4 * 64 * 4) * sizeof(float);
       const int xo = xcd_arrangement(N / 16, C / 16, 4.0 * N * O * 4, 4.0 * O * C * 9);
-      if (O == 128) DF_LAUNCH((k_conv3x3_img2_all<128, true>), grid4, dim3(512), lds4, stream(), dy, w, add, dx, (float*)nullptr, C, xo);
-      else DF_LAUNCH((k_conv3x3_img2_all<256, true>), grid4, dim3(512), lds4, stream(), dy, w, add, dx, (float*)nullptr, C, xo);
+      if (O == 128) DF_LAUNCH((k_conv3x3_img2_all<128, true>), grid4, dim3(512), lds4, stream(), dy, w, add, dx, (float*)nullptr, C, xo, BnInput{});
+      else DF_LAUNCH((k_conv3x3_img2_all<256, true>), grid4, dim3(512), lds4, stream(), dy, w, add, dx, (float*)nullptr, C, xo, BnInput{});
       DF_LAUNCH_CHECK();
       return DFHIP_OK;
     }
@@ -4979,6 +5072,17 @@ int dfhip_conv2d_forward_bn_input(const float* x, const float* partials_in, int 
   // (shape test first: a call that launches nothing must not count as a launch of the family)
   const bool want = partials && rows_out;
   int rows = 0;
+  if (H == 2 && W == 2) {
+    // 2 x 2 images: the all-positions kernel, every wave builds the pairs of its own channels from the rows
+    if (run_conv_img2_bn(x, w, bias, y, N, C, H, W, O, k, stride, pad, want ? partials : nullptr, cap_rows, &rows, bn, true) < 0)
+      return DFHIP_OK;
+    ProfScope prof("conv2d_fwd_igemm", flops, bytes);
+    int st2 = run_conv_img2_bn(x, w, bias, y, N, C, H, W, O, k, stride, pad, want ? partials : nullptr, cap_rows, &rows, bn, false);
+    if (st2 != DFHIP_OK) return st2 < 0 ? DFHIP_RUNTIME_ERROR : st2;
+    if (want) *rows_out = rows;
+    *done = 1;
+    return DFHIP_OK;
+  }
   if (run_conv_rowmma(x, w, bias, y, N, C, H, W, O, k, stride, pad, want ? partials : nullptr, cap_rows, &rows, &bn, true) < 0)
     return DFHIP_OK;
   // the (scale, shift) table: built by every workgroup of the convolution from the producer's rows (the register-operand

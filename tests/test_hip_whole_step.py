@@ -86,10 +86,11 @@ CASES = {
                                   # (of the 19 BatchNorm layers behind the stem, the 8 of the 16 x 16 / 8 x 8 stages that do
                                   # not sit in a block with a convolution shortcut and whose gradient comes from such a kernel have no launch of their own)
                                   "bn2d_bwd": 11,
-                                  # (7 apply launches + 3 for the pairs of a block with a convolution shortcut; the six
-                                  # BatchNorms that stand between two convolutions are applied on the second one's loads, and
-                                  # its workgroups add up the first one's partial rows themselves: no launch)
-                                  "bn2d_fwd": 10, "bn_relu_pool_fwd": 1, "pool_linear_fwd": 1,
+                                  # (5 apply launches -- the bn2 + identity + ReLU of the blocks without a convolution shortcut --
+                                  # + 3 for the pairs of a block with one; the eight BatchNorms that stand between two
+                                  # convolutions are applied on the second one's loads, and its workgroups add up the first
+                                  # one's partial rows themselves: no launch)
+                                  "bn2d_fwd": 8, "bn_relu_pool_fwd": 1, "pool_linear_fwd": 1,
                                   "pool_linear_bwd": 1, "softmax_ce_fwd": 1, "adam_step": 1}),
     "cnn_bs256_overwrite": ("cnn", 256, "overwrite", {"adam_step": 1}),
     "resnet18_bs128_accumulate": ("resnet18", 128, "accumulate", {"conv2d_wgrad_grouped": 1, "adam_step": 1}),
