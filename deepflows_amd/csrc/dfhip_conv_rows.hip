@@ -112,6 +112,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   RS_STAMP(0);
   // ---- BNI: the (scale, shift) pair of this thread's channel is requested first (dfhip_bn2d_finalize_partials wrote
   // the table from the producer's partials) ----
+  // (Built, measured and dropped: a wave owning C / 8 channels with its lanes split over the rows and lane exchanges
+  // instead of the LDS round and the second barrier -- the per-lane rows make every load sixteen short segments:
+  // 16.5 -> 17.1 and 17.9 -> 20.4 us.)
   // bn.combine: there was no such launch -- every workgroup adds the producer's rows up for itself (thread = a channel
   // x a sixteenth / an eighth of the rows, 12-byte loads requested here, in front of the weights; the shifted sums of
   // k_bn_finalize_partials, combined through LDS in a fixed order), workgroup (0, 0) leaves the table, the batch
@@ -124,9 +127,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   if constexpr (BNI) {
     if (bn.combine) {
       const float* pc = bn.part + bn_c * 3;
+      // (every load instruction of the workgroup queues in front of its weight and pixel loads: half of them when the rows are few)
+      if (bn.rows <= BNG * BRP / 2) {
 #pragma unroll
-      for (int k2 = 0; k2 < BRP; k2++)
-        bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(bn_gr + BNG * k2, bn.rows - 1) * (C * 3));
+        for (int k2 = 0; k2 < BRP / 2; k2++)
+          bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(bn_gr + BNG * k2, bn.rows - 1) * (C * 3));
+#pragma unroll
+        for (int k2 = BRP / 2; k2 < BRP; k2++) bn_row[k2] = (f32x3u){0.0f, 0.0f, 0.0f};
+      } else {
+#pragma unroll
+        for (int k2 = 0; k2 < BRP; k2++)
+          bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(bn_gr + BNG * k2, bn.rows - 1) * (C * 3));
+      }
       bn_shift = pc[1];                               // row 0's mean
       if (tid < C) {
         if (bn.gamma) bn_g = bn.gamma[tid];
@@ -868,8 +880,13 @@ int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y,
   const int64_t tiles = (int64_t)N * HW / 16;
   // (width, channels) -> tiles per wave, tile sets x channel tiles per workgroup
   int nt, ts, ow;
-  if (W == 16 && C == 32) { nt = 4; ts = 4; ow = 2; }
-  else if (W == 8 && C == 64) { nt = 2; ts = 4; ow = 2; }
+  // 16- and 8-wide layers: eight tile sets x one channel tile per workgroup (twice the pixel loads, half the weight image and
+  // half as many partial rows for the consumer of the statistics: 15.1 -> 14.5 and 16.1 -> 15.2 us plain, -0.4 us with a
+  // BatchNorm operand); DFHIP_ROWMMA_TS8=0: four tile sets x two channel tiles (rounds 2-3), bit 0 / 1: plain / BatchNorm form
+  static int ts8 = getenv("DFHIP_ROWMMA_TS8") ? atoi(getenv("DFHIP_ROWMMA_TS8")) : 3;
+  const bool wide = (ts8 & 1) && !bn && partials, wide_bn = (ts8 & 2) && bn;
+  if (W == 16 && C == 32) { nt = 4; ts = (wide || wide_bn) ? 8 : 4; ow = (wide || wide_bn) ? 1 : 2; }
+  else if (W == 8 && C == 64) { nt = 2; ts = (wide || wide_bn) ? 8 : 4; ow = (wide || wide_bn) ? 1 : 2; }
   else if (W == 4 && H == 4 && C == 128) { nt = 1; ts = 8; ow = 1; }
   else return -1;
   if (O % (16 * ow) != 0 || tiles % (ts * nt) != 0 || (W == 16 && H % nt != 0)) return -1;
@@ -881,10 +898,14 @@ int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y,
   if (dry_run) return DFHIP_OK;              // eligible: nothing launched
   if (bn) {
     if (!bn->affine) return -1;
+    if (wide_bn && W == 16) return launch_rowmma<4, 32, 4, false, 8, 1, 4, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
+    if (wide_bn && W == 8) return launch_rowmma<3, 64, 2, false, 8, 1, 4, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
     if (W == 16) return launch_rowmma<4, 32, 4, false, 4, 2, 4, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
     if (W == 8) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
     return launch_rowmma<2, 128, 1, true, 8, 1, 8, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
   }
+  if (wide && W == 16) return launch_rowmma<4, 32, 4, false, 8, 1, 4, 1>(x, w, bias, y, partials, H, O, grid);
+  if (wide && W == 8) return launch_rowmma<3, 64, 2, false, 8, 1, 4, 1>(x, w, bias, y, partials, H, O, grid);
   if (W == 16) {
     if (variant == 1) return launch_rowmma<4, 32, 4, false, 4, 2, 8, 1>(x, w, bias, y, partials, H, O, grid);
     if (variant == 2) return launch_rowmma<4, 32, 4, false, 4, 2, 4, 2>(x, w, bias, y, partials, H, O, grid);
