@@ -1063,8 +1063,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restric
     bn_shift = pc[1];
     if (bn.gamma) bn_g = bn.gamma[cb + bc];
     if (bn.beta) bn_b = bn.beta[cb + bc];
-    if (bn.running_mean) bn_rm = bn.running_mean[cb + bc];
-    if (bn.running_var) bn_rv = bn.running_var[cb + bc];
+    if (blockIdx.x == 0 && blockIdx.y == 0) {                         // (only the workgroup that updates them)
+      if (bn.running_mean) bn_rm = bn.running_mean[cb + bc];
+      if (bn.running_var) bn_rv = bn.running_var[cb + bc];
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   request(0);

@@ -143,8 +143,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
       if (tid < C) {
         if (bn.gamma) bn_g = bn.gamma[tid];
         if (bn.beta) bn_b = bn.beta[tid];
-        if (bn.running_mean) bn_rm = bn.running_mean[tid];
-        if (bn.running_var) bn_rv = bn.running_var[tid];
+        if (blockIdx.x == 0 && blockIdx.y == 0) {                     // (only the workgroup that updates them)
+          if (bn.running_mean) bn_rm = bn.running_mean[tid];
+          if (bn.running_var) bn_rv = bn.running_var[tid];
+        }
       }
     } else {
       if (tid < C) bn_pair = *reinterpret_cast<const f32x2*>(bn.affine + 2 * tid);
@@ -645,6 +647,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
   const int n0 = wg.x * 16, o0 = wg.y * 16, h = blockIdx.z;
   float* Wl = smem_i4 + wave * WSL;
   float* Xs = Wl + 72 * WP;
+  __shared__ __attribute__((aligned(8))) float bn_wtab[COMB ? 8 : 1][COMB ? CW : 1][2];   // a wave's own pairs
   const int cb = wave * CW;
   f32x4 wq[5], xq[8];
   auto request = [&](int ch) {
@@ -680,8 +683,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
     bn_shift = pc[1];
     if (bn.gamma) bn_g = bn.gamma[cb + n];
     if (bn.beta) bn_b = bn.beta[cb + n];
-    if (bn.running_mean) bn_rm = bn.running_mean[cb + n];
-    if (bn.running_var) bn_rv = bn.running_var[cb + n];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {     // (only the workgroup that updates them)
+      if (bn.running_mean) bn_rm = bn.running_mean[cb + n];
+      if (bn.running_var) bn_rv = bn.running_var[cb + n];
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   request(0);
@@ -716,6 +721,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
     const float rsd = 1.0f / sqrtf(var + bn.eps);
     bn_pair[0] = bn_g * rsd;
     bn_pair[1] = bn_b - mu * bn_pair[0];
+    if (kk == 0) { bn_wtab[wave][n][0] = bn_pair[0]; bn_wtab[wave][n][1] = bn_pair[1]; }   // (read behind the wave barriers below)
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && kk == 0) {
       const int c = cb + n;
       if (bn.save_mean) bn.save_mean[c] = mu;
@@ -765,9 +771,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
 #pragma unroll
       for (int p = 0; p < 2; p++) {
         f32x2 sc;
-        if constexpr (combine) {       // (every lane of the wave holds the pair of channel cb + (lane & 15))
-          sc[0] = __shfl(bn_pair[0], 8 * ch + 4 * p + kk, 64);
-          sc[1] = __shfl(bn_pair[1], 8 * ch + 4 * p + kk, 64);
+        if constexpr (combine) {
+          sc = *reinterpret_cast<const f32x2*>(&bn_wtab[wave][8 * ch + 4 * p + kk][0]);
         } else {
           sc = *reinterpret_cast<const f32x2*>(aff + 2 * (c0 + 4 * p + kk));
         }

@@ -126,8 +126,10 @@ def _family_of(kernel):
     # kernels that serve the accumulate-mode input gradient through a template flag (`DG`) belong to that family
     if k.startswith("k_dgrad_s2_acc"):
         return "conv2d_dgrad_igemm"
-    if k.startswith("k_conv3x3_img2_all<") and k.endswith(", true>"):
-        return "conv2d_dgrad_igemm"
+    if k.startswith("k_conv3x3_img2_all<"):          # <C, DG, BNC>
+        args = [a.strip() for a in k[len("k_conv3x3_img2_all<"):-1].split(",")]
+        if len(args) > 1 and args[1] == "true":
+            return "conv2d_dgrad_igemm"
     if k.startswith("k_conv3x3_rowmma<"):
         args = [a.strip() for a in k[len("k_conv3x3_rowmma<"):-1].split(",")]
         if len(args) > 8 and args[8] == "true":
