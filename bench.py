@@ -340,6 +340,10 @@ def main():
                     help="PMC summary (tools/pmc_summary.py --json) to quote for traffic / executed flops instead of the "
                          "newest matching file under profiles/")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
+    ap.add_argument("--settle-ms", type=float, default=250.0,
+                    help="untimed replays of the captured step in front of the timed region, in milliseconds of wall time: the "
+                         "clock governor needs ~0.2 s of load to reach the clock it then holds (tools/soak.py: 5 000 replays); "
+                         "0 = the two warm replays only")
     ap.add_argument("--no-prof-gate", action="store_true",
                     help="per-family event pass with the queue running dry between launches (host-paced)")
     ap.add_argument("--overlap", action="store_true",
@@ -397,6 +401,9 @@ def main():
     # order, one host call per step instead of ~100
     captured = None
     overlapped = False
+    settle_replays = 0
+    # (under rocprofv3 every replay is traced: the counter passes divide by a fixed number of steps, tools/profile_round.sh)
+    profiled_run = args.no_prof_gate
     if not args.no_graph and sync is not None and args.overlap and args.workload == "resnet18":
         # data parallel: two graphs split where layer4's gradients are complete, the all-reduce of
         # that bucket runs on the communication stream beside the rest of the backward pass
@@ -421,6 +428,12 @@ def main():
             for _ in range(2):
                 loss = captured.replay()
             mod.synchronize()
+            t_settle = time.perf_counter()
+            while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms and not profiled_run:
+                for _ in range(20):
+                    loss = captured.replay()
+                mod.synchronize()
+                settle_replays += 20
         except Exception as e:                      # stay on the eager path, say so
             print(f"[bench] step capture failed ({type(e).__name__}: {e}); timing the eager path", file=sys.stderr)
             captured = None
@@ -582,7 +595,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["text"],
                        "global_batch": batch * comm.world, "batch_per_gpu": batch, "parallelism": f"dp{comm.world}",
-                       "conv_dgrad": args.dgrad, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,
+                       "settle_replays_untimed": settle_replays, "conv_dgrad": args.dgrad, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,
                        "allreduce_elems": exchanged,
                        # the exchange step: inside the captured graph or enqueued behind it; gradients the last sync() had to
                        # copy into the bucket (0: every backward kernel wrote its gradient in place)
