@@ -345,7 +345,10 @@ int dfhip_stem_backward(const float* x, const float* z, const float* y, const fl
  * (tensor.py:779-791, 872-877) and forms dw (O, C, 3, 3), dgamma, dbeta (O) as dfhip_stem_backward does.  Replaces
  * dfhip_conv2d_forward_stats + dfhip_bn_relu_maxpool2_forward_partials / dfhip_stem_backward for that shape
  * (nn/functional.py:316-374 + nn/modules/batchnorm.py:30-55 in the reference).  *done = 0 (nothing launched) for any
- * other shape. */
+ * other shape.  Inside a weight-gradient group (dfhip_wgrad_group_begin / _end) with gradients queued, the 3x3 backward
+ * leaves its last step -- totals over the workgroups' slabs -> dw, dbias, dgamma, dbeta -- to the group's slab-sum launch:
+ * like a queued dfhip_conv2d_wgrad, those four arrays hold their values after the group has been flushed (by _end, by any
+ * entry point that flushes deferred work, or by one that is handed one of them). */
 int dfhip_stem_forward_noz(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
                            float* y, float* save_mean, float* save_var, float* running_mean, float* running_var, int N,
                            int C, int H, int W, int O, int k, int stride, int pad, float eps, float momentum, int* done);
