@@ -4594,7 +4594,9 @@ bool deferred_touches(const void* p) {
   if (!p) return false;
   if (g_stem_pending.active) {
     const StemCombine& c = g_stem_pending.c;
-    if (p == c.dw || p == c.dgamma || p == c.dbeta || p == c.dbias || p == c.slabs) return true;
+    const float* q = (const float*)p;
+    auto in = [&](const float* lo, int64_t n) { return lo && q >= lo && q < lo + n; };
+    if (in(c.dw, (int64_t)c.O * c.KK) || in(c.dgamma, c.O) || in(c.dbeta, c.O) || in(c.dbias, c.O) || p == c.slabs) return true;
   }
   for (const auto& sp : g_side_pending)              // a gradient in flight on the side stream: join first
     for (const auto& r : sp.dws)

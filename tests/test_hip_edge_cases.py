@@ -170,6 +170,52 @@ def test_deferred_slab_sum_is_invisible(hip_device):
     assert not _back(mod, z).any()
 
 
+def test_stem_backward_inside_a_weight_gradient_group(hip_device):
+    """Inside a weight-gradient group the one-pass stem backward leaves its last step (totals over the slabs -> dw, dgamma,
+    dbeta) to the group's slab-sum launch (dfhip_stem_combine.h).  Same bits as outside a group, and a device consumer of
+    one of the pending arrays before the group ends sees the finished values."""
+    mod = hip_device.mod
+    rng = np.random.default_rng(77)
+    N, C, H, W, O = 32, 3, 32, 32, 32
+    x = _arr(mod, rng.standard_normal((N, C, H, W)).astype(np.float32))
+    w = _arr(mod, (0.2 * rng.standard_normal((O, C, 3, 3))).astype(np.float32))
+    gamma = _arr(mod, (1.0 + 0.1 * rng.standard_normal(O)).astype(np.float32))
+    beta = _arr(mod, (0.1 * rng.standard_normal(O)).astype(np.float32))
+    y, mean, var = mod.Array(N * O * 16 * 16), mod.Array(O), mod.Array(O)
+    assert mod.stem_forward_noz(x, w, None, gamma, beta, y, mean, var, None, None, N, C, H, W, O, 3, 1, 1, 1e-5, 0.1)
+    g = _arr(mod, rng.standard_normal((N, O, 16, 16)).astype(np.float32))
+    # a queued weight gradient for the group to carry
+    xa = _arr(mod, rng.standard_normal((N, 32, 16, 16)).astype(np.float32))
+    da = _arr(mod, rng.standard_normal((N, 32, 16, 16)).astype(np.float32))
+    geo = (N, 32, 16, 16, 32, 3, 1, 1)
+
+    def run(grouped, touch):
+        dw, dgamma, dbeta, dwq = mod.Array(O * C * 9), mod.Array(O), mod.Array(O), mod.Array(32 * 32 * 9)
+        doubled = None
+        if grouped:
+            mod.wgrad_group_begin()
+        mod.conv2d_wgrad(xa, da, dwq, *geo)
+        assert mod.stem_backward_noz(x, w, None, y, g, gamma, beta, mean, var, dw, None, dgamma, dbeta, N, C, H, W, O, 3, 1, 1, 1e-5)
+        if touch:                                   # a consumer of a pending array in front of the group's end
+            doubled = mod.Array(O)
+            mod.scalar_mul(dgamma, 2.0, doubled)
+        if grouped:
+            mod.wgrad_group_end()
+        out = [_back(mod, a).copy() for a in (dw, dgamma, dbeta, dwq)]
+        return out, (_back(mod, doubled).copy() if doubled is not None else None)
+
+    ref, _ = run(False, False)
+    for touch in (False, True):
+        got, doubled = run(True, touch)
+        for a, b, name in zip(got, ref, ("dw", "dgamma", "dbeta", "queued dw")):
+            if name == "queued dw":                 # (a grouped launch plans its workgroups differently: another summation order)
+                assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max(), name
+            else:
+                assert np.array_equal(a, b), f"{name} differs inside a group (touch={touch})"
+        if touch:
+            assert np.array_equal(doubled, 2.0 * ref[1])
+
+
 def test_dgrad_add_epilogue(hip_device):
     from oracle import ref_ops
     mod = hip_device.mod
