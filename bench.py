@@ -428,12 +428,19 @@ def main():
             for _ in range(2):
                 loss = captured.replay()
             mod.synchronize()
-            t_settle = time.perf_counter()
-            while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms and not profiled_run:
+            if args.settle_ms > 0 and not profiled_run:
+                # (the SAME number of replays on every rank -- a replay may contain the all-reduce: 20 timed ones, then as many
+                # as the slowest rank's estimate asks for)
+                t_settle = time.perf_counter()
                 for _ in range(20):
                     loss = captured.replay()
                 mod.synchronize()
-                settle_replays += 20
+                per = max(1e-6, (time.perf_counter() - t_settle) / 20)
+                more = int(comm.max_float(float(min(5000, int(args.settle_ms * 1e-3 / per)))))
+                for _ in range(more):
+                    loss = captured.replay()
+                mod.synchronize()
+                settle_replays = 20 + more
         except Exception as e:                      # stay on the eager path, say so
             print(f"[bench] step capture failed ({type(e).__name__}: {e}); timing the eager path", file=sys.stderr)
             captured = None
