@@ -41,6 +41,15 @@ int run_dgrad_ow_pair(const float* dy, const float* w, const float* dy2, const f
                       int N, int C, int H, int W, int O, const BnBwdIn* bi, const BnBwdIn* bi2, BnStatsOut* so,
                       bool dry_run = false);
 
+// argument check of a dfhip_bn_bwd_in at the C entry points (dfhip_conv.hip, dfhip_wgrad.hip)
+inline int check_bn_in(const char* fn, const BnBwdIn* b) {
+  if (!b) return DFHIP_OK;
+  DF_CHECK_ARG(b->z && b->rows && b->mean && b->var, "%s: dfhip_bn_bwd_in with a null array", fn);
+  DF_CHECK_ARG(b->nrows >= 1 && b->nrows <= kBnRowsMax && b->K >= 2 && b->K <= 3 && b->kidx >= 1 && b->kidx < b->K,
+               "%s: dfhip_bn_bwd_in rows %d (1..%d), K %d, kidx %d", fn, b->nrows, kBnRowsMax, b->K, b->kidx);
+  return DFHIP_OK;
+}
+
 }  // namespace dfhip
 
 #if defined(__HIPCC__)

@@ -68,6 +68,12 @@ struct BnInput {
   int combine;                 // 1: no bn_finalize_partials launch has run -- the consuming kernel adds the rows up itself
 };
 
+// dfhip_conv.hip, shared with dfhip_wgrad.hip: pixel-group shape of a staged kernel, argument check of every convolution
+// entry point (sets the error text, computes oh / ow), exact division by multiplication (magic = ceil(2^32 / d), 0 = d <= 1)
+void plan_groups(int N, int HD, int WD, int tp, int& BI, int& BR, int& BC, int& gi, int& gr, int& gc);
+int check_conv_args(const char* name, int N, int C, int H, int W, int O, int k, int stride, int pad, int& oh, int& ow);
+inline unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)((((uint64_t)1 << 32) + d - 1) / d); }
+
 // dfhip_fused.hip: bn.part -> bn.affine (+ save_mean / save_var / running statistics); -1 when there is nothing to combine
 int bn_finalize_partials(const BnInput& bn, int C);
 

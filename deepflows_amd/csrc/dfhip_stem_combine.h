@@ -1,7 +1,7 @@
 // The last step of the one-pass stem backward (dfhip_stem.hip: k_stem_bwd<.., 2> leaves one slab of totals per workgroup): the
 // totals over the slabs in a fixed order and dW, dgamma, dbeta, dbias from them.  It is a launch of its own
 // (k_stem_combine) or -- inside a weight-gradient group, whose slab-sum launch runs right behind the stem's backward pass
-// anyway -- extra workgroups of k_wgrad_group_sum (dfhip_conv.hip): the same body, the same bits.
+// anyway -- extra workgroups of k_wgrad_group_sum (dfhip_wgrad.hip): the same body, the same bits.
 #pragma once
 #include "dfhip_internal.h"
 
@@ -19,7 +19,7 @@ struct StemCombine {
   float m, eps;
 };
 
-// host side (dfhip_conv.hip): hand the combine to the next grouped slab sum; false = no group is collecting (launch it)
+// host side (dfhip_wgrad.hip): hand the combine to the next grouped slab sum; false = no group is collecting (launch it)
 bool stem_combine_defer(const StemCombine& c, int blocks);
 // dfhip_stem.hip: the stand-alone launch
 int stem_combine_launch(const StemCombine& c, int blocks);
