@@ -114,7 +114,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   // the table from the producer's partials) ----
   // (Built, measured and dropped: a wave owning C / 8 channels with its lanes split over the rows and lane exchanges
   // instead of the LDS round and the second barrier -- the per-lane rows make every load sixteen short segments:
-  // 16.5 -> 17.1 and 17.9 -> 20.4 us.)
+  // 16.5 -> 17.1 and 17.9 -> 20.4 us; every wave finishing the sums for itself behind the first barrier -- no second
+  // barrier, eight times the divisions: 16.5 -> 16.5, 17.9 -> 18.3 us.)
   // bn.combine: there was no such launch -- every workgroup adds the producer's rows up for itself (thread = a channel
   // x a sixteenth / an eighth of the rows, 12-byte loads requested here, in front of the weights; the shifted sums of
   // k_bn_finalize_partials, combined through LDS in a fixed order), workgroup (0, 0) leaves the table, the batch
