@@ -965,6 +965,80 @@ __global__ __launch_bounds__(512) void k_bn_fused_bwd_pair(const float* __restri
   bn_fused_bwd_body(blockIdx.x, dy, q.x, q.gamma, q.save_mean, q.save_var, q.dx, q.dgamma, q.dbeta, N, C, HW, q.eps);
 }
 
+// 2 x 2 planes (HW == 4, ResNet layer4): a channel's plane is 16 bytes, so with a workgroup per channel every lane touches a
+// cache line of its own (64 lines per load instruction, 8 channels' workgroups pulling the same lines).  Here a workgroup
+// owns EIGHT neighbouring channels -- 128 bytes = one line per image --, thread (image, channel) requests 16-byte pieces
+// that are contiguous over the eight channels, the per-channel sums meet through three lane exchanges and LDS (a fixed
+// order), and the pass that applies them reuses the registers.  N <= 512 * kBn4 / 8 images.
+constexpr int kBn4 = 8;                             // 16-byte pieces per thread
+__device__ __forceinline__ void bn_fused_bwd_hw4_body(int cg, const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                      const float* __restrict__ save_var, float* __restrict__ dx,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C,
+                                                      float eps) {
+  __shared__ float sh[8][8][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = tid & 7, c = cg * 8 + j;            // (512 % 8 == 0: a thread keeps its channel over its pieces)
+  const float mean = save_mean[c], rsd = 1.0f / sqrtf(save_var[c] + eps);
+  const float w = chan_param(gamma, save_mean, c, 1.0f);
+  float4 xh[kBn4], gv[kBn4];
+  float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int u = 0; u < kBn4; u++) {
+    const int img = (tid >> 3) + 64 * u;
+    const int64_t off = ((int64_t)min(img, N - 1) * C + c) * 4;
+    const float4 xv = *reinterpret_cast<const float4*>(x + off);
+    gv[u] = *reinterpret_cast<const float4*>(dy + off);
+    if (img >= N) gv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    xh[u].x = (xv.x - mean) * rsd; xh[u].y = (xv.y - mean) * rsd;
+    xh[u].z = (xv.z - mean) * rsd; xh[u].w = (xv.w - mean) * rsd;
+    s1 += (gv[u].x + gv[u].y) + (gv[u].z + gv[u].w);
+    s2 += (gv[u].x * xh[u].x + gv[u].y * xh[u].y) + (gv[u].z * xh[u].z + gv[u].w * xh[u].w);
+  }
+#pragma unroll
+  for (int m = 8; m < 64; m *= 2) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+  if (lane < 8) { sh[wave][lane][0] = s1; sh[wave][lane][1] = s2; }
+  __syncthreads();
+  float sdy = 0.0f, sdyx = 0.0f;
+#pragma unroll
+  for (int w8 = 0; w8 < 8; w8++) { sdy += sh[w8][j][0]; sdyx += sh[w8][j][1]; }
+  if (tid < 8) {
+    if (dgamma) dgamma[c] = sdyx;
+    if (dbeta) dbeta[c] = sdy;
+  }
+  if (!dx) return;
+  const float m = (float)N * 4.0f;
+  const float k1 = sdy / m, k2 = sdyx / m;
+#pragma unroll
+  for (int u = 0; u < kBn4; u++) {
+    const int img = (tid >> 3) + 64 * u;
+    if (img < N) {
+      float4 r;
+      r.x = (gv[u].x - k1 - xh[u].x * k2) * w * rsd;
+      r.y = (gv[u].y - k1 - xh[u].y * k2) * w * rsd;
+      r.z = (gv[u].z - k1 - xh[u].z * k2) * w * rsd;
+      r.w = (gv[u].w - k1 - xh[u].w * k2) * w * rsd;
+      *reinterpret_cast<float4*>(dx + ((int64_t)img * C + c) * 4) = r;
+    }
+  }
+}
+__global__ __launch_bounds__(512) void k_bn_fused_bwd_hw4(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                          const float* __restrict__ save_var, float* __restrict__ dx,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C,
+                                                          float eps) {
+  bn_fused_bwd_hw4_body(blockIdx.x, dy, x, gamma, save_mean, save_var, dx, dgamma, dbeta, N, C, eps);
+}
+__global__ __launch_bounds__(512) void k_bn_fused_bwd_pair_hw4(const float* __restrict__ dy, BnBwdSet A, BnBwdSet B, int N, int C) {
+  const BnBwdSet& q = blockIdx.y ? B : A;
+  bn_fused_bwd_hw4_body(blockIdx.x, dy, q.x, q.gamma, q.save_mean, q.save_var, q.dx, q.dgamma, q.dbeta, N, C, q.eps);
+}
+
+inline bool bn_hw4_ok(int N, int C, int HW) {
+  static int on = getenv("DFHIP_BN_BWD_HW4") ? atoi(getenv("DFHIP_BN_BWD_HW4")) : 1;
+  return on && HW == 4 && C % 8 == 0 && N <= 64 * kBn4;
+}
+
 inline bool bn_fused_ok(int N, int C, int HW) {
   return (HW & 3) == 0 && (int64_t)N * HW <= (int64_t)512 * 4 * kBnVec && C >= 32;
 }
@@ -1852,6 +1926,12 @@ int dfhip_bn2d_backward(const float* dy, const float* x, const float* gamma, con
   DF_CHECK_ARG(N > 0 && C > 0 && HW > 0, "bn2d_backward: non-positive dimension");
   DF_CHECK_ARG(dy && x && save_mean && save_var, "bn2d_backward: null array");
   ProfScope prof("bn2d_bwd", 0.0, 20.0 * (double)N * C * HW);
+  if (bn_hw4_ok(N, C, HW)) {
+    DF_LAUNCH(k_bn_fused_bwd_hw4, dim3((unsigned)(C / 8)), dim3(512), 0, stream(), dy, x, gamma, save_mean, save_var, dx,
+              dgamma, dbeta, N, C, eps);
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
   if (bn_fused_ok(N, C, HW)) {
     DF_LAUNCH(k_bn_fused_bwd, dim3((unsigned)C), dim3(512), 0, stream(), dy, x, gamma, save_mean,
                        save_var, dx, dgamma, dbeta, N, C, HW, eps);
@@ -1915,6 +1995,11 @@ int dfhip_bn2d_backward_pair(const float* dy, const float* xa, const float* gamm
   ProfScope prof("bn2d_bwd", 0.0, 36.0 * (double)N * C * HW);
   BnBwdSet A = {xa, gamma_a, save_mean_a, save_var_a, dxa, dgamma_a, dbeta_a, eps_a};
   BnBwdSet B = {xb, gamma_b, save_mean_b, save_var_b, dxb, dgamma_b, dbeta_b, eps_b};
+  if (bn_hw4_ok(N, C, HW)) {
+    DF_LAUNCH(k_bn_fused_bwd_pair_hw4, dim3((unsigned)(C / 8), 2), dim3(512), 0, stream(), dy, A, B, N, C);
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
   DF_LAUNCH(k_bn_fused_bwd_pair, dim3((unsigned)C, 2), dim3(512), 0, stream(), dy, A, B, N, C, HW);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
