@@ -579,6 +579,91 @@ __global__ __launch_bounds__(kThreads) void k_bn_apply_partials_pair(BnFwdSet A,
   });
 }
 
+// The two kernels above on 2 x 2 planes (HW == 4, ResNet layer4): a workgroup owns EIGHT neighbouring channels -- one 128-byte
+// line per image -- and a slice of the images; thread (image, channel) requests 16-byte pieces that are contiguous over the
+// eight channels (with a workgroup per channel every lane touched a line of its own, and three quarters of the threads had
+// nothing to do).  The partial rows of the eight channels are combined by all threads (row = thread / 8 + 32 i), lane
+// exchanges + LDS in a fixed order.  PAIR: y = bnA(xA) + bnB(xB); otherwise y = bn(x) (+ residual).
+struct Hw4Stats { float mean, rsd, w, b; };
+__device__ __forceinline__ Hw4Stats bn_hw4_stats(const BnFwdSet& q, int c, int C, bool writer, float (*sw)[8][3]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = tid & 7;
+  const float shift = q.partials[(int64_t)c * 3 + 1];                 // row 0's mean
+  const float w = chan_param(q.gamma, q.partials, c, 1.0f), b = chan_param(q.beta, q.partials, c, 0.0f);
+  RowSums t = {0.0f, 0.0f, 0.0f};
+  {
+    const int r = tid >> 3;                                             // (clamped: no load under a condition)
+    const float* p = q.partials + ((int64_t)min(r, q.rows - 1) * C + c) * 3;
+    const float p0 = p[0], p1 = p[1], p2 = p[2];
+    if (r < q.rows) rows_add(t, p0, p1, p2, shift);
+  }
+  for (int r = (tid >> 3) + 32; r < q.rows; r += 32) {
+    const float* p = q.partials + ((int64_t)r * C + c) * 3;
+    rows_add(t, p[0], p[1], p[2], shift);
+  }
+#pragma unroll
+  for (int m = 8; m < 64; m *= 2) { t.n += __shfl_xor(t.n, m, 64); t.a1 += __shfl_xor(t.a1, m, 64); t.a2 += __shfl_xor(t.a2, m, 64); }
+  if (lane < 8) { sw[wave][lane][0] = t.n; sw[wave][lane][1] = t.a1; sw[wave][lane][2] = t.a2; }
+  __syncthreads();
+  const float n = (sw[0][j][0] + sw[1][j][0]) + (sw[2][j][0] + sw[3][j][0]);
+  const float a1 = (sw[0][j][1] + sw[1][j][1]) + (sw[2][j][1] + sw[3][j][1]);
+  const float a2 = (sw[0][j][2] + sw[1][j][2]) + (sw[2][j][2] + sw[3][j][2]);
+  const float mu_s = n > 0.0f ? a1 / n : 0.0f;
+  const float mean = shift + mu_s;
+  const float var = n > 0.0f ? fmaxf(a2 - a1 * mu_s, 0.0f) / n : 0.0f;  // biased variance (batchnorm.py:41-42)
+  if (writer) {
+    if (q.save_mean) q.save_mean[c] = mean;
+    if (q.save_var) q.save_var[c] = var;
+    if (q.running_mean) q.running_mean[c] = q.running_mean[c] * (1.0f - q.momentum) + mean * q.momentum;
+    if (q.running_var) q.running_var[c] = q.running_var[c] * (1.0f - q.momentum) + var * q.momentum;
+  }
+  return {mean, 1.0f / sqrtf(var + q.eps), w, b};
+}
+
+template <bool PAIR>
+__global__ __launch_bounds__(kThreads) void k_bn_apply_partials_hw4(BnFwdSet A, BnFwdSet B, const float* __restrict__ residual,
+                                                                    float* __restrict__ y, int N, int C, int ipb) {
+  __shared__ float swa[4][8][3], swb[PAIR ? 4 : 1][8][3];
+  const int tid = threadIdx.x, j = tid & 7, c = blockIdx.x * 8 + j, s = blockIdx.y;
+  const int n_lo = s * ipb, n_hi = min(N, n_lo + ipb);
+  // the thread's (up to two) pieces are requested before the rows are added up
+  float4 xv[2], uv[2];
+  int64_t off[2];
+  bool have[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int img = n_lo + (tid >> 3) + 32 * u;
+    have[u] = img < n_hi;
+    off[u] = ((int64_t)(have[u] ? img : n_lo) * C + c) * 4;
+    xv[u] = *reinterpret_cast<const float4*>(A.x + off[u]);
+    if constexpr (PAIR) uv[u] = *reinterpret_cast<const float4*>(B.x + off[u]);
+    else uv[u] = residual ? *reinterpret_cast<const float4*>(residual + off[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const bool writer = s == 0 && tid < 8;
+  const Hw4Stats a = bn_hw4_stats(A, c, C, writer, swa);
+  Hw4Stats b = {0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (PAIR) b = bn_hw4_stats(B, c, C, writer, swb);
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    if (!have[u]) continue;
+    const float4 v = xv[u], q = uv[u];
+    float4 r;
+    if constexpr (PAIR) {
+      r.x = ((v.x - a.mean) * a.rsd * a.w + a.b) + ((q.x - b.mean) * b.rsd * b.w + b.b);
+      r.y = ((v.y - a.mean) * a.rsd * a.w + a.b) + ((q.y - b.mean) * b.rsd * b.w + b.b);
+      r.z = ((v.z - a.mean) * a.rsd * a.w + a.b) + ((q.z - b.mean) * b.rsd * b.w + b.b);
+      r.w = ((v.w - a.mean) * a.rsd * a.w + a.b) + ((q.w - b.mean) * b.rsd * b.w + b.b);
+    } else {
+      r.x = (v.x - a.mean) * a.rsd * a.w + a.b;
+      r.y = (v.y - a.mean) * a.rsd * a.w + a.b;
+      r.z = (v.z - a.mean) * a.rsd * a.w + a.b;
+      r.w = (v.w - a.mean) * a.rsd * a.w + a.b;
+      if (residual) { r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w; }
+    }
+    *reinterpret_cast<float4*>(y + off[u]) = r;
+  }
+}
+
 // ---- input pipeline on the device (test/ResNet_CIFAR10_cuda.py:129-148, 180-184) -----------------
 // augment_batch: reflect-pad by `pad`, crop at (ys, xs), horizontal flip, optional erase rectangle,
 // clip to [-1, 1] — pure data movement, bit-exact.  The per-image decisions (drawn on the host in
@@ -1887,6 +1972,16 @@ int dfhip_bn2d_forward_partials(const float* x, const float* partials, int rows,
   DF_CHECK_ARG(x && y && partials, "bn2d_forward_partials: null array");
   double n = (double)N * C * HW;
   ProfScope prof("bn2d_fwd", 0.0, (residual ? 12.0 : 8.0) * n);
+  static int hw4_on = getenv("DFHIP_BN_FWD_HW4") ? atoi(getenv("DFHIP_BN_FWD_HW4")) : 1;
+  if (hw4_on && HW == 4 && C % 8 == 0) {
+    // 2 x 2 planes: eight channels (a line per image) x 64 images per workgroup
+    const int ipb4 = 64, S4 = (int)df_ceil_div(N, ipb4);
+    BnFwdSet A = {x, partials, rows, gamma, beta, save_mean, save_var, running_mean, running_var, eps, momentum};
+    DF_LAUNCH((k_bn_apply_partials_hw4<false>), dim3((unsigned)(C / 8), (unsigned)S4), dim3(kThreads), 0, stream(), A, A, residual,
+              y, N, C, ipb4);
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
   int S, ipb;
   bn_split(N, C, S, ipb);
   DF_LAUNCH(k_bn_apply_partials, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), x, partials,
@@ -1970,6 +2065,14 @@ int dfhip_bn2d_forward_partials_pair(const float* xa, const float* partials_a, i
                 momentum_a};
   BnFwdSet B = {xb, partials_b, rows_b, gamma_b, beta_b, save_mean_b, save_var_b, running_mean_b, running_var_b, eps_b,
                 momentum_b};
+  static int hw4_on = getenv("DFHIP_BN_FWD_HW4") ? atoi(getenv("DFHIP_BN_FWD_HW4")) : 1;
+  if (hw4_on && HW == 4 && C % 8 == 0) {
+    const int ipb4 = 64, S4 = (int)df_ceil_div(N, ipb4);
+    DF_LAUNCH((k_bn_apply_partials_hw4<true>), dim3((unsigned)(C / 8), (unsigned)S4), dim3(kThreads), 0, stream(), A, B,
+              (const float*)nullptr, y, N, C, ipb4);
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
   DF_LAUNCH(k_bn_apply_partials_pair, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), A, B, y, N,
                      C, HW, ipb);
   DF_LAUNCH_CHECK();
