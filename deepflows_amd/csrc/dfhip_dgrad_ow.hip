@@ -500,7 +500,7 @@ template <int O, int GEO, bool PAIR, bool TR, int HS = 1>
 __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__ dy, const float* __restrict__ w,
                                                        const float* __restrict__ add, float* __restrict__ dx, int C,
                                                        const float* __restrict__ dy2, const float* __restrict__ w2, int S,
-                                                       int xo) {
+                                                       int xo, int coal) {
   static_assert(!PAIR || GEO >= 1, "the shortcut rides on the stride-2 forms");
   static_assert(GEO != 2 || TR, "the sub-image form reads its planes through the strip");
   static_assert(HS == 1 || (HS == 2 && GEO != 2), "row halves: whole 4 x 4 images only");
@@ -710,6 +710,39 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
   else products(std::integral_constant<int, 0>{});
   __syncthreads();                                  // the weight image is dead: it becomes the exchange area
   f32x4* ex = reinterpret_cast<f32x4*>(smem);
+  if (coal) {
+    // All four waves leave their partial tiles in LDS, then the 256 threads walk the workgroup's output in MEMORY order --
+    // (image, channel, row): 16-byte pieces that are neighbours in dx -- and add the four partials of a piece in wave
+    // order (the sums of the one-wave epilogue below, bit for bit).  A lane of the accumulator is an image: stored
+    // straight from the registers every lane of a store instruction is a line of its own (64 lines, and as many for
+    // the gradient the tensor already holds).
+#pragma unroll
+    for (int q = 0; q < NQ; q++) ex[(wave * NQ + q) * 64 + lane] = acc[q];
+    __syncthreads();
+    const float* exf = reinterpret_cast<const float*>(smem);
+    const int rowp = GEO == 2 ? S : 4, plane = GEO == 2 ? S * S : 16;
+    const int64_t wbase = ((int64_t)n0 * C + c0) * plane + (GEO == 2 ? 4 * qy * S + 4 * qx : 0) + 8 * hz;
+#pragma unroll
+    for (int i = 0; i < 16 * 16 * NY / 256; i++) {
+      const int f = tid + 256 * i;
+      const int y = f % NY, ch = (f / NY) % 16, im = f / (NY * 16);
+      const int src = ((ch >> 2) * 16 + im) * 4 + (ch & 3);         // float index of (lane, v) inside a tile's 64 x 4 block
+      f32x4 r;
+#pragma unroll
+      for (int xx = 0; xx < 4; xx++) {
+        const int q = y * 4 + xx;
+        float t = exf[(0 * NQ + q) * 256 + src];
+        t += exf[(1 * NQ + q) * 256 + src];
+        t += exf[(2 * NQ + q) * 256 + src];
+        t += exf[(3 * NQ + q) * 256 + src];
+        r[xx] = t;
+      }
+      const int64_t at = wbase + ((int64_t)im * C + ch) * plane + rowp * y;
+      if (add) r += *reinterpret_cast<const f32x4*>(add + at);
+      *reinterpret_cast<f32x4*>(dx + at) = r;
+    }
+    return;
+  }
   if (wave > 0) {
 #pragma unroll
     for (int q = 0; q < NQ; q++) ex[((wave - 1) * NQ + q) * 64 + lane] = acc[q];
@@ -744,7 +777,9 @@ int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* 
   // whole images give (N / 16) x (C / 16) workgroups: where that leaves CUs without one, a workgroup takes two image rows
   const bool halves = GEO != 2 && tr && halves_env && (N / 16) * (C / 16) < num_cus();
   dim3 grid((unsigned)(N / 16), (unsigned)(C / 16), (unsigned)(GEO == 2 ? (S / 4) * (S / 4) : (halves ? 2 : 1)));
-  const size_t base = std::max((size_t)(PAIR ? 5 : 4) * O * 16, (size_t)3 * 16 * 64 * 4) * sizeof(float);
+  static int coal_env = getenv("DFHIP_IMG4_COAL") ? atoi(getenv("DFHIP_IMG4_COAL")) : 1;
+  const int coal = coal_env ? 1 : 0;               // the epilogue in memory order (four partial tiles in LDS instead of three)
+  const size_t base = std::max((size_t)(PAIR ? 5 : 4) * O * 16, (size_t)4 * 16 * 64 * 4) * sizeof(float);
   const size_t lds = base + (tr ? (size_t)4 * kImg4Strip * sizeof(float) : 0);
   // blockIdx.y selects 16 input channels' weight columns (NSL slices x O), blockIdx.x 16 images of dY
   const int dyp = GEO == 0 ? 16 : (GEO == 1 ? 4 : (S / 2) * (S / 2));
@@ -762,11 +797,11 @@ int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* 
     attr = true;
   }
   if constexpr (GEO == 2) {
-    DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
+    DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo, coal);
   } else {
-    if (halves) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true, 2>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
-    else if (tr) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
-    else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, false>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
+    if (halves) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true, 2>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo, coal);
+    else if (tr) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo, coal);
+    else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, false>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo, coal);
   }
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
