@@ -18,6 +18,15 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // BatchNorm descriptors of one launch, as the kernels see them
+// taps (1, 1), (1, 2) and (2, 1), (2, 2) of a 3x3 weight record are two pairs of neighbouring floats: two 8-byte loads (4-byte
+// aligned: the records are 36 bytes apart) instead of four 4-byte ones -- the weight slices of a workgroup were 8-64 load
+// instructions per thread, each a strided gather over ~18 lines
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ void load_taps_4578(const float* __restrict__ q, float (&out)[4]) {
+  const f32x2u a = *reinterpret_cast<const f32x2u*>(q + 4), b = *reinterpret_cast<const f32x2u*>(q + 7);
+  out[0] = a[0]; out[1] = a[1]; out[2] = b[0]; out[3] = b[1];
+}
+
 struct OwBn {
   BnBwdIn in, in2;             // of dy (and of the shortcut's dy2); rows == nullptr: dz = dy
   const float* zt[2];          // the (<= 2) layers whose output gradient dx is: their inputs and batch means
@@ -72,7 +81,7 @@ struct OwGeo {
   // the NSL weights of one (o, c) pair, from the (O, C, k, k) tensor
   __device__ static void slices(const float* __restrict__ w, int64_t oc, float (&out)[4]) {
     if (GEO == 2) { out[0] = w[oc]; out[1] = out[2] = out[3] = 0.0f; }
-    else { const float* q = w + oc * 9; out[0] = q[4]; out[1] = q[5]; out[2] = q[7]; out[3] = q[8]; }
+    else load_taps_4578(w + oc * 9, out);
   }
 };
 
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__
     for (int i = 0; i < 8; i++) {
       const int e = tid + 256 * (i0 + i), o = e >> 4, c = e & 15;
       const float* q = w + ((int64_t)o * C + c0 + c) * 9;
-      wv[i][0] = q[4]; wv[i][1] = q[5]; wv[i][2] = q[7]; wv[i][3] = q[8];
+      load_taps_4578(q, wv[i]);
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -656,7 +665,7 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
     for (int i = 0; i < PB; i++) {
       const int e = tid + 256 * (i0 + i), o = e >> 4, c = e & 15;
       const float* q = w + ((int64_t)o * C + c0 + c) * 9;
-      wv[i][0] = q[4]; wv[i][1] = q[5]; wv[i][2] = q[7]; wv[i][3] = q[8];
+      load_taps_4578(q, wv[i]);
       wv2[i] = PAIR ? w2[(int64_t)o * C + c0 + c] : 0.0f;
     }
 #pragma unroll
