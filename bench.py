@@ -197,6 +197,8 @@ def pmc_file(workload, dgrad, explicit=None):
                        f"is {csrc_fingerprint()}: stale, not quoted")
             continue
         return pmc, f"{rel} (git {pmc.get('git', '?')}, kernel sources {pmc['csrc_sha16']})"
+    if len(why) > 2:                      # (the newest two say it all)
+        why = why[:2] + [f"... and {len(why) - 2} older set(s)"]
     return None, "; ".join(why) if why else "no PMC pass of this workload / mode on file"
 
 
