@@ -379,26 +379,28 @@ def test_adam_notices_a_step_count_the_device_does_not_share(hip_device):
     Graph.free_graph_all()
 
 
-def test_paired_batchnorm_matches_two_layers(hip_device):
+@pytest.mark.parametrize("N,C,H,O", [(8, 32, 16, 64), (32, 128, 4, 256)])
+def test_paired_batchnorm_matches_two_layers(hip_device, N, C, H, O):
     """bn_a(conv_a(x)) + bn_b(conv_b(x)) as the paired node (one launch each way) against the two separate
-    BatchNorm nodes + residual add: outputs, input / parameter gradients and running statistics."""
+    BatchNorm nodes + residual add: outputs, input / parameter gradients and running statistics.  (The second shape ends on
+    2 x 2 planes: the kernels with eight channels per workgroup.)"""
     import numpy as np
     from deepflows_amd import nn, tensor
     from deepflows_amd.tensor import Graph, Tensor
     F = nn.functional
     dev = hip_device
     rng = np.random.default_rng(3)
-    x = rng.standard_normal((8, 32, 16, 16)).astype(np.float32)
-    gy = rng.standard_normal((8, 64, 8, 8)).astype(np.float32)
+    x = rng.standard_normal((N, C, H, H)).astype(np.float32)
+    gy = rng.standard_normal((N, O, H // 2, H // 2)).astype(np.float32)
     results = []
     for paired in (True, False):
         np.random.seed(5)
-        conv_a = nn.Conv2d(32, 64, kernel_size=3, stride=2, padding=1, bias=False, device=dev)
-        conv_b = nn.Conv2d(32, 64, kernel_size=1, stride=2, padding=0, bias=False, device=dev)
-        bn_a, bn_b = nn.BatchNorm2d(64, device=dev), nn.BatchNorm2d(64, device=dev)
+        conv_a = nn.Conv2d(C, O, kernel_size=3, stride=2, padding=1, bias=False, device=dev)
+        conv_b = nn.Conv2d(C, O, kernel_size=1, stride=2, padding=0, bias=False, device=dev)
+        bn_a, bn_b = nn.BatchNorm2d(O, device=dev), nn.BatchNorm2d(O, device=dev)
         for bn, s in ((bn_a, 1.0), (bn_b, 2.0)):
             bn.train()
-            bn.weight.data.device.from_numpy((rng.standard_normal((1, 64, 1, 1)) * 0 + s).astype(np.float32), bn.weight.data._handle)
+            bn.weight.data.device.from_numpy((rng.standard_normal((1, O, 1, 1)) * 0 + s).astype(np.float32), bn.weight.data._handle)
         xt = Tensor(x, device=dev, requires_grad=True)
         za, zb = conv_a(xt), conv_b(xt)
         if paired:
@@ -418,7 +420,7 @@ def test_paired_batchnorm_matches_two_layers(hip_device):
 
 
 @pytest.mark.parametrize("C,HW,dgrad", [(32, 16, "overwrite"), (64, 8, "overwrite"), (128, 4, "overwrite"),
-                                         (64, 8, "accumulate")])
+                                         (256, 2, "overwrite"), (64, 8, "accumulate")])
 def test_bn_applied_on_the_next_convolutions_loads(hip_device, C, HW, dgrad):
     """conv2(bn1(conv1(x))) of a residual block (no activation in between) with bn1 applied on conv2's operand loads
     (one node, bn1's output never written) against the three separate nodes: output, BatchNorm partials consumed by
