@@ -692,7 +692,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
   }
   request(0);
   f32x2 bn_pair = {1.0f, 0.0f};
-  if constexpr (combine) {
+  auto finish_table = [&]() {
     float tn = 0.0f, t1 = 0.0f, t2 = 0.0f;
     auto add_rows = [&](int r0) {
 #pragma unroll
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
       bn.affine[2 * c] = bn_pair[0];
       bn.affine[2 * c + 1] = bn_pair[1];
     }
-  }
+  };
 #pragma unroll
   for (int ch = 0; ch < NCHK; ch++) {
 #pragma unroll
@@ -768,6 +768,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (combine) {
+      // (the sums are finished HERE, behind the first slice's commit: the rows' latency hides under it)
+      if (ch == 0) {
+        finish_table();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
     if (aff) {
 #pragma unroll
       for (int p = 0; p < 2; p++) {
