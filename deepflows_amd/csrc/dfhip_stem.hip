@@ -49,7 +49,8 @@ __device__ unsigned long long g_st2[512 * 8 * 8];
         (i) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();                     \
   } while (0)
 static void st2_dump(const char* what, int gx) {
-  static int calls = 0;
+  static int calls_f = 0, calls_b = 0;                 // (forward and backward alternate: a counter each)
+  int& calls = what[0] == 'f' ? calls_f : calls_b;
   if (++calls % 20) return;
   std::vector<unsigned long long> h((size_t)gx * 8 * 8);
   (void)hipStreamSynchronize(stream());
