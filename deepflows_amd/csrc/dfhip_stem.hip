@@ -159,6 +159,7 @@ __global__ __launch_bounds__(512) void k_stem_fwd_sel(const float* __restrict__ 
   __shared__ float Wl[32 * KK + 32];
   __shared__ __attribute__((aligned(16))) float Xl[C * G::CH];
   __shared__ float sred[8][2][32], sshift[8][2][16], scount[8], Gl[32], Bl[32];
+  __shared__ __attribute__((aligned(16))) float Tz[8][32 * 16];     // a wave's pooled row: [channel][16 windows], stored as 16-byte pieces
   ST2(6); ST2(0);
   int item = blockIdx.x;
   f32x4 tv[QR];
@@ -256,7 +257,6 @@ __global__ __launch_bounds__(512) void k_stem_fwd_sel(const float* __restrict__ 
       // the window's extreme: vertical in registers, horizontal from the neighbouring lane (DPP); a flipped sign bit
       // turns a minimum into a maximum (exact).  Both lanes of a pair hold the window's value and store it to the same
       // address (no exec juggling per store); the scratch tensor has 32 channel planes whatever O is.
-      float* zo = zsel + ((int64_t)n * 32 * pairs + pr) * 16 + (l31 >> 1);
       float m[16];
 #pragma unroll
       for (int rr = 0; rr < 16; rr++) {
@@ -265,11 +265,25 @@ __global__ __launch_bounds__(512) void k_stem_fwd_sel(const float* __restrict__ 
       }
 #pragma unroll
       for (int rr = 0; rr < 16; rr++) m[rr] = vmax(m[rr], lane_xor1(m[rr]));
+      // through the wave's LDS strip: two 16-byte stores per lane (16 channel segments of 64 bytes each) instead of sixteen
+      // 4-byte ones (two segments each) -- the store instructions of the eight waves were the busiest unit of the loop
 #pragma unroll
       for (int rr = 0; rr < 16; rr++) {
         const unsigned sb = ((negmask >> rr) & 1u) << 31;
-        zo[(int64_t)((rr & 3) + 8 * (rr >> 2) + 4 * half) * pairs * 16] = __uint_as_float(__float_as_uint(m[rr]) ^ sb);
+        Tz[wave][((rr & 3) + 8 * (rr >> 2) + 4 * half) * 16 + (l31 >> 1)] = __uint_as_float(__float_as_uint(m[rr]) ^ sb);
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int h2 = 0; h2 < 2; h2++) {
+        const int chn = 16 * h2 + (lane >> 2);
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(&Tz[wave][chn * 16 + (lane & 3) * 4]);
+        *reinterpret_cast<f32x4*>(zsel + (((int64_t)n * 32 + chn) * pairs + pr) * 16 + (lane & 3) * 4) = v4;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     item = next;
     if (item < N) {
