@@ -200,5 +200,7 @@ def test_bench_exchange_path_runs_on_one_gpu():
     # round 4: the exchange is part of the captured graph, the gradients are formed in the bucket, its time is reported
     assert d["config"]["exchange_captured"] is True, d["config"]["exchange_fallback_reason"]
     assert d["config"]["grads_copied_into_bucket"] == 0
-    assert d["config"]["exchange_us_in_graph"] is not None and d["config"]["exchange_us_in_graph"] < 25.0
+    # (a timing: measured -12 ... +6 us over six boxes, best of three alternating pairs; round 3's pack launch + eager
+    # exchange behind the graph was ~40 us -- the bound only has to tell the two apart)
+    assert d["config"]["exchange_us_in_graph"] is not None and d["config"]["exchange_us_in_graph"] < 35.0
     print("exchange at world 1 inside the captured step: %+.1f us per step" % d["config"]["exchange_us_in_graph"])
