@@ -72,7 +72,10 @@ def test_conv_linearity_and_bias(hip_device):
     assert_close(out[3], out[0] + b.reshape(1, O, 1, 1), 1e-6, "bias epilogue")
 
 
-@pytest.mark.parametrize("shape", [(256, 32, 32, 32), (256, 64, 8, 8), (256, 256, 2, 2)])
+@pytest.mark.parametrize("shape", [(256, 32, 32, 32), (256, 64, 8, 8), (256, 256, 2, 2),
+                                   # 2 x 2 planes, eight channels per workgroup: a ragged batch, the largest batch and the
+                                   # smallest channel count that form takes, one image more than it takes
+                                   (80, 256, 2, 2), (512, 8, 2, 2), (513, 16, 2, 2)])
 def test_batchnorm_full_size(hip_device, shape):
     mod = hip_device.mod
     n, c, h, w = shape

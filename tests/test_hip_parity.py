@@ -99,7 +99,8 @@ def test_wide_resnet18_one_step(hip_device):
 
 
 @pytest.mark.parametrize("shape", [(8, 32, 16, 16, 32, 3, 1, 1), (6, 32, 16, 16, 64, 3, 2, 1), (4, 64, 8, 8, 64, 3, 1, 1),
-                                   (16, 128, 4, 4, 128, 3, 1, 1), (32, 256, 2, 2, 256, 3, 1, 1), (64, 128, 2, 2, 80, 3, 1, 1), (5, 32, 16, 16, 64, 1, 2, 0),
+                                   (16, 128, 4, 4, 128, 3, 1, 1), (32, 256, 2, 2, 256, 3, 1, 1), (64, 128, 2, 2, 80, 3, 1, 1),
+                                   (80, 128, 2, 2, 64, 3, 1, 1), (5, 32, 16, 16, 64, 1, 2, 0),
                                    (8, 64, 8, 8, 128, 1, 2, 0),
                                    (3, 16, 12, 12, 40, 3, 1, 1)])
 def test_conv_bn_partials_and_residual(hip_device, shape):
