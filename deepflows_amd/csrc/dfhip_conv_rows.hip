@@ -897,8 +897,8 @@ int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y,
   int nt, ts, ow;
   // 16- and 8-wide layers: eight tile sets x one channel tile per workgroup (twice the pixel loads, half the weight image and
   // half as many partial rows for the consumer of the statistics: 15.1 -> 14.5 and 16.1 -> 15.2 us plain, -0.4 us with a
-  // BatchNorm operand); DFHIP_ROWMMA_TS8=0: four tile sets x two channel tiles (rounds 2-3), bit 0 / 1: plain / BatchNorm form
-  static int ts8 = getenv("DFHIP_ROWMMA_TS8") ? atoi(getenv("DFHIP_ROWMMA_TS8")) : 3;
+  // BatchNorm operand); DFHIP_ROWMMA_TS8=0: four tile sets x two channel tiles (rounds 2-3), bit 0 / 1 / 2: plain / BatchNorm form / accumulate-mode input gradient
+  static int ts8 = getenv("DFHIP_ROWMMA_TS8") ? atoi(getenv("DFHIP_ROWMMA_TS8")) : 7;
   const bool wide = (ts8 & 1) && !bn && partials, wide_bn = (ts8 & 2) && bn;
   if (W == 16 && C == 32) { nt = 4; ts = (wide || wide_bn) ? 8 : 4; ow = (wide || wide_bn) ? 1 : 2; }
   else if (W == 8 && C == 64) { nt = 2; ts = (wide || wide_bn) ? 8 : 4; ow = (wide || wide_bn) ? 1 : 2; }
@@ -950,15 +950,20 @@ int run_conv_rowmma_dgrad(const float* dy, const float* w, const float* add, flo
   const int64_t HW = (int64_t)H * W;
   if (HW % 16 != 0) return -1;
   const int64_t tiles = (int64_t)N * HW / 16;
+  // (eight tile sets x one channel tile per workgroup on the 16- and 8-wide layers, as the forward launches: DFHIP_ROWMMA_TS8 bit 2)
+  static int ts8 = getenv("DFHIP_ROWMMA_TS8") ? atoi(getenv("DFHIP_ROWMMA_TS8")) : 7;
+  const bool wide = (ts8 & 4) != 0;
   int nt, ts, ow;
-  if (W == 16 && O == 32) { nt = 4; ts = 4; ow = 2; }
-  else if (W == 8 && O == 64) { nt = 2; ts = 4; ow = 2; }
+  if (W == 16 && O == 32) { nt = 4; ts = wide ? 8 : 4; ow = wide ? 1 : 2; }
+  else if (W == 8 && O == 64) { nt = 2; ts = wide ? 8 : 4; ow = wide ? 1 : 2; }
   else if (W == 4 && H == 4 && O == 128) { nt = 1; ts = 8; ow = 1; }
   else return -1;
   if (C % (16 * ow) != 0 || tiles % (ts * nt) != 0 || (W == 16 && H % nt != 0)) return -1;
   const int64_t gx = tiles / (ts * nt);
   if (gx * (C / (16 * ow)) < num_cus() / 2) return -1;
   dim3 grid((unsigned)gx, (unsigned)(C / (16 * ow)));
+  if (wide && W == 16) return launch_rowmma<4, 32, 4, false, 8, 1, 4, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
+  if (wide && W == 8) return launch_rowmma<3, 64, 2, false, 8, 1, 4, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
   if (W == 16) return launch_rowmma<4, 32, 4, false, 4, 2, 4, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
   if (W == 8) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
   return launch_rowmma<2, 128, 1, true, 8, 1, 8, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
