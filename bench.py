@@ -273,7 +273,7 @@ def epoch_bench(args):
         trainer.run_epoch(data_loader(X[:tail], Y[:tail], batch, shuffle=False), 0, 30)   # and the tail-size one
     mod.synchronize()
     times = []
-    for ep in range(2):
+    for ep in range(4):
         t0 = time.perf_counter()
         losses = trainer.run_epoch(loader, ep + 1, 30)
         mod.synchronize()
@@ -306,7 +306,7 @@ def epoch_bench(args):
         bound = f"{k} ({host[k]:.3f} ms per batch; the host's stages add up to {sum(host.values()):.3f} ms against {stages['gpu_step_ms']:.3f} ms of GPU work)"
     print(json.dumps({"metric": "epoch images/sec, ResNet-18 CIFAR-10 bs=%d through DataLoader + device input pipeline" % batch,
                       "value": value, "unit": "images/s", "n_gpus": 1, "epoch_images": n_img, "epoch_s": epoch_s,
-                      "epochs_timed": len(times), "batches": len(losses), "tail_batch": tail,
+                      "epochs_timed": len(times), "epoch_s_all": [round(t, 5) for t in times], "batches": len(losses), "tail_batch": tail,
                       "resident_batch_images_per_s": resident, "fraction_of_resident": value / resident,
                       "stages_ms_per_batch": {k: round(v, 4) for k, v in stages.items()}, "bound_stage": bound,
                       "final_loss": float(losses[-1]), "model": args.model, "data": "synthetic", "dtype": "f32",
