@@ -4,9 +4,11 @@
 // Reference being replaced: tensor.py:708 (dC . B^T) -> __im2col2d.grad_fn (nn/functional.py:285-294: the k*k
 // overlapping windows are ASSIGNED in (i, j) row-major order) -> __pad2d.grad_fn (:307-313); with the BatchNorm
 // descriptors also the autograd chain of nn/modules/batchnorm.py:30-55 on either side of the convolution.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 #include <type_traits>
 
 #include "dfhip_bnbwd.h"
@@ -26,6 +28,41 @@ __device__ __forceinline__ void load_taps_4578(const float* __restrict__ q, floa
   const f32x2u a = *reinterpret_cast<const f32x2u*>(q + 4), b = *reinterpret_cast<const f32x2u*>(q + 7);
   out[0] = a[0]; out[1] = a[1]; out[2] = b[0]; out[3] = b[1];
 }
+
+// diagnostic build only (-DDFHIP_OW_STAMPS): per-wave cycle stamps of k_dgrad_ow_s1 (s_memtime; 6 / 7: s_memrealtime at the start /
+// end of the wave), dumped for every 20th launch of each instantiation: where a 8-12 us launch's cycles go
+#ifdef DFHIP_OW_STAMPS
+__device__ unsigned long long g_ow_stamps[1024 * 8 * 8];
+#define OW_STAMP(i)                                                                                         \
+  do {                                                                                                      \
+    if ((threadIdx.x & 63) == 0 && (blockIdx.y * gridDim.x + blockIdx.x) < 1024)                            \
+      g_ow_stamps[((blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8 + (i)] =             \
+          (i) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();                       \
+  } while (0)
+static void ow_stamp_dump(const char* what, int wgs, int nw, int* calls) {
+  if (++*calls % 20) return;
+  const int nb = wgs < 1024 ? wgs : 1024;
+  std::vector<unsigned long long> h((size_t)nb * 8 * 8);
+  (void)hipStreamSynchronize(stream());
+  (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_ow_stamps), h.size() * sizeof(unsigned long long));
+  double seg[6] = {0};
+  unsigned long long r0 = ~0ull, r1 = 0, rs = 0;
+  size_t cnt = 0;
+  for (int b = 0; b < nb; b++)
+    for (int w = 0; w < nw; w++) {
+      const unsigned long long* r = &h[((size_t)b * 8 + w) * 8];
+      for (int k = 1; k <= 5; k++) seg[k] += (double)(r[k] - r[k - 1]);
+      r0 = std::min(r0, r[6]); r1 = std::max(r1, r[7]); rs = std::max(rs, r[6]);
+      cnt++;
+    }
+  fprintf(stderr, "[ow-stamp] %s, %d workgroups x %d waves: first start -> last end %.2f us, last wave starts +%.2f us; mean cycles per wave: "
+          "until the loads are issued %.0f, weights to LDS + table %.0f, barrier %.0f, operand transform + MFMAs %.0f, stores + rows %.0f\n",
+          what, wgs, nw, (double)(r1 - r0) / 100.0, (double)(rs - r0) / 100.0, seg[1] / cnt, seg[2] / cnt, seg[3] / cnt, seg[4] / cnt,
+          seg[5] / cnt);
+}
+#else
+#define OW_STAMP(i) do { } while (0)
+#endif
 
 struct OwBn {
   BnBwdIn in, in2;             // of dy (and of the shortcut's dy2); rows == nullptr: dz = dy
@@ -115,6 +152,7 @@ __global__ __launch_bounds__(64 * NW) void k_dgrad_ow_s1(const float* __restrict
   const int lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
+  OW_STAMP(6); OW_STAMP(0);
   const int HW = H << lw;
   const int c0 = blockIdx.y * 32;
   const int tile = min((int)blockIdx.x * NW + wave, tiles - 1);   // 32 consecutive pixels of one image (clamped: a
@@ -208,6 +246,7 @@ __global__ __launch_bounds__(64 * NW) void k_dgrad_ow_s1(const float* __restrict
       load_operands();
     }
   }
+  OW_STAMP(1);
 #pragma unroll
   for (int i = 0; i < PAIRS; i++) {
     const int e = threadIdx.x + NT * i, o = e >> 5, c = e & 31;
@@ -215,8 +254,12 @@ __global__ __launch_bounds__(64 * NW) void k_dgrad_ow_s1(const float* __restrict
     for (int q = 0; q < NSL; q++) Wl[q][o][c] = wv[i][q];
     if constexpr (PAIR) Wl[NSL][o][c] = wv2[i];
   }
+  OW_STAMP(2);
   __syncthreads();
+  OW_STAMP(3);
+#ifndef DFHIP_OW_STAMPS
   if constexpr (NST == 0) { if (!live) return; }
+#endif
   if constexpr (BN) {
     __builtin_amdgcn_sched_barrier(0);
     load_epilogue();
@@ -255,6 +298,7 @@ __global__ __launch_bounds__(64 * NW) void k_dgrad_ow_s1(const float* __restrict
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], mine ? sv2[kp] : 0.0f, acc, 0, 0, 0);
     }
   }
+  OW_STAMP(4);
   float outv[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) outv[r] = acc[r] + held[r];
@@ -288,6 +332,7 @@ __global__ __launch_bounds__(64 * NW) void k_dgrad_ow_s1(const float* __restrict
       bn.rows[((int64_t)blockIdx.x * C + c0) * KS + threadIdx.x] = t;
     }
   }
+  OW_STAMP(5); OW_STAMP(7);
 }
 
 // The same for 128 / 256 output channels: ONE tile per workgroup, its four waves split the reduction
@@ -843,6 +888,10 @@ int launch_ow_s1(const float* dy, const float* w, const float* add, float* dx, i
     DF_LAUNCH((k_dgrad_ow_s1<O, GEO, PAIR, false, 0, 4>), grid, dim3(256), 0, stream(), dy, w, add, dx, C, H, lw, tiles, pg,
               dy2, w2, bn);
     DF_LAUNCH_CHECK();
+#ifdef DFHIP_OW_STAMPS
+    { static int calls = 0; char what[96]; snprintf(what, sizeof(what), "O %d GEO %d PAIR %d plain", O, GEO, (int)PAIR);
+      ow_stamp_dump(what, (int)(grid.x * grid.y), 4, &calls); }
+#endif
     return DFHIP_OK;
   }
   if constexpr (GEO == 2) {
@@ -875,6 +924,11 @@ int launch_ow_s1(const float* dy, const float* w, const float* add, float* dx, i
 #undef DF_OW_NW
 #undef DF_OW
     DF_LAUNCH_CHECK();
+#ifdef DFHIP_OW_STAMPS
+    { static int calls[2][3] = {{0}}; char what[96];
+      snprintf(what, sizeof(what), "O %d GEO %d PAIR %d pending %d rows-out %d", O, GEO, (int)PAIR, (int)bni, nst);
+      ow_stamp_dump(what, (int)(grid.x * grid.y), nw, &calls[bni ? 1 : 0][nst]); }
+#endif
     return DFHIP_OK;
   }
 }
