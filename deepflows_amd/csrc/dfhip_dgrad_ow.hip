@@ -108,6 +108,19 @@ struct OwGeo {
       const int ry = l31 >> (lw - 1), rx = l31 & ((1 << (lw - 1)) - 1);
       const int R = b * (128 >> lw) + 2 * ry + py;          // flat row (n * H + y); H is even
       n = R / H; y = R - n * H; x = 2 * rx + px;
+    } else if (GEO == 0 && pg) {
+      // Stride 1 with pg: the tiles of a group of 32 / W images (H tiles) are its image rows 0 -- one tile -- and then the
+      // pixels of rows 1 .. H - 1 in memory order, H - 1 tiles.  A tile then never holds image row 0 TOGETHER with later
+      // rows, i.e. never all four tap classes: every wave runs two MFMA passes (x = 0 or not) where the waves of the
+      // tiles that held row 0 ran four -- and with one wave per SIMD those waves were the length of the launch.
+      const int W = 1 << lw, G = 32 >> lw;
+      const int g = t / H, k = t - g * H;
+      if (k == 0) { n = g * G + (l31 >> lw); y = 0; x = l31 & (W - 1); }
+      else {
+        const int q = (k - 1) * 32 + l31, per = (H - 1) << lw;
+        const int im = q / per, r2 = q - im * per;
+        n = g * G + im; y = 1 + (r2 >> lw); x = r2 & (W - 1);
+      }
     } else {
       const int HW = H << lw, p = t * 32 + l31;
       n = p / HW;
@@ -1017,7 +1030,13 @@ int run_dgrad_ow(const float* dy, const float* w, const float* add, float* dx, i
   if (lean_ok && (O == 32 || O == 64)) {
     if (bnform && geo == 2) return -2;
     const float* none = nullptr;
-#define DF_A(OV, GV) return launch_ow_s1<OV, GV, false>(dy, w, add, dx, C, H, lw, tiles, pg, none, none, bi, nullptr, so, dry_run)
+    // stride 1: tiles that never mix image row 0 with later rows (OwGeo::decode, `pg`): DFHIP_DGRAD_ROW0 bit 0: 16-wide images,
+    // bit 1: 8-wide ones
+    static int row0_env = getenv("DFHIP_DGRAD_ROW0") ? atoi(getenv("DFHIP_DGRAD_ROW0")) : 3;
+    const bool row0 = geo == 0 && W <= 32 && N % (32 / W) == 0 && tiles % H == 0 &&
+                      ((W == 16 && (row0_env & 1)) || (W == 8 && (row0_env & 2)));
+    const int pgs = geo == 0 ? (row0 ? 1 : 0) : pg;
+#define DF_A(OV, GV) return launch_ow_s1<OV, GV, false>(dy, w, add, dx, C, H, lw, tiles, pgs, none, none, bi, nullptr, so, dry_run)
     if (O == 32) { if (geo == 0) DF_A(32, 0); else if (geo == 1) DF_A(32, 1); else DF_A(32, 2); }
     else { if (geo == 0) DF_A(64, 0); else if (geo == 1) DF_A(64, 1); else DF_A(64, 2); }
 #undef DF_A

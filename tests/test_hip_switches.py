@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 OVERWRITE = [
     ("DFHIP_DGRAD_LEAN", "0"), ("DFHIP_DGRAD_IMG2", "0"), ("DFHIP_DGRAD_IMG4", "0"), ("DFHIP_DGRAD_PAIR", "0"),
-    ("DFHIP_DGRAD_IMG8", "0"), ("DFHIP_IMG4_TR", "0"), ("DFHIP_IMG4_HALVES", "0"), ("DFHIP_BN_INPUT_COMBINE", "0"), ("DFHIP_STEM_COMBINE_RIDES", "0"), ("DFHIP_IMG2_BN_INPUT", "0"), ("DFHIP_ROWMMA_TS8", "0"), ("DFHIP_BN_BWD_HW4", "0"), ("DFHIP_BN_FWD_HW4", "0"), ("DFHIP_IMG4_COAL", "0"), ("DFHIP_WGRAD_PAIR", "0"), ("DFHIP_WGRAD_DIRECT", "0"),
+    ("DFHIP_DGRAD_IMG8", "0"), ("DFHIP_IMG4_TR", "0"), ("DFHIP_IMG4_HALVES", "0"), ("DFHIP_BN_INPUT_COMBINE", "0"), ("DFHIP_STEM_COMBINE_RIDES", "0"), ("DFHIP_IMG2_BN_INPUT", "0"), ("DFHIP_ROWMMA_TS8", "0"), ("DFHIP_BN_BWD_HW4", "0"), ("DFHIP_BN_FWD_HW4", "0"), ("DFHIP_IMG4_COAL", "0"), ("DFHIP_DGRAD_ROW0", "0"), ("DFHIP_DGRAD_ROW0", "1"), ("DFHIP_WGRAD_PAIR", "0"), ("DFHIP_WGRAD_DIRECT", "0"),
     ("DFHIP_WGRAD_GROUP_DIV", "4"), ("DFHIP_WGRAD_ROWS", "0"), ("DFHIP_WGRAD_TAP", "0"), ("DFHIP_WGRAD_DEFER", "0"),
     ("DFHIP_WGRAD_STEM3", "0"), ("DFHIP_WGRAD_KT5", "0"), ("DFHIP_IGEMM_K5", "0"), ("DFHIP_IGEMM_K5_SPEC", "0"),
     ("DFHIP_IMG2_LEAN", "0"), ("DFHIP_SHORTCUT_LEAN", "0"), ("DFHIP_STEM_ROWS", "0"), ("DFHIP_VEC_STORE", "0"),
