@@ -17,6 +17,10 @@ bool profiling();             // per-family HIP-event profiling is switched on (
 bool capturing();             // a stream capture (dfhip_graph_begin) is open
 int ensure_init();             // lazy dfhip_init(LOCAL_RANK or 0)
 int num_cus();
+int overlap_cus();            // DFHIP_OVERLAP_CUS: CUs (a multiple of 8) of the backward chain's stream, 0 = one stream
+int make_masked_stream(hipStream_t* out, int first_bit, int nbits);
+int chain_begin();            // the library's launches go to the chain stream (after everything queued so far) ...
+int chain_end();              // ... and back (the library stream waits for the chain)
 
 // RAII HIP-event bracket around one kernel family launch (active only if profiling on)
 struct ProfScope {

@@ -48,7 +48,45 @@ static char g_devname[256] = "";
 static hipStream_t g_side = nullptr;
 static hipEvent_t g_side_fork_ev = nullptr, g_side_join_ev = nullptr;
 static bool g_side_target = false, g_side_pending = false;
-hipStream_t stream() { return g_side_target ? g_side : g_stream; }
+// Round 5: CU-partitioned streams.  Two streams of this stack run their kernels at the same time only when their CU masks
+// are DISJOINT (tools/probes/two_streams2.hip: a chain of dependent kernels beside one long kernel takes the sum of the two on
+// plain streams -- any number of hardware queues -- and the maximum on masked streams that share no CU).  A mask bit stands
+// for one CU of EVERY XCD (tools/probes/cu_mask_map.hip): bits 0..8n-1 = n CUs per XCD.  DFHIP_OVERLAP_CUS=n: during a
+// backward sweep (dfhip_wgrad_group_begin .. _end) the library's launches go to a "chain" stream on n CUs and the grouped
+// weight gradients (DFHIP_WGRAD_SIDE) to a stream on the other 256 - n.
+static hipStream_t g_chain = nullptr;
+static hipEvent_t g_chain_ev = nullptr;
+static bool g_chain_on = false;
+hipStream_t stream() { return g_side_target ? g_side : (g_chain_on ? g_chain : g_stream); }
+int overlap_cus() {
+  static int n = getenv("DFHIP_OVERLAP_CUS") ? atoi(getenv("DFHIP_OVERLAP_CUS")) : 0;
+  return (n >= 8 && n <= 248) ? (n & ~7) : 0;
+}
+int make_masked_stream(hipStream_t* out, int first_bit, int nbits) {
+  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int c = first_bit; c < first_bit + nbits && c < 256; c++) mask[c / 32] |= 1u << (c % 32);
+  DF_HIP(hipExtStreamCreateWithCUMask(out, 8, mask));
+  return DFHIP_OK;
+}
+int chain_begin() {
+  if (!overlap_cus() || g_chain_on) return DFHIP_OK;
+  if (!g_chain) {
+    int st = make_masked_stream(&g_chain, 0, overlap_cus());
+    if (st != DFHIP_OK) return st;
+    DF_HIP(hipEventCreateWithFlags(&g_chain_ev, hipEventDisableTiming));
+  }
+  DF_HIP(hipEventRecord(g_chain_ev, g_stream));
+  DF_HIP(hipStreamWaitEvent(g_chain, g_chain_ev, 0));
+  g_chain_on = true;
+  return DFHIP_OK;
+}
+int chain_end() {
+  if (!g_chain_on) return DFHIP_OK;
+  g_chain_on = false;
+  DF_HIP(hipEventRecord(g_chain_ev, g_chain));
+  DF_HIP(hipStreamWaitEvent(g_stream, g_chain_ev, 0));
+  return DFHIP_OK;
+}
 bool initialised() { return g_init; }
 int num_cus() { return g_num_cus; }
 
@@ -76,7 +114,17 @@ static int do_init(int device_id) {
     return DFHIP_INVALID_ARGUMENT;
   }
   DF_HIP(hipSetDevice(device_id));
-  DF_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  if (const char* cm = getenv("DFHIP_CU_MASK")) {
+    // diagnostic (round 5, tools/probes/two_streams2.hip): the library stream on a subset of the CUs -- "lo<N>" = mask bits
+    // 0..N-1, "hi<N>" = bits 256-N..255 (which CUs those are: tools/probes/cu_mask_map.hip)
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int n = atoi(cm + 2);
+    for (int c = 0; c < 256; c++)
+      if ((cm[0] == 'l' && c < n) || (cm[0] == 'h' && c >= 256 - n)) mask[c / 32] |= 1u << (c % 32);
+    DF_HIP(hipExtStreamCreateWithCUMask(&g_stream, 8, mask));
+  } else {
+    DF_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  }
   hipDeviceProp_t prop;
   DF_HIP(hipGetDeviceProperties(&prop, device_id));
   g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -894,6 +942,7 @@ struct UploadSlot {
   hipEvent_t consumed = nullptr; // the library stream has passed the kernels that read the destination
   bool in_flight = false;
   bool released = false;         // `consumed` was recorded behind the readers of the previous upload (dfhip_upload_release)
+  const void* last_dst = nullptr;  // the array the release point belongs to: the flag is honoured for an upload INTO IT only
 };
 static UploadSlot g_up[2];
 static hipStream_t g_copy_stream = nullptr;
@@ -922,8 +971,11 @@ int dfhip_upload_async(const void* host, float* dst, int64_t bytes, int slot) {
   // marked the end of those readers (dfhip_upload_release) the copy waits for exactly that point -- and runs beside
   // whatever was queued after it: the training step of the batch before --; otherwise it waits for everything queued so far
   // (round 3's behaviour: the copy of batch k + 1 then started only when step k had finished, ~0.1 ms per step exposed).
-  if (!u.released) DF_HIP(hipEventRecord(u.consumed, g_stream));
+  // (the release point says "the readers of the slot's LAST destination are queued": an upload through the same slot into
+  // another array -- a second pipeline of another batch shape shares g_up -- waits for everything queued so far instead)
+  if (!u.released || u.last_dst != (const void*)dst) DF_HIP(hipEventRecord(u.consumed, g_stream));
   u.released = false;
+  u.last_dst = dst;
   DF_HIP(hipStreamWaitEvent(g_copy_stream, u.consumed, 0));
   DF_HIP(hipMemcpyAsync(dst, u.pinned, (size_t)bytes, hipMemcpyHostToDevice, g_copy_stream));
   DF_HIP(hipEventRecord(u.done, g_copy_stream));

@@ -2618,7 +2618,12 @@ int group_flush() {
 int side_flush() {
   if (g_queue.empty()) return DFHIP_OK;
   if (!g_side) {
-    DF_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+    if (overlap_cus()) {
+      int st = make_masked_stream(&g_side, overlap_cus(), 256 - overlap_cus());
+      if (st != DFHIP_OK) return st;
+    } else {
+      DF_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+    }
     DF_HIP(hipEventCreateWithFlags(&g_side_fork, hipEventDisableTiming));
   }
   hipEvent_t done = nullptr;
@@ -3239,12 +3244,22 @@ int dfhip_stem_backward(const float* x, const float* z, const float* y, const fl
 int dfhip_wgrad_group_begin(void) {
   DF_INIT();
   g_group_on = true;
+  if (overlap_cus() && !capturing()) return chain_begin();
   return DFHIP_OK;
 }
 
 int dfhip_wgrad_group_end(void) {
   DF_INIT_KEEP();
   g_group_on = false;
+  if (overlap_cus()) {
+    // the side stream's launches join the chain, the chain joins the library stream, what is still queued runs on all CUs
+    if (!g_side_pending.empty()) {
+      int st = side_join();
+      if (st != DFHIP_OK) return st;
+    }
+    int st = chain_end();
+    if (st != DFHIP_OK) return st;
+  }
   return flush_deferred();
 }
 

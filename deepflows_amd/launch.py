@@ -118,19 +118,25 @@ def spawn_ranks(world, command, timeout=None, grace=20.0, out=None, err=None, en
                 pass
 
     # SIGTERM to the spawner (a job timeout) must not leave ranks behind that wait in a collective forever and hold their
-    # GPUs: it is turned into an exception that unwinds through the `finally` below
-    def on_term(signum, frame):
-        raise _Terminated(signum)
+    # GPUs.  The handler only sets a flag: the poll loop below sees it within 50 ms and unwinds through `finally` (an
+    # exception raised from the handler could land inside Popen -- a child that is not in `procs` yet -- or inside reap()).
+    term = {"signum": None}
 
-    old_term = None
+    def on_term(signum, frame):
+        term["signum"] = signum
+
+    _unset = object()
+    old_term = _unset
     if threading.current_thread() is threading.main_thread():
         try:
             old_term = signal.signal(signal.SIGTERM, on_term)
         except (ValueError, OSError):
-            old_term = None
+            old_term = _unset
     code = 0
     try:
         for r in range(world):
+            if term["signum"] is not None:
+                raise _Terminated(term["signum"])
             p = subprocess.Popen(command, env=rank_environment(r, world, port, base=env), stdout=subprocess.PIPE,
                                  stderr=None, text=True, bufsize=1)
             procs.append(p)
@@ -142,6 +148,8 @@ def spawn_ranks(world, command, timeout=None, grace=20.0, out=None, err=None, en
         deadline = None if timeout is None else time.monotonic() + timeout
         failed_at = None
         while True:
+            if term["signum"] is not None:
+                raise _Terminated(term["signum"])
             states = [p.poll() for p in procs]
             bad = [(r, s) for r, s in enumerate(states) if s not in (None, 0)]
             if bad and failed_at is None:
@@ -164,10 +172,11 @@ def spawn_ranks(world, command, timeout=None, grace=20.0, out=None, err=None, en
         err.write("[launch] signal %d: terminating the ranks\n" % int(e.args[0]))
     finally:
         # (a failed Popen of a later rank, KeyboardInterrupt, SIGTERM, any exception: no rank outlives the spawner)
-        reap()
-        if old_term is not None:
+        reap()                   # (a second SIGTERM while this runs only sets the flag again: the reap completes)
+        if old_term is not _unset:
             try:
-                signal.signal(signal.SIGTERM, old_term)
+                # (None = the previous handler was installed from C: SIG_DFL is the nearest thing Python can put back)
+                signal.signal(signal.SIGTERM, old_term if old_term is not None else signal.SIG_DFL)
             except (ValueError, OSError):
                 pass
     for p in procs:

@@ -575,9 +575,11 @@ class _Conv2dFused(_FusedNode):
                 if pend is not None:
                     g = _pending_materialise(pend, g)
                     self._plain_grad = (grad, g)
+                    pend = None                   # (dz exists now: the single-launch path below must not apply it again)
                 if spend is not None:
                     sg = _pending_materialise(spend, sg)
                     sib.grad = sg                 # (the shortcut's weight gradient then reads the plain tensor)
+                    spend = None
                 if dev.conv2d_dgrad_pair(g._handle, self.wd._handle, sg.compact()._handle, sib.wd._handle, h(add),
                                          out._handle, N, C, H, W, O):
                     sib._dx_delivered = True

@@ -50,6 +50,23 @@ def _is(x, op):
     return st is not None and st[0] == op
 
 
+_STATS_DONE = "running statistics already updated"
+
+
+def _consumed(bn_record):
+    """A fused launch has just run the BatchNorm of this record (running_mean / running_var updated ONCE, as the reference's
+    single module call does, nn/modules/batchnorm.py:44-52) without producing the record's own tensor.  Whoever still holds
+    the record and touches it later gets the same values from a normalisation that leaves the running statistics alone."""
+    st = _state(bn_record)
+    if st is not None and st[0] == "bn":
+        st[3] = _STATS_DONE
+
+
+def _stats_done(bn_record):
+    st = _state(bn_record)
+    return st is not None and st[3] == _STATS_DONE
+
+
 def _can_defer(x):
     """deferral applies to tensors of a fused device while gradients are recorded"""
     if not ENABLED or not is_grad_enable():
@@ -105,12 +122,17 @@ def max_pool2d(module, x):
     conv_l = _state(bn_l)[1]
     conv, bn = _state(conv_l)[2], _state(bn_l)[2]
     x0 = realize(_state(conv_l)[1])
+    if _stats_done(bn_l):                                  # (this BatchNorm call has been launched by another consumer)
+        return None
     out = F.stem_conv_bn_relu_pool_train(x0, conv, bn, module)
     if out is not None:                                    # one node, the convolution's output never exists
+        _consumed(bn_l)
         return out
     z = realize(conv_l)
     if F.bn_relu_maxpool2_fusable(z, bn, module):
-        return F.bn_relu_maxpool2_train(z, bn)             # pool(relu(bn(z))) as one node
+        out = F.bn_relu_maxpool2_train(z, bn)              # pool(relu(bn(z))) as one node
+        _consumed(bn_l)
+        return out
     return None                                            # (the caller pools realize(x))
 
 
@@ -140,18 +162,23 @@ def _mean(x, axis, keepdims):
 
 def _force(lz):
     """the node a deferred result stands for, launched on its own"""
-    op, x, module, _, _ = object.__getattribute__(lz, "_lz")
+    op, x, module, extra, _ = object.__getattribute__(lz, "_lz")
     if op == "conv":
-        if _is(x, "bn"):
+        if _is(x, "bn") and not _stats_done(x):
             # conv(bn(z)): BatchNorm applied on the convolution's operand loads where the device has that form
             bn_l = _state(x)
             z = realize(bn_l[1])
             out = F.bn_conv2d_train(z, bn_l[2], module)
             if out is not None:
+                _consumed(x)
                 return out
         xr = realize(x)
         return F.conv2d(xr, module.weight, module.padding, module.stride, bias=module.bias)
     if op == "bn":
+        if extra == _STATS_DONE:
+            # a fused launch consumed this call: same batch statistics, same values, running statistics left alone (the
+            # second node's gradients add up with the first's: the backward pass of a BatchNorm is linear in dy)
+            return F.batch_norm2d_train(realize(x), module.weight, module.bias, None, None, module.eps, module.momentum)
         return module.forward(realize(x))
     if op == "linear":
         return F.linear(realize(x), module.weight, module.bias)
@@ -181,7 +208,9 @@ def _add(a, b):
 def _block_tail(out_l, identity):
     """test/ResNet_CIFAR10_cuda.py:31-47 from `out = self.bn2(out)` on: the launches of the hand-fused block
     (workloads.ResidualBlock.forward)"""
-    if not _is(out_l, "bn") or not _is(_state(out_l)[1], "conv"):
+    if not _is(out_l, "bn") or not _is(_state(out_l)[1], "conv") or _stats_done(out_l):
+        return None
+    if _is(identity, "bn") and _stats_done(identity):
         return None
     bn2 = _state(out_l)[2]
     conv2_l = _state(out_l)[1]
@@ -216,9 +245,14 @@ def _block_tail(out_l, identity):
     z2 = realize(conv2_l)                              # conv2(bn1(z1)): bn1 on the operand loads where that form applies
     if short is not None:
         if F.batch_norm2d_pair_fusable(z2, bn2, zd, bn_d):
-            return F.batch_norm2d_pair_train(z2, bn2, zd, bn_d)        # bn2(z2) + bn_d(zd): one launch each way
-        identity = bn_d.forward(zd)
-    return bn2.forward(z2, residual=realize(identity))
+            out = F.batch_norm2d_pair_train(z2, bn2, zd, bn_d)         # bn2(z2) + bn_d(zd): one launch each way
+            _consumed(out_l)
+            _consumed(identity)
+            return out
+        # (realize(identity) below launches bn_d(zd) as the record's own node)
+    out = bn2.forward(z2, residual=realize(identity))
+    _consumed(out_l)
+    return out
 
 
 tensor._lazy_hooks.update({"force": _force, "add": _add, "mean": _mean})

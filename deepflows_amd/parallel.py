@@ -160,6 +160,18 @@ class GradientBucket:
                 p.grad_slot = None
         self.slots = []
 
+    def attach(self):
+        """the parameters point at THIS bucket's slices again (after another bucket over the same parameters was built and
+        abandoned: every constructor re-assigns p.grad_slot)"""
+        if self.flat is not None and IN_PLACE:
+            self.slots = []
+            off = 0
+            for p, n in zip(self.params, self.sizes):
+                slot = self._view(off, p)
+                self.slots.append(slot)
+                p.grad_slot = slot
+                off += n
+
     def _view(self, offset, p):
         h = self.flat._handle
         if isinstance(h, np.ndarray):

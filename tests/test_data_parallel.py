@@ -101,3 +101,31 @@ def test_world1_bucket_is_a_noop():
     b = parallel.GradientBucket([], comm)
     assert b.flat is None
     b.sync()
+
+
+def test_abandoned_buckets_hand_the_gradient_slots_back(cpu_oracle):
+    """bench.py --overlap builds two more buckets over the same parameters (every constructor re-assigns p.grad_slot); when
+    the overlapped capture fails they are released and the single bucket takes its slots back"""
+    sys.path.insert(0, ROOT)
+    from deepflows_amd import parallel
+    from deepflows_amd.tensor import Tensor
+
+    class Exchanging(parallel.LocalCommunicator):
+        exchanges = True
+
+    comm = Exchanging()
+    params = [Tensor(np.ones((3, 2), np.float32), device=cpu_oracle, requires_grad=True),
+              Tensor(np.ones((4,), np.float32), device=cpu_oracle, requires_grad=True)]
+    main = parallel.GradientBucket(params, comm)
+    own = [p.grad_slot for p in params]
+    assert all(s is not None for s in own)
+    late, early = parallel.GradientBucket(params[:1], comm), parallel.GradientBucket(params[1:], comm)
+    assert params[0].grad_slot is not own[0]
+    late.release()
+    early.release()
+    assert params[0].grad_slot is None and params[1].grad_slot is None
+    main.attach()
+    for p, off in zip(params, (0, 6)):
+        p.grad_slot.fill(7.0)
+        assert np.all(main.flat.numpy()[off:off + p.size] == 7.0)
+        main.flat.fill(0.0)

@@ -1,0 +1,190 @@
+"""GPU: a recorded module call (nn/lazy.py) that a fused launch CONSUMED is still a value its holder may read later.
+
+The reference calls every module exactly once (nn/modules/batchnorm.py:30-55: one forward = one momentum update of
+running_mean / running_var).  On the hip device `bn2(out)` is only recorded, and `+ identity` (or the next convolution, or
+the stem's pooling layer) launches the fused kernel of the sequence.  A script that keeps `feat = self.bn2(out)` and reads
+`feat` after that point (feature extraction, an auxiliary loss, a second consumer) must get the oracle's bn2(out), the
+running statistics of ONE call, and gradients that add up over both uses."""
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_close
+
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from deepflows_amd import backend_api
+    from oracle.numpy_device import NumpyDevice
+    return backend_api.register_device("cpu", NumpyDevice())
+
+
+def _drop_oracle():
+    from deepflows_amd import backend_api
+    backend_api.unregister_device("cpu")
+
+
+class _Net:
+    """conv / bn layers of one scenario, built in a fixed order from a fixed seed (the same weights on every device)"""
+
+    def __init__(self, dev, cin, c, stride=1, shortcut=False):
+        from deepflows_amd import nn
+        np.random.seed(3)
+        self.conv1 = nn.Conv2d(cin, c, kernel_size=3, stride=stride, padding=1, bias=False, device=dev)
+        self.bn1 = nn.BatchNorm2d(c, device=dev)
+        self.conv2 = nn.Conv2d(c, c, kernel_size=3, stride=1, padding=1, bias=False, device=dev)
+        self.bn2 = nn.BatchNorm2d(c, device=dev)
+        self.conv3 = nn.Conv2d(c, c, kernel_size=3, stride=1, padding=1, bias=False, device=dev)
+        self.convd = nn.Conv2d(cin, c, kernel_size=1, stride=stride, padding=0, bias=False, device=dev) if shortcut else None
+        self.bnd = nn.BatchNorm2d(c, device=dev) if shortcut else None
+        self.relu, self.pool = nn.ReLU(), nn.MaxPool2d(2, 2)
+        rng = np.random.default_rng(11)
+        for bn in (self.bn1, self.bn2, self.bnd):
+            if bn is None:
+                continue
+            from deepflows_amd.tensor import Tensor
+            bn.weight.data = Tensor(rng.uniform(0.5, 1.5, (1, c, 1, 1)).astype(np.float32), device=dev).data
+            bn.bias.data = Tensor(rng.uniform(-0.5, 0.5, (1, c, 1, 1)).astype(np.float32), device=dev).data
+        for m in (self.conv1, self.bn1, self.conv2, self.bn2, self.conv3, self.convd, self.bnd):
+            if m is not None:
+                m.train()
+
+    def bns(self):
+        return [b for b in (self.bn1, self.bn2, self.bnd) if b is not None]
+
+    def params(self):
+        ps = []
+        for m in (self.conv1, self.bn1, self.conv2, self.bn2, self.conv3, self.convd, self.bnd):
+            if m is not None:
+                ps += [p for p in (m.weight, getattr(m, "bias", None)) if p is not None]
+        return ps
+
+
+def _sq(t):
+    from deepflows_amd import tensor
+    return tensor.mean(t * t)
+
+
+# ---- the scenarios: each returns (loss tensor, {name: tensor whose value is compared}) ---------------------------------
+def block_tail_held(net, x):
+    """test/ResNet_CIFAR10_cuda.py:31-47 with `feat = self.bn2(out)` kept across `out + identity`"""
+    out = net.conv1(x)
+    out = net.bn1(out)
+    out = net.conv2(out)
+    feat = net.bn2(out)
+    out = feat + x
+    return _sq(out) + _sq(feat) * 0.5, {"out": out, "feat": feat}
+
+
+def bn1_held_across_conv2(net, x):
+    """`t = bn1(conv1(x)); y = conv2(t) + t` (conv2(out) + out)"""
+    t = net.bn1(net.conv1(x))
+    y = net.conv2(t) + t
+    return _sq(y), {"y": y, "t": t}
+
+
+def two_convs_read_one_bn(net, x):
+    t = net.bn1(net.conv1(x))
+    ya = net.conv2(t)
+    yb = net.conv3(t)
+    return _sq(ya) + _sq(yb) * 2.0, {"ya": ya, "yb": yb}
+
+
+def stem_held(net, x):
+    """pool(relu(bn(conv(x)))) with the BatchNorm output and the ReLU output read afterwards"""
+    t = net.bn1(net.conv1(x))
+    r = net.relu(t)
+    p = net.pool(r)
+    return _sq(p) + _sq(r) * 0.25 + _sq(t) * 0.125, {"p": p, "r": r, "t": t}
+
+
+def pair_tail_held(net, x):
+    """a block with a convolution shortcut: bn2(..) and bn_d(conv_d(x)) both kept across the sum"""
+    out = net.conv1(x)
+    out = net.bn1(out)
+    out = net.conv2(out)
+    feat = net.bn2(out)
+    idt = net.bnd(net.convd(x))
+    out = feat + idt
+    return _sq(out) + _sq(feat) * 0.5 + _sq(idt) * 0.25, {"out": out, "feat": feat, "idt": idt}
+
+
+def skip_from_stem_relu(net, x):
+    """a skip connection taken from relu(bn(conv)) in front of the pooling layer"""
+    r = net.relu(net.bn1(net.conv1(x)))
+    p = net.pool(r)
+    q = net.conv2(r)
+    return _sq(p) + _sq(q), {"p": p, "q": q}
+
+
+SCENARIOS = {
+    "block_tail_held": (block_tail_held, dict(cin=8, c=8), (4, 8, 8, 8)),
+    "block_tail_held_bench_size": (block_tail_held, dict(cin=32, c=32), (128, 32, 16, 16)),
+    "bn1_held_across_conv2": (bn1_held_across_conv2, dict(cin=8, c=8), (4, 8, 8, 8)),
+    "bn1_held_across_conv2_bench_size": (bn1_held_across_conv2, dict(cin=32, c=32), (128, 32, 16, 16)),
+    "two_convs_read_one_bn": (two_convs_read_one_bn, dict(cin=8, c=8), (4, 8, 8, 8)),
+    "stem_held": (stem_held, dict(cin=3, c=32), (16, 3, 32, 32)),
+    "pair_tail_held": (pair_tail_held, dict(cin=32, c=64, stride=2, shortcut=True), (16, 32, 16, 16)),
+    "skip_from_stem_relu": (skip_from_stem_relu, dict(cin=3, c=8), (4, 3, 8, 8)),
+}
+
+
+def _run(dev, name, count_bn=False):
+    from deepflows_amd.tensor import Graph, Tensor
+    fn, kw, shape = SCENARIOS[name]
+    net = _Net(dev, **kw)
+    x = Tensor(np.random.default_rng(5).standard_normal(shape).astype(np.float32), device=dev, requires_grad=True)
+    if count_bn:
+        dev.mod.prof_reset()
+        dev.mod.prof_enable(True)
+    loss, held = fn(net, x)
+    res = {k: v.numpy().copy() for k, v in held.items()}
+    fwd_bn = None
+    if count_bn:
+        dev.mod.synchronize()
+        fwd_bn = {k: v["calls"] for k, v in dev.mod.prof_read().items()}
+        dev.mod.prof_enable(False)
+    loss.backward()
+    res["loss"] = loss.numpy().copy()
+    res["dx"] = x.grad.numpy().copy()
+    for i, p in enumerate(net.params()):
+        res[f"grad{i}"] = p.grad.numpy().copy()
+    for i, bn in enumerate(net.bns()):
+        res[f"running_mean{i}"] = bn.running_mean.numpy().copy()
+        res[f"running_var{i}"] = bn.running_var.numpy().copy()
+    Graph.free_graph_all()
+    return res, fwd_bn
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_held_record_is_read_after_the_fused_launch_consumed_it(hip_device, name):
+    hip_device.mod.conv_dgrad_mode = "accumulate"      # the complete chain rule: what two uses of one value must add up to
+    got, counts = _run(hip_device, name, count_bn=True)
+    from oracle import accumulate_mode
+    cpu = _oracle()
+    try:
+        with accumulate_mode.enabled():
+            want, _ = _run(cpu, name)
+    finally:
+        _drop_oracle()
+    print(f"\n{name}: forward launch counts {counts}")
+    for k in want:
+        tol = 1e-4 if not k.startswith(("grad", "dx")) else 2e-4
+        assert_close(got[k], want[k], tol, f"{name}: {k}")
+
+
+def test_running_statistics_move_once_per_module_call(hip_device):
+    """the momentum update applied twice would put running_mean at 0.19 * mean instead of 0.1 * mean"""
+    got, _ = _run(hip_device, "block_tail_held")
+    cpu = _oracle()
+    try:
+        want, _ = _run(cpu, "block_tail_held")
+    finally:
+        _drop_oracle()
+    for k in want:
+        if k.startswith("running"):
+            assert_close(got[k], want[k], 1e-5, k)
+            assert np.abs(want[k] - (0.0 if "mean" in k else 1.0)).max() > 1e-3      # (the update is visible at all)

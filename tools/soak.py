@@ -49,6 +49,7 @@ def main():
         cs.replay()
     mod.synchronize()
     clock0 = mod.clock_probe(200.0)
+    s1b = mod.pool_stats()      # (the capture itself and the clock probe's buffer are behind us: from here on, replays only)
     # the 30-replay region bench.py times, then the long run in chunks (the per-chunk times show a drift, if any)
     t0 = time.perf_counter()
     for _ in range(30):
@@ -66,9 +67,9 @@ def main():
         mod.synchronize()
         chunks.append((time.perf_counter() - t0) * 1e3 / per)
     total = time.perf_counter() - t_all
+    s2 = mod.pool_stats()
     clock1 = mod.clock_probe(200.0)
     lr = float(loss.numpy()[0])
-    s2 = mod.pool_stats()
     assert np.isfinite(lr) and lr < losses[-1] + 1e-3
     print(json.dumps({"job": "ResNet-18 CIFAR-10 bs=%d, captured step, model=%s" % (args.batch, args.model),
                       "replays": per * n_chunk, "ms_per_step_sustained": total * 1e3 / (per * n_chunk),
@@ -77,7 +78,9 @@ def main():
                       "mfma_clock_mhz_before": clock0[0], "mfma_clock_mhz_after": clock1[0],
                       "mfma_probe_tflops_before": clock0[1], "mfma_probe_tflops_after": clock1[1],
                       "final_loss": lr, "reserved_mb": s2["reserved_bytes"] / 1e6,
-                      "hipmalloc_calls_during_replays": s2["hipmalloc_calls"] - s1["hipmalloc_calls"]}))
+                      "hipmalloc_calls_capture_and_probe": s1b["hipmalloc_calls"] - s1["hipmalloc_calls"],
+                      "hipmalloc_calls_during_replays": s2["hipmalloc_calls"] - s1b["hipmalloc_calls"]}))
+    assert s2["hipmalloc_calls"] == s1b["hipmalloc_calls"], "a replayed step reached hipMalloc"
 
 
 if __name__ == "__main__":
