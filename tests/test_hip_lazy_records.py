@@ -151,7 +151,8 @@ def _run(dev, name, count_bn=False):
     res["loss"] = loss.numpy().copy()
     res["dx"] = x.grad.numpy().copy()
     for i, p in enumerate(net.params()):
-        res[f"grad{i}"] = p.grad.numpy().copy()
+        if p.grad is not None:                         # (a layer the scenario does not call has no gradient, on any device)
+            res[f"grad{i}"] = p.grad.numpy().copy()
     for i, bn in enumerate(net.bns()):
         res[f"running_mean{i}"] = bn.running_mean.numpy().copy()
         res[f"running_var{i}"] = bn.running_var.numpy().copy()
@@ -166,12 +167,15 @@ def test_held_record_is_read_after_the_fused_launch_consumed_it(hip_device, name
     from oracle import accumulate_mode
     cpu = _oracle()
     try:
-        with accumulate_mode.enabled():
+        with accumulate_mode.accumulate_im2col_gradient():
             want, _ = _run(cpu, name)
     finally:
         _drop_oracle()
     print(f"\n{name}: forward launch counts {counts}")
     for k in want:
+        if k not in got:         # (a layer the scenario never calls: the primitive path holds the zeros it was born with)
+            assert k.startswith("grad") and not np.any(want[k]), f"{name}: {k} is missing on hip"
+            continue
         tol = 1e-4 if not k.startswith(("grad", "dx")) else 2e-4
         assert_close(got[k], want[k], tol, f"{name}: {k}")
 
