@@ -129,10 +129,6 @@ _SIGS = {
     "dfhip_comm_rccl_path": [c_char_p, c_int],
     "dfhip_comm_count": [POINTER(c_int), POINTER(c_int)],
     "dfhip_clock_probe": [c_double, POINTER(c_double), POINTER(c_double)],
-    "dfhip_side_fork": [],
-    "dfhip_side_target": [c_int],
-    "dfhip_side_join": [],
-    "dfhip_side_probe": [c_int, c_int, c_int],
     "dfhip_comm_destroy": [],
     "dfhip_graph_begin": [],
     "dfhip_graph_end": [POINTER(c_void_p)],

@@ -1316,8 +1316,7 @@ static int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b)
 // main kernel; returns -1 when the shape is not eligible (the generic kernel takes it then)
 int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, float* partials = nullptr,
                  int cap_rows = 0, int* rows_out = nullptr) {
-  static int k5_on = getenv("DFHIP_IGEMM_K5") ? atoi(getenv("DFHIP_IGEMM_K5")) : 1;
-  if (g.CS % 8 != 0 || !(g.k == 1 || g.k == 3 || (g.k == 5 && k5_on))) return -1;
+  if (g.CS % 8 != 0 || !(g.k == 1 || g.k == 3 || g.k == 5)) return -1;
   if (g.mode != 0 && g.CD % 32 != 0) return -1;    // dgrad weight rows are staged as whole 32-channel runs
   if ((g.HS * g.WS) % 4 != 0) return -1;            // channel planes must stay 16-byte aligned
   const int k2 = g.k * g.k;
@@ -1338,9 +1337,9 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, 
     if (RL % 4 != 0 || (g.gr > 1 && (g.WS % 4 != 0))) continue;
     g.PE = g.BI * RL;
     int64_t jobs = (int64_t)gi * g.gr * dtiles;
-    static int jobmul = getenv("DFHIP_JOBMUL") ? atoi(getenv("DFHIP_JOBMUL")) : 1;
+    constexpr int jobmul = 1;
     if (jobs < (int64_t)num_cus() * jobmul && pt > 1) continue;
-    static size_t lds_cap_single = (size_t)(getenv("DFHIP_LDS_SINGLE") ? atoi(getenv("DFHIP_LDS_SINGLE")) : 150) * 1024;
+    constexpr size_t lds_cap_single = (size_t)(150) * 1024;
     auto fits = [&](int cc) {
       size_t wl = g.mode == 0 ? (size_t)33 * cc * k2 : (size_t)cc * 32 * k2;
       size_t stage_b = 2 * ((size_t)cc * (g.PE + 4) + wl) * 4;    // (+4: the zero slot of a channel)
@@ -1351,7 +1350,7 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, 
       const size_t cap = jobs > (int64_t)num_cus() ? 76 * 1024 : lds_cap_single;
       return lds <= cap && pvecs <= 512 * kPV && wvecs <= 512 * kWV;
     };
-    static int maxchunks = getenv("DFHIP_MAXCHUNKS") ? atoi(getenv("DFHIP_MAXCHUNKS")) : 2;
+    constexpr int maxchunks = 2;
     int c = std::max(8, 2 * ksplit);
     while (c < 32 && g.CS / c > maxchunks && g.CS % (2 * c) == 0 && fits(2 * c)) c *= 2;
     if (g.CS % c != 0 || !fits(c)) continue;
@@ -1378,8 +1377,7 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, 
   dim3 grid((unsigned)(gi * g.gr), (unsigned)dtiles, 1);
   int st = DFHIP_OK;
   g.stats = nullptr;
-  static int vec_store = getenv("DFHIP_VEC_STORE") ? atoi(getenv("DFHIP_VEC_STORE")) : 1;
-  g.vec_store = (vec_store && (g.BR * g.BC) % 4 == 0 && (g.HD * g.WD) % 4 == 0) ? 1 : 0;
+  g.vec_store = ((g.BR * g.BC) % 4 == 0 && (g.HD * g.WD) % 4 == 0) ? 1 : 0;
   if (partials) {
     if ((int)grid.x > cap_rows) return -1;
     g.stats = partials;
@@ -1401,10 +1399,7 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, 
   if (g.k == 1) st = DF_V4(1);
   else if (g.k == 3) st = DF_V4(3);
   else {    // 5x5 (the CNN workload's second convolution)
-    static int k5_spec = getenv("DFHIP_IGEMM_K5_SPEC") ? atoi(getenv("DFHIP_IGEMM_K5_SPEC")) : 1;
-    if (k5_spec) st = DF_V4(5);
-    else st = g.mode == 0 ? launch_igemm_v4n<5, 0, 0>(g, grid, lds)
-                          : (g.mode == 1 ? launch_igemm_v4n<5, 1, 0>(g, grid, lds) : launch_igemm_v4n<5, 2, 0>(g, grid, lds));
+    st = DF_V4(5);           // (the tap count at compile time: -20 % on the CNN's 5x5 layer against the run-time loop)
   }
 #undef DF_V4
   if (st != DFHIP_OK) return st;
@@ -1444,8 +1439,7 @@ int run_igemm_v4(Geo g, int dest_channels, float* final_dst, const float* bias, 
 
 // 3x3 / stride 1 / pad 1 on 2 x 2 images (128 or 256 source channels, batch a multiple of 32); -1 when not eligible
 int run_conv_img2(const Geo& g, int O, float* y, const float* bias, float* partials, int cap_rows, int* rows_out) {
-  static int enabled = getenv("DFHIP_IMG2_LEAN") ? atoi(getenv("DFHIP_IMG2_LEAN")) : 1;
-  if (!enabled || g.mode != 0 || g.k != 3 || g.so != 1 || g.sd != 1 || g.u0 != -1) return -1;
+  if (g.mode != 0 || g.k != 3 || g.so != 1 || g.sd != 1 || g.u0 != -1) return -1;
   if (g.HS != 2 || g.WS != 2 || g.HD != 2 || g.WD != 2 || (g.N % 32) != 0) return -1;
   if (!(g.CS == 128 || g.CS == 256)) return -1;
   // all four positions per workgroup (k_conv3x3_img2_all): 16 images x 16 channels; other channel counts / more rows than
@@ -1467,9 +1461,7 @@ int run_conv_img2(const Geo& g, int O, float* y, const float* bias, float* parti
 // for its own channels (k_conv3x3_img2_all<.., BNC>); -1 when the shape is not one it takes
 int run_conv_img2_bn(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int O, int k,
                      int stride, int pad, float* partials, int cap_rows, int* rows_out, const BnInput& bn, bool dry_run) {
-  static int enabled = getenv("DFHIP_IMG2_LEAN") ? atoi(getenv("DFHIP_IMG2_LEAN")) : 1;
-  static int bn_on = getenv("DFHIP_IMG2_BN_INPUT") ? atoi(getenv("DFHIP_IMG2_BN_INPUT")) : 1;
-  if (!enabled || !bn_on || k != 3 || stride != 1 || pad != 1 || H != 2 || W != 2 || (N % 32) != 0) return -1;
+  if (k != 3 || stride != 1 || pad != 1 || H != 2 || W != 2 || (N % 32) != 0) return -1;
   if (!(C == 128 || C == 256) || O % 16 != 0 || !bn.part || bn.rows < 1 || !bn.affine) return -1;
   const int rows4 = N / 16;
   if (partials && rows4 > cap_rows) return -1;
@@ -1486,8 +1478,7 @@ int run_conv_img2_bn(const float* x, const float* w, const float* bias, float* y
 
 // shortcut convolution (1x1 / stride 2 / pad 0, 32-256 source channels); -1 when not eligible
 int run_conv1x1s2(const Geo& g, int O, float* y, const float* bias, float* partials, int cap_rows, int* rows_out) {
-  static int enabled = getenv("DFHIP_SHORTCUT_LEAN") ? atoi(getenv("DFHIP_SHORTCUT_LEAN")) : 1;
-  if (!enabled || g.mode != 0 || g.k != 1 || g.so != 2 || g.sd != 1 || g.u0 != 0) return -1;
+  if (g.mode != 0 || g.k != 1 || g.so != 2 || g.sd != 1 || g.u0 != 0) return -1;
   if (!(g.CS == 32 || g.CS == 64 || g.CS == 128 || g.CS == 256)) return -1;
   if ((g.HS & 1) || (g.WS & 1) || g.HD * 2 != g.HS || g.WD * 2 != g.WS) return -1;
   int lw = 0;
@@ -1501,7 +1492,7 @@ int run_conv1x1s2(const Geo& g, int O, float* y, const float* bias, float* parti
   if (rows_out) *rows_out = partials ? rows : 0;
   // channel tiles per workgroup: as many as still leave two workgroups per CU (and 64 KB of LDS per workgroup)
   const int OT = (int)df_ceil_div(O, 32);
-  static int dtmax = getenv("DFHIP_SHORTCUT_DT") ? atoi(getenv("DFHIP_SHORTCUT_DT")) : 8;
+  constexpr int dtmax = 8;
   int DT = 1;
   auto lds_of = [&](int dt) { return ((size_t)dt * g.CS * 33 + 4 * 32 * 36 + 4 * 96) * sizeof(float); };
   // (more tiles per workgroup with 87-155 KB of LDS and one workgroup per CU were measured: 128 channels 23.6 -> 26.2 us)
@@ -1521,17 +1512,13 @@ int run_conv1x1s2(const Geo& g, int O, float* y, const float* bias, float* parti
 // few-channel 3x3 stem on 32-wide images; returns -1 when the shape is not one it takes
 int run_conv_rows3(const Geo& g, int dest_channels, float* final_dst, const float* bias, float* partials = nullptr,
                    int cap_rows = 0, int* rows_out = nullptr) {
-  static int enabled = getenv("DFHIP_STEM_ROWS") ? atoi(getenv("DFHIP_STEM_ROWS")) : 1;
-  if (!enabled || g.mode != 0 || g.k != 3 || g.so != 1 || g.sd != 1 || g.u0 != -1) return -1;
+  if (g.mode != 0 || g.k != 3 || g.so != 1 || g.sd != 1 || g.u0 != -1) return -1;
   if (g.CS < 1 || g.CS > 4 || g.WS != 32 || g.WD != 32 || g.HS != g.HD) return -1;
   if ((int64_t)g.N * df_ceil_div(g.HS, 8) >= ((int64_t)1 << 31)) return -1;        // band index in an int
   // a workgroup per band of rb rows of an image (the whole image when there are enough images to fill the chip);
   // more bands than partial rows / twice the CUs: the workgroups walk them
-  static int rb_env = getenv("DFHIP_STEM_BAND") ? atoi(getenv("DFHIP_STEM_BAND")) : 0;
-  int rb = rb_env > 0 ? std::min(rb_env, 32) : 32;
-  if (rb_env <= 0) {
-    while (rb > 8 && (int64_t)g.N * df_ceil_div(g.HS, rb) < num_cus()) rb /= 2;
-  }
+  int rb = 32;
+  while (rb > 8 && (int64_t)g.N * df_ceil_div(g.HS, rb) < num_cus()) rb /= 2;
   const int bands = df_ceil_div(g.HS, rb);
   const int64_t items = (int64_t)g.N * bands;
   const bool want_part = partials && rows_out && cap_rows > 0;
@@ -1761,8 +1748,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
   }
   if (mode == 1) {
     // 2 x 2 images: the forward's all-positions kernel with the roles of the channel counts swapped (k_conv3x3_img2_all<DG>)
-    static int img2dg = getenv("DFHIP_DGRAD_IMG2_ACC") ? atoi(getenv("DFHIP_DGRAD_IMG2_ACC")) : 1;
-    if (img2dg && k == 3 && stride == 1 && pad == 1 && H == 2 && W == 2 && N % 16 == 0 && C % 16 == 0 &&
+    if (k == 3 && stride == 1 && pad == 1 && H == 2 && W == 2 && N % 16 == 0 && C % 16 == 0 &&
         (O == 128 || O == 256)) {
       dim3 grid4((unsigned)(N / 16), (unsigned)(C / 16));
       const size_t lds4 = std::max((size_t)8 * (72 * 17 + 16 * 9 * 4), (size_t)7 * 4 * 64 * 4) * sizeof(float);
@@ -1834,8 +1820,7 @@ int dfhip_conv2d_dgrad_pair(const float* dy, const float* w, const float* dy2, c
   int oh, ow;
   int s = check_conv_args("conv2d_dgrad_pair", N, C, H, W, O, 3, 2, 1, oh, ow);
   if (s != DFHIP_OK) return s;
-  static int pair_on = getenv("DFHIP_DGRAD_PAIR") ? atoi(getenv("DFHIP_DGRAD_PAIR")) : 1;
-  if (pair_on && mode == 1) {
+  if (mode == 1) {
     // accumulate mode: the stride-2 kernel that multiplies only the (pixel, tap) pairs that exist, shortcut included
     double flopsa = 2.0 * N * oh * ow * (double)C * 10 * O;
     double bytesa = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * oh * ow);
@@ -1877,8 +1862,7 @@ int dfhip_conv2d_bn_bwd_supported(int N, int C, int H, int W, int O, int k, int 
   *stats_rows = *dgrad_ok ? so.nrows : 0;
   // the grouped direct body of the weight gradient: whole 32-channel tiles, planes of 2 .. 16 pixels a side (DF_ROWS_KINDS)
   const bool k3 = k == 3 && pad == 1, k1 = k == 1 && pad == 0 && stride == 2;
-  static int direct_on = getenv("DFHIP_WGRAD_DIRECT") ? atoi(getenv("DFHIP_WGRAD_DIRECT")) : 1;
-  *wgrad_ok = direct_on && (k3 || k1) && C % 32 == 0 && O % 32 == 0 && N % 16 == 0 && H == W &&
+  *wgrad_ok = (k3 || k1) && C % 32 == 0 && O % 32 == 0 && N % 16 == 0 && H == W &&
               (W == 16 || W == 8 || W == 4 || (W == 2 && stride == 1)) && (stride == 1 || stride == 2) &&
               (stride == 1 || ow * 2 == W) && (H * W) % 4 == 0 && (oh * ow) % 4 == 0;
   return DFHIP_OK;
@@ -1952,10 +1936,9 @@ int dfhip_conv2d_forward_bn_input(const float* x, const float* partials_in, int 
   if (s != DFHIP_OK) return s;
   DF_CHECK_ARG(x && w && y && partials_in && save_mean && save_var && affine_out && done,
                "conv2d_forward_bn_input: null array");
+  DF_CHECK_ARG(rows_in >= 1, "conv2d_forward_bn_input: no partial rows");
   *done = 0;
   if (rows_out) *rows_out = 0;
-  static int enabled = getenv("DFHIP_BN_INPUT") ? atoi(getenv("DFHIP_BN_INPUT")) : 1;
-  if (!enabled) return DFHIP_OK;
   BnInput bn = {};
   bn.part = partials_in; bn.rows = rows_in; bn.gamma = gamma; bn.beta = beta; bn.eps = eps; bn.momentum = momentum;
   bn.save_mean = save_mean; bn.save_var = save_var; bn.running_mean = running_mean; bn.running_var = running_var;
@@ -1978,17 +1961,10 @@ int dfhip_conv2d_forward_bn_input(const float* x, const float* partials_in, int 
   }
   if (run_conv_rowmma(x, w, bias, y, N, C, H, W, O, k, stride, pad, want ? partials : nullptr, cap_rows, &rows, &bn, true) < 0)
     return DFHIP_OK;
-  // the (scale, shift) table: built by every workgroup of the convolution from the producer's rows (the register-operand
+  // the (scale, shift) table is built by every workgroup of the convolution from the producer's rows (the register-operand
   // kernels: the rows are requested in front of the weights; the image-per-lane kernel of the 4 x 4 layers: every wave
-  // for its own sixteen channels), or by a launch of its own (DFHIP_BN_INPUT_COMBINE=0)
-  static int combine_env = getenv("DFHIP_BN_INPUT_COMBINE") ? atoi(getenv("DFHIP_BN_INPUT_COMBINE")) : 1;
-  bn.combine = combine_env && rows_in >= 1 ? 1 : 0;
+  // for its own sixteen channels) -- a launch of its own for it cost 4.2 us + a kernel boundary (round 4)
   int st = DFHIP_OK;
-  if (!bn.combine) {
-    st = bn_finalize_partials(bn, C);
-    if (st < 0) return DFHIP_OK;
-    if (st != DFHIP_OK) return st;
-  }
   ProfScope prof("conv2d_fwd_igemm", flops, bytes);
   st = run_conv_rowmma(x, w, bias, y, N, C, H, W, O, k, stride, pad, want ? partials : nullptr, cap_rows, &rows, &bn);
   if (st < 0) {

@@ -72,13 +72,11 @@ __device__ unsigned long long g_rows_stamps[512 * 8 * 8];
 // whole image (H * W == 16): vertical variants by DPP instead of loads.  A workgroup is 8 waves = TS tile sets x
 // OW output-channel tiles; the weights of its OW tiles go through LDS in chunks of CG channel groups (chunk
 // k + 1 is requested before and committed after the MFMAs of chunk k: one barrier per chunk, every chunk has
-// LDS space of its own); the pixel operands of chunk k + XA are requested at the same point.
+// LDS space of its own); the pixel operands of chunk k + 1 are requested at the same point.
 // DG: the INPUT GRADIENT of the same convolution in its mathematically correct ("accumulate") form -- a 3x3 / stride
 // 1 / pad 1 convolution of dY with the weights transposed and flipped: x = dY (C = the convolution's output
 // channels), O = its input channels, operand (d, s, t) = w[s][d][8 - t]; `bias` is then a TENSOR of the output's
 // shape that is added to the result (the gradient the input already holds, tensor.py:444), not a vector.
-// EW: every weight chunk is requested in the prologue and committed during the first half of chunk 0's MFMAs: ONE
-// barrier inside the reduction instead of one per chunk (each cost the workgroup ~1 600 cycles of matrix-pipe time).
 // BNI: x is the RAW output of the previous convolution and the operand of this one is its training-mode BatchNorm
 // (batchnorm.py:30-55, no activation in between: test/ResNet_CIFAR10_cuda.py:31-35): bn.affine holds the per-channel
 // (scale, shift) of that BatchNorm (dfhip_bn2d_finalize_partials: a few-microsecond launch that combines the
@@ -86,7 +84,7 @@ __device__ unsigned long long g_rows_stamps[512 * 8 * 8];
 // fma(raw, scale, shift) on its way out of the load registers -- the normalised tensor is never written or read.
 // (Combining the partials inside this kernel instead -- every workgroup for itself, 100 KB of rows each -- cost
 // 2-3.7 us per launch: 256 workgroups pulling the same lines through L2 at the same moment.)
-template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, int XA, bool DG, bool EW, bool BNI>
+template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, bool DG, bool BNI>
 __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        float* __restrict__ partials, int H, int O, BnInput bn) {
@@ -116,7 +114,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   // instead of the LDS round and the second barrier -- the per-lane rows make every load sixteen short segments:
   // 16.5 -> 17.1 and 17.9 -> 20.4 us; every wave finishing the sums for itself behind the first barrier -- no second
   // barrier, eight times the divisions: 16.5 -> 16.5, 17.9 -> 18.3 us.)
-  // bn.combine: there was no such launch -- every workgroup adds the producer's rows up for itself (thread = a channel
+  // There is no launch for the table -- every workgroup adds the producer's rows up for itself (thread = a channel
   // x a sixteenth / an eighth of the rows, 12-byte loads requested here, in front of the weights; the shifted sums of
   // k_bn_finalize_partials, combined through LDS in a fixed order), workgroup (0, 0) leaves the table, the batch
   // statistics and the running statistics behind for the backward pass.
@@ -126,31 +124,27 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   float bn_shift = 0.0f, bn_g = 1.0f, bn_b = 0.0f, bn_rm = 0.0f, bn_rv = 0.0f;
   const int bn_c = tid % C, bn_gr = tid / C;
   if constexpr (BNI) {
-    if (bn.combine) {
-      const float* pc = bn.part + bn_c * 3;
-      // (every load instruction of the workgroup queues in front of its weight and pixel loads: half of them when the rows are few)
-      if (bn.rows <= BNG * BRP / 2) {
+    const float* pc = bn.part + bn_c * 3;
+    // (every load instruction of the workgroup queues in front of its weight and pixel loads: half of them when the rows are few)
+    if (bn.rows <= BNG * BRP / 2) {
 #pragma unroll
-        for (int k2 = 0; k2 < BRP / 2; k2++)
-          bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(bn_gr + BNG * k2, bn.rows - 1) * (C * 3));
+      for (int k2 = 0; k2 < BRP / 2; k2++)
+        bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(bn_gr + BNG * k2, bn.rows - 1) * (C * 3));
 #pragma unroll
-        for (int k2 = BRP / 2; k2 < BRP; k2++) bn_row[k2] = (f32x3u){0.0f, 0.0f, 0.0f};
-      } else {
-#pragma unroll
-        for (int k2 = 0; k2 < BRP; k2++)
-          bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(bn_gr + BNG * k2, bn.rows - 1) * (C * 3));
-      }
-      bn_shift = pc[1];                               // row 0's mean
-      if (tid < C) {
-        if (bn.gamma) bn_g = bn.gamma[tid];
-        if (bn.beta) bn_b = bn.beta[tid];
-        if (blockIdx.x == 0 && blockIdx.y == 0) {                     // (only the workgroup that updates them)
-          if (bn.running_mean) bn_rm = bn.running_mean[tid];
-          if (bn.running_var) bn_rv = bn.running_var[tid];
-        }
-      }
+      for (int k2 = BRP / 2; k2 < BRP; k2++) bn_row[k2] = (f32x3u){0.0f, 0.0f, 0.0f};
     } else {
-      if (tid < C) bn_pair = *reinterpret_cast<const f32x2*>(bn.affine + 2 * tid);
+#pragma unroll
+      for (int k2 = 0; k2 < BRP; k2++)
+        bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(bn_gr + BNG * k2, bn.rows - 1) * (C * 3));
+    }
+    bn_shift = pc[1];                               // row 0's mean
+    if (tid < C) {
+      if (bn.gamma) bn_g = bn.gamma[tid];
+      if (bn.beta) bn_b = bn.beta[tid];
+      if (blockIdx.x == 0 && blockIdx.y == 0) {                     // (only the workgroup that updates them)
+        if (bn.running_mean) bn_rm = bn.running_mean[tid];
+        if (bn.running_var) bn_rv = bn.running_var[tid];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -170,7 +164,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
     // (threads past the end re-do the piece 512 places back: every load has an UNCONDITIONAL consumer -- under a
     // condition the compiler sinks the load into the commit, behind the MFMAs it was meant to overlap)
     const int q = tid + 512 * u;
-    const int qq = q < TOT4 ? q : q - 512;
+    const int qq = q < TOT4 ? q : q % TOT4;
     if constexpr (!DG) {
       const int tl = qq / (16 * ROW4), r = qq - tl * (16 * ROW4);
       const int m = r / ROW4, e4 = r - m * ROW4;
@@ -196,8 +190,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
     }
   }
   const int64_t wchunk = DG ? (int64_t)(4 * CG) * O * 9 : 36 * CG;     // floats between two chunks of a piece
-  f32x4 wv[EW ? NCH : 2][PER];                 // two chunks in flight (EW: all of them)
-#define RM_WSLOT(chunk) (EW ? (chunk) : (chunk) & 1)
+  f32x4 wv[2][PER];                            // two chunks in flight
+#define RM_WSLOT(chunk) ((chunk) & 1)
 #define RM_WLOAD(chunk)                                                                         \
   do {                                                                                          \
     _Pragma("unroll") for (int u = 0; u < PER; u++)                                             \
@@ -211,12 +205,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
     }                                                                                           \
   } while (0)
   RM_WLOAD(0);
-  if constexpr (EW) {
-#pragma unroll
-    for (int c1 = 1; c1 < NCH; c1++) RM_WLOAD(c1);
-  } else {
-    if (NCH > 1) RM_WLOAD(1);
-  }
+  if (NCH > 1) RM_WLOAD(1);
   __builtin_amdgcn_sched_barrier(0);           // the weight loads stay in front of the pixel loads
 
   // ---- per-lane source offsets (elements from x, channel group 0) and validity of every load ----
@@ -275,36 +264,30 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
       __builtin_amdgcn_sched_barrier(0);       /* group by group: the first group lands first */                 \
     }                                                                                                            \
   } while (0)
-#pragma unroll
-  for (int c0 = 0; c0 < XA && c0 < NCH; c0++) RM_XLOAD(c0);
+  RM_XLOAD(0);
   RS_STAMP(1);
   if constexpr (BNI) {
-    if (bn.combine) {
-      float tn = 0.0f, t1 = 0.0f, t2 = 0.0f;
-      auto add_rows = [&](int r0) {
+    float tn = 0.0f, t1 = 0.0f, t2 = 0.0f;
+    auto add_rows = [&](int r0) {
 #pragma unroll
-        for (int k2 = 0; k2 < BRP; k2++) {
-          const bool in = r0 + bn_gr + BNG * k2 < bn.rows;
-          const float nb = in ? bn_row[k2][0] : 0.0f, d = nb > 0.0f ? bn_row[k2][1] - bn_shift : 0.0f;
-          tn += nb;
-          t1 = fmaf(nb, d, t1);
-          t2 += fmaf(nb * d, d, in ? bn_row[k2][2] : 0.0f);
-        }
-      };
-      add_rows(0);
-      for (int r0 = BNG * BRP; r0 < bn.rows; r0 += BNG * BRP) {     // (more rows than one pass holds: uniform, rare)
-        const float* pc = bn.part + bn_c * 3;
-#pragma unroll
-        for (int k2 = 0; k2 < BRP; k2++)
-          bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(r0 + bn_gr + BNG * k2, bn.rows - 1) * (C * 3));
-        add_rows(r0);
+      for (int k2 = 0; k2 < BRP; k2++) {
+        const bool in = r0 + bn_gr + BNG * k2 < bn.rows;
+        const float nb = in ? bn_row[k2][0] : 0.0f, d = nb > 0.0f ? bn_row[k2][1] - bn_shift : 0.0f;
+        tn += nb;
+        t1 = fmaf(nb, d, t1);
+        t2 += fmaf(nb * d, d, in ? bn_row[k2][2] : 0.0f);
       }
-      bn_acc[bn_gr][bn_c][0] = tn; bn_acc[bn_gr][bn_c][1] = t1; bn_acc[bn_gr][bn_c][2] = t2;
-      // (summed per channel behind the barrier of the first weight commit; a second barrier publishes the table)
-    } else {
-      if (tid < C) { bn_tab[tid][0] = bn_pair[0]; bn_tab[tid][1] = bn_pair[1]; }
-      // (the table becomes visible with the barrier behind the first weight commit)
+    };
+    add_rows(0);
+    for (int r0 = BNG * BRP; r0 < bn.rows; r0 += BNG * BRP) {     // (more rows than one pass holds: uniform, rare)
+      const float* pc = bn.part + bn_c * 3;
+#pragma unroll
+      for (int k2 = 0; k2 < BRP; k2++)
+        bn_row[k2] = *reinterpret_cast<const f32x3u*>(pc + (int64_t)min(r0 + bn_gr + BNG * k2, bn.rows - 1) * (C * 3));
+      add_rows(r0);
     }
+    bn_acc[bn_gr][bn_c][0] = tn; bn_acc[bn_gr][bn_c][1] = t1; bn_acc[bn_gr][bn_c][2] = t2;
+    // (summed per channel behind the barrier of the first weight commit; a second barrier publishes the table)
   }
   RM_WCOMMIT(0);
   RS_STAMP(2);
@@ -325,29 +308,27 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
 #pragma unroll
   for (int q = 0; q < CBLK; q++) a4[0][q] = Wl4[q * (kBlk / 4)];
   if constexpr (BNI) {
-    if (bn.combine) {
-      if (tid < C) {
-        float n = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    if (tid < C) {
+      float n = 0.0f, a1 = 0.0f, a2 = 0.0f;
 #pragma unroll
-        for (int g2 = 0; g2 < BNG; g2++) { n += bn_acc[g2][tid][0]; a1 += bn_acc[g2][tid][1]; a2 += bn_acc[g2][tid][2]; }
-        const float mu_s = n > 0.0f ? a1 / n : 0.0f;
-        const float mu = bn_shift + mu_s;
-        const float var = n > 0.0f ? fmaxf(a2 - a1 * mu_s, 0.0f) / n : 0.0f;          // biased variance (batchnorm.py:41-42)
-        const float rsd = 1.0f / sqrtf(var + bn.eps);
-        bn_pair[0] = bn_g * rsd;
-        bn_pair[1] = bn_b - mu * bn_pair[0];
-        if (blockIdx.x == 0 && blockIdx.y == 0) {
-          if (bn.save_mean) bn.save_mean[tid] = mu;
-          if (bn.save_var) bn.save_var[tid] = var;
-          if (bn.running_mean) bn.running_mean[tid] = bn_rm * (1.0f - bn.momentum) + mu * bn.momentum;
-          if (bn.running_var) bn.running_var[tid] = bn_rv * (1.0f - bn.momentum) + var * bn.momentum;
-          bn.affine[2 * tid] = bn_pair[0];
-          bn.affine[2 * tid + 1] = bn_pair[1];
-        }
+      for (int g2 = 0; g2 < BNG; g2++) { n += bn_acc[g2][tid][0]; a1 += bn_acc[g2][tid][1]; a2 += bn_acc[g2][tid][2]; }
+      const float mu_s = n > 0.0f ? a1 / n : 0.0f;
+      const float mu = bn_shift + mu_s;
+      const float var = n > 0.0f ? fmaxf(a2 - a1 * mu_s, 0.0f) / n : 0.0f;          // biased variance (batchnorm.py:41-42)
+      const float rsd = 1.0f / sqrtf(var + bn.eps);
+      bn_pair[0] = bn_g * rsd;
+      bn_pair[1] = bn_b - mu * bn_pair[0];
+      if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (bn.save_mean) bn.save_mean[tid] = mu;
+        if (bn.save_var) bn.save_var[tid] = var;
+        if (bn.running_mean) bn.running_mean[tid] = bn_rm * (1.0f - bn.momentum) + mu * bn.momentum;
+        if (bn.running_var) bn.running_var[tid] = bn_rv * (1.0f - bn.momentum) + var * bn.momentum;
+        bn.affine[2 * tid] = bn_pair[0];
+        bn.affine[2 * tid + 1] = bn_pair[1];
       }
-      if (tid < C) { bn_tab[tid][0] = bn_pair[0]; bn_tab[tid][1] = bn_pair[1]; }
-      __syncthreads();
     }
+    if (tid < C) { bn_tab[tid][0] = bn_pair[0]; bn_tab[tid][1] = bn_pair[1]; }
+    __syncthreads();
   }
   float bsh[2][NT][3][3];
   auto make_shifts = [&](float (&b)[NT][3][3], const float (&rw)[NL]) {
@@ -402,23 +383,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
 #pragma unroll
   for (int ch = 0; ch < NCH; ch++) {
     // chunk ch + 1 (requested a chunk ago) is committed now and made visible by a barrier in the MIDDLE of this
-    // chunk's MFMAs, where no wave waits for anything else; chunk ch + 2 and the pixels of ch + XA are requested
-    if constexpr (EW) {
-      if (ch == 0) {
-#pragma unroll
-        for (int c1 = 1; c1 < NCH; c1++) RM_WCOMMIT(c1);
-      }
-    } else {
-      if (ch + 1 < NCH) RM_WCOMMIT(ch + 1);
-      if (ch + 2 < NCH) RM_WLOAD(ch + 2);
-    }
+    // chunk's MFMAs, where no wave waits for anything else; chunk ch + 2 and the pixels of ch + 1 are requested
+    if (ch + 1 < NCH) RM_WCOMMIT(ch + 1);
+    if (ch + 2 < NCH) RM_WLOAD(ch + 2);
     __builtin_amdgcn_sched_barrier(0);
-    if (ch + XA < NCH) RM_XLOAD(ch + XA);
+    if (ch + 1 < NCH) RM_XLOAD(ch + 1);
     for (int g = 0; g < CG; g++) {
       const int p = ch * CG + g;
       if (g == CG / 2 && ch + 1 < NCH) {
 #ifndef DFHIP_ROWS_NOBAR        // (diagnostic build, timing only: no barrier inside the reduction)
-        if (!EW || ch == 0) __syncthreads();
+        __syncthreads();
 #endif
         // the next chunk's operands are visible now: read them here, half a chunk before their first use
 #pragma unroll
@@ -556,8 +530,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   RS_STAMP(7);
 }
 
-template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, int XA, bool DG = false, bool EW = false,
-          bool BNI = false>
+template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, bool DG = false, bool BNI = false>
 int launch_rowmma(const float* x, const float* w, const float* bias, float* y, float* partials, int H, int O,
                   dim3 grid, const BnInput* bnp = nullptr) {
   BnInput bn = {};
@@ -565,11 +538,11 @@ int launch_rowmma(const float* x, const float* w, const float* bias, float* y, f
   const size_t lds = (size_t)OW * (C / 4 * 9 / 4) * kBlk * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA, DG, EW, BNI>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, DG, BNI>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536)));
     attr = true;
   }
-  DF_LAUNCH((k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, XA, DG, EW, BNI>), grid, dim3(512), lds, stream(), x, w, bias, y,
+  DF_LAUNCH((k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, DG, BNI>), grid, dim3(512), lds, stream(), x, w, bias, y,
                      partials, H, O, bn);
   DF_LAUNCH_CHECK();
 #ifdef DFHIP_ROWS_STAMPS
@@ -591,9 +564,9 @@ int launch_rowmma(const float* x, const float* w, const float* bias, float* y, f
       }
       fprintf(stderr, "[rows-clock] cycles per wave mean %.0f max %.0f; wave life mean %.2f us max %.2f us -> %.3f GHz\n",
               cyc_sum / nw, cyc_max, rt_sum / nw / 100.0, rt_max / 100.0, cyc_sum / rt_sum / 10.0);
-      fprintf(stderr, "[rows-stamp] LW %d C %d NT %d TS %d OW %d CG %d XA %d EW %d grid %u x %u: first start -> last end %.2f us, last "
+      fprintf(stderr, "[rows-stamp] LW %d C %d NT %d TS %d OW %d CG %d grid %u x %u: first start -> last end %.2f us, last "
               "wave starts +%.2f us; mean cycles per wave: issue %.0f, w-commit %.0f, barrier %.0f, mfma-loop %.0f, epilogue %.0f\n",
-              LW, C, NT, TS, OW, CG, XA, (int)EW, grid.x, grid.y, (double)(r1 - r0) / 100.0, (double)(rs - r0) / 100.0,
+              LW, C, NT, TS, OW, CG, grid.x, grid.y, (double)(r1 - r0) / 100.0, (double)(rs - r0) / 100.0,
               seg[1] / nw, seg[2] / nw, seg[3] / nw, seg[4] / nw, seg[5] / nw);
     }
   }
@@ -667,7 +640,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
   f32x4 acc[8];
 #pragma unroll
   for (int q = 0; q < 8; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // aff && bn.combine: no launch has turned the producer's rows into the (scale, shift) table -- a wave needs the
+  // COMB: no launch has turned the producer's rows into the (scale, shift) table -- a wave needs the
   // pairs of its own sixteen channels only: lane (g, c) adds up rows g, g + 4, ... of channel cb + c (requested in
   // front of the first chunk), the four groups meet through two lane exchanges, and the operand lanes fetch their
   // channel's pair from lane c with a bpermute; no barrier, nothing through LDS.  Workgroup (0, 0, 0) leaves the
@@ -675,7 +648,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restric
   constexpr int BRP = 8;
   f32x3u bn_row[COMB ? BRP : 1];
   float bn_shift = 0.0f, bn_g = 1.0f, bn_b = 0.0f, bn_rm = 0.0f, bn_rv = 0.0f;
-  constexpr bool combine = COMB;                  // (the launcher picks the build: aff && bn.combine)
+  constexpr bool combine = COMB;
   if constexpr (combine) {
     const float* pc = bn.part + (cb + n) * 3;
 #pragma unroll
@@ -850,8 +823,7 @@ namespace dfhip {
 // 4 x 4 images with an image on the lane (k_conv3x3_img4_fwd); -1 when the shape is not one it takes
 static int run_conv_img4_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int O,
                              float* partials, int cap_rows, int* rows_out, const BnInput* bn, bool dry_run) {
-  static int enabled = getenv("DFHIP_IMG4_FWD") ? atoi(getenv("DFHIP_IMG4_FWD")) : 1;
-  if (!enabled || C != 128 || N % 16 != 0 || O % 16 != 0) return -1;
+  if (C != 128 || N % 16 != 0 || O % 16 != 0) return -1;
   const int rows = N / 16 * 2;
   if (partials && rows > cap_rows) return -1;
   if ((int64_t)rows * (O / 16) < num_cus() / 2) return -1;
@@ -869,7 +841,7 @@ static int run_conv_img4_fwd(const float* x, const float* w, const float* bias, 
   // blockIdx.y selects 16 output channels' weights, blockIdx.x 16 images' planes (both halves of an image tile are
   // neighbours in z: they share the planes of the middle rows)
   const int xo = xcd_arrangement(N / 16, O / 16, 4.0 * N * C * 16, 4.0 * O * C * 9);
-  if (bn && bn->combine)
+  if (bn)
     DF_LAUNCH((k_conv3x3_img4_fwd<128, true>), grid, dim3(512), lds, stream(), x, w, bias, y, partials, O,
               (const float*)bn->affine, xo, *bn);
   else
@@ -883,9 +855,7 @@ static int run_conv_img4_fwd(const float* x, const float* w, const float* bias, 
 int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int O,
                     int k, int stride, int pad, float* partials, int cap_rows, int* rows_out, const BnInput* bn,
                     bool dry_run) {
-  static int enabled = getenv("DFHIP_ROWMMA") ? atoi(getenv("DFHIP_ROWMMA")) : 1;
-  static int variant = getenv("DFHIP_ROWMMA_VARIANT") ? atoi(getenv("DFHIP_ROWMMA_VARIANT")) : 0;
-  if (!enabled || k != 3 || stride != 1 || pad != 1) return -1;
+  if (k != 3 || stride != 1 || pad != 1) return -1;
   if (W == 4 && H == 4 && C == 128) {
     const int st4 = run_conv_img4_fwd(x, w, bias, y, N, C, O, partials, cap_rows, rows_out, bn, dry_run);
     if (st4 >= 0) return st4;
@@ -895,13 +865,14 @@ int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y,
   const int64_t tiles = (int64_t)N * HW / 16;
   // (width, channels) -> tiles per wave, tile sets x channel tiles per workgroup
   int nt, ts, ow;
-  // 16- and 8-wide layers: eight tile sets x one channel tile per workgroup (twice the pixel loads, half the weight image and
-  // half as many partial rows for the consumer of the statistics: 15.1 -> 14.5 and 16.1 -> 15.2 us plain, -0.4 us with a
-  // BatchNorm operand); DFHIP_ROWMMA_TS8=0: four tile sets x two channel tiles (rounds 2-3), bit 0 / 1 / 2: plain / BatchNorm form / accumulate-mode input gradient
-  static int ts8 = getenv("DFHIP_ROWMMA_TS8") ? atoi(getenv("DFHIP_ROWMMA_TS8")) : 7;
-  const bool wide = (ts8 & 1) && !bn && partials, wide_bn = (ts8 & 2) && bn;
-  if (W == 16 && C == 32) { nt = 4; ts = (wide || wide_bn) ? 8 : 4; ow = (wide || wide_bn) ? 1 : 2; }
-  else if (W == 8 && C == 64) { nt = 2; ts = (wide || wide_bn) ? 8 : 4; ow = (wide || wide_bn) ? 1 : 2; }
+  // 16- and 8-wide layers that leave BatchNorm partials or read a BatchNorm operand: eight tile sets x one channel tile per
+  // workgroup (twice the pixel loads, half the weight image and half as many partial rows for the consumer of the statistics:
+  // 15.1 -> 14.5 and 16.1 -> 15.2 us plain, -0.4 us with a BatchNorm operand); without statistics four tile sets x two tiles.
+  // Measured and dropped (rounds 2-5): weight chunks of eight channel groups, two chunks of pixels ahead, every weight chunk
+  // committed in the prologue (one barrier), half the tiles per wave on twice the workgroups (+4.5 us with a BatchNorm operand).
+  const bool wide = (!bn && partials) || bn;
+  if (W == 16 && C == 32) { nt = 4; ts = wide ? 8 : 4; ow = wide ? 1 : 2; }
+  else if (W == 8 && C == 64) { nt = 2; ts = wide ? 8 : 4; ow = wide ? 1 : 2; }
   else if (W == 4 && H == 4 && C == 128) { nt = 1; ts = 8; ow = 1; }
   else return -1;
   if (O % (16 * ow) != 0 || tiles % (ts * nt) != 0 || (W == 16 && H % nt != 0)) return -1;
@@ -913,31 +884,15 @@ int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y,
   if (dry_run) return DFHIP_OK;              // eligible: nothing launched
   if (bn) {
     if (!bn->affine) return -1;
-    if (wide_bn && W == 16) return launch_rowmma<4, 32, 4, false, 8, 1, 4, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
-    if (wide_bn && W == 8) return launch_rowmma<3, 64, 2, false, 8, 1, 4, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
-    if (W == 16) return launch_rowmma<4, 32, 4, false, 4, 2, 4, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
-    if (W == 8) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
-    return launch_rowmma<2, 128, 1, true, 8, 1, 8, 1, false, false, true>(x, w, bias, y, partials, H, O, grid, bn);
+    if (W == 16) return launch_rowmma<4, 32, 4, false, 8, 1, 4, false, true>(x, w, bias, y, partials, H, O, grid, bn);
+    if (W == 8) return launch_rowmma<3, 64, 2, false, 8, 1, 4, false, true>(x, w, bias, y, partials, H, O, grid, bn);
+    return launch_rowmma<2, 128, 1, true, 8, 1, 8, false, true>(x, w, bias, y, partials, H, O, grid, bn);
   }
-  if (wide && W == 16) return launch_rowmma<4, 32, 4, false, 8, 1, 4, 1>(x, w, bias, y, partials, H, O, grid);
-  if (wide && W == 8) return launch_rowmma<3, 64, 2, false, 8, 1, 4, 1>(x, w, bias, y, partials, H, O, grid);
-  if (W == 16) {
-    if (variant == 1) return launch_rowmma<4, 32, 4, false, 4, 2, 8, 1>(x, w, bias, y, partials, H, O, grid);
-    if (variant == 2) return launch_rowmma<4, 32, 4, false, 4, 2, 4, 2>(x, w, bias, y, partials, H, O, grid);
-    return launch_rowmma<4, 32, 4, false, 4, 2, 4, 1>(x, w, bias, y, partials, H, O, grid);
-  }
-  if (W == 8) {
-    if (variant == 1) return launch_rowmma<3, 64, 2, false, 4, 2, 8, 1>(x, w, bias, y, partials, H, O, grid);
-    if (variant == 2) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 2>(x, w, bias, y, partials, H, O, grid);
-    if (variant == 3) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 1, false, true>(x, w, bias, y, partials, H, O, grid);
-    if (variant == 4) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 2, false, true>(x, w, bias, y, partials, H, O, grid);
-    return launch_rowmma<3, 64, 2, false, 4, 2, 4, 1>(x, w, bias, y, partials, H, O, grid);
-  }
-  if (variant == 1) return launch_rowmma<2, 128, 1, true, 8, 1, 4, 2>(x, w, bias, y, partials, H, O, grid);
-  if (variant == 2) return launch_rowmma<2, 128, 1, true, 8, 1, 8, 2>(x, w, bias, y, partials, H, O, grid);
-  if (variant == 3) return launch_rowmma<2, 128, 1, true, 8, 1, 8, 1, false, true>(x, w, bias, y, partials, H, O, grid);
-  if (variant == 4) return launch_rowmma<2, 128, 1, true, 8, 1, 4, 2, false, true>(x, w, bias, y, partials, H, O, grid);
-  return launch_rowmma<2, 128, 1, true, 8, 1, 8, 1>(x, w, bias, y, partials, H, O, grid);
+  if (W == 16) return wide ? launch_rowmma<4, 32, 4, false, 8, 1, 4>(x, w, bias, y, partials, H, O, grid)
+                           : launch_rowmma<4, 32, 4, false, 4, 2, 4>(x, w, bias, y, partials, H, O, grid);
+  if (W == 8) return wide ? launch_rowmma<3, 64, 2, false, 8, 1, 4>(x, w, bias, y, partials, H, O, grid)
+                          : launch_rowmma<3, 64, 2, false, 4, 2, 4>(x, w, bias, y, partials, H, O, grid);
+  return launch_rowmma<2, 128, 1, true, 8, 1, 8>(x, w, bias, y, partials, H, O, grid);
 }
 
 
@@ -945,28 +900,23 @@ int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y,
 // w (O, C, 3, 3) -> dx (N, C, H, W) (+ add); -1 when the shape is not eligible
 int run_conv_rowmma_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int C, int H, int W,
                           int O, int k, int stride, int pad) {
-  static int enabled = getenv("DFHIP_ROWMMA_DGRAD") ? atoi(getenv("DFHIP_ROWMMA_DGRAD")) : 1;
-  if (!enabled || k != 3 || stride != 1 || pad != 1) return -1;
+  if (k != 3 || stride != 1 || pad != 1) return -1;
   const int64_t HW = (int64_t)H * W;
   if (HW % 16 != 0) return -1;
   const int64_t tiles = (int64_t)N * HW / 16;
-  // (eight tile sets x one channel tile per workgroup on the 16- and 8-wide layers, as the forward launches: DFHIP_ROWMMA_TS8 bit 2)
-  static int ts8 = getenv("DFHIP_ROWMMA_TS8") ? atoi(getenv("DFHIP_ROWMMA_TS8")) : 7;
-  const bool wide = (ts8 & 4) != 0;
-  int nt, ts, ow;
-  if (W == 16 && O == 32) { nt = 4; ts = wide ? 8 : 4; ow = wide ? 1 : 2; }
-  else if (W == 8 && O == 64) { nt = 2; ts = wide ? 8 : 4; ow = wide ? 1 : 2; }
-  else if (W == 4 && H == 4 && O == 128) { nt = 1; ts = 8; ow = 1; }
+  // (eight tile sets x one channel tile per workgroup on the 16- and 8-wide layers, as the forward launches)
+  int nt, ts = 8, ow = 1;
+  if (W == 16 && O == 32) nt = 4;
+  else if (W == 8 && O == 64) nt = 2;
+  else if (W == 4 && H == 4 && O == 128) nt = 1;
   else return -1;
   if (C % (16 * ow) != 0 || tiles % (ts * nt) != 0 || (W == 16 && H % nt != 0)) return -1;
   const int64_t gx = tiles / (ts * nt);
   if (gx * (C / (16 * ow)) < num_cus() / 2) return -1;
   dim3 grid((unsigned)gx, (unsigned)(C / (16 * ow)));
-  if (wide && W == 16) return launch_rowmma<4, 32, 4, false, 8, 1, 4, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
-  if (wide && W == 8) return launch_rowmma<3, 64, 2, false, 8, 1, 4, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
-  if (W == 16) return launch_rowmma<4, 32, 4, false, 4, 2, 4, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
-  if (W == 8) return launch_rowmma<3, 64, 2, false, 4, 2, 4, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
-  return launch_rowmma<2, 128, 1, true, 8, 1, 8, 1, true>(dy, w, add, dx, nullptr, H, C, grid);
+  if (W == 16) return launch_rowmma<4, 32, 4, false, 8, 1, 4, true>(dy, w, add, dx, nullptr, H, C, grid);
+  if (W == 8) return launch_rowmma<3, 64, 2, false, 8, 1, 4, true>(dy, w, add, dx, nullptr, H, C, grid);
+  return launch_rowmma<2, 128, 1, true, 8, 1, 8, true>(dy, w, add, dx, nullptr, H, C, grid);
 }
 
 }  // namespace dfhip

@@ -59,7 +59,7 @@ constexpr int kBlk2 = 260;   // LDS pitch (floats) of a block of four operands x
 // KS: waves that share a tile and split every chunk's channel groups between them (1 or 2; their accumulators are
 // summed through LDS at the end): two waves per SIMD where the problem has only 1 024 tile x channel-tile units, and
 // each wave requests only its own groups' pixels.
-template <int C, int OWW, int TS, int OWG, int CG, int XA, int KS, bool LSH>
+template <int C, int OWW, int TS, int OWG, int CG, int XA, int KS>
 __global__ __launch_bounds__(64 * TS * OWG * KS) void k_conv3x3s2_pair(const float* __restrict__ x,
                                                                  const float* __restrict__ w,
                                                                  const float* __restrict__ wd,
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64 * TS * OWG * KS) void k_conv3x3s2_pair(const flo
 #pragma unroll
   for (int u = 0; u < PER; u++) {
     const int q = tid + NTHR * u;
-    const int qq = q < TOT4 ? q : q - NTHR;    // (threads past the end re-do a piece: every load keeps a consumer)
+    const int qq = q < TOT4 ? q : q % TOT4;    // (threads past the end re-do a piece: every load keeps a consumer)
     const int tl = qq / (16 * ROW4), r = qq - tl * (16 * ROW4);
     const int m = r / ROW4, e4 = r - m * ROW4;
     wsrc[u] = w + ((int64_t)(o_wg + tl * 16 + m) * C * 9) + 4 * e4;
@@ -144,13 +144,12 @@ __global__ __launch_bounds__(64 * TS * OWG * KS) void k_conv3x3s2_pair(const flo
   // per source row i: the taps j = 1, 2 are the adjacent pixels (2s, 2s + 1) -- ONE 8-byte load -- and j = 0 is pixel
   // 2s - 1 (the address unit takes ~24 cycles per wave load of this kernel's shape whatever its width: nine 4-byte
   // loads per channel group kept it busier than the matrix cores)
-  unsigned xo2[3], xo0[3];
+  unsigned xo2[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     const int yy = 2 * r + i - 1;
     const bool rowok = yy >= 0 && yy < W;
     xo2[i] = rowok ? (unsigned)((((int64_t)img * C + kk) * W + yy) * W + 2 * s) * 4u : kOut;
-    xo0[i] = (rowok && s > 0) ? (unsigned)((((int64_t)img * C + kk) * W + yy) * W + 2 * s - 1) * 4u : kOut;
   }
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7fffffff, 0x00020000);
   float raw[NG / KS][9];                       // this wave's groups: chunk ch holds raw[ch * CGW ..]
@@ -162,11 +161,7 @@ __global__ __launch_bounds__(64 * TS * OWG * KS) void k_conv3x3s2_pair(const flo
       _Pragma("unroll") for (int i_ = 0; i_ < 3; i_++) {                                                  \
         const f32x2 t2_ = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)xo2[i_], p_ * (16 * HW), 0)); \
         raw[q_][i_ * 3 + 1] = t2_[0]; raw[q_][i_ * 3 + 2] = t2_[1];                                       \
-        if constexpr (LSH) {                                  /* pixel 2s - 1 is the neighbouring lane's 2(s-1) + 1 */ \
-          raw[q_][i_ * 3] = 0.0f;                                                                            \
-        } else {                                                                                            \
-          raw[q_][i_ * 3] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)xo0[i_], p_ * (16 * HW), 0)); \
-        }                                                                                                   \
+        raw[q_][i_ * 3] = 0.0f;          /* pixel 2s - 1 is the neighbouring lane's 2(s-1) + 1: a lane shift below */ \
       }                                                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                                  \
     }                                                                                                     \
@@ -179,7 +174,7 @@ __global__ __launch_bounds__(64 * TS * OWG * KS) void k_conv3x3s2_pair(const flo
 #pragma unroll
   for (int u = 0; u < PER; u++) {
     const int q = tid + NTHR * u;
-    const int qq = q < TOT4 ? q : q - NTHR;
+    const int qq = q < TOT4 ? q : q % TOT4;
     const int tl = qq / (16 * ROW4), r = qq - tl * (16 * ROW4);
     const int m = r / ROW4, e4 = r - m * ROW4;
 #pragma unroll
@@ -241,14 +236,13 @@ __global__ __launch_bounds__(64 * TS * OWG * KS) void k_conv3x3s2_pair(const flo
           for (int q = 0; q < WBLK; q++)
             a4[(ch + 1) & 1][a][q] = Wl4[a * (NBLK * kBlk2 / 4) + ((ch + 1) * CBLK + q) * (kBlk2 / 4)];
       }
-      if constexpr (LSH) {
-        // tap column 0 = the left neighbour's column 2 (one DPP move + one select per source row; the address unit
-        // was the busier side: six wave loads per channel group against twenty MFMAs)
+      // tap column 0 = the left neighbour's column 2 (one DPP move + one select per source row; the address unit
+      // was the busier side: six wave loads per channel group against twenty MFMAs -- a 4-byte load of pixel 2s - 1 per
+      // source row instead: +1 us)
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-          const float sh = dpp_mov2<0x111>(raw[p][i * 3 + 2]);    // row_shr:1, zero into lane 0 of the 16
-          raw[p][i * 3] = s > 0 ? sh : 0.0f;
-        }
+      for (int i = 0; i < 3; i++) {
+        const float sh = dpp_mov2<0x111>(raw[p][i * 3 + 2]);    // row_shr:1, zero into lane 0 of the 16
+        raw[p][i * 3] = s > 0 ? sh : 0.0f;
       }
 #pragma unroll
       for (int t = 0; t < 9; t++) {
@@ -342,17 +336,17 @@ __global__ __launch_bounds__(64 * TS * OWG * KS) void k_conv3x3s2_pair(const flo
   S2_STAMP(7);
 }
 
-template <int C, int OWW, int TS, int OWG, int CG, int XA, int KS = 1, bool LSH = false>
-int launch_s2_(const float* x, const float* w, const float* wd, float* y, float* yd, float* partials, float* partials_d,
+template <int C, int OWW, int TS, int OWG, int CG, int XA, int KS = 1>
+int launch_s2(const float* x, const float* w, const float* wd, float* y, float* yd, float* partials, float* partials_d,
               int lwo, int O, dim3 grid) {
   const size_t lds = (size_t)(OWG * OWW) * (C / 4 * 10 / 4) * kBlk2 * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA, KS, LSH>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA, KS>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536)));
     attr = true;
   }
-  DF_LAUNCH((k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA, KS, LSH>), grid, dim3(64 * TS * OWG * KS), lds, stream(), x, w, wd, y, yd, partials,
+  DF_LAUNCH((k_conv3x3s2_pair<C, OWW, TS, OWG, CG, XA, KS>), grid, dim3(64 * TS * OWG * KS), lds, stream(), x, w, wd, y, yd, partials,
             partials_d, lwo, O);
   DF_LAUNCH_CHECK();
 #ifdef DFHIP_S2_STAMPS
@@ -380,14 +374,6 @@ int launch_s2_(const float* x, const float* w, const float* wd, float* y, float*
   }
 #endif
   return DFHIP_OK;
-}
-
-template <int C, int OWW, int TS, int OWG, int CG, int XA, int KS = 1>
-int launch_s2(const float* x, const float* w, const float* wd, float* y, float* yd, float* partials, float* partials_d,
-              int lwo, int O, dim3 grid) {
-  static int lsh = getenv("DFHIP_S2_LSH") ? atoi(getenv("DFHIP_S2_LSH")) : 1;
-  if (lsh) return launch_s2_<C, OWW, TS, OWG, CG, XA, KS, true>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-  return launch_s2_<C, OWW, TS, OWG, CG, XA, KS, false>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
 }
 
 
@@ -690,8 +676,7 @@ namespace dfhip {
 // [+ that of the block's conv1x1/s2/p0 shortcut from dy2, w2]; -1 when the shape is not one this kernel takes
 int run_dgrad_s2_acc(const float* dy, const float* w, const float* dy2, const float* w2, const float* add, float* dx, int N,
                      int C, int H, int W, int O, bool dry_run) {
-  static int enabled = getenv("DFHIP_DGRAD_S2_ACC") ? atoi(getenv("DFHIP_DGRAD_S2_ACC")) : 1;
-  if (!enabled || H != W || H < 4 || (H & (H - 1)) || C % 32 != 0 || !(O == 64 || O == 128 || O == 256)) return -1;
+  if (H != W || H < 4 || (H & (H - 1)) || C % 32 != 0 || !(O == 64 || O == 128 || O == 256)) return -1;
   const int64_t cp = (int64_t)N * (H / 2) * (W / 2);       // pixels per class
   if (cp % 128 != 0) return -1;
   if (dry_run) return DFHIP_OK;
@@ -728,9 +713,8 @@ int run_dgrad_s2_acc(const float* dy, const float* w, const float* dy2, const fl
 // not one this kernel takes (dry_run: only the shape test)
 int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y, float* yd, int N, int C, int H, int W,
                        int O, float* partials, float* partials_d, int cap_rows, int* rows_out, bool dry_run) {
-  static int enabled = getenv("DFHIP_S2_PAIR") ? atoi(getenv("DFHIP_S2_PAIR")) : 1;
-  if (!enabled || H != W) return -1;
-  static int img4 = getenv("DFHIP_S2_IMG4") ? atoi(getenv("DFHIP_S2_IMG4")) : 1;
+  if (H != W) return -1;
+  constexpr int img4 = 1;
   if (img4 && C == 128 && H == 4 && N % 16 == 0 && O % 16 == 0 && (!partials || N / 16 <= cap_rows) &&
       (int64_t)(N / 16) * (O / 16) >= num_cus() / 2) {
     // an image on the lane, taps outside the image not multiplied (k_conv3x3s2_img4_pair)
@@ -748,13 +732,16 @@ int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
   }
-  static int variant = getenv("DFHIP_S2_VARIANT") ? atoi(getenv("DFHIP_S2_VARIANT")) : 0;
-  int otw, ts, owg, lwo;
-  if (C == 32 && H == 16) { otw = 2; ts = 4; owg = 2; lwo = 3; }
-  else if (C == 64 && H == 8) { otw = 2; ts = 4; owg = 1; lwo = 2; }
-  else if (C == 128 && H == 4) { otw = 1; ts = 4; owg = 1; lwo = 1; }
+  // (32 -> 64 channels: a workgroup = eight pixel tiles x ONE group of two channel tiles -- a pixel tile is then requested by
+  // one wave of the workgroup only and the weight image is half as large: 11.8 -> 11.3 us against four tiles x two groups
+  // (round 5).  Measured and dropped before: chunks of four channel groups (13.4 -> 14.9 us), three chunks of pixels ahead,
+  // two waves splitting a tile's groups.)
+  int otw, ts, lwo;
+  if (C == 32 && H == 16) { otw = 2; ts = 8; lwo = 3; }
+  else if (C == 64 && H == 8) { otw = 2; ts = 4; lwo = 2; }
+  else if (C == 128 && H == 4) { otw = 1; ts = 4; lwo = 1; }
   else return -1;
-  const int ocw = otw * owg * 16;              // output channels per workgroup
+  const int ocw = otw * 16;                    // output channels per workgroup
   const int64_t opix = (int64_t)N * (H / 2) * (W / 2);
   if (O % ocw != 0 || opix % (16 * ts) != 0) return -1;
   const int64_t gx = opix / (16 * ts);
@@ -763,22 +750,8 @@ int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y
   if (rows_out) *rows_out = partials ? (int)gx : 0;
   if (dry_run) return DFHIP_OK;
   dim3 grid((unsigned)gx, (unsigned)(O / ocw));
-  if (C == 32) {
-    // (chunks of two channel groups, two chunks of pixels ahead: the first MFMA waits for a quarter of the operands
-    // instead of half -- 13.4 us against 14.9 with chunks of four)
-    if (variant == 1) return launch_s2<32, 2, 4, 2, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-    if (variant == 3) return launch_s2<32, 2, 4, 2, 2, 3>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-    return launch_s2<32, 2, 4, 2, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-  }
-  if (C == 64) {
-    // (two channel tiles per wave: the two waves of a tile otherwise request the same pixels twice -- 12.8 against
-    // 15.5 us; splitting the channel groups over two waves per tile changes nothing: 13.0)
-    if (variant == 1) return launch_s2<64, 2, 4, 1, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-    if (variant == 3) return launch_s2<64, 2, 4, 1, 2, 3>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-    return launch_s2<64, 2, 4, 1, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-  }
-  if (variant == 1) return launch_s2<128, 1, 4, 1, 4, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-  if (variant == 3) return launch_s2<128, 1, 4, 1, 2, 3>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  if (C == 32) return launch_s2<32, 2, 8, 1, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  if (C == 64) return launch_s2<64, 2, 4, 1, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
   return launch_s2<128, 1, 4, 1, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
 }
 

@@ -557,25 +557,23 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__
 // keeps tap (1 + (y & 1), 1 + (x & 1)) of source (y >> 1, x >> 1) (four sources); PAIR (GEO 1): the block's 1x1 /
 // stride 2 shortcut adds sum_o dY2[o][y/2][x/2] W2[o][c] on the pixels with even (y, x) -- a fifth slice.
 // GEO 2: the GEO 1 pattern on one 4 x 4 block (blockIdx.z) of an 8 x 8 image whose dY is 4 x 4 (layer3's first
-// block: 256 workgroups where whole images would give 64).  TR: the dY planes are requested in memory order and turned
+// block: 256 workgroups where whole images would give 64).  The dY planes are requested in memory order and turned
 // into the image-per-lane order through a wave-private LDS strip (see the operand section below).
 // HS 2 (GEO 0 / 1): blockIdx.z selects image rows 2 z, 2 z + 1 -- eight accumulators per lane, twice the workgroups (the
 // 128-channel layers gave 128 workgroups of four waves: half the CUs had nothing, the other half one wave per SIMD);
 // a pixel's products are added in the same order either way.
 constexpr int kImg4Strip = 16 * 260;     // floats of a wave's transposition strip (16 images x (256 + 4))
-template <int O, int GEO, bool PAIR, bool TR, int HS = 1>
+template <int O, int GEO, bool PAIR, int HS = 1>
 __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__ dy, const float* __restrict__ w,
                                                        const float* __restrict__ add, float* __restrict__ dx, int C,
                                                        const float* __restrict__ dy2, const float* __restrict__ w2, int S,
-                                                       int xo, int coal) {
+                                                       int xo) {
   static_assert(!PAIR || GEO >= 1, "the shortcut rides on the stride-2 forms");
-  static_assert(GEO != 2 || TR, "the sub-image form reads its planes through the strip");
   static_assert(HS == 1 || (HS == 2 && GEO != 2), "row halves: whole 4 x 4 images only");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int OQ = O / 4, NK = OQ / 4;             // o per wave, MFMA k-steps per wave
   constexpr int SW = GEO == 0 ? 3 : 2, NS = SW * SW;  // sources per image: SW x SW of a (GEO 0: 4, GEO 1: 2)-wide plane
-  constexpr int PW = GEO == 0 ? 4 : 2, SP = PW * PW;  // dY plane
   constexpr int NSL = PAIR ? 5 : 4;
   float* Wl = smem;                                 // [NSL slices][O][16 channels]; later the exchange area [3][16][64] f32x4
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -590,9 +588,9 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
   // dY operands of this wave's o range: the sources of image n0 + n, channel ob + 4 p + kk.  A lane is an IMAGE, so
   // read directly every lane of a request is a line of its own and the address unit takes them one per cycle (24-48
   // requests x 64 lines per wave); instead the wave requests its (16 images x channels) block in the order it lies in
-  // memory -- a request = 1 KB = 8 lines -- and turns it through a wave-private LDS strip (`TR`).
+  // memory -- a request = 1 KB = 8 lines -- and turns it through a wave-private LDS strip.
   float sv[NK][NS], sv2[PAIR ? NK : 1][4];
-  if constexpr (TR) {
+  {
     constexpr int WLF = (NSL * O * 16 > 3 * 16 * 64 * 4) ? NSL * O * 16 : 3 * 16 * 64 * 4;
     float* strip = smem + WLF + wave * kImg4Strip;
     if constexpr (GEO == 0) {
@@ -690,28 +688,6 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
       turn(dy, sv);
       if constexpr (PAIR) turn(dy2, sv2);
     }
-  } else {
-    const float* sp = dy + ((int64_t)(n0 + n) * O + ob + kk) * SP;
-#pragma unroll
-    for (int p = 0; p < NK; p++) {
-      if constexpr (GEO == 1) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(sp + (int64_t)p * 4 * SP);       // the 2 x 2 plane
-        sv[p][0] = t[0]; sv[p][1] = t[1]; sv[p][2] = t[2]; sv[p][3] = t[3];
-      } else {
-#pragma unroll
-        for (int u = 0; u < SW; u++)
-#pragma unroll
-          for (int v = 0; v < SW; v++) sv[p][u * SW + v] = sp[(int64_t)p * 4 * SP + u * PW + v];
-      }
-    }
-    if constexpr (PAIR) {
-      const float* sp2 = dy2 + ((int64_t)(n0 + n) * O + ob + kk) * SP;
-#pragma unroll
-      for (int p = 0; p < NK; p++) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(sp2 + (int64_t)p * 4 * SP);     // the 2 x 2 plane
-        sv2[p][0] = t[0]; sv2[p][1] = t[1]; sv2[p][2] = t[2]; sv2[p][3] = t[3];
-      }
-    }
   }
   // weight slices: (o, c) pairs, taps 4, 5, 7, 8 of each (+ the shortcut's weight)
   constexpr int PAIRS = O * 16 / 256, PB = PAIRS < 8 ? PAIRS : 8;
@@ -777,98 +753,63 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
   else products(std::integral_constant<int, 0>{});
   __syncthreads();                                  // the weight image is dead: it becomes the exchange area
   f32x4* ex = reinterpret_cast<f32x4*>(smem);
-  if (coal) {
-    // All four waves leave their partial tiles in LDS, then the 256 threads walk the workgroup's output in MEMORY order --
-    // (image, channel, row): 16-byte pieces that are neighbours in dx -- and add the four partials of a piece in wave
-    // order (the sums of the one-wave epilogue below, bit for bit).  A lane of the accumulator is an image: stored
-    // straight from the registers every lane of a store instruction is a line of its own (64 lines, and as many for
-    // the gradient the tensor already holds).
+  // All four waves leave their partial tiles in LDS, then the 256 threads walk the workgroup's output in MEMORY order --
+  // (image, channel, row): 16-byte pieces that are neighbours in dx -- and add the four partials of a piece in wave
+  // order.  A lane of the accumulator is an image: stored straight from the registers every lane of a store instruction
+  // is a line of its own (64 lines, and as many for the gradient the tensor already holds; one wave storing the sums
+  // that way: 7.7 -> 7.3 us x 3, 10.3 -> 9.9, 10.9 -> 10.7 us in round 4).
 #pragma unroll
-    for (int q = 0; q < NQ; q++) ex[(wave * NQ + q) * 64 + lane] = acc[q];
-    __syncthreads();
-    const float* exf = reinterpret_cast<const float*>(smem);
-    const int rowp = GEO == 2 ? S : 4, plane = GEO == 2 ? S * S : 16;
-    const int64_t wbase = ((int64_t)n0 * C + c0) * plane + (GEO == 2 ? 4 * qy * S + 4 * qx : 0) + 8 * hz;
-#pragma unroll
-    for (int i = 0; i < 16 * 16 * NY / 256; i++) {
-      const int f = tid + 256 * i;
-      const int y = f % NY, ch = (f / NY) % 16, im = f / (NY * 16);
-      const int src = ((ch >> 2) * 16 + im) * 4 + (ch & 3);         // float index of (lane, v) inside a tile's 64 x 4 block
-      f32x4 r;
-#pragma unroll
-      for (int xx = 0; xx < 4; xx++) {
-        const int q = y * 4 + xx;
-        float t = exf[(0 * NQ + q) * 256 + src];
-        t += exf[(1 * NQ + q) * 256 + src];
-        t += exf[(2 * NQ + q) * 256 + src];
-        t += exf[(3 * NQ + q) * 256 + src];
-        r[xx] = t;
-      }
-      const int64_t at = wbase + ((int64_t)im * C + ch) * plane + rowp * y;
-      if (add) r += *reinterpret_cast<const f32x4*>(add + at);
-      *reinterpret_cast<f32x4*>(dx + at) = r;
-    }
-    return;
-  }
-  if (wave > 0) {
-#pragma unroll
-    for (int q = 0; q < NQ; q++) ex[((wave - 1) * NQ + q) * 64 + lane] = acc[q];
-  }
+  for (int q = 0; q < NQ; q++) ex[(wave * NQ + q) * 64 + lane] = acc[q];
   __syncthreads();
-  if (wave == 0) {
+  const float* exf = reinterpret_cast<const float*>(smem);
+  const int rowp = GEO == 2 ? S : 4, plane = GEO == 2 ? S * S : 16;
+  const int64_t wbase = ((int64_t)n0 * C + c0) * plane + (GEO == 2 ? 4 * qy * S + 4 * qx : 0) + 8 * hz;
 #pragma unroll
-    for (int ww = 0; ww < 3; ww++)
+  for (int i = 0; i < 16 * 16 * NY / 256; i++) {
+    const int f = tid + 256 * i;
+    const int y = f % NY, ch = (f / NY) % 16, im = f / (NY * 16);
+    const int src = ((ch >> 2) * 16 + im) * 4 + (ch & 3);         // float index of (lane, v) inside a tile's 64 x 4 block
+    f32x4 r;
 #pragma unroll
-      for (int q = 0; q < NQ; q++) acc[q] += ex[(ww * NQ + q) * 64 + lane];
-    // register v of lane (kk, n) is channel c0 + 4 kk + v of image n0 + n; its sixteen pixels are adjacent
-    // (GEO 2: rows of the block are S floats apart in an S x S plane)
-    const int rowp = GEO == 2 ? S : 4, plane = GEO == 2 ? S * S : 16;
-    const int64_t obase = ((int64_t)(n0 + n) * C + c0 + 4 * kk) * plane + (GEO == 2 ? 4 * qy * S + 4 * qx : 0) + 8 * hz;
-#pragma unroll
-    for (int v = 0; v < 4; v++)
-#pragma unroll
-      for (int y = 0; y < NY; y++) {
-        f32x4 r = {acc[y * 4][v], acc[y * 4 + 1][v], acc[y * 4 + 2][v], acc[y * 4 + 3][v]};
-        if (add) r += *reinterpret_cast<const f32x4*>(add + obase + (int64_t)plane * v + rowp * y);
-        *reinterpret_cast<f32x4*>(dx + obase + (int64_t)plane * v + rowp * y) = r;
-      }
+    for (int xx = 0; xx < 4; xx++) {
+      const int q = y * 4 + xx;
+      float t = exf[(0 * NQ + q) * 256 + src];
+      t += exf[(1 * NQ + q) * 256 + src];
+      t += exf[(2 * NQ + q) * 256 + src];
+      t += exf[(3 * NQ + q) * 256 + src];
+      r[xx] = t;
+    }
+    const int64_t at = wbase + ((int64_t)im * C + ch) * plane + rowp * y;
+    if (add) r += *reinterpret_cast<const f32x4*>(add + at);
+    *reinterpret_cast<f32x4*>(dx + at) = r;
   }
 }
 
 template <int O, int GEO, bool PAIR>
 int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* dx, int N, int C, const float* dy2,
                       const float* w2, int S = 4) {
-  static int tr_env = getenv("DFHIP_IMG4_TR") ? atoi(getenv("DFHIP_IMG4_TR")) : 1;
-  static int halves_env = getenv("DFHIP_IMG4_HALVES") ? atoi(getenv("DFHIP_IMG4_HALVES")) : 1;
-  const int tr = GEO == 2 ? 1 : tr_env;
   // whole images give (N / 16) x (C / 16) workgroups: where that leaves CUs without one, a workgroup takes two image rows
-  const bool halves = GEO != 2 && tr && halves_env && (N / 16) * (C / 16) < num_cus();
+  const bool halves = GEO != 2 && (N / 16) * (C / 16) < num_cus();
   dim3 grid((unsigned)(N / 16), (unsigned)(C / 16), (unsigned)(GEO == 2 ? (S / 4) * (S / 4) : (halves ? 2 : 1)));
-  static int coal_env = getenv("DFHIP_IMG4_COAL") ? atoi(getenv("DFHIP_IMG4_COAL")) : 1;
-  const int coal = coal_env ? 1 : 0;               // the epilogue in memory order (four partial tiles in LDS instead of three)
   const size_t base = std::max((size_t)(PAIR ? 5 : 4) * O * 16, (size_t)4 * 16 * 64 * 4) * sizeof(float);
-  const size_t lds = base + (tr ? (size_t)4 * kImg4Strip * sizeof(float) : 0);
+  const size_t lds = base + (size_t)4 * kImg4Strip * sizeof(float);
   // blockIdx.y selects 16 input channels' weight columns (NSL slices x O), blockIdx.x 16 images of dY
   const int dyp = GEO == 0 ? 16 : (GEO == 1 ? 4 : (S / 2) * (S / 2));
   const int xo = xcd_arrangement(N / 16, C / 16, 4.0 * N * O * dyp * (PAIR ? 2 : 1), 4.0 * O * C * (PAIR ? 5 : 4));
   static bool attr = false;
   if (!attr) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)std::max(base + (size_t)4 * kImg4Strip * sizeof(float), (size_t)65536)));
-    if constexpr (GEO != 2) {
-      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)std::max(base, (size_t)65536)));
-      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if constexpr (GEO != 2)
+      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)std::max(base + (size_t)4 * kImg4Strip * sizeof(float), (size_t)65536)));
-    }
     attr = true;
   }
   if constexpr (GEO == 2) {
-    DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo, coal);
+    DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
   } else {
-    if (halves) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true, 2>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo, coal);
-    else if (tr) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, true>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo, coal);
-    else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, false>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo, coal);
+    if (halves) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, 2>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
+    else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
   }
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -911,9 +852,8 @@ int launch_ow_s1(const float* dy, const float* w, const float* add, float* dx, i
     return -2;
   } else {
     // eight waves per workgroup for the 32-channel layers (half the rows, half the readers of the rows: see the kernel)
-    static int nw8 = getenv("DFHIP_DGRAD_BN_NW8") ? atoi(getenv("DFHIP_DGRAD_BN_NW8")) : 1;
     constexpr bool CAN8 = O == 32 && !PAIR;
-    const int nw = (CAN8 && nw8) ? 8 : 4;
+    constexpr int nw = CAN8 ? 8 : 4;
     dim3 grid((unsigned)df_ceil_div(tiles, nw), (unsigned)(C / 32));
     if (so) so->nrows = (int)grid.x;
     if (dry_run) return DFHIP_OK;
@@ -927,11 +867,7 @@ int launch_ow_s1(const float* dy, const float* w, const float* add, float* dx, i
 #define DF_OW(BNIV, NSTV, NWV)                                                                                          \
   DF_LAUNCH((k_dgrad_ow_s1<O, GEO, PAIR, BNIV, NSTV, NWV>), grid, dim3(64 * NWV), 0, stream(), dy, w, add, dx, C, H, lw, \
             tiles, pg, dy2, w2, bn)
-#define DF_OW_NW(BNIV, NSTV)                                    \
-  do {                                                          \
-    if constexpr (CAN8) { if (nw == 8) { DF_OW(BNIV, NSTV, 8); break; } } \
-    DF_OW(BNIV, NSTV, 4);                                       \
-  } while (0)
+#define DF_OW_NW(BNIV, NSTV) DF_OW(BNIV, NSTV, nw)
     if (bni) { if (nst == 0) DF_OW_NW(true, 0); else if (nst == 1) DF_OW_NW(true, 1); else DF_OW_NW(true, 2); }
     else { if (nst == 1) DF_OW_NW(false, 1); else DF_OW_NW(false, 2); }
 #undef DF_OW_NW
@@ -952,8 +888,6 @@ namespace dfhip {
 
 int run_dgrad_ow(const float* dy, const float* w, const float* add, float* dx, int N, int C, int H, int W, int O, int k,
                  int stride, int pad, const BnBwdIn* bi, BnStatsOut* so, bool dry_run) {
-  static int lean = getenv("DFHIP_DGRAD_LEAN") ? atoi(getenv("DFHIP_DGRAD_LEAN")) : 1;
-  if (!lean) return -1;
   const int oh = (H + 2 * pad - k) / stride + 1, ow = (W + 2 * pad - k) / stride + 1;
   const bool bnform = bi || so;
   int lw = 0;
@@ -966,8 +900,7 @@ int run_dgrad_ow(const float* dy, const float* w, const float* add, float* dx, i
   const int tiles = lean_ok ? (int)((int64_t)N * H * W / 32) : 0;
   // stride 2: parity-grouped tiles when whole 128-pixel blocks tile the tensor
   const int pg = (geo == 1 && ((int64_t)N * H * W) % 128 == 0 && W <= 64) ? 1 : 0;
-  static int img2 = getenv("DFHIP_DGRAD_IMG2") ? atoi(getenv("DFHIP_DGRAD_IMG2")) : 1;
-  if (img2 && geo == 0 && H == 2 && W == 2 && N % 16 == 0 && C % 16 == 0 && (O == 128 || O == 256 || O == 512)) {
+  if (geo == 0 && H == 2 && W == 2 && N % 16 == 0 && C % 16 == 0 && (O == 128 || O == 256 || O == 512)) {
     if (bnform) return -2;
     if (dry_run) return DFHIP_OK;
     // 2 x 2 images: a plain product (k_dgrad_ow_img2)
@@ -990,8 +923,7 @@ int run_dgrad_ow(const float* dy, const float* w, const float* add, float* dx, i
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
   }
-  static int img4 = getenv("DFHIP_DGRAD_IMG4") ? atoi(getenv("DFHIP_DGRAD_IMG4")) : 1;
-  if (img4 && (geo == 0 || geo == 1) && H == 4 && W == 4 && N % 16 == 0 && C % 16 == 0 &&
+  if ((geo == 0 || geo == 1) && H == 4 && W == 4 && N % 16 == 0 && C % 16 == 0 &&
       ((geo == 0 && (O == 64 || O == 128)) || (geo == 1 && (O == 128 || O == 256)))) {
     if (bnform) return -2;
     if (dry_run) return DFHIP_OK;
@@ -1030,11 +962,8 @@ int run_dgrad_ow(const float* dy, const float* w, const float* add, float* dx, i
   if (lean_ok && (O == 32 || O == 64)) {
     if (bnform && geo == 2) return -2;
     const float* none = nullptr;
-    // stride 1: tiles that never mix image row 0 with later rows (OwGeo::decode, `pg`): DFHIP_DGRAD_ROW0 bit 0: 16-wide images,
-    // bit 1: 8-wide ones
-    static int row0_env = getenv("DFHIP_DGRAD_ROW0") ? atoi(getenv("DFHIP_DGRAD_ROW0")) : 3;
-    const bool row0 = geo == 0 && W <= 32 && N % (32 / W) == 0 && tiles % H == 0 &&
-                      ((W == 16 && (row0_env & 1)) || (W == 8 && (row0_env & 2)));
+    // stride 1, 16- and 8-wide images: tiles that never mix image row 0 with later rows (OwGeo::decode, `pg`)
+    const bool row0 = geo == 0 && (W == 16 || W == 8) && N % (32 / W) == 0 && tiles % H == 0;
     const int pgs = geo == 0 ? (row0 ? 1 : 0) : pg;
 #define DF_A(OV, GV) return launch_ow_s1<OV, GV, false>(dy, w, add, dx, C, H, lw, tiles, pgs, none, none, bi, nullptr, so, dry_run)
     if (O == 32) { if (geo == 0) DF_A(32, 0); else if (geo == 1) DF_A(32, 1); else DF_A(32, 2); }
@@ -1047,23 +976,18 @@ int run_dgrad_ow(const float* dy, const float* w, const float* add, float* dx, i
 int run_dgrad_ow_pair(const float* dy, const float* w, const float* dy2, const float* w2, const float* add, float* dx,
                       int N, int C, int H, int W, int O, const BnBwdIn* bi, const BnBwdIn* bi2, BnStatsOut* so,
                       bool dry_run) {
-  static int lean = getenv("DFHIP_DGRAD_LEAN") ? atoi(getenv("DFHIP_DGRAD_LEAN")) : 1;
-  static int pair_on = getenv("DFHIP_DGRAD_PAIR") ? atoi(getenv("DFHIP_DGRAD_PAIR")) : 1;
-  if (!lean || !pair_on) return -1;
   const int oh = (H + 2 - 3) / 2 + 1, ow = (W + 2 - 3) / 2 + 1;
   const bool bnform = bi || bi2 || so;
   int lw = 0;
   while ((1 << lw) < W) lw++;
-  static int img4 = getenv("DFHIP_DGRAD_IMG4") ? atoi(getenv("DFHIP_DGRAD_IMG4")) : 1;
-  if (img4 && H == 4 && W == 4 && N % 16 == 0 && C % 16 == 0 && (O == 128 || O == 256)) {
+  if (H == 4 && W == 4 && N % 16 == 0 && C % 16 == 0 && (O == 128 || O == 256)) {
     // 4 x 4 images (layer4's first block): the image-per-lane kernel with the shortcut as a fifth slice
     if (bnform) return -2;
     if (dry_run) return DFHIP_OK;
     return O == 128 ? launch_dgrad_img4<128, 1, true>(dy, w, add, dx, N, C, dy2, w2)
                     : launch_dgrad_img4<256, 1, true>(dy, w, add, dx, N, C, dy2, w2);
   }
-  static int img8 = getenv("DFHIP_DGRAD_IMG8") ? atoi(getenv("DFHIP_DGRAD_IMG8")) : 1;
-  if (img4 && img8 && H == 8 && W == 8 && N % 16 == 0 && C % 16 == 0 && (O == 64 || O == 128)) {
+  if (H == 8 && W == 8 && N % 16 == 0 && C % 16 == 0 && (O == 64 || O == 128)) {
     // 8 x 8 images (layer3's first block): four 4 x 4 blocks per image, each the image-per-lane kernel of the case above
     if (bnform) return -2;
     if (dry_run) return DFHIP_OK;

@@ -1122,8 +1122,7 @@ __global__ __launch_bounds__(512) void k_bn_fused_bwd_pair_hw4(const float* __re
 }
 
 inline bool bn_hw4_ok(int N, int C, int HW) {
-  static int on = getenv("DFHIP_BN_BWD_HW4") ? atoi(getenv("DFHIP_BN_BWD_HW4")) : 1;
-  return on && HW == 4 && C % 8 == 0 && N <= 64 * kBn4;
+  return HW == 4 && C % 8 == 0 && N <= 64 * kBn4;
 }
 
 inline bool bn_fused_ok(int N, int C, int HW) {
@@ -1671,46 +1670,6 @@ int fill_batch(TensorBatch& tb, int n, int first, float* const* p, const float* 
 
 }  // namespace
 
-// (scale, shift) of a training-mode BatchNorm from convolution partials, nothing normalised: the consumer is a
-// convolution that applies the pair on its operand loads (dfhip_conv2d_forward_bn_input).  One wave per channel.
-__global__ __launch_bounds__(256) void k_bn_finalize_partials(BnInput bn, int C) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C) return;
-  constexpr int RP = 8;                     // rows per lane: up to 512 rows
-  float pn[RP], pm[RP], pq[RP];
-#pragma unroll
-  for (int k = 0; k < RP; k++) {
-    // (unconditional loads at a clamped row, all in flight together: a load under `if (r < rows)` is a basic block
-    // of its own and a round trip of its own)
-    const int r = lane + 64 * k;
-    const float* p = bn.part + ((int64_t)min(r, bn.rows - 1) * C + c) * 3;
-    const float a0 = p[0], a1 = p[1], a2 = p[2];
-    pn[k] = r < bn.rows ? a0 : 0.0f; pm[k] = a1; pq[k] = r < bn.rows ? a2 : 0.0f;
-  }
-  // one butterfly over three shifted sums (rows_add above; the shift is row 0's mean) instead of the weighted mean
-  // first and the centred moment about it second
-  const float g_c = chan_param(bn.gamma, bn.part, c, 1.0f), b_c = chan_param(bn.beta, bn.part, c, 0.0f);   // (up front)
-  const float rm_c = chan_param(bn.running_mean, bn.part, c, 0.0f), rv_c = chan_param(bn.running_var, bn.part, c, 0.0f);
-  const float shift = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pm[0])));
-  RowSums t = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int k = 0; k < RP; k++) rows_add(t, pn[k], pm[k], pq[k], shift);
-  t.n = wave_sum(t.n); t.a1 = wave_sum(t.a1); t.a2 = wave_sum(t.a2);
-  if (lane != 0) return;
-  const float n = t.n;
-  const float mu_s = n > 0.0f ? t.a1 / n : 0.0f;
-  const float mu = shift + mu_s;
-  const float var = n > 0.0f ? fmaxf(t.a2 - t.a1 * mu_s, 0.0f) / n : 0.0f;           // biased variance (batchnorm.py:41-42)
-  const float rsd = 1.0f / sqrtf(var + bn.eps);
-  const float sc = g_c * rsd;
-  const float sh = b_c - mu * sc;
-  if (bn.save_mean) bn.save_mean[c] = mu;
-  if (bn.save_var) bn.save_var[c] = var;
-  if (bn.running_mean) bn.running_mean[c] = rm_c * (1.0f - bn.momentum) + mu * bn.momentum;
-  if (bn.running_var) bn.running_var[c] = rv_c * (1.0f - bn.momentum) + var * bn.momentum;
-  bn.affine[2 * c] = sc;
-  bn.affine[2 * c + 1] = sh;
-}
 
 // ---- classifier head: y = (scale * sum_hw x) . W + b, the two mean(axis=2) calls and the Linear of
 // test/ResNet_CIFAR10_cuda.py:96-99 as one launch each way.  A workgroup is an image; a thread walks channels.
@@ -1926,16 +1885,6 @@ int stem_pool_apply(const float* sel, int sel_planes, const float* partials, int
   return DFHIP_OK;
 }
 
-namespace dfhip {
-int bn_finalize_partials(const BnInput& bn, int C) {
-  if (bn.rows < 1 || bn.rows > 512 || !bn.part || !bn.affine) return -1;
-  ProfScope prof("bn2d_fwd", 0.0, 12.0 * (double)bn.rows * C);
-  DF_LAUNCH(k_bn_finalize_partials, dim3((unsigned)df_ceil_div(C, 4)), dim3(256), 0, stream(), bn, C);
-  DF_LAUNCH_CHECK();
-  return DFHIP_OK;
-}
-}  // namespace dfhip
-
 extern "C" {
 
 int dfhip_bn2d_forward_train(const float* x, const float* gamma, const float* beta, float* y,
@@ -1974,8 +1923,7 @@ int dfhip_bn2d_forward_partials(const float* x, const float* partials, int rows,
   DF_CHECK_ARG(x && y && partials, "bn2d_forward_partials: null array");
   double n = (double)N * C * HW;
   ProfScope prof("bn2d_fwd", 0.0, (residual ? 12.0 : 8.0) * n);
-  static int hw4_on = getenv("DFHIP_BN_FWD_HW4") ? atoi(getenv("DFHIP_BN_FWD_HW4")) : 1;
-  if (hw4_on && HW == 4 && C % 8 == 0) {
+  if (HW == 4 && C % 8 == 0) {
     // 2 x 2 planes: eight channels (a line per image) x 64 images per workgroup
     const int ipb4 = 64, S4 = (int)df_ceil_div(N, ipb4);
     BnFwdSet A = {x, partials, rows, gamma, beta, save_mean, save_var, running_mean, running_var, eps, momentum};
@@ -2067,8 +2015,7 @@ int dfhip_bn2d_forward_partials_pair(const float* xa, const float* partials_a, i
                 momentum_a};
   BnFwdSet B = {xb, partials_b, rows_b, gamma_b, beta_b, save_mean_b, save_var_b, running_mean_b, running_var_b, eps_b,
                 momentum_b};
-  static int hw4_on = getenv("DFHIP_BN_FWD_HW4") ? atoi(getenv("DFHIP_BN_FWD_HW4")) : 1;
-  if (hw4_on && HW == 4 && C % 8 == 0) {
+  if (HW == 4 && C % 8 == 0) {
     const int ipb4 = 64, S4 = (int)df_ceil_div(N, ipb4);
     DF_LAUNCH((k_bn_apply_partials_hw4<true>), dim3((unsigned)(C / 8), (unsigned)S4), dim3(kThreads), 0, stream(), A, B,
               (const float*)nullptr, y, N, C, ipb4);

@@ -69,7 +69,6 @@ struct BnInput {
   float* running_mean;         // C or nullptr: updated in place (batchnorm.py:44-52)
   float* running_var;
   float* affine;               // C x (scale, shift): y = x * scale + shift, for the weight gradient
-  int combine;                 // 1: no bn_finalize_partials launch has run -- the consuming kernel adds the rows up itself
 };
 
 // dfhip_conv.hip, shared with dfhip_wgrad.hip: pixel-group shape of a staged kernel, argument check of every convolution
@@ -78,8 +77,6 @@ void plan_groups(int N, int HD, int WD, int tp, int& BI, int& BR, int& BC, int& 
 int check_conv_args(const char* name, int N, int C, int H, int W, int O, int k, int stride, int pad, int& oh, int& ow);
 inline unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)((((uint64_t)1 << 32) + d - 1) / d); }
 
-// dfhip_fused.hip: bn.part -> bn.affine (+ save_mean / save_var / running statistics); -1 when there is nothing to combine
-int bn_finalize_partials(const BnInput& bn, int C);
 
 // dfhip_conv_rows.hip: register-operand 3x3 / stride 1 / pad 1 forward kernel; -1 when the shape is not eligible
 // (bn: the operand is the BatchNorm of x, see BnInput)

@@ -41,13 +41,6 @@ static hipStream_t g_stream = nullptr;
 static int g_num_cus = 256;
 static char g_devname[256] = "";
 
-// A second stream for work that may run BESIDE what the library stream does next (weight gradients beside the rest of
-// the backward pass): dfhip_side_fork makes it wait for everything queued on the library stream so far, launches
-// issued while side_active() go to it, dfhip_side_join makes the library stream wait for it.  Inside a capture the two
-// become a fork and a join of the graph.
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_side_fork_ev = nullptr, g_side_join_ev = nullptr;
-static bool g_side_target = false, g_side_pending = false;
 // Round 5: CU-partitioned streams.  Two streams of this stack run their kernels at the same time only when their CU masks
 // are DISJOINT (tools/probes/two_streams2.hip: a chain of dependent kernels beside one long kernel takes the sum of the two on
 // plain streams -- any number of hardware queues -- and the maximum on masked streams that share no CU).  A mask bit stands
@@ -57,7 +50,7 @@ static bool g_side_target = false, g_side_pending = false;
 static hipStream_t g_chain = nullptr;
 static hipEvent_t g_chain_ev = nullptr;
 static bool g_chain_on = false;
-hipStream_t stream() { return g_side_target ? g_side : (g_chain_on ? g_chain : g_stream); }
+hipStream_t stream() { return g_chain_on ? g_chain : g_stream; }
 int overlap_cus() {
   static int n = getenv("DFHIP_OVERLAP_CUS") ? atoi(getenv("DFHIP_OVERLAP_CUS")) : 0;
   return (n >= 8 && n <= 248) ? (n & ~7) : 0;
@@ -137,24 +130,13 @@ static int do_init(int device_id) {
 int ensure_init() { return g_init ? DFHIP_OK : do_init(-1); }
 
 int xcd_arrangement(int nx, int ny, double x_bytes, double y_bytes) {
-  // default OFF: measured on the ResNet-18 layers it takes (profiles/r03b_xcd_*): the L2 fills drop as sized (2 x 2
-  // forward 20.0 -> 9.0 MB, its input gradient 20.0 -> 11.6 MB, layer4's stride-2 gradient 13.8 -> 9.6 MB per launch)
-  // but no launch gets shorter (+0.1 ... +0.6 us: the weights come out of the Infinity Cache either way, and with the
-  // arrangement the 32 workgroups of an XCD ask for the same weight lines at the same moment).  DFHIP_XCD_ORDER=1
-  // chooses the arrangement by bytes, 2 / 4 / 8 force one.
-  static int enabled = getenv("DFHIP_XCD_ORDER") ? atoi(getenv("DFHIP_XCD_ORDER")) : 0;
-  if (!enabled || nx <= 0 || ny <= 0 || ((int64_t)nx * ny) % 8 != 0) return 0;
-  if (enabled == 2 || enabled == 4 || enabled == 8) {            // forced arrangement (A/B runs)
-    return (ny % enabled == 0 && nx % (8 / enabled) == 0) ? enabled : 0;
-  }
-  int best = 0;
-  double best_bytes = y_bytes + x_bytes / 8.0;                   // natural order: an XCD sees every y tile, 1/8 of x
-  for (int xo = 1; xo <= 8; xo *= 2) {
-    if (ny % xo != 0 || nx % (8 / xo) != 0) continue;
-    const double b = y_bytes / xo + x_bytes / (8 / xo);
-    if (b < best_bytes * 0.999) { best_bytes = b; best = xo; }
-  }
-  return best;
+  // OFF.  An arrangement of the image-per-lane kernels' workgroups that gives every XCD's L2 1/8 of the weight tensor was
+  // measured in rounds 3 and 5 (profiles/r03b_xcd_*, gpurun r05e): the L2 fills drop as sized (2 x 2 forward 20.0 -> 9.0 MB, its
+  // input gradient 20.0 -> 11.6 MB, layer4's stride-2 gradient 13.8 -> 9.6 MB per launch) but no launch gets shorter and the
+  // step longer (0.6875 -> 0.7003 ms: the weights come out of the Infinity Cache either way, and with the arrangement the 32
+  // workgroups of an XCD ask for the same weight lines at the same moment).  The kernels keep the `xo` argument (0 = grid order).
+  (void)nx; (void)ny; (void)x_bytes; (void)y_bytes;
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -218,10 +200,6 @@ static int pool_alloc(size_t bytes, void** out) {
     }
     g_n_hipmalloc++;
     {
-      static int trace = getenv("DFHIP_POOL_TRACE") ? atoi(getenv("DFHIP_POOL_TRACE")) : 0;
-      if (trace && g_n_hipmalloc > trace)
-        fprintf(stderr, "[pool] hipMalloc #%lld of %zu bytes (in use %.1f MB, reserved %.1f MB)\n",
-                (long long)g_n_hipmalloc, bytes, g_in_use / 1e6, g_reserved / 1e6);
     }
     g_reserved += (int64_t)bytes;
     g_blocks[p] = Block{bytes, 0};
@@ -374,7 +352,22 @@ static int kernel_record(const void* fn, int slot) {
   g_krec.push_back(r);
   return (int)g_krec.size() - 1;
 }
+// DFHIP_KERNEL_LOG=<file> (diagnostic): every kernel instantiation this process launches is appended to the file once, by
+// name -- the union over the test-suite and the benches says which instantiations of the library are reachable by default
+// (tools/kernel_coverage.py compares it with the stubs the shared object holds)
+static void note_kernel(const void* fn) {
+  static std::unordered_map<const void*, bool> seen;
+  if (!seen.emplace(fn, true).second) return;
+  static const char* path = getenv("DFHIP_KERNEL_LOG");
+  const char* mangled = hipKernelNameRefByPtr(fn, g_stream);
+  if (FILE* f = fopen(path, "a")) {
+    fprintf(f, "%s\n", mangled ? mangled : "?");
+    fclose(f);
+  }
+}
 bool prof_kernel_events(const void* fn, hipEvent_t* start, hipEvent_t* stop) {
+  static const bool klog = getenv("DFHIP_KERNEL_LOG") != nullptr;
+  if (klog) note_kernel(fn);
   if (g_prof_scope < 0 || g_capture_open) return false;
   hipEvent_t a = get_event(), b = get_event();
   if (!a || !b) return false;
@@ -637,8 +630,7 @@ int dfhip_h2d(const float* host, float* dst, int64_t n) {
     memcpy(sl.p, (const char*)host + off, b);
     // up to 32 MB: a kernel on the library stream reads the pinned slot (no hop to the copy engine's queue between
     // two launches of the stream -- with per-step uploads in front of graph replays the SDMA path cost 0.1-0.7 ms per step)
-    static int by_kernel = getenv("DFHIP_UPLOAD_KERNEL") ? atoi(getenv("DFHIP_UPLOAD_KERNEL")) : 1;
-    if (by_kernel && b <= ((size_t)32 << 20) && ((((uintptr_t)dst) + off) & 15) == 0) {
+    if (b <= ((size_t)32 << 20) && ((((uintptr_t)dst) + off) & 15) == 0) {
       const int64_t nf = (int64_t)(b / sizeof(float));
       const int blocks = (int)std::min<int64_t>(1024, (nf / 4 + 255) / 256 + 1);
       hipLaunchKernelGGL(k_copy_from_host, dim3(blocks), dim3(256), 0, g_stream, (const float*)sl.p,
@@ -877,11 +869,9 @@ int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n,
     DF_HIP(hipHostMalloc(&sl.p, want, hipHostMallocDefault));
     sl.bytes = want;
   }
-  static int by_kernel = getenv("DFHIP_UPLOAD_KERNEL") ? atoi(getenv("DFHIP_UPLOAD_KERNEL")) : 1;
   // the mask crosses PCIe as bytes (a quarter of the floats: 2 MB per step of the CNN workload were 40 us in front of every
   // replay) and becomes floats in the kernel that fetches it
-  static int as_bytes = getenv("DFHIP_MASK_BYTES") ? atoi(getenv("DFHIP_MASK_BYTES")) : 1;
-  if (by_kernel && as_bytes && (((uintptr_t)dst) & 15) == 0) {
+  if ((((uintptr_t)dst) & 15) == 0) {
     if (*pos < 0 || *pos > kMtN) {
       set_error("upload_bernoulli_mask: bad generator position");
       return DFHIP_INVALID_ARGUMENT;
@@ -897,15 +887,10 @@ int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n,
     sl.busy = true;
     return DFHIP_OK;
   }
+  // (a destination that is not 16-byte aligned: the mask as floats through a plain copy)
   int st = dfhip_host_bernoulli_mask(key, pos, keep, n, (float*)sl.p);
   if (st != DFHIP_OK) return st;
-  if (by_kernel && (((uintptr_t)dst) & 15) == 0) {
-    const int blocks = (int)std::min<int64_t>(1024, (n / 4 + 255) / 256 + 1);
-    hipLaunchKernelGGL(k_copy_from_host, dim3(blocks), dim3(256), 0, g_stream, (const float*)sl.p, dst, n);
-    DF_LAUNCH_CHECK();
-  } else {
-    DF_HIP(hipMemcpyAsync(dst, sl.p, b, hipMemcpyHostToDevice, g_stream));
-  }
+  DF_HIP(hipMemcpyAsync(dst, sl.p, b, hipMemcpyHostToDevice, g_stream));
   DF_HIP(hipEventRecord(sl.done, g_stream));
   sl.busy = true;
   return DFHIP_OK;
@@ -1028,80 +1013,6 @@ static void release_capture_blocks(int capture_id) {
   }
 }
 
-static int side_fork() {
-  if (!g_side) {
-    DF_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
-    DF_HIP(hipEventCreateWithFlags(&g_side_fork_ev, hipEventDisableTiming));
-    DF_HIP(hipEventCreateWithFlags(&g_side_join_ev, hipEventDisableTiming));
-  }
-  DF_HIP(hipEventRecord(g_side_fork_ev, g_stream));
-  DF_HIP(hipStreamWaitEvent(g_side, g_side_fork_ev, 0));
-  g_side_pending = true;
-  return DFHIP_OK;
-}
-static int side_join() {
-  g_side_target = false;
-  if (g_side_pending) {
-    DF_HIP(hipEventRecord(g_side_join_ev, g_side));
-    DF_HIP(hipStreamWaitEvent(g_stream, g_side_join_ev, 0));
-    g_side_pending = false;
-  }
-  return DFHIP_OK;
-}
-int dfhip_side_fork(void) { DF_INIT_KEEP(); return side_fork(); }
-int dfhip_side_target(int on) {
-  DF_INIT_KEEP();
-  DF_CHECK_ARG(!on || g_side_pending, "side_target: fork first");
-  // Launches retargeted this way share the library stream's scratch areas and pool ordering: only kernels that use neither
-  // may run there.  That is true of the diagnostic load (dfhip_side_probe) and of nothing a front end would call, so the
-  // switch is refused unless the diagnostic asked for it (DF_SIDE_PROBE / DFHIP_SIDE_TARGET=1).
-  static int allowed = (getenv("DF_SIDE_PROBE") || (getenv("DFHIP_SIDE_TARGET") && atoi(getenv("DFHIP_SIDE_TARGET")))) ? 1 : 0;
-  DF_CHECK_ARG(!on || allowed, "side_target: diagnostic only (the side stream shares the library stream's scratch areas); "
-               "set DFHIP_SIDE_TARGET=1 to use it anyway");
-  g_side_target = on != 0;
-  return DFHIP_OK;
-}
-int dfhip_side_join(void) { DF_INIT_KEEP(); return side_join(); }
-
-// diagnostic: `wgs` workgroups of the clock-probe loop (iters x 4 MFMAs per wave) on the side stream, each holding
-// lds_bytes of LDS so that nothing else fits beside it on its CU -- what a long matrix-bound launch beside the main
-// stream costs the main stream
-int dfhip_side_probe(int wgs, int iters, int lds_bytes) {
-  DF_INIT_KEEP();
-  DF_CHECK_ARG(wgs > 0 && iters > 0 && lds_bytes >= 0 && lds_bytes <= 160 * 1024, "side_probe: bad arguments");
-  static unsigned long long* d = nullptr;
-  static int cap = 0;
-  if (cap < wgs) {
-    DF_CHECK_ARG(!g_capture_open, "side_probe: first call (allocation) inside a capture");
-    if (d) (void)hipFree(d);
-    DF_HIP(hipMalloc((void**)&d, (size_t)wgs * 8 * sizeof(unsigned long long)));
-    cap = wgs;
-  }
-  static bool attr = false;
-  if (!attr) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_clock_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
-  // DFHIP_SIDE_FREE=1 (diagnostic): the load is enqueued on the second stream WITHOUT a fork event -- it runs beside whatever
-  // the library stream does, ordered only against earlier loads (tools/probes/side_free.py: what a persistent kernel on
-  // a second queue costs the captured step, without the fork / join edges of a graph)
-  static int free_run = getenv("DFHIP_SIDE_FREE") ? atoi(getenv("DFHIP_SIDE_FREE")) : 0;
-  if (free_run) {
-    if (!g_side) {
-      DF_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
-      DF_HIP(hipEventCreateWithFlags(&g_side_fork_ev, hipEventDisableTiming));
-      DF_HIP(hipEventCreateWithFlags(&g_side_join_ev, hipEventDisableTiming));
-    }
-    g_side_pending = true;                          // (dfhip_side_join then waits for it)
-  } else {
-    int s = side_fork();
-    if (s != DFHIP_OK) return s;
-  }
-  hipLaunchKernelGGL(k_clock_probe, dim3((unsigned)wgs), dim3(256), (size_t)lds_bytes, g_side, d, iters, 0.41f);
-  DF_LAUNCH_CHECK();
-  return DFHIP_OK;
-}
-
 int dfhip_graph_begin(void) {
   DF_INIT();
   DF_CHECK_ARG(!g_capture_open, "a capture is already open");
@@ -1124,7 +1035,6 @@ int dfhip_graph_end(void** graph_exec) {
   // the capture must be closed even when it has been invalidated (an illegal call inside it, e.g. a
   // blocking copy): otherwise every later launch on the stream fails
   const int f__ = flush_deferred();
-  (void)side_join();                               // a forked side stream must be back before the capture closes
   int id = g_capture_open;
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamEndCapture(g_stream, &graph);
@@ -1379,9 +1289,9 @@ static int comm_async_check(const char* where) {
   return DFHIP_OK;
 }
 
-// hipStreamSynchronize with the communicator polled meanwhile; DFHIP_COMM_TIMEOUT_S (default 1800) bounds the wait
+// hipStreamSynchronize with the communicator polled meanwhile; DFHIP_COMM_TIMEOUT_S (default 300) bounds the wait
 static int comm_sync_stream(hipStream_t s, const char* where) {
-  static double limit = getenv("DFHIP_COMM_TIMEOUT_S") ? atof(getenv("DFHIP_COMM_TIMEOUT_S")) : 1800.0;
+  static double limit = getenv("DFHIP_COMM_TIMEOUT_S") ? atof(getenv("DFHIP_COMM_TIMEOUT_S")) : 300.0;
   const auto t0 = std::chrono::steady_clock::now();
   for (int spins = 0;; spins++) {
     const hipError_t q = hipStreamQuery(s);

@@ -718,8 +718,7 @@ size_t stem_bwd_lds(int C, int k) {
 }
 
 bool stem_shape(int N, int C, int H, int W, int O, int k, int stride, int pad) {
-  static int enabled = getenv("DFHIP_STEM_NOZ") ? atoi(getenv("DFHIP_STEM_NOZ")) : 1;
-  return enabled && N >= 1 && (k == 3 || k == 5) && stride == 1 && pad == k / 2 && W == 32 && C >= 1 && C <= 3 && O >= 1 &&
+  return N >= 1 && (k == 3 || k == 5) && stride == 1 && pad == k / 2 && W == 32 && C >= 1 && C <= 3 && O >= 1 &&
          O <= 32 && H >= 2 && H <= 32 && !(H & 1);
 }
 
@@ -780,11 +779,9 @@ int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, c
   DF_INIT_KEEP();
   DF_CHECK_ARG(x && w && y && g && save_mean && save_var && dw && done, "stem_backward_noz: null array");
   *done = 0;
-  static int onepass = getenv("DFHIP_STEM_ONEPASS") ? atoi(getenv("DFHIP_STEM_ONEPASS")) : 1;
-  static int ride_env = getenv("DFHIP_STEM_COMBINE_RIDES") ? atoi(getenv("DFHIP_STEM_COMBINE_RIDES")) : 1;
   // queued weight gradients stay queued when the one-pass form runs inside their group: the group's slab-sum launch then
   // does this call's last step (the slabs of totals live in the second scratch area, the group's own in the first)
-  const bool ride = ride_env && onepass && k == 3 && group_collecting() && stem_shape(N, C, H, W, O, k, stride, pad);
+  const bool ride = k == 3 && group_collecting() && stem_shape(N, C, H, W, O, k, stride, pad);
   if (!ride) {
     int f__ = flush_deferred();
     if (f__ != DFHIP_OK) return f__;
@@ -793,7 +790,7 @@ int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, c
   const int KK = C * k * k;
   // (k_stem_bwd<.., 1> adds up at most 16 lanes x 16 slices: the slices of the first pass are capped at 256 whatever the device)
   const int gx = (int)std::min<int64_t>(N, std::min(num_cus(), 256));
-  const bool one = onepass && k == 3;   // (5x5: two accumulator sets of three tiles do not fit the registers)
+  const bool one = k == 3;   // (5x5: two accumulator sets of three tiles do not fit the registers)
   const size_t SL = (size_t)2 * O * KK + 3 * O + KK;
   const size_t ws_bytes = std::max((size_t)O * gx * 2 + (size_t)gx * O * (KK + 1), (size_t)gx * SL) * sizeof(float);
   float* ws = ride ? workspace2(ws_bytes) : workspace(ws_bytes);

@@ -2142,8 +2142,7 @@ int launch_wgrad_v3(WGeo g, float* dw, size_t lds, int gx, int ktg, int otg) {
 
 // the few-channel stem on 32-wide images (k_wgrad_stem3); -1 when the shape is not one it takes
 int run_wgrad_stem3(WGeo g, float* dw, bool stem) {
-  static int enabled = getenv("DFHIP_WGRAD_STEM3") ? atoi(getenv("DFHIP_WGRAD_STEM3")) : 1;
-  if (!enabled || g.k != 3 || g.stride != 1 || g.pad != 1 || g.W != 32 || g.ow != 32 || g.oh != g.H) return -1;
+  if (g.k != 3 || g.stride != 1 || g.pad != 1 || g.W != 32 || g.ow != 32 || g.oh != g.H) return -1;
   if (g.C < 1 || g.C > 3 || g.O < 1 || g.O > 32 || g.H > 32 || (g.H & 1)) return -1;
   if (stem && (g.st.S < 1 || g.st.S > 32 || (g.O * g.st.S) % 2 != 0 || g.O * g.st.S * 2 > 4 * 512)) return -1;
   const int64_t n = (int64_t)g.O * g.C * 9;
@@ -2204,8 +2203,7 @@ int run_wgrad_v3(WGeo g, float* dw, bool stem = false) {
   const int OT = g.O <= 32 ? 1 : 2;
   // (column tiles per workgroup: with 64 output channels and a 5x5 kernel -- 800 columns -- five tiles per workgroup
   // halve the dY operand reads per MFMA; DFHIP_WGRAD_KT5=0 restores two)
-  static int kt5 = getenv("DFHIP_WGRAD_KT5") ? atoi(getenv("DFHIP_WGRAD_KT5")) : 1;
-  const int KT = (g.k == 1 || KW <= 32) ? 1 : (g.O <= 32 ? 5 : ((kt5 && g.k == 5 && KW >= 320) ? 5 : 2));
+  const int KT = (g.k == 1 || KW <= 32) ? 1 : (g.O <= 32 ? 5 : ((g.k == 5 && KW >= 320) ? 5 : 2));
   const int CH = std::min(g.C, (KT * 32 + k2 - 2) / k2 + 1);
   int gi = 1;
   size_t lds = 0;
@@ -2273,7 +2271,6 @@ int launch_slab_sum(const SlabSum& a) {
 template <int KS, int PAD, int STRIDE, int W, int OW, int UR>
 int launch_wgrad_rows(RGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
   const int T = KS * KS;
-  static int defer = getenv("DFHIP_WGRAD_DEFER") ? atoi(getenv("DFHIP_WGRAD_DEFER")) : 1;
   // the slabs go to the scratch slot the pending sum does not read
   const int slot = g_def.active ? 1 - g_def.slot : 0;
   g.slabs = workspace_slot(slot, (size_t)ps * OT * CT * T * 1024 * sizeof(float));
@@ -2323,7 +2320,6 @@ int launch_wgrad_rows(RGeo g, float* dw, size_t lds, int ps, int CT, int OT) {
     fprintf(stderr, "\n");
   }
   SlabSum mine = make_slab_sum(g.slabs, dw, ps, OT, CT, T, g.O, g.C);
-  if (!defer) return launch_slab_sum(mine);
   g_def.a = mine;
   g_def.active = true;
   g_def.slot = slot;
@@ -2367,34 +2363,16 @@ std::vector<hipEvent_t> g_side_events;            // recycled join events
 hipStream_t g_group_stream = nullptr;             // stream the group kernels go to (nullptr: the library stream)
 float* g_group_slabs = nullptr;                   // slab area supplied by the side flush (nullptr: scratch slot 0)
 
-// Workgroup length of a grouped layer (operands from global memory).  The body runs one workgroup per CU (470 registers), so
-// the launch ends when the CU with the longest queue does: a layer is cut so that a workgroup is about `target` cycles of
-// its executed MFMAs (64 issue cycles each, four waves) -- long enough that the ~12 000 cycles around the MFMA stream (first
-// operands, cross-wave sum, slab stores) stay small, short enough that the longest workgroup is a fraction of the launch
-// (with the 256 / (tiles * 16) rule the 64-channel layers ran 400 000-cycle workgroups: the whole launch).
-static double replan_direct(GQueued& e, int target) {
-  GDesc& d = e.d;
-  int UR = 1, NP = 1;
-  switch (d.kind) {
-#define DF_UR(ID, KSV, PADV, SV, WV, OWV, URV, NPV) case ID: UR = URV; NP = NPV; break;
-    DF_ROWS_KINDS(DF_UR)
-#undef DF_UR
-    default: break;
-  }
-  // cycles of a wave per unit, measured with the in-kernel counters (-DDFHIP_STAMPS, DFHIP_CONV_STAMP=1; batch 256): the
-  // MFMA issue slots of the unit plus what its operand loads and hand-over cost -- units of few MFMAs (1x1 kernels, 2 x 2
-  // planes) are bound by the latency of their loads, not by their MFMA count
+// Estimated cycles of one workgroup of a grouped layer (operands from global memory): the launch dispatches the longest
+// workgroups first.  Cycles of a wave per unit were measured with the in-kernel counters (-DDFHIP_STAMPS, DFHIP_CONV_STAMP=1;
+// batch 256): the MFMA issue slots of the unit plus what its operand loads and hand-over cost -- units of few MFMAs (1x1
+// kernels, 2 x 2 planes) are bound by the latency of their loads, not by their MFMA count; ~14 000 cycles around the MFMA
+// stream (first operands, cross-wave sum, slab stores).  (Cutting every layer to a common cycle target instead of 32
+// workgroups per layer was measured in round 3: the shorter tail came back as prologues / epilogues of the extra workgroups.)
+static double replan_direct(const GQueued& e) {
   static const double kUnitCycles[13] = {9260, 8720, 7640, 5560, 4780, 4680, 4490, 9400, 7200, 2840, 19000, 9800, 9400};
-  const int upr = d.oh / UR, U = (d.N / (2 * NP)) * upr;
-  const double unit_cycles = d.kind >= 0 && d.kind < 13 ? kUnitCycles[d.kind] : 5000.0;
-  if (target > 0) {
-    const double per_wave = std::max(1.0, (target - 14000.0) / unit_cycles);
-    const int want = 4 * (int)std::max(1.0, std::floor(per_wave + 0.5));
-    const int ps = std::max(1, (int)std::floor((double)U / want + 0.5));
-    d.units = std::max(4, ((int)df_ceil_div(U, ps) + 3) & ~3);
-    d.ps = (int)df_ceil_div(U, d.units);
-  }
-  return d.units / 4 * unit_cycles + 14000.0;
+  const double unit_cycles = e.d.kind >= 0 && e.d.kind < 13 ? kUnitCycles[e.d.kind] : 5000.0;
+  return e.d.units / 4 * unit_cycles + 14000.0;
 }
 
 int group_flush() {
@@ -2437,9 +2415,8 @@ int group_flush() {
       return st < 0 ? DFHIP_RUNTIME_ERROR : st;
     }
   }
-  static int target = getenv("DFHIP_WGRAD_GROUP_CYCLES") ? atoi(getenv("DFHIP_WGRAD_GROUP_CYCLES")) : 0;
   for (auto& e : q) {
-    e.work = e.d.direct ? replan_direct(e, target) : (double)e.d.N * e.d.oh * e.d.oh * e.T / e.d.ps * 16.0;
+    e.work = e.d.direct ? replan_direct(e) : (double)e.d.N * e.d.oh * e.d.oh * e.T / e.d.ps * 16.0;
     e.rides_on = -1;
     e.d.dy2 = nullptr; e.d.slabs2 = nullptr;
     e.d.bnz2 = nullptr; e.d.bntab2 = nullptr;
@@ -2449,8 +2426,7 @@ int group_flush() {
   // a block's 1x1 / stride-2 shortcut reads the same tensor as its 3x3 / stride-2 convolution: the shortcut's weight gradient
   // rides on that layer's workgroups (wgrad_rows_direct<PAIR>) -- it keeps its slabs (one per workgroup of the host layer) and
   // its entry in the slab sum, and has no workgroups of its own
-  static int pair_on = getenv("DFHIP_WGRAD_PAIR") ? atoi(getenv("DFHIP_WGRAD_PAIR")) : 1;
-  if (pair_on && q.size() <= (size_t)kMaxGroup) {
+  if (q.size() <= (size_t)kMaxGroup) {
     for (size_t b = 0; b < q.size(); b++) {
       GQueued& sc = q[b];
       if (!(sc.d.direct && sc.k == 1 && sc.stride == 2 && !sc.d.aff)) continue;
@@ -2657,8 +2633,6 @@ int side_join() {
 // returns -1 when the shape is not one the row-unit kernel is built for
 int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
                    int k, int stride, int pad, const float* aff, const float* bnz, const float* bntab) {
-  static int enabled = getenv("DFHIP_WGRAD_ROWS") ? atoi(getenv("DFHIP_WGRAD_ROWS")) : 1;
-  if (!enabled) return -1;
   if (aff && !g_group_on) return -1;        // the affine operand exists in the grouped direct body only
   if (bnz && (!g_group_on || W > 16)) return -1;   // so does the BatchNorm-backward operand (planes up to 16 wide)
   if (C < 16 || (N & 1)) return -1;
@@ -2675,14 +2649,14 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
   // (8: re-measured with the round-3 body -- 4 / 6 / 8 / 10 / 12 / 16 / 24: 131 / 138 / 127 / 140 / 135 / 138 / 240 us for the R18 sweep)
   static int gdiv = getenv("DFHIP_WGRAD_GROUP_DIV") ? atoi(getenv("DFHIP_WGRAD_GROUP_DIV")) : 8;
   const int ps0 = std::max(1, num_cus() / (CT * OT) / (grouped ? std::max(1, gdiv) : 1));
-  static int gpb1 = getenv("DFHIP_WGRAD_GPB") ? atoi(getenv("DFHIP_WGRAD_GPB")) : 2;   // groups per block aimed at
-  static int gpbg = getenv("DFHIP_WGRAD_GROUP_GPB") ? atoi(getenv("DFHIP_WGRAD_GROUP_GPB")) : 2;
+  constexpr int gpb1 = 2;   // groups per block aimed at
+  constexpr int gpbg = 2;
   const int gpb = grouped ? gpbg : gpb1;
   // output rows per unit (must match the instantiations)
   const int UR = k == 1 ? 1 : (stride == 1 ? (W >= 16 ? 1 : (W == 8 ? 2 : (W == 4 ? 4 : 2))) : (W >= 16 ? 1 : 2));
   const double per_block = (double)(N / 2) * (oh / UR) / ps0;
   const double target = std::max((double)kRowsWaves, per_block / std::max(1, gpb));
-  static int gcap = getenv("DFHIP_WGRAD_GROUP_LDS") ? atoi(getenv("DFHIP_WGRAD_GROUP_LDS")) : 160;
+  constexpr int gcap = 160;
   const size_t lds_cap = grouped ? (size_t)gcap * 1024 : 160 * 1024;
   RGeo g = {};
   double best = 1e30;
@@ -2722,8 +2696,7 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
   // (no staging plan -- 32-wide planes exceed the vectors a thread keeps in flight -- is fine for a layer the grouped launch
   // takes with its operands straight from global memory)
   const bool staged_plan = best < 1e29;
-  static int direct_allowed = getenv("DFHIP_WGRAD_DIRECT") ? atoi(getenv("DFHIP_WGRAD_DIRECT")) : 1;
-  if (!staged_plan && !(grouped && direct_allowed && C % 32 == 0 && O % 32 == 0)) return -1;
+  if (!staged_plan && !(grouped && C % 32 == 0 && O % 32 == 0)) return -1;
   if (!staged_plan) { g.BI = 2; g.BR = UR; g.gr = oh / UR; g.RLr = std::min(H, (UR - 1) * stride + k); g.units = 4; }
   g.x = x; g.dy = dy;
   g.N = N; g.C = C; g.H = H; g.O = O; g.oh = oh;
@@ -2751,8 +2724,7 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
     d.m_br = g.m_br; d.m_xc = g.m_xc; d.m_xi = g.m_xi; d.m_dc = g.m_dc; d.m_di = g.m_di;
     d.single = g.single; d.kind = kind; d.ps = ps; d.CT = CT; d.OT = OT;
     e.dw = dw; e.T = k * k; e.lds = best_lds;
-    static int direct_on = getenv("DFHIP_WGRAD_DIRECT") ? atoi(getenv("DFHIP_WGRAD_DIRECT")) : 1;
-    const bool direct = direct_on && C % 32 == 0 && O % 32 == 0 && (N / 2) % NPk == 0;
+    const bool direct = C % 32 == 0 && O % 32 == 0 && (N / 2) % NPk == 0;
     if (!direct && !staged_plan) return -1;
     if ((aff || bnz) && !direct) return -1;
     d.aff = aff;
@@ -2926,15 +2898,13 @@ static int bank_stride(int n) { return ((n - 2 + 63) / 64) * 64 + 2; }
 // returns -1 when the shape is not eligible for the tap-major kernel
 int run_wgrad_tap(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
                   int k, int stride, int pad) {
-  static int enabled = getenv("DFHIP_WGRAD_TAP") ? atoi(getenv("DFHIP_WGRAD_TAP")) : 1;
-  if (!enabled) return -1;
   if (!(k == 1 || k == 3) || C < 16 || (N & 1)) return -1;
   if ((H * W) % 4 != 0 || (oh * ow) % 4 != 0) return -1;
   if (pad >= k) return -1;
   const int CT = (int)df_ceil_div(C, 32), OT = (int)df_ceil_div(O, 32);
   const int64_t steps_total = (int64_t)(N / 2) * oh * ow;
   const int ps0 = std::max(1, num_cus() / (CT * OT));
-  static int gpb = getenv("DFHIP_WGRAD_GPB") ? atoi(getenv("DFHIP_WGRAD_GPB")) : 2;   // groups per block aimed at
+  constexpr int gpb = 2;   // groups per block aimed at
   const double target = (double)std::max<int64_t>(16, steps_total / ps0 / std::max(1, gpb));
   TGeo g = {};
   double best = 1e30;
@@ -2977,7 +2947,7 @@ int run_wgrad_tap(const float* x, const float* dy, float* dw, int N, int C, int 
   const int ps = std::max(1, std::min(g.ngroups, ps0));
   const int xv = (int)df_ceil_div(32 * P * RL4, 512), dv = (int)df_ceil_div(32 * P * BRBC4, 512);
   // images of 8 x 8 and more lose little to the padding taps; smaller ones skip them
-  static int dense_min = getenv("DFHIP_WGRAD_DENSE_MIN") ? atoi(getenv("DFHIP_WGRAD_DENSE_MIN")) : 8;
+  constexpr int dense_min = 8;
   const bool dense = k == 3 && std::min(oh, ow) >= dense_min;
   if (k == 3 && dense) {
     if (xv <= 1 && dv <= 1) return launch_wgrad_tap<3, 1, 1, true>(g, dw, best_lds, ps, CT, OT);
@@ -3184,8 +3154,7 @@ int dfhip_stem_backward(const float* x, const float* z, const float* y, const fl
   int oh, ow;
   int s = check_conv_args("stem_backward", N, C, H, W, O, k, stride, pad, oh, ow);
   if (s != DFHIP_OK) return s;
-  static int enabled = getenv("DFHIP_STEM_FUSED_BWD") ? atoi(getenv("DFHIP_STEM_FUSED_BWD")) : 1;
-  if (!enabled || O > 32 || (oh & 1) || (ow & 7) || stride != 1 || C > 4) return DFHIP_OK;
+  if (O > 32 || (oh & 1) || (ow & 7) || stride != 1 || C > 4) return DFHIP_OK;
   WGeo wg = {};
   wg.x = x; wg.dy = z;
   wg.N = N; wg.C = C; wg.H = H; wg.W = W; wg.O = O; wg.oh = oh; wg.ow = ow;

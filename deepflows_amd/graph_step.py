@@ -38,9 +38,6 @@ class CapturedTrainStep:
         self.mod, self.optimizer, self.sync = mod, optimizer, sync
         optimizer.device_hyper = True
         optimizer.push_hyper()                      # allocates the scalar array outside the capture
-        if os.environ.get("DF_SIDE_PROBE"):         # (the diagnostic load allocates its stamp buffer on first use)
-            mod.side_probe(*[int(v) for v in os.environ["DF_SIDE_PROBE"].split(",")])
-            mod.side_join()
         # Round 4: the exchange step is captured too where the collective library lets a stream capture record it (RCCL
         # does for ncclAllReduce): a data-parallel step is then ONE graph launch -- backward, all-reduce of the bucket the
         # backward kernels wrote, optimizer -- with nothing issued eagerly behind it.  If the capture refuses (an older
@@ -68,12 +65,7 @@ class CapturedTrainStep:
             outputs = model(inputs)
             loss = criterion(outputs, targets)
             optimizer.zero_grad()
-            probe = os.environ.get("DF_SIDE_PROBE")      # diagnostic: "wgs,iters,lds_bytes" of MFMA load beside backward
-            if probe:
-                mod.side_probe(*[int(v) for v in probe.split(",")])
             loss.backward()
-            if probe:
-                mod.side_join()
             if sync is not None and with_exchange:
                 sync()
             if sync is None or with_exchange:

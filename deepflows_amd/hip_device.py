@@ -698,17 +698,6 @@ class HipModule:
         _lib.check(self._lib.dfhip_clock_probe(float(milliseconds), byref(mhz), byref(tf)))
         return float(mhz.value), float(tf.value)
 
-    def side_fork(self):
-        _lib.check(self._lib.dfhip_side_fork())
-
-    def side_target(self, on):
-        _lib.check(self._lib.dfhip_side_target(int(bool(on))))
-
-    def side_join(self):
-        _lib.check(self._lib.dfhip_side_join())
-
-    def side_probe(self, wgs, iters, lds_bytes=0):
-        _lib.check(self._lib.dfhip_side_probe(int(wgs), int(iters), int(lds_bytes)))
 
     def pool_stats(self):
         a, b, c = c_int64(), c_int64(), c_int64()

@@ -42,7 +42,6 @@ def _grad_out(param, shape, device):
 
 # rows of the BatchNorm partials buffer a fused convolution may fill (one per workgroup)
 _BN_PARTIAL_ROWS = 512
-_CONV_BN_STATS = os.environ.get("DF_CONV_BN_STATS", "1") != "0"
 
 # ---- BatchNorm2d backward without a launch of its own (include/dfhip.h: dfhip_bn_bwd_in / dfhip_bn_stats_out) -----------
 # The autograd chain of nn/modules/batchnorm.py:30-55 needs sum(dy) and sum(dy * (z - mean)) over the whole batch before
@@ -52,10 +51,9 @@ _CONV_BN_STATS = os.environ.get("DF_CONV_BN_STATS", "1") != "0"
 # weight-gradient kernels form dz on their operand loads.  Anything that cannot take a pending gradient writes it out first
 # (_pending_materialise); DF_BN_BWD_FUSED=0 switches the whole mechanism off.
 _BN_BWD_FUSED = os.environ.get("DF_BN_BWD_FUSED", "1") != "0"
-# the same for the two convolutions that read a block's input when its shortcut is a convolution (one launch forms both input
-# gradients): measured, that launch with two pending operands takes longer than the two stand-alone BatchNorm launches it
-# replaces (layer2's first block: 9.2 -> 24 us against 5.2 + 6.5 us) -- off unless asked for
-_BN_BWD_PAIR = os.environ.get("DF_BN_BWD_PAIR", "0") != "0"
+# (The two convolutions that read a block's input when its shortcut is a convolution do NOT take pending gradients: their one
+# launch with two pending operands was measured slower than the two stand-alone BatchNorm launches it replaces -- layer2's
+# first block: 9.2 -> 24 us against 5.2 + 6.5 us, round 4.)
 
 
 class _PendingBN:
@@ -255,7 +253,7 @@ class _LinearReluFused(_FusedNode):
     def build(cls, x, w, b):
         dev = x.device
         fn = getattr(dev.mod, "linear_relu_forward", None)
-        if fn is None or not _LINEAR_RELU or x.ndim != 2 or w.ndim != 2:
+        if fn is None or x.ndim != 2 or w.ndim != 2:
             return None
         m, k = (int(v) for v in x.shape)
         p = int(w.shape[1])
@@ -292,7 +290,6 @@ class _LinearReluFused(_FusedNode):
         return dx if node is self.x else (dw if node is self.w else db)
 
 
-_LINEAR_RELU = os.environ.get("DF_LINEAR_RELU", "1") != "0"
 
 
 def linear_relu(input: Tensor, weight: Tensor, bias=None):
@@ -456,7 +453,7 @@ class _Conv2dFused(_FusedNode):
         # the shape was served by a kernel without that epilogue)
         self.bn_partials = None
         stats_fn = getattr(x.device.mod, "conv2d_forward_stats", None)
-        if stats_fn is not None and _CONV_BN_STATS and is_grad_enable():
+        if stats_fn is not None and is_grad_enable():
             part = _new((_BN_PARTIAL_ROWS, O, 3), x.device)
             rows = stats_fn(self.xd._handle, self.wd._handle, bh, out._handle, *self.geo,
                             part._handle, _BN_PARTIAL_ROWS)
@@ -475,7 +472,7 @@ class _Conv2dFused(_FusedNode):
         x = realize(x)
         dev = x.device
         fn = getattr(dev.mod, "conv2d_forward_s2_pair", None)
-        if (fn is None or not _S2_PAIR or len(x.shape) != 4 or conv1.bias is not None or conv_d.bias is not None
+        if (fn is None or len(x.shape) != 4 or conv1.bias is not None or conv_d.bias is not None
                 or (int(conv1.kernel_size), int(conv1.stride), int(conv1.padding)) != (3, 2, 1)
                 or (int(conv_d.kernel_size), int(conv_d.stride), int(conv_d.padding)) != (1, 2, 0)
                 or tuple(conv1.weight.shape[:2]) != tuple(conv_d.weight.shape[:2])):
@@ -487,7 +484,7 @@ class _Conv2dFused(_FusedNode):
         xd = x.data.compact()
         w1, wd = conv1.weight.data.compact(), conv_d.weight.data.compact()
         y1, yd = _new((N, O, H // 2, W // 2), dev), _new((N, O, H // 2, W // 2), dev)
-        stats = _CONV_BN_STATS and is_grad_enable()
+        stats = is_grad_enable()
         p1 = _new((_BN_PARTIAL_ROWS, O, 3), dev) if stats else None
         pd = _new((_BN_PARTIAL_ROWS, O, 3), dev) if stats else None
         h = lambda t: t._handle if t is not None else None
@@ -529,15 +526,9 @@ class _Conv2dFused(_FusedNode):
         if self.bias is not None:
             return False
         host = self._sibling_host() if getattr(self, "_sibling_host", None) is not None else None
-        if (host is not None or self.shortcut_sibling is not None) and not _BN_BWD_PAIR:
-            return False
-        if host is not None:
-            # a block's 1x1 shortcut: its input gradient rides on conv1's pair launch
-            dg = mod.conv2d_bn_bwd_supported(*host.geo, pair=True)[0] if self.x.requires_grad else True
-        elif self.shortcut_sibling is not None:
-            dg = mod.conv2d_bn_bwd_supported(*self.geo, pair=True)[0] if self.x.requires_grad else True
-        else:
-            dg = mod.conv2d_bn_bwd_supported(*self.geo)[0] if self.x.requires_grad else True
+        if host is not None or self.shortcut_sibling is not None:
+            return False             # (the pair launch of a block with a convolution shortcut takes no pending operand)
+        dg = mod.conv2d_bn_bwd_supported(*self.geo)[0] if self.x.requires_grad else True
         wg = mod.conv2d_bn_bwd_supported(*self.geo)[1] if self.w.requires_grad else True
         return dg and wg
 
@@ -613,7 +604,7 @@ class _Conv2dFused(_FusedNode):
                 # cannot happen while the pooling node checks that it is the only consumer (the placeholder holds
                 # no values to fall back on): refuse rather than return a gradient without the other contribution
                 raise RuntimeError("stem backward: the convolution's output gradient is not the placeholder its "
-                                   "pooling node handed out (another consumer?); set DF_STEM_FUSED_BWD=0")
+                                   "pooling node handed out (another consumer?)")
             out = _grad_out(self.w, self.wd.shape, dev)
             if pend is not None:
                 _pending_table(pend, dev)         # (written by the input-gradient launch where there was one)
@@ -718,7 +709,7 @@ def mean_hw_linear(x: Tensor, fc) -> Tensor:
     x = realize(x)
     mod = x.device.mod
     if (_fused(x) and len(x.shape) == 4 and hasattr(mod, "pool_linear_forward") and int(fc.weight.shape[1]) <= 16
-            and int(fc.weight.shape[0]) == int(x.shape[1]) and os.environ.get("DF_HEAD_FUSED", "1") != "0"):
+            and int(fc.weight.shape[0]) == int(x.shape[1])):
         return _PoolLinearFused(x, fc.weight, fc.bias)
     return fc(mean_hw(x))
 
@@ -1058,8 +1049,6 @@ class _BnConv2dFused(_FusedNode):
         return dcb
 
 
-_BN_INPUT = os.environ.get("DF_BN_INPUT", "1") != "0"
-_S2_PAIR = os.environ.get("DF_S2_PAIR", "1") != "0"
 
 
 def bn_conv2d_train(x, bn, conv):
@@ -1069,7 +1058,7 @@ def bn_conv2d_train(x, bn, conv):
     kernel): the caller then writes conv(bn(x))."""
     x = realize(x)
     mod = x.device.mod
-    if not (_BN_INPUT and _CONV_BN_STATS and _fused(x) and hasattr(mod, "conv2d_forward_bn_input") and bn.training
+    if not (_fused(x) and hasattr(mod, "conv2d_forward_bn_input") and bn.training
             and is_grad_enable() and bn.weight is not None and bn.bias is not None):
         return None
     return _BnConv2dFused.build(x, bn, conv)
@@ -1129,7 +1118,7 @@ class _BnReluPoolFused(_FusedNode):
             dg, db = _grad_out(self.weight, (1, C, 1, 1), dev), _grad_out(self.bias, (1, C, 1, 1), dev)
             h = lambda t: t._handle if t is not None else None
             conv = self.x if isinstance(self.x, _Conv2dFused) else None
-            if (conv is not None and _STEM_FUSED_BWD and hasattr(dev.mod, "stem_backward") and self.x.requires_grad
+            if (conv is not None and hasattr(dev.mod, "stem_backward") and self.x.requires_grad
                     and not conv.x.requires_grad and conv.bias is None and conv.w.requires_grad
                     and conv._dw_ready is None and len(conv.children) == 1 and conv.children[0] is self):
                 # (only when this node is the convolution output's ONLY consumer: another consumer's contribution
@@ -1156,7 +1145,6 @@ class _BnReluPoolFused(_FusedNode):
         return dg if node is self.weight else db
 
 
-_STEM_FUSED_BWD = os.environ.get("DF_STEM_FUSED_BWD", "1") != "0"
 
 
 def bn_relu_maxpool2_fusable(x, bn, pool):
@@ -1190,7 +1178,7 @@ class _StemNoZFused(_FusedNode):
         fn = getattr(dev.mod, "stem_forward_noz", None)
         k = getattr(pool, "kernel_size", None)
         st = getattr(pool, "stride", k)
-        if (fn is None or not _STEM_NOZ or not _fused(x) or not bn.training or not is_grad_enable() or x.requires_grad
+        if (fn is None or not _fused(x) or not bn.training or not is_grad_enable() or x.requires_grad
                 or len(x.shape) != 4 or bn.weight is None or bn.bias is None
                 or k != 2 or (st not in (None, 0, 2)) or getattr(pool, "padding", 0) not in (0, None)):
             return None
@@ -1237,7 +1225,6 @@ class _StemNoZFused(_FusedNode):
         return dg if node is self.weight else db
 
 
-_STEM_NOZ = os.environ.get("DF_STEM_NOZ", "1") != "0"
 
 
 def stem_conv_bn_relu_pool_train(x, conv, bn, pool):

@@ -511,16 +511,6 @@ int dfhip_comm_rccl_path(char* out, int cap);
  * families against the data-sheet peak and reports this figure beside it. */
 int dfhip_clock_probe(double milliseconds, double* mhz, double* tflops);
 
-/* Side stream: work that may run beside what the library stream does next (weight gradients beside the rest of the
- * backward pass).  _fork: the side stream waits for everything queued on the library stream so far; _target(1): later
- * launches of the library go to the side stream until _target(0); _join: the library stream waits for the side stream
- * (also done by dfhip_graph_end).  Inside a capture these are a fork and a join of the graph.  dfhip_side_probe is a
- * diagnostic load (fork + `wgs` workgroups of an MFMA loop, lds_bytes of LDS each) for sizing what such overlap costs. */
-int dfhip_side_fork(void);
-int dfhip_side_target(int on);
-int dfhip_side_join(void);
-int dfhip_side_probe(int wgs, int iters, int lds_bytes);
-
 /* size of the communicator and this process's rank in it, as RCCL reports them (ncclCommCount / ncclCommUserRank) */
 int dfhip_comm_count(int* ranks, int* rank);
 int dfhip_comm_destroy(void);

@@ -389,19 +389,3 @@ def test_accumulate_dgrad_of_the_stride2_layers_with_shortcut_and_held_gradient(
     assert_close(_back(mod, dxh, shape), want3 + want1 + held, 1e-4, name + " accumulate dgrad + shortcut + held gradient")
     assert mod.conv2d_dgrad_pair(dyh, wh, dy2h, w2h, None, dxh, N, C, H, W, O, mode="accumulate")
     assert_close(_back(mod, dxh, shape), want3 + want1, 1e-4, name + " accumulate dgrad + shortcut")
-
-
-def test_xcd_aware_tile_order_gives_the_same_results():
-    """The XCD arrangement of the image-per-lane kernels (dfhip_internal.h xcd_tile; off by default, a speed switch
-    only) renumbers workgroups: the layer3 / layer4 full-size checks must pass unchanged with it on (the switch is
-    read once per process, hence the child process)."""
-    import os
-    import subprocess
-    import sys
-    from conftest import ROOT
-    for order in ("1", "8"):
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_fullsize.py"), "-q", "-x",
-                            "-m", "gpu", "-k", "test_conv_layer_full_size and (l3 or l4)"],
-                           env=dict(os.environ, DFHIP_XCD_ORDER=order), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-        assert " passed" in r.stdout

@@ -1,6 +1,5 @@
-"""GPU: every tuning / diagnostic switch of DESIGN §10 (environment variables read once per process: kernel variants that
-are compiled in but not taken by default -- the staged kernels behind the lean ones, stand-alone behind grouped launches,
-the unfused compositions behind the fused nodes) against the DEFAULT path: one training step of the two convolutional
+"""GPU: every switch of DESIGN §10 (environment variables read once per process: the unfused compositions behind the fused
+nodes, stand-alone behind grouped launches) against the DEFAULT path: one training step of the two convolutional
 benchmark jobs (ResNet-18 and CNN, batch 256) per switch in a child process, loss / logits / 62 |grad| sums / the stem's weight
 gradient / post-step |param| sums compared with the default child's (which tests/test_hip_whole_step.py pins to the oracle).
 A switch only changes which kernels run, i.e. the fp32 summation order: 1e-4 relative."""
@@ -16,19 +15,14 @@ from conftest import ROOT, rel_err
 
 pytestmark = pytest.mark.gpu
 
+# Round 5: every switch whose variant DESIGN records as slower is gone together with the code only it reached; what is left
+# selects a composition the front end also reaches by itself for other models (unfused module calls, stand-alone launches,
+# the packed exchange bucket) or is a diagnostic of this round (weight gradients on a second stream / on CU-masked streams).
 OVERWRITE = [
-    ("DFHIP_DGRAD_LEAN", "0"), ("DFHIP_DGRAD_IMG2", "0"), ("DFHIP_DGRAD_IMG4", "0"), ("DFHIP_DGRAD_PAIR", "0"),
-    ("DFHIP_DGRAD_IMG8", "0"), ("DFHIP_IMG4_TR", "0"), ("DFHIP_IMG4_HALVES", "0"), ("DFHIP_BN_INPUT_COMBINE", "0"), ("DFHIP_STEM_COMBINE_RIDES", "0"), ("DFHIP_IMG2_BN_INPUT", "0"), ("DFHIP_ROWMMA_TS8", "0"), ("DFHIP_BN_BWD_HW4", "0"), ("DFHIP_BN_FWD_HW4", "0"), ("DFHIP_IMG4_COAL", "0"), ("DFHIP_DGRAD_ROW0", "0"), ("DFHIP_DGRAD_ROW0", "1"), ("DFHIP_WGRAD_PAIR", "0"), ("DFHIP_WGRAD_DIRECT", "0"),
-    ("DFHIP_WGRAD_GROUP_DIV", "4"), ("DFHIP_WGRAD_ROWS", "0"), ("DFHIP_WGRAD_TAP", "0"), ("DFHIP_WGRAD_DEFER", "0"),
-    ("DFHIP_WGRAD_STEM3", "0"), ("DFHIP_WGRAD_KT5", "0"), ("DFHIP_IGEMM_K5", "0"), ("DFHIP_IGEMM_K5_SPEC", "0"),
-    ("DFHIP_IMG2_LEAN", "0"), ("DFHIP_SHORTCUT_LEAN", "0"), ("DFHIP_STEM_ROWS", "0"), ("DFHIP_VEC_STORE", "0"),
-    ("DFHIP_BN_INPUT", "0"), ("DFHIP_STEM_FUSED_BWD", "0"), ("DF_STEM_NOZ", "0"), ("DFHIP_STEM_ONEPASS", "0"),
-    ("DFHIP_XCD_ORDER", "1"), ("DFHIP_BN_BWD_FUSED", "0"), ("DF_BN_BWD_FUSED", "0"), ("DF_BN_BWD_PAIR", "1"),
-    ("DF_LAZY_MODULES", "0"), ("DF_LINEAR_RELU", "0"), ("DFHIP_MASK_BYTES", "0"), ("DF_S2_PAIR", "0"),
-    ("DF_CONV_BN_STATS", "0"), ("DF_HEAD_FUSED", "0"), ("DF_WGRAD_GROUP", "0"), ("DF_BN_INPUT", "0"),
-    ("DF_STEM_FUSED_BWD", "0"), ("DFHIP_DGRAD_BN_NW8", "0"), ("DF_GRAD_IN_BUCKET", "0"),
+    ("DF_LAZY_MODULES", "0"), ("DF_WGRAD_GROUP", "0"), ("DF_BN_BWD_FUSED", "0"), ("DFHIP_BN_BWD_FUSED", "0"),
+    ("DF_GRAD_IN_BUCKET", "0"), ("DFHIP_WGRAD_GROUP_DIV", "4"), ("DFHIP_WGRAD_SIDE", "6"),
 ]
-ACCUMULATE = [("DFHIP_DGRAD_IMG2_ACC", "0"), ("DFHIP_DGRAD_S2_ACC", "0"), ("DFHIP_WGRAD_DIRECT", "0")]
+ACCUMULATE = [("DF_LAZY_MODULES", "0"), ("DF_WGRAD_GROUP", "0")]
 
 
 def _child(tmp, tag, mode, env_extra):

@@ -25,6 +25,11 @@ one() {   # one <suffix> <workload> <dgrad> [extra bench args]
       $(find $OUT/pmc_fetch$sfx $OUT/pmc_write$sfx $OUT/pmc_sq$sfx -name "*counter_collection.csv") > $OUT/pmc_summary$sfx.log 2>&1
   python3 tools/pmc_summary.py $(find $OUT/pmc_fetch$sfx $OUT/pmc_write$sfx $OUT/pmc_sq$sfx -name "*counter_collection.csv") > $OUT/pmc_per_kernel$sfx.txt 2>&1
   rm -rf $OUT/pmc_fetch$sfx $OUT/pmc_write$sfx $OUT/pmc_sq$sfx
+  # where the waves' cycles go (quad-cycles): parked on s_waitcnt / barriers, stalled at issue, issuing; and which pipe issues
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES \
+      --kernel-trace --output-format csv -d $OUT/pmc_wave$sfx -o p -- $CMD > $OUT/pmc_wave$sfx.log 2>&1
+  python3 tools/pmc_any.py $(find $OUT/pmc_wave$sfx -name "*counter_collection.csv") > $OUT/pmc_wave_cycles$sfx.txt 2>&1
+  rm -rf $OUT/pmc_wave$sfx
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats$sfx -o s -- $CMD > $OUT/stats$sfx.log 2>&1
   f=$(find $OUT/stats$sfx -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && python3 tools/kernel_stats_txt.py $f > $OUT/rocprof_kernel_stats$sfx.txt
