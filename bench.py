@@ -286,7 +286,8 @@ def epoch_bench(args):
             fn()
         return (time.perf_counter() - t0) * 1e3 / reps
     it = iter(loader)
-    stage_loader = per_batch(lambda: next(it))
+    # (a short --epoch-images leaves fewer full batches than the default 40 repetitions)
+    stage_loader = per_batch(lambda: next(it), reps=max(1, min(40, n_img // batch - 1)))
     stage_decisions = per_batch(lambda: draw_decisions(batch, 32, 32, 1, 30))
     pipe = DeviceBatchPipeline(dev, (batch, 3, 32, 32))
     xb, yb = X[:batch], Y[:batch]

@@ -1504,10 +1504,15 @@ struct AdamHyper {
   float lr, b1, b2, omb1, omb2, bc1, bc2, eps, wd, gscale;
 };
 
+// the tensor a block belongs to: the last t with blk_start[t] <= blk (blk_start is ascending; six dependent scalar loads
+// instead of up to 62 -- the big tensors are the last ones of a ResNet's list)
 __device__ __forceinline__ int find_tensor(const TensorBatch& tb, int blk) {
-  int t = 0;
-  while (t + 1 < tb.n && blk >= tb.blk_start[t + 1]) t++;
-  return t;
+  int lo = 0, hi = tb.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (blk >= tb.blk_start[mid]) lo = mid; else hi = mid - 1;
+  }
+  return lo;
 }
 
 // one element of the update — optim/adam.py:42-60, same operation order

@@ -1997,8 +1997,11 @@ __global__ __launch_bounds__(256) void k_wgrad_group_sum(SGroup a) {
     return;
   }
   const int b = (int)blockIdx.x - a.stem_blocks;
-  int li = 0;
-  while (li + 1 < a.n && b >= a.vb_end[li]) li++;
+  int li = 0, hi = a.n - 1;                          // the first layer with b < vb_end[li] (ascending: a binary search)
+  while (li < hi) {
+    const int mid = (li + hi) >> 1;
+    if (b >= a.vb_end[mid]) li = mid + 1; else hi = mid;
+  }
   const SlabSum& d = a.s[li];
   const int vb = b - (li ? a.vb_end[li - 1] : 0);
   if (d.T == 9) wgrad_group_sum_body<9>(d, vb, part);
