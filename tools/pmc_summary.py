@@ -132,7 +132,7 @@ def _family_of(kernel):
             return "conv2d_dgrad_igemm"
     if k.startswith("k_conv3x3_rowmma<"):
         args = [a.strip() for a in k[len("k_conv3x3_rowmma<"):-1].split(",")]
-        if len(args) > 8 and args[8] == "true":
+        if len(args) > 7 and args[7] == "true":      # <LW, C, NT, VDPP, TS, OW, CG, DG, BNI> since round 5
             return "conv2d_dgrad_igemm"
     for fam, prefixes in FAMILIES.items():
         if any((k == pr[:-1]) if pr.endswith("$") else k.startswith(pr) for pr in prefixes):
