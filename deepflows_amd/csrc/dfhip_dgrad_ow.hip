@@ -146,6 +146,31 @@ struct OwGeo {
 // ONE row of sums, and every workgroup of the consuming launch reads all rows -- with 512 workgroups of 4 waves on the
 // 16 x 16 x 32-channel layers that was 512 x 64 KB = 32 MB of row reads per launch (PMC: 40 MB fetched for 19.6 MB algorithmic),
 // with 256 workgroups of 8 waves it is 256 x 32 KB.
+#ifdef DFHIP_RIDER_PROBE
+// Diagnostic build (round 5, tools/probes/rider_probe.sh): extra workgroups of this kernel -- the ones past the last tile --
+// spin on independent fp32 MFMAs for g_rider_iters x 4 instructions per wave: what a matrix-bound rider that shares the CUs
+// of a chain kernel costs that kernel, and how much matrix work it gets done meanwhile.
+__device__ int g_rider_iters;
+__device__ __forceinline__ void rider_spin() {
+  typedef float r4 __attribute__((ext_vector_type(4)));
+  r4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  const float x = 0.3f + threadIdx.x * 1e-3f;
+  const int iters = g_rider_iters;
+  if (iters < 0) {                                   // control: a rider that only SLEEPS for -iters x 0.1 us (no pipe is used)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(-iters) * 10ull) __builtin_amdgcn_s_sleep(8);
+    return;
+  }
+  for (int i = 0; i < iters; i++) {
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, 0.5f, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, 0.25f, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, 0.125f, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, 0.0625f, a3, 0, 0, 0);
+  }
+  const float r = a0[0] + a1[1] + a2[2] + a3[3];
+  asm volatile("" ::"v"(r));                         // (the sums are "used": the loop stays)
+}
+#endif
 template <int O, int GEO, bool PAIR, bool BNI, int NST, int NW>
 __global__ __launch_bounds__(64 * NW) void k_dgrad_ow_s1(const float* __restrict__ dy, const float* __restrict__ w,
                                                      const float* __restrict__ add, float* __restrict__ dx,
@@ -162,6 +187,9 @@ __global__ __launch_bounds__(64 * NW) void k_dgrad_ow_s1(const float* __restrict
   __shared__ float wsum[NST ? NW : 1][NST ? 32 : 1][KS];
   __shared__ float mtl[NST ? NST : 1][32];
   __shared__ __attribute__((aligned(16))) float tpart[BNI ? bn_part_floats(64 * NW) : 4];
+#ifdef DFHIP_RIDER_PROBE
+  if ((int)blockIdx.x * NW >= tiles) { rider_spin(); return; }      // (uniform per workgroup)
+#endif
   const int lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -859,6 +887,20 @@ int launch_ow_s1(const float* dy, const float* w, const float* add, float* dx, i
     if (dry_run) return DFHIP_OK;
     int st = make_ow_bn(bn, bi, bi2, so, (int)grid.x, (int)grid.y, C);
     if (st != DFHIP_OK) return st;
+#ifdef DFHIP_RIDER_PROBE
+    {
+      static int wgs = getenv("DFHIP_RIDER_WGS") ? atoi(getenv("DFHIP_RIDER_WGS")) : 0;
+      static int iters = getenv("DFHIP_RIDER_ITERS") ? atoi(getenv("DFHIP_RIDER_ITERS")) : 0;
+      static bool told = false;
+      if (!told) {
+        const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_rider_iters), &iters, sizeof(int));
+        fprintf(stderr, "[rider] O %d GEO %d: %d extra workgroups x %d iterations (hipMemcpyToSymbol: %s), grid %u x %u\n", O, GEO, wgs,
+                iters, hipGetErrorString(e), grid.x, grid.y);
+        told = true;
+      }
+      if (wgs > 0) grid.x += (unsigned)(wgs / (int)grid.y);      // (DFHIP_RIDER_WGS in all, over the grid's rows)
+    }
+#endif
     const int nst = so ? so->n : 0;
     const bool bni = bi || bi2;
     // (of a PAIR only one gradient may be pending: the other one's descriptor is the identity, its z operand re-reads dY)
