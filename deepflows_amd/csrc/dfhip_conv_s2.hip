@@ -732,13 +732,14 @@ int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
   }
-  // (32 -> 64 channels: a workgroup = eight pixel tiles x ONE group of two channel tiles -- a pixel tile is then requested by
-  // one wave of the workgroup only and the weight image is half as large: 11.8 -> 11.3 us against four tiles x two groups
-  // (round 5).  Measured and dropped before: chunks of four channel groups (13.4 -> 14.9 us), three chunks of pixels ahead,
-  // two waves splitting a tile's groups.)
+  // (a workgroup = eight pixel tiles x ONE group of channel tiles -- 32 -> 64 channels two tiles per wave, 64 -> 128 one: a pixel
+  // tile is requested by one wave of the workgroup only and the weight image is half as large: 11.8 -> 11.3 and 11.3 -> 10.1 us
+  // against four tiles x two groups / two channel tiles per wave (round 5; the 64-channel form has fewer weight pieces than
+  // staging threads: the spare threads' piece index is taken modulo the piece count).  Measured and dropped before: chunks of
+  // four channel groups (13.4 -> 14.9 us), three chunks of pixels ahead, two waves splitting a tile's groups.)
   int otw, ts, lwo;
   if (C == 32 && H == 16) { otw = 2; ts = 8; lwo = 3; }
-  else if (C == 64 && H == 8) { otw = 2; ts = 4; lwo = 2; }
+  else if (C == 64 && H == 8) { otw = 1; ts = 8; lwo = 2; }
   else if (C == 128 && H == 4) { otw = 1; ts = 4; lwo = 1; }
   else return -1;
   const int ocw = otw * 16;                    // output channels per workgroup
@@ -751,7 +752,7 @@ int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y
   if (dry_run) return DFHIP_OK;
   dim3 grid((unsigned)gx, (unsigned)(O / ocw));
   if (C == 32) return launch_s2<32, 2, 8, 1, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
-  if (C == 64) return launch_s2<64, 2, 4, 1, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
+  if (C == 64) return launch_s2<64, 1, 8, 1, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
   return launch_s2<128, 1, 4, 1, 2, 2>(x, w, wd, y, yd, partials, partials_d, lwo, O, grid);
 }
 
