@@ -121,9 +121,8 @@ __device__ __forceinline__ DfTile xcd_tile(int xo) {
 }
 #endif
 namespace dfhip {
-// the arrangement for a grid of nx x ny tiles whose y operand (what blockIdx.y selects: weights) is y_bytes and whose x
-// operand (images) is x_bytes in all: the divisor xo of 8 with ny % xo == 0, nx % (8 / xo) == 0 that minimises the
-// bytes one XCD's L2 has to hold; 0 (natural order) when nothing divides or DFHIP_XCD_ORDER=0
+// 0 = grid order.  (An arrangement that gives every XCD's L2 1/8 of the weights was measured in rounds 3 and 5: fewer bytes,
+// more time -- dfhip_runtime.hip.)
 int xcd_arrangement(int nx, int ny, double x_bytes, double y_bytes);
 }
 

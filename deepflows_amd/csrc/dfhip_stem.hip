@@ -724,6 +724,7 @@ bool stem_shape(int N, int C, int H, int W, int O, int k, int stride, int pad) {
 
 // the instantiations: C = 1 .. 3 input channels, 3x3 or 5x5
 #define DF_STEM_CASES(X) X(1, 3) X(2, 3) X(3, 3) X(1, 5) X(2, 5) X(3, 5)
+#define DF_STEM_CASES5(X) X(1, 5) X(2, 5) X(3, 5)      // the two-pass backward exists for the 5x5 stems only
 
 }  // namespace
 
@@ -806,7 +807,7 @@ int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, c
 #define DF_CASE(CV, KV)                                                                                                   \
     DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<CV, KV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
     DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<CV, KV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-    DF_STEM_CASES(DF_CASE)
+    DF_STEM_CASES5(DF_CASE)
 #undef DF_CASE
     DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<1, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     DF_HIP(hipFuncSetAttribute((const void*)k_stem_bwd<2, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
@@ -839,7 +840,7 @@ int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, c
     ProfScope prof("bn_relu_pool_bwd", 0.0, 4.0 * ((double)N * C * H * 32 + npix / 2));
 #define DF_CASE(CV, KV) \
     if (C == CV && k == KV) DF_LAUNCH((k_stem_bwd<CV, KV, 0>), dim3((unsigned)gx), dim3(512), lds, stream(), b);
-    DF_STEM_CASES(DF_CASE)
+    DF_STEM_CASES5(DF_CASE)
 #undef DF_CASE
     DF_LAUNCH_CHECK();
     st2_dump("bwd_stats", gx);
@@ -848,7 +849,7 @@ int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, c
     ProfScope prof("conv2d_wgrad_igemm", 2.0 * N * H * 32.0 * KK * O, 4.0 * ((double)N * C * H * 32 + (double)O * KK + npix / 2));
 #define DF_CASE(CV, KV) \
     if (C == CV && k == KV) DF_LAUNCH((k_stem_bwd<CV, KV, 1>), dim3((unsigned)gx), dim3(512), lds, stream(), b);
-    DF_STEM_CASES(DF_CASE)
+    DF_STEM_CASES5(DF_CASE)
 #undef DF_CASE
     DF_LAUNCH_CHECK();
     st2_dump("bwd_wgrad", gx);

@@ -2205,7 +2205,7 @@ int run_wgrad_v3(WGeo g, float* dw, bool stem = false) {
   if ((g.H * g.W) % 4 != 0 || (g.oh * g.ow) % 4 != 0) return -1;   // 16-byte aligned channel planes
   const int OT = g.O <= 32 ? 1 : 2;
   // (column tiles per workgroup: with 64 output channels and a 5x5 kernel -- 800 columns -- five tiles per workgroup
-  // halve the dY operand reads per MFMA; DFHIP_WGRAD_KT5=0 restores two)
+  // halve the dY operand reads per MFMA)
   const int KT = (g.k == 1 || KW <= 32) ? 1 : (g.O <= 32 ? 5 : ((g.k == 5 && KW >= 320) ? 5 : 2));
   const int CH = std::min(g.C, (KT * 32 + k2 - 2) / k2 + 1);
   int gi = 1;
