@@ -25,6 +25,10 @@ Recorded forms (x0 a real tensor):
     mean(x0, axis=2), mean(mean(x0, 2), 2)     "mean2", "meanhw"
     fc(x0), x0 two-dimensional                 "linear"
 Completing calls: MaxPool2d(relu(bn(conv(x0)))), bn(conv(bn(conv(x0)))) + identity, Linear(meanhw(x0)), F.relu(fc(x0)).
+A record is single-shot: when a fused launch has run the BatchNorm of a record it did not hand out (`bn1` applied on conv2's
+loads, `bn2` inside the block's tail, the stem's BatchNorm), whoever still holds the record and touches it later gets the same
+values from a normalisation that does NOT update running_mean / running_var a second time (the reference calls each module
+once: nn/modules/batchnorm.py:44-52), and such a record is not fused again (tests/test_hip_lazy_records.py).
 DF_LAZY_MODULES=0 switches the mechanism off (every module call launches its own node, as before)."""
 import os
 import weakref
