@@ -21,6 +21,8 @@ pytestmark = pytest.mark.gpu
 OVERWRITE = [
     ("DF_LAZY_MODULES", "0"), ("DF_WGRAD_GROUP", "0"), ("DF_BN_BWD_FUSED", "0"), ("DFHIP_BN_BWD_FUSED", "0"),
     ("DF_GRAD_IN_BUCKET", "0"), ("DFHIP_WGRAD_GROUP_DIV", "4"), ("DFHIP_WGRAD_SIDE", "6"),
+    # (round 5's diagnostic: the backward chain on 128 CUs, every four queued weight gradients on the other 128)
+    (("DFHIP_OVERLAP_CUS", "128"), ("DFHIP_WGRAD_SIDE", "4")),
 ]
 ACCUMULATE = [("DF_LAZY_MODULES", "0"), ("DF_WGRAD_GROUP", "0")]
 
@@ -36,9 +38,12 @@ def _child(tmp, tag, mode, env_extra):
 
 def _run_matrix(tmp_path, mode, switches):
     tmp = str(tmp_path)
-    jobs = [("default", {})] + [(f"{k}={v}", {k: v}) for k, v in switches]
+    # (a switch is (name, value) or a tuple of such pairs that belong together)
+    def env_of(sw):
+        return dict(sw) if isinstance(sw[0], tuple) else {sw[0]: sw[1]}
+    jobs = [("default", {})] + [(" ".join(f"{k}={v}" for k, v in env_of(sw).items()), env_of(sw)) for sw in switches]
     with ThreadPoolExecutor(max_workers=4) as pool:
-        done = list(pool.map(lambda j: _child(tmp, j[0].replace("=", "_"), mode, j[1]), jobs))
+        done = list(pool.map(lambda j: _child(tmp, j[0].replace("=", "_").replace(" ", "+"), mode, j[1]), jobs))
     failed = [(tag, err) for tag, rc, err, _ in done if rc != 0]
     assert not failed, f"children failed: {failed}"
     base = np.load(done[0][3])
