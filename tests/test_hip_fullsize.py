@@ -28,11 +28,27 @@ def _back(mod, h, shape):
     return mod.to_numpy(h, (h.size,), (1,), 0).reshape(shape)
 
 
+# Shapes that reach kernel instantiations the benchmarked models do not (tools/kernel_coverage.py, round 5: the whole-image
+# forms of the 4 x 4 input gradients that larger batches take, the 64- and 128-channel 4 x 4 / 2 x 2 layers, 512 output
+# channels on 2 x 2 images): (batch, C, H, W, O, k, stride, pad)
+OTHER = {"l3_n512": (512, 128, 4, 4, 128, 3, 1, 1), "l4a_n512": (512, 128, 4, 4, 256, 3, 2, 1), "c64_4x4": (256, 64, 4, 4, 64, 3, 1, 1),
+         "c128_2x2": (64, 128, 2, 2, 128, 3, 1, 1), "c256_512_2x2": (64, 256, 2, 2, 512, 3, 1, 1), "l2_n64": (64, 64, 8, 8, 64, 3, 1, 1),
+         "l1_n32": (32, 32, 16, 16, 32, 3, 1, 1)}
+
+
+@pytest.mark.parametrize("name", list(OTHER))
+def test_conv_other_sizes_the_dispatch_reaches(hip_device, name):
+    _conv_layer(hip_device, name, OTHER[name][0], OTHER[name][1:])
+
+
 @pytest.mark.parametrize("name", list(LAYERS))
 def test_conv_layer_full_size(hip_device, name):
+    _conv_layer(hip_device, name, N, LAYERS[name])   # (every layer of both benchmarked models at the benchmarked batch)
+
+
+def _conv_layer(hip_device, name, n, layer):
     mod = hip_device.mod
-    C, H, W, O, k, s, p = LAYERS[name]
-    n = N                                   # (every layer of both benchmarked models at the benchmarked batch)
+    C, H, W, O, k, s, p = layer
     oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     rng = np.random.default_rng(hash(name) % 1000)
     x = rng.standard_normal((n, C, H, W)).astype(np.float32)
