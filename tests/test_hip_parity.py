@@ -694,7 +694,7 @@ def test_stem_backward_without_the_full_resolution_gradient(hip_device, k, pad):
 
 @pytest.mark.parametrize("N,C,H,O,K,bias", [(32, 3, 32, 32, 3, False), (5, 3, 32, 32, 3, True), (7, 2, 16, 20, 3, False),
                                               (3, 1, 8, 32, 3, False), (300, 3, 32, 32, 3, False), (32, 3, 32, 32, 5, True),
-                                              (6, 2, 16, 24, 5, False), (260, 3, 32, 32, 5, True)])
+                                              (6, 2, 16, 24, 5, False), (260, 3, 32, 32, 5, True), (4, 1, 16, 16, 5, False)])
 def test_stem_without_its_convolution_output(hip_device, N, C, H, O, K, bias):
     """pool(relu(bn(conv(x)))) as the one node whose 33 MB convolution output never exists (dfhip_stem.hip: the
     convolution keeps the window extreme that survives bn + relu + max -- the minimum where gamma < 0 --, the backward
