@@ -97,6 +97,59 @@ def build_job(workload, dev, rank, batch, register_blocks=True, model_kind="plai
     return model, opt, crit, Tensor(x, device=dev), Tensor(y, device=dev)
 
 
+def other_configurations(dev, steps):
+    """The BASELINE's other single-GPU configurations inside the default run (so that the driver's own run times them too, not
+    only the builder's profiles/): CNN-CIFAR10 bs 256 and MLP-MNIST bs 128 (BASELINE.json configs 2-3), and the headline model
+    in the mathematically complete input-gradient mode.  Each: 3 eager warm-up steps, the captured step, 2 warm + ~0.1 s of
+    untimed replays, `steps` timed replays between synchronize pairs.  A configuration that fails is reported as such and
+    never touches the headline."""
+    from deepflows_amd import workloads
+    from deepflows_amd.graph_step import CapturedTrainStep
+    from deepflows_amd.tensor import Graph
+    mod = dev.mod
+    out = {}
+    for name, wl, dgrad in (("cnn_cifar10_bs256", "cnn", "overwrite"), ("mlp_mnist_bs128", "mlp", "overwrite"),
+                            ("resnet18_bs256_accumulate_dgrad", "resnet18", "accumulate")):
+        saved = mod.conv_dgrad_mode
+        cap = None
+        try:
+            mod.conv_dgrad_mode = dgrad
+            batch = WORKLOADS[wl]["batch"]
+            model, opt, crit, xt, yt = build_job(wl, dev, 0, batch)
+            for _ in range(3):
+                workloads.train_step(model, crit, opt, xt, yt)
+                Graph.free_graph()
+            cap = CapturedTrainStep(model, crit, opt, xt, yt)
+            for _ in range(2):
+                cap.replay()
+            mod.synchronize()
+            t = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t < 0.1:
+                cap.replay()
+                n += 1
+            mod.synchronize()
+            t = time.perf_counter()
+            for _ in range(steps):
+                loss = cap.replay()
+            mod.synchronize()
+            dt = time.perf_counter() - t
+            out[name] = {"value": batch * steps / dt, "unit": "samples/s" if wl == "mlp" else "images/s",
+                         "ms_per_step": dt * 1e3 / steps, "steps": steps, "settle_replays_untimed": n + 2,
+                         "final_loss": float(loss.numpy()[0]), "workload": WORKLOADS[wl]["text"], "conv_dgrad": dgrad}
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            mod.conv_dgrad_mode = saved
+            if cap is not None:
+                try:
+                    cap.destroy()
+                except Exception:
+                    pass
+            Graph.free_graph_all()
+    return out
+
+
 def host_cores():
     """(physical cores of one socket, logical CPUs) from lscpu; falls back to os.cpu_count()."""
     logical = os.cpu_count() or 1
@@ -339,6 +392,8 @@ def main():
                     help="do not time the other model class beside the headline (profiler passes: every launch of the run is then "
                          "one of the 3 warm-up + 2 + K replayed + K eager steps the counters are divided by)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="do not time the BASELINE's other single-GPU configurations (CNN, MLP, accumulate mode) behind the headline")
     ap.add_argument("--pmc-traffic", default=None,
                     help="PMC summary (tools/pmc_summary.py --json) to quote for traffic / executed flops instead of the "
                          "newest matching file under profiles/")
@@ -585,6 +640,13 @@ def main():
         print(f"[bench] clock probe failed: {e}", file=sys.stderr)
         clock_mhz = probe_tflops = None
     comm.barrier()
+    others = None
+    if (args.workload == "resnet18" and args.dgrad == "overwrite" and comm.world == 1 and sync is None and captured is not None
+            and not profiled_run and not args.no_other_configs and not args.no_other_model):
+        try:
+            others = other_configurations(dev, args.steps)
+        except Exception as e:
+            print(f"[bench] the other configurations were not timed ({type(e).__name__}: {e})", file=sys.stderr)
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
@@ -657,6 +719,8 @@ def main():
             "final_loss": final_loss,
             "model": args.model if args.workload == "resnet18" else None,
             f"{other_kind}_images_per_s": other_value,
+            # BASELINE.json configs 2-3 and the accumulate mode, timed in this same run (never the headline)
+            "other_configurations": others,
             "roofline": roofline,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in
                         sorted(fams.items(), key=lambda kv: -kv[1]["ms_per_step"])},
