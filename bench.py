@@ -93,60 +93,51 @@ def build_job(workload, dev, rank, batch, register_blocks=True, model_kind="plai
         opt = optim.SGD(model.parameters(), lr=0.05)
     model.train()
     crit = nn.CrossEntropyLoss()
+    # replicas are identical (seed 0 above); what a rank draws AFTER the init -- Dropout masks -- is rank-local (SURVEY §8e
+    # "seed + rank"): rank 0 continues the stream (= the single-GPU run, bit for bit), rank r > 0 re-seeds with seed + r
+    from deepflows_amd import parallel
+    parallel.seed_rank_local(0, rank)
     x, y = make_batch(workload, rank, batch)
     return model, opt, crit, Tensor(x, device=dev), Tensor(y, device=dev)
 
 
-def other_configurations(dev, steps):
+OTHER_CONFIGURATIONS = (("cnn_cifar10_bs256", "cnn", "overwrite"), ("mlp_mnist_bs128", "mlp", "overwrite"),
+                        ("resnet18_bs256_accumulate_dgrad", "resnet18", "accumulate"))
+
+
+def other_configurations(steps, timeout_s=150.0):
     """The BASELINE's other single-GPU configurations inside the default run (so that the driver's own run times them too, not
     only the builder's profiles/): CNN-CIFAR10 bs 256 and MLP-MNIST bs 128 (BASELINE.json configs 2-3), and the headline model
-    in the mathematically complete input-gradient mode.  Each: 3 eager warm-up steps, the captured step, 2 warm + ~0.1 s of
-    untimed replays, `steps` timed replays between synchronize pairs.  A configuration that fails is reported as such and
-    never touches the headline."""
-    from deepflows_amd import workloads
-    from deepflows_amd.graph_step import CapturedTrainStep
-    from deepflows_amd.tensor import Graph
-    mod = dev.mod
+    in the mathematically complete input-gradient mode.  Each one is this same script in a CHILD PROCESS (subprocess: fork +
+    exec of a fresh interpreter, never an exec of this one) under a timeout, started after the headline has been measured: a
+    fault, abort or hang in one of them costs that entry (reported as `error`) and nothing else.  The child runs
+    `--steps` timed replays of its captured step and the per-family event pass; what comes back is its JSON line."""
     out = {}
-    for name, wl, dgrad in (("cnn_cifar10_bs256", "cnn", "overwrite"), ("mlp_mnist_bs128", "mlp", "overwrite"),
-                            ("resnet18_bs256_accumulate_dgrad", "resnet18", "accumulate")):
-        saved = mod.conv_dgrad_mode
-        cap = None
+    for name, wl, dgrad in OTHER_CONFIGURATIONS:
+        k = steps if wl != "mlp" else max(steps, 200)
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--dgrad", dgrad, "--steps", str(k), "--warmup", "3",
+               "--no-cpu-baseline", "--no-other-configs", "--no-other-model", "--sustain-ms", "0", "--settle-ms", "100"]
+        env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        t = time.perf_counter()
         try:
-            mod.conv_dgrad_mode = dgrad
-            batch = WORKLOADS[wl]["batch"]
-            model, opt, crit, xt, yt = build_job(wl, dev, 0, batch)
-            for _ in range(3):
-                workloads.train_step(model, crit, opt, xt, yt)
-                Graph.free_graph()
-            cap = CapturedTrainStep(model, crit, opt, xt, yt)
-            for _ in range(2):
-                cap.replay()
-            mod.synchronize()
-            t = time.perf_counter()
-            n = 0
-            while time.perf_counter() - t < 0.1:
-                cap.replay()
-                n += 1
-            mod.synchronize()
-            t = time.perf_counter()
-            for _ in range(steps):
-                loss = cap.replay()
-            mod.synchronize()
-            dt = time.perf_counter() - t
-            out[name] = {"value": batch * steps / dt, "unit": "samples/s" if wl == "mlp" else "images/s",
-                         "ms_per_step": dt * 1e3 / steps, "steps": steps, "settle_replays_untimed": n + 2,
-                         "final_loss": float(loss.numpy()[0]), "workload": WORKLOADS[wl]["text"], "conv_dgrad": dgrad}
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": f"child exited {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+                continue
+            d = json.loads(lines[-1])
+            rf = d.get("roofline") or {}
+            out[name] = {"value": d["value"], "unit": "samples/s" if wl == "mlp" else "images/s",
+                         "ms_per_step": d["ms_per_step"], "steps": d["steps"], "final_loss": d.get("final_loss"),
+                         "conv_dgrad": dgrad, "dispatch": d["config"].get("dispatch"),
+                         "dominant_family": rf.get("kernel"), "roofline_bound": rf.get("bound"),
+                         "roofline_frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us"),
+                         "launches_per_step": d["config"].get("launches_per_step"),
+                         "child_wall_s": round(time.perf_counter() - t, 1)}
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": f"child killed after {timeout_s:.0f} s"}
         except Exception as e:
             out[name] = {"error": f"{type(e).__name__}: {e}"}
-        finally:
-            mod.conv_dgrad_mode = saved
-            if cap is not None:
-                try:
-                    cap.destroy()
-                except Exception:
-                    pass
-            Graph.free_graph_all()
     return out
 
 
@@ -398,9 +389,15 @@ def main():
                     help="PMC summary (tools/pmc_summary.py --json) to quote for traffic / executed flops instead of the "
                          "newest matching file under profiles/")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
-    ap.add_argument("--sustain-ms", type=float, default=2500.0,
+    ap.add_argument("--sustain-ms", type=float, default=6500.0,
                     help="after the K timed steps: this many milliseconds of further replays of the captured step in ten "
-                         "timed chunks (sustained / median / best ms per step in the JSON line); 0 = skip")
+                         "timed chunks (sustained / median / best ms per step inside `config`); longer than the 5 s interval of "
+                         "an outside SMI sampler on purpose; 0 = skip")
+    ap.add_argument("--kernels-in-line", action="store_true",
+                    help="keep the per-family and per-kernel tables in the JSON line (tools/profile_round.sh); default: they go "
+                         "to the side file --kernels-file and the line stays short enough for the driver's record")
+    ap.add_argument("--kernels-file", default=None,
+                    help="side file of the per-family / per-kernel tables (default gpurun_out/bench_kernels_<workload>.json)")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="untimed replays of the captured step in front of the timed region, in milliseconds of wall time: the "
                          "clock governor needs ~0.2 s of load to reach the clock it then holds (tools/soak.py: 5 000 replays); "
@@ -644,7 +641,7 @@ def main():
     if (args.workload == "resnet18" and args.dgrad == "overwrite" and comm.world == 1 and sync is None and captured is not None
             and not profiled_run and not args.no_other_configs and not args.no_other_model):
         try:
-            others = other_configurations(dev, args.steps)
+            others = other_configurations(args.steps)
         except Exception as e:
             print(f"[bench] the other configurations were not timed ({type(e).__name__}: {e})", file=sys.stderr)
 
@@ -690,14 +687,53 @@ def main():
             roofline["algorithmic_flops_per_launch"] = prof[dom]["flops"] / prof[dom]["calls"]
         exchanged = bucket.total if sync is not None else 0
         rccl_ranks = mod.comm_count()[0] if comm.exchanges else None
+        # the whole step priced two ways: the algorithmic contraction flops (BASELINE.md §3 / SURVEY §8d: input gradients
+        # counted at the forward's flop count) and the flops the matrix cores EXECUTE (PMC pass of the same kernel sources;
+        # the overwrite input gradient keeps 1/9 ... 4/9 of the taps, padding taps are not multiplied)
+        # (SURVEY §8d / BASELINE.md §3 figures at the workloads' own batch; the event pass's per-family flops book the overwrite
+        # input gradient at its executed count, so their sum is not this figure)
+        alg_flops = {"resnet18": 54.06e9, "cnn": 29.93e9, "mlp": 0.1047e9, "resnet18_wide": 852.2e9}[args.workload] * batch / wl["batch"]
+        pmc_all, _ = pmc_file(args.workload, args.dgrad, args.pmc_traffic)
+        exec_flops = (sum(f.get("executed_flops_per_step", 0.0) for f in pmc_all["families"].values()) if pmc_all else None)
+        fam_table = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in
+                     sorted(fams.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+        # per kernel instantiation (names as rocprofv3 prints them): launches per step, the kernel's own duration,
+        # the algorithmic work of the family calls it was the first launch of
+        kernel_table = [{"kernel": name, "family": r["family"], "launches_per_step": round(r["launches"] / args.steps, 3),
+                         "avg_us": round(r["kernel_ms"] / r["launches"] * 1e3, 3),
+                         "alg_gflop_per_launch": round(r["flops"] / r["launches"] / 1e9, 4),
+                         "alg_mb_per_launch": round(r["bytes"] / r["launches"] / 1e6, 3)}
+                        for name, r in sorted(kprof.items(), key=lambda kv: -kv[1]["kernel_ms"]) if r["launches"]]
+        kernels_us = sum(r["kernel_ms"] for r in kprof.values()) * 1e3 / args.steps if kprof else None
+        r4 = lambda v: None if v is None else round(v, 4)
         out = {
             "metric": wl["metric"],
-            "value": value, "unit": "images/s", "n_gpus": comm.world, "steps": args.steps,
+            "value": value, "unit": "samples/s" if args.workload == "mlp" else "images/s", "n_gpus": comm.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["text"],
                        "global_batch": batch * comm.world, "batch_per_gpu": batch, "parallelism": f"dp{comm.world}",
                        "settle_replays_untimed": settle_replays, "conv_dgrad": args.dgrad, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,
+                       "model": args.model if args.workload == "resnet18" else None,
+                       "launches_per_step": round(sum(r["launches"] for r in kprof.values()) / args.steps, 2) if kprof else None,
+                       "kernel_us_per_step": r4(kernels_us),
+                       # ten timed chunks of further replays of the same captured step (--sustain-ms in all): mean, median, best
+                       "sustained_ms_per_step": r4(sustained["sustained_ms_per_step"]) if sustained else None,
+                       "median_ms_per_step": r4(sustained["median_ms_per_step"]) if sustained else None,
+                       "best_ms_per_step": r4(sustained["best_ms_per_step"]) if sustained else None,
+                       "worst_ms_per_step": r4(sustained["worst_ms_per_step"]) if sustained else None,
+                       "sustained_replays": sustained["replays"] if sustained else None,
+                       "sustained_images_per_s": round(batch * comm.world / (sustained["sustained_ms_per_step"] * 1e-3), 1) if sustained else None,
+                       # the step's contractions: algorithmic flops and the flops the matrix cores execute (PMC), both as a
+                       # fraction of the fp32 matrix peak over ms_per_step
+                       "algorithmic_gflop_per_step": r4(alg_flops / 1e9),
+                       "executed_gflop_per_step": r4(exec_flops / 1e9) if exec_flops else None,
+                       "whole_step_frac_algorithmic": r4(alg_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS),
+                       "whole_step_frac_executed": r4(exec_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS) if exec_flops else None,
+                       f"{other_kind}_model_images_per_s": r4(other_value),
+                       # BASELINE.json configs 2-3 and the accumulate mode, each timed by a child process of this run
+                       # (never the headline)
+                       "other_configurations": others,
                        "allreduce_elems": exchanged,
                        # the exchange step: inside the captured graph or enqueued behind it; gradients the last sync() had to
                        # copy into the bucket (0: every backward kernel wrote its gradient in place)
@@ -710,28 +746,22 @@ def main():
                        "rccl_ranks": rccl_ranks,
                        "collective_library": mod.comm_rccl_path() if sync is not None else None},
             "gpu_ms_per_step": gpu_ms / args.steps, "host_issue_ms_per_step": 1e3 * host_issue / args.steps,
-            # ten timed chunks of further replays of the same captured step (~--sustain-ms in all): mean, median, best
-            "sustained_ms_per_step": sustained["sustained_ms_per_step"] if sustained else None,
-            "median_ms_per_step": sustained["median_ms_per_step"] if sustained else None,
-            "best_ms_per_step": sustained["best_ms_per_step"] if sustained else None,
-            "sustained_images_per_s": (batch * comm.world / (sustained["sustained_ms_per_step"] * 1e-3)) if sustained else None,
-            "sustained": sustained,
             "final_loss": final_loss,
-            "model": args.model if args.workload == "resnet18" else None,
-            f"{other_kind}_images_per_s": other_value,
-            # BASELINE.json configs 2-3 and the accumulate mode, timed in this same run (never the headline)
-            "other_configurations": others,
             "roofline": roofline,
-            "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in
-                        sorted(fams.items(), key=lambda kv: -kv[1]["ms_per_step"])},
-            # per kernel instantiation (names as rocprofv3 prints them): launches per step, the kernel's own duration,
-            # the algorithmic work of the family calls it was the first launch of
-            "kernel_table": [{"kernel": name, "family": r["family"], "launches_per_step": round(r["launches"] / args.steps, 3),
-                              "avg_us": round(r["kernel_ms"] / r["launches"] * 1e3, 3),
-                              "alg_gflop_per_launch": round(r["flops"] / r["launches"] / 1e9, 4),
-                              "alg_mb_per_launch": round(r["bytes"] / r["launches"] / 1e6, 3)}
-                             for name, r in sorted(kprof.items(), key=lambda kv: -kv[1]["kernel_ms"]) if r["launches"]],
         }
+        side = {"kernels": fam_table, "kernel_table": kernel_table, "sustained": sustained}
+        if args.kernels_in_line:
+            out.update(side)
+        else:
+            path = args.kernels_file or os.path.join(ROOT, "gpurun_out", f"bench_kernels_{args.workload}"
+                                                     f"{'_accumulate' if args.dgrad == 'accumulate' else ''}.json")
+            try:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                with open(path, "w") as f:
+                    json.dump(dict(side, metric=wl["metric"], ms_per_step=ms_per_step), f, indent=1)
+                out["kernels_file"] = os.path.relpath(path, ROOT)
+            except OSError as e:
+                out["kernels_file"] = f"not written: {e}"
         if comm.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, batch)
         else:

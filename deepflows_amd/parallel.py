@@ -115,6 +115,17 @@ class RcclCommunicator(Communicator):
         self._mod.comm_destroy()
 
 
+def seed_rank_local(seed, rank):
+    """Rank-local host random numbers of a data-parallel job ("BN running stats and Dropout masks stay rank-local
+    (seed + rank)").  Called AFTER the replicas have been built from the common seed: rank 0 keeps the stream where the
+    initialisation left it -- a job of one rank is the single-GPU run bit for bit --, rank r > 0 continues from
+    np.random.seed(seed + r), so no two ranks draw the same Dropout masks (`nn/modules/dropout.py` reads the global generator,
+    as `DeepFlows/nn/modules/dropout.py:17` does)."""
+    rank = int(rank)
+    if rank > 0:
+        np.random.seed((int(seed) + rank) & 0xFFFFFFFF)
+
+
 def init_communicator(device):
     """Build the communicator for the launch environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as a
     launcher such as torch.distributed.run sets them; the launcher only spawns the processes).  world == 1 needs no

@@ -94,6 +94,92 @@ def test_world2_gloo_matches_averaged_gradients(tmp_path):
         assert np.abs(a - w).max() <= 1e-5 * max(1.0, np.abs(w).max())
 
 
+CNN_WORKER = r'''
+import os, sys, json, hashlib
+import numpy as np
+sys.path.insert(0, os.environ["DF_ROOT"])
+sys.path.insert(0, os.path.join(os.environ["DF_ROOT"], "tests"))
+from deepflows_amd import backend_api, nn, optim, parallel, workloads
+from deepflows_amd.nn.modules import dropout as dropout_mod
+from gloo_communicator import GlooCommunicator
+from deepflows_amd.tensor import Graph, Tensor
+from oracle.numpy_device import NumpyDevice
+
+dev = backend_api.register_device("cpu", NumpyDevice())
+backend_api.set_default_device("cpu")
+comm = GlooCommunicator()
+rank, world = comm.rank, comm.world
+masks = []
+draw = dropout_mod.bernoulli_mask
+def recording(keep, shape):
+    m = draw(keep, shape)
+    masks.append(hashlib.sha256(np.ascontiguousarray(m).tobytes()).hexdigest())
+    return m
+dropout_mod.bernoulli_mask = recording
+np.random.seed(0)                                   # identical replicas ...
+model = workloads.CIFAR10_CNN(10, device=dev)
+model.train()
+opt = optim.Adam(model.parameters(), lr=5e-3, weight_decay=5e-4)
+parallel.seed_rank_local(0, rank)                   # ... rank-local masks (what bench.py's build_job does)
+bucket = parallel.GradientBucket(opt.params, comm)
+opt.grad_scale = 1.0 / world
+rng = np.random.default_rng(1234 + rank)            # rank-local data, as bench.make_batch
+losses = []
+for step in range(3):
+    x = np.clip(rng.standard_normal((4, 3, 32, 32)).astype(np.float32), -1, 1)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 4)]
+    loss, _ = workloads.train_step(model, nn.CrossEntropyLoss(), opt, Tensor(x, device=dev), Tensor(y, device=dev),
+                                   sync=bucket.sync)
+    losses.append(float(loss.numpy()[0]))
+    Graph.free_graph()
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+out = {"rank": rank, "losses": losses, "masks": masks,
+       "params": [sha(p.data.numpy()) for p in model.parameters()],
+       "running": [sha(getattr(bn, k).numpy()) for bn in (model.bn1, model.bn2, model.bn3)
+                   for k in ("running_mean", "running_var")],
+       "finite": bool(all(np.isfinite(p.data.numpy()).all() for p in model.parameters()))}
+json.dump(out, open(os.path.join(os.environ["DF_OUT"], f"cnn_rank{rank}.json"), "w"))
+comm.barrier()
+'''
+
+
+def test_world2_gloo_cnn_batchnorm_and_dropout_stay_rank_local(tmp_path):
+    """SURVEY §8e on the CNN of BASELINE config 3 (BatchNorm + Dropout), two ranks over gloo, three Adam steps with the
+    gradient bucket: the replicas' parameters stay bit-identical (same averaged gradient on both ranks), the BatchNorm running
+    statistics are rank-local (each rank saw its own batches), and the Dropout masks differ between the ranks in every step
+    (parallel.seed_rank_local: the seed + rank rule; VERDICT r5 weak #1)."""
+    script = tmp_path / "cnn_worker.py"
+    script.write_text(CNN_WORKER)
+    env = dict(os.environ, DF_ROOT=ROOT, DF_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    port = 31500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    a, b = [json.load(open(tmp_path / f"cnn_rank{k}.json")) for k in range(2)]
+    assert a["finite"] and b["finite"]
+    assert a["params"] == b["params"], "replicas diverged"
+    assert len(a["masks"]) == 3 and len(b["masks"]) == 3
+    assert all(ma != mb for ma, mb in zip(a["masks"], b["masks"])), "two ranks drew the same Dropout mask"
+    assert all(ra != rb for ra, rb in zip(a["running"], b["running"])), "BatchNorm running statistics are not rank-local"
+    assert a["losses"] != b["losses"]
+
+
+def test_seed_rank_local_keeps_rank0_on_the_single_gpu_stream():
+    sys.path.insert(0, ROOT)
+    from deepflows_amd import parallel
+    np.random.seed(0)
+    np.random.random(5)
+    want = np.random.get_state()[1].copy()
+    parallel.seed_rank_local(0, 0)
+    assert np.array_equal(np.random.get_state()[1], want)
+    parallel.seed_rank_local(0, 3)
+    got3 = np.random.random(4)
+    np.random.seed(3)
+    assert np.array_equal(got3, np.random.random(4))
+
+
 def test_world1_bucket_is_a_noop():
     sys.path.insert(0, ROOT)
     from deepflows_amd import parallel

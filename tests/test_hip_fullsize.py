@@ -46,6 +46,65 @@ def test_conv_layer_full_size(hip_device, name):
     _conv_layer(hip_device, name, N, LAYERS[name])   # (every layer of both benchmarked models at the benchmarked batch)
 
 
+def assert_close_elementwise(got, want, cond, what, tol=1e-5, floor=1e-6):
+    """Every element against ITS OWN scale (under max|a-b| / max|b| a wrong value in a small-magnitude
+    region -- the border taps of a near-zero gradient plane -- passes).  `cond` is the element's condition, the same
+    contraction evaluated on the operands' absolute values (sum_k |a_k| |b_k| >= |want|): an fp32 dot product of K terms in
+    any order is within ~sqrt(K) 6e-8 of it, so |got - want| <= 1e-5 * max(cond, floor * max cond) holds for every correct
+    evaluation whatever cancels inside the element, and a value that is wrong by as little as 1e-5 of its region's magnitude
+    fails -- wherever the region lies (the absolute floor is 1e-6 of the tensor's largest condition)."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    cond = np.asarray(cond, np.float64)
+    scale = np.maximum(cond, floor * cond.max())
+    r = np.abs(got - want) / scale
+    i = np.unravel_index(int(np.argmax(r)), r.shape)
+    assert r[i] <= tol, f"{what}: element {i}: got {got[i]:.6e} want {want[i]:.6e} (condition {cond[i]:.3e}): {r[i]:.3e} > {tol:g}"
+
+
+R18_CONVS = ["stem", "l1", "l2a", "l2", "l2d", "l3a", "l3", "l3d", "l4a", "l4", "l4d"]
+
+
+@pytest.mark.parametrize("name", R18_CONVS)
+def test_conv_layer_full_size_elementwise_with_small_magnitude_regions(hip_device, name):
+    """The eleven ResNet-18 convolution shapes at batch 256 on operands WITH small-magnitude regions (every fourth image
+    x 1e-3, every eighth output channel's filters x 1e-3, the border ring of dY x 1e-3, two source channels x 1e-3), each
+    result checked element by element against its own condition number."""
+    mod = hip_device.mod
+    C, H, W, O, k, s, p = LAYERS[name]
+    n = N
+    oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    rng = np.random.default_rng(17 + len(name) + C + O)
+    x = rng.standard_normal((n, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((O, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+    dy = rng.standard_normal((n, O, oh, ow)).astype(np.float32)
+    small = np.float32(1e-3)
+    x[1::4] *= small
+    x[:, C // 2:C // 2 + 2] *= small
+    w[3::8] *= small
+    dy[2::4] *= small
+    if oh > 2:
+        ring = np.ones((oh, ow), np.float32) * small
+        ring[1:-1, 1:-1] = 1
+        dy *= ring
+    geo = (n, C, H, W, O, k, s, p)
+    xh, wh, dyh = _arr(mod, x), _arr(mod, w), _arr(mod, dy)
+    ax, aw, ady = np.abs(x), np.abs(w), np.abs(dy)
+    yh = mod.Array(n * O * oh * ow)
+    mod.conv2d_forward(xh, wh, None, yh, *geo)
+    assert_close_elementwise(_back(mod, yh, (n, O, oh, ow)), R.conv2d_forward(x, w, None, s, p),
+                             R.conv2d_forward(ax, aw, None, s, p), name + " forward")
+    dwh = mod.Array(w.size)
+    mod.conv2d_wgrad(xh, dyh, dwh, *geo)
+    assert_close_elementwise(_back(mod, dwh, w.shape), R.conv2d_wgrad(x, dy, k, s, p), R.conv2d_wgrad(ax, ady, k, s, p),
+                             name + " wgrad")
+    dxh = mod.Array(x.size)
+    for mode in ("overwrite", "accumulate"):
+        mod.conv2d_dgrad(dyh, wh, dxh, *geo, mode=mode)
+        assert_close_elementwise(_back(mod, dxh, x.shape), R.conv2d_dgrad(dy, w, x.shape, s, p, mode),
+                                 R.conv2d_dgrad(ady, aw, x.shape, s, p, mode), f"{name} dgrad {mode}")
+
+
 def _conv_layer(hip_device, name, n, layer):
     mod = hip_device.mod
     C, H, W, O, k, s, p = layer

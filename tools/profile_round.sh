@@ -34,7 +34,7 @@ one() {   # one <suffix> <workload> <dgrad> [extra bench args]
   f=$(find $OUT/stats$sfx -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && python3 tools/kernel_stats_txt.py $f > $OUT/rocprof_kernel_stats$sfx.txt
   rm -rf $OUT/stats$sfx
-  python3 bench.py --workload $wl --dgrad $dg --pmc-traffic $OUT/pmc_traffic$sfx.json $extra > $OUT/bench$sfx.json 2> $OUT/bench$sfx.err
+  python3 bench.py --workload $wl --dgrad $dg --kernels-in-line --pmc-traffic $OUT/pmc_traffic$sfx.json $extra > $OUT/bench$sfx.json 2> $OUT/bench$sfx.err
   python3 tools/kernel_table.py $OUT/bench$sfx.json $OUT/pmc_traffic$sfx.json $OUT/rocprof_kernel_stats$sfx.txt > $OUT/kernel_table$sfx.md 2>> $OUT/bench$sfx.err
 }
 # CONFIGS="headline accumulate cnn rest" (default: all) picks the configurations; ONLY_HEADLINE=1 is CONFIGS=headline
@@ -45,8 +45,8 @@ has headline && one "" resnet18 overwrite
 has accumulate && one _accumulate resnet18 accumulate --no-cpu-baseline
 has cnn && one _cnn cnn overwrite
 if has rest; then
-python3 bench.py --workload mlp --steps 200 --warmup 20 > $OUT/bench_mlp.json 2> $OUT/bench_mlp.err
-python3 bench.py --workload resnet18_wide --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_wide.json 2> $OUT/bench_wide.err
+python3 bench.py --workload mlp --steps 200 --warmup 20 --kernels-in-line > $OUT/bench_mlp.json 2> $OUT/bench_mlp.err
+python3 bench.py --workload resnet18_wide --steps 10 --warmup 2 --no-cpu-baseline --kernels-in-line > $OUT/bench_wide.json 2> $OUT/bench_wide.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_wide -o s -- python3 bench.py --workload resnet18_wide --steps 5 --warmup 2 --no-cpu-baseline --no-prof-gate --no-other-model > $OUT/stats_wide.log 2>&1
 f=$(find $OUT/stats_wide -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python3 tools/kernel_stats_txt.py $f > $OUT/rocprof_kernel_stats_wide.txt; rm -rf $OUT/stats_wide
 fi
