@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "dfhip_internal.h"
+#include "dfhip_head.h"
 
 using namespace dfhip;
 
@@ -1858,6 +1859,159 @@ __global__ __launch_bounds__(1024) void k_pool_linear_bwd(const float* __restric
   }
 }
 
+// ---- classifier head AND its loss in one launch (training step): y = fc(mean(mean(x, 2), 2)), loss = CE(y, target) -- what
+// test/ResNet_CIFAR10_cuda.py:96-99 + :186 (`criterion(outputs, targets)`) compute with three nodes -- and, because every
+// quantity of the backward pass that belongs to ONE image depends on that image's logits only, d loss / d logits (for the
+// upstream gradient of exactly 1 that loss.backward() seeds, tensor.py:428) and the input gradient dx as well.  A workgroup
+// is an image, a thread walks CPT channels (their pooled values and rows of W stay in registers between the forward and the
+// backward half).  The arithmetic is that of k_pool_linear_fwd, k_ce_small<true> and k_pool_linear_bwd expression by
+// expression.  The loss is the mean of the row losses: the last workgroup to arrive (agent-scope counter) adds them up in
+// the order k_ce_small uses; what is left of the backward pass -- dW, db: sums over the images -- is head_grads_body
+// (dfhip_head.h).  Rounds 1-5: three launches (4.7 + 5.1 + 7.7 us at batch 256) for 2 MB of traffic.
+// IPB images per workgroup (256 threads each).
+template <int P, int CPT, int IPB>
+__global__ __launch_bounds__(256 * IPB) void k_head_ce(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ b, const float* __restrict__ target,
+                                                      float* __restrict__ pooled, float* __restrict__ logits,
+                                                      float* __restrict__ dlogits, float* __restrict__ dx,
+                                                      float* rowloss, float* __restrict__ loss, int N, int C, int HW, int Pn,
+                                                      float scale, float gscale, float inv_rows) {
+  __shared__ float sh[IPB][4][P];
+  __shared__ float slog[IPB][P];
+  const int img = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  const int n = min((int)blockIdx.x * IPB + img, N - 1);        // (an image past the end re-does the last one; nothing of it is stored)
+  const bool live = (int)blockIdx.x * IPB + img < N;
+  float acc[P], pv[CPT], wr[CPT][P];
+#pragma unroll
+  for (int j = 0; j < P; j++) acc[j] = 0.0f;
+  float tv[P];                                     // the target row: requested with the first loads
+#pragma unroll
+  for (int j = 0; j < P; j++) {
+    const float v = target[(int64_t)n * Pn + min(j, Pn - 1)];
+    tv[j] = j < Pn ? v : 0.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < CPT; q++) {
+    const int c = tid + 256 * q, cc = min(c, C - 1);
+    const float* xp = x + ((int64_t)n * C + cc) * HW;
+    float s = 0.0f;
+    if ((HW & 3) == 0) {
+      for (int i = 0; i < HW; i += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(xp + i);
+        s += v.x; s += v.y; s += v.z; s += v.w;
+      }
+    } else {
+      for (int i = 0; i < HW; i++) s += xp[i];
+    }
+    pv[q] = c < C ? s * scale : 0.0f;
+    if (c < C && live) pooled[(int64_t)n * C + c] = pv[q];
+    const float* wp = w + (int64_t)cc * Pn;
+#pragma unroll
+    for (int j = 0; j < P; j++) wr[q][j] = wp[min(j, Pn - 1)];
+#pragma unroll
+    for (int j = 0; j < P; j++) acc[j] = fmaf(pv[q], wr[q][j], acc[j]);
+  }
+  {                                                // head_block_sum per image (its four waves)
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+      float v = acc[j];
+      v = wave_sum(v);
+      if (lane == 0) sh[img][wave][j] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < P; j++) acc[j] = sh[img][0][j] + sh[img][1][j] + sh[img][2][j] + sh[img][3][j];
+  }
+  if (tid < P) {
+    float r = 0.0f;
+#pragma unroll
+    for (int j = 0; j < P; j++)
+      if (j == tid) r = acc[j];
+    const float y = r + ((b && tid < Pn) ? b[tid] : 0.0f);
+    slog[img][tid] = tid < Pn ? y : -INFINITY;
+    if (tid < Pn && live) logits[(int64_t)n * Pn + tid] = y;
+  }
+  __syncthreads();
+  // cross-entropy of the row and d loss / d logits, by every thread (k_ce_small<true>'s expressions)
+  float xv[P];
+#pragma unroll
+  for (int j = 0; j < P; j++) xv[j] = slog[img][j];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < P; j++) m = fmaxf(m, xv[j]);
+  float ex[P], se = 0.0f;
+#pragma unroll
+  for (int j = 0; j < P; j++) {
+    ex[j] = expf(xv[j] - m);
+    if (j < Pn) se += ex[j];
+  }
+  const float lse = logf(se);
+  float row = 0.0f;
+#pragma unroll
+  for (int j = 0; j < P; j++)
+    if (j < Pn) row += -((xv[j] - m) - lse) * tv[j];
+  const float gs = 1.0f * inv_rows;
+  float st = 0.0f;
+#pragma unroll
+  for (int j = 0; j < P; j++)
+    if (j < Pn) st += tv[j];
+  float gu[P], gsum = 0.0f;
+#pragma unroll
+  for (int j = 0; j < P; j++) {
+    gu[j] = gs * tv[j] * -1.0f + ex[j] * ((gs * st) / se);
+    if (j < Pn) gsum += gu[j];
+  }
+  float d[P];
+#pragma unroll
+  for (int j = 0; j < P; j++) d[j] = j < Pn ? gu[j] + (xv[j] == m ? -gsum : 0.0f) : 0.0f;
+  if (tid < Pn && live) {
+    float r = 0.0f;
+#pragma unroll
+    for (int j = 0; j < P; j++)
+      if (j == tid) r = d[j];
+    dlogits[(int64_t)n * Pn + tid] = r;
+  }
+  // the input gradient: dx[n][c][:] = gscale * sum_j d[j] w[c][j] (k_pool_linear_bwd's expressions)
+  if (dx) {
+#pragma unroll
+    for (int q = 0; q < CPT; q++) {
+      const int c = tid + 256 * q;
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < P; j++) s = fmaf(d[j], wr[q][j], s);
+      s *= gscale;
+      if (c < C && live) {
+        float* o = dx + ((int64_t)n * C + c) * HW;
+        if ((HW & 3) == 0) {
+          const float4 v = make_float4(s, s, s, s);
+          for (int i = 0; i < HW; i += 4) *reinterpret_cast<float4*>(o + i) = v;
+        } else {
+          for (int i = 0; i < HW; i++) o[i] = s;
+        }
+      }
+    }
+  }
+  // The loss is the mean of the row losses: a sum over the workgroups.  Built and measured first (round 6): the last
+  // workgroup to arrive adds them up -- a written-through store of the row loss, then a ticket (agent-scope atomics): two
+  // dependent round trips to the memory side at the end of EVERY workgroup, 5.5 -> 10.3 us (12.3 us with a release fence,
+  // which writes the XCD's whole L2 back; 13.1 us with four images per workgroup and a quarter of the tickets).  So the rows
+  // are left as they are and the sum is part of whatever reads them next: head_grads_body in the backward pass (no launch
+  // inside a weight-gradient group), dfhip_loss_finish when the loss is read before that (hip_device.DeferredHipArray).
+  if (tid == 0 && live) rowloss[n] = row;
+}
+
+__global__ __launch_bounds__(256) void k_loss_finish(const float* __restrict__ rowloss, float* __restrict__ loss, int N,
+                                                    float inv_rows) {
+  __shared__ float part[16];
+  loss_finish_body(rowloss, loss, N, inv_rows, part);
+}
+
+__global__ __launch_bounds__(256) void k_head_grads(const HeadGrads h) {
+  __shared__ __attribute__((aligned(16))) float lds[kHeadLdsFloats];
+  head_grads_body(h, (int)blockIdx.x, lds);
+}
+
 int stem_bwd_stats(const float* z, const float* y, const float* g, const float* gamma, const float* beta,
                    const float* mean, const float* var, int N, int C, int H, int W, float eps, const float** partial,
                    int* S_out) {
@@ -1889,6 +2043,15 @@ int stem_pool_apply(const float* sel, int sel_planes, const float* partials, int
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
+
+namespace dfhip {
+int head_grads_launch(const HeadGrads& h) {
+  ProfScope prof("head_grads", 2.0 * h.N * (double)h.C * h.Pn, 4.0 * ((double)h.N * h.C + (double)h.N * h.Pn + (double)h.C * h.Pn));
+  DF_LAUNCH(k_head_grads, dim3((unsigned)head_grads_blocks(h)), dim3(256), 0, stream(), h);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+}  // namespace dfhip
 
 extern "C" {
 
@@ -2284,6 +2447,52 @@ int dfhip_pool_linear_backward(const float* dy, const float* pooled, const float
   DF_LAUNCH(k_pool_linear_bwd<16>, dim3(grid), dim3(1024), 0, stream(), dy, pooled, w, dx, dw, db, N, C, HW, P, gscale);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
+}
+
+int dfhip_head_ce_forward(const float* x, const float* w, const float* b, const float* target, float* pooled,
+                          float* logits, float* loss, float* dlogits, float* dx, float* rowloss, int N, int C, int HW,
+                          int P, float scale, float gscale, int* done) {
+  DF_INIT();
+  DF_CHECK_ARG(done, "head_ce_forward: null done");
+  *done = 0;
+  DF_CHECK_ARG(N > 0 && C > 0 && HW > 0 && P > 0, "head_ce_forward: bad dimensions");
+  DF_CHECK_ARG(x && w && target && pooled && logits && loss && dlogits && rowloss, "head_ce_forward: null array");
+  if (!(P <= 16 && C <= 512 && N <= 4096)) return DFHIP_OK;       // (the caller launches the three nodes)
+  ProfScope prof("head_ce_fwd_bwd", 4.0 * N * (double)C * P,
+                 4.0 * ((dx ? 2.0 : 1.0) * N * (double)C * HW + (double)N * C + (double)C * P + 3.0 * N * P));
+  const float inv_rows = 1.0f / (float)N;
+  constexpr int IPB = 1;
+  const dim3 grid((unsigned)((N + IPB - 1) / IPB));
+  if (C <= 256)
+    DF_LAUNCH((k_head_ce<16, 1, IPB>), grid, dim3(256 * IPB), 0, stream(), x, w, b, target, pooled, logits, dlogits, dx,
+              rowloss, loss, N, C, HW, P, scale, gscale, inv_rows);
+  else
+    DF_LAUNCH((k_head_ce<16, 2, IPB>), grid, dim3(256 * IPB), 0, stream(), x, w, b, target, pooled, logits, dlogits, dx,
+              rowloss, loss, N, C, HW, P, scale, gscale, inv_rows);
+  DF_LAUNCH_CHECK();
+  *done = 1;
+  return DFHIP_OK;
+}
+
+int dfhip_loss_finish(const float* rowloss, float* loss, int N) {
+  DF_INIT();
+  DF_CHECK_ARG(rowloss && loss && N > 0, "loss_finish: bad arguments");
+  ProfScope prof("loss_finish", 0.0, 4.0 * N);
+  DF_LAUNCH(k_loss_finish, dim3(1), dim3(256), 0, stream(), rowloss, loss, N, 1.0f / (float)N);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+int dfhip_head_grads(const float* dlogits, const float* pooled, float* dw, float* db, const float* rowloss, float* loss,
+                     int N, int C, int P) {
+  DF_INIT_KEEP();
+  DF_TOUCH(dw); DF_TOUCH(db); DF_TOUCH(loss);
+  DF_CHECK_ARG(N > 0 && C > 0 && P > 0 && P <= dfhip::kHeadP, "head_grads: bad dimensions (P <= 16)");
+  DF_CHECK_ARG(dlogits && pooled && (!loss || rowloss), "head_grads: null array");
+  if (!dw && !db && !loss) return DFHIP_OK;
+  dfhip::HeadGrads h = {dlogits, pooled, dw, db, rowloss, loss, 1.0f / (float)N, N, C, P};
+  if (dfhip::head_grads_defer(h)) return DFHIP_OK;      // extra workgroups of the open group's slab-sum launch
+  return dfhip::head_grads_launch(h);
 }
 
 int dfhip_softmax_ce_backward(const float* logits, const float* target, const float* gloss,

@@ -14,6 +14,7 @@
 #include "dfhip_internal.h"
 #include "dfhip_bnbwd.h"
 #include "dfhip_stem_combine.h"
+#include "dfhip_head.h"
 
 using namespace dfhip;
 
@@ -1511,6 +1512,8 @@ struct SGroup {
   SlabSum s[kMaxGroup];
   int stem_blocks;              // the first workgroups of the launch: the stem's one-pass backward, last step (dfhip_stem_combine.h)
   StemCombine stem;
+  int head_blocks;              // then the classifier head's sums over the images (dfhip_head.h)
+  HeadGrads head;
 };
 
 // Row-unit weight gradient with the operands straight from global memory (grouped launches, channel
@@ -1996,7 +1999,12 @@ __global__ __launch_bounds__(256) void k_wgrad_group_sum(SGroup a) {
     stem_combine_body(a.stem, (int)blockIdx.x);
     return;
   }
-  const int b = (int)blockIdx.x - a.stem_blocks;
+  if ((int)blockIdx.x < a.stem_blocks + a.head_blocks) {
+    static_assert(sizeof(part) >= kHeadLdsFloats * sizeof(float), "the head's sums fit the slab sum's LDS");
+    head_grads_body(a.head, (int)blockIdx.x - a.stem_blocks, reinterpret_cast<float*>(part));
+    return;
+  }
+  const int b = (int)blockIdx.x - a.stem_blocks - a.head_blocks;
   int li = 0, hi = a.n - 1;                          // the first layer with b < vb_end[li] (ascending: a binary search)
   while (li < hi) {
     const int mid = (li + hi) >> 1;
@@ -2346,6 +2354,7 @@ struct GQueued {
 std::vector<GQueued> g_queue;
 bool g_group_on = false;
 struct StemPending { bool active = false; StemCombine c; int blocks = 0; } g_stem_pending;
+struct HeadPending { bool active = false; HeadGrads h; } g_head_pending;
 int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
                    int k, int stride, int pad, const float* aff = nullptr, const float* bnz = nullptr,
                    const float* bntab = nullptr);
@@ -2586,8 +2595,14 @@ int group_flush() {
         g_stem_pending.active = false;
         sbytes += 4.0 * (double)sg.stem.splits * (2.0 * sg.stem.O * sg.stem.KK + 3.0 * sg.stem.O + sg.stem.KK);
       }
+      if (g_head_pending.active && !g_group_stream && i0 + kMaxGroup >= q.size()) {
+        sg.head = g_head_pending.h;
+        sg.head_blocks = head_grads_blocks(sg.head);
+        g_head_pending.active = false;
+        sbytes += 4.0 * ((double)sg.head.N * sg.head.C + (double)sg.head.N * sg.head.Pn + (double)sg.head.C * sg.head.Pn);
+      }
       ProfScope prof("wgrad_slab_sum", 0.0, sbytes);
-      DF_LAUNCH(k_wgrad_group_sum, dim3((unsigned)(vbs + sg.stem_blocks)), dim3(256), 0, gst, sg);
+      DF_LAUNCH(k_wgrad_group_sum, dim3((unsigned)(vbs + sg.stem_blocks + sg.head_blocks)), dim3(256), 0, gst, sg);
       DF_LAUNCH_CHECK();
     }
   }
@@ -2979,6 +2994,11 @@ int flush_deferred() {
     int st = stem_combine_launch(g_stem_pending.c, g_stem_pending.blocks);
     if (st != DFHIP_OK) return st;
   }
+  if (g_head_pending.active) {                      // no grouped slab sum took them along
+    g_head_pending.active = false;
+    int st = head_grads_launch(g_head_pending.h);
+    if (st != DFHIP_OK) return st;
+  }
   if (!g_side_pending.empty()) {
     int st = side_join();
     if (st != DFHIP_OK) return st;
@@ -2996,6 +3016,13 @@ bool deferred_touches(const void* p) {
     auto in = [&](const float* lo, int64_t n) { return lo && q >= lo && q < lo + n; };
     if (in(c.dw, (int64_t)c.O * c.KK) || in(c.dgamma, c.O) || in(c.dbeta, c.O) || in(c.dbias, c.O) || p == c.slabs) return true;
   }
+  if (g_head_pending.active) {
+    const HeadGrads& h = g_head_pending.h;
+    const float* q = (const float*)p;
+    auto in = [&](const float* lo, int64_t n) { return lo && q >= lo && q < lo + n; };
+    if (in(h.dw, (int64_t)h.C * h.Pn) || in(h.db, h.Pn) || in(h.dl, (int64_t)h.N * h.Pn) || in(h.pooled, (int64_t)h.N * h.C) ||
+        in(h.loss, 1) || in(h.rowloss, h.N)) return true;
+  }
   for (const auto& sp : g_side_pending)              // a gradient in flight on the side stream: join first
     for (const auto& r : sp.dws)
       if ((const float*)p >= r.first && (const float*)p < r.second) return true;
@@ -3009,6 +3036,14 @@ bool deferred_touches(const void* p) {
 int deferred_scratch_slot() { return g_def.active ? g_def.slot : -1; }
 bool group_collecting() { return g_group_on && !g_queue.empty() && !g_group_stream && g_side_pending.empty(); }
 bool stem_combine_pending() { return g_stem_pending.active; }
+bool head_grads_defer(const HeadGrads& h) {
+  // (the head's backward is the FIRST node of a sweep: the group is open, nothing is queued yet; dfhip_wgrad_group_end flushes
+  // what the group left behind)
+  if (!g_group_on || g_group_stream || !g_side_pending.empty() || g_head_pending.active || overlap_cus()) return false;
+  g_head_pending.h = h;
+  g_head_pending.active = true;
+  return true;
+}
 bool stem_combine_defer(const StemCombine& c, int blocks) {
   if (!group_collecting() || g_stem_pending.active) return false;
   g_stem_pending.c = c;

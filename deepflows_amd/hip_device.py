@@ -52,6 +52,47 @@ class HipArray:
         return f"HipArray(size={self.size}, ptr=0x{(self.ptr or 0):x})"
 
 
+class DeferredHipArray(HipArray):
+    """A device array whose contents one more step has to complete: `finish` (a callable that enqueues that step) runs the
+    first time anything asks for the array's address -- every use of an array goes through `.ptr` -- unless whoever owes the
+    step has delivered it meanwhile (`settled()`).  Used for the loss of the fused classifier head: its launch leaves row
+    losses, their mean is added up by the backward pass's slab-sum launch, or by one small launch when the loss is read
+    first (dfhip_head_ce_forward in include/dfhip.h says why the launch itself does not finish it).  `.raw_ptr` is the
+    address without that side effect (for the launches that WRITE the array)."""
+
+    __slots__ = ("_raw", "_finish")
+
+    def __init__(self, size, lib):
+        self._finish = None
+        HipArray.__init__(self, size, lib)
+
+    @property
+    def ptr(self):
+        f = self._finish
+        if f is not None:
+            self._finish = None
+            f()
+        return self._raw
+
+    @ptr.setter
+    def ptr(self, value):
+        self._raw = value
+
+    @property
+    def raw_ptr(self):
+        return self._raw
+
+    def owe(self, finish):
+        self._finish = finish
+
+    def settled(self):
+        self._finish = None
+
+    def __del__(self):
+        self._finish = None                         # (nothing is launched for an array nobody will read)
+        HipArray.__del__(self)
+
+
 def _dims(seq):
     n = len(seq)
     return n, (c_int64 * max(n, 1))(*[int(v) for v in seq])
@@ -541,6 +582,31 @@ class HipModule:
         g = lambda h: h.ptr if h is not None else None
         _lib.check(self._lib.dfhip_pool_linear_backward(dy.ptr, pooled.ptr, w.ptr, g(dx), g(dw), g(db), N, C, HW, P,
                                                         float(gscale)))
+
+    def head_ce_forward(self, x, w, b, target, pooled, logits, loss, dlogits, dx, rowloss, N, C, HW, P, scale, gscale):
+        """classifier head + cross-entropy + everything of their backward pass that belongs to one image, one launch; False
+        when the shape is outside the kernel (nothing was launched)"""
+        done = ctypes.c_int(0)
+        g = lambda h: h.ptr if h is not None else None
+        _lib.check(self._lib.dfhip_head_ce_forward(x.ptr, w.ptr, g(b), target.ptr, pooled.ptr, logits.ptr,
+                                                   getattr(loss, "raw_ptr", None) or loss.ptr,
+                                                   dlogits.ptr, g(dx), rowloss.ptr, N, C, HW, P, float(scale), float(gscale),
+                                                   ctypes.byref(done)))
+        return bool(done.value)
+
+    def head_grads(self, dlogits, pooled, dw, db, N, C, P, rowloss=None, loss=None):
+        """the sums over the images of the head's backward pass; with (rowloss, loss) also the mean of the row losses"""
+        g = lambda h: h.ptr if h is not None else None
+        raw = lambda h: None if h is None else getattr(h, "raw_ptr", None) or h.ptr
+        _lib.check(self._lib.dfhip_head_grads(dlogits.ptr, pooled.ptr, g(dw), g(db), g(rowloss), raw(loss), N, C, P))
+        if loss is not None and hasattr(loss, "settled"):
+            loss.settled()
+
+    def deferred_array(self, size):
+        return DeferredHipArray(size, self._lib)
+
+    def loss_finish(self, rowloss, loss, N):
+        _lib.check(self._lib.dfhip_loss_finish(rowloss.ptr, getattr(loss, "raw_ptr", None) or loss.ptr, N))
 
     def softmax_ce_backward(self, logits, target, gloss, dlogits, rows, cols):
         _lib.check(self._lib.dfhip_softmax_ce_backward(logits.ptr, target.ptr, gloss.ptr, dlogits.ptr,

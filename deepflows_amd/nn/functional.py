@@ -375,7 +375,14 @@ class _CrossEntropyFused(_FusedNode):
         return out
 
 
+_lazy_head_ce = None       # nn/lazy.py: cross_entropy(fc(mean(mean(x, 2), 2)), target) as one launch, or None
+
+
 def cross_entropy(input: Tensor, target: Tensor, reduction: str = 'mean', dim: int = 1):
+    if _lazy_head_ce is not None and reduction == 'mean' and dim == 1:
+        loss = _lazy_head_ce(input, target)
+        if loss is not None:
+            return loss
     input = realize(input)
     if (_fused(input) and reduction == 'mean' and dim == 1 and input.ndim == 2
             and not target.requires_grad):
@@ -702,6 +709,88 @@ class _PoolLinearFused(_FusedNode):
             self._grads = (grad, dx, dw, db)
         _, dx, dw, db = self._grads
         return dx if node is self.x else (dw if node is self.w else db)
+
+
+class _HeadLogits(_FusedNode):
+    """The logits of `head_ce_train`: the node _PoolLinearFused would be, its arrays filled by the head + loss launch.  When the
+    gradient that arrives is the d loss / d logits that launch left behind (nothing else used the logits), the input gradient
+    is the one it left behind too and only the sums over the images (dW, db) remain -- extra workgroups of the sweep's grouped
+    slab sum on the hip device (dfhip_head_grads), a launch otherwise; any other gradient takes _PoolLinearFused's launch."""
+
+    def __init__(self, x, w, b, wd, pooled, out, dl, dx, rowloss, loss):
+        self.x, self.w, self.b, self.wd, self.pooled = x, w, b, wd, pooled
+        self.rowloss, self.loss = rowloss, loss
+        N, C, H, W = (int(v) for v in x.shape)
+        self.geo = (N, C, H * W, int(w.shape[1]))
+        self.dl_pre, self.dx_pre = dl, dx
+        self._grads = None
+        super().__init__(out, [x, w, b])
+
+    def grad_fn(self, node, grad):
+        if self._grads is None or self._grads[0] is not grad:
+            N, C, HW, P = self.geo
+            dev = grad.device
+            dw = _grad_out(self.w, self.wd.shape, dev) if self.w.requires_grad else None
+            db = _grad_out(self.b, self.b.shape, dev) if (self.b is not None and self.b.requires_grad) else None
+            h = lambda t: t._handle if t is not None else None
+            if grad is self.dl_pre and (self.dx_pre is not None or not self.x.requires_grad):
+                dx = self.dx_pre
+                # (dW, db and the mean of the row losses: extra workgroups of the sweep's slab sum inside a group)
+                dev.head_grads(self.dl_pre._handle, self.pooled._handle, h(dw), h(db), N, C, P,
+                               self.rowloss._handle, self.loss._handle)
+            else:
+                dx = _new(self.x.shape, dev) if self.x.requires_grad else None
+                dev.pool_linear_backward(grad.compact()._handle, self.pooled._handle, self.wd._handle, h(dx), h(dw), h(db),
+                                         N, C, HW, P, 1.0 / float(HW))
+            self._grads = (grad, dx, dw, db)
+        _, dx, dw, db = self._grads
+        return dx if node is self.x else (dw if node is self.w else db)
+
+
+class _HeadCELoss(_FusedNode):
+    """The loss of `head_ce_train`: the node _CrossEntropyFused would be, with d loss / d logits for the unit seed on file."""
+
+    def __init__(self, logits, ld, td, out, dl):
+        self.ld, self.td, self.unit_grad = ld, td, dl
+        super().__init__(out, [logits])
+
+    grad_fn = _CrossEntropyFused.grad_fn
+
+
+def head_ce_train(x: Tensor, fc, target: Tensor):
+    """criterion(fc(mean(mean(x, 2), 2)), target) with CrossEntropyLoss -- the end of the forward pass of
+    test/ResNet_CIFAR10_cuda.py (:96-99, :186) -- as ONE launch that also leaves d loss / d logits and the head's input
+    gradient behind (everything of the backward pass that belongs to one image; dfhip_head_ce_forward).  Returns
+    (logits node, loss node) -- the two nodes the unfused calls would have put on the tape, so that whatever else reads
+    the logits differentiates correctly -- or None when the device has no such kernel for the shape."""
+    x = realize(x)
+    mod = x.device.mod
+    if not (_fused(x) and len(x.shape) == 4 and hasattr(mod, "head_ce_forward") and is_grad_enable() and x.requires_grad
+            and not target.requires_grad and target.ndim == 2 and int(fc.weight.shape[1]) <= 16
+            and int(fc.weight.shape[0]) == int(x.shape[1]) and int(target.shape[0]) == int(x.shape[0])
+            and int(target.shape[1]) == int(fc.weight.shape[1]) and target.device == x.device):
+        return None
+    N, C, H, W = (int(v) for v in x.shape)
+    P = int(fc.weight.shape[1])
+    dev = x.device
+    w, b = fc.weight, fc.bias
+    wd = w.data.compact()
+    td = target.data.compact()
+    pooled, out, dl = _new((N, C), dev), _new((N, P), dev), _new((N, P), dev)
+    rowloss, dx = _new((N,), dev), _new(x.shape, dev)
+    # the loss is the mean of the row losses the launch leaves behind: added up by the backward pass (head_grads), or by a
+    # launch of its own if somebody reads it first -- the array says so (hip_device.DeferredHipArray)
+    loss_arr = mod.deferred_array(1)
+    loss = BackendTensor.make((1,), device=dev, handle=loss_arr)
+    scale = 1.0 / (float(N * C * H * W) * float(N * C * W))
+    if not dev.head_ce_forward(x.data.compact()._handle, wd._handle, b.data.compact()._handle if b is not None else None,
+                               td._handle, pooled._handle, out._handle, loss._handle, dl._handle, dx._handle, rowloss._handle,
+                               N, C, H * W, P, scale, 1.0 / float(H * W)):
+        return None
+    rl = rowloss._handle
+    loss_arr.owe(lambda: mod.loss_finish(rl, loss_arr, N))
+    logits = _HeadLogits(x, w, b, wd, pooled, out, dl, dx, rowloss, loss)
+    return logits, _HeadCELoss(logits, out, td, loss, dl)
 
 
 def mean_hw_linear(x: Tensor, fc) -> Tensor:

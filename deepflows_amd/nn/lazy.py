@@ -24,7 +24,9 @@ Recorded forms (x0 a real tensor):
     relu(bn(conv(x0)))                         "relu"
     mean(x0, axis=2), mean(mean(x0, 2), 2)     "mean2", "meanhw"
     fc(x0), x0 two-dimensional                 "linear"
-Completing calls: MaxPool2d(relu(bn(conv(x0)))), bn(conv(bn(conv(x0)))) + identity, Linear(meanhw(x0)), F.relu(fc(x0)).
+    fc(mean(mean(x0, 2), 2))                   "head"      (the classifier head; launched as one node when touched)
+Completing calls: MaxPool2d(relu(bn(conv(x0)))), bn(conv(bn(conv(x0)))) + identity, F.relu(fc(x0)),
+CrossEntropyLoss(head) (round 6: head + loss + the per-image half of their backward pass from one launch).
 A record is single-shot: when a fused launch has run the BatchNorm of a record it did not hand out (`bn1` applied on conv2's
 loads, `bn2` inside the block's tail, the stem's BatchNorm), whoever still holds the record and touches it later gets the same
 values from a normalisation that does NOT update running_mean / running_var a second time (the reference calls each module
@@ -39,6 +41,7 @@ from ..tensor import LazyTensor, Tensor, realize
 from . import functional as F
 
 ENABLED = os.environ.get("DF_LAZY_MODULES", "1") != "0"
+HEAD_CE = os.environ.get("DF_HEAD_CE", "1") != "0"      # head + CrossEntropyLoss from one launch (0: the three nodes of rounds 1-5)
 
 
 def _state(x):
@@ -144,7 +147,10 @@ def linear(module, x):
     """Linear.forward: on mean(mean(x0, 2), 2) the classifier head as one node; on a 2-D tensor of a fused device the call is
     recorded (an F.relu may follow: one node for both); None = the module launches F.linear"""
     if _is(x, "meanhw"):
-        return F.mean_hw_linear(realize(_state(x)[1]), module)
+        x0 = realize(_state(x)[1])
+        if HEAD_CE and F._fused(x0) and hasattr(x0.device.mod, "head_ce_forward") and int(module.weight.shape[1]) <= 16:
+            return LazyTensor("head", x0, module)          # (a CrossEntropyLoss may complete it: head + loss in one launch)
+        return F.mean_hw_linear(x0, module)
     if ENABLED and is_grad_enable() and _state(x) is None:
         xr = realize(x)
         if isinstance(xr, Tensor) and F._fused(xr) and len(xr.shape) == 2 and hasattr(xr.device.mod, "linear_relu_forward"):
@@ -186,6 +192,8 @@ def _force(lz):
         return module.forward(realize(x))
     if op == "linear":
         return F.linear(realize(x), module.weight, module.bias)
+    if op == "head":
+        return F.mean_hw_linear(realize(x), module)
     if op == "relu":
         return F.relu(realize(x))
     if op == "mean2":
@@ -259,5 +267,32 @@ def _block_tail(out_l, identity):
     return out
 
 
+def head(x, module):
+    """fc(mean(mean(x, 2), 2)) for a model that calls the fused head itself (workloads.ResNet18): recorded like the module
+    calls, so that the criterion can complete it"""
+    x = realize(x)
+    if (ENABLED and HEAD_CE and is_grad_enable() and F._fused(x) and hasattr(x.device.mod, "head_ce_forward")
+            and len(x.shape) == 4 and int(module.weight.shape[1]) <= 16):
+        return LazyTensor("head", x, module)
+    return F.mean_hw_linear(x, module)
+
+
+def _head_ce(logits, target):
+    """F.cross_entropy on a recorded classifier head: head + loss (+ the per-image half of their backward pass) from one
+    launch; the record then holds the logits node.  None = not that form."""
+    if not _is(logits, "head"):
+        return None
+    st = object.__getattribute__(logits, "_lz")
+    tgt = realize(target)
+    if not isinstance(tgt, Tensor):
+        return None
+    both = F.head_ce_train(st[1], st[2], tgt)
+    if both is None:
+        return None
+    st[4] = both[0]
+    return both[1]
+
+
 tensor._lazy_hooks.update({"force": _force, "add": _add, "mean": _mean})
 F._lazy_relu = relu
+F._lazy_head_ce = _head_ce

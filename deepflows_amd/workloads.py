@@ -202,8 +202,8 @@ class ResNet(nn.Module):
         for blk in self.layer4:
             x = blk(x)
         # mean(axis=2) twice (each divides by the TOTAL element count), then the classifier: one node on
-        # the hip device
-        return nn.functional.mean_hw_linear(x, self.fc)
+        # the hip device -- recorded, so that a CrossEntropyLoss can complete it (head + loss from one launch, nn/lazy.py)
+        return nn.lazy.head(x, self.fc)
 
 
 # ---- the other convolutional models of the example scripts -----------------------

@@ -420,6 +420,30 @@ int dfhip_pool_linear_forward(const float* x, const float* w, const float* b, fl
 int dfhip_pool_linear_backward(const float* dy, const float* pooled, const float* w, float* dx, float* dw,
                                float* db, int N, int C, int HW, int P, float gscale);
 
+/* The classifier head AND its loss from one launch (training step): logits (N, P) as dfhip_pool_linear_forward,
+ * loss (1) = cross-entropy(logits, target) as dfhip_softmax_ce_forward (nn/functional.py:104-115: stable log-softmax x dense
+ * target, sum / N), dlogits (N, P) as dfhip_softmax_ce_forward_grad (upstream gradient exactly 1, tensor.py:428) and
+ * dx (N, C, HW or NULL) = gscale * (dlogits . w^T) broadcast over the pixels as dfhip_pool_linear_backward -- everything of
+ * test/ResNet_CIFAR10_cuda.py:96-99 + :186 and of its backward pass that belongs to ONE image; pooled (N, C) is kept.
+ * The loss is a sum over the workgroups: the launch leaves the N row losses in `rowloss`, and loss[0] is NOT valid until
+ * dfhip_head_grads (the backward pass: no launch inside a weight-gradient group) or dfhip_loss_finish (one small launch: a
+ * reader that comes first) has added them up in dfhip_softmax_ce_forward's order -- an arrival counter inside the launch
+ * costs every workgroup two round trips to the memory side (measured: 5.5 -> 10.3 us).  *done = 0 and nothing launched
+ * when the shape is outside the kernel (P <= 16, C <= 512, N <= 4096): the caller runs the three entry points above. */
+int dfhip_head_ce_forward(const float* x, const float* w, const float* b, const float* target, float* pooled,
+                          float* logits, float* loss, float* dlogits, float* dx, float* rowloss, int N, int C, int HW,
+                          int P, float scale, float gscale, int* done);
+
+/* dw (C, P) = pooled^T . dlogits (tensor.py:716), db (P) = column sums of dlogits (tensor.py:462-483); either may be NULL.
+ * rowloss / loss (or NULL, NULL): also the mean of the row losses (see dfhip_head_ce_forward).
+ * Between dfhip_wgrad_group_begin and _end the sums are extra workgroups of the group's slab-sum launch (no launch of their
+ * own; the input arrays must stay alive until dfhip_wgrad_group_end returns), otherwise one launch. */
+int dfhip_head_grads(const float* dlogits, const float* pooled, float* dw, float* db, const float* rowloss, float* loss,
+                     int N, int C, int P);
+
+/* loss[0] = (sum of the N row losses of dfhip_head_ce_forward) / N, dfhip_softmax_ce_forward's order of additions. */
+int dfhip_loss_finish(const float* rowloss, float* loss, int N);
+
 /* Sum `src` over the axes in which dst_shape is 1 (or missing leading axes): replaces
  * the host un-broadcast of tensor.py:462-483.  Shapes are right-aligned.                */
 int dfhip_reduce_to_shape(const float* src, float* dst, int src_ndim, const int64_t* src_shape,

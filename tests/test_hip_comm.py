@@ -184,7 +184,7 @@ def test_bench_exchange_path_runs_on_one_gpu():
     from conftest import ROOT
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", DF_FORCE_COMM="1", DF_FORCE_SYNC="1",
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 1000))
-    code = ("import sys, runpy; sys.argv = ['bench.py', '--steps', '3', '--warmup', '2', '--no-cpu-baseline']; "
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--steps', '3', '--warmup', '2', '--no-cpu-baseline', '--kernels-in-line', '--sustain-ms', '0']; "
             "runpy.run_path(%r, run_name='__main__'); assert 'torch' not in sys.modules, 'torch was imported'"
             % os.path.join(ROOT, "bench.py"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)

@@ -90,8 +90,12 @@ CASES = {
                                   # + 3 for the pairs of a block with one; the eight BatchNorms that stand between two
                                   # convolutions are applied on the second one's loads, and its workgroups add up the first
                                   # one's partial rows themselves: no launch)
-                                  "bn2d_fwd": 8, "bn_relu_pool_fwd": 1, "pool_linear_fwd": 1,
-                                  "pool_linear_bwd": 1, "softmax_ce_fwd": 1, "adam_step": 1}),
+                                  # (round 6: the classifier head, the loss and the per-image half of their backward pass are
+                                  # ONE launch; dW_fc, db_fc and the mean of the row losses ride on the slab sum: the three
+                                  # families of rounds 1-5 -- pool_linear_fwd, softmax_ce_fwd, pool_linear_bwd -- must not run)
+                                  "bn2d_fwd": 8, "bn_relu_pool_fwd": 1, "head_ce_fwd_bwd": 1, "wgrad_slab_sum": 1,
+                                  "pool_linear_fwd": None, "pool_linear_bwd": None, "softmax_ce_fwd": None,
+                                  "head_grads": None, "loss_finish": None, "adam_step": 1}),
     "cnn_bs256_overwrite": ("cnn", 256, "overwrite", {"adam_step": 1}),
     "resnet18_bs128_accumulate": ("resnet18", 128, "accumulate", {"conv2d_wgrad_grouped": 1, "adam_step": 1}),
 }

@@ -24,3 +24,12 @@ timeit("bwd dx only", lambda: mod.pool_linear_backward(dy, pooled, w, dx, None, 
 timeit("bwd dw only", lambda: mod.pool_linear_backward(dy, pooled, w, None, dw, None, N, C, HW, P, 0.25))
 timeit("bwd db only", lambda: mod.pool_linear_backward(dy, pooled, w, None, None, db, N, C, HW, P, 0.25))
 timeit("bwd none", lambda: mod.pool_linear_backward(dy, pooled, w, None, None, None, N, C, HW, P, 0.25))
+# round 6: head + loss (+ the per-image half of their backward pass) from one launch, and the sums over the images
+if hasattr(mod, "head_ce_forward"):
+    tgt = mod.Array(N * P); mod.from_numpy(np.eye(P, dtype=np.float32)[rng.integers(0, P, N)], tgt)
+    loss, dl, rowloss = mod.Array(1), mod.Array(N * P), mod.Array(N)
+    timeit("head_ce (one launch)", lambda: mod.head_ce_forward(x, w, b, tgt, pooled, y, loss, dl, dx, rowloss, N, C, HW, P, 1e-3, 0.25))
+    timeit("head_ce without dx", lambda: mod.head_ce_forward(x, w, b, tgt, pooled, y, loss, dl, None, rowloss, N, C, HW, P, 1e-3, 0.25))
+    timeit("head_grads (own launch)", lambda: mod.head_grads(dl, pooled, dw, db, N, C, P))
+    timeit("ce fwd+grad (old)", lambda: mod.softmax_ce_forward_grad(y, tgt, loss, dl, N, P))
+    print("loss", mod.to_numpy(loss, (1,), (1,), 0))
