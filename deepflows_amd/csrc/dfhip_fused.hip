@@ -1623,15 +1623,30 @@ __device__ __forceinline__ void sgd_block(const TensorBatch& tb, const SgdHyper&
   float* p = tb.p[t];
   const float* g = tb.g[t];
   float* mb = tb.s1[t];
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+  // (a block's 16 elements per thread are requested together: a plain loop was 16 dependent round trips -- 6.9 us for the
+  // perceptron's 0.2 M parameters, most of it latency)
+  constexpr int U = kChunk / kThreads;
+  float gv[U], pv[U], mv[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t i = min(lo + threadIdx.x + (int64_t)u * kThreads, hi - 1);
+    gv[u] = g[i];
+    pv[u] = p[i];
+    mv[u] = h.use_momentum ? mb[i] : 0.0f;
+  }
+  asm volatile("" ::: "memory");                   // (a compiler barrier: the selection DAG sinks plain loads to their uses)
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t i = lo + threadIdx.x + (int64_t)u * kThreads;
+    if (i >= hi) break;
     // optim/sgd.py:16-24
-    float gi = g[i];
+    float gi = gv[u];
     if (h.gscale != 1.0f) gi = gi * h.gscale;
-    float pi = p[i];
+    const float pi = pv[u];
     gi = gi + pi * h.wd;
     float upd = gi;
     if (h.use_momentum) {
-      float vi = mb[i] * h.mu + gi;
+      const float vi = mv[u] * h.mu + gi;
       mb[i] = vi;
       upd = h.nesterov ? gi + h.mu * vi : vi;
     }
@@ -2009,7 +2024,7 @@ __global__ __launch_bounds__(256) void k_loss_finish(const float* __restrict__ r
 
 __global__ __launch_bounds__(256) void k_head_grads(const HeadGrads h) {
   __shared__ __attribute__((aligned(16))) float lds[kHeadLdsFloats];
-  head_grads_body(h, (int)blockIdx.x, lds);
+  head_grads_body<false>(h, (int)blockIdx.x, lds);
 }
 
 int stem_bwd_stats(const float* z, const float* y, const float* g, const float* gamma, const float* beta,

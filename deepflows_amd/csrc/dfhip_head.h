@@ -20,7 +20,7 @@ struct HeadGrads {
   int N, C, Pn;
 };
 constexpr int kHeadP = 16;                         // compile-time bound of Pn
-constexpr int kHeadLdsFloats = 256 * kHeadP + 3 * 64 * kHeadP;
+constexpr int kHeadLdsFloats = 256 * kHeadP;
 __host__ __device__ inline int head_grads_blocks(const HeadGrads& h) { return (h.C + 63) / 64; }
 
 // host side (dfhip_wgrad.hip): hand the sums to the slab-sum launch of the weight-gradient group that is open; false = no
@@ -49,13 +49,19 @@ __device__ __forceinline__ float head_wave_sum(float v) {
 __device__ __forceinline__ void loss_finish_body(const float* __restrict__ rowloss, float* __restrict__ loss, int N,
                                                  float inv_rows, float* part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the four rows of a thread's first pass are requested together: one round trip, not four)
+  float tot[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int r = 64 * (4 * wave + k) + lane;
+    tot[k] = rowloss[min(r, N - 1)] * (r < N ? 1.0f : 0.0f);
+  }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int W16 = 4 * wave + k;
-    float tot = 0.0f;
-    for (int r = 64 * W16 + lane; r < N; r += 1024) tot += rowloss[r];
-    tot = head_wave_sum(tot);
-    if (lane == 0) part[W16] = tot;
+    for (int r = 64 * W16 + lane + 1024; r < N; r += 1024) tot[k] += rowloss[r];
+    const float t = head_wave_sum(tot[k]);
+    if (lane == 0) part[W16] = t;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -66,25 +72,28 @@ __device__ __forceinline__ void loss_finish_body(const float* __restrict__ rowlo
   }
 }
 
-// 256 threads; block `blk` owns the 64 channels blk * 64 + lane; its four waves take every fourth image (a row of pooled is
-// read coalesced over the channels, 16 rows in flight per wave), the rows of dlogits wait in LDS; the waves meet through LDS
-// in the order 0, 1, 2, 3.  Block 0 also forms db (thread j: the images in order).  A fixed order of additions: the same bits
-// in every run, inside a group or not.  lds: kHeadLdsFloats floats.
+// 256 threads; block `blk` owns the 64 channels [64 blk, 64 blk + 64), a wave sixteen of them: dW tile (16 channels x 16
+// classes) += A (16 channels x 4 images) . B (4 images x 16 classes) with v_mfma_f32_16x16x4 -- A is pooled^T (lane: channel
+// lane % 16 of image 4 s + lane / 16; a chunk's 64 operands are requested up front), B the rows of dlogits out of LDS (256
+// images at a time, zero rows past the end of a ragged chunk).  A wave holds ALL images of its channels: no sum across waves
+// or workgroups.  (Round 6, first form: a thread per channel and 16 multiply-adds per image out of LDS -- 1 024 dependent
+// fmas per thread, 3.8 us of a 8.6 us launch.)  Block 0 also forms db (thread j: the images in four chains), the last block
+// the loss.  A fixed order of additions: the same bits in every run, inside a group or not.  lds: kHeadLdsFloats floats.
+// LEAN (inside k_wgrad_group_sum: the body must stay below the slab sum's own registers): 32 operands in flight, not 64.
+template <bool LEAN>
 __device__ __forceinline__ void head_grads_body(const HeadGrads& h, int blk, float* lds) {
+  typedef float f32x4h __attribute__((ext_vector_type(4)));
   constexpr int P = kHeadP;
   if (blk == head_grads_blocks(h) - 1 && h.loss) { // (the block with the fewest channels also finishes the loss)
     loss_finish_body(h.rowloss, h.loss, h.N, h.inv_rows, lds);
     __syncthreads();
   }
   float* sdy = lds;                                // [256][P]
-  float* shw = lds + 256 * P;                      // [3][64][P]
-  // (the wave index as a scalar: the row offsets of the 64 images below are then scalar arithmetic, not 64 vector registers
-  // of loop-invariant addresses -- the first build held 416 registers)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = blk * 64 + lane, cc = min(c, h.C - 1);
-  float acc[P];
-#pragma unroll
-  for (int j = 0; j < P; j++) acc[j] = 0.0f;
+  const int i = lane & 15, kk = lane >> 4;
+  const int c0 = blk * 64 + wave * 16;
+  const int cc = min(c0 + i, h.C - 1);
+  f32x4h acc = {0.0f, 0.0f, 0.0f, 0.0f};
   float dbv = 0.0f;
   for (int n0 = 0; n0 < h.N; n0 += 256) {
     const int nb = min(256, h.N - n0);
@@ -92,68 +101,49 @@ __device__ __forceinline__ void head_grads_body(const HeadGrads& h, int blk, flo
     float stg[P];
 #pragma unroll
     for (int j = 0; j < P; j++) {
+      // (times 0 / 1, not a select: under a condition the compiler sinks each load into a branch of its own -- sixteen
+      // dependent round trips)
       const float v = h.dl[(int64_t)(n0 + min(tid, nb - 1)) * h.Pn + min(j, h.Pn - 1)];
-      stg[j] = (tid < nb && j < h.Pn) ? v : 0.0f;
+      stg[j] = v * ((tid < nb && j < h.Pn) ? 1.0f : 0.0f);
     }
+    const float* base = h.pooled + (int64_t)n0 * h.C + cc;
+    constexpr int RS = LEAN ? 32 : 64;             // operands per round
+    float av[RS];
+#pragma unroll
+    for (int s2 = 0; s2 < RS; s2++) av[s2] = base[(int64_t)min(4 * s2 + kk, nb - 1) * h.C];
+    asm volatile("" ::: "memory");                 // (a compiler barrier: the selection DAG sinks plain loads to their uses)
 #pragma unroll
     for (int j = 0; j < P; j++) sdy[tid * P + j] = stg[j];
-    if (nb == 256) {
-      // a full chunk: the wave's 64 images in four rounds of 16 rows of pooled, one round ahead.  The round loop is a real
-      // loop over a walking pointer (unrolled, the 64 row addresses became loop invariants held in registers: 416 of them in
-      // the first build), and only two images' LDS reads are in flight: inside k_wgrad_group_sum this body must stay below
-      // the slab sum's own registers, or the whole launch drops to one wave per SIMD
-      const float* rp = h.pooled + (int64_t)(n0 + wave) * h.C + cc;
-      const int64_t step = (int64_t)4 * h.C;
-      float pa[16], pb[16];
-#pragma unroll
-      for (int u = 0; u < 16; u++) pa[u] = rp[u * step];
-      __syncthreads();
+    __syncthreads();
 #pragma unroll 1
-      for (int r = 0; r < 4; r++) {
-        rp += 16 * step;
-        if (r < 3) {
+    for (int r = 0; r < 64 / RS; r++) {
+      if (r > 0) {
 #pragma unroll
-          for (int u = 0; u < 16; u++) pb[u] = rp[u * step];
-        }
-        const float4* g = reinterpret_cast<const float4*>(sdy + (wave + 64 * r) * P);
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-#pragma unroll
-          for (int q = 0; q < P / 4; q++) {
-            const float4 gv = g[(4 * u) * (P / 4) + q];
-            acc[4 * q] = fmaf(pa[u], gv.x, acc[4 * q]); acc[4 * q + 1] = fmaf(pa[u], gv.y, acc[4 * q + 1]);
-            acc[4 * q + 2] = fmaf(pa[u], gv.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(pa[u], gv.w, acc[4 * q + 3]);
-          }
-          if (u & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int u = 0; u < 16; u++) pa[u] = pb[u];
+        for (int s2 = 0; s2 < RS; s2++) av[s2] = base[(int64_t)min(4 * (RS * r + s2) + kk, nb - 1) * h.C];
+        asm volatile("" ::: "memory");
       }
-    } else {
-      __syncthreads();
-      for (int n = wave; n < nb; n += 4) {             // a ragged chunk: image by image
-        const float pv = h.pooled[(int64_t)(n0 + n) * h.C + cc];
 #pragma unroll
-        for (int j = 0; j < P; j++) acc[j] = fmaf(pv, sdy[n * P + j], acc[j]);
-      }
+      for (int s2 = 0; s2 < RS; s2++)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], sdy[(4 * (RS * r + s2) + kk) * P + i], acc, 0, 0, 0);
     }
     if (blk == 0 && h.db && tid < h.Pn) {
-      for (int n = 0; n < nb; n++) dbv += sdy[n * P + tid];
+      // (sixteen LDS reads in flight, four chains: one read per trip of a plain loop was 256 dependent round trips)
+      float c4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int n = 0; n < 256; n += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = sdy[(n + u) * P + tid];       // (rows past nb hold zeros)
+#pragma unroll
+        for (int u = 0; u < 16; u++) c4[u & 3] += v[u];
+      }
+      dbv += (c4[0] + c4[1]) + (c4[2] + c4[3]);
     }
   }
-  if (wave >= 1) {
+  // lane holds dW[c0 + 4 kk + v][i]
+  if (h.dw && i < h.Pn) {
 #pragma unroll
-    for (int j = 0; j < P; j++) shw[((wave - 1) * 64 + lane) * P + j] = acc[j];
-  }
-  __syncthreads();
-  if (wave == 0 && c < h.C && h.dw) {
-#pragma unroll
-    for (int j = 0; j < P; j++) {
-      float r = acc[j];
-#pragma unroll
-      for (int w2 = 0; w2 < 3; w2++) r += shw[(w2 * 64 + lane) * P + j];
-      if (j < h.Pn) h.dw[(int64_t)c * h.Pn + j] = r;
-    }
+    for (int v = 0; v < 4; v++)
+      if (c0 + 4 * kk + v < h.C) h.dw[(int64_t)(c0 + 4 * kk + v) * h.Pn + i] = acc[v];
   }
   if (blk == 0 && h.db && tid < h.Pn) h.db[tid] = dbv;
 }

@@ -2001,7 +2001,7 @@ __global__ __launch_bounds__(256) void k_wgrad_group_sum(SGroup a) {
   }
   if ((int)blockIdx.x < a.stem_blocks + a.head_blocks) {
     static_assert(sizeof(part) >= kHeadLdsFloats * sizeof(float), "the head's sums fit the slab sum's LDS");
-    head_grads_body(a.head, (int)blockIdx.x - a.stem_blocks, reinterpret_cast<float*>(part));
+    head_grads_body<true>(a.head, (int)blockIdx.x - a.stem_blocks, reinterpret_cast<float*>(part));
     return;
   }
   const int b = (int)blockIdx.x - a.stem_blocks - a.head_blocks;

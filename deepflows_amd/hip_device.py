@@ -602,6 +602,23 @@ class HipModule:
         if loss is not None and hasattr(loss, "settled"):
             loss.settled()
 
+    def mlp2_ce_forward(self, x, w1, b1, w2, b2, target, zpre, h, logits, dlogits, dz1, rowloss, M, K, HD, P):
+        """fc1 -> relu -> fc2 -> cross-entropy and the per-row half of their backward pass, one launch; False when the shape
+        is outside the kernel (nothing was launched)"""
+        done = ctypes.c_int(0)
+        g = lambda a: a.ptr if a is not None else None
+        _lib.check(self._lib.dfhip_mlp2_ce_forward(x.ptr, w1.ptr, g(b1), w2.ptr, g(b2), target.ptr, g(zpre), h.ptr, logits.ptr,
+                                                   dlogits.ptr, dz1.ptr, rowloss.ptr, M, K, HD, P, ctypes.byref(done)))
+        return bool(done.value)
+
+    def mlp2_ce_backward(self, x, h, dz1, dlogits, dw1, db1, dw2, db2, rowloss, loss, M, K, HD, P):
+        g = lambda a: a.ptr if a is not None else None
+        raw = lambda a: None if a is None else getattr(a, "raw_ptr", None) or a.ptr
+        _lib.check(self._lib.dfhip_mlp2_ce_backward(x.ptr, h.ptr, dz1.ptr, dlogits.ptr, dw1.ptr, g(db1), dw2.ptr, g(db2),
+                                                    g(rowloss), raw(loss), M, K, HD, P))
+        if loss is not None and hasattr(loss, "settled"):
+            loss.settled()
+
     def deferred_array(self, size):
         return DeferredHipArray(size, self._lib)
 

@@ -292,6 +292,92 @@ class _LinearReluFused(_FusedNode):
 
 
 
+class _MlpHidden(_LinearReluFused):
+    """relu(fc1(x)) of `mlp2_ce_train`: the node _LinearReluFused would be, its arrays filled by the fused forward launch.  When
+    the gradient that arrives is the one the fused backward launch was given (d loss / d pre-activation, handed over by
+    _MlpLogits), the layer's parameter gradients are the ones that launch formed; any other gradient takes the ordinary
+    backward launch."""
+    _pre = None                # (dz1 BackendTensor, dW1, db1)
+
+    def grad_fn(self, node, grad):
+        if self._pre is not None and grad is self._pre[0]:
+            return self._pre[1] if node is self.w else (self._pre[2] if node is self.b else None)
+        return super().grad_fn(node, grad)
+
+
+class _MlpLogits(_LinearFused):
+    """fc2(h) of `mlp2_ce_train`.  When the gradient that arrives is the d loss / d logits of the fused forward launch and
+    nothing else reads h, ONE launch forms every parameter gradient of both layers (dW1, db1, dW2, db2) and finishes the
+    loss (dfhip_mlp2_ce_backward); h's node is then handed d loss / d pre-activation, which it recognises."""
+
+    def grad_fn(self, node, grad):
+        hn = self.x
+        if self._grads is not None and self._grads[0] is grad:
+            _, dx, dw2, db2 = self._grads
+            return dx if node is self.x else (dw2 if node is self.w else db2)
+        if (grad is self.dl_pre and isinstance(hn, _MlpHidden) and len(hn.children) == 1 and hn.children[0] is self
+                and hn.grad is None and not hn.x.requires_grad):
+            if self._grads is None or self._grads[0] is not grad:
+                dev = grad.device
+                xd, w1d, _z = hn._saved
+                hd, w2d = self._saved
+                M, K = (int(v) for v in xd.shape)
+                HD, P = (int(v) for v in w2d.shape)
+                dw1 = _grad_out(hn.w, (K, HD), dev)
+                db1 = _grad_out(hn.b, hn.b.shape, dev) if (hn.b is not None and hn.b.requires_grad) else None
+                dw2 = _grad_out(self.w, (HD, P), dev)
+                db2 = _grad_out(self.b, self.b.shape, dev) if (self.b is not None and self.b.requires_grad) else None
+                hh = lambda t: t._handle if t is not None else None
+                dev.mlp2_ce_backward(xd._handle, hd._handle, self.dz1_pre._handle, self.dl_pre._handle, dw1._handle, hh(db1),
+                                     dw2._handle, hh(db2), self.rowloss._handle, self.loss._handle, M, K, HD, P)
+                hn._pre = (self.dz1_pre, dw1, db1)
+                self._grads = (grad, self.dz1_pre, dw2, db2)
+            _, dz1, dw2, db2 = self._grads
+            return dz1 if node is self.x else (dw2 if node is self.w else db2)
+        return super().grad_fn(node, grad)
+
+
+def mlp2_ce_train(x: Tensor, fc1, fc2, target: Tensor):
+    """criterion(fc2(F.relu(fc1(x))), target) with CrossEntropyLoss -- the forward pass of test/MLP_MNIST_cuda.py:44-59 -- as
+    ONE launch that also leaves d loss / d logits and d loss / d (fc1 output) behind (dfhip_mlp2_ce_forward).  Returns the
+    three nodes the unfused calls would have put on the tape (relu(fc1(x)), the logits, the loss) or None when the device has
+    no such kernel for the shapes."""
+    x = realize(x)
+    mod = x.device.mod
+    w1, b1, w2, b2 = fc1.weight, fc1.bias, fc2.weight, fc2.bias
+    if not (_fused(x) and x.ndim == 2 and hasattr(mod, "mlp2_ce_forward") and is_grad_enable() and not x.requires_grad
+            and w1.requires_grad and w2.requires_grad and not target.requires_grad and target.ndim == 2
+            and int(w1.shape[0]) == int(x.shape[1]) and int(w2.shape[0]) == int(w1.shape[1])
+            and tuple(int(v) for v in target.shape) == (int(x.shape[0]), int(w2.shape[1])) and target.device == x.device):
+        return None
+    M, K = (int(v) for v in x.shape)
+    HD, P = (int(v) for v in w2.shape)
+    dev = x.device
+    xd, w1d, w2d, td = x.data.compact(), w1.data.compact(), w2.data.compact(), target.data.compact()
+    z, h, dz1 = _new((M, HD), dev), _new((M, HD), dev), _new((M, HD), dev)
+    out, dl, rowloss = _new((M, P), dev), _new((M, P), dev), _new((M,), dev)
+    hb = lambda t: t.data.compact()._handle if t is not None else None
+    if not dev.mlp2_ce_forward(xd._handle, w1d._handle, hb(b1), w2d._handle, hb(b2), td._handle, z._handle, h._handle,
+                               out._handle, dl._handle, dz1._handle, rowloss._handle, M, K, HD, P):
+        return None
+    loss_arr = mod.deferred_array(1)
+    loss = BackendTensor.make((1,), device=dev, handle=loss_arr)
+    rl = rowloss._handle
+    loss_arr.owe(lambda: mod.loss_finish(rl, loss_arr, M))
+    hn = _MlpHidden.__new__(_MlpHidden)
+    hn.x, hn.w, hn.b = x, w1, b1
+    hn._saved = (xd, w1d, z)
+    hn._grads = None
+    _FusedNode.__init__(hn, h, [x, w1, b1])
+    ln = _MlpLogits.__new__(_MlpLogits)
+    ln.x, ln.w, ln.b = hn, w2, b2
+    ln._saved = (h, w2d)
+    ln._grads = None
+    ln.dl_pre, ln.dz1_pre, ln.rowloss, ln.loss = dl, dz1, rowloss, loss
+    _FusedNode.__init__(ln, out, [hn, w2, b2])
+    return hn, ln, _HeadCELoss(ln, out, td, loss, dl)
+
+
 def linear_relu(input: Tensor, weight: Tensor, bias=None):
     """F.relu(F.linear(input, weight, bias)); one node on a fused device when the layer is small enough for the
     one-launch kernels."""

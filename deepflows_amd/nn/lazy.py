@@ -25,6 +25,7 @@ Recorded forms (x0 a real tensor):
     mean(x0, axis=2), mean(mean(x0, 2), 2)     "mean2", "meanhw"
     fc(x0), x0 two-dimensional                 "linear"
     fc(mean(mean(x0, 2), 2))                   "head"      (the classifier head; launched as one node when touched)
+    relu(fc(x0)), fc2(relu(fc1(x0)))           "linrelu", "mlp2"   (test/MLP_MNIST_cuda.py:51-54)
 Completing calls: MaxPool2d(relu(bn(conv(x0)))), bn(conv(bn(conv(x0)))) + identity, F.relu(fc(x0)),
 CrossEntropyLoss(head) (round 6: head + loss + the per-image half of their backward pass from one launch).
 A record is single-shot: when a fused launch has run the BatchNorm of a record it did not hand out (`bn1` applied on conv2's
@@ -41,6 +42,7 @@ from ..tensor import LazyTensor, Tensor, realize
 from . import functional as F
 
 ENABLED = os.environ.get("DF_LAZY_MODULES", "1") != "0"
+MLP_CE = os.environ.get("DF_MLP_CE", "1") != "0"        # fc2(relu(fc1(x))) + CrossEntropyLoss: one launch each way (0: five launches)
 HEAD_CE = os.environ.get("DF_HEAD_CE", "1") != "0"      # head + CrossEntropyLoss from one launch (0: the three nodes of rounds 1-5)
 
 
@@ -116,8 +118,12 @@ def relu(x):
         return LazyTensor("relu", x)
     if _is(x, "linear"):
         st = _state(x)
+        x0 = realize(st[1])
+        if MLP_CE and hasattr(x0.device.mod, "mlp2_ce_forward") and not x0.requires_grad:
+            # (a second Linear and a CrossEntropyLoss may complete it: the whole perceptron's step as one launch each way)
+            return LazyTensor("linrelu", x)
         # (the recorded fc(x) itself stays recorded: whoever still holds it and touches it later launches the plain Linear)
-        return F.linear_relu(realize(st[1]), st[2].weight, st[2].bias)
+        return F.linear_relu(x0, st[2].weight, st[2].bias)
     return None
 
 
@@ -146,6 +152,8 @@ def max_pool2d(module, x):
 def linear(module, x):
     """Linear.forward: on mean(mean(x0, 2), 2) the classifier head as one node; on a 2-D tensor of a fused device the call is
     recorded (an F.relu may follow: one node for both); None = the module launches F.linear"""
+    if _is(x, "linrelu") and _state(_state(x)[1]) is not None:
+        return LazyTensor("mlp2", x, module)               # fc2(relu(fc1(x0))), nothing of it launched yet
     if _is(x, "meanhw"):
         x0 = realize(_state(x)[1])
         if HEAD_CE and F._fused(x0) and hasattr(x0.device.mod, "head_ce_forward") and int(module.weight.shape[1]) <= 16:
@@ -194,6 +202,13 @@ def _force(lz):
         return F.linear(realize(x), module.weight, module.bias)
     if op == "head":
         return F.mean_hw_linear(realize(x), module)
+    if op == "linrelu":
+        lin = _state(x)
+        if lin is not None:                                # relu(fc(x0)) as one node (test/MLP_MNIST_cuda.py:51-52)
+            return F.linear_relu(realize(lin[1]), lin[2].weight, lin[2].bias)
+        return F.relu(realize(x))                          # (somebody has launched the Linear meanwhile)
+    if op == "mlp2":
+        return F.linear(realize(x), module.weight, module.bias)
     if op == "relu":
         return F.relu(realize(x))
     if op == "mean2":
@@ -280,6 +295,8 @@ def head(x, module):
 def _head_ce(logits, target):
     """F.cross_entropy on a recorded classifier head: head + loss (+ the per-image half of their backward pass) from one
     launch; the record then holds the logits node.  None = not that form."""
+    if _is(logits, "mlp2"):
+        return _mlp2_ce(logits, target)
     if not _is(logits, "head"):
         return None
     st = object.__getattribute__(logits, "_lz")
@@ -291,6 +308,27 @@ def _head_ce(logits, target):
         return None
     st[4] = both[0]
     return both[1]
+
+
+def _mlp2_ce(logits, target):
+    """CrossEntropyLoss on fc2(relu(fc1(x0))) with nothing of it launched: forward + the per-row half of the backward pass
+    from one launch; the records then hold the nodes.  None = not that form."""
+    st2 = object.__getattribute__(logits, "_lz")
+    hid = st2[1]
+    if not _is(hid, "linrelu"):
+        return None
+    sth = object.__getattribute__(hid, "_lz")
+    lin = _state(sth[1])
+    if lin is None:
+        return None
+    tgt = realize(target)
+    if not isinstance(tgt, Tensor):
+        return None
+    nodes = F.mlp2_ce_train(lin[1], lin[2], st2[2], tgt)
+    if nodes is None:
+        return None
+    sth[4], st2[4] = nodes[0], nodes[1]
+    return nodes[2]
 
 
 tensor._lazy_hooks.update({"force": _force, "add": _add, "mean": _mean})

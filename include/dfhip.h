@@ -444,6 +444,23 @@ int dfhip_head_grads(const float* dlogits, const float* pooled, float* dw, float
 /* loss[0] = (sum of the N row losses of dfhip_head_ce_forward) / N, dfhip_softmax_ce_forward's order of additions. */
 int dfhip_loss_finish(const float* rowloss, float* loss, int N);
 
+/* A two-layer perceptron's training step, one launch each way (test/MLP_MNIST_cuda.py:37-59: fc1 -> F.relu -> fc2, then
+ * CrossEntropyLoss; BASELINE.json config 2).  Forward: zpre (M, HD or NULL) = x (M, K) . w1 (K, HD) + b1 (HD or NULL), h = relu(zpre)
+ * (nn/functional.py:8-16), logits (M, P) = h . w2 (HD, P) + b2 (P or NULL), the row losses of cross_entropy(logits, target)
+ * (nn/functional.py:104-115) in rowloss (M), dlogits (M, P) for an upstream gradient of exactly 1 (tensor.py:428) and
+ * dz1 (M, HD) = d loss / d (x . w1 + b1) = (dlogits . w2^T) where relu's output equals its input (tensor.py:872-877: also
+ * at 0) -- everything of both passes that belongs to one row of the batch.  *done = 0 and nothing launched when the shape
+ * is outside the kernel (K % 16 == 0, HD in {64, 128, 256}, P <= 16, M <= 4096).
+ * Backward: dw1 (K, HD) = x^T . dz1, dw2 (HD, P) = h^T . dlogits (tensor.py:716), db1 (HD or NULL) / db2 (P or NULL) =
+ * column sums of dz1 / dlogits (tensor.py:462-483), and loss[0] (or NULL) = the mean of the row losses in
+ * dfhip_softmax_ce_forward's order.  x needs no gradient on this path (the caller takes the per-layer entry points if it
+ * does). */
+int dfhip_mlp2_ce_forward(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                          const float* target, float* zpre, float* h, float* logits, float* dlogits, float* dz1,
+                          float* rowloss, int M, int K, int HD, int P, int* done);
+int dfhip_mlp2_ce_backward(const float* x, const float* h, const float* dz1, const float* dlogits, float* dw1, float* db1,
+                           float* dw2, float* db2, const float* rowloss, float* loss, int M, int K, int HD, int P);
+
 /* Sum `src` over the axes in which dst_shape is 1 (or missing leading axes): replaces
  * the host un-broadcast of tensor.py:462-483.  Shapes are right-aligned.                */
 int dfhip_reduce_to_shape(const float* src, float* dst, int src_ndim, const int64_t* src_shape,
