@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (matrix)
+PEAK_MFMA_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 (families named *_bf16: the opt-in weight-gradient mode)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak
 
 # families whose roofline is HBM bandwidth although they run MFMAs: the reference-exact ("overwrite") input
@@ -101,8 +102,10 @@ def build_job(workload, dev, rank, batch, register_blocks=True, model_kind="plai
     return model, opt, crit, Tensor(x, device=dev), Tensor(y, device=dev)
 
 
-OTHER_CONFIGURATIONS = (("cnn_cifar10_bs256", "cnn", "overwrite"), ("mlp_mnist_bs128", "mlp", "overwrite"),
-                        ("resnet18_bs256_accumulate_dgrad", "resnet18", "accumulate"))
+OTHER_CONFIGURATIONS = (("cnn_cifar10_bs256", "cnn", "overwrite", "f32"), ("mlp_mnist_bs128", "mlp", "overwrite", "f32"),
+                        ("resnet18_bs256_accumulate_dgrad", "resnet18", "accumulate", "f32"),
+                        # opt-in reduced precision: bf16 operands in the weight gradients' matrix products
+                        ("resnet18_bs256_bf16_weight_gradients", "resnet18", "overwrite", "bf16"))
 
 
 def other_configurations(steps, timeout_s=150.0):
@@ -113,9 +116,10 @@ def other_configurations(steps, timeout_s=150.0):
     fault, abort or hang in one of them costs that entry (reported as `error`) and nothing else.  The child runs
     `--steps` timed replays of its captured step and the per-family event pass; what comes back is its JSON line."""
     out = {}
-    for name, wl, dgrad in OTHER_CONFIGURATIONS:
+    for name, wl, dgrad, mm in OTHER_CONFIGURATIONS:
         k = steps if wl != "mlp" else max(steps, 200)
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--dgrad", dgrad, "--steps", str(k), "--warmup", "3",
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--dgrad", dgrad, "--matmul-dtype", mm,
+               "--steps", str(k), "--warmup", "3",
                "--no-cpu-baseline", "--no-other-configs", "--no-other-model", "--sustain-ms", "0", "--settle-ms", "100"]
         env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         t = time.perf_counter()
@@ -129,7 +133,7 @@ def other_configurations(steps, timeout_s=150.0):
             rf = d.get("roofline") or {}
             out[name] = {"value": d["value"], "unit": "samples/s" if wl == "mlp" else "images/s",
                          "ms_per_step": d["ms_per_step"], "steps": d["steps"], "final_loss": d.get("final_loss"),
-                         "conv_dgrad": dgrad, "dispatch": d["config"].get("dispatch"),
+                         "conv_dgrad": dgrad, "conv_matmul_dtype": mm, "dispatch": d["config"].get("dispatch"),
                          "dominant_family": rf.get("kernel"), "roofline_bound": rf.get("bound"),
                          "roofline_frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us"),
                          "launches_per_step": d["config"].get("launches_per_step"),
@@ -263,7 +267,8 @@ def family_rooflines(prof, steps):
         if r["flops"] > 0:
             ent["tflops"] = r["flops"] / r["calls"] / avg_s / 1e12
         if r["flops"] > 0 and name not in HBM_BOUND_FAMILIES:
-            ent["bound"], ent["frac"] = "mfma", ent["tflops"] / PEAK_MFMA_F32_TFLOPS
+            peak = PEAK_MFMA_BF16_TFLOPS if name.endswith("_bf16") else PEAK_MFMA_F32_TFLOPS
+            ent["bound"], ent["frac"], ent["peak_tflops"] = "mfma", ent["tflops"] / peak, peak
         else:
             ent["bound"], ent["frac"] = "hbm", ent["gbs"] / PEAK_HBM_GBS
             if "tflops" in ent:                 # executed flops of an HBM-bound MFMA family, for the record
@@ -369,6 +374,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's own)")
     ap.add_argument("--dgrad", choices=["overwrite", "accumulate"], default="overwrite",
                     help="conv input-gradient mode: reference-exact (default) or mathematically correct")
+    ap.add_argument("--matmul-dtype", choices=["f32", "bf16"], default="f32",
+                    help="opt-in (never the headline, outside the 1e-4 parity contract): bf16 operands with fp32 accumulation in "
+                         "the convolution weight gradients' matrix products (HipModule.conv_matmul_dtype)")
     ap.add_argument("--registration", choices=["all", "f6"], default="all",
                     help="all = every block registered (62 tensors); f6 = the reference script's 5 tensors")
     ap.add_argument("--model", choices=["plain", "fused"], default="plain",
@@ -438,6 +446,7 @@ def main():
     dev = backend_api.Device("hip")            # raises when the extension / GPU is missing
     mod = dev.mod
     mod.conv_dgrad_mode = args.dgrad
+    mod.conv_matmul_dtype = args.matmul_dtype
     comm = parallel.init_communicator(dev)
     model, opt, crit, xt, yt = build_job(args.workload, dev, rank, batch, register_blocks=(args.registration == "all"),
                                          model_kind=args.model)
@@ -638,7 +647,7 @@ def main():
         clock_mhz = probe_tflops = None
     comm.barrier()
     others = None
-    if (args.workload == "resnet18" and args.dgrad == "overwrite" and comm.world == 1 and sync is None and captured is not None
+    if (args.workload == "resnet18" and args.dgrad == "overwrite" and args.matmul_dtype == "f32" and comm.world == 1 and sync is None and captured is not None
             and not profiled_run and not args.no_other_configs and not args.no_other_model):
         try:
             others = other_configurations(args.steps)
@@ -654,7 +663,7 @@ def main():
         if dom:
             d = fams[dom]
             if d["bound"] == "mfma":
-                roofline = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": PEAK_MFMA_F32_TFLOPS,
+                roofline = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": d.get("peak_tflops", PEAK_MFMA_F32_TFLOPS),
                             "unit": "TFLOP/s", "frac": d["frac"], "traffic": None}
             else:
                 roofline = {"kernel": dom, "bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS,
@@ -710,10 +719,10 @@ def main():
             "metric": wl["metric"],
             "value": value, "unit": "samples/s" if args.workload == "mlp" else "images/s", "n_gpus": comm.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.matmul_dtype == "f32" else "bf16 operands / f32 accumulation in the weight gradients, f32 elsewhere", "data": "synthetic",
             "config": {"workload": wl["text"],
                        "global_batch": batch * comm.world, "batch_per_gpu": batch, "parallelism": f"dp{comm.world}",
-                       "settle_replays_untimed": settle_replays, "conv_dgrad": args.dgrad, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,
+                       "settle_replays_untimed": settle_replays, "conv_dgrad": args.dgrad, "conv_matmul_dtype": args.matmul_dtype, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,
                        "model": args.model if args.workload == "resnet18" else None,
                        "launches_per_step": round(sum(r["launches"] for r in kprof.values()) / args.steps, 2) if kprof else None,
                        "kernel_us_per_step": r4(kernels_us),

@@ -107,6 +107,8 @@ _SIGS = {
     "dfhip_head_ce_forward": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P],
     "dfhip_head_grads": [P, P, P, P, P, P, c_int, c_int, c_int],
     "dfhip_loss_finish": [P, P, c_int],
+    "dfhip_set_conv_matmul_dtype": [c_int],
+    "dfhip_conv_matmul_dtype": [],
     "dfhip_mlp2_ce_forward": [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "dfhip_mlp2_ce_backward": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int],
     "dfhip_reduce_to_shape": [P, P, c_int, I64P, c_int, I64P],

@@ -1727,6 +1727,10 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
   // computes and then mostly discards; the family is bound by its bytes, not by the matrix cores.
   double flops = mode == 0 ? 2.0 * N * H * W * (double)C * O : 2.0 * N * oh * ow * (double)C * k * k * O;
   double bytes = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * k * k + (double)N * O * oh * ow);
+  // the BatchNorm-backward forms read more (round 6: the per-kernel table booked 19.6 MB for a launch that reads 42): z of the
+  // pending BatchNorm under the dY operand, the inputs of the layers whose row sums the launch leaves behind, the rows
+  if (bi) bytes += 4.0 * ((double)N * O * oh * ow + (double)bi->nrows * O * bi->K);
+  if (so) bytes += 4.0 * so->n * (double)N * C * H * W;
   ProfScope prof(mode == 0 ? "conv2d_dgrad_overwrite_igemm" : "conv2d_dgrad_igemm", flops, bytes);
   Geo g = {};
   g.src = dy; g.wgt = w;
@@ -1797,7 +1801,10 @@ static int dgrad_pair_overwrite(const float* dy, const float* w, const float* dy
     return DFHIP_OK;
   }
   const double flops = 2.0 * N * H * W * (double)C * O + 2.0 * N * oh * ow * (double)C * O;
-  const double bytes = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * oh * ow);
+  double bytes = 4.0 * ((double)N * C * H * W * (add ? 2 : 1) + (double)O * C * 10 + 2.0 * N * O * oh * ow);
+  if (bi) bytes += 4.0 * ((double)N * O * oh * ow + (double)bi->nrows * O * bi->K);
+  if (bi2) bytes += 4.0 * ((double)N * O * oh * ow + (double)bi2->nrows * O * bi2->K);
+  if (so) bytes += 4.0 * so->n * (double)N * C * H * W;
   ProfScope prof("conv2d_dgrad_overwrite_igemm", flops, bytes);
   const int st = run_dgrad_ow_pair(dy, w, dy2, w2, add, dx, N, C, H, W, O, bi, bi2, so);
   if (st < 0) { set_error("conv2d_dgrad_pair: the shape test and the kernel's own disagree"); return DFHIP_RUNTIME_ERROR; }

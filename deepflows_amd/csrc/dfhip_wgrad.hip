@@ -1586,9 +1586,17 @@ struct WgUnit {
 // BN: dY (and the shortcut's dY) are gradients of BatchNorm outputs whose backward pass is applied here, on the operand: a lane
 // is an output channel, so the channel's (A, B, mean, Cc) are four registers; the BatchNorm input z arrives through pieces of
 // its own (same offsets as dY) and a row of dY becomes A dy + B (z - mean) + Cc when the MFMAs first reach it.
-template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP, bool PAIR, bool BN>
+// BF (opt-in, dfhip_set_conv_matmul_dtype(1); outside the 1e-4 parity contract): the contraction on v_mfma_f32_32x32x8_bf16
+// -- fp32 accumulators, the operands rounded to bf16 (nearest even) as they are packed.  The fp32 body multiplies one pixel
+// of the image pair per instruction (K = 2: the two images of the lane halves); four consecutive pixels of a row are the
+// bf16 instruction's K = 8, and in its operand layout lane half h supplies k = 4 h .. 4 h + 3 -- exactly the four values that
+// lane already holds for those four pixels.  So nothing about the loads or the registers changes: four fp32 operands are
+// packed into two registers and ONE instruction of 32 cycles replaces four of 64.  A column outside the image is a zero
+// operand (the fp32 body skips the instruction).
+template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP, bool PAIR, bool BN, bool BF = false>
 __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, const int bx, const int by,
                                                   const int bz) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   static_assert(!PAIR || (KS == 3 && STRIDE == 2 && PAD == 1), "the shortcut rides on the 3x3 / stride-2 body");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1760,6 +1768,39 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
 #pragma unroll
             for (int cc = 0; cc < W; cc++) c.b[p][ur * STRIDE + i][cc] = fmaf(c.b[p][ur * STRIDE + i][cc], aff_sc, aff_sh);
           }
+          if constexpr (BF && OW % 4 == 0) {
+#pragma unroll
+            for (int s4 = 0; s4 < OW; s4 += 4) {
+              const int it0 = ((p * UR + ur) * KS + i) * OW + s4;
+#pragma unroll
+              for (int k = (it0 * NPIECE + NIT - 1) / NIT; k < ((it0 + 4) * NPIECE + NIT - 1) / NIT; k++) piece(n, nu, k);
+              __builtin_amdgcn_sched_barrier(0);
+              if (rowok) {
+                const bf16x4 pa = {(__bf16)c.a[p][ur][s4], (__bf16)c.a[p][ur][s4 + 1], (__bf16)c.a[p][ur][s4 + 2],
+                                   (__bf16)c.a[p][ur][s4 + 3]};
+#pragma unroll
+                for (int j = 0; j < KS; j++) {
+                  float bv[4];
+#pragma unroll
+                  for (int e = 0; e < 4; e++) {
+                    const int col = (s4 + e) * STRIDE + j - PAD;
+                    bv[e] = (col >= 0 && col < W) ? c.b[p][ur * STRIDE + i][col >= 0 && col < W ? col : 0] : 0.0f;
+                  }
+                  const bf16x4 pb = {(__bf16)bv[0], (__bf16)bv[1], (__bf16)bv[2], (__bf16)bv[3]};
+                  acc[i * KS + j] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(pa, pb, acc[i * KS + j], 0, 0, 0);
+                }
+                if constexpr (PAIR) {                        // the centre tap's pixels (row 2 (r + ur), columns 2 s: always inside)
+                  if (i == 1) {
+                    const bf16x4 pa2 = {(__bf16)c.a2[p][ur][s4], (__bf16)c.a2[p][ur][s4 + 1], (__bf16)c.a2[p][ur][s4 + 2],
+                                        (__bf16)c.a2[p][ur][s4 + 3]};
+                    const bf16x4 pb2 = {(__bf16)c.b[p][ur * STRIDE + 1][2 * s4], (__bf16)c.b[p][ur * STRIDE + 1][2 * s4 + 2],
+                                        (__bf16)c.b[p][ur * STRIDE + 1][2 * s4 + 4], (__bf16)c.b[p][ur * STRIDE + 1][2 * s4 + 6]};
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(pa2, pb2, acc2, 0, 0, 0);
+                  }
+                }
+              }
+            }
+          } else
 #pragma unroll
           for (int s = 0; s < OW; s++) {
             const int it = ((p * UR + ur) * KS + i) * OW + s;
@@ -1856,20 +1897,20 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
   }
 }
 
-template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP>
+template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP, bool BF = false>
 __device__ __forceinline__ void wgrad_direct_any(const GDesc& d, float* smem, const int bx, const int by, const int bz) {
   const bool bn = d.bnz != nullptr || d.bnz2 != nullptr;
   if constexpr (KS == 3 && STRIDE == 2) {
     if (d.dy2) {
-      if (bn) wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, true, true>(d, smem, bx, by, bz);
-      else wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, true, false>(d, smem, bx, by, bz);
+      if (bn) wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, true, true, BF>(d, smem, bx, by, bz);
+      else wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, true, false, BF>(d, smem, bx, by, bz);
       return;
     }
   }
   if constexpr (W <= 16) {       // (the BatchNorm operand exists for the planes of the CIFAR models' residual stages)
-    if (bn) { wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, false, true>(d, smem, bx, by, bz); return; }
+    if (bn) { wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, false, true, BF>(d, smem, bx, by, bz); return; }
   }
-  wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, false, false>(d, smem, bx, by, bz);
+  wgrad_rows_direct<KS, PAD, STRIDE, W, OW, UR, NP, false, false, BF>(d, smem, bx, by, bz);
 }
 
 // (id, kernel, pad, stride, W, OW, output rows per unit, image pairs per unit of the direct body: units of few MFMAs are
@@ -1882,8 +1923,8 @@ __device__ __forceinline__ void wgrad_direct_any(const GDesc& d, float* smem, co
 
 // (one wave per SIMD, like the stand-alone kernel: the row-unit body needs ~470 registers, and built
 // for two resident workgroups -- 256 registers -- it spills 120-210 of them)
-__global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <bool BF>
+__device__ __forceinline__ void wgrad_group_body(const WGroup& a, float* smem) {
   const int b = blockIdx.x;
 #ifdef DFHIP_STAMPS
   const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -1905,9 +1946,11 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
   g.stamps = nullptr;
   g.single = d.single;
   switch (d.kind) {
+    // (BF: the bf16 contraction exists for the direct body on rows of 4 and more output pixels, W <= 16 -- the CIFAR
+    // models' planes; everything else in a bf16 launch runs the fp32 body)
 #define DF_CASE(ID, KSV, PADV, SV, WV, OWV, URV, NPV)                                              \
   case ID:                                                                                         \
-    if (d.direct) wgrad_direct_any<KSV, PADV, SV, WV, OWV, URV, NPV>(d, smem, bx, by, bz);        \
+    if (d.direct) wgrad_direct_any<KSV, PADV, SV, WV, OWV, URV, NPV, (BF && OWV % 4 == 0 && WV <= 16)>(d, smem, bx, by, bz); \
     else wgrad_rows_body<KSV, PADV, SV, WV, OWV, URV, true>(g, smem, bx, by, bz, d.ps, d.CT, d.OT); \
     break;
     DF_ROWS_KINDS(DF_CASE)
@@ -1921,6 +1964,18 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
     a.ticks[4 * (size_t)gridDim.x + b] = wall_clock64();
   }
 #endif
+}
+
+__global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group(WGroup a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  wgrad_group_body<false>(a, smem);
+}
+
+// the same launch with the bf16 contraction (dfhip_set_conv_matmul_dtype(1)): a kernel of its own, so that the fp32
+// launch's code and registers are exactly what they were
+__global__ __launch_bounds__(64 * kRowsWaves) void k_wgrad_group_bf16(WGroup a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  wgrad_group_body<true>(a, smem);
 }
 
 // Slab sum of a grouped launch, tap-major per thread: a thread owns one (tile, q, lane) position --
@@ -2353,6 +2408,7 @@ struct GQueued {
 };
 std::vector<GQueued> g_queue;
 bool g_group_on = false;
+int g_matmul_dtype = 0;                           // dfhip_set_conv_matmul_dtype: 0 fp32, 1 bf16 operands (grouped weight gradients)
 struct StemPending { bool active = false; StemCombine c; int blocks = 0; } g_stem_pending;
 struct HeadPending { bool active = false; HeadGrads h; } g_head_pending;
 int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
@@ -2475,6 +2531,8 @@ int group_flush() {
   if (lds > attr_lds) {
     DF_HIP(hipFuncSetAttribute((const void*)k_wgrad_group, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)std::max(lds, (size_t)65536)));
+    DF_HIP(hipFuncSetAttribute((const void*)k_wgrad_group_bf16, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)std::max(lds, (size_t)65536)));
     attr_lds = std::max(lds, (size_t)65536);
   }
   for (size_t i0 = 0; i0 < q.size(); i0 += kMaxGroup) {
@@ -2524,8 +2582,9 @@ int group_flush() {
       (void)hipEventRecord(se0, gst);
     }
     {
-      ProfScope prof("conv2d_wgrad_grouped", flops, bytes);
-      DF_LAUNCH(k_wgrad_group, dim3((unsigned)wgs), dim3(64 * kRowsWaves), lds, gst, wg);
+      ProfScope prof(g_matmul_dtype == 1 ? "conv2d_wgrad_grouped_bf16" : "conv2d_wgrad_grouped", flops, bytes);
+      if (g_matmul_dtype == 1) DF_LAUNCH(k_wgrad_group_bf16, dim3((unsigned)wgs), dim3(64 * kRowsWaves), lds, gst, wg);
+      else DF_LAUNCH(k_wgrad_group, dim3((unsigned)wgs), dim3(64 * kRowsWaves), lds, gst, wg);
       DF_LAUNCH_CHECK();
     }
     if (stamp_mode) {      // cycles of a workgroup against the launch's wall time: the clock under this kernel
@@ -3248,6 +3307,15 @@ int dfhip_stem_backward(const float* x, const float* z, const float* y, const fl
 // deferred work, or that touches a queued dw) runs all of them as one launch plus one slab-sum
 // launch.  Contract: the x and dy arrays of a queued call stay allocated and unmodified until the
 // flush; dw holds the gradient only after it.
+int dfhip_set_conv_matmul_dtype(int dtype) {
+  DF_INIT();
+  DF_CHECK_ARG(dtype == 0 || dtype == 1, "set_conv_matmul_dtype: 0 (fp32) or 1 (bf16 operands, fp32 accumulation)");
+  g_matmul_dtype = dtype;
+  return DFHIP_OK;
+}
+
+int dfhip_conv_matmul_dtype(void) { return g_matmul_dtype; }
+
 int dfhip_wgrad_group_begin(void) {
   DF_INIT();
   g_group_on = true;

@@ -188,6 +188,15 @@ int dfhip_conv2d_forward_bn_input(const float* x, const float* partials_in, int 
 int dfhip_conv2d_wgrad_affine(const float* x, const float* affine, const float* dy, float* dw,
                               int N, int C, int H, int W, int O, int k, int stride, int pad);
 
+/* Opt-in reduced-precision contraction (OUTSIDE the 1e-4 parity contract, never the default): dtype 1 =
+ * the operands of the convolution weight gradients' matrix products are rounded to bf16 (nearest even) while they are
+ * packed, accumulation stays fp32 (v_mfma_f32_32x32x8_bf16).  Applies to the grouped launch (dfhip_wgrad_group_begin /
+ * _end) on rows of >= 4 output pixels; everything else -- forward, input gradients, BatchNorm, the optimizer, the layers
+ * the bf16 body does not take -- computes in fp32 as before.  dtype 0 = fp32 (the reference's arithmetic,
+ * backend_tensor.py:154-158). */
+int dfhip_set_conv_matmul_dtype(int dtype);
+int dfhip_conv_matmul_dtype(void);
+
 /* Grouped weight gradients (extension; the reference computes A^T . dC inside each node's grad_fn,
  * tensor.py:716, but nothing reads a weight's .grad before backward() returns, tensor.py:421-499).
  * Between _begin and _end, dfhip_conv2d_wgrad calls are queued where the fast kernel takes the
