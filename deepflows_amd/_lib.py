@@ -107,6 +107,7 @@ _SIGS = {
     "dfhip_head_ce_forward": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P],
     "dfhip_head_grads": [P, P, P, P, P, P, c_int, c_int, c_int],
     "dfhip_loss_finish": [P, P, c_int],
+    "dfhip_dropout_apply": [P, P, P, c_int64, c_float, c_int],
     "dfhip_set_conv_matmul_dtype": [c_int],
     "dfhip_conv_matmul_dtype": [],
     "dfhip_mlp2_ce_forward": [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],

@@ -89,13 +89,19 @@ struct OwBn {
 // GEO 0: 3x3 / stride 1 / pad 1 (above).  GEO 1: 3x3 / stride 2 / pad 1 -- the surviving tap of pixel
 // (y, x) is (1 + (y & 1), 1 + (x & 1)) and its source (y >> 1, x >> 1): a nearest-neighbour
 // up-sampling of dY followed by one of four 1x1 convolutions by pixel parity.  GEO 2: 1x1 / stride 2 /
-// pad 0 -- even (y, x) receive sum_o dY[o][y/2][x/2] W[o][c], the others stay zero.
+// pad 0 -- even (y, x) receive sum_o dY[o][y/2][x/2] W[o][c], the others stay zero.  GEO 3 (round 6; the CNN workload's
+// conv2, test/CNN_CIFAR10_cuda.py:66): 5x5 / stride 1 / pad 2 -- the last of the 25 assignments that reaches input pixel
+// (y, x) is tap (2 + min(y, 2), 2 + min(x, 2)), its source (max(y - 2, 0), max(x - 2, 0)): nine weight slices by
+// (min(y, 2), min(x, 2)), 1/25 of the products of the true gradient (the staged implicit-GEMM kernel this replaces for that
+// layer multiplied all 25 taps' worth of zeros: 27 us for 25 MB).
 template <int GEO>
 struct OwGeo {
-  static constexpr int NSL = GEO == 2 ? 1 : 4;      // weight slices
+  static constexpr int NSL = GEO == 2 ? 1 : (GEO == 3 ? 9 : 4);      // weight slices
+  static constexpr int NSA = GEO == 3 ? 9 : 4;                      // (registers of a thread's slice values)
   __device__ static void pixel(int y, int x, int& u, int& v, int& cls) {
     if (GEO == 0) { u = max(y - 1, 0); v = max(x - 1, 0); cls = (y >= 1 ? 2 : 0) + (x >= 1 ? 1 : 0); }
     else if (GEO == 1) { u = y >> 1; v = x >> 1; cls = ((y & 1) << 1) + (x & 1); }
+    else if (GEO == 3) { u = max(y - 2, 0); v = max(x - 2, 0); cls = 3 * min(y, 2) + min(x, 2); }
     else { u = y >> 1; v = x >> 1; cls = ((y | x) & 1) ? -1 : 0; }
   }
   // lane -> pixel of tile t.  Default: 32 consecutive pixels of the flattened (n, y, x) space.  Stride 2
@@ -129,9 +135,14 @@ struct OwGeo {
     }
   }
   // the NSL weights of one (o, c) pair, from the (O, C, k, k) tensor
-  __device__ static void slices(const float* __restrict__ w, int64_t oc, float (&out)[4]) {
-    if (GEO == 2) { out[0] = w[oc]; out[1] = out[2] = out[3] = 0.0f; }
-    else load_taps_4578(w + oc * 9, out);
+  __device__ static void slices(const float* __restrict__ w, int64_t oc, float (&out)[NSA]) {
+    if constexpr (GEO == 2) { out[0] = w[oc]; out[1] = out[2] = out[3] = 0.0f; }
+    else if constexpr (GEO == 3) {
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) out[3 * a + b] = w[oc * 25 + (2 + a) * 5 + 2 + b];
+    } else load_taps_4578(w + oc * 9, out);
   }
 };
 
@@ -182,7 +193,10 @@ __global__ __launch_bounds__(64 * NW) void k_dgrad_ow_s1(const float* __restrict
   constexpr int KS = 1 + NST;
   constexpr int NT = 64 * NW;                       // threads: NW waves, a 32-pixel tile each
   constexpr bool BN = BNI || NST > 0;               // a BatchNorm build: more loads than a wave keeps in flight, see below
-  __shared__ float Wl[NSL + (PAIR ? 1 : 0)][O][32]; // the weight slices of this channel tile: [slice][o][c]
+  // the weight slices of this channel tile: [slice][o][c] (the nine slices of a 5x5 kernel: 74 KB at 64 channels, dynamic LDS)
+  __shared__ float Wl_static[GEO == 3 ? 1 : NSL + (PAIR ? 1 : 0)][GEO == 3 ? 1 : O][32];
+  extern __shared__ __attribute__((aligned(16))) float Wl_dynamic[];
+  float (*Wl)[O][32] = GEO == 3 ? reinterpret_cast<float (*)[O][32]>(Wl_dynamic) : reinterpret_cast<float (*)[O][32]>(Wl_static);
   __shared__ float4 tab[BNI ? (PAIR ? 2 : 1) : 1][BNI ? O : 1];
   __shared__ float wsum[NST ? NW : 1][NST ? 32 : 1][KS];
   __shared__ float mtl[NST ? NST : 1][32];
@@ -203,13 +217,13 @@ __global__ __launch_bounds__(64 * NW) void k_dgrad_ow_s1(const float* __restrict
   const int rem = (y << lw) + x;
   int u, v, cls;                                    // source pixel, slice q <-> tap (1 + (q >> 1), 1 + (q & 1))
   OwGeo<GEO>::pixel(y, x, u, v, cls);
-  const int slw = GEO == 0 ? lw : lw - 1;           // source plane: H x W, or H/2 x W/2
-  const int SHW = GEO == 0 ? HW : HW >> 2;
+  const int slw = (GEO == 0 || GEO == 3) ? lw : lw - 1;   // source plane: H x W (stride 1), or H/2 x W/2
+  const int SHW = (GEO == 0 || GEO == 3) ? HW : HW >> 2;
   const int64_t soff = ((int64_t)n * O + half) * SHW + (u << slw) + v;
   const int64_t obase = ((int64_t)n * C + c0) * HW + rem;
   constexpr int PAIRS = O * 32 / NT;
   static_assert(O * 32 % NT == 0, "whole rounds of weight staging");
-  float wv[PAIRS][4], wv2[PAIRS];
+  float wv[PAIRS][OwGeo<GEO>::NSA], wv2[PAIRS];
   auto load_weights = [&]() {       // the thread's share of the weight slices: (o, c) pairs, the four taps 4, 5, 7, 8 of each
 #pragma unroll
     for (int i = 0; i < PAIRS; i++) {
@@ -394,21 +408,23 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict_
   const int half = lane >> 5, l31 = lane & 31;
   const int HW = H << lw;
   const int c0 = blockIdx.y * 32;
-  const int slw = GEO == 0 ? lw : lw - 1;           // source plane: H x W, or H/2 x W/2
-  const int SHW = GEO == 0 ? HW : HW >> 2;
+  const int slw = (GEO == 0 || GEO == 3) ? lw : lw - 1;   // source plane: H x W (stride 1), or H/2 x W/2
+  const int SHW = (GEO == 0 || GEO == 3) ? HW : HW >> 2;
   const int ob = wave * OQ;                         // this wave's slice of the reduction
   // the weight slices of this channel tile, once per workgroup (it walks several pixel tiles)
   constexpr int PAIRS = O * 32 / 256;
-  for (int i0 = 0; i0 < PAIRS; i0 += 16) {          // sixteen (o, c) pairs in flight per thread
-    float wv[16][4], wv2[16];
+  constexpr int WB = PAIRS < 16 ? PAIRS : 16;
+  static_assert(PAIRS % WB == 0, "whole rounds of weight staging");
+  for (int i0 = 0; i0 < PAIRS; i0 += WB) {          // up to sixteen (o, c) pairs in flight per thread
+    float wv[WB][OwGeo<GEO>::NSA], wv2[WB];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < WB; i++) {
       const int e = threadIdx.x + 256 * (i0 + i), o = e >> 5, c = e & 31;
       OwGeo<GEO>::slices(w, (int64_t)o * C + c0 + c, wv[i]);
       wv2[i] = PAIR ? w2[(int64_t)o * C + c0 + c] : 0.0f;
     }
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < WB; i++) {
       const int e = threadIdx.x + 256 * (i0 + i), o = e >> 5, c = e & 31;
 #pragma unroll
       for (int q = 0; q < NSL; q++) Wl[(q * O + o) * 32 + c] = wv[i][q];
@@ -936,9 +952,36 @@ int run_dgrad_ow(const float* dy, const float* w, const float* add, float* dx, i
   while ((1 << lw) < W) lw++;
   // (a tile is 32 consecutive pixels of the flattened (n, y, x) space; every lane decodes its own pixel)
   const int geo = (k == 3 && stride == 1 && pad == 1) ? 0 : (k == 3 && stride == 2 && pad == 1) ? 1
-                  : (k == 1 && stride == 2 && pad == 0) ? 2 : -1;
+                  : (k == 1 && stride == 2 && pad == 0) ? 2 : (k == 5 && stride == 1 && pad == 2) ? 3 : -1;
   const bool lean_ok = geo >= 0 && C % 32 == 0 && (1 << lw) == W && H >= 2 && W >= 2 &&
-                       ((int64_t)N * H * W) % 32 == 0 && (geo == 0 || (H % 2 == 0 && oh * 2 == H && ow * 2 == W));
+                       ((int64_t)N * H * W) % 32 == 0 &&
+                       (geo == 0 || geo == 3 || (H % 2 == 0 && oh * 2 == H && ow * 2 == W));
+  if (geo == 3) {
+    // 5x5 / stride 1 / pad 2 (the CNN workload's conv2): nine weight slices in dynamic LDS, one workgroup per CU walks the tiles
+    if (!(lean_ok && (O == 32 || O == 64) && W >= 4 && H >= 3)) return -1;
+    if (bnform) return -2;
+    if (dry_run) return DFHIP_OK;
+    const int tiles = (int)((int64_t)N * H * W / 32);
+    // a wave owns a 32-pixel tile outright (k_dgrad_ow_s1), four tiles per workgroup, the nine slices in dynamic LDS
+    dim3 grid((unsigned)df_ceil_div(tiles, 4), (unsigned)(C / 32));
+    const size_t lds = (size_t)9 * O * 32 * sizeof(float);
+    OwBn bn = OwBn{};
+#define DF_K5(OV)                                                                                             \
+  do {                                                                                                        \
+    static bool attr = false;                                                                                 \
+    if (!attr) {                                                                                              \
+      DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_s1<OV, 3, false, false, 0, 4>,                       \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536))); \
+      attr = true;                                                                                            \
+    }                                                                                                         \
+    DF_LAUNCH((k_dgrad_ow_s1<OV, 3, false, false, 0, 4>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, H, lw, tiles, 0, \
+              (const float*)nullptr, (const float*)nullptr, bn);                                               \
+  } while (0)
+    if (O == 32) DF_K5(32); else DF_K5(64);
+#undef DF_K5
+    DF_LAUNCH_CHECK();
+    return DFHIP_OK;
+  }
   const int tiles = lean_ok ? (int)((int64_t)N * H * W / 32) : 0;
   // stride 2: parity-grouped tiles when whole 128-pixel blocks tile the tensor
   const int pg = (geo == 1 && ((int64_t)N * H * W) % 128 == 0 && W <= 64) ? 1 : 0;

@@ -1183,6 +1183,25 @@ __global__ __launch_bounds__(kThreads) void k_maxpool_bwd(const float* __restric
   }
 }
 
+// Dropout in training mode (nn/modules/dropout.py:31: `x * mask / (1 - p)`): forward BWD = false: y = (x * mask) / s; backward
+// BWD = true: dx = (g / s) * mask -- the two nodes' arithmetic (a product, a division by the scalar: backend_tensor.py:551-586
+// and their grad_fn's, tensor.py:640-676) in the same order, one launch instead of two each way.
+template <bool BWD>
+__global__ __launch_bounds__(kThreads) void k_dropout(const float* __restrict__ x, const float* __restrict__ m,
+                                                      float* __restrict__ y, int64_t n, float s) {
+  const int64_t n4 = n >> 2;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  auto f = [s](float a, float k) { return BWD ? __fmul_rn(__fdiv_rn(a, s), k) : __fdiv_rn(__fmul_rn(a, k), s); };
+  for (int64_t i = tid; i < n4; i += step) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i], k = reinterpret_cast<const float4*>(m)[i];
+    float4 r;
+    r.x = f(v.x, k.x); r.y = f(v.y, k.y); r.z = f(v.z, k.z); r.w = f(v.w, k.w);
+    reinterpret_cast<float4*>(y)[i] = r;
+  }
+  for (int64_t i = (n4 << 2) + tid; i < n; i += step) y[i] = f(x[i], m[i]);
+}
+
 __global__ __launch_bounds__(kThreads) void k_relu_fwd(const float* __restrict__ x,
                                                        float* __restrict__ y, int64_t n) {
   int64_t n4 = n >> 2;
@@ -2358,6 +2377,19 @@ int dfhip_maxpool2d_backward(const float* x, const float* y, const float* dy, fl
   ProfScope prof("maxpool2d_bwd", 0.0, 8.0 * (double)n_in + 8.0 * (double)NC * oh * ow);
   DF_LAUNCH(k_maxpool_bwd, dim3(grid_for(n_in)), dim3(kThreads), 0, stream(), x, y, dy, dx,
                      n_in, H, W, oh, ow, k);
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
+}
+
+int dfhip_dropout_apply(const float* x, const float* mask, float* y, int64_t n, float keep, int backward) {
+  DF_INIT_KEEP();
+  DF_TOUCH(x); DF_TOUCH(mask); DF_TOUCH(y);
+  DF_CHECK_ARG(n >= 0 && keep > 0.0f, "dropout_apply: bad arguments");
+  if (n == 0) return DFHIP_OK;
+  DF_CHECK_ARG(x && mask && y, "dropout_apply: null array");
+  ProfScope prof(backward ? "dropout_bwd" : "dropout_fwd", 0.0, 12.0 * (double)n);
+  if (backward) DF_LAUNCH(k_dropout<true>, dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), x, mask, y, n, keep);
+  else DF_LAUNCH(k_dropout<false>, dim3(grid_for(n, 4)), dim3(kThreads), 0, stream(), x, mask, y, n, keep);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }

@@ -632,6 +632,9 @@ class HipModule:
         if loss is not None and hasattr(loss, "settled"):
             loss.settled()
 
+    def dropout_apply(self, x, mask, y, n, keep, backward):
+        _lib.check(self._lib.dfhip_dropout_apply(x.ptr, mask.ptr, y.ptr, int(n), float(keep), 1 if backward else 0))
+
     def deferred_array(self, size):
         return DeferredHipArray(size, self._lib)
 

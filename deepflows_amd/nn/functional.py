@@ -229,6 +229,32 @@ class _ReLUFused(_FusedNode):
         return out
 
 
+class _DropoutFused(_FusedNode):
+    """x * mask / (1 - p) (nn/modules/dropout.py:31) as one node: one launch each way with the two primitive nodes' values bit
+    for bit (dfhip_dropout_apply); the mask is the host-drawn array the module uploaded"""
+
+    def __init__(self, x, mask, keep):
+        self.mask, self.keep = mask, float(keep)
+        xd = x.data.compact()
+        out = _new(x.shape, x.device)
+        x.device.mod.dropout_apply(xd._handle, mask._handle, out._handle, xd._handle.size, self.keep, False)
+        super().__init__(out, [x])
+
+    def grad_fn(self, node, grad):
+        g = grad.compact()
+        out = _new(g.shape, g.device)
+        g.device.mod.dropout_apply(g._handle, self.mask._handle, out._handle, g._handle.size, self.keep, True)
+        return out
+
+
+def dropout_train(x: Tensor, mask, keep):
+    """x * mask / keep for a mask BackendTensor of x's shape"""
+    x = realize(x)
+    if _fused(x) and hasattr(x.device.mod, "dropout_apply") and is_grad_enable():
+        return _DropoutFused(x, mask.compact(), keep)
+    return x * mask / keep
+
+
 _lazy_relu = None           # nn/lazy.py: relu of a recorded call (relu(fc(x)), relu(bn(conv(x)))) extends or completes the record
 
 

@@ -71,7 +71,8 @@ class Dropout(Module):
                 if up is None or mask._handle.size < 8192 or not up(mask._handle, 1 - self.p):
                     mask_np = np.ascontiguousarray(bernoulli_mask(1 - self.p, x.shape))
                     x.device.from_numpy(mask_np, mask._handle)
-            return x * mask / (1 - self.p)
+            from .. import functional as F
+            return F.dropout_train(x, mask, 1 - self.p)
         return x * (1 - self.p)
 
     def extra_repr(self):

@@ -470,6 +470,11 @@ int dfhip_mlp2_ce_forward(const float* x, const float* w1, const float* b1, cons
 int dfhip_mlp2_ce_backward(const float* x, const float* h, const float* dz1, const float* dlogits, float* dw1, float* db1,
                            float* dw2, float* db2, const float* rowloss, float* loss, int M, int K, int HD, int P);
 
+/* Dropout in training mode as one launch each way (nn/modules/dropout.py:31 `x * mask / (1 - p)`, the mask drawn on the
+ * host): backward = 0: y = (x * mask) / keep; backward = 1 (x is the upstream gradient): y = (x / keep) * mask -- the two
+ * primitive nodes' results bit for bit (backend_tensor.py:551-586, tensor.py:640-676).  keep = 1 - p. */
+int dfhip_dropout_apply(const float* x, const float* mask, float* y, int64_t n, float keep, int backward);
+
 /* Sum `src` over the axes in which dst_shape is 1 (or missing leading axes): replaces
  * the host un-broadcast of tensor.py:462-483.  Shapes are right-aligned.                */
 int dfhip_reduce_to_shape(const float* src, float* dst, int src_ndim, const int64_t* src_shape,

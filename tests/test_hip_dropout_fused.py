@@ -1,0 +1,73 @@
+"""GPU: Dropout in training mode as one launch each way (dfhip_dropout_apply) -- nn/modules/dropout.py:31 `x * mask / (1 - p)`
+with the two primitive nodes' values bit for bit, forward and backward; and the 5x5 / stride 1 / pad 2 overwrite-mode input
+gradient on the one-tap-per-pixel kernels (nn/functional.py:285-294: the last of the 25 assignments wins)."""
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_close
+from oracle import ref_ops as R
+
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape,p", [((256, 2048), 0.5), ((37, 101), 0.3), ((8, 16, 5, 5), 0.8)])
+def test_dropout_is_one_launch_each_way_with_the_primitive_bits(hip_device, cpu_oracle, shape, p):
+    from deepflows_amd import nn, tensor
+    from deepflows_amd.tensor import Graph, Tensor
+    rng = np.random.default_rng(3)
+    x_np = rng.standard_normal(shape).astype(np.float32)
+    res = {}
+    for name, dev in (("hip", hip_device), ("cpu", cpu_oracle)):
+        np.random.seed(11)                                 # the same mask on both devices (the module draws it on the host)
+        x = Tensor(x_np, device=dev, requires_grad=True)
+        drop = nn.Dropout(p)
+        drop.train()
+        if name == "hip":
+            dev.mod.prof_reset(); dev.mod.prof_enable(True)
+        y = drop(x)
+        loss = tensor.sum(y * y)
+        loss.backward()
+        if name == "hip":
+            dev.mod.synchronize(); dev.mod.prof_enable(False)
+            fams = {k: v["calls"] for k, v in dev.mod.prof_read().items() if v["calls"]}
+            assert fams.get("dropout_fwd") == 1 and fams.get("dropout_bwd") == 1, fams
+        res[name] = (y.numpy().copy(), x.grad.numpy().copy())
+        Graph.free_graph_all()
+    assert np.array_equal(res["hip"][0], res["cpu"][0])    # (x * mask) / (1 - p): two roundings, the same on both
+    assert_close(res["hip"][1], res["cpu"][1], 1e-6, "dx")
+    assert (res["hip"][0] == 0).any() and (res["hip"][0] != 0).any()
+
+
+K5 = {"cnn2_bs256": (256, 32, 16, 16, 64), "c64_o32_8x8": (64, 64, 8, 8, 32), "c32_o32_4x4": (32, 32, 4, 4, 32),
+      "c32_o64_32x32": (8, 32, 32, 32, 64)}
+
+
+@pytest.mark.parametrize("name", list(K5))
+def test_5x5_overwrite_input_gradient_on_the_one_tap_kernels(hip_device, name):
+    mod = hip_device.mod
+    N, C, H, W, O = K5[name]
+    rng = np.random.default_rng(len(name))
+    w = (rng.standard_normal((O, C, 5, 5)) / np.sqrt(C * 25)).astype(np.float32)
+    dy = rng.standard_normal((N, O, H, W)).astype(np.float32)
+    held = rng.standard_normal((N, C, H, W)).astype(np.float32)
+
+    def arr(a):
+        h = mod.Array(a.size)
+        mod.from_numpy(a, h)
+        return h
+    wh, dyh, dxh = arr(w), arr(dy), mod.Array(N * C * H * W)
+    mod.prof_reset(); mod.prof_enable(True)
+    mod.conv2d_dgrad(dyh, wh, dxh, N, C, H, W, O, 5, 1, 2, mode="overwrite")
+    mod.synchronize(); mod.prof_enable(False)
+    kern = [k for k, v in mod.prof_read_kernels().items() if v["launches"]]
+    assert any("k_dgrad_ow_s1<" in k for k in kern), kern
+    got = mod.to_numpy(dxh, (dxh.size,), (1,), 0).reshape(N, C, H, W)
+    want = R.conv2d_dgrad(dy, w, (N, C, H, W), 1, 2, "overwrite")
+    assert_close(got, want, 1e-4, name)
+    # one tap per pixel: 64 products per element -- every element against its own condition
+    cond = R.conv2d_dgrad(np.abs(dy), np.abs(w), (N, C, H, W), 1, 2, "overwrite")
+    err = np.abs(got.astype(np.float64) - want) / np.maximum(cond, 1e-6 * cond.max())
+    assert err.max() <= 1e-5, err.max()
