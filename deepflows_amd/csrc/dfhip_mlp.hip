@@ -216,6 +216,160 @@ __global__ __launch_bounds__(64 * NW * kKS) void k_mlp2_fwd(
   }
 }
 
+// ---- the forward pass as TWO launches (the default from 64 rows on): every workgroup of the one-launch kernel above streams
+// all of W1 (803 KB for 784 -> 256) through its CU -- 17.8 us, whatever the round size (DFHIP_MLP_R) --, and nothing but a
+// split of the hidden units or of K over workgroups shortens that, which puts fc2 (all hidden units of a row) behind a
+// launch boundary.  k_mlp_fc1: z = x . W1 + b1, a 16 x 16 tile per workgroup (128 workgroups at 128 x 256), its four waves a
+// quarter of K each, every operand requested up front; k_mlp2_tail: relu, fc2, cross-entropy, d loss / d logits,
+// d loss / d z for four rows per workgroup (the second half of the kernel above).
+__global__ __launch_bounds__(256) void k_mlp_fc1(const float* __restrict__ x, const float* __restrict__ w1,
+                                                const float* __restrict__ b1, float* __restrict__ z, int M, int K, int HD) {
+  __shared__ f32x4 red[3][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kk = lane >> 4;
+  const int r0 = (int)blockIdx.x * 16, c0 = (int)blockIdx.y * 16;
+  const int kq = K / 4, kb = wave * kq;            // (K % 16 == 0: kq is a multiple of 4)
+  const float* xr = x + (int64_t)min(r0 + i, M - 1) * K + kb + 4 * kk;        // A[i][k]: 4 consecutive k per 16-k chunk
+  const float* wp = w1 + (int64_t)(kb + 4 * kk) * HD + c0 + i;                // B[k][j = i]
+  constexpr int CH = 13;                            // 16-k chunks in flight (K <= 4 * 16 * CH + tail: 784 -> 12.25)
+  const int full = kq / 16, tail = (kq - 16 * full) / 4;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int t0 = 0; t0 < full; t0 += CH) {
+    float4 xv[CH];
+    float wv[CH][4];
+#pragma unroll
+    for (int t = 0; t < CH; t++) {
+      const int tc = min(t0 + t, full - 1);         // (a chunk past the end re-reads the last one: times 0)
+      xv[t] = *reinterpret_cast<const float4*>(xr + 16 * tc);
+#pragma unroll
+      for (int e = 0; e < 4; e++) wv[t][e] = wp[(int64_t)(16 * tc + e) * HD];
+    }
+    asm volatile("" ::: "memory");                 // (a compiler barrier: the selection DAG sinks plain loads to their uses)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < CH; t++) {
+      const float on = t0 + t < full ? 1.0f : 0.0f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t].x * on, wv[t][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t].y * on, wv[t][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t].z * on, wv[t][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t].w * on, wv[t][3], acc, 0, 0, 0);
+    }
+  }
+  for (int s2 = 0; s2 < tail; s2++) {              // the rest of the range, 4 k at a time: lane (i, kk) takes k = kk
+    const int k = kb + 16 * full + 4 * s2 + kk;
+    const float a = x[(int64_t)min(r0 + i, M - 1) * K + k];
+    const float b = w1[(int64_t)k * HD + c0 + i];
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+  }
+  if (wave > 0) red[wave - 1][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {                                  // lane holds D[4 kk + v][i]
+    const float bias = b1 ? b1[c0 + i] : 0.0f;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const float s3 = ((acc[v] + red[0][lane][v]) + (red[1][lane][v] + red[2][lane][v])) + bias;
+      if (r0 + 4 * kk + v < M) z[(int64_t)(r0 + 4 * kk + v) * HD + c0 + i] = s3;
+    }
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_mlp2_tail(
+    const float* __restrict__ z, const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ target,
+    float* __restrict__ h, float* __restrict__ logits, float* __restrict__ dlogits, float* __restrict__ dz1,
+    float* __restrict__ rowloss, int M, int Pn, float inv_rows) {
+  constexpr int HD = 64 * NW, P = kP, NWAVES = NW;
+  __shared__ float hs[4][HD];
+  __shared__ float sw2[HD][P];
+  __shared__ float plog[NWAVES][4][P];
+  __shared__ float sdl[4][P];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r0 = (int)blockIdx.x * 4;
+  const int col = tid;
+  constexpr int W2V = (HD * P + 64 * NWAVES - 1) / (64 * NWAVES);
+  float w2v[W2V];
+#pragma unroll
+  for (int i = 0; i < W2V; i++) {
+    const int e = tid + 64 * NWAVES * i, c = e / P, j = e - c * P;
+    const float v = w2[(int64_t)min(c, HD - 1) * Pn + min(j, Pn - 1)];
+    w2v[i] = v * ((c < HD && j < Pn) ? 1.0f : 0.0f);
+  }
+  float zv[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) zv[r] = z[(int64_t)min(r0 + r, M - 1) * HD + col];
+#pragma unroll
+  for (int i = 0; i < W2V; i++) {
+    const int e = tid + 64 * NWAVES * i;
+    if (e < HD * P) (&sw2[0][0])[e] = w2v[i];
+  }
+  bool pass[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const float y = relu_point(zv[r]);             // maximum(z, 0): NaN stays NaN (np.maximum)
+    pass[r] = y == zv[r];                          // tensor.py:872-877: the gradient passes where y == x (also at 0)
+    hs[r][col] = y;
+    if (r0 + r < M) h[(int64_t)(r0 + r) * HD + col] = y;
+  }
+  __syncthreads();
+  float w2r[P];
+#pragma unroll
+  for (int j = 0; j < P; j++) w2r[j] = sw2[col][j];
+  {
+    constexpr int CPW = HD / NWAVES;               // 64 hidden units per wave, for (row, class) = (lane / 16, lane % 16)
+    const int r = lane >> 4, j = lane & 15, cb = wave * CPW;
+    float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};        // (four chains; added in a fixed order)
+#pragma unroll
+    for (int c = 0; c < CPW; c++) s4[c & 3] = fmaf(hs[r][cb + c], sw2[cb + c][j], s4[c & 3]);
+    plog[wave][r][j] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int r = lane >> 4, j = lane & 15;
+    const int row = min(r0 + r, M - 1);
+    float y = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; w++) y += plog[w][r][j];
+    y += (b2 && j < Pn) ? b2[j] : 0.0f;
+    const float xv = j < Pn ? y : -INFINITY;
+    const float tv = j < Pn ? target[(int64_t)row * Pn + j] : 0.0f;
+    auto row_max = [](float v) {
+      v = fmaxf(v, __shfl_xor(v, 8, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64));
+      v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 1, 64));
+      return v;
+    };
+    auto row_sum = [](float v) {
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+      return v;
+    };
+    const float m = row_max(xv);
+    const float ex = expf(xv - m);
+    const float se = row_sum(ex);
+    const float lse = logf(se);
+    const float nll = j < Pn ? -((xv - m) - lse) * tv : 0.0f;
+    const float rl = row_sum(nll);
+    const float gs = 1.0f * inv_rows;
+    const float st = row_sum(tv);
+    const float gu = j < Pn ? gs * tv * -1.0f + ex * ((gs * st) / se) : 0.0f;
+    const float gsum = row_sum(gu);
+    const float d = j < Pn ? gu + (xv == m ? -gsum : 0.0f) : 0.0f;
+    sdl[r][j] = d;
+    if (r0 + r < M && j < Pn) {
+      logits[(int64_t)row * Pn + j] = y;
+      dlogits[(int64_t)row * Pn + j] = d;
+    }
+    if (r0 + r < M && j == 0) rowloss[row] = rl;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < P; j++) s = fmaf(sdl[r][j], w2r[j], s);
+    if (r0 + r < M) dz1[(int64_t)(r0 + r) * HD + col] = pass[r] ? s : 0.0f;
+  }
+}
+
 struct MlpBwd {
   const float* x;        // (M, K)
   const float* h;        // (M, HD)
@@ -313,10 +467,28 @@ int dfhip_mlp2_ce_forward(const float* x, const float* w1, const float* b1, cons
   DF_CHECK_ARG(M > 0 && K > 0 && HD > 0 && P > 0, "mlp2_ce_forward: bad dimensions");
   DF_CHECK_ARG(x && w1 && w2 && target && h && logits && dlogits && dz1 && rowloss, "mlp2_ce_forward: null array");
   if (!(K % 16 == 0 && K <= 4096 && (HD == 64 || HD == 128 || HD == 256) && P <= kP && M <= 4096)) return DFHIP_OK;
-  ProfScope prof("mlp2_ce_fwd", 2.0 * M * ((double)K * HD + 2.0 * HD * P),
-                 4.0 * ((double)M * K + (double)K * HD + (double)HD * P + 2.0 * M * HD + 3.0 * M * P));
   const float inv_rows = 1.0f / (float)M;
   const dim3 grid((unsigned)((M + 3) / 4));
+  static int one = -1;                               // DFHIP_MLP_ONE=1: the one-launch forward kernel at every size
+  if (one < 0) one = getenv("DFHIP_MLP_ONE") ? atoi(getenv("DFHIP_MLP_ONE")) : 0;
+  if (M >= 64 && !one) {
+    // two launches: z = x . W1 + b1 on 16 x 16 tiles, then everything that belongs to a row (zpre is the buffer between them)
+    float* zb = zpre ? zpre : dz1;                   // (without a caller's array the pre-activations pass through dz1's)
+    {
+      ProfScope prof("mlp_fc1_fwd", 2.0 * M * (double)K * HD, 4.0 * ((double)M * K + (double)K * HD + (double)M * HD));
+      DF_LAUNCH(k_mlp_fc1, dim3((unsigned)((M + 15) / 16), (unsigned)(HD / 16)), dim3(256), 0, stream(), x, w1, b1, zb, M, K, HD);
+      DF_LAUNCH_CHECK();
+    }
+    ProfScope prof("mlp2_ce_fwd", 4.0 * M * (double)HD * P, 4.0 * (4.0 * M * HD + (double)HD * P + 3.0 * M * P));
+    if (HD == 64) DF_LAUNCH(k_mlp2_tail<1>, grid, dim3(64), 0, stream(), zb, w2, b2, target, h, logits, dlogits, dz1, rowloss, M, P, inv_rows);
+    else if (HD == 128) DF_LAUNCH(k_mlp2_tail<2>, grid, dim3(128), 0, stream(), zb, w2, b2, target, h, logits, dlogits, dz1, rowloss, M, P, inv_rows);
+    else DF_LAUNCH(k_mlp2_tail<4>, grid, dim3(256), 0, stream(), zb, w2, b2, target, h, logits, dlogits, dz1, rowloss, M, P, inv_rows);
+    DF_LAUNCH_CHECK();
+    *done = 1;
+    return DFHIP_OK;
+  }
+  ProfScope prof("mlp2_ce_fwd", 2.0 * M * ((double)K * HD + 2.0 * HD * P),
+                 4.0 * ((double)M * K + (double)K * HD + (double)HD * P + 2.0 * M * HD + 3.0 * M * P));
 #define DF_FWD(NWV, RV)                                                                                                 \
   DF_LAUNCH((k_mlp2_fwd<NWV, RV>), grid, dim3(64 * NWV * kKS), (size_t)4 * K * sizeof(float), stream(), x, w1, b1, w2, b2, \
             target, zpre, h, logits, dlogits, dz1, rowloss, M, K, P, inv_rows)
