@@ -1943,9 +1943,9 @@ int dfhip_conv2d_forward_bn_input(const float* x, const float* partials_in, int 
   if (s != DFHIP_OK) return s;
   DF_CHECK_ARG(x && w && y && partials_in && save_mean && save_var && affine_out && done,
                "conv2d_forward_bn_input: null array");
-  DF_CHECK_ARG(rows_in >= 1, "conv2d_forward_bn_input: no partial rows");
   *done = 0;
   if (rows_out) *rows_out = 0;
+  if (rows_in < 1) return DFHIP_OK;     // (the documented contract for what the entry does not take: *done = 0, the caller writes conv(bn(x)))
   BnInput bn = {};
   bn.part = partials_in; bn.rows = rows_in; bn.gamma = gamma; bn.beta = beta; bn.eps = eps; bn.momentum = momentum;
   bn.save_mean = save_mean; bn.save_var = save_var; bn.running_mean = running_mean; bn.running_var = running_var;

@@ -110,10 +110,18 @@ static int do_init(int device_id) {
   if (const char* cm = getenv("DFHIP_CU_MASK")) {
     // diagnostic (round 5, tools/probes/two_streams2.hip): the library stream on a subset of the CUs -- "lo<N>" = mask bits
     // 0..N-1, "hi<N>" = bits 256-N..255 (which CUs those are: tools/probes/cu_mask_map.hip)
+    // (DIAGNOSTIC ONLY.  The value is checked: a prefix other than lo / hi, a missing or out-of-range count used to give an
+    // all-zero mask -- ADVICE r5)
     uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int n = atoi(cm + 2);
+    const size_t len = strlen(cm);
+    const bool lo = len >= 3 && cm[0] == 'l' && cm[1] == 'o', hi = len >= 3 && cm[0] == 'h' && cm[1] == 'i';
+    const int n = (lo || hi) ? atoi(cm + 2) : 0;
+    if (n < 1 || n > 256) {
+      set_error("DFHIP_CU_MASK=%s: expected lo<N> or hi<N> with 1 <= N <= 256", cm);
+      return DFHIP_INVALID_ARGUMENT;
+    }
     for (int c = 0; c < 256; c++)
-      if ((cm[0] == 'l' && c < n) || (cm[0] == 'h' && c >= 256 - n)) mask[c / 32] |= 1u << (c % 32);
+      if ((lo && c < n) || (hi && c >= 256 - n)) mask[c / 32] |= 1u << (c % 32);
     DF_HIP(hipExtStreamCreateWithCUMask(&g_stream, 8, mask));
   } else {
     DF_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));

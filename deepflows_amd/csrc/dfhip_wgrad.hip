@@ -3327,13 +3327,14 @@ int dfhip_wgrad_group_end(void) {
   DF_INIT_KEEP();
   g_group_on = false;
   if (overlap_cus()) {
-    // the side stream's launches join the chain, the chain joins the library stream, what is still queued runs on all CUs
-    if (!g_side_pending.empty()) {
-      int st = side_join();
-      if (st != DFHIP_OK) return st;
-    }
-    int st = chain_end();
+    // (DFHIP_OVERLAP_CUS is a DIAGNOSTIC switch: copies, synchronize and the collectives do not follow the chain stream.)
+    // The side stream's launches join the chain, the chain joins the library stream, what is still queued runs on all CUs;
+    // the chain ends whatever the join returned (an error used to leave every later launch on the chain stream)
+    int st = DFHIP_OK;
+    if (!g_side_pending.empty()) st = side_join();
+    const int st2 = chain_end();
     if (st != DFHIP_OK) return st;
+    if (st2 != DFHIP_OK) return st2;
   }
   return flush_deferred();
 }

@@ -99,7 +99,17 @@ FAMILIES = {
     # kernel-name prefix (a trailing $ = exact name) -> the family bench.py reports (dfhip ProfScope names);
     # first match wins
     "wgrad_slab_sum": ("k_wgrad_group_sum",),
+    "conv2d_wgrad_grouped_bf16": ("k_wgrad_group_bf16",),
     "conv2d_wgrad_grouped": ("k_wgrad_group",),
+    # round 6
+    "head_ce_fwd_bwd": ("k_head_ce",),
+    "head_grads": ("k_head_grads",),
+    "loss_finish": ("k_loss_finish",),
+    "mlp_fc1_fwd": ("k_mlp_fc1",),
+    "mlp2_ce_fwd": ("k_mlp2_fwd", "k_mlp2_tail"),
+    "mlp2_ce_bwd": ("k_mlp2_bwd",),
+    "dropout_fwd": ("k_dropout<false>",),
+    "dropout_bwd": ("k_dropout<true>",),
     "conv2d_wgrad_igemm": ("k_conv_wgrad_rows", "k_conv_wgrad_v3", "k_conv_wgrad_tap", "k_conv_wgrad<", "k_wgrad_tap_sum",
                            "k_flat_slab_sum", "k_wgrad_stem3", "k_stem_bwd<1, true>", "k_stem_bwd<2, true>",
                            "k_stem_bwd<3, true>", "k_stem_slab_sum"),
