@@ -1041,6 +1041,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad_tap(TGeo g) {
 struct SlabSum {
   const float* slabs;
   float* dw;
+  int tstride, toff;            // taps per (o, c) record of dw and the record's first tap this sum writes (T, 0 but for a tap row of a 5x5 kernel)
   int ps, SL, OT, CT, T, O, C;
   int nvb;                      // virtual blocks: ceil(OT*CT*T*256 / (256 / SL)); 0 = nothing to do
 };
@@ -1485,6 +1486,7 @@ struct GDesc {
   unsigned m_br, m_xc, m_xi, m_dc, m_di;
   int single, kind, ps, CT, OT;
   int wg_end;                // workgroups of layers 0..this one (exclusive end of this layer's range)
+  int tap_row0;              // kind 13 (one tap row of a 5x5 kernel per entry): the tap row
   int direct;                // operands straight from global memory (units = units per block, m_br = magic(oh / UR))
   const float* dy2;          // direct, 3x3 / stride 2 only, or nullptr: dY of the block's 1x1 shortcut, whose weight
   float* slabs2;             //   gradient this layer's workgroups compute too (group_flush pairs the two queue entries)
@@ -1593,19 +1595,25 @@ struct WgUnit {
 // lane already holds for those four pixels.  So nothing about the loads or the registers changes: four fp32 operands are
 // packed into two registers and ONE instruction of 32 cycles replaces four of 64.  A column outside the image is a zero
 // operand (the fp32 body skips the instruction).
-template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP, bool PAIR, bool BN, bool BF = false>
+// KR (round 6; default KS: the whole kernel): tap ROWS this call computes.  A 5x5 kernel's 25 accumulator tiles do not fit a wave's
+// registers, so its weight gradient is queued as five entries of one tap row each (KR = 1, d.tap_row0 = 0 .. 4): five
+// accumulators, per unit one row of dY and ONE source row (the row the tap row reads), the same MFMAs-per-load balance as the 3x3
+// body; the slab sum writes each entry's five taps into its row of the (O, C, 5, 5) tensor.
+template <int KS, int PAD, int STRIDE, int W, int OW, int UR, int NP, bool PAIR, bool BN, bool BF = false, int KR = KS>
 __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, const int bx, const int by,
                                                   const int bz) {
+  static_assert(KR == KS || (KR == 1 && !PAIR), "a call computes the whole kernel or one tap row");
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   static_assert(!PAIR || (KS == 3 && STRIDE == 2 && PAD == 1), "the shortcut rides on the 3x3 / stride-2 body");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  constexpr int T = KS * KS, NW = kRowsWaves;
-  constexpr int NXR = (UR - 1) * STRIDE + KS;
+  constexpr int T = KR * KS, NW = kRowsWaves;
+  constexpr int NXR = (UR - 1) * STRIDE + KR;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int H = d.H, oh = d.oh;
+  const int row0 = KR == KS ? 0 : d.tap_row0;      // (a one-row call: the tap row it computes)
   const int upr = oh / UR;                         // units per group of NP image pairs
   const int rot = (upr & (upr - 1)) == 0 ? upr - 1 : 0;
   const int rsh = upr == 2 ? 1 : 0;
@@ -1655,7 +1663,7 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
   // the youngest load.
   constexpr int VA = OW % 4 == 0 ? 4 : 2, VB = W % 4 == 0 ? 4 : 2;
   constexpr int PA = UR * (OW / VA), PBR = W / VB;
-  constexpr int NUSED = wg_used_rows<KS, STRIDE, UR>();
+  constexpr int NUSED = wg_used_rows<KR, STRIDE, UR>();
   constexpr int PA2 = PAIR ? 2 * PA : PA;                   // (PAIR: the shortcut's dY rows follow the convolution's)
   constexpr int PAZ = BN ? PA2 : 0;                         // (BN: then the BatchNorm inputs under both)
   constexpr int PPP = PA2 + PAZ + NUSED * PBR;              // pieces per pair
@@ -1705,7 +1713,7 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
       }
     } else {
       // the kk-th used source row
-      const int xr = wg_nth_used_row<KS, STRIDE, UR>((kk - PA2 - PAZ) / PBR);
+      const int xr = wg_nth_used_row<KR, STRIDE, UR>((kk - PA2 - PAZ) / PBR);
       const int q = (kk - PA2 - PAZ) % PBR;
       const int row = min(max(un.rs + xr, 0), H - 1);
       const unsigned so = un.xbase + (unsigned)p * xpair + (unsigned)(row * W * 4);
@@ -1727,7 +1735,7 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
     ri -= ri >= upr ? upr : 0;
     const int r = ri * UR;
     WgUnit un;
-    un.rs = r * STRIDE - PAD;
+    un.rs = r * STRIDE - PAD + row0;
     un.ybase = (unsigned)pg * (unsigned)NP * ypair + (unsigned)(r * OW * 4);
     un.xbase = (unsigned)pg * (unsigned)NP * xpair;
     return un;
@@ -1738,7 +1746,7 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
   const bool affine = d.aff != nullptr;
   float aff_sc = 1.0f, aff_sh = 0.0f;
   if (affine) { aff_sc = d.aff[2 * (by * 32 + l31)]; aff_sh = d.aff[2 * (by * 32 + l31) + 1]; }
-  constexpr int NIT = NP * UR * KS * OW;                     // (pair, ur, i, s) iterations of a unit, <= KS MFMAs each
+  constexpr int NIT = NP * UR * KR * OW;                     // (pair, ur, i, s) iterations of a unit, <= KS MFMAs each
   // MFMAs of the unit in `c` (rows from cu.rs), the pieces of unit `nu` into `n` on the way
   auto compute = [&](Ops& c, const WgUnit& cu, Ops& n, const WgUnit& nu) {
 #ifdef DFHIP_STAMPS
@@ -1750,7 +1758,7 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
 #pragma unroll
       for (int ur = 0; ur < UR; ur++) {
 #pragma unroll
-        for (int i = 0; i < KS; i++) {
+        for (int i = 0; i < KR; i++) {
           // (a scalar branch per tap row even where the unit is the whole plane and the answer is known at compile time: as one
           // basic block the unit of a 2 x 2 plane took 50 600 cycles per workgroup against 44 700 -- same box, -DDFHIP_STAMPS)
           const bool rowok = (unsigned)(cu.rs + ur * STRIDE + i) < (unsigned)H;
@@ -1764,14 +1772,14 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
               }
             }
           }
-          if (affine && (ur == 0 || i + STRIDE >= KS)) {     // first use of source row ur * STRIDE + i
+          if (affine && (ur == 0 || i + STRIDE >= KR)) {     // first use of source row ur * STRIDE + i
 #pragma unroll
             for (int cc = 0; cc < W; cc++) c.b[p][ur * STRIDE + i][cc] = fmaf(c.b[p][ur * STRIDE + i][cc], aff_sc, aff_sh);
           }
           if constexpr (BF && OW % 4 == 0) {
 #pragma unroll
             for (int s4 = 0; s4 < OW; s4 += 4) {
-              const int it0 = ((p * UR + ur) * KS + i) * OW + s4;
+              const int it0 = ((p * UR + ur) * KR + i) * OW + s4;
 #pragma unroll
               for (int k = (it0 * NPIECE + NIT - 1) / NIT; k < ((it0 + 4) * NPIECE + NIT - 1) / NIT; k++) piece(n, nu, k);
               __builtin_amdgcn_sched_barrier(0);
@@ -1803,7 +1811,7 @@ __device__ __forceinline__ void wgrad_rows_direct(const GDesc& d, float* smem, c
           } else
 #pragma unroll
           for (int s = 0; s < OW; s++) {
-            const int it = ((p * UR + ur) * KS + i) * OW + s;
+            const int it = ((p * UR + ur) * KR + i) * OW + s;
             // pieces k with floor(k * NIT / NPIECE) == it
 #pragma unroll
             for (int k = (it * NPIECE + NIT - 1) / NIT; k < ((it + 1) * NPIECE + NIT - 1) / NIT; k++) piece(n, nu, k);
@@ -1955,6 +1963,9 @@ __device__ __forceinline__ void wgrad_group_body(const WGroup& a, float* smem) {
     break;
     DF_ROWS_KINDS(DF_CASE)
 #undef DF_CASE
+    case 13:      // one tap row of a 5x5 / stride 1 / pad 2 kernel on 16 x 16 planes (queue_wgrad_k5)
+      wgrad_rows_direct<5, 2, 1, 16, 16, 1, 1, false, false, BF, 1>(d, smem, bx, by, bz);
+      break;
     default: break;
   }
 #ifdef DFHIP_STAMPS
@@ -2037,7 +2048,7 @@ __device__ __forceinline__ void wgrad_group_sum_body(const SlabSum& d, const int
 #pragma unroll
       for (int e = 0; e < 4; e++)
         if (o + e < d.O) {
-          float* dst = d.dw + ((int64_t)(o + e) * d.C + c) * TT;
+          float* dst = d.dw + ((int64_t)(o + e) * d.C + c) * d.tstride + d.toff;
 #pragma unroll
           for (int t = 0; t < TT; t++)
             dst[t] = e == 0 ? acc[t].x : (e == 1 ? acc[t].y : (e == 2 ? acc[t].z : acc[t].w));
@@ -2068,6 +2079,7 @@ __global__ __launch_bounds__(256) void k_wgrad_group_sum(SGroup a) {
   const SlabSum& d = a.s[li];
   const int vb = b - (li ? a.vb_end[li - 1] : 0);
   if (d.T == 9) wgrad_group_sum_body<9>(d, vb, part);
+  else if (d.T == 5) wgrad_group_sum_body<5>(d, vb, part);
   else wgrad_group_sum_body<1>(d, vb, part);
 }
 
@@ -2321,6 +2333,7 @@ DeferredSum g_def;
 SlabSum make_slab_sum(const float* slabs, float* dw, int ps, int OT, int CT, int T, int O, int C) {
   SlabSum a;
   a.slabs = slabs; a.dw = dw; a.ps = ps; a.OT = OT; a.CT = CT; a.T = T; a.O = O; a.C = C;
+  a.tstride = T; a.toff = 0;
   a.SL = 1;                                       // slices: at most eight slabs per thread
   while (a.SL < 256 && a.SL * 8 < ps) a.SL *= 2;
   a.nvb = (int)df_ceil_div((int64_t)OT * CT * T * 256, 256 / a.SL);
@@ -2404,6 +2417,7 @@ struct GQueued {
   double flops, bytes;
   double work;                   // estimated cycles of one of its workgroups (set by group_flush)
   int rides_on;                  // -1, or the queue index of the 3x3 / stride-2 layer whose workgroups compute this 1x1 shortcut too
+  int tstride, toff;             // (kind 13) the slab sum's record stride and first tap in dw; 0, 0 = T, 0
   int W, ow, k, stride, pad;     // the rest of the call's arguments (a small group is re-planned as stand-alone launches)
 };
 std::vector<GQueued> g_queue;
@@ -2438,8 +2452,8 @@ float* g_group_slabs = nullptr;                   // slab area supplied by the s
 // stream (first operands, cross-wave sum, slab stores).  (Cutting every layer to a common cycle target instead of 32
 // workgroups per layer was measured in round 3: the shorter tail came back as prologues / epilogues of the extra workgroups.)
 static double replan_direct(const GQueued& e) {
-  static const double kUnitCycles[13] = {9260, 8720, 7640, 5560, 4780, 4680, 4490, 9400, 7200, 2840, 19000, 9800, 9400};
-  const double unit_cycles = e.d.kind >= 0 && e.d.kind < 13 ? kUnitCycles[e.d.kind] : 5000.0;
+  static const double kUnitCycles[14] = {9260, 8720, 7640, 5560, 4780, 4680, 4490, 9400, 7200, 2840, 19000, 9800, 9400, 5600};
+  const double unit_cycles = e.d.kind >= 0 && e.d.kind < 14 ? kUnitCycles[e.d.kind] : 5000.0;
   return e.d.units / 4 * unit_cycles + 14000.0;
 }
 
@@ -2460,6 +2474,7 @@ int group_flush() {
       g_group_on = false;
       int st = DFHIP_OK;
       for (auto& e : q) {
+        if (e.d.kind == 13 && e.d.tap_row0 > 0) continue;      // (a 5x5 kernel's five entries: the general path computes all rows)
         const float* edy = e.d.dy;
         float* tmp = nullptr;
         if (e.d.bnz) {                              // the pending BatchNorm backward written out once
@@ -2559,6 +2574,7 @@ int group_flush() {
         wg.d[nl++] = e.d;
       }
       sg.s[i] = make_slab_sum(e.d.slabs, e.dw, e.d.ps, e.d.OT, e.d.CT, e.T, e.d.O, e.d.C);
+      if (e.tstride) { sg.s[i].tstride = e.tstride; sg.s[i].toff = e.toff; }
       // tap-major items: (tile, q, lane) positions, 256 / SL of them per block
       sg.s[i].SL = 1;
       while (sg.s[i].SL < 8 && sg.s[i].SL * 2 <= e.d.ps) sg.s[i].SL *= 2;
@@ -2708,8 +2724,38 @@ int side_join() {
 }
 
 // returns -1 when the shape is not one the row-unit kernel is built for
+// 5x5 / stride 1 / pad 2 on 16 x 16 planes inside a group (the CNN workload's conv2, test/CNN_CIFAR10_cuda.py:66): five queue
+// entries, one tap row each (wgrad_rows_direct<.., KR = 1>), cut so that the five together are about one workgroup per CU
+static int queue_wgrad_k5(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow) {
+  const int CT = C / 32, OT = O / 32;
+  const int upr = oh, U = (N / 2) * upr;                       // UR = 1, NP = 1
+  const int want = std::max(1, (num_cus() * 7 / 8) / (5 * CT * OT));
+  int upb = (int)df_ceil_div(U, want);
+  upb = std::max(4, (upb + 3) & ~3);
+  for (int i0 = 0; i0 < 5; i0++) {
+    GQueued e = {};
+    GDesc& d = e.d;
+    d.x = x; d.dy = dy; d.slabs = nullptr;
+    d.N = N; d.C = C; d.H = H; d.O = O; d.oh = oh;
+    d.kind = 13; d.direct = 1; d.CT = CT; d.OT = OT; d.tap_row0 = i0;
+    d.units = upb;
+    d.ps = (int)df_ceil_div(U, upb);
+    d.m_br = magic_u32((unsigned)upr);
+    e.dw = dw; e.T = 5; e.tstride = 25; e.toff = 5 * i0;
+    e.lds = (size_t)3 * kRowsWaves * 4 * 64 * 16;
+    e.flops = 2.0 * N * oh * ow * (double)C * 5 * O;
+    e.bytes = 4.0 * ((double)N * C * H * W + (double)O * C * 25 + (double)N * O * oh * ow) / 5.0;
+    e.W = W; e.ow = ow; e.k = 5; e.stride = 1; e.pad = 2;
+    g_queue.push_back(e);
+  }
+  return DFHIP_OK;
+}
+
 int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
                    int k, int stride, int pad, const float* aff, const float* bnz, const float* bntab) {
+  if (g_group_on && !g_group_stream && k == 5 && stride == 1 && pad == 2 && H == 16 && W == 16 && oh == 16 && ow == 16 &&
+      C % 32 == 0 && O % 32 == 0 && N % 2 == 0 && !aff && !bnz && g_queue.size() + 5 <= (size_t)kMaxGroup)
+    return queue_wgrad_k5(x, dy, dw, N, C, H, W, O, oh, ow);
   if (aff && !g_group_on) return -1;        // the affine operand exists in the grouped direct body only
   if (bnz && (!g_group_on || W > 16)) return -1;   // so does the BatchNorm-backward operand (planes up to 16 wide)
   if (C < 16 || (N & 1)) return -1;
@@ -3087,7 +3133,7 @@ bool deferred_touches(const void* p) {
       if ((const float*)p >= r.first && (const float*)p < r.second) return true;
   const float* q = (const float*)p;
   for (const auto& e : g_queue)
-    if (q >= e.dw && q < e.dw + (int64_t)e.d.O * e.d.C * e.T) return true;
+    if (q >= e.dw && q < e.dw + (int64_t)e.d.O * e.d.C * (e.tstride ? e.tstride : e.T)) return true;
   if (!g_def.active) return false;
   const float* lo = g_def.a.dw;
   return q >= lo && q < lo + (int64_t)g_def.a.O * g_def.a.C * g_def.a.T;

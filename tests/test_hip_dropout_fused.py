@@ -71,3 +71,52 @@ def test_5x5_overwrite_input_gradient_on_the_one_tap_kernels(hip_device, name):
     cond = R.conv2d_dgrad(np.abs(dy), np.abs(w), (N, C, H, W), 1, 2, "overwrite")
     err = np.abs(got.astype(np.float64) - want) / np.maximum(cond, 1e-6 * cond.max())
     assert err.max() <= 1e-5, err.max()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("name", ["cnn2_bs256", "c64_o32_bs64"])
+def test_5x5_weight_gradient_as_five_tap_rows_of_the_grouped_launch(hip_device, name, mode):
+    """tensor.py:716 for the CNN workload's conv2 (5x5 / stride 1 / pad 2 on 16 x 16 planes): inside a weight-gradient group the
+    layer is five queue entries of one tap row each (25 accumulator tiles do not fit a wave), the slab sum writes each entry's
+    five taps into its row of the (O, C, 5, 5) tensor; fp32 against the oracle at 1e-4 and element by element against the
+    condition sums, the opt-in bf16 contraction against its measured budget"""
+    mod = hip_device.mod
+    N, C, O = {"cnn2_bs256": (256, 32, 64), "c64_o32_bs64": (64, 64, 32)}[name]
+    H = W = 16
+    rng = np.random.default_rng(41 + N)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    dy = rng.standard_normal((N, O, H, W)).astype(np.float32)
+    x3 = rng.standard_normal((N, 64, 8, 8)).astype(np.float32)          # conv3 of the CNN rides in the same group
+    dy3 = rng.standard_normal((N, 128, 8, 8)).astype(np.float32)
+
+    def arr(a):
+        h = mod.Array(a.size)
+        mod.from_numpy(a, h)
+        return h
+    xh, dyh, dwh = arr(x), arr(dy), mod.Array(O * C * 25)
+    x3h, dy3h, dw3h = arr(x3), arr(dy3), mod.Array(128 * 64 * 9)
+    mod.conv_matmul_dtype = mode
+    try:
+        mod.prof_reset(); mod.prof_enable(True)
+        assert mod.wgrad_group_begin()
+        mod.conv2d_wgrad(xh, dyh, dwh, N, C, H, W, O, 5, 1, 2)
+        mod.conv2d_wgrad(x3h, dy3h, dw3h, N, 64, 8, 8, 128, 3, 1, 1)
+        mod.wgrad_group_end()
+        mod.synchronize(); mod.prof_enable(False)
+    finally:
+        mod.conv_matmul_dtype = "f32"
+    fams = {f: v["calls"] for f, v in mod.prof_read().items() if v["calls"]}
+    fam = "conv2d_wgrad_grouped_bf16" if mode == "bf16" else "conv2d_wgrad_grouped"
+    assert fams.get(fam) == 1 and "conv2d_wgrad_igemm" not in fams, fams
+    got = mod.to_numpy(dwh, (dwh.size,), (1,), 0).reshape(O, C, 5, 5).astype(np.float64)
+    want = R.conv2d_wgrad(x, dy, 5, 1, 2).astype(np.float64)
+    cond = R.conv2d_wgrad(np.abs(x), np.abs(dy), 5, 1, 2).astype(np.float64)
+    err = np.abs(got - want) / np.maximum(cond, 1e-6 * cond.max())
+    got3 = mod.to_numpy(dw3h, (dw3h.size,), (1,), 0).reshape(128, 64, 3, 3)
+    if mode == "f32":
+        assert_close(got, want, 1e-4, name)
+        assert err.max() <= 1e-5, err.max()
+        assert_close(got3, R.conv2d_wgrad(x3, dy3, 3, 1, 1), 1e-4, name + " conv3")
+    else:
+        K = N * H * W
+        assert 3e-7 < err.max() <= 8.0 * 2.0 ** -8 / np.sqrt(K), err.max()
