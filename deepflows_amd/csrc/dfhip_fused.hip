@@ -1562,19 +1562,32 @@ __device__ __forceinline__ void adam_block(const TensorBatch& tb, const AdamHype
   float* v = tb.s2[t];
   const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
   int64_t i = lo + threadIdx.x;
-  if (vec) {
-    const int64_t hi4 = lo + ((hi - lo) & ~(int64_t)3);
-    for (int64_t j = lo + 4 * (int64_t)threadIdx.x; j < hi4; j += 4 * kThreads) {
-      float4 pv = *reinterpret_cast<float4*>(p + j), mv = *reinterpret_cast<float4*>(m + j);
-      float4 vv = *reinterpret_cast<float4*>(v + j);
-      const float4 gv = *reinterpret_cast<const float4*>(g + j);
-      adam_element(pv.x, gv.x, mv.x, vv.x, h);
-      adam_element(pv.y, gv.y, mv.y, vv.y, h);
-      adam_element(pv.z, gv.z, mv.z, vv.z, h);
-      adam_element(pv.w, gv.w, mv.w, vv.w, h);
-      *reinterpret_cast<float4*>(p + j) = pv;
-      *reinterpret_cast<float4*>(m + j) = mv;
-      *reinterpret_cast<float4*>(v + j) = vv;
+  const int64_t hi4 = lo + ((hi - lo) & ~(int64_t)3);
+  if (vec && hi4 > lo) {
+    // the block's (up to) four 16-byte pieces per thread and array are requested TOGETHER, in front of a compiler barrier
+    // (round 6): written as a loop, the stores of one trip keep the loads of the next behind them (p, m, v may alias as far as
+    // the compiler knows) -- four dependent round trips per block; and instruction selection sinks plain loads to their uses
+    constexpr int U = kChunk / (4 * kThreads);
+    float4 pv[U], mv[U], vv[U], gv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t jj = min(lo + 4 * ((int64_t)threadIdx.x + (int64_t)u * kThreads), hi4 - 4);   // (clamped: no load under a condition)
+      pv[u] = *reinterpret_cast<const float4*>(p + jj); mv[u] = *reinterpret_cast<const float4*>(m + jj);
+      vv[u] = *reinterpret_cast<const float4*>(v + jj); gv[u] = *reinterpret_cast<const float4*>(g + jj);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t j = lo + 4 * ((int64_t)threadIdx.x + (int64_t)u * kThreads);
+      if (j < hi4) {
+        adam_element(pv[u].x, gv[u].x, mv[u].x, vv[u].x, h);
+        adam_element(pv[u].y, gv[u].y, mv[u].y, vv[u].y, h);
+        adam_element(pv[u].z, gv[u].z, mv[u].z, vv[u].z, h);
+        adam_element(pv[u].w, gv[u].w, mv[u].w, vv[u].w, h);
+        *reinterpret_cast<float4*>(p + j) = pv[u];
+        *reinterpret_cast<float4*>(m + j) = mv[u];
+        *reinterpret_cast<float4*>(v + j) = vv[u];
+      }
     }
     i = hi4 + threadIdx.x;                         // the (< 4 element) tail
   }
