@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64 * NW * kKS) void k_mlp2_fwd(
 }
 
 // ---- the forward pass as TWO launches (the default from 64 rows on): every workgroup of the one-launch kernel above streams
-// all of W1 (803 KB for 784 -> 256) through its CU -- 17.8 us, whatever the round size (DFHIP_MLP_R) --, and nothing but a
+// all of W1 (803 KB for 784 -> 256) through its CU -- 17.8 us, whatever the depth of its prefetch --, and nothing but a
 // split of the hidden units or of K over workgroups shortens that, which puts fc2 (all hidden units of a row) behind a
 // launch boundary.  k_mlp_fc1: z = x . W1 + b1, a 16 x 16 tile per workgroup (128 workgroups at 128 x 256), its four waves a
 // quarter of K each, every operand requested up front; k_mlp2_tail: relu, fc2, cross-entropy, d loss / d logits,
@@ -492,12 +492,11 @@ int dfhip_mlp2_ce_forward(const float* x, const float* w1, const float* b1, cons
 #define DF_FWD(NWV, RV)                                                                                                 \
   DF_LAUNCH((k_mlp2_fwd<NWV, RV>), grid, dim3(64 * NWV * kKS), (size_t)4 * K * sizeof(float), stream(), x, w1, b1, w2, b2, \
             target, zpre, h, logits, dlogits, dz1, rowloss, M, K, P, inv_rows)
-  static int rsel = -1;                              // (experiment: DFHIP_MLP_R = 16 / 20 / 24)
-  if (rsel < 0) rsel = getenv("DFHIP_MLP_R") ? atoi(getenv("DFHIP_MLP_R")) : 16;
+  // (16 k per round.  Rounds of 20 and 24 -- deeper prefetch, up to the 128 registers a 1 024-thread workgroup allows -- were
+  // measured in round 6: 17.8 / 17.5 / 18.5 us; rounds of 28 spill: 26.9 us.  The launch is bound by its W1 stream, not by
+  // the depth of the prefetch.)
   if (HD == 64) DF_FWD(1, 16);
   else if (HD == 128) DF_FWD(2, 16);
-  else if (rsel == 20) DF_FWD(4, 20);
-  else if (rsel == 24) DF_FWD(4, 24);
   else DF_FWD(4, 16);
 #undef DF_FWD
   DF_LAUNCH_CHECK();
