@@ -50,7 +50,9 @@ def _steps(dev, sizes, x_np, y_np, steps, read_hidden=False, x_grad=False):
 
 
 CASES = {"mnist_784_256_10_bs128": ((784, 256, 10), 128), "ragged_48_64_7_bs37": ((48, 64, 7), 37),
-         "hidden128_bs256": ((160, 128, 16), 256), "bs1030": ((32, 64, 10), 1030)}
+         "hidden128_bs256": ((160, 128, 16), 256), "bs1030": ((32, 64, 10), 1030),
+         # below 64 rows the forward pass is ONE launch (k_mlp2_fwd): every hidden width of it
+         "one_launch_hidden128_bs48": ((64, 128, 10), 48), "one_launch_hidden256_bs40": ((784, 256, 10), 40)}
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -73,6 +75,7 @@ def test_mlp_step_is_one_launch_each_way(hip_device, cpu_oracle, name):
     for i, (a, b) in enumerate(zip(got["params"], want["params"])):
         assert_close(a, b, 1e-4, f"{name} param {i} after 3 SGD steps")
     assert fams.get("mlp2_ce_fwd") == 3 and fams.get("mlp2_ce_bwd") == 3, fams
+    assert fams.get("mlp_fc1_fwd") == (3 if M >= 64 else None), fams      # (two launches forward from 64 rows on)
     assert "gemm_mfma_f32" not in fams and "softmax_ce_fwd" not in fams and "loss_finish" not in fams, fams
 
 
