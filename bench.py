@@ -104,8 +104,9 @@ def build_job(workload, dev, rank, batch, register_blocks=True, model_kind="plai
 
 OTHER_CONFIGURATIONS = (("cnn_cifar10_bs256", "cnn", "overwrite", "f32"), ("mlp_mnist_bs128", "mlp", "overwrite", "f32"),
                         ("resnet18_bs256_accumulate_dgrad", "resnet18", "accumulate", "f32"),
-                        # opt-in reduced precision: bf16 operands in the weight gradients' matrix products
-                        ("resnet18_bs256_bf16_weight_gradients", "resnet18", "overwrite", "bf16"))
+                        # opt-in reduced precision: bf16 operands in the layer1-2 forward convolutions' and the weight
+                        # gradients' matrix products
+                        ("resnet18_bs256_bf16_contractions", "resnet18", "overwrite", "bf16"))
 
 
 def other_configurations(steps, timeout_s=150.0):
@@ -376,7 +377,8 @@ def main():
                     help="conv input-gradient mode: reference-exact (default) or mathematically correct")
     ap.add_argument("--matmul-dtype", choices=["f32", "bf16"], default="f32",
                     help="opt-in (never the headline, outside the 1e-4 parity contract): bf16 operands with fp32 accumulation in "
-                         "the convolution weight gradients' matrix products (HipModule.conv_matmul_dtype)")
+                         "the register-operand forward convolutions' and the grouped weight gradients' matrix products "
+                         "(HipModule.conv_matmul_dtype)")
     ap.add_argument("--registration", choices=["all", "f6"], default="all",
                     help="all = every block registered (62 tensors); f6 = the reference script's 5 tensors")
     ap.add_argument("--model", choices=["plain", "fused"], default="plain",
@@ -719,7 +721,7 @@ def main():
             "metric": wl["metric"],
             "value": value, "unit": "samples/s" if args.workload == "mlp" else "images/s", "n_gpus": comm.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.matmul_dtype == "f32" else "bf16 operands / f32 accumulation in the weight gradients, f32 elsewhere", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.matmul_dtype == "f32" else "bf16 operands / f32 accumulation in the layer1-2 forward convolutions and the grouped weight gradients, f32 elsewhere", "data": "synthetic",
             "config": {"workload": wl["text"],
                        "global_batch": batch * comm.world, "batch_per_gpu": batch, "parallelism": f"dp{comm.world}",
                        "settle_replays_untimed": settle_replays, "conv_dgrad": args.dgrad, "conv_matmul_dtype": args.matmul_dtype, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,

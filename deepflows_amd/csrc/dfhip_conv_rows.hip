@@ -84,11 +84,19 @@ __device__ unsigned long long g_rows_stamps[512 * 8 * 8];
 // fma(raw, scale, shift) on its way out of the load registers -- the normalised tensor is never written or read.
 // (Combining the partials inside this kernel instead -- every workgroup for itself, 100 KB of rows each -- cost
 // 2-3.7 us per launch: 256 workgroups pulling the same lines through L2 at the same moment.)
-template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, bool DG, bool BNI>
+// BF (opt-in, dfhip_set_conv_matmul_dtype(1); outside the 1e-4 parity contract; forward only): the contraction on
+// v_mfma_f32_16x16x16_bf16, fp32 accumulators.  A weight chunk is CG = 4 channel groups = 16 source channels = the K of ONE bf16
+// instruction, and in its operand layout lane (m, kk) supplies k = 4 kk .. 4 kk + 3 -- with k = 4 kk + e standing for channel
+// 4 (p0 + e) + kk these are the four values the lane holds for the chunk's four groups in the fp32 kernel.  So the loads, the
+// BatchNorm operand transform, the lane shifts and the weight staging are the fp32 kernel's; the four groups' operands of a
+// tap are rounded (nearest even) into two registers and one instruction of 16 cycles replaces four of 32.
+template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, bool DG, bool BNI, bool BF = false>
 __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        float* __restrict__ partials, int H, int O, BnInput bn) {
   static_assert(TS * OW == 8, "a workgroup is eight waves");
+  static_assert(!BF || (CG == 4 && !VDPP && !DG), "the bf16 contraction: a chunk is one K = 16, forward, rows of 8 / 16 pixels");
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float Wl[];   // [OW][C/4*9/4 blocks][64 lanes][4] at pitch kBlk
   __shared__ float sred[8][16][2];
   __shared__ __attribute__((aligned(8))) float bn_tab[BNI ? C : 1][2];
@@ -380,6 +388,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
     bn_apply(nr, raw[0], tabr[0]);
     make_shifts(bsh[0], nr);
   }
+  float bfc[BF && LW == 4 ? 3 : 1][BF && LW == 4 ? NT + 2 : 1][BF && LW == 4 ? CG : 1];              // bf16: (column variant, row, group)
+  float bfb[BF && LW != 4 ? NT : 1][BF && LW != 4 ? 3 : 1][BF && LW != 4 ? 3 : 1][BF && LW != 4 ? CG : 1]; // (tile, tap row, tap column, group)
 #pragma unroll
   for (int ch = 0; ch < NCH; ch++) {
     // chunk ch + 1 (requested a chunk ago) is committed now and made visible by a barrier in the MIDDLE of this
@@ -402,7 +412,47 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
         if (p + 2 < NG) tabr[p + 2] = *reinterpret_cast<const f32x2*>(&bn_tab[4 * (p + 2) + kk][0]);
       }
       // the nine pixel operands of every tile from this group's registers
-      if constexpr (LW == 4) {
+      if constexpr (BF) {
+        // bf16: the group's operands are made as in the fp32 kernel and kept; the chunk's last group packs the four
+        // groups' values of every (tile, tap) and issues the chunk's 9 NT instructions
+        float nr[NL];
+        bn_apply(nr, raw[p], tabr[BNI ? p : 0]);
+        if constexpr (LW == 4) {
+#pragma unroll
+          for (int r = 0; r < NT + 2; r++) {
+            bfc[1][r][g] = nr[r];
+            bfc[0][r][g] = dpp_mov<kShr1>(nr[r]);
+            bfc[2][r][g] = dpp_mov<kShl1>(nr[r]);
+          }
+        } else {
+          float bl[NT][3][3];
+          make_shifts(bl, nr);
+#pragma unroll
+          for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+              for (int j = 0; j < 3; j++) bfb[t][i][j][g] = bl[t][i][j];
+        }
+        if (g == CG - 1) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+              const int t9 = i * 3 + j;
+              const bf16x4 pa = {(__bf16)a4[ch & 1][(0 * 9 + t9) >> 2][(0 * 9 + t9) & 3], (__bf16)a4[ch & 1][(1 * 9 + t9) >> 2][(1 * 9 + t9) & 3],
+                                 (__bf16)a4[ch & 1][(2 * 9 + t9) >> 2][(2 * 9 + t9) & 3], (__bf16)a4[ch & 1][(3 * 9 + t9) >> 2][(3 * 9 + t9) & 3]};
+#pragma unroll
+              for (int t = 0; t < NT; t++) {
+                bf16x4 pb;
+                if constexpr (LW == 4) pb = (bf16x4){(__bf16)bfc[j][t + i][0], (__bf16)bfc[j][t + i][1], (__bf16)bfc[j][t + i][2], (__bf16)bfc[j][t + i][3]};
+                else pb = (bf16x4){(__bf16)bfb[t][i][j][0], (__bf16)bfb[t][i][j][1], (__bf16)bfb[t][i][j][2], (__bf16)bfb[t][i][j][3]};
+                acc[t][t9 % NCN] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pb, acc[t][t9 % NCN], 0, 0, 0);
+              }
+            }
+          }
+        }
+      } else if constexpr (LW == 4) {
         float c1[NT + 2], c0[NT + 2], c2[NT + 2], nr[NL];
         bn_apply(nr, raw[p], tabr[BNI ? p : 0]);
 #pragma unroll
@@ -530,7 +580,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_rowmma(const float* __restrict_
   RS_STAMP(7);
 }
 
-template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, bool DG = false, bool BNI = false>
+template <int LW, int C, int NT, bool VDPP, int TS, int OW, int CG, bool DG = false, bool BNI = false, bool BF = false>
 int launch_rowmma(const float* x, const float* w, const float* bias, float* y, float* partials, int H, int O,
                   dim3 grid, const BnInput* bnp = nullptr) {
   BnInput bn = {};
@@ -538,11 +588,11 @@ int launch_rowmma(const float* x, const float* w, const float* bias, float* y, f
   const size_t lds = (size_t)OW * (C / 4 * 9 / 4) * kBlk * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, DG, BNI>,
+    DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, DG, BNI, BF>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, (size_t)65536)));
     attr = true;
   }
-  DF_LAUNCH((k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, DG, BNI>), grid, dim3(512), lds, stream(), x, w, bias, y,
+  DF_LAUNCH((k_conv3x3_rowmma<LW, C, NT, VDPP, TS, OW, CG, DG, BNI, BF>), grid, dim3(512), lds, stream(), x, w, bias, y,
                      partials, H, O, bn);
   DF_LAUNCH_CHECK();
 #ifdef DFHIP_ROWS_STAMPS
@@ -882,12 +932,18 @@ int run_conv_rowmma(const float* x, const float* w, const float* bias, float* y,
   if (rows_out) *rows_out = partials ? (int)gx : 0;
   dim3 grid((unsigned)gx, (unsigned)(O / (16 * ow)));
   if (dry_run) return DFHIP_OK;              // eligible: nothing launched
+  // opt-in bf16 contraction (dfhip_set_conv_matmul_dtype(1)): the eight-tile-set forms of the 16- and 8-wide layers
+  const bool bf = conv_matmul_dtype_is_bf16() && wide;
   if (bn) {
     if (!bn->affine) return -1;
+    if (W == 16 && bf) return launch_rowmma<4, 32, 4, false, 8, 1, 4, false, true, true>(x, w, bias, y, partials, H, O, grid, bn);
+    if (W == 8 && bf) return launch_rowmma<3, 64, 2, false, 8, 1, 4, false, true, true>(x, w, bias, y, partials, H, O, grid, bn);
     if (W == 16) return launch_rowmma<4, 32, 4, false, 8, 1, 4, false, true>(x, w, bias, y, partials, H, O, grid, bn);
     if (W == 8) return launch_rowmma<3, 64, 2, false, 8, 1, 4, false, true>(x, w, bias, y, partials, H, O, grid, bn);
     return launch_rowmma<2, 128, 1, true, 8, 1, 8, false, true>(x, w, bias, y, partials, H, O, grid, bn);
   }
+  if (W == 16 && bf) return launch_rowmma<4, 32, 4, false, 8, 1, 4, false, false, true>(x, w, bias, y, partials, H, O, grid);
+  if (W == 8 && bf) return launch_rowmma<3, 64, 2, false, 8, 1, 4, false, false, true>(x, w, bias, y, partials, H, O, grid);
   if (W == 16) return wide ? launch_rowmma<4, 32, 4, false, 8, 1, 4>(x, w, bias, y, partials, H, O, grid)
                            : launch_rowmma<4, 32, 4, false, 4, 2, 4>(x, w, bias, y, partials, H, O, grid);
   if (W == 8) return wide ? launch_rowmma<3, 64, 2, false, 8, 1, 4>(x, w, bias, y, partials, H, O, grid)

@@ -3149,6 +3149,7 @@ bool head_grads_defer(const HeadGrads& h) {
   g_head_pending.active = true;
   return true;
 }
+bool conv_matmul_dtype_is_bf16() { return g_matmul_dtype == 1; }
 bool stem_combine_defer(const StemCombine& c, int blocks) {
   if (!group_collecting() || g_stem_pending.active) return false;
   g_stem_pending.c = c;

@@ -139,9 +139,10 @@ class HipModule:
         self.device_name = buf.value.decode()
         self.conv_dgrad_mode = "overwrite"   # reference-exact col2im; "accumulate" = true gradient
 
-    # Opt-in reduced precision of the convolution weight gradients' matrix products (outside the 1e-4
-    # parity contract, never the default): "f32" = the reference's arithmetic, "bf16" = bf16 operands, fp32 accumulation
-    # (dfhip_set_conv_matmul_dtype).  Everything else computes in fp32 either way.
+    # Opt-in reduced precision of the matrix products of the layer1-2 forward convolutions and of the grouped convolution
+    # weight gradients (outside the 1e-4 parity contract, never the default): "f32" = the reference's
+    # arithmetic, "bf16" = bf16 operands, fp32 accumulation (dfhip_set_conv_matmul_dtype).  Everything else computes in fp32
+    # either way.
     @property
     def conv_matmul_dtype(self):
         return "bf16" if self._lib.dfhip_conv_matmul_dtype() == 1 else "f32"

@@ -189,11 +189,12 @@ int dfhip_conv2d_wgrad_affine(const float* x, const float* affine, const float* 
                               int N, int C, int H, int W, int O, int k, int stride, int pad);
 
 /* Opt-in reduced-precision contraction (OUTSIDE the 1e-4 parity contract, never the default): dtype 1 =
- * the operands of the convolution weight gradients' matrix products are rounded to bf16 (nearest even) while they are
- * packed, accumulation stays fp32 (v_mfma_f32_32x32x8_bf16).  Applies to the grouped launch (dfhip_wgrad_group_begin /
- * _end) on rows of >= 4 output pixels; everything else -- forward, input gradients, BatchNorm, the optimizer, the layers
- * the bf16 body does not take -- computes in fp32 as before.  dtype 0 = fp32 (the reference's arithmetic,
- * backend_tensor.py:154-158). */
+ * the operands of two kernel families' matrix products are rounded to bf16 (nearest even) while they are packed, accumulation
+ * stays fp32: the grouped convolution weight gradients (dfhip_wgrad_group_begin / _end; v_mfma_f32_32x32x8_bf16, rows of >= 4
+ * output pixels) and the register-operand 3x3 / stride 1 forward convolutions of 16- and 8-wide planes with BatchNorm
+ * statistics or a BatchNorm operand (dfhip_conv2d_forward_stats, dfhip_conv2d_forward_bn_input; v_mfma_f32_16x16x16_bf16).
+ * Everything else -- the other forward kernels, input gradients, BatchNorm, the optimizer -- computes in fp32 as before.
+ * dtype 0 = fp32 (the reference's arithmetic, backend_tensor.py:154-158). */
 int dfhip_set_conv_matmul_dtype(int dtype);
 int dfhip_conv_matmul_dtype(void);
 

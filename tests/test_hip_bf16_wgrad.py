@@ -78,9 +78,61 @@ def test_grouped_weight_gradient_in_bf16_against_the_fp32_oracle(bf16_mode, name
         assert err.max() <= 1e-5           # (rows of 2 output pixels stay on the fp32 body inside the bf16 launch)
 
 
-def test_a_training_step_in_bf16_mode_changes_only_the_weight_gradients(hip_device):
-    """ResNet-18 bs 64, one step in each mode from the same weights: the loss, the logits and every gradient that is not a
-    convolution weight's keep their fp32 bits; the convolution weights' gradients differ by the bf16 budget"""
+@pytest.mark.parametrize("bn_operand", [False, True])
+@pytest.mark.parametrize("name", ["l1", "l2"])
+def test_register_operand_forward_in_bf16_against_the_fp32_oracle(bf16_mode, name, bn_operand):
+    """the layer1 / layer2 forward kernels (k_conv3x3_rowmma<.., BF>: a weight chunk of 16 source channels = the K of one
+    v_mfma_f32_16x16x16_bf16), plain and with the previous BatchNorm applied on the operand loads; budget as above"""
+    mod = bf16_mode.mod
+    C, H, W, O, k, s, p = LAYERS[name]
+    n = 256
+    rng = np.random.default_rng(5 + C)
+    x = rng.standard_normal((n, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((O, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+    xh, wh, yh = _arr(mod, x), _arr(mod, w), mod.Array(n * O * H * W)
+    cap = 512
+    part = mod.Array(cap * O * 3)
+    mod.prof_reset(); mod.prof_enable(True)
+    if not bn_operand:
+        rows = mod.conv2d_forward_stats(xh, wh, None, yh, n, C, H, W, O, 3, 1, 1, part, cap)
+        assert rows > 0
+        xin = x
+    else:
+        # x is the raw output of a previous convolution: its partial rows, then conv(bn(x)) with bn on the operand loads
+        mod.conv_matmul_dtype = "f32"
+        w0 = (rng.standard_normal((C, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+        z0h, part0 = mod.Array(n * C * H * W), mod.Array(cap * C * 3)
+        rows0 = mod.conv2d_forward_stats(xh, _arr(mod, w0), None, z0h, n, C, H, W, C, 3, 1, 1, part0, cap)
+        mod.conv_matmul_dtype = "bf16"
+        z0 = _back(mod, z0h, (n, C, H, W))
+        gamma = rng.uniform(0.5, 1.5, C).astype(np.float32)
+        beta = rng.uniform(-0.5, 0.5, C).astype(np.float32)
+        sm, sv, aff = mod.Array(C), mod.Array(C), mod.Array(2 * C)
+        done, rows = mod.conv2d_forward_bn_input(z0h, part0, rows0, _arr(mod, gamma), _arr(mod, beta), 1e-5, 0.1, sm, sv, None, None,
+                                                 aff, wh, None, yh, n, C, H, W, O, 3, 1, 1, part, cap)
+        assert done and rows > 0
+        mu = z0.mean(axis=(0, 2, 3), dtype=np.float64)
+        var = z0.var(axis=(0, 2, 3), dtype=np.float64)
+        xin = (((z0 - mu[None, :, None, None]) / np.sqrt(var + 1e-5)[None, :, None, None]) * gamma[None, :, None, None]
+               + beta[None, :, None, None]).astype(np.float32)
+    mod.synchronize(); mod.prof_enable(False)
+    kern = [k_ for k_, v in mod.prof_read_kernels().items() if v["launches"]]
+    assert any(k_.startswith("k_conv3x3_rowmma<") and k_.rstrip(">").endswith("true") for k_ in kern), kern   # (the BF instantiation)
+    got = _back(mod, yh, (n, O, H, W)).astype(np.float64)
+    want = R.conv2d_forward(xin, w, None, 1, 1).astype(np.float64)
+    cond = R.conv2d_forward(np.abs(xin), np.abs(w), None, 1, 1).astype(np.float64)
+    err = np.abs(got - want) / np.maximum(cond, 1e-6 * cond.max())
+    K = 9 * C
+    print(f"\n{name} bn_operand={bn_operand}: K = {K}, max |err| / condition = {err.max():.3e} (2^-8 / sqrt(K) = {2.0 ** -8 / np.sqrt(K):.3e}), "
+          f"max|err| / max|y| = {np.abs(got - want).max() / np.abs(want).max():.3e}")
+    assert 3e-7 < err.max() <= 8.0 * 2.0 ** -8 / np.sqrt(K), err.max()
+
+
+def test_a_training_step_in_bf16_mode_stays_inside_its_budget(hip_device):
+    """ResNet-18 bs 256 (the benchmarked job: smaller batches take other forward kernels), one step in each mode from the same
+    weights: the bf16 contractions are the layer1 / layer2 forward
+    convolutions and the grouped weight gradients; loss, logits and every gradient stay within the budget of a chain of
+    bf16-rounded products (measured: loss 1e-4, gradients 1e-2 of their largest element), everything else is fp32"""
     import bench
     from deepflows_amd.tensor import Graph
     mod = hip_device.mod
@@ -88,7 +140,7 @@ def test_a_training_step_in_bf16_mode_changes_only_the_weight_gradients(hip_devi
     for mode in ("f32", "bf16"):
         mod.conv_matmul_dtype = mode
         try:
-            model, opt, crit, xt, yt = bench.build_job("resnet18", hip_device, 0, 64)
+            model, opt, crit, xt, yt = bench.build_job("resnet18", hip_device, 0, 256)
             out = model(xt)
             loss = crit(out, yt)
             opt.zero_grad()
@@ -98,14 +150,23 @@ def test_a_training_step_in_bf16_mode_changes_only_the_weight_gradients(hip_devi
         finally:
             mod.conv_matmul_dtype = "f32"
             Graph.free_graph_all()
-    assert runs["f32"][0] == runs["bf16"][0]
-    changed = 0
+    l32, l16 = runs["f32"][0], runs["bf16"][0]
+    print(f"\nloss f32 {l32:.7f} bf16 {l16:.7f} rel {abs(l16 - l32) / l32:.2e}")
+    # (the reference's mean(axis) divides by the TOTAL element count, SURVEY F5: the pooled features are ~1e-6 of the classifier's
+    # bias, so the loss itself does not feel a 1e-3 perturbation of the features -- the gradients do)
+    assert abs(l16 - l32) / l32 <= 2e-3
+    worst, changed = 0.0, 0
+    # (the scale of a tensor's comparison is its own largest element, floored at 1e-3 of the largest element of any gradient:
+    # behind BatchNorm a per-channel shift is annihilated, so the BatchNorm biases' gradients of the inner blocks are sums that
+    # cancel to ~1e-6 of their terms -- rounding noise in either mode)
+    top = max(float(np.abs(g).max()) for g in runs["f32"][1].values())
     for n_, g32 in runs["f32"][1].items():
         g16 = runs["bf16"][1][n_]
-        if g32.ndim == 4 and g32.shape[1] >= 32:          # a convolution weight the grouped launch takes
-            rel = np.abs(g16 - g32).max() / max(np.abs(g32).max(), 1e-30)
-            assert rel <= 2e-2, (n_, rel)
-            changed += rel > 1e-6
-        else:
-            assert np.array_equal(g16, g32), n_
-    assert changed >= 10, changed
+        rel = np.abs(g16 - g32).max() / max(np.abs(g32).max(), 1e-3 * top)
+        worst = max(worst, rel)
+        changed += rel > 1e-6
+        if rel > 5e-2:
+            print(n_, rel, float(np.abs(g32).max()), top)
+        assert rel <= 5e-2, (n_, rel)
+    print(f"largest gradient difference relative to the tensor's largest element: {worst:.2e}; {changed} tensors differ")
+    assert changed >= 30, changed
