@@ -692,6 +692,9 @@ def main():
                     roofline["executed_flops_per_launch"] = ex
                     roofline["frac_executed"] = ex / (d["avg_us"] * 1e-6) / 1e12 / PEAK_MFMA_F32_TFLOPS
                     roofline["mfma_busy"] = pfam.get("mfma_busy")
+            if args.matmul_dtype == "bf16" and not dom.endswith("_bf16"):
+                roofline["note"] = ("opt-in bf16 mode: this family keeps its fp32 name and peak although the layer1-2 launches of "
+                                    "it run v_mfma_f32_16x16x16_bf16")
             roofline["mfma_clock_mhz_under_load"] = clock_mhz
             roofline["mfma_probe_tflops"] = probe_tflops
             roofline["algorithmic_bytes_per_launch"] = prof[dom]["bytes"] / prof[dom]["calls"]
