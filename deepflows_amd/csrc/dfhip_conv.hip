@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_conv1x1s2_fwd(const float* __restrict__
 template <int C, bool DG = false, bool BNC = false>
 __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
-                                                          float* __restrict__ stats, int O, int xo, BnInput bn) {
+                                                          float* __restrict__ stats, int O, BnInput bn) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
   static_assert(!(DG && BNC), "the BatchNorm operand is a forward form");
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_img2_all(const float* __restric
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, n = lane & 15;
-  const DfTile wg = xcd_tile(xo);               // (image tile, channel tile): XCD-aware order, dfhip_internal.h
+  const DfTile wg = {(int)blockIdx.x, (int)blockIdx.y};          // (image tile, channel tile) in grid order
   const int n0 = wg.x * 16, o0 = wg.y * 16;
   float* Wl = smem + wave * WSL;
   float* Xs = Wl + 72 * WP;
@@ -1450,9 +1450,8 @@ int run_conv_img2(const Geo& g, int O, float* y, const float* bias, float* parti
   dim3 grid4((unsigned)rows4, (unsigned)(O / 16));
   const size_t lds4 = std::max((size_t)8 * (72 * 17 + 16 * 9 * 4), (size_t)7 * 4 * 64 * 4) * sizeof(float);
   // XCD arrangement: blockIdx.y selects 16 output channels' weights, blockIdx.x 16 images' planes
-  const int xo = xcd_arrangement(rows4, O / 16, 4.0 * g.N * g.CS * 4, 4.0 * O * g.CS * 9);
-  if (g.CS == 128) DF_LAUNCH(k_conv3x3_img2_all<128>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, xo, BnInput{});
-  else DF_LAUNCH(k_conv3x3_img2_all<256>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, xo, BnInput{});
+  if (g.CS == 128) DF_LAUNCH(k_conv3x3_img2_all<128>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, BnInput{});
+  else DF_LAUNCH(k_conv3x3_img2_all<256>, grid4, dim3(512), lds4, stream(), g.src, g.wgt, bias, y, partials, O, BnInput{});
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -1469,9 +1468,8 @@ int run_conv_img2_bn(const float* x, const float* w, const float* bias, float* y
   if (dry_run) return DFHIP_OK;
   dim3 grid4((unsigned)rows4, (unsigned)(O / 16));
   const size_t lds4 = std::max((size_t)8 * (72 * 17 + 16 * 9 * 4), (size_t)7 * 4 * 64 * 4) * sizeof(float);
-  const int xo = xcd_arrangement(rows4, O / 16, 4.0 * N * C * 4, 4.0 * O * C * 9);
-  if (C == 128) DF_LAUNCH((k_conv3x3_img2_all<128, false, true>), grid4, dim3(512), lds4, stream(), x, w, bias, y, partials, O, xo, bn);
-  else DF_LAUNCH((k_conv3x3_img2_all<256, false, true>), grid4, dim3(512), lds4, stream(), x, w, bias, y, partials, O, xo, bn);
+  if (C == 128) DF_LAUNCH((k_conv3x3_img2_all<128, false, true>), grid4, dim3(512), lds4, stream(), x, w, bias, y, partials, O, bn);
+  else DF_LAUNCH((k_conv3x3_img2_all<256, false, true>), grid4, dim3(512), lds4, stream(), x, w, bias, y, partials, O, bn);
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }
@@ -1756,9 +1754,8 @@ static int conv2d_dgrad_impl(const float* dy, const float* w, const float* add, 
         (O == 128 || O == 256)) {
       dim3 grid4((unsigned)(N / 16), (unsigned)(C / 16));
       const size_t lds4 = std::max((size_t)8 * (72 * 17 + 16 * 9 * 4), (size_t)7 * 4 * 64 * 4) * sizeof(float);
-      const int xo = xcd_arrangement(N / 16, C / 16, 4.0 * N * O * 4, 4.0 * O * C * 9);
-      if (O == 128) DF_LAUNCH((k_conv3x3_img2_all<128, true>), grid4, dim3(512), lds4, stream(), dy, w, add, dx, (float*)nullptr, C, xo, BnInput{});
-      else DF_LAUNCH((k_conv3x3_img2_all<256, true>), grid4, dim3(512), lds4, stream(), dy, w, add, dx, (float*)nullptr, C, xo, BnInput{});
+      if (O == 128) DF_LAUNCH((k_conv3x3_img2_all<128, true>), grid4, dim3(512), lds4, stream(), dy, w, add, dx, (float*)nullptr, C, BnInput{});
+      else DF_LAUNCH((k_conv3x3_img2_all<256, true>), grid4, dim3(512), lds4, stream(), dy, w, add, dx, (float*)nullptr, C, BnInput{});
       DF_LAUNCH_CHECK();
       return DFHIP_OK;
     }

@@ -660,14 +660,14 @@ template <int C, bool COMB>
 __global__ __launch_bounds__(512) void k_conv3x3_img4_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           float* __restrict__ stats, int O,
-                                                          const float* __restrict__ aff, int xo, BnInput bn) {
+                                                          const float* __restrict__ aff, BnInput bn) {
   constexpr int CW = C / 8, NCHK = CW / 8, WP = 17, XP = 33;      // XP: float4 pitch of an image's strip row
   static_assert(CW == 16, "a wave's channels are one DPP row of the combine below");
   constexpr int WSL = 72 * WP + 16 * XP * 4;                       // floats of a wave's area
   extern __shared__ __attribute__((aligned(16))) float smem_i4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, n = lane & 15;
-  const DfTile wg = xcd_tile(xo);                // XCD-aware order (dfhip_internal.h)
+  const DfTile wg = {(int)blockIdx.x, (int)blockIdx.y};          // (image tile, channel tile) in grid order
   const int n0 = wg.x * 16, o0 = wg.y * 16, h = blockIdx.z;
   float* Wl = smem_i4 + wave * WSL;
   float* Xs = Wl + 72 * WP;
@@ -890,13 +890,12 @@ static int run_conv_img4_fwd(const float* x, const float* w, const float* bias, 
   }
   // blockIdx.y selects 16 output channels' weights, blockIdx.x 16 images' planes (both halves of an image tile are
   // neighbours in z: they share the planes of the middle rows)
-  const int xo = xcd_arrangement(N / 16, O / 16, 4.0 * N * C * 16, 4.0 * O * C * 9);
   if (bn)
     DF_LAUNCH((k_conv3x3_img4_fwd<128, true>), grid, dim3(512), lds, stream(), x, w, bias, y, partials, O,
-              (const float*)bn->affine, xo, *bn);
+              (const float*)bn->affine, *bn);
   else
     DF_LAUNCH((k_conv3x3_img4_fwd<128, false>), grid, dim3(512), lds, stream(), x, w, bias, y, partials, O,
-              bn ? (const float*)bn->affine : (const float*)nullptr, xo, BnInput{});
+              bn ? (const float*)bn->affine : (const float*)nullptr, BnInput{});
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
 }

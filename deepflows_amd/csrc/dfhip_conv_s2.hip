@@ -390,13 +390,13 @@ template <int C>
 __global__ __launch_bounds__(512) void k_conv3x3s2_img4_pair(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ wd, float* __restrict__ y,
                                                              float* __restrict__ yd, float* __restrict__ partials,
-                                                             float* __restrict__ partials_d, int O, int xo) {
+                                                             float* __restrict__ partials_d, int O) {
   constexpr int CW = C / 8, NCHK = CW / 8, WP = 17, XP = 33;
   constexpr int WSL = 72 * WP + 8 * WP + 16 * XP * 4;      // weights [72][17], shortcut weights [8][17], planes [16][33] float4
   extern __shared__ __attribute__((aligned(16))) float smem_p4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, n = lane & 15;
-  const DfTile wg = xcd_tile(xo);                // XCD-aware order (dfhip_internal.h)
+  const DfTile wg = {(int)blockIdx.x, (int)blockIdx.y};          // (image tile, channel tile) in grid order
   const int n0 = wg.x * 16, o0 = wg.y * 16;
   float* Wl = smem_p4 + wave * WSL;
   float* Dl = Wl + 72 * WP;
@@ -727,8 +727,7 @@ int run_conv3x3s2_pair(const float* x, const float* w, const float* wd, float* y
       DF_HIP(hipFuncSetAttribute((const void*)k_conv3x3s2_img4_pair<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
       attr4 = true;
     }
-    const int xo = xcd_arrangement(N / 16, O / 16, 4.0 * N * C * 16, 4.0 * O * C * 10);
-    DF_LAUNCH(k_conv3x3s2_img4_pair<128>, grid4, dim3(512), lds4, stream(), x, w, wd, y, yd, partials, partials_d, O, xo);
+    DF_LAUNCH(k_conv3x3s2_img4_pair<128>, grid4, dim3(512), lds4, stream(), x, w, wd, y, yd, partials, partials_d, O);
     DF_LAUNCH_CHECK();
     return DFHIP_OK;
   }

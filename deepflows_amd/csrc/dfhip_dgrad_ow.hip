@@ -512,8 +512,7 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_s1_ks(const float* __restrict_
 // ---------------------------------------------------------------------------------------
 template <int O>
 __global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       const float* __restrict__ add, float* __restrict__ dx, int C,
-                                                       int xo) {
+                                                       const float* __restrict__ add, float* __restrict__ dx, int C) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int OQ = O / 4, NK = OQ / 4;             // o per wave, MFMA k-steps per wave
@@ -521,7 +520,7 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img2(const float* __restrict__
   float* red = smem + 4 * O * 16;                   // [3 waves][16 values][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, n = lane & 15;
-  const DfTile wg = xcd_tile(xo);                   // XCD-aware order (dfhip_internal.h)
+  const DfTile wg = {(int)blockIdx.x, (int)blockIdx.y};          // (image tile, channel tile) in grid order
   const int n0 = wg.x * 16, c0 = wg.y * 16;
   const int ob = wave * OQ;
   // dY operand of this wave's o range: pixel (0, 0) of image n0 + n, channel ob + 4 p + kk
@@ -610,8 +609,7 @@ constexpr int kImg4Strip = 16 * 260;     // floats of a wave's transposition str
 template <int O, int GEO, bool PAIR, int HS = 1>
 __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__ dy, const float* __restrict__ w,
                                                        const float* __restrict__ add, float* __restrict__ dx, int C,
-                                                       const float* __restrict__ dy2, const float* __restrict__ w2, int S,
-                                                       int xo) {
+                                                       const float* __restrict__ dy2, const float* __restrict__ w2, int S) {
   static_assert(!PAIR || GEO >= 1, "the shortcut rides on the stride-2 forms");
   static_assert(HS == 1 || (HS == 2 && GEO != 2), "row halves: whole 4 x 4 images only");
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -622,7 +620,7 @@ __global__ __launch_bounds__(256) void k_dgrad_ow_img4(const float* __restrict__
   float* Wl = smem;                                 // [NSL slices][O][16 channels]; later the exchange area [3][16][64] f32x4
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 4, n = lane & 15;
-  const DfTile wg = xcd_tile(xo);                   // XCD-aware order (dfhip_internal.h)
+  const DfTile wg = {(int)blockIdx.x, (int)blockIdx.y};          // (image tile, channel tile) in grid order
   const int n0 = wg.x * 16, c0 = wg.y * 16;
   const int ob = wave * OQ;
   // GEO 2: the image is S x S (S = 8), this workgroup's 4 x 4 block of it is (qy, qx); its sources are a 2 x 2 block of
@@ -838,8 +836,6 @@ int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* 
   const size_t base = std::max((size_t)(PAIR ? 5 : 4) * O * 16, (size_t)4 * 16 * 64 * 4) * sizeof(float);
   const size_t lds = base + (size_t)4 * kImg4Strip * sizeof(float);
   // blockIdx.y selects 16 input channels' weight columns (NSL slices x O), blockIdx.x 16 images of dY
-  const int dyp = GEO == 0 ? 16 : (GEO == 1 ? 4 : (S / 2) * (S / 2));
-  const int xo = xcd_arrangement(N / 16, C / 16, 4.0 * N * O * dyp * (PAIR ? 2 : 1), 4.0 * O * C * (PAIR ? 5 : 4));
   static bool attr = false;
   if (!attr) {
     DF_HIP(hipFuncSetAttribute((const void*)k_dgrad_ow_img4<O, GEO, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -850,10 +846,10 @@ int launch_dgrad_img4(const float* dy, const float* w, const float* add, float* 
     attr = true;
   }
   if constexpr (GEO == 2) {
-    DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
+    DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S);
   } else {
-    if (halves) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, 2>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
-    else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S, xo);
+    if (halves) DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR, 2>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S);
+    else DF_LAUNCH((k_dgrad_ow_img4<O, GEO, PAIR>), grid, dim3(256), lds, stream(), dy, w, add, dx, C, dy2, w2, S);
   }
   DF_LAUNCH_CHECK();
   return DFHIP_OK;
@@ -992,7 +988,6 @@ int run_dgrad_ow(const float* dy, const float* w, const float* add, float* dx, i
     dim3 grid((unsigned)(N / 16), (unsigned)(C / 16));
     const size_t lds = ((size_t)4 * O * 16 + 3 * 16 * 64) * sizeof(float);
     // blockIdx.y selects 16 input channels' weight columns (all O, four taps), blockIdx.x 16 images of dY
-    const int xo2 = xcd_arrangement(N / 16, C / 16, 4.0 * N * O * 4, 4.0 * O * C * 4);
 #define DF_I2(OV)                                                                                          \
   do {                                                                                                     \
     static bool attr = false;                                                                              \
@@ -1001,7 +996,7 @@ int run_dgrad_ow(const float* dy, const float* w, const float* add, float* dx, i
                                  (int)std::max(lds, (size_t)65536)));                                      \
       attr = true;                                                                                         \
     }                                                                                                      \
-    DF_LAUNCH(k_dgrad_ow_img2<OV>, grid, dim3(256), lds, stream(), dy, w, add, dx, C, xo2);                \
+    DF_LAUNCH(k_dgrad_ow_img2<OV>, grid, dim3(256), lds, stream(), dy, w, add, dx, C);                \
   } while (0)
     if (O == 128) DF_I2(128); else if (O == 256) DF_I2(256); else DF_I2(512);
 #undef DF_I2

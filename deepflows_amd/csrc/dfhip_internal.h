@@ -100,33 +100,13 @@ int run_dgrad_s2_acc(const float* dy, const float* w, const float* dy2, const fl
 
 }  // namespace dfhip
 
-// ---- XCD-aware tile order ---------------------------------------------------------------------------------------
-// MI355X deals workgroups round-robin over its 8 XCDs in linear-id order (x fastest), and each XCD has an L2 of its
-// own: with the natural (blockIdx.x = image tile, blockIdx.y = channel tile) order every XCD sees EVERY channel tile,
-// i.e. each of the eight L2s pulls the whole weight tensor (MI355X_MICROARCH.md, Workgroup dispatch; measured on the
-// 2 x 2-image layers: 20 MB fetched for a 2.4 MB weight tensor).  xcd_tile() renumbers the tiles of a 2-D grid so
-// that the 8 XCDs form an xo x (8 / xo) arrangement: XCD (jo, ji) owns the channel tiles [jo * ny / xo, ...) and the
-// image tiles [ji * nx / (8 / xo), ...), and its L2 holds 1 / xo of the weights and xo / 8 of the images.  Placement
-// is a speed matter only (HIP promises none): any xo gives the same results.  xo = 0: the natural order.
+// ---- tile of a 2-D grid ----------------------------------------------------------------------------------------------
+// (Rounds 3-5 carried an XCD-aware renumbering of the image-per-lane kernels' workgroups here -- every XCD's L2 holding 1/8 of
+// a layer3-4 weight tensor instead of all of it: the L2 fills dropped as sized (2 x 2 forward 20.0 -> 9.0 MB per launch), no
+// launch got shorter and the step longer (0.6875 -> 0.7003 ms: the weights come out of the Infinity Cache either way, and with
+// the arrangement the 32 workgroups of an XCD ask for the same lines at the same moment).  Switched off in round 5, removed in
+// round 6: profiles/r03b_xcd_*, docs/DESIGN_round_5.md item 4.)
 struct DfTile { int x, y; };
-#if defined(__HIPCC__)
-__device__ __forceinline__ DfTile xcd_tile(int xo) {
-  const int nx = (int)gridDim.x, ny = (int)gridDim.y;
-  if (xo <= 0) return {(int)blockIdx.x, (int)blockIdx.y};
-  const int lin = (int)blockIdx.y * nx + (int)blockIdx.x;      // (nx * ny % 8 == 0: every z plane starts on XCD 0's turn)
-  const int j = lin & 7, s = lin >> 3;
-  const int xi = 8 / xo, jo = j % xo, ji = j / xo;
-  const int wx = nx / xi, wy = ny / xo;
-  const int li = s % wx, lo = s / wx;
-  return {ji * wx + li, jo * wy + lo};
-}
-#endif
-namespace dfhip {
-// 0 = grid order.  (An arrangement that gives every XCD's L2 1/8 of the weights was measured in rounds 3 and 5: fewer bytes,
-// more time -- dfhip_runtime.hip.)
-int xcd_arrangement(int nx, int ny, double x_bytes, double y_bytes);
-}
-
 // ---- point-wise pieces of the stem (BatchNorm -> ReLU -> MaxPool 2x2) shared by its kernels ----
 #if defined(__HIPCC__)
 __device__ __forceinline__ float bn_point(float v, float mean, float rsd, float w, float b) {

@@ -137,15 +137,6 @@ static int do_init(int device_id) {
 
 int ensure_init() { return g_init ? DFHIP_OK : do_init(-1); }
 
-int xcd_arrangement(int nx, int ny, double x_bytes, double y_bytes) {
-  // OFF.  An arrangement of the image-per-lane kernels' workgroups that gives every XCD's L2 1/8 of the weight tensor was
-  // measured in rounds 3 and 5 (profiles/r03b_xcd_*, gpurun r05e): the L2 fills drop as sized (2 x 2 forward 20.0 -> 9.0 MB, its
-  // input gradient 20.0 -> 11.6 MB, layer4's stride-2 gradient 13.8 -> 9.6 MB per launch) but no launch gets shorter and the
-  // step longer (0.6875 -> 0.7003 ms: the weights come out of the Infinity Cache either way, and with the arrangement the 32
-  // workgroups of an XCD ask for the same weight lines at the same moment).  The kernels keep the `xo` argument (0 = grid order).
-  (void)nx; (void)ny; (void)x_bytes; (void)y_bytes;
-  return 0;
-}
 
 // ---------------------------------------------------------------------------------------
 // Caching pool.  Exact-size free lists (rounded to 256 B); a training loop requests the
