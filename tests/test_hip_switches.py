@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 OVERWRITE = [
     ("DF_LAZY_MODULES", "0"), ("DF_WGRAD_GROUP", "0"), ("DF_BN_BWD_FUSED", "0"), ("DFHIP_BN_BWD_FUSED", "0"),
     ("DF_GRAD_IN_BUCKET", "0"), ("DFHIP_WGRAD_GROUP_DIV", "4"), ("DFHIP_WGRAD_SIDE", "6"),
-    # (round 6: head + loss + the head's backward as the four launches of rounds 1-5)
+    # (round 6: head + loss + the head's backward as the three launches of rounds 1-5)
     ("DF_HEAD_CE", "0"),
     # (round 5's diagnostic: the backward chain on 128 CUs, every four queued weight gradients on the other 128)
     (("DFHIP_OVERLAP_CUS", "128"), ("DFHIP_WGRAD_SIDE", "4")),
