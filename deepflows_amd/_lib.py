@@ -39,6 +39,8 @@ _SIGS = {
     "dfhip_init": [c_int],
     "dfhip_host_bernoulli_mask": [P, POINTER(c_int), c_double, c_int64, P],
     "dfhip_upload_bernoulli_mask": [P, POINTER(c_int), c_double, c_int64, P],
+    "dfhip_upload_bernoulli_masks": [P, POINTER(c_int), c_int, P, P, P],
+    "dfhip_host_rng_isa": [c_int],
     "dfhip_device_count": [POINTER(c_int)],
     "dfhip_sync": [],
     "dfhip_device_name": [c_char_p, c_int],

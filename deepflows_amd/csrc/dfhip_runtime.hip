@@ -644,194 +644,7 @@ int dfhip_h2d(const float* host, float* dst, int64_t n) {
   return DFHIP_OK;
 }
 
-// ---- Dropout masks: NumPy's global generator, continued in C ------------------------------------------------
-// The reference draws a mask with np.random.binomial(1, keep, shape) on the host (nn/modules/dropout.py:16-18).  For
-// n = 1 NumPy's sampler consumes ONE double of the legacy MT19937 stream per element and thresholds it, and a
-// double is (a >> 5) * 2^26 + (b >> 6) over 2^53 of two consecutive 32-bit outputs: the mask is a pure function of
-// the generator state.  dfhip_host_bernoulli_mask continues that stream from a copy of the state (key[624], pos) the
-// caller took with np.random.get_state() and hands the advanced state back -- same masks, same position of the
-// global generator afterwards -- in blocks the compiler vectorises (regenerate 624 words, temper 624 words, pair
-// them), about three times faster than the scalar generator; at 0.5 M elements per step the CNN workload's replayed
-// step was bound by exactly that.  Host code only: no device call.
-namespace {
-constexpr int kMtN = 624, kMtM = 397;
-inline void mt_regenerate(uint32_t* mt) {
-  constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MA = 0x9908b0dfu;
-  int i = 0;
-  for (; i < kMtN - kMtM; i++) {
-    const uint32_t y = (mt[i] & UP) | (mt[i + 1] & LO);
-    mt[i] = mt[i + kMtM] ^ (y >> 1) ^ ((0u - (y & 1u)) & MA);
-  }
-  for (; i < kMtN - 1; i++) {
-    const uint32_t y = (mt[i] & UP) | (mt[i + 1] & LO);
-    mt[i] = mt[i + (kMtM - kMtN)] ^ (y >> 1) ^ ((0u - (y & 1u)) & MA);
-  }
-  const uint32_t y = (mt[kMtN - 1] & UP) | (mt[0] & LO);
-  mt[kMtN - 1] = mt[kMtM - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & MA);
-}
-inline uint32_t mt_temper(uint32_t y) {
-  y ^= y >> 11;
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= y >> 18;
-  return y;
-}
-}  // namespace
-
-// (the block loops are compiled twice: for the baseline x86-64 and for AVX2, picked at run time)
-#define DF_MT_BODY                                                                                   \
-  constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MA = 0x9908b0dfu;                          \
-  int i = 0;                                                                                         \
-  for (; i < kMtN - kMtM; i++) {                                                                     \
-    const uint32_t y = (mt[i] & UP) | (mt[i + 1] & LO);                                              \
-    mt[i] = mt[i + kMtM] ^ (y >> 1) ^ ((0u - (y & 1u)) & MA);                                        \
-  }                                                                                                  \
-  for (; i < kMtN - 1; i++) {                                                                        \
-    const uint32_t y = (mt[i] & UP) | (mt[i + 1] & LO);                                              \
-    mt[i] = mt[i + (kMtM - kMtN)] ^ (y >> 1) ^ ((0u - (y & 1u)) & MA);                               \
-  }                                                                                                  \
-  const uint32_t y = (mt[kMtN - 1] & UP) | (mt[0] & LO);                                             \
-  mt[kMtN - 1] = mt[kMtM - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & MA);
-namespace {
-__attribute__((target("avx2"))) inline void mt_regenerate_avx2(uint32_t* mt) { DF_MT_BODY }
-}
-extern "C++" {            // (the generators are templates over the element type of the mask)
-#define DF_MASK_ATTR
-#define DF_MASK_NAME bernoulli_mask_base
-#define DF_MT_REGEN mt_regenerate
-template <typename OUT>
-DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64_t n, OUT* out) {
-  // tempered outputs are produced a block at a time into `buf`; `have` of them are not consumed yet
-  uint32_t buf[kMtN];
-  int p = *pos, have = 0, at = 0;
-  const bool low = keep <= 0.5;                     // NumPy's inversion sampler mirrors the test for keep > 0.5
-  const double thr = low ? 1.0 - keep : keep;
-  uint32_t carry_a = 0;
-  bool has_carry = false;
-  int64_t done = 0;
-  while (done < n) {
-    if (have == 0) {
-      if (p == kMtN) { DF_MT_REGEN(key); p = 0; }
-      have = kMtN - p;
-      for (int i = 0; i < have; i++) buf[i] = mt_temper(key[p + i]);
-      p = kMtN;
-      at = 0;
-    }
-    if (has_carry) {                                // a double straddling two blocks
-      const uint32_t a = carry_a >> 5, b = buf[at] >> 6;
-      const double u = (a * 67108864.0 + b) / 9007199254740992.0;
-      out[done++] = low ? (u > thr ? (OUT)1 : (OUT)0) : (u > thr ? (OUT)0 : (OUT)1);
-      at++; have--;
-      has_carry = false;
-      continue;
-    }
-    int64_t pairs = have / 2;
-    if (pairs > n - done) pairs = n - done;
-    const uint32_t* q = buf + at;
-    OUT* o = out + done;
-    if (low) {
-      for (int64_t i = 0; i < pairs; i++) {
-        const double u = ((q[2 * i] >> 5) * 67108864.0 + (q[2 * i + 1] >> 6)) / 9007199254740992.0;
-        o[i] = u > thr ? (OUT)1 : (OUT)0;
-      }
-    } else {
-      for (int64_t i = 0; i < pairs; i++) {
-        const double u = ((q[2 * i] >> 5) * 67108864.0 + (q[2 * i + 1] >> 6)) / 9007199254740992.0;
-        o[i] = u > thr ? (OUT)0 : (OUT)1;
-      }
-    }
-    done += pairs;
-    at += (int)(2 * pairs);
-    have -= (int)(2 * pairs);
-    if (done < n && have == 1) {                    // odd word left in the block: first half of the next double
-      carry_a = buf[at];
-      has_carry = true;
-      have = 0;
-    }
-  }
-  // words of the last block that were tempered but not consumed go back: the generator stands right behind the last
-  // word used
-  *pos = p - have;
-  return DFHIP_OK;
-}
-
-#undef DF_MASK_ATTR
-#undef DF_MASK_NAME
-#undef DF_MT_REGEN
-#define DF_MASK_ATTR __attribute__((target("avx2")))
-#define DF_MASK_NAME bernoulli_mask_avx2
-#define DF_MT_REGEN mt_regenerate_avx2
-template <typename OUT>
-DF_MASK_ATTR static int DF_MASK_NAME(uint32_t* key, int* pos, double keep, int64_t n, OUT* out) {
-  // tempered outputs are produced a block at a time into `buf`; `have` of them are not consumed yet
-  uint32_t buf[kMtN];
-  int p = *pos, have = 0, at = 0;
-  const bool low = keep <= 0.5;                     // NumPy's inversion sampler mirrors the test for keep > 0.5
-  const double thr = low ? 1.0 - keep : keep;
-  uint32_t carry_a = 0;
-  bool has_carry = false;
-  int64_t done = 0;
-  while (done < n) {
-    if (have == 0) {
-      if (p == kMtN) { DF_MT_REGEN(key); p = 0; }
-      have = kMtN - p;
-      for (int i = 0; i < have; i++) buf[i] = mt_temper(key[p + i]);
-      p = kMtN;
-      at = 0;
-    }
-    if (has_carry) {                                // a double straddling two blocks
-      const uint32_t a = carry_a >> 5, b = buf[at] >> 6;
-      const double u = (a * 67108864.0 + b) / 9007199254740992.0;
-      out[done++] = low ? (u > thr ? (OUT)1 : (OUT)0) : (u > thr ? (OUT)0 : (OUT)1);
-      at++; have--;
-      has_carry = false;
-      continue;
-    }
-    int64_t pairs = have / 2;
-    if (pairs > n - done) pairs = n - done;
-    const uint32_t* q = buf + at;
-    OUT* o = out + done;
-    if (low) {
-      for (int64_t i = 0; i < pairs; i++) {
-        const double u = ((q[2 * i] >> 5) * 67108864.0 + (q[2 * i + 1] >> 6)) / 9007199254740992.0;
-        o[i] = u > thr ? (OUT)1 : (OUT)0;
-      }
-    } else {
-      for (int64_t i = 0; i < pairs; i++) {
-        const double u = ((q[2 * i] >> 5) * 67108864.0 + (q[2 * i + 1] >> 6)) / 9007199254740992.0;
-        o[i] = u > thr ? (OUT)0 : (OUT)1;
-      }
-    }
-    done += pairs;
-    at += (int)(2 * pairs);
-    have -= (int)(2 * pairs);
-    if (done < n && have == 1) {                    // odd word left in the block: first half of the next double
-      carry_a = buf[at];
-      has_carry = true;
-      have = 0;
-    }
-  }
-  // words of the last block that were tempered but not consumed go back: the generator stands right behind the last
-  // word used
-  *pos = p - have;
-  return DFHIP_OK;
-}
-
-#undef DF_MASK_ATTR
-#undef DF_MASK_NAME
-#undef DF_MT_REGEN
-
-}  // extern "C++"
-
-int dfhip_host_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n, float* out) {
-  if (!key || !pos || !out || n < 0 || *pos < 0 || *pos > kMtN) {
-    set_error("host_bernoulli_mask: bad arguments");
-    return DFHIP_INVALID_ARGUMENT;
-  }
-  static const bool avx2 = __builtin_cpu_supports("avx2");
-  return avx2 ? bernoulli_mask_avx2<float>(key, pos, keep, n, out) : bernoulli_mask_base<float>(key, pos, keep, n, out);
-}
-
+// ---- Dropout masks (the generator itself: dfhip_hostrng.hip) ------------------------------------------------------
 // a mask of 0 / 1 BYTES read from pinned host memory -> floats in device memory (four elements per thread)
 __global__ __launch_bounds__(256) void k_mask_bytes_from_host(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
   const int64_t n4 = n >> 2;
@@ -871,13 +684,11 @@ int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n,
   // the mask crosses PCIe as bytes (a quarter of the floats: 2 MB per step of the CNN workload were 40 us in front of every
   // replay) and becomes floats in the kernel that fetches it
   if ((((uintptr_t)dst) & 15) == 0) {
-    if (*pos < 0 || *pos > kMtN) {
+    if (*pos < 0 || *pos > 624 || !(keep >= 0.0 && keep <= 1.0)) {
       set_error("upload_bernoulli_mask: bad generator position");
       return DFHIP_INVALID_ARGUMENT;
     }
-    static const bool avx2 = __builtin_cpu_supports("avx2");
-    const int stb = avx2 ? bernoulli_mask_avx2<uint8_t>(key, pos, keep, n, (uint8_t*)sl.p)
-                         : bernoulli_mask_base<uint8_t>(key, pos, keep, n, (uint8_t*)sl.p);
+    const int stb = host_bernoulli_mask_u8(key, pos, keep, n, (uint8_t*)sl.p);
     if (stb != DFHIP_OK) return stb;
     const int blocks = (int)std::min<int64_t>(1024, (n / 4 + 255) / 256 + 1);
     hipLaunchKernelGGL(k_mask_bytes_from_host, dim3(blocks), dim3(256), 0, g_stream, (const uint8_t*)sl.p, dst, n);
@@ -982,6 +793,106 @@ int dfhip_upload_release(int slot) {
   if (!u.done) return DFHIP_OK;                     // (nothing was ever uploaded through this slot)
   DF_HIP(hipEventRecord(u.consumed, g_stream));
   u.released = true;
+  return DFHIP_OK;
+}
+
+// ---- all Dropout masks of a step in one call (a captured step's graph inputs) ------------------------------------------
+// The masks of a step are drawn one after the other into pinned memory as BITS (0.5 M elements = 64 KB) and become the float
+// arrays the captured kernels read with ONE launch in front of the graph: the kernel fetches the bits over PCIe itself
+// (a byte per thread, eight floats out).  Measured on the CNN workload (0.391 ms per step without any upload): a kernel per
+// mask fetching 0 / 1 BYTES stood 23 us in front of every replay and ONE such kernel for both masks as long (the fetch of
+// 0.5 MB in 4-byte requests is what takes the time, not the launch); the same bytes sent by the copy engine on a second
+// stream beside the running step and expanded from device memory cost 44 us (the hop to the copy queue and back).
+namespace {
+constexpr int kMaskBatch = 8;
+struct MaskTable {
+  const uint8_t* src[kMaskBatch];
+  float* dst[kMaskBatch];
+  int64_t n[kMaskBatch];
+};
+struct MaskStage {
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+  hipEvent_t expanded = nullptr;  // the library stream has passed the kernel that read `pinned`
+  bool pending = false;
+};
+MaskStage g_mask_stage[4];
+int g_mask_stage_next = 0;
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_masks_expand(MaskTable t) {
+  const uint8_t* __restrict__ src = t.src[blockIdx.y];
+  float* __restrict__ dst = t.dst[blockIdx.y];
+  const int64_t n = t.n[blockIdx.y], n8 = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const unsigned b = src[i];
+    reinterpret_cast<float4*>(dst)[2 * i] = make_float4((float)(b & 1), (float)((b >> 1) & 1), (float)((b >> 2) & 1), (float)((b >> 3) & 1));
+    reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4((float)((b >> 4) & 1), (float)((b >> 5) & 1), (float)((b >> 6) & 1), (float)((b >> 7) & 1));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(n8 << 3) + threadIdx.x] = (float)((src[n8] >> threadIdx.x) & 1);
+}
+
+int dfhip_upload_bernoulli_masks(uint32_t* key, int* pos, int count, const double* keep, const int64_t* n, float* const* dst) {
+  DF_INIT();
+  DF_CHECK_ARG(key && pos && count >= 0 && (count == 0 || (keep && n && dst)), "upload_bernoulli_masks: bad arguments");
+  if (g_capture_open) {
+    set_error("upload_bernoulli_masks inside a graph capture: register the masks as graph inputs instead");
+    return DFHIP_RUNTIME_ERROR;
+  }
+  bool plain = *pos >= 0 && *pos <= 624;
+  for (int i = 0; i < count; i++) {
+    DF_CHECK_ARG(n[i] >= 0 && (n[i] == 0 || dst[i]), "upload_bernoulli_masks: bad mask");
+    if ((((uintptr_t)dst[i]) & 15) != 0 || !(keep[i] >= 0.0 && keep[i] <= 1.0)) plain = false;
+  }
+  if (!plain) {        // (an unaligned destination or arguments the single call reports: one mask at a time, the same stream order)
+    for (int i = 0; i < count; i++) {
+      const int st = dfhip_upload_bernoulli_mask(key, pos, keep[i], n[i], dst[i]);
+      if (st != DFHIP_OK) return st;
+    }
+    return DFHIP_OK;
+  }
+  for (int i0 = 0; i0 < count; i0 += kMaskBatch) {
+    const int cnt = std::min(kMaskBatch, count - i0);
+    size_t off[kMaskBatch], bits = 0;
+    int64_t longest = 0;
+    for (int i = 0; i < cnt; i++) {
+      off[i] = bits;
+      bits += (((size_t)n[i0 + i] + 7) / 8 + 63) & ~(size_t)63;
+      longest = std::max(longest, n[i0 + i]);
+    }
+    if (longest == 0) continue;
+    const size_t total = bits + (size_t)longest;        // the bits of every mask, then the bytes of the one being drawn
+    MaskStage& st = g_mask_stage[g_mask_stage_next];
+    g_mask_stage_next = (g_mask_stage_next + 1) & 3;
+    if (!st.expanded) DF_HIP(hipEventCreateWithFlags(&st.expanded, hipEventDisableTiming));
+    if (st.pending) {                                   // the pinned buffer is free again
+      DF_HIP(hipEventSynchronize(st.expanded));
+      st.pending = false;
+    }
+    if (st.pinned_bytes < total) {
+      if (st.pinned) (void)hipHostFree(st.pinned);
+      st.pinned = nullptr;
+      st.pinned_bytes = 0;
+      const size_t want = std::max(total, (size_t)1 << 20);
+      DF_HIP(hipHostMalloc(&st.pinned, want, hipHostMallocDefault));
+      st.pinned_bytes = want;
+    }
+    MaskTable t;
+    for (int i = 0; i < kMaskBatch; i++) { t.src[i] = nullptr; t.dst[i] = nullptr; t.n[i] = 0; }
+    for (int i = 0; i < cnt; i++) {
+      uint8_t* at = (uint8_t*)st.pinned + off[i];
+      const int s = host_bernoulli_mask_bits(key, pos, keep[i0 + i], n[i0 + i], (uint8_t*)st.pinned + bits, at);
+      if (s != DFHIP_OK) return s;
+      t.src[i] = at;
+      t.dst[i] = dst[i0 + i];
+      t.n[i] = n[i0 + i];
+    }
+    const int blocks = (int)std::min<int64_t>(512, (longest / 8 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_masks_expand, dim3(blocks, cnt), dim3(256), 0, g_stream, t);
+    DF_LAUNCH_CHECK();
+    DF_HIP(hipEventRecord(st.expanded, g_stream));
+    st.pending = true;
+  }
   return DFHIP_OK;
 }
 

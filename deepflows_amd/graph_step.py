@@ -90,11 +90,12 @@ class CapturedTrainStep:
         opt.push_hyper()
         if self.feeds and os.environ.get("DF_DEBUG_SKIP_FEEDS") != "1":     # (diagnostic switch: timing without the uploads)
             # Dropout masks of this step: drawn on the host exactly as the eager forward pass would draw them
-            # (nn/modules/dropout.py), uploaded on the library stream in front of the graph
+            # (nn/modules/dropout.py); they cross PCIe beside the step that is running and become the graph's input arrays
+            # with one launch in front of the graph (dfhip_upload_bernoulli_masks)
             from .nn.modules.dropout import bernoulli_mask
-            for mask, keep in self.feeds:
-                up = getattr(self.mod, "upload_bernoulli_mask", None)
-                if up is None or mask._handle.size < 8192 or not up(mask._handle, keep):
+            batch = getattr(self.mod, "upload_bernoulli_masks", None)
+            if batch is None or not batch(self.feeds):
+                for mask, keep in self.feeds:
                     self.mod.from_numpy(np.ascontiguousarray(bernoulli_mask(keep, mask.shape)), mask._handle)
         self.graph.replay()
         if self.sync is not None and not self.exchange_captured:

@@ -181,6 +181,23 @@ class HipModule:
         np.random.set_state(("MT19937", key, pos.value, st[3], st[4]))
         return True
 
+    def upload_bernoulli_masks(self, feeds):
+        """Every Dropout mask of a step -- feeds = [(array, keep), ...] in forward order -- in one call: drawn one after
+        the other from NumPy's global generator as upload_bernoulli_mask draws one, sent beside the step that is running
+        and turned into floats by one launch.  False when the generator is not the legacy MT19937."""
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            return False
+        cnt = len(feeds)
+        key = np.array(st[1], dtype=np.uint32, copy=True)
+        pos = ctypes.c_int(int(st[2]))
+        keeps = (ctypes.c_double * cnt)(*[float(k) for _, k in feeds])
+        ns = (ctypes.c_int64 * cnt)(*[int(m._handle.size) for m, _ in feeds])
+        dsts = (ctypes.c_void_p * cnt)(*[int(m._handle.ptr) for m, _ in feeds])
+        _lib.check(self._lib.dfhip_upload_bernoulli_masks(key.ctypes.data, ctypes.byref(pos), cnt, keeps, ns, dsts))
+        np.random.set_state(("MT19937", key, pos.value, st[3], st[4]))
+        return True
+
     def to_numpy(self, handle, shape, strides, offset):
         shape = tuple(int(s) for s in shape)
         strides = tuple(int(s) for s in strides)

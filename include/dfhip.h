@@ -579,6 +579,13 @@ int dfhip_host_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n, f
 /* the same mask generated straight into a pinned staging slot and copied to the device array `dst` on the library
  * stream (Dropout's from_numpy of nn/modules/dropout.py:28 without the intermediate host array) */
 int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n, float* dst);
+/* `count` masks drawn one after the other from the same stream (the Dropout layers of a captured step in forward order:
+ * nn/modules/dropout.py:16-18 once per layer) -- bytes over PCIe on the copy stream beside the step that is running, one
+ * launch on the library stream that turns them into the float arrays dst[i] */
+int dfhip_upload_bernoulli_masks(uint32_t* key, int* pos, int count, const double* keep, const int64_t* n, float* const* dst);
+/* vector width of the helpers above: 0 plain C, 1 AVX2, 2 AVX-512 (F + BW + VL), -1 the widest the host has (the
+ * default).  A level the host lacks is clamped; returns the level in effect.  For the tests: all three must agree. */
+int dfhip_host_rng_isa(int level);
 
 /* ---- whole-step capture (hipGraph) -------------------------------------------------- */
 int dfhip_graph_begin(void);                   /* hipStreamBeginCapture on the library stream */

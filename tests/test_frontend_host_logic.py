@@ -208,24 +208,37 @@ def test_large_dropout_masks_continue_numpys_stream_in_c():
     from deepflows_amd.nn.modules.dropout import _continue_numpy_stream, bernoulli_mask
     if not _lib.library_present():
         pytest.skip("libdfhip.so is not built")
-    for keep in (0.5, 0.3, 0.8):
-        for n in (8192, 100001, 524288):
-            for pre, odd in ((0, False), (1, False), (311, True), (312, True), (625, False)):
-                def prep():
-                    np.random.seed(11)
-                    if pre:
-                        np.random.random_sample(pre)
-                    if odd:
-                        np.random.randint(0, 1000)       # one 32-bit word: the stream position becomes odd
-                prep()
-                a = np.random.binomial(1, keep, n).astype(np.float32)
-                nxt_a = np.random.random_sample(5)
-                prep()
-                b = _continue_numpy_stream(keep, (n,))
-                assert b is not None
-                nxt_b = np.random.random_sample(5)
-                assert np.array_equal(a, b), (keep, n, pre, odd)
-                assert np.array_equal(nxt_a, nxt_b), (keep, n, pre, odd)
+    lib = _lib.load()
+    try:
+        for keep in (0.5, 0.3, 0.8):
+            for n in (8192, 100001, 524288):
+                for pre, odd in ((0, False), (1, False), (311, True), (312, True), (625, False)):
+                    def prep():
+                        np.random.seed(11)
+                        if pre:
+                            np.random.random_sample(pre)
+                        if odd:
+                            np.random.randint(0, 1000)       # one 32-bit word: the stream position becomes odd
+                    prep()
+                    a = np.random.binomial(1, keep, n).astype(np.float32)
+                    nxt_a = np.random.random_sample(5)
+                    # every vector width the library carries (plain C, AVX2, AVX-512: a level the host lacks is clamped)
+                    for isa in (0, 1, 2):
+                        lib.dfhip_host_rng_isa(isa)
+                        prep()
+                        b = _continue_numpy_stream(keep, (n,))
+                        assert b is not None
+                        nxt_b = np.random.random_sample(5)
+                        assert np.array_equal(a, b), (keep, n, pre, odd, isa)
+                        assert np.array_equal(nxt_a, nxt_b), (keep, n, pre, odd, isa)
+    finally:
+        lib.dfhip_host_rng_isa(-1)
+    # the ends of the range: keep = 1 (every element kept), keep = 0
+    for keep in (1.0, 0.0):
+        np.random.seed(5)
+        a = np.random.binomial(1, keep, 10000).astype(np.float32)
+        np.random.seed(5)
+        assert np.array_equal(a, _continue_numpy_stream(keep, (10000,))), keep
     np.random.seed(2)
     a = np.random.binomial(1, 0.5, (256, 2048)).astype(np.float32)
     np.random.seed(2)

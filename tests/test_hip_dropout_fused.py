@@ -120,3 +120,31 @@ def test_5x5_weight_gradient_as_five_tap_rows_of_the_grouped_launch(hip_device, 
     else:
         K = N * H * W
         assert 3e-7 < err.max() <= 8.0 * 2.0 ** -8 / np.sqrt(K), err.max()
+
+
+def test_all_masks_of_a_step_in_one_call_continue_numpys_stream(hip_device):
+    """dfhip_upload_bernoulli_masks (a captured step's Dropout inputs: graph_step.CapturedTrainStep.replay): the masks
+    np.random.binomial(1, keep, n) would draw one after the other (nn/modules/dropout.py:16-18 once per layer), the same
+    position of the global generator afterwards -- sizes that are no multiple of 8, more masks than one launch takes, an
+    odd stream position, every vector width of the host generator"""
+    from deepflows_amd import _lib
+    lib = _lib.load()
+    mod = hip_device.mod
+    sizes = [(256, 2048), (37, 101), (3,), (8191,), (256, 512), (1,), (4096,), (13, 7, 5), (100003,), (64,)]
+    keeps = [0.5, 0.3, 0.8, 0.5, 0.75, 0.5, 1.0, 0.1, 0.5, 0.0]
+    try:
+        for isa in (0, 1, 2):
+            lib.dfhip_host_rng_isa(isa)
+            np.random.seed(21)
+            np.random.randint(0, 1000)                          # (one 32-bit word: an odd stream position)
+            want = [np.random.binomial(1, k, s).astype(np.float32) for s, k in zip(sizes, keeps)]
+            after = np.random.random_sample(4)
+            np.random.seed(21)
+            np.random.randint(0, 1000)
+            arrays = [hip_device.empty(s, dtype="float32") for s in sizes]
+            assert mod.upload_bernoulli_masks(list(zip(arrays, keeps)))
+            assert np.array_equal(after, np.random.random_sample(4))
+            for a, w, s in zip(arrays, want, sizes):
+                assert np.array_equal(a.numpy(), w), (isa, s)
+    finally:
+        lib.dfhip_host_rng_isa(-1)
