@@ -107,6 +107,7 @@ _SIGS = {
     "dfhip_pool_linear_forward": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_float],
     "dfhip_pool_linear_backward": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float],
     "dfhip_head_ce_forward": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P],
+    "dfhip_droplin_ce_forward": [P, P, c_float, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P],
     "dfhip_head_grads": [P, P, P, P, P, P, c_int, c_int, c_int],
     "dfhip_loss_finish": [P, P, c_int],
     "dfhip_dropout_apply": [P, P, P, c_int64, c_float, c_int],

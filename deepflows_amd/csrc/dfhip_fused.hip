@@ -1916,13 +1916,18 @@ __global__ __launch_bounds__(1024) void k_pool_linear_bwd(const float* __restric
 // the order k_ce_small uses; what is left of the backward pass -- dW, db: sums over the images -- is head_grads_body
 // (dfhip_head.h).  Rounds 1-5: three launches (4.7 + 5.1 + 7.7 us at batch 256) for 2 MB of traffic.
 // IPB images per workgroup (256 threads each).
-template <int P, int CPT, int IPB>
+// DROP (round 6, the CNN workload's tail -- test/CNN_CIFAR10_cuda.py:104-107 `x = self.drop(x); x = self.fc(x)` + the
+// criterion): the rows are two-dimensional (HW == 1) and what the Linear reads is Dropout's x * mask / keep
+// (nn/modules/dropout.py:31, k_dropout's two roundings); `pooled` is then Dropout's output and dx the gradient at Dropout's
+// INPUT (k_dropout<true>'s (g / keep) * mask).  All of a thread's operands are requested before the first is used.
+template <int P, int CPT, int IPB, bool DROP = false>
 __global__ __launch_bounds__(256 * IPB) void k_head_ce(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ b, const float* __restrict__ target,
                                                       float* __restrict__ pooled, float* __restrict__ logits,
                                                       float* __restrict__ dlogits, float* __restrict__ dx,
                                                       float* rowloss, float* __restrict__ loss, int N, int C, int HW, int Pn,
-                                                      float scale, float gscale, float inv_rows) {
+                                                      float scale, float gscale, float inv_rows,
+                                                      const float* __restrict__ mask, float keep) {
   __shared__ float sh[IPB][4][P];
   __shared__ float slog[IPB][P];
   const int img = threadIdx.x >> 8, tid = threadIdx.x & 255;
@@ -1937,26 +1942,49 @@ __global__ __launch_bounds__(256 * IPB) void k_head_ce(const float* __restrict__
     const float v = target[(int64_t)n * Pn + min(j, Pn - 1)];
     tv[j] = j < Pn ? v : 0.0f;
   }
+  float mk[DROP ? CPT : 1];
+  if constexpr (DROP) {
+    float xr[CPT];
 #pragma unroll
-  for (int q = 0; q < CPT; q++) {
-    const int c = tid + 256 * q, cc = min(c, C - 1);
-    const float* xp = x + ((int64_t)n * C + cc) * HW;
-    float s = 0.0f;
-    if ((HW & 3) == 0) {
-      for (int i = 0; i < HW; i += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(xp + i);
-        s += v.x; s += v.y; s += v.z; s += v.w;
-      }
-    } else {
-      for (int i = 0; i < HW; i++) s += xp[i];
+    for (int q = 0; q < CPT; q++) {
+      const int cc = min(tid + 256 * q, C - 1);
+      xr[q] = x[(int64_t)n * C + cc];
+      mk[q] = mask[(int64_t)n * C + cc];
+      const float* wp = w + (int64_t)cc * Pn;
+#pragma unroll
+      for (int j = 0; j < P; j++) wr[q][j] = wp[min(j, Pn - 1)];
     }
-    pv[q] = c < C ? s * scale : 0.0f;
-    if (c < C && live) pooled[(int64_t)n * C + c] = pv[q];
-    const float* wp = w + (int64_t)cc * Pn;
+    asm volatile("" ::: "memory");                 // (a compiler barrier: plain loads are sunk to their first use otherwise)
 #pragma unroll
-    for (int j = 0; j < P; j++) wr[q][j] = wp[min(j, Pn - 1)];
+    for (int q = 0; q < CPT; q++) {
+      const int c = tid + 256 * q;
+      pv[q] = c < C ? __fdiv_rn(__fmul_rn(xr[q], mk[q]), keep) : 0.0f;
+      if (c < C && live) pooled[(int64_t)n * C + c] = pv[q];
 #pragma unroll
-    for (int j = 0; j < P; j++) acc[j] = fmaf(pv[q], wr[q][j], acc[j]);
+      for (int j = 0; j < P; j++) acc[j] = fmaf(pv[q], wr[q][j], acc[j]);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < CPT; q++) {
+      const int c = tid + 256 * q, cc = min(c, C - 1);
+      const float* xp = x + ((int64_t)n * C + cc) * HW;
+      float s = 0.0f;
+      if ((HW & 3) == 0) {
+        for (int i = 0; i < HW; i += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(xp + i);
+          s += v.x; s += v.y; s += v.z; s += v.w;
+        }
+      } else {
+        for (int i = 0; i < HW; i++) s += xp[i];
+      }
+      pv[q] = c < C ? s * scale : 0.0f;
+      if (c < C && live) pooled[(int64_t)n * C + c] = pv[q];
+      const float* wp = w + (int64_t)cc * Pn;
+#pragma unroll
+      for (int j = 0; j < P; j++) wr[q][j] = wp[min(j, Pn - 1)];
+#pragma unroll
+      for (int j = 0; j < P; j++) acc[j] = fmaf(pv[q], wr[q][j], acc[j]);
+    }
   }
   {                                                // head_block_sum per image (its four waves)
     const int lane = tid & 63, wave = tid >> 6;
@@ -2028,6 +2056,7 @@ __global__ __launch_bounds__(256 * IPB) void k_head_ce(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < P; j++) s = fmaf(d[j], wr[q][j], s);
       s *= gscale;
+      if constexpr (DROP) s = __fmul_rn(__fdiv_rn(s, keep), mk[q]);
       if (c < C && live) {
         float* o = dx + ((int64_t)n * C + c) * HW;
         if ((HW & 3) == 0) {
@@ -2525,10 +2554,36 @@ int dfhip_head_ce_forward(const float* x, const float* w, const float* b, const 
   const dim3 grid((unsigned)((N + IPB - 1) / IPB));
   if (C <= 256)
     DF_LAUNCH((k_head_ce<16, 1, IPB>), grid, dim3(256 * IPB), 0, stream(), x, w, b, target, pooled, logits, dlogits, dx,
-              rowloss, loss, N, C, HW, P, scale, gscale, inv_rows);
+              rowloss, loss, N, C, HW, P, scale, gscale, inv_rows, (const float*)nullptr, 1.0f);
   else
     DF_LAUNCH((k_head_ce<16, 2, IPB>), grid, dim3(256 * IPB), 0, stream(), x, w, b, target, pooled, logits, dlogits, dx,
-              rowloss, loss, N, C, HW, P, scale, gscale, inv_rows);
+              rowloss, loss, N, C, HW, P, scale, gscale, inv_rows, (const float*)nullptr, 1.0f);
+  DF_LAUNCH_CHECK();
+  *done = 1;
+  return DFHIP_OK;
+}
+
+int dfhip_droplin_ce_forward(const float* x, const float* mask, float keep, const float* w, const float* b, const float* target,
+                             float* xd, float* logits, float* loss, float* dlogits, float* dx, float* rowloss, int N, int C,
+                             int P, int* done) {
+  DF_INIT();
+  DF_CHECK_ARG(done, "droplin_ce_forward: null done");
+  *done = 0;
+  DF_CHECK_ARG(N > 0 && C > 0 && P > 0 && keep > 0.0f, "droplin_ce_forward: bad dimensions");
+  DF_CHECK_ARG(x && mask && w && target && xd && logits && loss && dlogits && rowloss, "droplin_ce_forward: null array");
+  if (!(P <= 16 && C <= 2048 && N <= 4096)) return DFHIP_OK;      // (the caller launches the nodes one by one)
+  ProfScope prof("droplin_ce_fwd_bwd", 4.0 * N * (double)C * P,
+                 4.0 * ((dx ? 4.0 : 3.0) * N * (double)C + (double)C * P + 3.0 * N * P));
+  const float inv_rows = 1.0f / (float)N;
+  const dim3 grid((unsigned)N);
+#define DF_DROPLIN(CPT)                                                                                                    \
+  DF_LAUNCH((k_head_ce<16, CPT, 1, true>), grid, dim3(256), 0, stream(), x, w, b, target, xd, logits, dlogits, dx, rowloss,   \
+            loss, N, C, 1, P, 1.0f, 1.0f, inv_rows, mask, keep)
+  if (C <= 256) DF_DROPLIN(1);
+  else if (C <= 512) DF_DROPLIN(2);
+  else if (C <= 1024) DF_DROPLIN(4);
+  else DF_DROPLIN(8);
+#undef DF_DROPLIN
   DF_LAUNCH_CHECK();
   *done = 1;
   return DFHIP_OK;

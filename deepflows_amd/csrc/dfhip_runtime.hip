@@ -645,18 +645,10 @@ int dfhip_h2d(const float* host, float* dst, int64_t n) {
 }
 
 // ---- Dropout masks (the generator itself: dfhip_hostrng.hip) ------------------------------------------------------
-// a mask of 0 / 1 BYTES read from pinned host memory -> floats in device memory (four elements per thread)
-__global__ __launch_bounds__(256) void k_mask_bytes_from_host(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
-  const int64_t n4 = n >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    const uchar4 b = reinterpret_cast<const uchar4*>(src)[i];
-    reinterpret_cast<float4*>(dst)[i] = make_float4((float)b.x, (float)b.y, (float)b.z, (float)b.w);
-  }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = (float)src[(n4 << 2) + threadIdx.x];
-}
-
-// the same mask generated straight into a pinned staging slot and sent to `dst` on the library stream: no
-// intermediate host array (a fresh 2 MB NumPy array per step is 512 first-touch page faults) and no second copy
+// the mask generated straight into a pinned staging slot and sent to `dst` on the library stream: no intermediate host
+// array (a fresh 2 MB NumPy array per step is 512 first-touch page faults) and no second copy.  A 16-byte aligned
+// destination (every array of the pool) takes the bit path of dfhip_upload_bernoulli_masks below.
+int dfhip_upload_bernoulli_masks(uint32_t* key, int* pos, int count, const double* keep, const int64_t* n, float* const* dst);
 int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n, float* dst) {
   DF_INIT();
   DF_CHECK_ARG(key && pos && dst && n >= 0, "upload_bernoulli_mask: bad arguments");
@@ -665,6 +657,8 @@ int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n,
     set_error("upload_bernoulli_mask inside a graph capture: register the mask as a graph input instead");
     return DFHIP_RUNTIME_ERROR;
   }
+  if ((((uintptr_t)dst) & 15) == 0) return dfhip_upload_bernoulli_masks(key, pos, 1, &keep, &n, &dst);
+  // (a destination that is not 16-byte aligned: the mask as floats through a plain copy)
   const size_t b = (size_t)n * sizeof(float);
   H2dSlot& sl = g_h2d[g_h2d_next];
   g_h2d_next = (g_h2d_next + 1) & 3;
@@ -681,23 +675,6 @@ int dfhip_upload_bernoulli_mask(uint32_t* key, int* pos, double keep, int64_t n,
     DF_HIP(hipHostMalloc(&sl.p, want, hipHostMallocDefault));
     sl.bytes = want;
   }
-  // the mask crosses PCIe as bytes (a quarter of the floats: 2 MB per step of the CNN workload were 40 us in front of every
-  // replay) and becomes floats in the kernel that fetches it
-  if ((((uintptr_t)dst) & 15) == 0) {
-    if (*pos < 0 || *pos > 624 || !(keep >= 0.0 && keep <= 1.0)) {
-      set_error("upload_bernoulli_mask: bad generator position");
-      return DFHIP_INVALID_ARGUMENT;
-    }
-    const int stb = host_bernoulli_mask_u8(key, pos, keep, n, (uint8_t*)sl.p);
-    if (stb != DFHIP_OK) return stb;
-    const int blocks = (int)std::min<int64_t>(1024, (n / 4 + 255) / 256 + 1);
-    hipLaunchKernelGGL(k_mask_bytes_from_host, dim3(blocks), dim3(256), 0, g_stream, (const uint8_t*)sl.p, dst, n);
-    DF_LAUNCH_CHECK();
-    DF_HIP(hipEventRecord(sl.done, g_stream));
-    sl.busy = true;
-    return DFHIP_OK;
-  }
-  // (a destination that is not 16-byte aligned: the mask as floats through a plain copy)
   int st = dfhip_host_bernoulli_mask(key, pos, keep, n, (float*)sl.p);
   if (st != DFHIP_OK) return st;
   DF_HIP(hipMemcpyAsync(dst, sl.p, b, hipMemcpyHostToDevice, g_stream));
@@ -839,12 +816,13 @@ int dfhip_upload_bernoulli_masks(uint32_t* key, int* pos, int count, const doubl
     set_error("upload_bernoulli_masks inside a graph capture: register the masks as graph inputs instead");
     return DFHIP_RUNTIME_ERROR;
   }
-  bool plain = *pos >= 0 && *pos <= 624;
+  DF_CHECK_ARG(*pos >= 0 && *pos <= 624, "upload_bernoulli_masks: bad generator position");
+  bool aligned = true;
   for (int i = 0; i < count; i++) {
-    DF_CHECK_ARG(n[i] >= 0 && (n[i] == 0 || dst[i]), "upload_bernoulli_masks: bad mask");
-    if ((((uintptr_t)dst[i]) & 15) != 0 || !(keep[i] >= 0.0 && keep[i] <= 1.0)) plain = false;
+    DF_CHECK_ARG(n[i] >= 0 && (n[i] == 0 || dst[i]) && keep[i] >= 0.0 && keep[i] <= 1.0, "upload_bernoulli_masks: bad mask");
+    if ((((uintptr_t)dst[i]) & 15) != 0) aligned = false;
   }
-  if (!plain) {        // (an unaligned destination or arguments the single call reports: one mask at a time, the same stream order)
+  if (!aligned) {      // (one mask at a time, the same stream order: the unaligned ones as floats through a plain copy)
     for (int i = 0; i < count; i++) {
       const int st = dfhip_upload_bernoulli_mask(key, pos, keep[i], n[i], dst[i]);
       if (st != DFHIP_OK) return st;

@@ -625,6 +625,16 @@ class HipModule:
                                                    ctypes.byref(done)))
         return bool(done.value)
 
+    def droplin_ce_forward(self, x, mask, keep, w, b, target, xd, logits, loss, dlogits, dx, rowloss, N, C, P):
+        """Dropout + classifier + cross-entropy + everything of their backward pass that belongs to one row, one launch;
+        False when the shape is outside the kernel (nothing was launched)"""
+        done = ctypes.c_int(0)
+        g = lambda h: h.ptr if h is not None else None
+        _lib.check(self._lib.dfhip_droplin_ce_forward(x.ptr, mask.ptr, float(keep), w.ptr, g(b), target.ptr, xd.ptr, logits.ptr,
+                                                      getattr(loss, "raw_ptr", None) or loss.ptr, dlogits.ptr, g(dx),
+                                                      rowloss.ptr, N, C, P, ctypes.byref(done)))
+        return bool(done.value)
+
     def head_grads(self, dlogits, pooled, dw, db, N, C, P, rowloss=None, loss=None):
         """the sums over the images of the head's backward pass; with (rowloss, loss) also the mean of the row losses"""
         g = lambda h: h.ptr if h is not None else None

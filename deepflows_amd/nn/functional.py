@@ -905,6 +905,78 @@ def head_ce_train(x: Tensor, fc, target: Tensor):
     return logits, _HeadCELoss(logits, out, td, loss, dl)
 
 
+class _DropLinLogits(_FusedNode):
+    """The logits of `droplin_ce_train` -- fc(drop(x)) -- with its arrays filled by the Dropout + Linear + loss launch.  When
+    the gradient that arrives is the d loss / d logits that launch left behind, the gradient at Dropout's input is the one it
+    left behind too and only dW, db remain (dfhip_head_grads: extra workgroups of the sweep's grouped slab sum inside a group);
+    any other gradient takes the Linear's backward launch and Dropout's."""
+
+    def __init__(self, x, mask, keep, w, b, wd, xd, out, dl, dx, rowloss, loss):
+        self.x, self.mask, self.keep, self.w, self.b, self.wd, self.xd = x, mask, float(keep), w, b, wd, xd
+        self.rowloss, self.loss = rowloss, loss
+        self.geo = (int(x.shape[0]), int(x.shape[1]), int(w.shape[1]))
+        self.dl_pre, self.dx_pre = dl, dx
+        self._grads = None
+        super().__init__(out, [x, w, b])
+
+    def grad_fn(self, node, grad):
+        if self._grads is None or self._grads[0] is not grad:
+            N, C, P = self.geo
+            dev = grad.device
+            dw = _grad_out(self.w, self.wd.shape, dev) if self.w.requires_grad else None
+            db = _grad_out(self.b, self.b.shape, dev) if (self.b is not None and self.b.requires_grad) else None
+            h = lambda t: t._handle if t is not None else None
+            if grad is self.dl_pre and (self.dx_pre is not None or not self.x.requires_grad):
+                dx = self.dx_pre
+                dev.head_grads(self.dl_pre._handle, self.xd._handle, h(dw), h(db), N, C, P, self.rowloss._handle,
+                               self.loss._handle)
+            else:
+                dxd = _new(self.x.shape, dev) if self.x.requires_grad else None
+                dev.pool_linear_backward(grad.compact()._handle, self.xd._handle, self.wd._handle, h(dxd), h(dw), h(db),
+                                         N, C, 1, P, 1.0)
+                dx = None
+                if dxd is not None:
+                    dx = _new(self.x.shape, dev)
+                    dev.mod.dropout_apply(dxd._handle, self.mask._handle, dx._handle, dxd._handle.size, self.keep, True)
+            self._grads = (grad, dx, dw, db)
+        _, dx, dw, db = self._grads
+        return dx if node is self.x else (dw if node is self.w else db)
+
+
+def droplin_ce_train(x: Tensor, mask, keep, fc, target: Tensor):
+    """criterion(fc(drop(x)), target) with CrossEntropyLoss for a two-dimensional x -- the end of the forward pass of
+    test/CNN_CIFAR10_cuda.py (:104-107 and its criterion) -- as ONE launch that also leaves d loss / d logits and the gradient
+    at Dropout's input behind (dfhip_droplin_ce_forward).  Returns (logits node, loss node) or None when the device has no such
+    kernel for the shape."""
+    x = realize(x)
+    mod = x.device.mod
+    if not (_fused(x) and len(x.shape) == 2 and hasattr(mod, "droplin_ce_forward") and is_grad_enable() and x.requires_grad
+            and not target.requires_grad and target.ndim == 2 and int(fc.weight.shape[1]) <= 16
+            and int(fc.weight.shape[0]) == int(x.shape[1]) and int(x.shape[1]) <= 2048
+            and int(target.shape[0]) == int(x.shape[0]) and int(target.shape[1]) == int(fc.weight.shape[1])
+            and target.device == x.device and tuple(int(v) for v in mask.shape) == tuple(int(v) for v in x.shape)):
+        return None
+    N, C = (int(v) for v in x.shape)
+    P = int(fc.weight.shape[1])
+    dev = x.device
+    w, b = fc.weight, fc.bias
+    wd = w.data.compact()
+    td = target.data.compact()
+    md = mask.compact()
+    xd, out, dl = _new((N, C), dev), _new((N, P), dev), _new((N, P), dev)
+    rowloss, dx = _new((N,), dev), _new(x.shape, dev)
+    loss_arr = mod.deferred_array(1)                    # (the mean of the row losses: see head_ce_train)
+    loss = BackendTensor.make((1,), device=dev, handle=loss_arr)
+    if not mod.droplin_ce_forward(x.data.compact()._handle, md._handle, float(keep), wd._handle,
+                                  b.data.compact()._handle if b is not None else None, td._handle, xd._handle, out._handle,
+                                  loss._handle, dl._handle, dx._handle, rowloss._handle, N, C, P):
+        return None
+    rl = rowloss._handle
+    loss_arr.owe(lambda: mod.loss_finish(rl, loss_arr, N))
+    logits = _DropLinLogits(x, md, keep, w, b, wd, xd, out, dl, dx, rowloss, loss)
+    return logits, _HeadCELoss(logits, out, td, loss, dl)
+
+
 def mean_hw_linear(x: Tensor, fc) -> Tensor:
     """fc(mean_hw(x)) for an nn.Linear `fc`; one node on a fused device when the layer is classifier-sized."""
     x = realize(x)

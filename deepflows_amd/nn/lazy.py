@@ -26,8 +26,10 @@ Recorded forms (x0 a real tensor):
     fc(x0), x0 two-dimensional                 "linear"
     fc(mean(mean(x0, 2), 2))                   "head"      (the classifier head; launched as one node when touched)
     relu(fc(x0)), fc2(relu(fc1(x0)))           "linrelu", "mlp2"   (test/MLP_MNIST_cuda.py:51-54)
+    drop(x0), fc(drop(x0)), x0 two-dimensional "drop", "droplin"   (test/CNN_CIFAR10_cuda.py:104-107)
 Completing calls: MaxPool2d(relu(bn(conv(x0)))), bn(conv(bn(conv(x0)))) + identity, F.relu(fc(x0)),
-CrossEntropyLoss(head) (round 6: head + loss + the per-image half of their backward pass from one launch).
+CrossEntropyLoss(head), CrossEntropyLoss(fc(drop(x0))) (round 6: head + loss + the per-image half of their backward pass
+from one launch).
 A record is single-shot: when a fused launch has run the BatchNorm of a record it did not hand out (`bn1` applied on conv2's
 loads, `bn2` inside the block's tail, the stem's BatchNorm), whoever still holds the record and touches it later gets the same
 values from a normalisation that does NOT update running_mean / running_var a second time (the reference calls each module
@@ -44,6 +46,7 @@ from . import functional as F
 ENABLED = os.environ.get("DF_LAZY_MODULES", "1") != "0"
 MLP_CE = os.environ.get("DF_MLP_CE", "1") != "0"        # fc2(relu(fc1(x))) + CrossEntropyLoss: one launch each way (0: five launches)
 HEAD_CE = os.environ.get("DF_HEAD_CE", "1") != "0"      # head + CrossEntropyLoss from one launch (0: the three nodes of rounds 1-5)
+DROPLIN_CE = os.environ.get("DF_DROPLIN_CE", "1") != "0"   # Dropout + classifier + CrossEntropyLoss from one launch (0: three nodes)
 
 
 def _state(x):
@@ -149,9 +152,23 @@ def max_pool2d(module, x):
     return None                                            # (the caller pools realize(x))
 
 
+def dropout(module, x, mask, keep):
+    """Dropout.forward in training mode with its mask drawn: on a two-dimensional tensor of a fused device the call is recorded
+    (a classifier-sized Linear and a CrossEntropyLoss may complete it); None = the module launches F.dropout_train"""
+    if not (ENABLED and DROPLIN_CE and is_grad_enable() and _state(x) is None):
+        return None
+    xr = realize(x)
+    if (isinstance(xr, Tensor) and F._fused(xr) and len(xr.shape) == 2 and xr.requires_grad and int(xr.shape[1]) <= 2048
+            and hasattr(xr.device.mod, "droplin_ce_forward")):
+        return LazyTensor("drop", xr, module, (mask, keep))
+    return None
+
+
 def linear(module, x):
     """Linear.forward: on mean(mean(x0, 2), 2) the classifier head as one node; on a 2-D tensor of a fused device the call is
     recorded (an F.relu may follow: one node for both); None = the module launches F.linear"""
+    if _is(x, "drop") and int(module.weight.shape[1]) <= 16 and int(module.weight.shape[0]) == int(_state(x)[1].shape[1]):
+        return LazyTensor("droplin", x, module)            # fc(drop(x0)), nothing of it launched yet
     if _is(x, "linrelu") and _state(_state(x)[1]) is not None:
         return LazyTensor("mlp2", x, module)               # fc2(relu(fc1(x0))), nothing of it launched yet
     if _is(x, "meanhw"):
@@ -208,6 +225,10 @@ def _force(lz):
             return F.linear_relu(realize(lin[1]), lin[2].weight, lin[2].bias)
         return F.relu(realize(x))                          # (somebody has launched the Linear meanwhile)
     if op == "mlp2":
+        return F.linear(realize(x), module.weight, module.bias)
+    if op == "drop":
+        return F.dropout_train(realize(x), extra[0], extra[1])
+    if op == "droplin":
         return F.linear(realize(x), module.weight, module.bias)
     if op == "relu":
         return F.relu(realize(x))
@@ -297,6 +318,8 @@ def _head_ce(logits, target):
     launch; the record then holds the logits node.  None = not that form."""
     if _is(logits, "mlp2"):
         return _mlp2_ce(logits, target)
+    if _is(logits, "droplin"):
+        return _droplin_ce(logits, target)
     if not _is(logits, "head"):
         return None
     st = object.__getattribute__(logits, "_lz")
@@ -304,6 +327,24 @@ def _head_ce(logits, target):
     if not isinstance(tgt, Tensor):
         return None
     both = F.head_ce_train(st[1], st[2], tgt)
+    if both is None:
+        return None
+    st[4] = both[0]
+    return both[1]
+
+
+def _droplin_ce(logits, target):
+    """CrossEntropyLoss on fc(drop(x0)) with nothing of it launched: one launch; the record then holds the logits node (the
+    Dropout's own record stays a record: whoever still holds it and touches it later launches a Dropout node with the same
+    mask).  None = not that form."""
+    st = object.__getattribute__(logits, "_lz")
+    drop = _state(st[1])
+    if drop is None:
+        return None
+    tgt = realize(target)
+    if not isinstance(tgt, Tensor):
+        return None
+    both = F.droplin_ce_train(drop[1], drop[3][0], drop[3][1], st[2], tgt)
     if both is None:
         return None
     st[4] = both[0]

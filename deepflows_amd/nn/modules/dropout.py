@@ -71,7 +71,10 @@ class Dropout(Module):
                 if up is None or mask._handle.size < 8192 or not up(mask._handle, 1 - self.p):
                     mask_np = np.ascontiguousarray(bernoulli_mask(1 - self.p, x.shape))
                     x.device.from_numpy(mask_np, mask._handle)
-            from .. import functional as F
+            from .. import functional as F, lazy
+            out = lazy.dropout(self, x, mask, 1 - self.p)      # (fc(drop(x)) + CrossEntropyLoss: one launch, nn/lazy.py)
+            if out is not None:
+                return out
             return F.dropout_train(x, mask, 1 - self.p)
         return x * (1 - self.p)
 

@@ -444,6 +444,15 @@ int dfhip_head_ce_forward(const float* x, const float* w, const float* b, const 
                           float* logits, float* loss, float* dlogits, float* dx, float* rowloss, int N, int C, int HW,
                           int P, float scale, float gscale, int* done);
 
+/* The same launch for a classifier behind a Dropout layer -- criterion(fc(drop(x)), target) with x (N, C) two-dimensional
+ * (test/CNN_CIFAR10_cuda.py:104-107 + its CrossEntropyLoss; BASELINE.json config 3): xd (N, C) = x * mask / keep
+ * (nn/modules/dropout.py:31, dfhip_dropout_apply's two roundings) is what the Linear reads and is kept for dfhip_head_grads
+ * (as `pooled`); dx (N, C or NULL) is the gradient at Dropout's INPUT, (dlogits . w^T) / keep * mask.  logits, loss, dlogits,
+ * rowloss as dfhip_head_ce_forward.  *done = 0 and nothing launched outside P <= 16, C <= 2048, N <= 4096. */
+int dfhip_droplin_ce_forward(const float* x, const float* mask, float keep, const float* w, const float* b, const float* target,
+                             float* xd, float* logits, float* loss, float* dlogits, float* dx, float* rowloss, int N, int C,
+                             int P, int* done);
+
 /* dw (C, P) = pooled^T . dlogits (tensor.py:716), db (P) = column sums of dlogits (tensor.py:462-483); either may be NULL.
  * rowloss / loss (or NULL, NULL): also the mean of the row losses (see dfhip_head_ce_forward).
  * Between dfhip_wgrad_group_begin and _end the sums are extra workgroups of the group's slab-sum launch (no launch of their

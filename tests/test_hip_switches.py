@@ -23,6 +23,8 @@ OVERWRITE = [
     ("DF_GRAD_IN_BUCKET", "0"), ("DFHIP_WGRAD_GROUP_DIV", "4"), ("DFHIP_WGRAD_SIDE", "6"),
     # (round 6: head + loss + the head's backward as the three launches of rounds 1-5)
     ("DF_HEAD_CE", "0"),
+    # (round 6: Dropout, the classifier behind it and the loss as three launches each way -- the CNN job)
+    ("DF_DROPLIN_CE", "0"),
     # (round 5's diagnostic: the backward chain on 128 CUs, every four queued weight gradients on the other 128)
     (("DFHIP_OVERLAP_CUS", "128"), ("DFHIP_WGRAD_SIDE", "4")),
 ]
