@@ -1933,7 +1933,7 @@ __global__ __launch_bounds__(256 * IPB) void k_head_ce(const float* __restrict__
   const int img = threadIdx.x >> 8, tid = threadIdx.x & 255;
   const int n = min((int)blockIdx.x * IPB + img, N - 1);        // (an image past the end re-does the last one; nothing of it is stored)
   const bool live = (int)blockIdx.x * IPB + img < N;
-  float acc[P], pv[CPT], wr[CPT][P];
+  float acc[P], pv[CPT], wr[DROP ? 1 : CPT][P];      // (DROP: the weights stay in LDS)
 #pragma unroll
   for (int j = 0; j < P; j++) acc[j] = 0.0f;
   float tv[P];                                     // the target row: requested with the first loads
@@ -1944,24 +1944,40 @@ __global__ __launch_bounds__(256 * IPB) void k_head_ce(const float* __restrict__
   }
   float mk[DROP ? CPT : 1];
   if constexpr (DROP) {
+    // The weights (C x Pn: 80 KB for the CNN workload's 2 048 x 10) go through LDS: a thread's channels are 256 apart and a
+    // channel's Pn weights 4 Pn bytes from the next channel's, so loading them per channel is 16 CPT requests of 64 scattered
+    // 4-byte words each (measured: 14.4 us for the launch); the flat copy is C Pn / 1 024 16-byte requests per thread.
+    extern __shared__ __attribute__((aligned(16))) float head_wl[];
     float xr[CPT];
 #pragma unroll
     for (int q = 0; q < CPT; q++) {
       const int cc = min(tid + 256 * q, C - 1);
       xr[q] = x[(int64_t)n * C + cc];
       mk[q] = mask[(int64_t)n * C + cc];
-      const float* wp = w + (int64_t)cc * Pn;
-#pragma unroll
-      for (int j = 0; j < P; j++) wr[q][j] = wp[min(j, Pn - 1)];
     }
-    asm volatile("" ::: "memory");                 // (a compiler barrier: plain loads are sunk to their first use otherwise)
+    {
+      constexpr int R4 = 20;                       // 16-byte requests of a thread per round
+      const int total = C * Pn, total4 = (((uintptr_t)w & 15) == 0) ? total >> 2 : 0;
+      for (int base = 0; base < total4; base += 256 * R4) {
+        typedef float f32x4w __attribute__((ext_vector_type(4)));   // (HIP's float4 struct is not promoted to registers here)
+        f32x4w wv4[R4];
+#pragma unroll
+        for (int u = 0; u < R4; u++) wv4[u] = reinterpret_cast<const f32x4w*>(w)[min(base + tid + 256 * u, total4 - 1)];
+        asm volatile("" ::: "memory");             // (a compiler barrier: plain loads are sunk to their first use otherwise)
+#pragma unroll
+        for (int u = 0; u < R4; u++)
+          if (base + tid + 256 * u < total4) reinterpret_cast<f32x4w*>(head_wl)[base + tid + 256 * u] = wv4[u];
+      }
+      for (int i = (total4 << 2) + tid; i < total; i += 256) head_wl[i] = w[i];
+    }
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < CPT; q++) {
-      const int c = tid + 256 * q;
+      const int c = tid + 256 * q, cc = min(c, C - 1);
       pv[q] = c < C ? __fdiv_rn(__fmul_rn(xr[q], mk[q]), keep) : 0.0f;
       if (c < C && live) pooled[(int64_t)n * C + c] = pv[q];
 #pragma unroll
-      for (int j = 0; j < P; j++) acc[j] = fmaf(pv[q], wr[q][j], acc[j]);
+      for (int j = 0; j < P; j++) acc[j] = fmaf(pv[q], head_wl[cc * Pn + min(j, Pn - 1)], acc[j]);
     }
   } else {
 #pragma unroll
@@ -2053,10 +2069,17 @@ __global__ __launch_bounds__(256 * IPB) void k_head_ce(const float* __restrict__
     for (int q = 0; q < CPT; q++) {
       const int c = tid + 256 * q;
       float s = 0.0f;
+      if constexpr (DROP) {
+        extern __shared__ __attribute__((aligned(16))) float head_wl[];
+        const int cc = min(c, C - 1);
 #pragma unroll
-      for (int j = 0; j < P; j++) s = fmaf(d[j], wr[q][j], s);
-      s *= gscale;
-      if constexpr (DROP) s = __fmul_rn(__fdiv_rn(s, keep), mk[q]);
+        for (int j = 0; j < P; j++) s = fmaf(d[j], head_wl[cc * Pn + min(j, Pn - 1)], s);
+        s = __fmul_rn(__fdiv_rn(s * gscale, keep), mk[q]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < P; j++) s = fmaf(d[j], wr[q][j], s);
+        s *= gscale;
+      }
       if (c < C && live) {
         float* o = dx + ((int64_t)n * C + c) * HW;
         if ((HW & 3) == 0) {
@@ -2576,9 +2599,18 @@ int dfhip_droplin_ce_forward(const float* x, const float* mask, float keep, cons
                  4.0 * ((dx ? 4.0 : 3.0) * N * (double)C + (double)C * P + 3.0 * N * P));
   const float inv_rows = 1.0f / (float)N;
   const dim3 grid((unsigned)N);
+  const size_t lds = (size_t)C * P * sizeof(float);
 #define DF_DROPLIN(CPT)                                                                                                    \
-  DF_LAUNCH((k_head_ce<16, CPT, 1, true>), grid, dim3(256), 0, stream(), x, w, b, target, xd, logits, dlogits, dx, rowloss,   \
-            loss, N, C, 1, P, 1.0f, 1.0f, inv_rows, mask, keep)
+  do {                                                                                                                     \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set) {                                                                                                       \
+      DF_HIP(hipFuncSetAttribute((const void*)k_head_ce<16, CPT, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                 2048 * 16 * (int)sizeof(float)));                                                         \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    DF_LAUNCH((k_head_ce<16, CPT, 1, true>), grid, dim3(256), lds, stream(), x, w, b, target, xd, logits, dlogits, dx,     \
+              rowloss, loss, N, C, 1, P, 1.0f, 1.0f, inv_rows, mask, keep);                                                 \
+  } while (0)
   if (C <= 256) DF_DROPLIN(1);
   else if (C <= 512) DF_DROPLIN(2);
   else if (C <= 1024) DF_DROPLIN(4);
@@ -2625,7 +2657,11 @@ int dfhip_softmax_ce_backward(const float* logits, const float* target, const fl
 
 int dfhip_reduce_to_shape(const float* src, float* dst, int src_ndim, const int64_t* src_shape,
                           int dst_ndim, const int64_t* dst_shape) {
-  DF_INIT();
+  // (a convolution's bias gradient in the middle of a backward sweep: what the sweep has deferred -- queued weight gradients,
+  // the head's sums waiting for the group's slab-sum launch -- stays deferred unless it touches these arrays)
+  DF_INIT_KEEP();
+  DF_TOUCH(src);
+  DF_TOUCH(dst);
   DF_CHECK_ARG(src_ndim >= 1 && src_ndim <= DFHIP_MAX_DIMS && dst_ndim >= 0 && dst_ndim <= src_ndim,
                "reduce_to_shape: bad ranks %d -> %d", src_ndim, dst_ndim);
   DF_CHECK_ARG(src && dst, "reduce_to_shape: null array");
@@ -2651,6 +2687,7 @@ int dfhip_reduce_to_shape(const float* src, float* dst, int src_ndim, const int6
     bn_split(N, C, S, ipb);
     float* partial = workspace_small((size_t)C * S * sizeof(float));
     if (!partial) return DFHIP_OUT_OF_MEMORY;
+    DF_TOUCH(partial);
     DF_LAUNCH(k_channel_sum, dim3((unsigned)C, (unsigned)S), dim3(kThreads), 0, stream(), src, partial, N, C,
                        HW, S, ipb);
     DF_LAUNCH_CHECK();

@@ -2419,6 +2419,7 @@ struct GQueued {
   int rides_on;                  // -1, or the queue index of the 3x3 / stride-2 layer whose workgroups compute this 1x1 shortcut too
   int tstride, toff;             // (kind 13) the slab sum's record stride and first tap in dw; 0, 0 = T, 0
   int W, ow, k, stride, pad;     // the rest of the call's arguments (a small group is re-planned as stand-alone launches)
+  int U;                         // (direct) units of one (channel tile, output tile): ps = ceil(U / units) -- group_flush may re-cut
 };
 std::vector<GQueued> g_queue;
 bool g_group_on = false;
@@ -2452,9 +2453,52 @@ float* g_group_slabs = nullptr;                   // slab area supplied by the s
 // stream (first operands, cross-wave sum, slab stores).  (Cutting every layer to a common cycle target instead of 32
 // workgroups per layer was measured in round 3: the shorter tail came back as prologues / epilogues of the extra workgroups.)
 static double replan_direct(const GQueued& e) {
-  static const double kUnitCycles[14] = {9260, 8720, 7640, 5560, 4780, 4680, 4490, 9400, 7200, 2840, 19000, 9800, 9400, 5600};
+  static const double kUnitCycles[14] = {9260, 8720, 7640, 5560, 4780, 4680, 4490, 9400, 7200, 2840, 19000, 9800, 9400, 4500};
   const double unit_cycles = e.d.kind >= 0 && e.d.kind < 14 ? kUnitCycles[e.d.kind] : 5000.0;
   return e.d.units / 4 * unit_cycles + 14000.0;
+}
+static double unit_cycles_of(const GQueued& e) { GQueued t = e; t.d.units = 4; return replan_direct(t) - 14000.0; }
+
+// A group that holds a 5x5 kernel's tap rows (queue_wgrad_k5 cut them for 7/8 of the chip as if they were alone) AND other
+// layers, all of it about one round of workgroups: every workgroup starts at once and the launch lasts as long as the longest
+// one -- so the layers are re-cut in proportion to their matrix cycles, to end together.  (The CNN workload's conv3 + conv2:
+// 32 workgroups of 285 k cycles beside 220 of 120 k, a launch of 130 us, after the cut 64 x 140 k + 190 x 140 k.)  Sweeps of many
+// layers (ResNet-18: 2.4 rounds, planned per layer) are left as queued.
+static void recut_one_round(std::vector<GQueued>& q) {
+  bool rows5 = false, others = false;
+  int64_t wgs = 0;
+  double total = 0.0;
+  for (const auto& e : q) {
+    if (!e.d.direct || e.U <= 0 || e.d.aff || (e.k == 1 && e.stride == 2)) return;
+    (e.d.kind == 13 ? rows5 : others) = true;
+    wgs += (int64_t)e.d.ps * e.d.CT * e.d.OT;
+    total += (double)e.d.CT * e.d.OT * (e.U / 4.0) * unit_cycles_of(e);
+  }
+  if (!rows5 || !others || wgs > (int64_t)num_cus() * 5 / 4) return;
+  for (auto& e : q) {
+    const double share = (double)e.d.CT * e.d.OT * (e.U / 4.0) * unit_cycles_of(e) / total;
+    int ps = (int)(share * num_cus() / (e.d.CT * e.d.OT) + 0.5);
+    ps = std::max(1, std::min(ps, e.U / 4));
+    int upb = (int)df_ceil_div(e.U, ps);
+    upb = std::max(4, (upb + 3) & ~3);
+    e.d.units = upb;
+    e.d.ps = (int)df_ceil_div(e.U, upb);
+  }
+  // (rounding may have gone past one round: the workgroups left over would run a second one by themselves -- take slabs from
+  // the layers whose workgroups are shortest until everything is resident at once)
+  for (;;) {
+    int64_t n = 0;
+    for (const auto& e : q) n += (int64_t)e.d.ps * e.d.CT * e.d.OT;
+    if (n <= num_cus()) break;
+    GQueued* pick = nullptr;
+    for (auto& e : q)
+      if (e.d.ps > 1 && (!pick || replan_direct(e) < replan_direct(*pick))) pick = &e;
+    if (!pick) break;
+    int upb = (int)df_ceil_div(pick->U, pick->d.ps - 1);
+    upb = std::max(4, (upb + 3) & ~3);
+    pick->d.units = upb;
+    pick->d.ps = (int)df_ceil_div(pick->U, upb);
+  }
 }
 
 int group_flush() {
@@ -2498,6 +2542,7 @@ int group_flush() {
       return st < 0 ? DFHIP_RUNTIME_ERROR : st;
     }
   }
+  if (!g_group_stream) recut_one_round(q);
   for (auto& e : q) {
     e.work = e.d.direct ? replan_direct(e) : (double)e.d.N * e.d.oh * e.d.oh * e.T / e.d.ps * 16.0;
     e.rides_on = -1;
@@ -2740,6 +2785,7 @@ static int queue_wgrad_k5(const float* x, const float* dy, float* dw, int N, int
     d.kind = 13; d.direct = 1; d.CT = CT; d.OT = OT; d.tap_row0 = i0;
     d.units = upb;
     d.ps = (int)df_ceil_div(U, upb);
+    e.U = U;
     d.m_br = magic_u32((unsigned)upr);
     e.dw = dw; e.T = 5; e.tstride = 25; e.toff = 5 * i0;
     e.lds = (size_t)3 * kRowsWaves * 4 * 64 * 16;
@@ -2860,6 +2906,7 @@ int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int
       d.direct = 1;
       d.units = upb;
       d.ps = (int)df_ceil_div(U, upb);
+      e.U = U;
       d.m_br = magic_u32((unsigned)upr);
       e.lds = (size_t)(k == 3 ? 3 : 1) * kRowsWaves * 4 * 64 * 16;
     }

@@ -10,7 +10,7 @@ from deepflows_amd import backend_api, workloads
 from deepflows_amd.tensor import Graph
 dev = backend_api.Device("hip")
 dev.mod.conv_matmul_dtype = os.environ.get("MM", "f32")
-model, opt, crit, xt, yt = bench.build_job("resnet18", dev, 0, 256)
+model, opt, crit, xt, yt = bench.build_job(os.environ.get("WORKLOAD", "resnet18"), dev, 0, 256)
 for i in range(int(os.environ.get("STEPS", "6"))):
     workloads.train_step(model, crit, opt, xt, yt)
     Graph.free_graph()
