@@ -1630,11 +1630,6 @@ __global__ void k_set_adam_hyper(float* hyper_dev, AdamHyper h) {
   *reinterpret_cast<AdamHyper*>(hyper_dev + 16) = h;
 }
 
-struct SgdHyper {
-  float lr, mu, wd, gscale;
-  int nesterov, use_momentum;
-};
-
 __device__ __forceinline__ void sgd_block(const TensorBatch& tb, const SgdHyper& h);
 
 __global__ __launch_bounds__(kThreads) void k_sgd(TensorBatch tb, SgdHyper h) { sgd_block(tb, h); }
@@ -1671,18 +1666,7 @@ __device__ __forceinline__ void sgd_block(const TensorBatch& tb, const SgdHyper&
   for (int u = 0; u < U; u++) {
     const int64_t i = lo + threadIdx.x + (int64_t)u * kThreads;
     if (i >= hi) break;
-    // optim/sgd.py:16-24
-    float gi = gv[u];
-    if (h.gscale != 1.0f) gi = gi * h.gscale;
-    const float pi = pv[u];
-    gi = gi + pi * h.wd;
-    float upd = gi;
-    if (h.use_momentum) {
-      const float vi = mv[u] * h.mu + gi;
-      mb[i] = vi;
-      upd = h.nesterov ? gi + h.mu * vi : vi;
-    }
-    p[i] = pi + (h.lr * upd) * -1.0f;
+    sgd_elem(p, mb, i, gv[u], pv[u], mv[u], h);       // optim/sgd.py:16-24 (dfhip_head.h)
   }
 }
 
@@ -2892,6 +2876,11 @@ int dfhip_sgd_hyper(float* hyper_dev, double lr, double momentum, double weight_
 
 int dfhip_sgd_step_dev(int n_tensors, float* const* params, const float* const* grads,
                        float* const* momentum_buf, const int64_t* sizes, const float* hyper_dev) {
+  DF_INIT_KEEP();
+  if (hyper_dev) {        // (a perceptron's deferred backward launch takes the update over exactly its gradients along)
+    const int took = mlp_bwd_take_sgd(n_tensors, params, grads, momentum_buf, sizes, nullptr, hyper_dev);
+    if (took) return took < 0 ? DFHIP_RUNTIME_ERROR : DFHIP_OK;
+  }
   DF_INIT();
   DF_CHECK_ARG(n_tensors >= 0 && hyper_dev, "sgd_step_dev: bad arguments");
   if (n_tensors == 0) return DFHIP_OK;
@@ -2912,12 +2901,17 @@ int dfhip_sgd_step_dev(int n_tensors, float* const* params, const float* const* 
 int dfhip_sgd_step(int n_tensors, float* const* params, const float* const* grads,
                    float* const* momentum_buf, const int64_t* sizes, double lr, double momentum,
                    double weight_decay, int nesterov, double grad_scale) {
+  DF_INIT_KEEP();
+  const SgdHyper h = make_sgd_hyper(lr, momentum, weight_decay, nesterov, grad_scale);
+  if (momentum <= 0.0 || momentum_buf) {
+    const int took = mlp_bwd_take_sgd(n_tensors, params, grads, momentum_buf, sizes, &h, nullptr);
+    if (took) return took < 0 ? DFHIP_RUNTIME_ERROR : DFHIP_OK;
+  }
   DF_INIT();
   DF_CHECK_ARG(n_tensors >= 0, "sgd_step: bad arguments");
   if (n_tensors == 0) return DFHIP_OK;
   DF_CHECK_ARG(params && grads && sizes, "sgd_step: null table");
   DF_CHECK_ARG(momentum <= 0.0 || momentum_buf, "sgd_step: momentum needs buffers");
-  const SgdHyper h = make_sgd_hyper(lr, momentum, weight_decay, nesterov, grad_scale);
   double total = 0;
   for (int i = 0; i < n_tensors; i++) total += (double)sizes[i];
   ProfScope prof("sgd_step", 0.0, (h.use_momentum ? 20.0 : 12.0) * total);

@@ -9,6 +9,20 @@
 
 namespace dfhip {
 
+// optim/sgd.py:16-24 on ONE gradient element (the multi-tensor launch k_sgd and the launches that apply the update to a
+// gradient the moment it is complete -- dfhip_mlp.hip -- share the expressions, hence the bits)
+struct SgdHyper {
+  float lr, mu, wd, gscale;
+  int nesterov, use_momentum;
+};
+// where the parameters (and momentum buffers) of the gradients a launch produces live, for such a launch
+struct SgdSites {
+  float* p[4];           // parameter of gradient slot 0 .. 3 (dfhip_mlp.hip: dW1, db1, dW2, db2); nullptr = no update
+  float* mb[4];          // its momentum buffer (use_momentum)
+  SgdHyper h;            // the scalars, or
+  const float* hyper_dev;   // where they live on the device (a captured step: dfhip_sgd_hyper keeps them current)
+};
+
 struct HeadGrads {
   const float* dl;       // (N, Pn) d loss / d logits
   const float* pooled;   // (N, C)
@@ -23,6 +37,14 @@ constexpr int kHeadP = 16;                         // compile-time bound of Pn
 constexpr int kHeadLdsFloats = 256 * kHeadP;
 __host__ __device__ inline int head_grads_blocks(const HeadGrads& h) { return (h.C + 63) / 64; }
 
+// dfhip_mlp.hip: the perceptron's backward launch stays deferred until something touches its arrays; an SGD step over exactly
+// its gradients is taken into the launch (1), see there
+bool mlp_bwd_pending_touches(const void* p);
+int mlp_bwd_flush();
+bool mlp_bwd_defer_free(float* p);
+int mlp_bwd_take_sgd(int n, float* const* params, const float* const* grads, float* const* mbuf, const int64_t* sizes,
+                     const SgdHyper* h, const float* hyper_dev);
+
 // host side (dfhip_wgrad.hip): hand the sums to the slab-sum launch of the weight-gradient group that is open; false = no
 // group is open (launch them)
 bool head_grads_defer(const HeadGrads& h);
@@ -30,6 +52,23 @@ bool head_grads_defer(const HeadGrads& h);
 int head_grads_launch(const HeadGrads& h);
 
 #if defined(__HIPCC__)
+__device__ __forceinline__ void sgd_elem(float* __restrict__ p, float* __restrict__ mb, int64_t i, float gi, float pi, float mi,
+                                         const SgdHyper& h) {
+  if (h.gscale != 1.0f) gi = gi * h.gscale;
+  gi = gi + pi * h.wd;
+  float upd = gi;
+  if (h.use_momentum) {
+    const float vi = mi * h.mu + gi;
+    mb[i] = vi;
+    upd = h.nesterov ? gi + h.mu * vi : vi;
+  }
+  p[i] = pi + (h.lr * upd) * -1.0f;
+}
+// (the element's parameter and momentum read here: for a launch that has just produced the gradient)
+__device__ __forceinline__ void sgd_elem_at(float* __restrict__ p, float* __restrict__ mb, int64_t i, float gi, const SgdHyper& h) {
+  sgd_elem(p, mb, i, gi, p[i], h.use_momentum ? mb[i] : 0.0f, h);
+}
+
 // (dfhip_fused.hip's wave_sum, instruction for instruction: the loss below has k_ce_small's bits)
 __device__ __forceinline__ float head_wave_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));   // row_ror:8
@@ -80,8 +119,10 @@ __device__ __forceinline__ void loss_finish_body(const float* __restrict__ rowlo
 // fmas per thread, 3.8 us of a 8.6 us launch.)  Block 0 also forms db (thread j: the images in four chains), the last block
 // the loss.  A fixed order of additions: the same bits in every run, inside a group or not.  lds: kHeadLdsFloats floats.
 // LEAN (inside k_wgrad_group_sum: the body must stay below the slab sum's own registers): 32 operands in flight, not 64.
+// sg / sh (dfhip_mlp.hip's backward launch with the optimizer step in it): slots 2, 3 of sg are dW's and db's parameters.
 template <bool LEAN>
-__device__ __forceinline__ void head_grads_body(const HeadGrads& h, int blk, float* lds) {
+__device__ __forceinline__ void head_grads_body(const HeadGrads& h, int blk, float* lds, const SgdSites* sg = nullptr,
+                                                const SgdHyper* sh = nullptr) {
   typedef float f32x4h __attribute__((ext_vector_type(4)));
   constexpr int P = kHeadP;
   if (blk == head_grads_blocks(h) - 1 && h.loss) { // (the block with the fewest channels also finishes the loss)
@@ -143,9 +184,16 @@ __device__ __forceinline__ void head_grads_body(const HeadGrads& h, int blk, flo
   if (h.dw && i < h.Pn) {
 #pragma unroll
     for (int v = 0; v < 4; v++)
-      if (c0 + 4 * kk + v < h.C) h.dw[(int64_t)(c0 + 4 * kk + v) * h.Pn + i] = acc[v];
+      if (c0 + 4 * kk + v < h.C) {
+        const int64_t at = (int64_t)(c0 + 4 * kk + v) * h.Pn + i;
+        h.dw[at] = acc[v];
+        if (sg && sg->p[2]) sgd_elem_at(sg->p[2], sg->mb[2], at, acc[v], *sh);
+      }
   }
-  if (blk == 0 && h.db && tid < h.Pn) h.db[tid] = dbv;
+  if (blk == 0 && h.db && tid < h.Pn) {
+    h.db[tid] = dbv;
+    if (sg && sg->p[3]) sgd_elem_at(sg->p[3], sg->mb[3], tid, dbv, *sh);
+  }
 }
 #endif
 

@@ -18,6 +18,8 @@
 // workgroup forms dW2, db1, db2, another the loss.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "dfhip_internal.h"
 #include "dfhip_head.h"
 
@@ -388,15 +390,21 @@ struct MlpBwd {
 // blocks [0, (K / 16) * HALVES): dW1 rows [16 b, 16 b + 16) x one half of the hidden units (all of them for 64), every operand
 // of the round requested up front; the blocks of the first 16 rows also form db1 from their dz1 operand.  Then HD / 64 blocks
 // of head_grads_body (dfhip_head.h): dW2 = h^T . dlogits, db2 and the mean of the row losses.
-template <int NW>
-__global__ __launch_bounds__(256) void k_mlp2_bwd(const MlpBwd a, const HeadGrads hg) {
+// SGD (the optimizer's call arrived while this launch was still deferred -- see mlp_bwd_take_sgd below): every gradient
+// element is complete in the thread that stores it, so optim/sgd.py:16-24 is applied to its parameter right there (sgd_elem,
+// dfhip_head.h: the multi-tensor launch's expressions and bits) and the step has no optimizer launch.
+template <int NW, bool SGD>
+__global__ __launch_bounds__(256) void k_mlp2_bwd(const MlpBwd a, const HeadGrads hg, const SgdSites sg) {
   constexpr int HD = 64 * NW, NT = NW >= 2 ? NW / 2 : 1, HALVES = NW / NT;      // NT 16-wide column tiles per wave (four waves)
   __shared__ __attribute__((aligned(16))) float lds[kHeadLdsFloats];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nb1 = (a.K / 16) * HALVES;
   const int blk = blockIdx.x;
+  SgdHyper sh = {};
+  if constexpr (SGD) sh = sg.hyper_dev ? *reinterpret_cast<const SgdHyper*>(sg.hyper_dev) : sg.h;
   if (blk >= nb1) {
-    head_grads_body<false>(hg, blk - nb1, lds);
+    if constexpr (SGD) head_grads_body<false>(hg, blk - nb1, lds, &sg, &sh);
+    else head_grads_body<false>(hg, blk - nb1, lds);
     return;
   }
   const int b = blk / HALVES, hh = blk - b * HALVES;
@@ -441,17 +449,59 @@ __global__ __launch_bounds__(256) void k_mlp2_bwd(const MlpBwd a, const HeadGrad
 #pragma unroll
   for (int t = 0; t < NT; t++)
 #pragma unroll
-    for (int v = 0; v < 4; v++)
-      a.dw1[(int64_t)(b * 16 + 4 * kk + v) * HD + c0 + 16 * t + i] = acc[t][v];
+    for (int v = 0; v < 4; v++) {
+      const int64_t at = (int64_t)(b * 16 + 4 * kk + v) * HD + c0 + 16 * t + i;
+      a.dw1[at] = acc[t][v];
+      if constexpr (SGD)
+        if (sg.p[0]) sgd_elem_at(sg.p[0], sg.mb[0], at, acc[t][v], sh);
+    }
   if (b == 0 && a.db1) {                           // db1 = column sums of dz1: the four row groups of a lane's column meet
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       float sct = colsum[t];
       sct += __shfl_xor(sct, 16, 64);
       sct += __shfl_xor(sct, 32, 64);
-      if (kk == 0) a.db1[c0 + 16 * t + i] = sct;
+      if (kk == 0) {
+        a.db1[c0 + 16 * t + i] = sct;
+        if constexpr (SGD)
+          if (sg.p[1]) sgd_elem_at(sg.p[1], sg.mb[1], c0 + 16 * t + i, sct, sh);
+      }
     }
   }
+}
+
+struct MlpPending { bool active = false; MlpBwd a; int HD = 0; std::vector<float*> frees; } g_mlp_pending;
+
+// arrays of the pending launch that were freed while it waited go back to the pool behind it
+int release_deferred_frees() {
+  int st = DFHIP_OK;
+  for (float* p : g_mlp_pending.frees) {
+    const int s = dfhip_free(p);
+    if (st == DFHIP_OK) st = s;
+  }
+  g_mlp_pending.frees.clear();
+  return st;
+}
+
+int mlp_bwd_launch(const MlpBwd& a, int HD, const SgdSites* sg) {
+  const int M = a.M, K = a.K, P = a.Pn;
+  ProfScope prof(sg ? "mlp2_ce_bwd_sgd" : "mlp2_ce_bwd", 2.0 * M * ((double)K * HD + (double)HD * P),
+                 4.0 * ((double)M * K + (sg ? 3.0 : 1.0) * ((double)K * HD + (double)HD * P) + 2.0 * M * HD + (double)M * P));
+  const HeadGrads hg = {a.dl, a.h, a.dw2, a.db2, a.rowloss, a.loss, a.inv_rows, M, HD, P};
+  const int halves = HD >= 128 ? 2 : 1;
+  const dim3 grid((unsigned)((K / 16) * halves + head_grads_blocks(hg)));
+  const SgdSites none = {};
+#define DF_BWD(NWV)                                                                                       \
+  do {                                                                                                    \
+    if (sg) DF_LAUNCH((k_mlp2_bwd<NWV, true>), grid, dim3(256), 0, stream(), a, hg, *sg);                 \
+    else DF_LAUNCH((k_mlp2_bwd<NWV, false>), grid, dim3(256), 0, stream(), a, hg, none);                  \
+  } while (0)
+  if (HD == 64) DF_BWD(1);
+  else if (HD == 128) DF_BWD(2);
+  else DF_BWD(4);
+#undef DF_BWD
+  DF_LAUNCH_CHECK();
+  return DFHIP_OK;
 }
 
 }  // namespace
@@ -510,17 +560,77 @@ int dfhip_mlp2_ce_backward(const float* x, const float* h, const float* dz1, con
   DF_CHECK_ARG(M > 0 && K > 0 && K % 16 == 0 && (HD == 64 || HD == 128 || HD == 256) && P > 0 && P <= kP,
                "mlp2_ce_backward: bad dimensions (K %% 16 == 0, HD 64 / 128 / 256, P <= 16)");
   DF_CHECK_ARG(x && h && dz1 && dlogits && dw1 && dw2 && (!loss || rowloss), "mlp2_ce_backward: null array");
-  ProfScope prof("mlp2_ce_bwd", 2.0 * M * ((double)K * HD + (double)HD * P),
-                 4.0 * ((double)M * K + (double)K * HD + (double)HD * P + 2.0 * M * HD + (double)M * P));
-  const MlpBwd a = {x, h, dz1, dlogits, dw1, db1, dw2, db2, rowloss, loss, M, K, P, 1.0f / (float)M};
-  const HeadGrads hg = {dlogits, h, dw2, db2, rowloss, loss, 1.0f / (float)M, M, HD, P};
-  const int halves = HD >= 128 ? 2 : 1;
-  const dim3 grid((unsigned)((K / 16) * halves + head_grads_blocks(hg)));
-  if (HD == 64) DF_LAUNCH(k_mlp2_bwd<1>, grid, dim3(256), 0, stream(), a, hg);
-  else if (HD == 128) DF_LAUNCH(k_mlp2_bwd<2>, grid, dim3(256), 0, stream(), a, hg);
-  else DF_LAUNCH(k_mlp2_bwd<4>, grid, dim3(256), 0, stream(), a, hg);
-  DF_LAUNCH_CHECK();
+  // Not launched yet: when the next thing that happens to these gradients is the optimizer's SGD step over exactly them, ONE
+  // launch forms the gradients and applies the step (dfhip_sgd_step / _dev ask mlp_bwd_take_sgd); anything else that touches
+  // one of the arrays launches the backward pass as it is (DF_INIT / DF_TOUCH -> flush_deferred -> mlp_bwd_flush).
+  g_mlp_pending.a = {x, h, dz1, dlogits, dw1, db1, dw2, db2, rowloss, loss, M, K, P, 1.0f / (float)M};
+  g_mlp_pending.HD = HD;
+  g_mlp_pending.active = true;
   return DFHIP_OK;
 }
 
 }  // extern "C"
+
+namespace dfhip {
+
+bool mlp_bwd_pending_touches(const void* p) {
+  if (!g_mlp_pending.active || !p) return false;
+  const MlpBwd& a = g_mlp_pending.a;
+  const int HD = g_mlp_pending.HD;
+  const float* q = (const float*)p;
+  auto in = [&](const float* lo, int64_t n) { return lo && q >= lo && q < lo + n; };
+  return in(a.dw1, (int64_t)a.K * HD) || in(a.db1, HD) || in(a.dw2, (int64_t)HD * a.Pn) || in(a.db2, a.Pn) || in(a.loss, 1) ||
+         in(a.x, (int64_t)a.M * a.K) || in(a.h, (int64_t)a.M * HD) || in(a.dz1, (int64_t)a.M * HD) ||
+         in(a.dl, (int64_t)a.M * a.Pn) || in(a.rowloss, a.M);
+}
+
+int mlp_bwd_flush() {
+  if (!g_mlp_pending.active) return DFHIP_OK;
+  g_mlp_pending.active = false;
+  const int st = mlp_bwd_launch(g_mlp_pending.a, g_mlp_pending.HD, nullptr);
+  const int st2 = release_deferred_frees();
+  return st != DFHIP_OK ? st : st2;
+}
+
+// dfhip_free of an array the pending launch reads or writes (Tensor.backward frees the tape -- the launch's operands -- before
+// the optimizer is called): the block stays allocated until the launch is on the stream
+bool mlp_bwd_defer_free(float* p) {
+  if (!mlp_bwd_pending_touches(p)) return false;
+  g_mlp_pending.frees.push_back(p);
+  return true;
+}
+
+// dfhip_sgd_step / dfhip_sgd_step_dev, before anything else: 1 = the deferred backward launch took this update along (the
+// call's gradients are exactly the pending launch's), 0 = not that case (the caller proceeds; its DF_INIT launches the pending
+// backward pass first), < 0 an error
+int mlp_bwd_take_sgd(int n, float* const* params, const float* const* grads, float* const* mbuf, const int64_t* sizes,
+                     const SgdHyper* h, const float* hyper_dev) {
+  if (!g_mlp_pending.active || !params || !grads || !sizes || n < 2 || n > 4) return 0;
+  if (h && h->use_momentum && !mbuf) return 0;
+  const MlpBwd& a = g_mlp_pending.a;
+  const int HD = g_mlp_pending.HD;
+  const float* slot_g[4] = {a.dw1, a.db1, a.dw2, a.db2};
+  const int64_t slot_n[4] = {(int64_t)a.K * HD, HD, (int64_t)HD * a.Pn, a.Pn};
+  int want = 0;
+  for (int k = 0; k < 4; k++) want += slot_g[k] ? 1 : 0;
+  if (n != want) return 0;
+  SgdSites sg = {};
+  for (int i = 0; i < n; i++) {
+    int k = 0;
+    while (k < 4 && !(slot_g[k] && grads[i] == slot_g[k] && sizes[i] == slot_n[k] && !sg.p[k])) k++;
+    if (k == 4 || !params[i]) return 0;
+    // (a parameter that is one of the launch's own inputs or outputs would be read and written in one launch)
+    if (mlp_bwd_pending_touches(params[i]) || (mbuf && mbuf[i] && mlp_bwd_pending_touches(mbuf[i]))) return 0;
+    sg.p[k] = params[i];
+    sg.mb[k] = mbuf ? mbuf[i] : nullptr;
+  }
+  if (h) sg.h = *h;
+  sg.hyper_dev = hyper_dev;
+  g_mlp_pending.active = false;
+  const int st = mlp_bwd_launch(a, HD, &sg);
+  const int st2 = release_deferred_frees();
+  if (st == DFHIP_OK && st2 == DFHIP_OK) return 1;
+  return -1;
+}
+
+}  // namespace dfhip

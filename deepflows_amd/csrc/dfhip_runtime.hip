@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "dfhip_internal.h"
+#include "dfhip_head.h"
 
 namespace dfhip {
 
@@ -530,6 +531,7 @@ int dfhip_malloc(int64_t n_floats, float** out) {
 }
 
 int dfhip_free(float* p) {
+  if (mlp_bwd_defer_free(p)) return DFHIP_OK;       // (an operand of a launch that is still deferred: freed behind it, dfhip_mlp.hip)
   DF_TOUCH(p);
   return pool_free((void*)p);
 }

@@ -3136,7 +3136,9 @@ int run_wgrad_tap(const float* x, const float* dy, float* dw, int N, int C, int 
 }  // namespace
 
 namespace dfhip {
-int flush_deferred() {
+// what a backward sweep has deferred (dfhip_wgrad_group_end ends the sweep with it; the perceptron's backward launch, which
+// waits for the optimizer BEHIND the sweep, is not part of it)
+static int flush_sweep() {
   if (!g_queue.empty()) {
     int st = group_flush();
     if (st != DFHIP_OK) return st;
@@ -3160,8 +3162,14 @@ int flush_deferred() {
   g_def.slot = -1;
   return launch_slab_sum(g_def.a);
 }
+int flush_deferred() {
+  const int st = flush_sweep();
+  if (st != DFHIP_OK) return st;
+  return mlp_bwd_flush();                           // (dfhip_mlp.hip: a perceptron's backward launch waiting for its optimizer)
+}
 bool deferred_touches(const void* p) {
   if (!p) return false;
+  if (mlp_bwd_pending_touches(p)) return true;
   if (g_stem_pending.active) {
     const StemCombine& c = g_stem_pending.c;
     const float* q = (const float*)p;
@@ -3430,7 +3438,7 @@ int dfhip_wgrad_group_end(void) {
     if (st != DFHIP_OK) return st;
     if (st2 != DFHIP_OK) return st2;
   }
-  return flush_deferred();
+  return flush_sweep();
 }
 
 }  // extern "C"

@@ -156,3 +156,79 @@ def test_captured_mlp_step_replays_the_eager_step(hip_device):
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     for a, b in zip(runs[0][1], runs[1][1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("opt_kind", ["plain", "momentum_wd", "nesterov"])
+def test_sgd_step_rides_on_the_backward_launch(hip_device, cpu_oracle, opt_kind):
+    """loss.backward(); opt.step() with nothing in between that reads the gradients: the backward launch is still deferred when
+    the optimizer's call arrives and takes the update along (dfhip_sgd_step -> mlp_bwd_take_sgd: optim/sgd.py:16-24 applied to
+    every gradient element where it is complete) -- three launches per step, the gradients still written"""
+    from deepflows_amd import nn, optim, workloads
+    from deepflows_amd.tensor import Graph, Tensor
+    sizes, M = (784, 256, 10), 128
+    kw = {"plain": {}, "momentum_wd": {"momentum": 0.9, "weight_decay": 5e-4},
+          "nesterov": {"momentum": 0.9, "nesterov": True}}[opt_kind]
+    rng = np.random.default_rng(12)
+    x_np = rng.random((M, sizes[0]), dtype=np.float32)
+    y_np = np.eye(sizes[-1], dtype=np.float32)[rng.integers(0, sizes[-1], M)]
+    res = {}
+    for name, dev in (("hip", hip_device), ("cpu", cpu_oracle)):
+        np.random.seed(0)
+        model = workloads.MLP(sizes, device=dev)
+        model.train()
+        opt = optim.SGD(model.parameters(), lr=0.05, **kw)
+        crit = nn.CrossEntropyLoss()
+        x, y = Tensor(x_np, device=dev), Tensor(y_np, device=dev)
+        if name == "hip":
+            dev.mod.prof_reset(); dev.mod.prof_enable(True)
+        losses = []
+        for _ in range(4):
+            loss = crit(model(x), y)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()                                   # (the gradients are read only AFTER the step)
+            losses.append(float(loss.numpy()[0]))
+            grads = [p.grad.numpy().copy() for p in model.parameters()]
+            Graph.free_graph()
+        if name == "hip":
+            dev.mod.synchronize(); dev.mod.prof_enable(False)
+            fams = {k: v["calls"] for k, v in dev.mod.prof_read().items() if v["calls"]}
+            assert fams.get("mlp2_ce_bwd_sgd") == 4 and "sgd_step" not in fams and "mlp2_ce_bwd" not in fams, fams
+        res[name] = (losses, grads, [p.data.numpy().copy() for p in model.parameters()])
+        Graph.free_graph_all()
+    assert_close(np.array(res["hip"][0]), np.array(res["cpu"][0]), 1e-4, "losses")
+    for i, (a, b) in enumerate(zip(res["hip"][1], res["cpu"][1])):
+        assert_close(a, b, 1e-4, f"grad {i} of the last step")
+    for i, (a, b) in enumerate(zip(res["hip"][2], res["cpu"][2])):
+        assert_close(a, b, 1e-4, f"param {i} after 4 steps ({opt_kind})")
+
+
+def test_step_in_the_launch_has_the_separate_launches_bits(hip_device):
+    """the same expressions on the same gradient values: parameters after three steps are bit-identical whether the update
+    rode on the backward launch or ran as the multi-tensor launch (the gradients read in between force the latter)"""
+    sizes, M = (784, 256, 10), 128
+    rng = np.random.default_rng(13)
+    x = rng.random((M, sizes[0]), dtype=np.float32)
+    y = np.eye(sizes[-1], dtype=np.float32)[rng.integers(0, sizes[-1], M)]
+    from deepflows_amd import nn, optim, workloads
+    from deepflows_amd.tensor import Graph, Tensor
+    outs = []
+    for read_between in (False, True):
+        np.random.seed(0)
+        model = workloads.MLP(sizes, device=hip_device)
+        model.train()
+        opt = optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+        crit = nn.CrossEntropyLoss()
+        xt, yt = Tensor(x, device=hip_device), Tensor(y, device=hip_device)
+        for _ in range(3):
+            loss = crit(model(xt), yt)
+            opt.zero_grad()
+            loss.backward()
+            if read_between:
+                model.fc1.weight.grad.numpy()
+            opt.step()
+            Graph.free_graph()
+        outs.append([p.data.numpy().copy() for p in model.parameters()])
+        Graph.free_graph_all()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)

@@ -102,11 +102,13 @@ FAMILIES = {
     "conv2d_wgrad_grouped_bf16": ("k_wgrad_group_bf16",),
     "conv2d_wgrad_grouped": ("k_wgrad_group",),
     # round 6
+    "droplin_ce_fwd_bwd": ("k_head_ce<16, 1, 1, true>", "k_head_ce<16, 2, 1, true>", "k_head_ce<16, 4, 1, true>", "k_head_ce<16, 8, 1, true>"),
     "head_ce_fwd_bwd": ("k_head_ce",),
     "head_grads": ("k_head_grads",),
     "loss_finish": ("k_loss_finish",),
     "mlp_fc1_fwd": ("k_mlp_fc1",),
     "mlp2_ce_fwd": ("k_mlp2_fwd", "k_mlp2_tail"),
+    "mlp2_ce_bwd_sgd": ("k_mlp2_bwd<1, true>", "k_mlp2_bwd<2, true>", "k_mlp2_bwd<4, true>"),
     "mlp2_ce_bwd": ("k_mlp2_bwd",),
     "dropout_fwd": ("k_dropout<false>",),
     "dropout_bwd": ("k_dropout<true>",),
