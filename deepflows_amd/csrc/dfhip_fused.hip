@@ -2663,9 +2663,13 @@ int dfhip_reduce_to_shape(const float* src, float* dst, int src_ndim, const int6
     else n_red *= src_shape[a];
   }
   if (n_dst * n_red == 0) return DFHIP_OK;
+  const bool channel_sum = src_ndim == 4 && rs.keep[0] == 0 && rs.keep[1] == 1 && rs.keep[2] == 0 && rs.keep[3] == 0 &&
+                           n_red >= 4096 && src_shape[1] < (1 << 20);
+  // (a queued layer's bias gradient: workgroups of the sweep's slab-sum launch, no launch here)
+  if (channel_sum && bias_sum_defer(src, dst, (int)src_shape[0], (int)src_shape[1], (int)(src_shape[2] * src_shape[3])))
+    return DFHIP_OK;
   ProfScope prof("reduce_to_shape", 0.0, 4.0 * (double)(n_dst * n_red + n_dst));
-  if (src_ndim == 4 && rs.keep[0] == 0 && rs.keep[1] == 1 && rs.keep[2] == 0 && rs.keep[3] == 0 &&
-      n_red >= 4096 && src_shape[1] < (1 << 20)) {
+  if (channel_sum) {
     const int N = (int)src_shape[0], C = (int)src_shape[1], HW = (int)(src_shape[2] * src_shape[3]);
     int S, ipb;
     bn_split(N, C, S, ipb);

@@ -1508,10 +1508,24 @@ struct WGroup {
   unsigned long long* ticks;   // diagnostic builds (-DDFHIP_STAMPS): cycles per workgroup
   GDesc d[kMaxGroup];
 };
+// A convolution's bias gradient (nn/modules/conv.py:104-108 adds a (1, O, 1, 1) bias: its gradient is dY summed over images
+// and pixels, tensor.py:462-483) as workgroups of the sweep's slab-sum launch: a workgroup per channel adds the channel's N
+// planes up in a fixed order.  Stand-alone it is two launches on the ~4 us floor (k_channel_sum + _finish: 8 us per layer).
+constexpr int kBiasSums = 4;
+struct BiasSums {
+  const float* src[kBiasSums];   // dY (N, C, HW)
+  float* dst[kBiasSums];         // (C)
+  int N[kBiasSums], C[kBiasSums], lq[kBiasSums];     // lq: log2(HW / 4)
+  int blk_end[kBiasSums];        // running channel count
+  int n;
+};
+
 struct SGroup {
   int n;
   int vb_end[kMaxGroup];
   SlabSum s[kMaxGroup];
+  int bias_blocks;              // after the stem's and the head's workgroups: bias gradients, a workgroup per channel
+  BiasSums bias;
   int stem_blocks;              // the first workgroups of the launch: the stem's one-pass backward, last step (dfhip_stem_combine.h)
   StemCombine stem;
   int head_blocks;              // then the classifier head's sums over the images (dfhip_head.h)
@@ -2057,6 +2071,39 @@ __device__ __forceinline__ void wgrad_group_sum_body(const SlabSum& d, const int
   }
 }
 
+// 256 threads, one channel: 16-byte loads, sixteen in flight per thread; lanes, then waves, added up in a fixed order
+__device__ __forceinline__ void bias_sum_body(const BiasSums& b, int blk, float* lds) {
+  typedef float f32x4b __attribute__((ext_vector_type(4)));
+  int i = 0;
+  while (i + 1 < b.n && blk >= b.blk_end[i]) i++;
+  const int c = blk - (i ? b.blk_end[i - 1] : 0);
+  const int lq = b.lq[i], q = 1 << lq, C = b.C[i];
+  const int F = b.N[i] << lq;                        // 16-byte pieces of the channel
+  const f32x4b* src = reinterpret_cast<const f32x4b*>(b.src[i]);
+  f32x4b acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  constexpr int U = 16;
+  for (int f0 = (int)threadIdx.x; f0 < F; f0 += 256 * U) {
+    f32x4b v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int f = min(f0 + 256 * u, F - 1);
+      v[u] = src[(((int64_t)(f >> lq) * C + c) << lq) + (f & (q - 1))];
+    }
+    asm volatile("" ::: "memory");                 // (a compiler barrier: the selection DAG sinks plain loads to their uses)
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const float on = f0 + 256 * u < F ? 1.0f : 0.0f;
+      acc += v[u] * on;
+    }
+  }
+  float t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  t = head_wave_sum(t);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) lds[wave] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) b.dst[i][c] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
 __global__ __launch_bounds__(256) void k_wgrad_group_sum(SGroup a) {
   __shared__ float4 part[256 * 9];
   // (the stem's workgroups are a chain of dependent round trips over its 256 slabs: dispatched first, they run beside the
@@ -2070,7 +2117,11 @@ __global__ __launch_bounds__(256) void k_wgrad_group_sum(SGroup a) {
     head_grads_body<true>(a.head, (int)blockIdx.x - a.stem_blocks, reinterpret_cast<float*>(part));
     return;
   }
-  const int b = (int)blockIdx.x - a.stem_blocks - a.head_blocks;
+  if ((int)blockIdx.x < a.stem_blocks + a.head_blocks + a.bias_blocks) {
+    bias_sum_body(a.bias, (int)blockIdx.x - a.stem_blocks - a.head_blocks, reinterpret_cast<float*>(part));
+    return;
+  }
+  const int b = (int)blockIdx.x - a.stem_blocks - a.head_blocks - a.bias_blocks;
   int li = 0, hi = a.n - 1;                          // the first layer with b < vb_end[li] (ascending: a binary search)
   while (li < hi) {
     const int mid = (li + hi) >> 1;
@@ -2426,6 +2477,7 @@ bool g_group_on = false;
 int g_matmul_dtype = 0;                           // dfhip_set_conv_matmul_dtype: 0 fp32, 1 bf16 operands (grouped weight gradients)
 struct StemPending { bool active = false; StemCombine c; int blocks = 0; } g_stem_pending;
 struct HeadPending { bool active = false; HeadGrads h; } g_head_pending;
+BiasSums g_bias_pending = {};                     // n > 0: bias gradients waiting for the group's slab-sum launch
 int run_wgrad_rows(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int O, int oh, int ow,
                    int k, int stride, int pad, const float* aff = nullptr, const float* bnz = nullptr,
                    const float* bntab = nullptr);
@@ -2721,8 +2773,15 @@ int group_flush() {
         g_head_pending.active = false;
         sbytes += 4.0 * ((double)sg.head.N * sg.head.C + (double)sg.head.N * sg.head.Pn + (double)sg.head.C * sg.head.Pn);
       }
+      if (g_bias_pending.n > 0 && !g_group_stream && i0 + kMaxGroup >= q.size()) {
+        sg.bias = g_bias_pending;
+        sg.bias_blocks = sg.bias.blk_end[sg.bias.n - 1];
+        g_bias_pending.n = 0;
+        for (int bi = 0; bi < sg.bias.n; bi++)
+          sbytes += 4.0 * ((double)sg.bias.N[bi] * sg.bias.C[bi] * (4 << sg.bias.lq[bi]) + sg.bias.C[bi]);
+      }
       ProfScope prof("wgrad_slab_sum", 0.0, sbytes);
-      DF_LAUNCH(k_wgrad_group_sum, dim3((unsigned)(vbs + sg.stem_blocks + sg.head_blocks)), dim3(256), 0, gst, sg);
+      DF_LAUNCH(k_wgrad_group_sum, dim3((unsigned)(vbs + sg.stem_blocks + sg.head_blocks + sg.bias_blocks)), dim3(256), 0, gst, sg);
       DF_LAUNCH_CHECK();
     }
   }
@@ -3153,6 +3212,15 @@ static int flush_sweep() {
     int st = head_grads_launch(g_head_pending.h);
     if (st != DFHIP_OK) return st;
   }
+  if (g_bias_pending.n > 0) {                       // (cannot happen while a rider is only accepted for a queued layer's dY)
+    SGroup sg = {};
+    sg.bias = g_bias_pending;
+    sg.bias_blocks = sg.bias.blk_end[sg.bias.n - 1];
+    g_bias_pending.n = 0;
+    ProfScope prof("reduce_to_shape", 0.0, 0.0);
+    DF_LAUNCH(k_wgrad_group_sum, dim3((unsigned)sg.bias_blocks), dim3(256), 0, stream(), sg);
+    DF_LAUNCH_CHECK();
+  }
   if (!g_side_pending.empty()) {
     int st = side_join();
     if (st != DFHIP_OK) return st;
@@ -3183,6 +3251,10 @@ bool deferred_touches(const void* p) {
     if (in(h.dw, (int64_t)h.C * h.Pn) || in(h.db, h.Pn) || in(h.dl, (int64_t)h.N * h.Pn) || in(h.pooled, (int64_t)h.N * h.C) ||
         in(h.loss, 1) || in(h.rowloss, h.N)) return true;
   }
+  for (int i = 0; i < g_bias_pending.n; i++) {
+    const float* q = (const float*)p;
+    if (q >= g_bias_pending.dst[i] && q < g_bias_pending.dst[i] + g_bias_pending.C[i]) return true;
+  }
   for (const auto& sp : g_side_pending)              // a gradient in flight on the side stream: join first
     for (const auto& r : sp.dws)
       if ((const float*)p >= r.first && (const float*)p < r.second) return true;
@@ -3202,6 +3274,24 @@ bool head_grads_defer(const HeadGrads& h) {
   if (!g_group_on || g_group_stream || !g_side_pending.empty() || g_head_pending.active || overlap_cus()) return false;
   g_head_pending.h = h;
   g_head_pending.active = true;
+  return true;
+}
+// dfhip_reduce_to_shape on (N, C, H, W) -> (1, C, 1, 1) inside a sweep: taken along by the group's slab-sum launch when `src` is
+// the dY of a layer that is queued in the group (so the array is alive until the group is flushed: the caller keeps a queued
+// layer's operands) and its planes are whole 16-byte pieces, a power of two of them
+bool bias_sum_defer(const float* src, float* dst, int N, int C, int HW) {
+  if (!group_collecting() || overlap_cus() || g_bias_pending.n >= kBiasSums || N <= 0 || C <= 0 || HW < 4) return false;
+  if ((HW & (HW - 1)) != 0 || (((uintptr_t)src) & 15) != 0) return false;
+  bool queued = false;
+  for (const auto& e : g_queue)
+    if (e.d.dy == src && e.d.N == N && e.d.O == C && e.d.oh * e.ow == HW && !e.d.bnz) queued = true;
+  if (!queued) return false;
+  BiasSums& b = g_bias_pending;
+  const int i = b.n++;
+  int lq = 0;
+  while ((4 << lq) < HW) lq++;
+  b.src[i] = src; b.dst[i] = dst; b.N[i] = N; b.C[i] = C; b.lq[i] = lq;
+  b.blk_end[i] = (i ? b.blk_end[i - 1] : 0) + C;
   return true;
 }
 bool conv_matmul_dtype_is_bf16() { return g_matmul_dtype == 1; }

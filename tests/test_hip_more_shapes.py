@@ -66,3 +66,40 @@ def test_compact_of_a_transposed_matrix(hip_device, rows, cols):
     t = Tensor(x, device=hip_device)
     got = t.data.permute((1, 0)).compact().numpy()
     assert np.array_equal(got, x.T)
+
+
+@pytest.mark.parametrize("geo", [(256, 32, 64, 16, 5, 2), (256, 64, 128, 8, 3, 1), (64, 32, 32, 4, 3, 1)])
+def test_bias_gradient_rides_on_the_sweeps_slab_sum(hip_device, cpu_oracle, geo):
+    """A convolution WITH a bias inside a backward sweep (the CNN workload's conv2 / conv3, test/CNN_CIFAR10_cuda.py:66-72): the
+    bias gradient -- dY summed over images and pixels, tensor.py:462-483 -- is formed by workgroups of the group's slab-sum launch
+    (no `reduce_to_shape` launch) when the layer's weight gradient is queued in the group"""
+    from deepflows_amd import nn, tensor
+    from deepflows_amd.tensor import Graph, Tensor
+    N, C, O, H, k, pad = geo
+    rng = np.random.default_rng(N + C + O)
+    x_np = rng.standard_normal((N, C, H, H)).astype(np.float32)
+    w_np = (rng.standard_normal((O, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+    b_np = rng.standard_normal((1, O, 1, 1)).astype(np.float32)
+    w2_np = (rng.standard_normal((O, O, 3, 3)) / np.sqrt(O * 9)).astype(np.float32)
+    res = {}
+    for name, dev in (("hip", hip_device), ("cpu", cpu_oracle)):
+        x = Tensor(x_np, device=dev, requires_grad=True)
+        conv = nn.Conv2d(C, O, kernel_size=k, padding=pad, device=dev)
+        conv.weight.data = Tensor(w_np, device=dev).data
+        conv.bias.data = Tensor(b_np, device=dev).data
+        conv2 = nn.Conv2d(O, O, kernel_size=3, padding=1, bias=False, device=dev)     # (a second queued layer: a group)
+        conv2.weight.data = Tensor(w2_np, device=dev).data
+        if name == "hip":
+            dev.mod.prof_reset(); dev.mod.prof_enable(True)
+        y = conv2(conv(x))
+        loss = tensor.sum(y * y) * (1.0 / y.numpy().size)
+        loss.backward()
+        if name == "hip":
+            dev.mod.synchronize(); dev.mod.prof_enable(False)
+            fams = {kk: v["calls"] for kk, v in dev.mod.prof_read().items() if v["calls"]}
+        res[name] = (conv.bias.grad.numpy().copy(), conv.weight.grad.numpy().copy(), conv2.weight.grad.numpy().copy())
+        Graph.free_graph_all()
+    for a, b, what in zip(res["hip"], res["cpu"], ("db", "dW", "dW2")):
+        assert_close(a, b, 1e-4, what)
+    if "conv2d_wgrad_grouped" in fams:                # (the layer went into a group: its bias gradient rode along)
+        assert "reduce_to_shape" not in fams, fams
