@@ -288,9 +288,6 @@ void (*const kPack[3])(const uint8_t*, int64_t, uint8_t*) = {pack_base, pack_avx
 }  // namespace
 
 namespace dfhip {
-int host_bernoulli_mask_u8(uint32_t* key, int* pos, double keep, int64_t n, uint8_t* out) {
-  return mask_from_stream<uint8_t>(key, pos, keep, n, out);
-}
 // the mask as bits ((n + 7) / 8 bytes at `bits`); `scratch` holds n bytes
 int host_bernoulli_mask_bits(uint32_t* key, int* pos, double keep, int64_t n, uint8_t* scratch, uint8_t* bits) {
   const int st = mask_from_stream<uint8_t>(key, pos, keep, n, scratch);

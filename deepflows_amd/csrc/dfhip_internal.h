@@ -19,8 +19,7 @@ int ensure_init();             // lazy dfhip_init(LOCAL_RANK or 0)
 int num_cus();
 int overlap_cus();            // DFHIP_OVERLAP_CUS: CUs (a multiple of 8) of the backward chain's stream, 0 = one stream
 int make_masked_stream(hipStream_t* out, int first_bit, int nbits);
-int host_bernoulli_mask_u8(uint32_t* key, int* pos, double keep, int64_t n, uint8_t* out);   // dfhip_hostrng.hip: the Dropout mask as 0 / 1 bytes
-int host_bernoulli_mask_bits(uint32_t* key, int* pos, double keep, int64_t n, uint8_t* scratch, uint8_t* bits);   // ... as bits
+int host_bernoulli_mask_bits(uint32_t* key, int* pos, double keep, int64_t n, uint8_t* scratch, uint8_t* bits);   // dfhip_hostrng.hip: the Dropout mask as bits
 bool bias_sum_defer(const float* src, float* dst, int N, int C, int HW);   // dfhip_wgrad.hip: a bias gradient as workgroups of the sweep's slab sum
 bool conv_matmul_dtype_is_bf16();   // dfhip_set_conv_matmul_dtype(1): bf16 operands in the convolutions' matrix products (opt-in)
 int chain_begin();            // the library's launches go to the chain stream (after everything queued so far) ...

@@ -683,28 +683,7 @@ __global__ __launch_bounds__(512) void k_stem_bwd(StemB g) {
 // db[channel] (when there is a bias)
 __global__ __launch_bounds__(256) void k_stem_slab_sum(const float* __restrict__ slabs, float* __restrict__ dw,
                                                        float* __restrict__ db, int n, int splits, int KK) {
-  __shared__ float part[8][32];
-  const int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
-  const int i = min(blockIdx.x * 32 + e, n - 1);
-  float t = 0.0f;
-  for (int s0 = sg; s0 < splits; s0 += 64) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = slabs[(int64_t)min(s0 + 8 * u, splits - 1) * n + i];
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (s0 + 8 * u < splits) t += v[u];
-  }
-  part[sg][e] = t;
-  __syncthreads();
-  if (threadIdx.x < 32 && blockIdx.x * 32 + e < n) {
-    float r = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 8; k++) r += part[k][e];
-    const int ch = i / (KK + 1), col = i - ch * (KK + 1);
-    if (col < KK) dw[ch * KK + col] = r;
-    else if (db) db[ch] = r;
-  }
+  stem_slab_sum_body(slabs, dw, db, n, splits, KK, (int)blockIdx.x);      // (dfhip_stem_combine.h: also a rider of the group's slab sum)
 }
 
 // One-pass backward: the totals over the workgroups' slabs and dW, dgamma, dbeta, dbias from them (dfhip_stem_combine.h;
@@ -782,7 +761,8 @@ int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, c
   *done = 0;
   // queued weight gradients stay queued when the one-pass form runs inside their group: the group's slab-sum launch then
   // does this call's last step (the slabs of totals live in the second scratch area, the group's own in the first)
-  const bool ride = k == 3 && group_collecting() && stem_shape(N, C, H, W, O, k, stride, pad);
+  // (round 6: the two-pass form of the 5x5 stems rides too -- its last step is a plain slab sum)
+  const bool ride = (k == 3 || k == 5) && group_collecting() && stem_shape(N, C, H, W, O, k, stride, pad);
   if (!ride) {
     int f__ = flush_deferred();
     if (f__ != DFHIP_OK) return f__;
@@ -854,9 +834,13 @@ int dfhip_stem_backward_noz(const float* x, const float* w, const float* bias, c
     DF_LAUNCH_CHECK();
     st2_dump("bwd_wgrad", gx);
     const int n = O * (KK + 1);
-    DF_LAUNCH(k_stem_slab_sum, dim3((unsigned)df_ceil_div(n, 32)), dim3(256), 0, stream(), (const float*)b.slabs, dw, dbias, n,
-              gx, KK);
-    DF_LAUNCH_CHECK();
+    StemCombine c = {};
+    c.plain = 1; c.slabs = b.slabs; c.dw = dw; c.dbias = dbias; c.O = O; c.KK = KK; c.splits = gx;
+    if (!(ride && stem_combine_defer(c, (int)df_ceil_div(n, 32)))) {
+      DF_LAUNCH(k_stem_slab_sum, dim3((unsigned)df_ceil_div(n, 32)), dim3(256), 0, stream(), (const float*)b.slabs, dw, dbias, n,
+                gx, KK);
+      DF_LAUNCH_CHECK();
+    }
   }
   *done = 1;
   return DFHIP_OK;

@@ -17,6 +17,8 @@ struct StemCombine {
   float* dbeta;
   int O, KK, splits;
   float m, eps;
+  int plain;             // 1: the two-pass form's last step (5x5 stems) -- slabs [splits][O][KK + 1] of finished gradients, column KK
+                         // the bias gradient: plain sums in a fixed order (k_stem_slab_sum's), blocks of 32 elements
 };
 
 // host side (dfhip_wgrad.hip): hand the combine to the next grouped slab sum; false = no group is collecting (launch it)
@@ -29,7 +31,37 @@ int stem_combine_launch(const StemCombine& c, int blocks);
 // threads owns eight consecutive elements (o, k) of dW; a thread sums every 32nd slab of the six totals its element needs
 // (A[o][k], B[o][k], the column sum S[k] and the three per-channel sums), all loads of a round in flight together; the 32
 // slab groups meet through the lanes and LDS.
+__device__ __forceinline__ void stem_slab_sum_body(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                   float* __restrict__ db, int n, int splits, int KK, int blk) {
+  __shared__ float part[8][32];
+  const int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int i = min(blk * 32 + e, n - 1);
+  float t = 0.0f;
+  for (int s0 = sg; s0 < splits; s0 += 64) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = slabs[(int64_t)min(s0 + 8 * u, splits - 1) * n + i];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (s0 + 8 * u < splits) t += v[u];
+  }
+  part[sg][e] = t;
+  __syncthreads();
+  if (threadIdx.x < 32 && blk * 32 + e < n) {
+    float r = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r += part[k][e];
+    const int ch = i / (KK + 1), col = i - ch * (KK + 1);
+    if (col < KK) dw[ch * KK + col] = r;
+    else if (db) db[ch] = r;
+  }
+}
+
 __device__ __forceinline__ void stem_combine_body(const StemCombine& c, int blk) {
+  if (c.plain) {                                   // (uniform per launch)
+    stem_slab_sum_body(c.slabs, c.dw, c.dbias, c.O * (c.KK + 1), c.splits, c.KK, blk);
+    return;
+  }
   __shared__ float part[4][6][8];
   const int e = threadIdx.x & 7, sg = threadIdx.x >> 3;
   const int n = c.O * c.KK, SL = 2 * n + 3 * c.O + c.KK;
