@@ -58,6 +58,8 @@ CASES = {
     "c64_p16": ((5, 64), 16, 0.8, False),
     "c1000_bs1200": ((1200, 1000), 10, 0.5, False),
     "c512": ((64, 512), 10, 0.5, False),
+    "odd_c301_p7": ((19, 301), 7, 0.5, False),                # (weights that are no whole 16-byte pieces)
+    "c2048_p16": ((48, 2048), 16, 0.25, False),               # (the largest weight tile: 128 KB of LDS)
 }
 
 
