@@ -372,6 +372,19 @@ def _mlp2_ce(logits, target):
     return nodes[2]
 
 
-tensor._lazy_hooks.update({"force": _force, "add": _add, "mean": _mean})
+def _maximum0(x):
+    """tensor.maximum(x, 0) on a recorded call or on a tensor of a fused device: F.relu's node (the reference's F.relu is this
+    call, nn/functional.py:15-16); None = the primitive node"""
+    if not ENABLED:
+        return None
+    if _state(x) is not None:
+        return F.relu(x)
+    xr = realize(x)
+    if isinstance(xr, Tensor) and F._fused(xr):
+        return F.relu(xr)
+    return None
+
+
+tensor._lazy_hooks.update({"force": _force, "add": _add, "mean": _mean, "maximum0": _maximum0})
 F._lazy_relu = relu
 F._lazy_head_ce = _head_ce

@@ -597,6 +597,16 @@ class log(UnaryOperator):
 
 
 class maximum(BinaryOperator):
+    def __new__(cls, x, y=None):
+        # maximum(x, 0) IS the reference's ReLU (nn/functional.py:15-16 is this very call; test/MobileNet.py:34 writes it out):
+        # on a fused device the one-launch node of F.relu instead of three elementwise launches (nn/lazy.py)
+        hook = _lazy_hooks.get("maximum0")
+        if hook is not None and isinstance(y, (int, float)) and not isinstance(y, bool) and y == 0:
+            out = hook(x)
+            if out is not None:
+                return out
+        return super().__new__(cls)
+
     def forward(self, x, y):
         return backend_api.maximum(x, y)
 
