@@ -103,6 +103,9 @@ def build_job(workload, dev, rank, batch, register_blocks=True, model_kind="plai
 
 
 OTHER_CONFIGURATIONS = (("cnn_cifar10_bs256", "cnn", "overwrite", "f32"), ("mlp_mnist_bs128", "mlp", "overwrite", "f32"),
+                        # the perceptron with FOUR steps per captured graph (the same kernels; a graph launch is a fifth of its
+                        # 19-us step -- graph_step.CapturedTrainStep(steps_per_graph=4))
+                        ("mlp_mnist_bs128_4_steps_per_graph", "mlp", "overwrite", "f32", ("--steps-per-graph", "4")),
                         ("resnet18_bs256_accumulate_dgrad", "resnet18", "accumulate", "f32"),
                         # opt-in reduced precision: bf16 operands in the layer1-2 forward convolutions' and the weight
                         # gradients' matrix products
@@ -117,11 +120,12 @@ def other_configurations(steps, timeout_s=150.0):
     fault, abort or hang in one of them costs that entry (reported as `error`) and nothing else.  The child runs
     `--steps` timed replays of its captured step and the per-family event pass; what comes back is its JSON line."""
     out = {}
-    for name, wl, dgrad, mm in OTHER_CONFIGURATIONS:
+    for name, wl, dgrad, mm, *extra in OTHER_CONFIGURATIONS:
         k = steps if wl != "mlp" else max(steps, 200)
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--dgrad", dgrad, "--matmul-dtype", mm,
-               "--steps", str(k), "--warmup", "3",
+               "--steps", str(k), "--warmup", "4",
                "--no-cpu-baseline", "--no-other-configs", "--no-other-model", "--sustain-ms", "0", "--settle-ms", "100"]
+        cmd += list(extra[0]) if extra else []
         env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         t = time.perf_counter()
         try:
@@ -138,6 +142,7 @@ def other_configurations(steps, timeout_s=150.0):
                          "dominant_family": rf.get("kernel"), "roofline_bound": rf.get("bound"),
                          "roofline_frac": rf.get("frac"), "avg_launch_us": rf.get("avg_launch_us"),
                          "launches_per_step": d["config"].get("launches_per_step"),
+                         "steps_per_graph": d["config"].get("steps_per_graph"),
                          "child_wall_s": round(time.perf_counter() - t, 1)}
         except subprocess.TimeoutExpired:
             out[name] = {"error": f"child killed after {timeout_s:.0f} s"}
@@ -399,6 +404,10 @@ def main():
                     help="PMC summary (tools/pmc_summary.py --json) to quote for traffic / executed flops instead of the "
                          "newest matching file under profiles/")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
+    ap.add_argument("--steps-per-graph", type=int, default=1, choices=(1, 2, 4, 8),
+                    help="consecutive steps held by ONE captured graph (graph_step.CapturedTrainStep: a graph launch costs 5-8 us "
+                         "of device time whatever it holds); 1 = a graph per step (the headline).  --steps / --warmup should be "
+                         "multiples of it; single process only")
     ap.add_argument("--sustain-ms", type=float, default=6500.0,
                     help="after the K timed steps: this many milliseconds of further replays of the captured step in ten "
                          "timed chunks (sustained / median / best ms per step inside `config`); longer than the 5 s interval of "
@@ -497,8 +506,9 @@ def main():
     if captured is None and not args.no_graph:
         try:
             from deepflows_amd.graph_step import CapturedTrainStep
-            captured = CapturedTrainStep(model, crit, opt, xt, yt, sync=sync)
-            for _ in range(2):
+            spg = args.steps_per_graph if sync is None else 1
+            captured = CapturedTrainStep(model, crit, opt, xt, yt, sync=sync, steps_per_graph=spg)
+            for _ in range(2 * spg):
                 loss = captured.replay()
             mod.synchronize()
             if args.settle_ms > 0 and not profiled_run:
@@ -510,6 +520,7 @@ def main():
                 mod.synchronize()
                 per = max(1e-6, (time.perf_counter() - t_settle) / 20)
                 more = int(comm.max_float(float(min(5000, int(args.settle_ms * 1e-3 / per)))))
+                more -= more % spg                       # (whole graphs: the timed region starts on a launch)
                 for _ in range(more):
                     loss = captured.replay()
                 mod.synchronize()
@@ -727,7 +738,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.matmul_dtype == "f32" else "bf16 operands / f32 accumulation in the layer1-2 forward convolutions and the grouped weight gradients, f32 elsewhere", "data": "synthetic",
             "config": {"workload": wl["text"],
                        "global_batch": batch * comm.world, "batch_per_gpu": batch, "parallelism": f"dp{comm.world}",
-                       "settle_replays_untimed": settle_replays, "conv_dgrad": args.dgrad, "conv_matmul_dtype": args.matmul_dtype, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "registered_params": args.registration,
+                       "settle_replays_untimed": settle_replays, "conv_dgrad": args.dgrad, "conv_matmul_dtype": args.matmul_dtype, "dispatch": ("hipgraph+overlapped-allreduce" if overlapped else "hipgraph") if captured is not None else "eager", "steps_per_graph": getattr(captured, "S", 1) if captured is not None else None, "registered_params": args.registration,
                        "model": args.model if args.workload == "resnet18" else None,
                        "launches_per_step": round(sum(r["launches"] for r in kprof.values()) / args.steps, 2) if kprof else None,
                        "kernel_us_per_step": r4(kernels_us),

@@ -29,7 +29,23 @@ class CapturedTrainStep:
     captured graph where the collective can be captured (`exchange_captured`), else the graph ends after backward and they
     are enqueued eagerly behind every replay on the same stream."""
 
-    def __init__(self, model, criterion, optimizer, inputs, targets, sync=None, capture_exchange=None):
+    def __init__(self, model, criterion, optimizer, inputs, targets, sync=None, capture_exchange=None, steps_per_graph=1):
+        """steps_per_graph = S > 1 (round 6): S consecutive steps in ONE graph -- a graph launch costs 5-8 us of device time
+        whatever it holds (tools/probes/queue_probe.hip: 12.9 us for a graph of three empty kernels, 107 us for 58), a fifth of
+        the perceptron's 19-us step.  `replay()` still advances ONE step per call: the graph is launched on every S-th call
+        and holds that call's step and the S - 1 that follow (the loss it returns is the one of the graph's last step;
+        Dropout masks of all S steps are drawn in step order in front of the launch; a tail of fewer than S calls has run
+        the whole graph).  `inputs` / `targets` may be lists of S tensors (one batch per step of the graph)."""
+        self.S = int(steps_per_graph)
+        self._phase = 0
+        if self.S not in (1, 2, 4, 8) or (self.S > 1 and sync is not None):
+            # (a power of two: Adam's device table of 1 024 steps' scalars is rewritten in front of a launch, never inside a graph)
+            raise ValueError("steps_per_graph: 1, 2, 4 or 8, and 1 with a gradient exchange")
+        self._inputs = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs] * self.S
+        self._targets = list(targets) if isinstance(targets, (list, tuple)) else [targets] * self.S
+        if len(self._inputs) != self.S or len(self._targets) != self.S:
+            raise ValueError("steps_per_graph: one input / target tensor, or a list of steps_per_graph of them")
+        inputs, targets = self._inputs[0], self._targets[0]
         mod = inputs.device.mod
         if not (getattr(mod, "fused", False) and hasattr(mod, "capture_begin")):
             raise RuntimeError("CapturedTrainStep needs the hip device")
@@ -62,15 +78,16 @@ class CapturedTrainStep:
         mod.capture_feeds = []                      # host-drawn inputs of the step (Dropout masks), in forward order
         mod.capture_begin()
         try:
-            outputs = model(inputs)
-            loss = criterion(outputs, targets)
-            optimizer.zero_grad()
-            loss.backward()
-            if sync is not None and with_exchange:
-                sync()
-            if sync is None or with_exchange:
-                optimizer.apply()
-            Graph.free_graph()
+            for s_i in range(self.S):
+                outputs = model(self._inputs[s_i])
+                loss = criterion(outputs, self._targets[s_i])
+                optimizer.zero_grad()
+                loss.backward()
+                if sync is not None and with_exchange:
+                    sync()
+                if sync is None or with_exchange:
+                    optimizer.apply()
+                Graph.free_graph()
         except BaseException:
             mod.capture_feeds = None
             try:
@@ -82,11 +99,18 @@ class CapturedTrainStep:
         self.feeds, mod.capture_feeds = mod.capture_feeds, None
         self.loss, self.outputs = loss, outputs
         self.grads = [p.grad for p in optimizer.params]     # the buffers backward writes on a replay
-        self.graph = mod.capture_end(keep=(loss, outputs, inputs, targets, self.grads, self.feeds))
+        self.graph = mod.capture_end(keep=(loss, outputs, self._inputs, self._targets, self.grads, self.feeds))
         # the capture only recorded the step: nothing ran, the optimizer's step count is unchanged
 
     def replay(self):
         opt = self.optimizer
+        if self.S > 1:
+            # one step per call: the graph of S steps goes out on the first call of every S
+            self._phase = (self._phase + 1) % self.S
+            if self._phase != 1 % self.S:
+                opt.note_replayed_apply()
+                opt.t += 1
+                return self.loss
         opt.push_hyper()
         if self.feeds and os.environ.get("DF_DEBUG_SKIP_FEEDS") != "1":     # (diagnostic switch: timing without the uploads)
             # Dropout masks of this step: drawn on the host exactly as the eager forward pass would draw them

@@ -232,3 +232,28 @@ def test_step_in_the_launch_has_the_separate_launches_bits(hip_device):
         Graph.free_graph_all()
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("workload,batch", [("mlp", 128), ("cnn", 64)])
+def test_four_steps_per_graph_are_four_replays(hip_device, workload, batch):
+    """graph_step.CapturedTrainStep(steps_per_graph=4): eight calls of replay() (two launches of a graph that holds four steps)
+    leave the parameters of eight replays of the one-step graph, bit for bit -- Dropout masks drawn in step order (CNN), Adam's
+    device table advanced once per step (CNN), the SGD step inside the backward launch (MLP)"""
+    import bench
+    from deepflows_amd.graph_step import CapturedTrainStep
+    from deepflows_amd.tensor import Graph
+    runs = []
+    for spg in (1, 4):
+        np.random.seed(0)
+        model, opt, crit, xt, yt = bench.build_job(workload, hip_device, 0, batch)
+        np.random.seed(77)
+        cap = CapturedTrainStep(model, crit, opt, xt, yt, steps_per_graph=spg)
+        for _ in range(8):
+            loss = cap.replay()
+        last = float(loss.numpy()[0])
+        cap.destroy()
+        runs.append((last, [p.data.numpy().copy() for p in model.parameters()], opt.t if hasattr(opt, "t") else None))
+        Graph.free_graph_all()
+    assert runs[0][0] == runs[1][0] and runs[0][2] == runs[1][2], (runs[0][0], runs[1][0], runs[0][2], runs[1][2])
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.array_equal(a, b)

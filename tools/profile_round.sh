@@ -46,6 +46,7 @@ has accumulate && one _accumulate resnet18 accumulate --no-cpu-baseline
 has cnn && one _cnn cnn overwrite
 if has rest; then
 python3 bench.py --workload mlp --steps 200 --warmup 20 --kernels-in-line > $OUT/bench_mlp.json 2> $OUT/bench_mlp.err
+python3 bench.py --workload mlp --steps 200 --warmup 20 --steps-per-graph 4 --no-other-configs --no-cpu-baseline > $OUT/bench_mlp_spg4.json 2> $OUT/bench_mlp_spg4.err
 python3 bench.py --matmul-dtype bf16 --no-cpu-baseline --no-other-configs --kernels-in-line > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
 python3 bench.py --workload resnet18_wide --steps 10 --warmup 2 --no-cpu-baseline --kernels-in-line > $OUT/bench_wide.json 2> $OUT/bench_wide.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_wide -o s -- python3 bench.py --workload resnet18_wide --steps 5 --warmup 2 --no-cpu-baseline --no-prof-gate --no-other-model > $OUT/stats_wide.log 2>&1
