@@ -3,6 +3,7 @@
 // us per kernel per stream.  Run it several times: the spread ACROSS streams of one process against the spread across processes.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <chrono>
 
@@ -12,8 +13,10 @@ __global__ void k_step(const float* __restrict__ in, float* __restrict__ out, in
 }
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int main() {
-  const int n = 256 * 256, K = 200, NS = 8;
+// usage: queue_probe [K kernels per graph = 200] [streams = 8]   (K = 1, 3, 6, 58 ...: what ONE graph launch costs beside its kernels)
+int main(int argc, char** argv) {
+  const int n = 256 * 256;
+  const int K = argc > 1 ? atoi(argv[1]) : 200, NS = argc > 2 ? atoi(argv[2]) : 8;
   float *a, *b;
   hipMalloc(&a, n * 4); hipMalloc(&b, n * 4);
   hipMemset(a, 0, n * 4); hipMemset(b, 0, n * 4);
@@ -31,10 +34,12 @@ int main() {
       for (int i = 0; i < 5; i++) hipGraphLaunch(ge, st[s]);
       hipStreamSynchronize(st[s]);
       double t0 = now();
-      for (int i = 0; i < 50; i++) hipGraphLaunch(ge, st[s]);
+      const int reps = K >= 100 ? 50 : 2000;
+      for (int i = 0; i < reps; i++) hipGraphLaunch(ge, st[s]);
       hipStreamSynchronize(st[s]);
       double t1 = now();
-      printf("round %d stream %d: %.3f us per dependent kernel\n", round, s, (t1 - t0) / (50.0 * K) * 1e6);
+      printf("round %d stream %d: %.3f us per dependent kernel, %.3f us per replay of the %d-kernel graph\n", round, s,
+             (t1 - t0) / ((double)reps * K) * 1e6, (t1 - t0) / reps * 1e6, K);
       hipGraphExecDestroy(ge); hipGraphDestroy(g);
     }
   return 0;
