@@ -158,6 +158,40 @@ def test_captured_mlp_step_replays_the_eager_step(hip_device):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("sizes,M", [((48, 64, 7), 96), ((160, 128, 16), 256)])
+def test_sgd_step_rides_on_the_backward_launch_at_every_hidden_width(hip_device, cpu_oracle, sizes, M):
+    """the 64- and 128-wide instantiations of the backward launch with the optimizer's step in it (k_mlp2_bwd<1 / 2, true>)"""
+    from deepflows_amd import nn, optim, workloads
+    from deepflows_amd.tensor import Graph, Tensor
+    rng = np.random.default_rng(M)
+    x_np = rng.random((M, sizes[0]), dtype=np.float32)
+    y_np = np.eye(sizes[-1], dtype=np.float32)[rng.integers(0, sizes[-1], M)]
+    res = {}
+    for name, dev in (("hip", hip_device), ("cpu", cpu_oracle)):
+        np.random.seed(0)
+        model = workloads.MLP(sizes, device=dev)
+        model.train()
+        opt = optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+        crit = nn.CrossEntropyLoss()
+        x, y = Tensor(x_np, device=dev), Tensor(y_np, device=dev)
+        if name == "hip":
+            dev.mod.prof_reset(); dev.mod.prof_enable(True)
+        for _ in range(3):
+            loss = crit(model(x), y)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            Graph.free_graph()
+        if name == "hip":
+            dev.mod.synchronize(); dev.mod.prof_enable(False)
+            fams = {k: v["calls"] for k, v in dev.mod.prof_read().items() if v["calls"]}
+            assert fams.get("mlp2_ce_bwd_sgd") == 3 and "sgd_step" not in fams, fams
+        res[name] = [p.data.numpy().copy() for p in model.parameters()]
+        Graph.free_graph_all()
+    for i, (a, b) in enumerate(zip(res["hip"], res["cpu"])):
+        assert_close(a, b, 1e-4, f"param {i} after 3 steps")
+
+
 @pytest.mark.parametrize("opt_kind", ["plain", "momentum_wd", "nesterov"])
 def test_sgd_step_rides_on_the_backward_launch(hip_device, cpu_oracle, opt_kind):
     """loss.backward(); opt.step() with nothing in between that reads the gradients: the backward launch is still deferred when
